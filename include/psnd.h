@@ -1,0 +1,157 @@
+/*
+ * psnd.h - C ABI of libpsnd_hip.so, the MI355X (gfx950) native hot path of pytorch_sound.
+ *
+ * The reference (AppleHolic/pytorch_sound, /root/reference) is pure Python: it has no FFI
+ * for this path; every "kernel" there is an ATen call.  This header is therefore the binding
+ * a maintainer adds (ctypes stub in INTEGRATION.md); each entry point cites the reference
+ * lines whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - device pointers unless the name says _host; caller owns every buffer, guarantees
+ *     contiguity and 4-byte alignment (16-byte where noted) and lifetime until the stream
+ *     has completed the work.
+ *   - work is ENQUEUED on `stream` (a hipStream_t passed as void*); no entry point
+ *     synchronises the device, allocates device memory or keeps mutable global state.
+ *   - return 0 on success, a negative PSND_E_* otherwise; psnd_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - "plans" are small read-only tables (window, twiddles, filterbank bands) built on the
+ *     HOST by psnd_*_plan_build into caller memory; the caller uploads them once to the
+ *     device and passes the device copy to the compute entry points.
+ */
+#ifndef PSND_H
+#define PSND_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSND_OK 0
+#define PSND_E_ARG (-1)         /* null pointer / bad enum / unsupported size            */
+#define PSND_E_SHAPE (-2)       /* shapes inconsistent (e.g. T <= pad, K != n_fft/2+1)    */
+#define PSND_E_HIP (-3)         /* HIP runtime reported an error at enqueue time         */
+#define PSND_E_UNSUPPORTED (-4) /* valid request the library has no kernel for (yet)     */
+
+/* framing conventions */
+#define PSND_FRAMING_CENTER 0  /* reflect-pad n_fft/2       : transforms.py:55-60, :298-301   */
+#define PSND_FRAMING_HIFIGAN 1 /* reflect-pad (n_fft-hop)/2 : transforms.py:352-353,
+                                  interface/hifi_gan.py:37,49 */
+
+int psnd_version(void);
+const char *psnd_last_error(void);
+
+/* ---- integer contract: frame indexing (bit-exact) -------------------------------------- */
+/* number of frames of the strided conv over the reflect-padded signal
+ * (transforms.py:55-66; F = T/hop + 1 for CENTER, T/hop for HIFIGAN when hop | T). */
+int64_t psnd_frame_count(int64_t T, int n_fft, int hop, int framing);
+/* original-sample index read by tap m of frame f (reflect map x[-i]=x[i], x[T-1+i]=x[T-1-i]). */
+int64_t psnd_frame_sample_index(int64_t f, int m, int64_t T, int n_fft, int hop, int framing);
+
+/* ---- STFT plan ------------------------------------------------------------------------- */
+/* bytes of the plan for an n_fft-point transform (0 if n_fft unsupported). */
+size_t psnd_stft_plan_bytes(int n_fft);
+/* window_host: n_fft taps, already zero-centre-padded from win_length (transforms.py:30-32).
+ * Fills plan_host (psnd_stft_plan_bytes(n_fft) bytes). */
+int psnd_stft_plan_build(int n_fft, const float *window_host, void *plan_host);
+
+/* ---- STFT forward: replaces STFT.transform (transforms.py:53-69),
+ *      STFTTorchAudio.forward/transform (transforms.py:297-311), the torch.stft + sqrt of
+ *      Audio2Mel.forward (transforms.py:351-363) and interface MelSpectrogram (hifi_gan.py:46-55).
+ *   wav   : (N,T) fp32
+ *   mag   : (N,K,F) fp32 or NULL     = sqrt(re^2 + im^2 + mag_eps)
+ *   phase : (N,K,F) fp32 or NULL     = atan2(im, re)
+ *   re,im : (N,K,F) fp32 or NULL (both or neither)
+ *   K = n_fft/2+1, F = psnd_frame_count(T, n_fft, hop, framing); frame axis fastest. */
+int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                  const void *plan, float mag_eps,
+                  float *mag, float *phase, float *re, float *im, void *stream);
+
+/* ---- STFT backward (autograd through transforms.py:55-69 / torch.stft):
+ *   gwav[n,t] = sum over (f,m) with frame_sample_index(f,m)==t of
+ *               win[m] * sum_k ( gre[n,k,f] cos(2 pi k m/n) - gim[n,k,f] sin(2 pi k m/n) )
+ *   where, when gmag != NULL, gre += gmag*re/mag, gim += gmag*im/mag with re/im/mag recomputed
+ *   from wav (mag = sqrt(re^2+im^2+mag_eps); 0/0 -> NaN exactly as autograd of sqrt does).
+ *   gmag / gre / gim: (N,K,F) or NULL (gre and gim both or neither; at least one source).
+ *   gwav : (N,T) fp32, fully overwritten. */
+int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                  const void *plan, float mag_eps,
+                  const float *gmag, const float *gre, const float *gim,
+                  float *gwav, void *stream);
+
+/* ---- inverse STFT: replaces STFT.inverse (transforms.py:71-101) ("next" row f1)
+ *   mag, phase : (N,K,F); out : (N,(F-1)*hop) fp32; eps as the reference (1e-9). */
+int psnd_istft(const float *mag, const float *phase, int64_t N, int64_t F, int n_fft, int hop,
+               const void *plan, float eps, float *out, void *stream);
+
+/* ---- mel projection + log + clamp: replaces transforms.py:235-243, :364-365,
+ *      interface/hifi_gan.py:58-61 -------------------------------------------------------- */
+#define PSND_LOG_NONE 0  /* linear mel                                   */
+#define PSND_LOG_E 1     /* ln                                           */
+#define PSND_LOG_10 2    /* log10                                        */
+size_t psnd_mel_plan_bytes(int M, int K);
+/* mel_filter_host: (M,K) fp32 row-major (the module's `mel_filter` buffer). */
+int psnd_mel_plan_build(int M, int K, const float *mel_filter_host, void *plan_host);
+/*   mag     : (N,K,F) fp32
+ *   out     : (N,M,F) fp32 = clamp( log( max(mel, pre_clamp_min) + log_offset ), lo, hi )
+ *             pre_clamp_min < 0 disables the inner max; lo/hi: pass -INF/+INF to disable.
+ *   mel_lin : (N,M,F) fp32 or NULL - the un-logged product, saved for backward. */
+int psnd_mel_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const void *mel_plan,
+                 int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                 float *out, float *mel_lin, void *stream);
+/*   gmag[n,k,f] = sum_m W[m,k] * gout[n,m,f] * dlog(mel_lin[n,m,f]) (0 where a clamp is active) */
+int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, int M, int K,
+                 const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
+                 float clamp_lo, float clamp_hi, float *gmag, void *stream);
+
+/* ---- fused wav -> log-mel (LogMelSpectrogram.forward, transforms.py:231-244; magnitude never
+ *      leaves the chip).  Same arguments as stft_fwd + mel_fwd.  mel_lin optional. */
+int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                    const void *stft_plan, float mag_eps, int M, const void *mel_plan,
+                    int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                    float *out, float *mel_lin, void *stream);
+
+/* ---- GroupNorm(1,C) over (C x T) of (x + residual), per-channel affine: replaces
+ *      modules.py:58, :114 (nn.GroupNorm(1, hidden)(x + input)) [+ optional ReLU :116].
+ *   x, res : (N,C,T) fp32 (res may be NULL); y : (N,C,T); stats : (N,2) mean, rstd (saved). */
+int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta,
+                        int64_t N, int C, int64_t T, float eps, int relu,
+                        float *y, float *stats, void *stream);
+/*   gx (== gradient wrt x and wrt res), ggamma/gbeta: (C) fp32, ACCUMULATED INTO (caller zeroes) */
+int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma,
+                        const float *y, const float *stats, int64_t N, int C, int64_t T, int relu,
+                        float *gx, float *ggamma, float *gbeta, void *stream);
+
+/* ---- scaled-dot attention core of MultiHeadAttention.scale_dot_att (modules.py:62-79).
+ *   k,v,q : (B,d,T) fp32, B = heads*N head-major (modules.py:38); mask : (B,T) uint8 (1 = padded)
+ *           or NULL.  scores[b,tk,tq] = k[b,:,tk].q[b,:,tq]/sqrt(d); key-padded rows -> -inf;
+ *           softmax over tk; query-padded columns -> 0; out[b,:,tq] = sum_tk v[b,:,tk] att[b,tk,tq].
+ *   out : (B,d,T); att : (B,T,T) or NULL (materialised only on request);
+ *   lse : (B,T) fp32 log-sum-exp per query column (saved for backward). */
+int psnd_attention_fwd(const float *k, const float *v, const float *q, const uint8_t *mask,
+                       int64_t B, int d, int64_t T, float *out, float *att, float *lse, void *stream);
+int psnd_attention_bwd(const float *gout, const float *k, const float *v, const float *q,
+                       const uint8_t *mask, const float *out, const float *lse,
+                       int64_t B, int d, int64_t T, float *gk, float *gv, float *gq, void *stream);
+
+/* ---- Conv1d / ConvTranspose1d stacks of models/vocoders/hifi_gan.py:32-147 -------------
+ *   dtype: 0 = fp32, 1 = bf16 (storage; accumulation is always fp32).
+ *   x : (N,Cin,L)  w : (Cout,Cin,k)  y : (N,Cout,Lout), Lout = L + 2*pad - dil*(k-1)  (stride 1)
+ *   pre_slope  : leaky-relu slope applied to x on load (1.0 = none)   [hifi_gan.py:57,59,86]
+ *   bias       : (Cout) or NULL;  residual : (N,Cout,Lout) added to y or NULL [hifi_gan.py:61,88] */
+int psnd_conv1d_fwd(const void *x, const void *w, const void *bias, const void *residual,
+                    int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
+                    float pre_slope, int dtype, void *y, void *stream);
+int psnd_conv1d_bwd_data(const void *gy, const void *w, const void *x,
+                         int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
+                         float pre_slope, int dtype, void *gx, void *stream);
+int psnd_conv1d_bwd_weight(const void *gy, const void *x,
+                           int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
+                           float pre_slope, int dtype, float *gw, float *gbias, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSND_H */

@@ -1,0 +1,105 @@
+"""ctypes binding of libpsnd_hip.so (include/psnd.h).  The product path has NO fallback:
+if the library is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpsnd_hip.so')
+
+PSND_OK = 0
+FRAMING_CENTER = 0
+FRAMING_HIFIGAN = 1
+LOG_NONE, LOG_E, LOG_10 = 0, 1, 2
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_INT = _c.c_int
+_F = _c.c_float
+
+# name -> (restype, argtypes); mirrors include/psnd.h one to one
+SIGNATURES = {
+    'psnd_version': (_INT, []),
+    'psnd_last_error': (_c.c_char_p, []),
+    'psnd_frame_count': (_I64, [_I64, _INT, _INT, _INT]),
+    'psnd_frame_sample_index': (_I64, [_I64, _INT, _I64, _INT, _INT, _INT]),
+    'psnd_stft_plan_bytes': (_c.c_size_t, [_INT]),
+    'psnd_stft_plan_build': (_INT, [_INT, _P, _P]),
+    'psnd_stft_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
+    # 'psnd_stft_bwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
+    'psnd_mel_plan_bytes': (_c.c_size_t, [_INT, _INT]),
+    'psnd_mel_plan_build': (_INT, [_INT, _INT, _P, _P]),
+    'psnd_mel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P]),
+    'psnd_mel_bwd': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
+}
+
+_lib = None
+
+
+class PsndError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsndError('libpsnd_hip.so not found at %s - run `python -m pytorch_sound_amd._build` '
+                            '(there is no CPU / eager fallback)' % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)       # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != PSND_OK:
+        msg = lib().psnd_last_error()
+        raise PsndError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def ptr(t):
+    """device (or host) pointer of a contiguous torch tensor, or NULL for None."""
+    if t is None:
+        return None
+    return _P(t.data_ptr())
+
+
+def np_ptr(a):
+    return _P(a.ctypes.data)
+
+
+def stream_ptr(device):
+    import torch
+    return _P(torch.cuda.current_stream(device).cuda_stream)
+
+
+def frame_count(T, n_fft, hop, framing=FRAMING_CENTER):
+    return int(lib().psnd_frame_count(int(T), int(n_fft), int(hop), int(framing)))
+
+
+def build_stft_plan(n_fft, window):
+    """window: array-like of n_fft taps (already centre-padded).  Returns a uint8 numpy plan."""
+    w = np.ascontiguousarray(np.asarray(window, dtype=np.float32))
+    if w.shape != (n_fft,):
+        raise PsndError('stft plan: window must have n_fft=%d taps, got %s' % (n_fft, w.shape))
+    nb = lib().psnd_stft_plan_bytes(int(n_fft))
+    if nb == 0:
+        raise PsndError('stft plan: n_fft=%d unsupported (power of two in [16, 8192])' % n_fft)
+    plan = np.zeros(nb, dtype=np.uint8)
+    check(lib().psnd_stft_plan_build(int(n_fft), np_ptr(w), np_ptr(plan)), 'psnd_stft_plan_build')
+    return plan
+
+
+def build_mel_plan(mel_filter):
+    W = np.ascontiguousarray(np.asarray(mel_filter, dtype=np.float32))
+    M, K = W.shape
+    nb = lib().psnd_mel_plan_bytes(M, K)
+    plan = np.zeros(nb, dtype=np.uint8)
+    check(lib().psnd_mel_plan_build(M, K, np_ptr(W), np_ptr(plan)), 'psnd_mel_plan_build')
+    return plan

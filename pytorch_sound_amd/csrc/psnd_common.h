@@ -1,0 +1,159 @@
+// psnd_common.h - shared host/device helpers for libpsnd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <type_traits>
+#include "../../include/psnd.h"
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------
+void psnd_set_error(const char *fmt, ...);
+
+#define PSND_FAIL(code, ...)          \
+    do {                              \
+        psnd_set_error(__VA_ARGS__);  \
+        return (code);                \
+    } while (0)
+
+#define PSND_CHECK_LAUNCH(what)                                                   \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// compile-time loops
+// ---------------------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// compile-time trigonometry: cos/sin(2*pi*j/n), exact octant reduction + Taylor on [0, pi/4]
+// ---------------------------------------------------------------------------------------
+namespace ct {
+constexpr double kPi = 3.141592653589793238462643383279502884;
+constexpr double taylor_sin(double x) {
+    double x2 = x * x, term = x, sum = x;
+    for (int i = 1; i < 12; ++i) {
+        term *= -x2 / double((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double taylor_cos(double x) {
+    double x2 = x * x, term = 1.0, sum = 1.0;
+    for (int i = 1; i < 12; ++i) {
+        term *= -x2 / double((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+// cos(2*pi*j/n) and sin(2*pi*j/n) for integer j, n (n multiple of 8 or small power of two)
+constexpr double cos2pi(long j, long n) {
+    j %= n;
+    if (j < 0) j += n;
+    // use symmetries to land in [0, n/8]
+    if (2 * j > n) return cos2pi(n - j, n);              // cos(2pi - x) = cos x
+    if (4 * j > n) return -cos2pi(n / 2 - j, n);                   // cos(pi - x) = -cos x
+    if (8 * j > n) {                                     // x in (pi/4, pi/2]: cos x = sin(pi/2 - x)
+        // pi/2 - x = 2pi*(n/4 - j)/n ; n divisible by 4 for every size we use
+        return taylor_sin(2.0 * kPi * double(n - 4 * j) / double(4 * n));
+    }
+    return taylor_cos(2.0 * kPi * double(j) / double(n));
+}
+constexpr double sin2pi(long j, long n) {
+    j %= n;
+    if (j < 0) j += n;
+    if (2 * j > n) return -sin2pi(n - j, n);             // sin(2pi - x) = -sin x
+    if (4 * j > n) return sin2pi(n / 2 - j, n);          // sin(pi - x) = sin x
+    if (8 * j > n) return taylor_cos(2.0 * kPi * double(n - 4 * j) / double(4 * n));
+    return taylor_sin(2.0 * kPi * double(j) / double(n));
+}
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+constexpr int bitrev(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+}  // namespace ct
+
+// ---------------------------------------------------------------------------------------
+// in-register complex FFT of compile-time size R (power of two), forward sign (e^{-i..}),
+// decimation in frequency, fully unrolled.  Input natural order; output X[q] lands in
+// slot bitrev(q).  All twiddles are immediates.
+// ---------------------------------------------------------------------------------------
+template <int R, int H, int BLK, int J>
+__device__ __forceinline__ void fft_bfly(float (&re)[R], float (&im)[R]) {
+    constexpr int i0 = BLK + J, i1 = BLK + J + H;
+    const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+    re[i0] = ar + br;
+    im[i0] = ai + bi;
+    const float tr = ar - br, ti = ai - bi;
+    // (tr + i ti) * (c - i s),  theta = 2*pi*J/(2H)
+    if constexpr (J == 0) {
+        re[i1] = tr;
+        im[i1] = ti;
+    } else if constexpr (2 * J == H) {  // -i
+        re[i1] = ti;
+        im[i1] = -tr;
+    } else if constexpr (4 * J == H) {  // (1 - i)/sqrt2
+        constexpr float r = (float)ct::cos2pi(1, 8);
+        re[i1] = (tr + ti) * r;
+        im[i1] = (ti - tr) * r;
+    } else if constexpr (4 * J == 3 * H) {  // (-1 - i)/sqrt2
+        constexpr float r = (float)ct::cos2pi(1, 8);
+        re[i1] = (ti - tr) * r;
+        im[i1] = -(tr + ti) * r;
+    } else {
+        constexpr float c = (float)ct::cos2pi(J, 2 * H);
+        constexpr float s = (float)ct::sin2pi(J, 2 * H);
+        re[i1] = __builtin_fmaf(ti, s, tr * c);
+        im[i1] = __builtin_fmaf(-tr, s, ti * c);
+    }
+}
+
+template <int R, int H>
+__device__ __forceinline__ void fft_stage(float (&re)[R], float (&im)[R]) {
+    if constexpr (H >= 1) {
+        static_for<0, R / (2 * H)>([&](auto bc) {
+            constexpr int blk = decltype(bc)::value * 2 * H;
+            static_for<0, H>([&](auto jc) { fft_bfly<R, H, blk, decltype(jc)::value>(re, im); });
+        });
+        fft_stage<R, H / 2>(re, im);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void fft_inreg(float (&re)[R], float (&im)[R]) {
+    fft_stage<R, R / 2>(re, im);
+}
+
+// unaligned-safe vector types (global multi-dword accesses only need dword alignment on gfx9)
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t T) {
+    if (i < 0) i = -i;
+    if (i >= T) i = 2 * (T - 1) - i;
+    // out-of-contract inputs (pad >= T) are rejected on the host; clamp keeps loads in bounds
+    if (i < 0) i = 0;
+    if (i >= T) i = T - 1;
+    return i;
+}
+
+__device__ __forceinline__ int reflect_idx32(int i, int T) {
+    i = i < 0 ? -i : i;
+    i = i >= T ? 2 * (T - 1) - i : i;
+    i = i < 0 ? 0 : i;
+    return i >= T ? T - 1 : i;
+}

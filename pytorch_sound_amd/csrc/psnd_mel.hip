@@ -1,0 +1,283 @@
+// psnd_mel.hip - mel projection + log + clamp (and its backward) on the fp32 matrix cores.
+//
+// Replaces `torch.matmul(mel_filter, mag)`, `torch.log(mel + off)`, clamp_min/clamp_max of
+// LogMelSpectrogram.forward (pytorch_sound/models/transforms.py:235-243), the matmul + log10 /
+// ln(clamp) of Audio2Mel (:364-365) and interface MelSpectrogram (interface/hifi_gan.py:58-61).
+//
+// OUT[r][f] = sum_c Wp[r][c] * IN[c][f] per clip, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+//   forward : r = mel band (M), c = frequency bin (K), IN = magnitude
+//   backward: r = frequency bin (K), c = mel band (M), IN = gout * dlog(mel_lin) (built on load)
+// The filterbank is triangular (each row is non-zero on a short run of bins), so the plan stores,
+// per 16-row tile, the [lo, hi) range of 4-column steps that hold any non-zero weight and the
+// kernel only walks that band: ~6.6x fewer MFMAs than the dense product at 80 x 513, which is
+// what moves the stage from the fp32-MFMA roof (157 TF) back under the HBM roof.
+//
+// One wave = one (clip, 64-frame tile, 16-row tile).  B operand: lane (kk = l>>4, fq = l&15) loads
+// 16 B = 4 consecutive frames of row c0+kk, so a wave instruction reads 4 rows x 256 contiguous
+// bytes; component j of that float4 feeds MFMA j, whose output column (l&15) is therefore frame
+// 4*(l&15)+j: each lane ends up with 4 consecutive frames per output row -> 16-B stores.
+#include "psnd_common.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+// plan: int32 header[HDR] then float weights.
+//   hdr[0]=M hdr[1]=K hdr[2]=MT hdr[3]=KS hdr[4]=KT hdr[5]=MS hdr[6]=fwd_w_off hdr[7]=bwd_w_off (floats from plan start)
+//   hdr[8 + 2*t + {0,1}]            fwd band [lo,hi) in 4-bin steps for mel tile t   (t < MT)
+//   hdr[8 + 2*MT + 2*t + {0,1}]     bwd band [lo,hi) in 4-mel steps for bin tile t   (t < KT)
+//   fwd weights: Wf[(t*KS + s)*64 + lane] = W[16 t + (lane&15)][4 s + (lane>>4)]
+//   bwd weights: Wb[(t*MS + s)*64 + lane] = W[4 s + (lane>>4)][16 t + (lane&15)]
+inline int hdr_ints(int MT, int KT) { return (8 + 2 * MT + 2 * KT + 63) & ~63; }
+
+struct MelParams {
+    const float *in0;   // fwd: mag ; bwd: gout
+    const float *in1;   // bwd: mel_lin
+    const int *plan;
+    float *out;         // fwd: log-mel ; bwd: gmag
+    float *lin;         // fwd: optional linear mel
+    long long F;
+    int N, R, Cc;       // rows (out), cols (reduction)
+    int RT, CS;         // row tiles, column steps
+    int band_off;       // offset into hdr of this direction's band table
+    int w_off;          // float offset of this direction's weights
+    int nft;            // 64-frame tiles per clip
+    int log_kind;
+    float log_offset, pre_clamp_min, clamp_lo, clamp_hi;
+};
+
+__device__ __forceinline__ float log_apply(float mel, int kind, float off, float pre) {
+    float v = mel;
+    if (pre >= 0.f) v = fmaxf(v, pre);
+    v += off;
+    if (kind == PSND_LOG_E) return logf(v);
+    if (kind == PSND_LOG_10) return log10f(v);
+    return v;
+}
+
+// derivative of the forward epilogue wrt mel (0 where any clamp is active; matches autograd of
+// torch.clamp(min=): gradient passes where input >= min / <= max).
+__device__ __forceinline__ float log_grad(float mel, int kind, float off, float pre, float lo, float hi) {
+    float pass = 1.f;
+    float v = mel;
+    if (pre >= 0.f) {
+        if (v < pre) pass = 0.f;
+        v = fmaxf(v, pre);
+    }
+    v += off;
+    float y = v, d = 1.f;
+    if (kind == PSND_LOG_E) {
+        y = logf(v);
+        d = 1.f / v;
+    } else if (kind == PSND_LOG_10) {
+        y = log10f(v);
+        d = 0.43429448190325182765f / v;
+    }
+    if (y < lo || y > hi) pass = 0.f;
+    return pass * d;
+}
+
+template <bool BWD>
+__device__ __forceinline__ f32x4 load_b(const MelParams &p, const float *in0, const float *in1, int c, long long f,
+                                        long long F) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c >= p.Cc) return v;
+    const size_t o = (size_t)c * F + f;
+    if (f + 3 < F) {
+        v = *reinterpret_cast<const f32x4_u *>(in0 + o);
+        if constexpr (BWD) {
+            const f32x4 m = *reinterpret_cast<const f32x4_u *>(in1 + o);
+            v.x *= log_grad(m.x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+            v.y *= log_grad(m.y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+            v.z *= log_grad(m.z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+            v.w *= log_grad(m.w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+        }
+    } else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j)
+            if (f + j < F) {
+                t[j] = in0[o + j];
+                if constexpr (BWD)
+                    t[j] *= log_grad(in1[o + j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+            }
+        v.x = t[0], v.y = t[1], v.z = t[2], v.w = t[3];
+    }
+    return v;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long per_clip = (long long)p.nft * p.RT;
+    if (wid >= per_clip * p.N) return;
+    const int clip = (int)(wid / per_clip);
+    const int rem = (int)(wid - (long long)clip * per_clip);
+    const int ft = rem / p.RT, rt = rem - ft * p.RT;
+    const long long F = p.F;
+    const long long f = (long long)ft * 64 + 4 * (lane & 15);
+    const int kk = lane >> 4;
+
+    const int lo = p.plan[p.band_off + 2 * rt], hi = p.plan[p.band_off + 2 * rt + 1];
+    const float *W = reinterpret_cast<const float *>(p.plan) + p.w_off + (size_t)rt * p.CS * 64 + lane;
+    const float *in0 = p.in0 + (size_t)clip * p.Cc * F;
+    const float *in1 = BWD ? p.in1 + (size_t)clip * p.Cc * F : nullptr;
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    if (lo < hi) {
+        float a = W[(size_t)lo * 64];
+        f32x4 b = load_b<BWD>(p, in0, in1, 4 * lo + kk, f, F);
+        for (int s = lo; s < hi; ++s) {
+            float an = 0.f;
+            f32x4 bn = {0.f, 0.f, 0.f, 0.f};
+            if (s + 1 < hi) {
+                an = W[(size_t)(s + 1) * 64];
+                bn = load_b<BWD>(p, in0, in1, 4 * (s + 1) + kk, f, F);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc3, 0, 0, 0);
+            a = an;
+            b = bn;
+        }
+    }
+    // D layout: col = lane&15 (-> frames f..f+3 across acc0..3), row = 4*(lane>>4) + reg
+    const size_t obase = (size_t)clip * p.R * F;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + 4 * kk + r;
+        if (row >= p.R) continue;
+        f32x4 v = {acc0[r], acc1[r], acc2[r], acc3[r]};
+        f32x4 y = v;
+        if constexpr (!BWD) {
+            y.x = fminf(fmaxf(log_apply(v.x, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+            y.y = fminf(fmaxf(log_apply(v.y, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+            y.z = fminf(fmaxf(log_apply(v.z, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+            y.w = fminf(fmaxf(log_apply(v.w, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+        }
+        const size_t o = obase + (size_t)row * F + f;
+        if (f + 3 < F) {
+            *reinterpret_cast<f32x4_u *>(p.out + o) = y;
+            if (!BWD && p.lin) *reinterpret_cast<f32x4_u *>(p.lin + o) = v;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (f + j < F) {
+                    p.out[o + j] = y[j];
+                    if (!BWD && p.lin) p.lin[o + j] = v[j];
+                }
+        }
+    }
+}
+
+struct MelHostPlan {
+    int M, K, MT, KS, KT, MS, hdr, fw_off, bw_off;
+    size_t total_bytes;
+};
+MelHostPlan mel_layout(int M, int K) {
+    MelHostPlan h;
+    h.M = M, h.K = K;
+    h.MT = (M + 15) / 16, h.KS = (K + 3) / 4;
+    h.KT = (K + 15) / 16, h.MS = (M + 3) / 4;
+    h.hdr = hdr_ints(h.MT, h.KT);
+    h.fw_off = h.hdr;
+    h.bw_off = h.fw_off + h.MT * h.KS * 64;
+    h.total_bytes = sizeof(float) * ((size_t)h.bw_off + (size_t)h.KT * h.MS * 64);
+    return h;
+}
+
+}  // namespace
+
+extern "C" size_t psnd_mel_plan_bytes(int M, int K) {
+    if (M <= 0 || K <= 0) return 0;
+    return mel_layout(M, K).total_bytes;
+}
+
+extern "C" int psnd_mel_plan_build(int M, int K, const float *W, void *plan_host) {
+    if (!W || !plan_host || M <= 0 || K <= 0) PSND_FAIL(PSND_E_ARG, "mel_plan_build: bad arguments");
+    const MelHostPlan h = mel_layout(M, K);
+    memset(plan_host, 0, h.total_bytes);
+    int *hdr = static_cast<int *>(plan_host);
+    float *fl = static_cast<float *>(plan_host);
+    hdr[0] = M, hdr[1] = K, hdr[2] = h.MT, hdr[3] = h.KS, hdr[4] = h.KT, hdr[5] = h.MS;
+    hdr[6] = h.fw_off, hdr[7] = h.bw_off;
+    auto w = [&](int m, int k) -> float { return (m < M && k < K) ? W[(size_t)m * K + k] : 0.f; };
+    for (int t = 0; t < h.MT; ++t) {
+        int lo = h.KS, hi = 0;
+        for (int s = 0; s < h.KS; ++s) {
+            bool any = false;
+            for (int lane = 0; lane < 64; ++lane) {
+                const float v = w(16 * t + (lane & 15), 4 * s + (lane >> 4));
+                fl[h.fw_off + ((size_t)t * h.KS + s) * 64 + lane] = v;
+                any |= (v != 0.f);   // NaN != 0 is true: NaN weights stay inside the band
+            }
+            if (any) {
+                if (s < lo) lo = s;
+                hi = s + 1;
+            }
+        }
+        if (hi <= lo) lo = hi = 0;
+        hdr[8 + 2 * t] = lo, hdr[8 + 2 * t + 1] = hi;
+    }
+    for (int t = 0; t < h.KT; ++t) {
+        int lo = h.MS, hi = 0;
+        for (int s = 0; s < h.MS; ++s) {
+            bool any = false;
+            for (int lane = 0; lane < 64; ++lane) {
+                const float v = w(4 * s + (lane >> 4), 16 * t + (lane & 15));
+                fl[h.bw_off + ((size_t)t * h.MS + s) * 64 + lane] = v;
+                any |= (v != 0.f);
+            }
+            if (any) {
+                if (s < lo) lo = s;
+                hi = s + 1;
+            }
+        }
+        if (hi <= lo) lo = hi = 0;
+        hdr[8 + 2 * h.MT + 2 * t] = lo, hdr[8 + 2 * h.MT + 2 * t + 1] = hi;
+    }
+    return PSND_OK;
+}
+
+static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, int64_t F, int M, int K,
+                      const void *plan, int log_kind, float log_offset, float pre, float lo, float hi,
+                      float *out, float *lin, void *stream) {
+    if (!in0 || !plan || !out || (bwd && !in1)) PSND_FAIL(PSND_E_ARG, "mel: null pointer");
+    if (M <= 0 || K <= 0 || N < 0 || F < 0) PSND_FAIL(PSND_E_SHAPE, "mel: M=%d K=%d N=%lld F=%lld", M, K, (long long)N, (long long)F);
+    if (log_kind < PSND_LOG_NONE || log_kind > PSND_LOG_10) PSND_FAIL(PSND_E_ARG, "mel: log_kind=%d", log_kind);
+    if (N == 0 || F == 0) return PSND_OK;
+    const MelHostPlan h = mel_layout(M, K);
+    MelParams p;
+    p.in0 = in0, p.in1 = in1, p.plan = static_cast<const int *>(plan), p.out = out, p.lin = lin;
+    p.F = F, p.N = (int)N;
+    p.log_kind = log_kind, p.log_offset = log_offset, p.pre_clamp_min = pre, p.clamp_lo = lo, p.clamp_hi = hi;
+    p.nft = (int)((F + 63) / 64);
+    if (!bwd) {
+        p.R = M, p.Cc = K, p.RT = h.MT, p.CS = h.KS, p.band_off = 8, p.w_off = h.fw_off;
+    } else {
+        p.R = K, p.Cc = M, p.RT = h.KT, p.CS = h.MS, p.band_off = 8 + 2 * h.MT, p.w_off = h.bw_off;
+    }
+    const long long waves = (long long)N * p.nft * p.RT;
+    const long long blocks = (waves + 3) / 4;
+    if (blocks >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "mel: grid too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!bwd) hipLaunchKernelGGL(mel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(mel_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    PSND_CHECK_LAUNCH(bwd ? "mel_bwd" : "mel_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_mel_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const void *mel_plan,
+                            int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                            float *out, float *mel_lin, void *stream) {
+    return mel_launch(false, mag, nullptr, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo,
+                      clamp_hi, out, mel_lin, stream);
+}
+
+extern "C" int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, int M, int K,
+                            const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
+                            float clamp_lo, float clamp_hi, float *gmag, void *stream) {
+    return mel_launch(true, gout, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo,
+                      clamp_hi, gmag, nullptr, stream);
+}

@@ -1,0 +1,186 @@
+"""Thin torch-tensor front end of the C ABI (include/psnd.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every number is produced
+by libpsnd_hip.so.  No function in this module has a CPU or eager fallback - a CPU tensor
+or a missing library raises.
+"""
+import math
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr, FRAMING_CENTER, FRAMING_HIFIGAN, LOG_NONE, LOG_E, LOG_10  # noqa: F401
+
+_INF = float('inf')
+
+
+def _need_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.PsndError('%s must be a CUDA(HIP) tensor: the MI355X path has no CPU fallback' % name)
+    if t.dtype != torch.float32:
+        raise _lib.PsndError('%s must be float32, got %s' % (name, t.dtype))
+
+
+def plan_tensor(plan_np):
+    """host plan (numpy uint8) -> torch uint8 tensor (CPU); callers register it as a buffer so
+    Module.to(device) carries it to the GPU."""
+    return torch.from_numpy(np.ascontiguousarray(plan_np))
+
+
+def stft_plan(n_fft, window):
+    return plan_tensor(_lib.build_stft_plan(n_fft, window))
+
+
+def mel_plan(mel_filter):
+    return plan_tensor(_lib.build_mel_plan(mel_filter))
+
+
+def frame_count(T, n_fft, hop, framing=FRAMING_CENTER):
+    return _lib.frame_count(T, n_fft, hop, framing)
+
+
+def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
+                 want_mag=True, want_phase=False, want_reim=False):
+    """wav (N,T) fp32 cuda -> dict of requested (N,K,F) tensors."""
+    _need_cuda(wav, 'wav')
+    if wav.dim() != 2:
+        raise _lib.PsndError('wav must be (N, T), got %s' % (tuple(wav.shape),))
+    if plan.device != wav.device:
+        raise _lib.PsndError('stft plan lives on %s but wav on %s (move the module with .to())' % (plan.device, wav.device))
+    wav = wav.contiguous()
+    N, T = wav.shape
+    F = frame_count(T, n_fft, hop, framing)
+    K = n_fft // 2 + 1
+    mk = lambda: torch.empty((N, K, F), dtype=torch.float32, device=wav.device)  # noqa: E731
+    mag = mk() if want_mag else None
+    phase = mk() if want_phase else None
+    re = mk() if want_reim else None
+    im = mk() if want_reim else None
+    with torch.cuda.device(wav.device):
+        check(lib().psnd_stft_fwd(ptr(wav), N, T, n_fft, hop, framing, ptr(plan), float(mag_eps),
+                                  ptr(mag), ptr(phase), ptr(re), ptr(im), stream_ptr(wav.device)), 'psnd_stft_fwd')
+    return {'mag': mag, 'phase': phase, 're': re, 'im': im}
+
+
+def stft_backward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0, gmag=None, gre=None, gim=None):
+    _need_cuda(wav, 'wav')
+    wav = wav.contiguous()
+    N, T = wav.shape
+    gs = [None if g is None else g.contiguous() for g in (gmag, gre, gim)]
+    for g in gs:
+        if g is not None:
+            _need_cuda(g, 'grad')
+    gwav = torch.empty_like(wav)
+    with torch.cuda.device(wav.device):
+        check(lib().psnd_stft_bwd(ptr(wav), N, T, n_fft, hop, framing, ptr(plan), float(mag_eps),
+                                  ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gwav), stream_ptr(wav.device)),
+              'psnd_stft_bwd')
+    return gwav
+
+
+def _clamp_args(clamp_lo, clamp_hi, pre_clamp_min):
+    lo = -_INF if clamp_lo is None else float(clamp_lo)
+    hi = _INF if clamp_hi is None else float(clamp_hi)
+    pre = -1.0 if pre_clamp_min is None else float(pre_clamp_min)
+    return lo, hi, pre
+
+
+def mel_forward(mag, mel_plan_t, M, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None,
+                clamp_lo=None, clamp_hi=None, want_lin=False):
+    _need_cuda(mag, 'mag')
+    mag = mag.contiguous()
+    N, K, F = mag.shape
+    lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+    out = torch.empty((N, M, F), dtype=torch.float32, device=mag.device)
+    lin = torch.empty_like(out) if want_lin else None
+    with torch.cuda.device(mag.device):
+        check(lib().psnd_mel_fwd(ptr(mag), N, F, M, K, ptr(mel_plan_t), log_kind, float(log_offset), pre, lo, hi,
+                                 ptr(out), ptr(lin), stream_ptr(mag.device)), 'psnd_mel_fwd')
+    return out, lin
+
+
+def mel_backward(gout, mel_lin, mel_plan_t, K, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None,
+                 clamp_lo=None, clamp_hi=None):
+    _need_cuda(gout, 'gout')
+    gout = gout.contiguous()
+    N, M, F = gout.shape
+    lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+    gmag = torch.empty((N, K, F), dtype=torch.float32, device=gout.device)
+    with torch.cuda.device(gout.device):
+        check(lib().psnd_mel_bwd(ptr(gout), ptr(mel_lin), N, F, M, K, ptr(mel_plan_t), log_kind, float(log_offset),
+                                 pre, lo, hi, ptr(gmag), stream_ptr(gout.device)), 'psnd_mel_bwd')
+    return gmag
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd glue
+# ---------------------------------------------------------------------------------------------
+class StftMagPhase(torch.autograd.Function):
+    """(mag, phase) of STFT.transform (transforms.py:53-69).  phase is detached there
+    (atan2 of .data) -> marked non-differentiable here."""
+
+    @staticmethod
+    def forward(ctx, wav, plan, n_fft, hop, framing, mag_eps, want_phase):
+        o = stft_forward(wav, n_fft, hop, plan, framing, mag_eps, True, want_phase, False)
+        ctx.save_for_backward(wav, plan)
+        ctx.cfg = (n_fft, hop, framing, mag_eps)
+        if want_phase:
+            ctx.mark_non_differentiable(o['phase'])
+            return o['mag'], o['phase']
+        return o['mag'], None
+
+    @staticmethod
+    def backward(ctx, gmag, _gphase):
+        wav, plan = ctx.saved_tensors
+        n_fft, hop, framing, mag_eps = ctx.cfg
+        gw = stft_backward(wav, n_fft, hop, plan, framing, mag_eps, gmag=gmag)
+        return gw, None, None, None, None, None, None
+
+
+class StftReIm(torch.autograd.Function):
+    """(re, im) of torch.stft as STFTTorchAudio.forward uses it (transforms.py:297-303); both
+    outputs are differentiable (transform() there does NOT detach the phase, :311)."""
+
+    @staticmethod
+    def forward(ctx, wav, plan, n_fft, hop, framing):
+        o = stft_forward(wav, n_fft, hop, plan, framing, 0.0, False, False, True)
+        ctx.save_for_backward(wav, plan)
+        ctx.cfg = (n_fft, hop, framing)
+        return o['re'], o['im']
+
+    @staticmethod
+    def backward(ctx, gre, gim):
+        wav, plan = ctx.saved_tensors
+        n_fft, hop, framing = ctx.cfg
+        if gre is None:
+            gre = torch.zeros_like(gim)
+        if gim is None:
+            gim = torch.zeros_like(gre)
+        gw = stft_backward(wav, n_fft, hop, plan, framing, 0.0, gre=gre, gim=gim)
+        return gw, None, None, None, None
+
+
+class MelLog(torch.autograd.Function):
+    """clamp(log(max(W @ mag, pre) + off), lo, hi) - transforms.py:235-243 / :364-365 /
+    interface/hifi_gan.py:58-61."""
+
+    @staticmethod
+    def forward(ctx, mag, plan, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi):
+        need_grad = ctx.needs_input_grad[0]
+        out, lin = mel_forward(mag, plan, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, want_lin=need_grad)
+        if need_grad:
+            ctx.save_for_backward(lin, plan)
+        ctx.cfg = (mag.shape[1], log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lin, plan = ctx.saved_tensors
+        K, log_kind, log_offset, pre, lo, hi = ctx.cfg
+        gmag = mel_backward(gout, lin, plan, K, log_kind, log_offset, pre, lo, hi)
+        return gmag, None, None, None, None, None, None, None
+
+
+def db_to_ln(db):
+    """np.log(np.power(10, db / 10)) of transforms.py:223,227"""
+    return math.log(math.pow(10.0, db / 10.0))

@@ -1,0 +1,44 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests never silently pass on a box without a GPU: they are skipped only when the
+    run did not ask for them; under `-m gpu` a missing device or library is a hard failure."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    asked = 'gpu' in (config.getoption('-m') or '') and 'not gpu' not in (config.getoption('-m') or '')
+    if asked:
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + '.npz'))
+    return load
+
+
+def seeded_wav(seed, N, T, sr=22050):
+    """same recipe as tools/gen_golden.py / BASELINE.md synthetic input"""
+    g = np.random.RandomState(seed)
+    t = np.arange(T) / sr
+    w = 0.0708 * g.randn(N, T) + 0.1 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 3000 * t + 0.3)
+    return np.clip(w, -1, 1).astype(np.float32)

@@ -1,0 +1,227 @@
+"""GPU parity tests of the STFT / mel hot path: HIP kernels (through the C ABI) vs the CPU oracle
+and the golden vectors captured from the imported reference.
+
+Tolerances (stated per north_star): frame indexing bit-exact; floating point compared with the
+float64 oracle at |err| <= 4e-6 * max|X| for FFT outputs (fp32 FFT round-off ~ log2(n) * 6e-8
+relative to the frame's largest bin; the reference's own two code paths - dense-DFT conv1d vs
+torch.stft - differ by 1.5e-6 of max), and <= 2e-5 absolute for log-mel values.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import seeded_wav
+from oracle import features as ofe
+
+pytestmark = pytest.mark.gpu
+
+FFT_RTOL = 4e-6
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU test run without a GPU'
+    return torch.device('cuda:0')
+
+
+def _k():
+    from pytorch_sound_amd import kernels
+    return kernels
+
+
+def _stft(wav_np, n_fft, hop, win_length=None, framing=0, mag_eps=0.0, window=None, **want):
+    K = _k()
+    dev = _dev()
+    w = ofe.analysis_window(n_fft, win_length) if window is None else np.asarray(window, np.float32)
+    plan = K.stft_plan(n_fft, w).to(dev)
+    out = K.stft_forward(torch.from_numpy(wav_np).to(dev), n_fft, hop, plan, framing, mag_eps, **want)
+    torch.cuda.synchronize()
+    return {k: (None if v is None else v.cpu().numpy()) for k, v in out.items()}
+
+
+CASES = [
+    # n_fft, hop, win, framing, N, T
+    (1024, 256, None, 0, 2, 4200),
+    (1024, 256, None, 0, 4, 44100),       # BASELINE config 1 shape
+    (1024, 256, 800, 0, 2, 3000),
+    (1024, 256, None, 1, 3, 8192),        # HiFi-GAN framing, config 3 segment
+    (1024, 300, None, 0, 1, 5000),        # hop not dividing n_fft
+    (1024, 255, 1000, 1, 2, 2049),        # odd hop, odd T -> unaligned rows
+    (512, 128, None, 0, 3, 1111),
+    (512, 128, 400, 1, 2, 4096),
+    (256, 64, 200, 0, 2, 700),
+    (256, 64, None, 1, 5, 1000),
+    (2048, 512, None, 0, 1, 6000),
+    (2048, 512, 1200, 1, 2, 9000),
+    (4096, 1024, None, 0, 1, 9000),       # generic path until the tuned 4096 kernel lands
+    (128, 32, None, 0, 2, 500),           # generic path
+    (64, 16, None, 1, 2, 200),            # generic path
+    (1024, 256, None, 0, 1, 513),         # minimum-ish T (> pad): every frame touches an edge
+    (1024, 256, None, 0, 33, 2600),       # many clips, partial last tile
+]
+
+
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', CASES)
+def test_stft_mag_vs_oracle(n_fft, hop, win, framing, N, T):
+    wav = seeded_wav(n_fft + hop + T, N, T)
+    got = _stft(wav, n_fft, hop, win, framing, want_mag=True)['mag']
+    ref = ofe.stft_mag_f64(wav, n_fft, hop, win, framing)
+    assert got.shape == ref.shape == (N, n_fft // 2 + 1, ofe.frame_count(T, n_fft, hop, framing))
+    tol = FFT_RTOL * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= tol
+
+
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9])
+def test_stft_reim_phase_vs_oracle(n_fft, hop, win, framing, N, T):
+    wav = seeded_wav(3 * n_fft + T, N, T)
+    got = _stft(wav, n_fft, hop, win, framing, want_mag=True, want_phase=True, want_reim=True)
+    re, im = ofe.stft_reim_f64(wav, n_fft, hop, win, framing)
+    tol = FFT_RTOL * np.sqrt(re * re + im * im).max()
+    assert np.abs(got['re'] - re).max() <= tol
+    assert np.abs(got['im'] - im).max() <= tol
+    assert np.abs(got['mag'] - np.sqrt(re * re + im * im)).max() <= tol
+    # phase: compare as unit vectors where the bin is well above round-off (atan2 is ill-conditioned at 0)
+    big = np.sqrt(re * re + im * im) > 1e-3 * np.sqrt(re * re + im * im).max()
+    d = np.angle(np.exp(1j * (got['phase'] - np.arctan2(im, re))))
+    assert np.abs(d[big]).max() <= 1e-3 * 4e-3 / 1e-3  # 4e-3 rad at |X| = 1e-3 max  (err ~ tol/|X|)
+    # self-consistency of the kernel's own outputs: phase == atan2(im, re) of what it wrote
+    d2 = np.angle(np.exp(1j * (got['phase'] - np.arctan2(got['im'], got['re']))))
+    assert np.abs(d2).max() <= 2e-6
+
+
+def test_stft_golden_reference(golden):
+    """mag / phase of the imported reference's STFT.transform (tools/gen_golden.py G1)."""
+    g = golden('stft')
+    for name in ['n1024_h256', 'n1024_h256_w800', 'n512_h128', 'n256_h64_w200', 'n2048_h512', 'n4096_h1024']:
+        n, h, w = (int(v) for v in g[name + '/params'])
+        got = _stft(g[name + '/wav'], n, h, w, 0, want_mag=True, want_phase=True)
+        ref = g[name + '/mag']
+        # the reference itself is a float32 dense DFT: allow its own round-off (1e-5 of max)
+        assert np.abs(got['mag'] - ref).max() <= 1e-5 * ref.max(), name
+        big = ref > 1e-2 * ref.max()
+        d = np.angle(np.exp(1j * (got['phase'] - g[name + '/phase'])))
+        assert np.abs(d[big]).max() <= 2e-3, name
+
+
+def test_frame_indexing_bit_exact():
+    """Impulse at sample p, all-ones window: the DC bin of frame f equals the NUMBER of taps of
+    frame f that read sample p under reflect indexing - small integers, exact in fp32."""
+    for n_fft, hop, T in [(1024, 256, 3000), (512, 128, 1500), (256, 64, 700), (2048, 512, 5000), (64, 16, 200)]:
+        for framing in (0, 1):
+            F = ofe.frame_count(T, n_fft, hop, framing)
+            idx = ofe.frame_sample_index(np.arange(F)[:, None], np.arange(n_fft)[None, :], T, n_fft, hop, framing)
+            pad = ofe.pad_amount(n_fft, hop, framing)
+            pos = [0, 1, hop - 1, hop, pad - 1, pad, pad + 1, T // 2, T - pad - 1, T - pad, T - 2, T - 1]
+            wav = np.zeros((len(pos), T), np.float32)
+            for i, p in enumerate(pos):
+                wav[i, p] = 1.0
+            got = _stft(wav, n_fft, hop, None, framing, window=np.ones(n_fft, np.float32), want_mag=False, want_reim=True)
+            for i, p in enumerate(pos):
+                count = (idx == p).sum(axis=1).astype(np.float32)          # F
+                assert np.array_equal(got['re'][i, 0, :], count), (n_fft, framing, p)
+
+
+def test_frame_indexing_golden(golden):
+    """Same contract against the taps recorded from the reference's own pad+conv (G2)."""
+    g = golden('impulse')
+    n, h, T = (int(v) for v in g['params'])
+    for framing in (0, 1):
+        taps = g['framing%d/taps' % framing]                                # P,n,F
+        wav = np.zeros((len(g['pos']), T), np.float32)
+        for i, p in enumerate(g['pos']):
+            wav[i, p] = 1.0
+        got = _stft(wav, n, h, None, framing, window=np.ones(n, np.float32), want_mag=False, want_reim=True)
+        assert np.array_equal(got['re'][:, 0, :], taps.sum(axis=1).astype(np.float32))
+
+
+def test_stft_linearity_and_parseval_full_size():
+    """BASELINE config 2 size (32 x 2 s): size-independent properties instead of the slow oracle."""
+    K = _k()
+    dev = _dev()
+    n_fft, hop = 1024, 256
+    a = torch.from_numpy(seeded_wav(1, 32, 44100)).to(dev)
+    b = torch.from_numpy(seeded_wav(2, 32, 44100)).to(dev)
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(dev)
+    A = K.stft_forward(a, n_fft, hop, plan, want_mag=True, want_reim=True)
+    B = K.stft_forward(b, n_fft, hop, plan, want_mag=False, want_reim=True)
+    S = K.stft_forward(0.5 * a - 2.0 * b, n_fft, hop, plan, want_mag=False, want_reim=True)
+    scale = float(A['mag'].max())
+    assert float((S['re'] - (0.5 * A['re'] - 2.0 * B['re'])).abs().max()) <= 8e-6 * scale
+    assert float((S['im'] - (0.5 * A['im'] - 2.0 * B['im'])).abs().max()) <= 8e-6 * scale
+    # Parseval per frame: |X0|^2 + |XC|^2 + 2 sum_{0<k<C} |Xk|^2 = n * sum_m (w x)^2
+    w = torch.from_numpy(ofe.analysis_window(n_fft)).to(dev).double()
+    xp = torch.nn.functional.pad(a.unsqueeze(1), (n_fft // 2, n_fft // 2), mode='reflect').squeeze(1).double()
+    fr = xp.unfold(-1, n_fft, hop) * w                                       # N,F,n
+    rhs = n_fft * (fr * fr).sum(-1)                                          # N,F
+    m2 = A['mag'].double() ** 2
+    lhs = m2[:, 0] + m2[:, -1] + 2 * m2[:, 1:-1].sum(1)
+    assert float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-12)).max()) <= 2e-5
+    assert A['mag'].shape == (32, 513, 173)
+
+
+def _mel(mag_np, W, **kw):
+    K = _k()
+    dev = _dev()
+    plan = K.mel_plan(W).to(dev)
+    out, lin = K.mel_forward(torch.from_numpy(mag_np).to(dev), plan, W.shape[0], want_lin=True, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), lin.cpu().numpy(), plan
+
+
+@pytest.mark.parametrize('sr,n_fft,M,fmin,fmax,F', [(22050, 1024, 80, 0, 8000, 173), (22050, 1024, 80, 0, None, 32),
+                                                    (16000, 512, 40, 50, 7000, 61), (44100, 4096, 128, 0, None, 70),
+                                                    (22050, 256, 13, 0, None, 5)])
+def test_mel_fwd_bwd_vs_oracle(sr, n_fft, M, fmin, fmax, F):
+    K = _k()
+    dev = _dev()
+    W = ofe.mel_filterbank(sr, n_fft, M, fmin, fmax)
+    g = np.random.RandomState(F)
+    mag = np.abs(g.randn(3, n_fft // 2 + 1, F)).astype(np.float32) * 3
+    mag[0, :, 0] = 0                                                          # silence frame -> lower clamp
+    lo, hi = ofe.db_to_ln(-50), ofe.db_to_ln(30)
+    mag[1] *= 300.0                                                           # drive the upper clamp
+    out, lin, plan = _mel(mag, W, log_kind=K.LOG_E, log_offset=1e-6, clamp_lo=lo, clamp_hi=hi)
+    lin64 = np.matmul(W.astype(np.float64), mag.astype(np.float64))
+    ref = np.clip(np.log(lin64 + 1e-6), lo, hi)
+    assert np.abs(lin - lin64).max() <= 2e-6 * np.abs(lin64).max()
+    assert np.abs(out - ref).max() <= 2e-5
+    assert (out == np.float32(lo)).any() and (out >= np.float32(hi) - 1e-6).any()
+    # backward: gmag = W^T (gout * [lo <= y <= hi] / (lin + off))
+    gout = g.randn(*out.shape).astype(np.float32)
+    y = np.log(lin64 + 1e-6)
+    dl = np.where((y < lo) | (y > hi), 0.0, 1.0 / (lin64 + 1e-6))
+    gref = np.einsum('mk,nmf->nkf', W.astype(np.float64), gout * dl)
+    got = K.mel_backward(torch.from_numpy(gout).to(dev), torch.from_numpy(lin).to(dev), plan, n_fft // 2 + 1,
+                         K.LOG_E, 1e-6, None, lo, hi).cpu().numpy()
+    # entries within float32 round-off of a clamp edge may legitimately flip; none here by construction
+    assert np.abs(got - gref).max() <= 3e-6 * np.abs(gref).max()
+
+
+def test_mel_dense_matrix_and_log10():
+    """A dense (non-banded) projection and the Audio2Mel epilogue log10(clamp(.,1e-5))."""
+    K = _k()
+    g = np.random.RandomState(3)
+    W = g.rand(24, 129).astype(np.float32)
+    mag = np.abs(g.randn(2, 129, 77)).astype(np.float32) * 1e-3
+    mag[0, :, :5] = 0
+    out, lin, _ = _mel(mag, W, log_kind=K.LOG_10, log_offset=0.0, pre_clamp_min=1e-5)
+    lin64 = np.matmul(W.astype(np.float64), mag.astype(np.float64))
+    assert np.abs(out - np.log10(np.maximum(lin64, 1e-5))).max() <= 2e-5
+
+
+def test_logmel_golden_reference(golden):
+    """LogMelSpectrogram.forward of the imported reference (G4), through stft_fwd + mel_fwd."""
+    K = _k()
+    dev = _dev()
+    g = golden('logmel')
+    for name in ['default', 'noclamp', 'zero_db_disables', 'silence']:
+        kw = g[name + '/kw']
+        sr, M, n_fft, win, hop = (int(v) for v in kw[:5])
+        min_db = None if np.isnan(kw[5]) else kw[5]
+        max_db = None if np.isnan(kw[6]) else kw[6]
+        wav = torch.from_numpy(g[name + '/wav']).to(dev)
+        plan = K.stft_plan(win, ofe.analysis_window(win)).to(dev)
+        mag = K.stft_forward(wav, win, hop, plan)['mag']
+        mplan = K.mel_plan(g[name + '/mel_filter']).to(dev)
+        out, _ = K.mel_forward(mag, mplan, M, K.LOG_E, 1e-6, None,
+                               ofe.db_to_ln(min_db) if min_db else None, ofe.db_to_ln(max_db) if max_db else None)
+        assert np.abs(out.cpu().numpy() - g[name + '/mel']).max() <= 2e-4, name
