@@ -27,7 +27,7 @@ SIGNATURES = {
     'psnd_stft_plan_bytes': (_c.c_size_t, [_INT]),
     'psnd_stft_plan_build': (_INT, [_INT, _P, _P]),
     'psnd_stft_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
-    # 'psnd_stft_bwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
+    'psnd_stft_bwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
     'psnd_mel_plan_bytes': (_c.c_size_t, [_INT, _INT]),
     'psnd_mel_plan_build': (_INT, [_INT, _INT, _P, _P]),
     'psnd_mel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P]),

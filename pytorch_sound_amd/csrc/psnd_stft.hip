@@ -19,48 +19,13 @@
 //           Lanes of a wave are 16 (or 32) consecutive frames x 4 (2) bins, so every store
 //           instruction writes 64-B (128-B) runs of the (N,K,F) frame-fastest output.
 // The only LDS round trip is the transposing exchange between the passes (4 KB/frame each way).
-#include "psnd_common.h"
+#include "psnd_stft_pass.h"
 #include <math.h>
 #include <string.h>
 #include <vector>
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------
-// plan layout (floats), for a (R1, L) decomposition of C = n/2:
-//   [0, L*ROW)            wt[l][2a+c] = 0.5 * win[2(l + L a) + c]          ROW = 2*R1 + 4
-//   [L*ROW, 2 L*ROW)      tw[l][2q+{0,1}] = (cos, -sin)(2 pi l q / C)
-//   [2 L*ROW, +VKP)       vk[k] = (-sin, -cos)(2 pi k / n), k = 0..C/2      VKP = round4(2(C/2+1))
-//   [.., +n)              win[n] raw analysis window (backward / inverse kernels)
-//   [.., +n)              (reserved)
-// ---------------------------------------------------------------------------------------------
-struct Decomp {
-    int n_fft, R1, L;
-};
-constexpr Decomp kDecomp[] = {{256, 16, 8}, {512, 16, 16}, {1024, 32, 16}, {2048, 32, 32}};
-
-const Decomp *find_decomp(int n_fft) {
-    for (const Decomp &d : kDecomp)
-        if (d.n_fft == n_fft) return &d;
-    return nullptr;
-}
-inline int round4(int x) { return (x + 3) & ~3; }
-inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
-
-struct PlanLayout {
-    int row, tab, vk, vkp, win, total;  // offsets in floats
-};
-PlanLayout plan_layout(int n_fft, int R1, int L) {
-    PlanLayout p;
-    int C = n_fft / 2;
-    p.row = 2 * R1 + 4;
-    p.tab = L * p.row;
-    p.vk = 2 * p.tab;
-    p.vkp = round4(2 * (C / 2 + 1));
-    p.win = p.vk + p.vkp;
-    p.total = p.win + n_fft;
-    return p;
-}
+using namespace psnd_stft;
 
 struct StftFwdParams {
     const float *wav;
@@ -87,70 +52,25 @@ struct Emit {
     }
 };
 
-// za = Z'[k], zb = Z'[C-k], v = v_k  ->  X[k] = S + E,  X[C-k] = conj(S - E)
-__device__ __forceinline__ void rfft_pair(float zar, float zai, float zbr, float zbi, float vr, float vi,
-                                          float &xkr, float &xki, float &xcr, float &xci) {
-    const float sr = zar + zbr, si = zai - zbi;
-    const float dr = zar - zbr, di = zai + zbi;
-    const float er = __builtin_fmaf(vr, dr, -vi * di);
-    const float ei = __builtin_fmaf(vr, di, vi * dr);
-    xkr = sr + er;
-    xki = si + ei;
-    xcr = sr - er;
-    xci = ei - si;
-}
-
 template <int R1, int L, bool MAG, bool PHASE, bool REIM>
 __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
-    constexpr int C = R1 * L, NFFT = 2 * C;
-    constexpr int FT = 512 / R1;          // frames per tile: FT * R1/2 pass-2 tasks == 256
-    constexpr int ROW = 2 * R1 + 4;
-    constexpr int SF = C + 4;             // exchange frame stride; SF/4 odd -> b128 reads conflict-free
-    constexpr int P1R = (FT * L) / 256;   // pass-1 rounds
-    constexpr int VKP = ((2 * (C / 2 + 1)) + 3) & ~3;
-    constexpr int LB = ct::ilog2(L), RB = ct::ilog2(R1);
-    static_assert(FT * L % 256 == 0 && P1R >= 1, "pass-1 tiling");
-    static_assert((SF / 4) % 2 == 1 && (ROW / 4) % 2 == 1, "LDS strides");
+    using G = Cfg<R1, L>;
+    constexpr int C = G::C, FT = G::FT, P1R = G::P1R, LB = G::LB;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *s_wt = smem;
-    float *s_tw = s_wt + L * ROW;
-    float *s_vk = s_tw + L * ROW;
-    float *s_xr = s_vk + VKP;
-    float *s_xi = s_xr + FT * SF;
-
+    const Smem s = carve<R1, L>(smem);
     const int t = threadIdx.x;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.plan);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        constexpr int NV = (2 * L * ROW + VKP) / 4;
-        for (int i = t; i < NV; i += 256) dst[i] = src[i];
-    }
+    load_tables<R1, L>(p.plan, smem, t);
     __syncthreads();
 
-    // XCD-aware tile walk: block b runs on XCD b % 8 (observed, speed only).  Give every XCD one
-    // contiguous range of tiles so that neighbouring frame tiles of a clip - which share the
-    // 128-B output lines at their common edge - are written through the same L2.
-    const int nb = gridDim.x, xcd = blockIdx.x & 7, bx = blockIdx.x >> 3;
-    const int nbx = (nb - xcd + 7) >> 3;
-    const int chunk = (p.total_tiles + 7) >> 3;
-    const int lo = xcd * chunk;
-    const int hi = min(lo + chunk, p.total_tiles);
-
-    // pass-2 identity
     int f2, qq;
-    if constexpr (FT == 16) {
-        f2 = t & 15;
-        qq = (t >> 6) + 4 * ((t >> 4) & 3);
-    } else {
-        f2 = t & (FT - 1);
-        qq = t / FT;
-    }
+    pass2_identity<R1, L>(t, f2, qq);
     const bool special = (qq == 0);
     const int qA = qq;
     const int qB = special ? R1 / 2 : R1 - qq;
 
-    for (int tile = lo + bx; tile < hi; tile += nbx) {
+    const TileWalk tw = tile_walk(p.total_tiles);
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
         const int clip = tile / p.ntile;
         const long long f0 = (long long)(tile - clip * p.ntile) * FT;
         const float *x = p.wav + (size_t)clip * p.T;
@@ -159,95 +79,14 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
 #pragma unroll 1
         for (int r = 0; r < P1R; ++r) {
             const int task = r * 256 + t;
-            const int fl = task / L, l = task % L;
-            const long long f = f0 + fl;
-            float zr[R1], zi[R1];
-            if (f < p.F) {
-                const long long s0 = f * p.hop - p.pad;
-                if (s0 >= 0 && s0 + NFFT <= p.T) {
-                    const float *px = x + s0 + 2 * l;
-                    static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
-                        constexpr int a = decltype(ac)::value;
-                        const f32x2_u v = *reinterpret_cast<const f32x2_u *>(px + 2 * L * a);
-                        zr[a] = v.x;
-                        zi[a] = v.y;
-                    });
-                } else {
-                    // clip edge: reflect-gather the frame into its own (still unused) exchange slot
-                    // with a small runtime loop, then pick it up with compile-time offsets.  The L
-                    // lanes of a frame sit in one wave, whose LDS operations execute in order.
-                    float *gr = s_xr + fl * SF, *gi = s_xi + fl * SF;
-                    const int Ti = (int)p.T, s0i = (int)s0;
-#pragma unroll 2
-                    for (int m = l; m < C; m += L) {
-                        gr[m] = x[reflect_idx32(s0i + 2 * m, Ti)];
-                        gi[m] = x[reflect_idx32(s0i + 2 * m + 1, Ti)];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
-                        constexpr int a = decltype(ac)::value;
-                        zr[a] = gr[l + L * a];
-                        zi[a] = gi[l + L * a];
-                    });
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
-                static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
-                    zr[decltype(ac)::value] = 0.f;
-                    zi[decltype(ac)::value] = 0.f;
-                });
-            }
-            const float *wrow = s_wt + l * ROW;
-            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-                zr[2 * i] *= w.x;
-                zi[2 * i] *= w.y;
-                zr[2 * i + 1] *= w.z;
-                zi[2 * i + 1] *= w.w;
-            });
-            fft_inreg<R1>(zr, zi);
-            const float *trow = s_tw + l * ROW;
-            float *oxr = s_xr + fl * SF + l;
-            float *oxi = s_xi + fl * SF + l;
-            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 4 * i);
-                constexpr int s0_ = ct::bitrev(2 * i, RB), s1_ = ct::bitrev(2 * i + 1, RB);
-                if constexpr (i == 0) {
-                    oxr[0] = zr[s0_];
-                    oxi[0] = zi[s0_];
-                } else {
-                    oxr[(2 * i) * L] = __builtin_fmaf(zr[s0_], w.x, -zi[s0_] * w.y);
-                    oxi[(2 * i) * L] = __builtin_fmaf(zr[s0_], w.y, zi[s0_] * w.x);
-                }
-                oxr[(2 * i + 1) * L] = __builtin_fmaf(zr[s1_], w.z, -zi[s1_] * w.w);
-                oxi[(2 * i + 1) * L] = __builtin_fmaf(zr[s1_], w.w, zi[s1_] * w.z);
-            });
+            fwd_pass1<R1, L>(s, x, p.T, p.F, f0, p.hop, p.pad, task / L, task % L);
         }
         __syncthreads();
 
         // ------------------------------- pass 2 -------------------------------------------
         {
             float ar[L], ai[L], br[L], bi[L];
-            const float *pa_r = s_xr + f2 * SF + qA * L, *pa_i = s_xi + f2 * SF + qA * L;
-            const float *pb_r = s_xr + f2 * SF + qB * L, *pb_i = s_xi + f2 * SF + qB * L;
-            static_for<0, L / 4>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pa_r + 4 * i);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pa_i + 4 * i);
-                const f32x4 v2 = *reinterpret_cast<const f32x4 *>(pb_r + 4 * i);
-                const f32x4 v3 = *reinterpret_cast<const f32x4 *>(pb_i + 4 * i);
-                ar[4 * i] = v0.x, ar[4 * i + 1] = v0.y, ar[4 * i + 2] = v0.z, ar[4 * i + 3] = v0.w;
-                ai[4 * i] = v1.x, ai[4 * i + 1] = v1.y, ai[4 * i + 2] = v1.z, ai[4 * i + 3] = v1.w;
-                br[4 * i] = v2.x, br[4 * i + 1] = v2.y, br[4 * i + 2] = v2.z, br[4 * i + 3] = v2.w;
-                bi[4 * i] = v3.x, bi[4 * i + 1] = v3.y, bi[4 * i + 2] = v3.z, bi[4 * i + 3] = v3.w;
-            });
-            fft_inreg<L>(ar, ai);
-            fft_inreg<L>(br, bi);
+            fwd_pass2_fft<R1, L>(s, f2, qA, qB, ar, ai, br, bi);
 
             const long long F = p.F;
             const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
@@ -257,6 +96,7 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
             const int iF = (int)F;
             const int stepF = R1 * iF;
             const int offA = qA * iF, offB = qB * iF;
+            const float *s_vk = s.vk;
             float xkr, xki, xcr, xci;
             if (!special) {
                 static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
@@ -357,9 +197,7 @@ __global__ __launch_bounds__(256) void stft_fwd_generic_kernel(StftFwdParams p, 
 
 template <int R1, int L>
 int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
-    constexpr int C = R1 * L, FT = 512 / R1;
-    constexpr int ROW = 2 * R1 + 4, SF = C + 4, VKP = ((2 * (C / 2 + 1)) + 3) & ~3;
-    constexpr size_t lds = sizeof(float) * (2 * L * ROW + VKP + 2 * FT * SF);
+    constexpr size_t lds = sizeof(float) * Cfg<R1, L>::LDS_FLOATS;
     int grid = p.total_tiles;
     const int cap = 256 * 8;  // ~8 tiles in flight per CU slot, grid-stride beyond
     if (grid > cap) grid = cap;
@@ -386,9 +224,11 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
 
 }  // namespace
 
+using namespace psnd_stft;
+
 extern "C" size_t psnd_stft_plan_bytes(int n_fft) {
     if (const Decomp *d = find_decomp(n_fft)) return sizeof(float) * (size_t)plan_layout(n_fft, d->R1, d->L).total;
-    if (is_pow2(n_fft) && n_fft >= 16 && n_fft <= 8192) return sizeof(float) * (size_t)n_fft;
+    if (generic_ok(n_fft)) return sizeof(float) * (size_t)n_fft;
     return 0;
 }
 

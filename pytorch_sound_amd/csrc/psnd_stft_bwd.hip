@@ -1,0 +1,418 @@
+// psnd_stft_bwd.hip - adjoint of the STFT stage for gfx950: what autograd computes through
+// F.pad(reflect) + F.conv1d(forward_basis) + sqrt(re^2+im^2) (pytorch_sound/models/transforms.py:55-69)
+// and through torch.stft (transforms.py:297-311), without the dense basis.
+//
+//   gwav[t] += win[m] * Re sum_{k=0..C} G[k] e^{+2 pi i k m / n}      for every (frame f, tap m) that
+//              reads sample t (reflect map), G = gre + i gim (+ gmag * X/|X| with X recomputed).
+//
+// It is the forward kernel run backwards on the same tiling (psnd_stft.hip):
+//   phase 0  (gmag only) forward pass 1 -> exchange, to recompute X
+//   phase 1  thread (frame, bin pair): forward radix-L + real split -> X[k], X[C-k]; G; adjoint
+//            split -> Zs[k], Zs[C-k] (same two butterflies); inverse radix-L in VGPRs; conj twiddle;
+//            written back over the thread's own two exchange rows
+//   phase 2  lane (frame, l): inverse radix-R1 over q in VGPRs -> the 2*R1 windowed time samples of
+//            the lane; overlap-add of the tile's FT frames in LDS (ds_add_f32 into a span buffer that
+//            aliases the exchange area), then ONE pass over the span: samples completed inside the
+//            tile are stored plainly (coalesced), the n-hop head/tail and reflected samples are
+//            atomically added to the zero-initialised gwav.
+#include "psnd_stft_pass.h"
+#include <math.h>
+
+namespace {
+using namespace psnd_stft;
+
+struct StftBwdParams {
+    const float *wav, *plan, *gmag, *gre, *gim;
+    float *gwav;
+    long long T, F;
+    int hop, pad, ntile, total_tiles;
+    float mag_eps;
+};
+
+template <bool FROM_MAG, bool FROM_REIM>
+struct GLoad {
+    const float *gmag, *gre, *gim;
+    float eps;
+    bool valid;
+    // gradient wrt (re, im) of bin at offset `off`, given the recomputed X there
+    __device__ __forceinline__ void operator()(int off, float xr, float xi, float &gr, float &gi) const {
+        gr = 0.f, gi = 0.f;
+        if (!valid) return;
+        if constexpr (FROM_MAG) {
+            const float m = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, eps)));
+            const float g = gmag[off] / m;   // 0/0 -> NaN exactly like autograd of sqrt at 0
+            gr = g * xr;
+            gi = g * xi;
+        }
+        if constexpr (FROM_REIM) {
+            gr += gre[off];
+            gi += gim[off];
+        }
+    }
+};
+
+__device__ __forceinline__ long long reflect64(long long i, long long T) {
+    if (i < 0) i = -i;
+    if (i >= T) i = 2 * (T - 1) - i;
+    return i;
+}
+
+template <int R1, int L, bool FROM_MAG, bool FROM_REIM>
+__global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
+    using G = Cfg<R1, L>;
+    constexpr int C = G::C, NFFT = G::NFFT, FT = G::FT, P1R = G::P1R, LB = G::LB, RB = G::RB, SF = G::SF, ROW = G::ROW;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Smem s = carve<R1, L>(smem);
+    const int t = threadIdx.x;
+    load_tables<R1, L>(p.plan, smem, t);
+    __syncthreads();
+
+    int f2, qq;
+    pass2_identity<R1, L>(t, f2, qq);
+    const bool special = (qq == 0);
+    const int qA = qq;
+    const int qB = special ? R1 / 2 : R1 - qq;
+
+    const int span_len = (FT - 1) * p.hop + NFFT;
+    const bool use_span = (P1R == 1) && (span_len <= 2 * FT * SF);
+    float *span = s.xr;   // aliases the exchange area once every lane has read its inputs
+
+    const TileWalk tw = tile_walk(p.total_tiles);
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+        const int clip = tile / p.ntile;
+        const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+        const float *x = p.wav + (size_t)clip * p.T;
+        float *gw = p.gwav + (size_t)clip * p.T;
+
+        if constexpr (FROM_MAG) {
+#pragma unroll 1
+            for (int r = 0; r < P1R; ++r) {
+                const int task = r * 256 + t;
+                fwd_pass1<R1, L>(s, x, p.T, p.F, f0, p.hop, p.pad, task / L, task % L);
+            }
+            __syncthreads();
+        }
+
+        // ------------------------------- phase 1 ------------------------------------------
+        {
+            float ar[L], ai[L], br[L], bi[L];      // forward butterflies (slot = bitrev(p))
+            float uAr[L], uAi[L], uBr[L], uBi[L];  // adjoint inputs Zs[q + R1 p] in natural p order
+            if constexpr (FROM_MAG) {
+                fwd_pass2_fft<R1, L>(s, f2, qA, qB, ar, ai, br, bi);
+            } else {
+                static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    ar[i] = ai[i] = br[i] = bi[i] = 0.f;
+                });
+            }
+            const long long F = p.F;
+            const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
+            GLoad<FROM_MAG, FROM_REIM> gload{FROM_MAG ? p.gmag + cbase : nullptr, FROM_REIM ? p.gre + cbase : nullptr,
+                                             FROM_REIM ? p.gim + cbase : nullptr, p.mag_eps, (f0 + f2) < F};
+            const int iF = (int)F;
+            const int stepF = R1 * iF;
+            const int offA = qA * iF, offB = qB * iF;
+            const float *s_vk = s.vk;
+            float xkr = 0.f, xki = 0.f, xcr = 0.f, xci = 0.f, gkr, gki, gcr, gci;
+            if (!special) {
+                static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(pc)::value;
+                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                    {   // bins k = qA + R1*pp  and  C-k = qB + R1*(L-1-pp)
+                        const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qA + R1 * pp));
+                        if constexpr (FROM_MAG) rfft_pair(ar[sa], ai[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
+                        gload(offA + pp * stepF, xkr, xki, gkr, gki);
+                        gload(offB + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                        irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uAr[pp], uAi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
+                    }
+                    {   // bins k = qB + R1*pp  and  C-k = qA + R1*(L-1-pp)
+                        const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qB + R1 * pp));
+                        if constexpr (FROM_MAG) rfft_pair(br[sa], bi[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
+                        gload(offB + pp * stepF, xkr, xki, gkr, gki);
+                        gload(offA + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                        irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uAr[L - 1 - pp], uAi[L - 1 - pp]);
+                    }
+                });
+            } else {
+                // butterfly q = 0: bins R1*p and C - R1*p = R1*(L-p)
+                static_for<0, L / 2 + 1>([&](auto pc) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(pc)::value;
+                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
+                    const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * pp));
+                    if constexpr (FROM_MAG) rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
+                    gload(pp * stepF, xkr, xki, gkr, gki);
+                    float z0r, z0i, z1r, z1i;
+                    if constexpr (pp == 0) {
+                        // H[0] = 2 Re G[0], H[C] = 2 Re G[C] (the imaginary parts of the DC / Nyquist
+                        // bins do not reach the real signal)
+                        gload(L * stepF, xcr, xci, gcr, gci);
+                        irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
+                        uAr[0] = z0r, uAi[0] = z0i;
+                    } else if constexpr (2 * pp == L) {
+                        irfft_pair(gkr, gki, gkr, gki, v.x, v.y, z0r, z0i, z1r, z1i);
+                        uAr[pp] = z0r, uAi[pp] = z0i;
+                    } else {
+                        gload((L - pp) * stepF, xcr, xci, gcr, gci);
+                        irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
+                        uAr[pp] = z0r, uAi[pp] = z0i;
+                        uAr[L - pp] = z1r, uAi[L - pp] = z1i;
+                    }
+                });
+                // butterfly q = R1/2: bins R1/2 + R1*p and R1/2 + R1*(L-1-p)
+                static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+                    constexpr int pp = decltype(pc)::value;
+                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                    const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 / 2 + R1 * pp));
+                    if constexpr (FROM_MAG) rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
+                    gload(offB + pp * stepF, xkr, xki, gkr, gki);
+                    gload(offB + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                    irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
+                });
+            }
+            // inverse radix-L over p (swap trick: FFT of (im, re) = swapped inverse FFT); U[q][l] in slot bitrev(l)
+            fft_inreg<L>(uAi, uAr);
+            fft_inreg<L>(uBi, uBr);
+            // conj twiddle W_C^{-lq} and write back over this thread's own two rows
+            float *oa_r = s.xr + f2 * SF + qA * L, *oa_i = s.xi + f2 * SF + qA * L;
+            float *ob_r = s.xr + f2 * SF + qB * L, *ob_i = s.xi + f2 * SF + qB * L;
+            static_for<0, L / 4>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                f32x4 var, vai, vbr, vbi;
+                static_for<0, 4>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int l = 4 * i + j, sl = ct::bitrev(l, LB);
+                    const f32x2 ta = *reinterpret_cast<const f32x2 *>(s.tw + l * ROW + 2 * qA);
+                    const f32x2 tb = *reinterpret_cast<const f32x2 *>(s.tw + l * ROW + 2 * qB);
+                    // U * conj(t), t = (cos, -sin) stored -> conj = (t.x, -t.y)
+                    var[j] = __builtin_fmaf(uAr[sl], ta.x, uAi[sl] * ta.y);
+                    vai[j] = __builtin_fmaf(uAi[sl], ta.x, -uAr[sl] * ta.y);
+                    vbr[j] = __builtin_fmaf(uBr[sl], tb.x, uBi[sl] * tb.y);
+                    vbi[j] = __builtin_fmaf(uBi[sl], tb.x, -uBr[sl] * tb.y);
+                });
+                *reinterpret_cast<f32x4 *>(oa_r + 4 * i) = var;
+                *reinterpret_cast<f32x4 *>(oa_i + 4 * i) = vai;
+                *reinterpret_cast<f32x4 *>(ob_r + 4 * i) = vbr;
+                *reinterpret_cast<f32x4 *>(ob_i + 4 * i) = vbi;
+            });
+        }
+        __syncthreads();
+
+        // ------------------------------- phase 2 ------------------------------------------
+        const long long t_start = f0 * p.hop - p.pad;
+#pragma unroll 1
+        for (int r = 0; r < P1R; ++r) {
+            const int task = r * 256 + t;
+            const int fl = task / L, l = task % L;
+            float zr[R1], zi[R1];
+            const float *ixr = s.xr + fl * SF + l, *ixi = s.xi + fl * SF + l;
+            static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                zr[q] = ixr[q * L];
+                zi[q] = ixi[q * L];
+            });
+            fft_inreg<R1>(zi, zr);   // inverse radix-R1 over q: z[l + L a] in slot bitrev(a)
+            const float *wrow = s.wt + l * ROW;
+            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+                constexpr int s0_ = ct::bitrev(2 * i, RB), s1_ = ct::bitrev(2 * i + 1, RB);
+                zr[s0_] *= w.x;
+                zi[s0_] *= w.y;
+                zr[s1_] *= w.z;
+                zi[s1_] *= w.w;
+            });
+            const bool fvalid = (f0 + fl) < p.F;
+            if (use_span) {
+                __syncthreads();   // every lane holds its inputs in registers: the exchange area is free
+                for (int i = t; i < span_len; i += 256) span[i] = 0.f;
+                __syncthreads();
+                if (fvalid) {
+                    float *sp = span + fl * p.hop + 2 * l;
+                    static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
+                        constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
+                        atomicAdd(sp + 2 * L * a, zr[sl]);
+                        atomicAdd(sp + 2 * L * a + 1, zi[sl]);
+                    });
+                }
+                __syncthreads();
+                const int int_lo = NFFT - p.hop, int_hi = FT * p.hop;
+                for (int i = t; i < span_len; i += 256) {
+                    const float v = span[i];
+                    const long long tg = t_start + i;
+                    if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {
+                        gw[tg] = v;
+                    } else if (v != 0.f) {
+                        const long long tr = reflect64(tg, p.T);
+                        if (tr >= 0 && tr < p.T) unsafeAtomicAdd(gw + tr, v);
+                    }
+                }
+            } else if (fvalid) {
+                const long long tb = (f0 + fl) * p.hop - p.pad + 2 * l;
+                static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
+                    const long long t0 = reflect64(tb + 2 * L * a, p.T), t1 = reflect64(tb + 2 * L * a + 1, p.T);
+                    if (t0 >= 0 && t0 < p.T) unsafeAtomicAdd(gw + t0, zr[sl]);
+                    if (t1 >= 0 && t1 < p.T) unsafeAtomicAdd(gw + t1, zi[sl]);
+                });
+            }
+        }
+        __syncthreads();   // exchange / span area is rewritten by the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic fallback (power-of-two n_fft without a tuned decomposition): one workgroup per
+// (clip, frame), radix-2 FFTs in LDS, global atomics.  plan = win[n].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_fft_radix2(float *sr, float *si, int C, int t, float sign) {
+    for (int h = 1; h < C; h <<= 1) {   // DIT on bit-reversed input, natural-order output
+        for (int j = t; j < C / 2; j += 256) {
+            const int blk = (j / h) * 2 * h, jj = j % h;
+            const int i0 = blk + jj, i1 = i0 + h;
+            float sn, cs;
+            sincospif(sign * (float)jj / (float)h, &sn, &cs);
+            const float br = sr[i1] * cs - si[i1] * sn, bi = sr[i1] * sn + si[i1] * cs;
+            const float ar = sr[i0], ai = si[i0];
+            sr[i0] = ar + br, si[i0] = ai + bi;
+            sr[i1] = ar - br, si[i1] = ai - bi;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool FROM_MAG, bool FROM_REIM>
+__global__ __launch_bounds__(256) void stft_bwd_generic_kernel(StftBwdParams p, int n_fft) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = n_fft / 2;
+    float *sr = smem, *si = smem + C, *hr = smem + 2 * C, *hi = hr + (C + 1);
+    const int t = threadIdx.x;
+    const long long f = blockIdx.x;
+    const int clip = blockIdx.y;
+    const float *x = p.wav + (size_t)clip * p.T;
+    float *gw = p.gwav + (size_t)clip * p.T;
+    const float *win = p.plan;
+    const long long s0 = f * p.hop - p.pad;
+    int bits = 0;
+    while ((1 << bits) < C) ++bits;
+    const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)p.F + (size_t)f;
+    if (FROM_MAG) {
+        for (int m = t; m < C; m += 256) {
+            const int r = __brev((unsigned)m) >> (32 - bits);
+            sr[r] = x[reflect_idx(s0 + 2 * m, p.T)] * win[2 * m];
+            si[r] = x[reflect_idx(s0 + 2 * m + 1, p.T)] * win[2 * m + 1];
+        }
+        __syncthreads();
+        lds_fft_radix2(sr, si, C, t, -1.f);
+    }
+    // H[k], k = 0..C
+    for (int k = t; k <= C; k += 256) {
+        float gr = 0.f, gi = 0.f;
+        const size_t off = cbase + (size_t)k * p.F;
+        if (FROM_MAG) {
+            const int kk = k % C, kc = (C - k) % C;
+            float sn, cs;
+            sincospif(-(float)k / (float)C, &sn, &cs);
+            float xkr, xki, xcr, xci;
+            rfft_pair(0.5f * sr[kk], 0.5f * si[kk], 0.5f * sr[kc], 0.5f * si[kc], sn, -cs, xkr, xki, xcr, xci);
+            const float m = __builtin_amdgcn_sqrtf(xkr * xkr + xki * xki + p.mag_eps);
+            const float g = p.gmag[off] / m;
+            gr = g * xkr, gi = g * xki;
+        }
+        if (FROM_REIM) gr += p.gre[off], gi += p.gim[off];
+        if (k == 0 || k == C) gr *= 2.f, gi = 0.f;
+        hr[k] = gr, hi[k] = gi;
+    }
+    __syncthreads();
+    for (int k = t; k < C; k += 256) {
+        float sn, cs;
+        sincospif(-(float)k / (float)C, &sn, &cs);
+        float zkr, zki, zcr, zci;
+        irfft_pair(hr[k], hi[k], hr[C - k], hi[C - k], sn, -cs, zkr, zki, zcr, zci);
+        const int r = __brev((unsigned)k) >> (32 - bits);
+        sr[r] = zkr, si[r] = zki;
+    }
+    __syncthreads();
+    lds_fft_radix2(sr, si, C, t, 1.f);
+    for (int m = t; m < C; m += 256) {
+        const long long t0 = reflect_idx(s0 + 2 * m, p.T), t1 = reflect_idx(s0 + 2 * m + 1, p.T);
+        unsafeAtomicAdd(gw + t0, 0.5f * sr[m] * win[2 * m]);
+        unsafeAtomicAdd(gw + t1, 0.5f * si[m] * win[2 * m + 1]);
+    }
+}
+
+template <int R1, int L>
+int launch_bwd(const StftBwdParams &p, bool from_mag, bool from_reim, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * Cfg<R1, L>::LDS_FLOATS;
+    int grid = p.total_tiles;
+    if (grid > 2048) grid = 2048;
+    grid = (grid + 7) & ~7;
+#define PSND_LAUNCH(M_, R_)                                                                          \
+    do {                                                                                             \
+        auto kern = stft_bwd_kernel<R1, L, M_, R_>;                                                  \
+        if (lds > 64 * 1024) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e)); \
+        }                                                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);                             \
+    } while (0)
+    if (from_mag && !from_reim) PSND_LAUNCH(true, false);
+    else if (!from_mag && from_reim) PSND_LAUNCH(false, true);
+    else PSND_LAUNCH(true, true);
+#undef PSND_LAUNCH
+    PSND_CHECK_LAUNCH("stft_bwd");
+    return PSND_OK;
+}
+
+}  // namespace
+
+using namespace psnd_stft;
+
+extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                             const void *plan, float mag_eps, const float *gmag, const float *gre,
+                             const float *gim, float *gwav, void *stream) {
+    if (!plan || !gwav) PSND_FAIL(PSND_E_ARG, "stft_bwd: null plan/gwav");
+    if ((gre == nullptr) != (gim == nullptr)) PSND_FAIL(PSND_E_ARG, "stft_bwd: gre and gim must be given together");
+    if (!gmag && !gre) PSND_FAIL(PSND_E_ARG, "stft_bwd: no gradient source");
+    if (gmag && !wav) PSND_FAIL(PSND_E_ARG, "stft_bwd: gmag needs wav (recompute)");
+    if (framing != PSND_FRAMING_CENTER && framing != PSND_FRAMING_HIFIGAN) PSND_FAIL(PSND_E_ARG, "stft_bwd: framing=%d", framing);
+    if (hop <= 0 || N < 0) PSND_FAIL(PSND_E_ARG, "stft_bwd: hop=%d N=%lld", hop, (long long)N);
+    if (psnd_stft_plan_bytes(n_fft) == 0) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd: n_fft=%d unsupported", n_fft);
+    const int pad = framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2;
+    if (pad < 0 || T <= pad) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: reflect padding %d needs T > pad (T=%lld)", pad, (long long)T);
+    if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: T too large");
+    if (N == 0) return PSND_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t me = hipMemsetAsync(gwav, 0, sizeof(float) * (size_t)N * (size_t)T, s);
+    if (me != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: memset: %s", hipGetErrorString(me));
+    const int64_t F = psnd_frame_count(T, n_fft, hop, framing);
+    if (F <= 0) return PSND_OK;
+    const int64_t K = n_fft / 2 + 1;
+    if (K * F >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: K*F too large");
+    StftBwdParams p;
+    p.wav = wav, p.plan = static_cast<const float *>(plan), p.gmag = gmag, p.gre = gre, p.gim = gim, p.gwav = gwav;
+    p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    const Decomp *d = find_decomp(n_fft);
+    if (d) {
+        const int FT = 512 / d->R1;
+        const int64_t ntile = (F + FT - 1) / FT;
+        if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: too many tiles");
+        p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+        switch (n_fft) {
+            case 256: return launch_bwd<16, 8>(p, gmag, gre, s);
+            case 512: return launch_bwd<16, 16>(p, gmag, gre, s);
+            case 1024: return launch_bwd<32, 16>(p, gmag, gre, s);
+            case 2048: return launch_bwd<32, 32>(p, gmag, gre, s);
+        }
+    }
+    if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_bwd(generic): grid too large");
+    p.ntile = 0, p.total_tiles = 0;
+    const size_t lds = sizeof(float) * (size_t)(2 * n_fft + 2);
+    dim3 grid((unsigned)F, (unsigned)N);
+    if (gmag && !gre) hipLaunchKernelGGL((stft_bwd_generic_kernel<true, false>), grid, dim3(256), lds, s, p, n_fft);
+    else if (!gmag && gre) hipLaunchKernelGGL((stft_bwd_generic_kernel<false, true>), grid, dim3(256), lds, s, p, n_fft);
+    else hipLaunchKernelGGL((stft_bwd_generic_kernel<true, true>), grid, dim3(256), lds, s, p, n_fft);
+    PSND_CHECK_LAUNCH("stft_bwd(generic)");
+    return PSND_OK;
+}
