@@ -81,11 +81,6 @@ int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, in
                   const float *gmag, const float *gre, const float *gim,
                   float *gwav, void *stream);
 
-/* ---- inverse STFT: replaces STFT.inverse (transforms.py:71-101) ("next" row f1)
- *   mag, phase : (N,K,F); out : (N,(F-1)*hop) fp32; eps as the reference (1e-9). */
-int psnd_istft(const float *mag, const float *phase, int64_t N, int64_t F, int n_fft, int hop,
-               const void *plan, float eps, float *out, void *stream);
-
 /* ---- mel projection + log + clamp: replaces transforms.py:235-243, :364-365,
  *      interface/hifi_gan.py:58-61 -------------------------------------------------------- */
 #define PSND_LOG_NONE 0  /* linear mel                                   */
@@ -105,51 +100,6 @@ int psnd_mel_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const voi
 int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, int M, int K,
                  const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
                  float clamp_lo, float clamp_hi, float *gmag, void *stream);
-
-/* ---- fused wav -> log-mel (LogMelSpectrogram.forward, transforms.py:231-244; magnitude never
- *      leaves the chip).  Same arguments as stft_fwd + mel_fwd.  mel_lin optional. */
-int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
-                    const void *stft_plan, float mag_eps, int M, const void *mel_plan,
-                    int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
-                    float *out, float *mel_lin, void *stream);
-
-/* ---- GroupNorm(1,C) over (C x T) of (x + residual), per-channel affine: replaces
- *      modules.py:58, :114 (nn.GroupNorm(1, hidden)(x + input)) [+ optional ReLU :116].
- *   x, res : (N,C,T) fp32 (res may be NULL); y : (N,C,T); stats : (N,2) mean, rstd (saved). */
-int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta,
-                        int64_t N, int C, int64_t T, float eps, int relu,
-                        float *y, float *stats, void *stream);
-/*   gx (== gradient wrt x and wrt res), ggamma/gbeta: (C) fp32, ACCUMULATED INTO (caller zeroes) */
-int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma,
-                        const float *y, const float *stats, int64_t N, int C, int64_t T, int relu,
-                        float *gx, float *ggamma, float *gbeta, void *stream);
-
-/* ---- scaled-dot attention core of MultiHeadAttention.scale_dot_att (modules.py:62-79).
- *   k,v,q : (B,d,T) fp32, B = heads*N head-major (modules.py:38); mask : (B,T) uint8 (1 = padded)
- *           or NULL.  scores[b,tk,tq] = k[b,:,tk].q[b,:,tq]/sqrt(d); key-padded rows -> -inf;
- *           softmax over tk; query-padded columns -> 0; out[b,:,tq] = sum_tk v[b,:,tk] att[b,tk,tq].
- *   out : (B,d,T); att : (B,T,T) or NULL (materialised only on request);
- *   lse : (B,T) fp32 log-sum-exp per query column (saved for backward). */
-int psnd_attention_fwd(const float *k, const float *v, const float *q, const uint8_t *mask,
-                       int64_t B, int d, int64_t T, float *out, float *att, float *lse, void *stream);
-int psnd_attention_bwd(const float *gout, const float *k, const float *v, const float *q,
-                       const uint8_t *mask, const float *out, const float *lse,
-                       int64_t B, int d, int64_t T, float *gk, float *gv, float *gq, void *stream);
-
-/* ---- Conv1d / ConvTranspose1d stacks of models/vocoders/hifi_gan.py:32-147 -------------
- *   dtype: 0 = fp32, 1 = bf16 (storage; accumulation is always fp32).
- *   x : (N,Cin,L)  w : (Cout,Cin,k)  y : (N,Cout,Lout), Lout = L + 2*pad - dil*(k-1)  (stride 1)
- *   pre_slope  : leaky-relu slope applied to x on load (1.0 = none)   [hifi_gan.py:57,59,86]
- *   bias       : (Cout) or NULL;  residual : (N,Cout,Lout) added to y or NULL [hifi_gan.py:61,88] */
-int psnd_conv1d_fwd(const void *x, const void *w, const void *bias, const void *residual,
-                    int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
-                    float pre_slope, int dtype, void *y, void *stream);
-int psnd_conv1d_bwd_data(const void *gy, const void *w, const void *x,
-                         int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
-                         float pre_slope, int dtype, void *gx, void *stream);
-int psnd_conv1d_bwd_weight(const void *gy, const void *x,
-                           int64_t N, int Cin, int Cout, int64_t L, int k, int dil, int pad,
-                           float pre_slope, int dtype, float *gw, float *gbias, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,144 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm, over
+xGMI inside a node; "gloo" for the CPU tests).  The reference has no distributed code at all
+(SURVEY 2.2); the only collective this adds to the hot path is the gradient all-reduce.
+
+FlatGradReducer
+  * parameters are packed, in REVERSE registration order (the order backward produces gradients),
+    into a few large flat fp32 buckets; every ``p.grad`` is a view into its bucket, so there is no
+    gather/scatter copy around the collective;
+  * a post-accumulate-grad hook per parameter counts arrivals; the moment a bucket is complete its
+    all-reduce (SUM) is launched asynchronously - RCCL runs it on its own stream while backward
+    keeps producing the next bucket;
+  * ``finish()`` (called before clip_grad / optimizer.step) waits for the outstanding collectives
+    and scales by 1/world.
+Bucket size: gradients here are small (hifi_gan_v1 55.7 MB fp32, v2 3.7 MB): xGMI rings are
+per-link bound (~153 GB/s/link), so latency, not bandwidth, dominates -> few large buckets
+(default 32 MiB) rather than DDP's 25 MB chunks per layer group.
+"""
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def is_main() -> bool:
+    return rank() == 0
+
+
+def init_from_env(backend: str = None) -> bool:
+    """Initialise the default process group from torchrun's environment (RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT / LOCAL_RANK).  Returns True when running distributed."""
+    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return False
+    if dist.is_initialized():
+        return True
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
+    return True
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0):
+    """rank-`src` parameters and buffers to every rank (start of training / after load)."""
+    if not is_dist():
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+
+
+def all_reduce_scalar(value, op: str = 'sum', device=None) -> float:
+    if not is_dist():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64 if device is None or device.type == 'cpu' else torch.float32,
+                     device=device or 'cpu')
+    dist.all_reduce(t, op={'sum': dist.ReduceOp.SUM, 'max': dist.ReduceOp.MAX, 'min': dist.ReduceOp.MIN}[op])
+    return float(t.item())
+
+
+class FlatGradReducer:
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20):
+        self.world = world_size()
+        self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []            # dicts: flat, params, pending, work
+        self._bucket_of = {}
+        self._handles = []
+        order = list(reversed(self.params))
+        groups, cur, cur_bytes = [], [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.device != cur[0].device):
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            total = sum(p.numel() for p in g)
+            flat = torch.zeros(total, dtype=torch.float32, device=g[0].device)
+            off = 0
+            for p in g:
+                if p.dtype != torch.float32:
+                    raise TypeError('FlatGradReducer keeps fp32 master gradients; got %s' % p.dtype)
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            b = {'flat': flat, 'params': g, 'pending': len(g), 'work': None}
+            self.buckets.append(b)
+            for p in g:
+                self._bucket_of[p] = b
+        if self.world > 1:
+            for p in self.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # gradients must stay views of the flat buffers: zero in place instead of dropping them
+    def zero_grad(self):
+        for b in self.buckets:
+            b['flat'].zero_()
+            b['pending'] = len(b['params'])
+            b['work'] = None
+            off = 0
+            for p in b['params']:
+                if p.grad is None or p.grad.data_ptr() != b['flat'].data_ptr() + off * 4:
+                    p.grad = b['flat'][off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish(self):
+        """wait for every bucket, average.  Buckets whose hooks did not all fire (unused parameters)
+        are reduced here so that ranks never diverge."""
+        if self.world <= 1:
+            return
+        for b in self.buckets:
+            if b['work'] is None:
+                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+        for b in self.buckets:
+            b['work'].wait()
+            b['flat'].mul_(1.0 / self.world)
+            b['work'] = None
+            b['pending'] = len(b['params'])
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -1,0 +1,74 @@
+"""HiFi-GAN interface: mel front end in the vocoder's framing convention + generator wrapper
+(pytorch_sound/interface/hifi_gan.py)."""
+import os
+
+import torch
+
+from pytorch_sound_amd import kernels as K
+from pytorch_sound_amd.interface import Interface
+from pytorch_sound_amd.models import build_model
+from pytorch_sound_amd.models.transforms import _HifiGanMel
+from pytorch_sound_amd.models.vocoders import hifi_gan  # noqa: F401  (registers the archs)
+from pytorch_sound_amd.utils.mel import mel_filterbank
+
+
+class AudioParameters:
+    sampling_rate: int = 22050
+    n_fft: int = 1024
+    window_size: int = 1024
+    hop_size: int = 256
+    num_mels: int = 80
+    fmin: float = 0.
+    fmax: float = 8000.
+
+
+MODEL_NAMES = ('hifi_gan_v1', 'hifi_gan_v2', 'hifi_gan_v3')
+CHKPT_DIR = os.environ.get('PSND_VOCODER_DIR',
+                           os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'assets', 'vocoders'))
+CHECKPOINTS = {name: os.path.join(CHKPT_DIR, name + '.pt') for name in MODEL_NAMES}
+
+
+class MelSpectrogram(_HifiGanMel):
+    """interface/hifi_gan.py:29-63: reflect-pad (n_fft - hop)/2, torch.stft(center=is_center),
+    sqrt(re^2 + im^2 + 1e-9), mel matmul, ln(clamp(., 1e-5))."""
+
+    def __init__(self, sampling_rate: int = 22050, n_fft: int = 1024, window_size: int = 1024, hop_size: int = 256,
+                 num_mels: int = 80, fmin: float = 0., fmax: float = 8000.):
+        super().__init__()
+        self._setup(n_fft, hop_size, window_size, mel_filterbank(sampling_rate, n_fft, num_mels, fmin, fmax),
+                    'window', 'mel_filter')
+        self.hop_size = hop_size
+        self.window_size = window_size
+        self.pad_size = (n_fft - hop_size) // 2
+
+    def forward(self, wav: torch.Tensor, is_center: bool = False) -> torch.Tensor:
+        if is_center:
+            # the reference pads by pad_size and THEN lets torch.stft centre-pad n_fft/2 more
+            wav = torch.nn.functional.pad(wav.unsqueeze(1), [self.pad_size, self.pad_size], mode='reflect').squeeze(1)
+            return self._logmel(wav.contiguous(), K.FRAMING_CENTER, 1e-9, K.LOG_E)
+        return self._logmel(wav, K.FRAMING_HIFIGAN, 1e-9, K.LOG_E)
+
+
+class InterfaceHifiGAN(Interface):
+    """wave <-> mel with a HiFi-GAN generator (interface/hifi_gan.py:66-117)."""
+
+    def __init__(self, model_name: str = 'hifi_gan_v1', chk_path: str = '', device='cpu'):
+        assert model_name in MODEL_NAMES, \
+            'Model name {} is not valid! choose in {}'.format(model_name, str(list(MODEL_NAMES)))
+        self.encoder = MelSpectrogram(**{k: getattr(AudioParameters, k) for k in
+                                         ('sampling_rate', 'n_fft', 'window_size', 'hop_size', 'num_mels',
+                                          'fmin', 'fmax')}).to(device)
+        self.decoder = build_model(model_name).to(device)
+        chkpt = torch.load(chk_path if chk_path else CHECKPOINTS[model_name], map_location='cpu', weights_only=False)
+        self.decoder.load_state_dict(chkpt['generator'])
+        self.decoder.remove_weight_norm()
+
+    @torch.no_grad()
+    def encode(self, wav_tensor: torch.Tensor) -> torch.Tensor:
+        assert wav_tensor.ndim == 2, '2D tensor (N, T) is needed'
+        return self.encoder(wav_tensor)
+
+    @torch.no_grad()
+    def decode(self, mel_tensor: torch.Tensor) -> torch.Tensor:
+        assert mel_tensor.ndim == 3, '3D tensor (N, C, T) is needed'
+        return self.decoder(mel_tensor)

@@ -184,3 +184,19 @@ class MelLog(torch.autograd.Function):
 def db_to_ln(db):
     """np.log(np.power(10, db / 10)) of transforms.py:223,227"""
     return math.log(math.pow(10.0, db / 10.0))
+
+
+def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9):
+    """STFT.inverse (transforms.py:71-101) - "next" row f1; kernel psnd_istft."""
+    fn = getattr(lib(), 'psnd_istft', None)
+    if fn is None:
+        raise _lib.PsndError('psnd_istft is not built into libpsnd_hip.so yet')
+    _need_cuda(magnitude, 'magnitude')
+    _need_cuda(phase, 'phase')
+    magnitude, phase = magnitude.contiguous(), phase.contiguous()
+    N, Kb, F = magnitude.shape
+    out = torch.empty((N, (F - 1) * hop), dtype=torch.float32, device=magnitude.device)
+    with torch.cuda.device(magnitude.device):
+        check(fn(ptr(magnitude), ptr(phase), N, F, n_fft, hop, ptr(plan), float(eps), ptr(out),
+                 stream_ptr(magnitude.device)), 'psnd_istft')
+    return out

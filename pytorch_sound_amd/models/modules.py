@@ -1,0 +1,107 @@
+"""Transformer blocks on the (N, C, T) layout of pytorch_sound/models/modules.py.
+
+Semantics pinned by tests/golden/modules.npz (generated from the imported reference):
+  * the fused 1x1 projection yields chunks in the order K, V, Q (modules.py:34)
+  * heads are folded into the batch dimension head-major: (H*N, C/H, T) (modules.py:38,48)
+  * scores[b, t_key, t_query] = k^T q / sqrt(d); softmax runs over KEYS (dim 1) (modules.py:66-74)
+  * ``mask`` is (N, T) bool, True = padding: padded key rows get -inf before the softmax, padded
+    query columns are zeroed after it (modules.py:69-76); the attention tensor is returned
+  * the "layer norm" is nn.GroupNorm(1, C): statistics over (C x T) jointly per sample, per-channel
+    affine; it is applied to (x + input) (modules.py:30,58,98,114)
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class MultiHeadAttention(nn.Module):
+
+    def __init__(self, hidden_dim: int, heads: int, dropout_rate: float):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.heads = heads
+        self.linear_kvq = nn.Conv1d(hidden_dim, hidden_dim * 3, 1, bias=False)
+        self.linear = nn.Conv1d(hidden_dim, hidden_dim, 1, bias=False)
+        self.drop_out = nn.Dropout(dropout_rate) if 0 < dropout_rate < 1 else None
+        self.layernorm = nn.GroupNorm(1, hidden_dim)
+
+    def _fold_heads(self, x: torch.Tensor) -> torch.Tensor:
+        n, c, t = x.shape
+        # (N, H, d, T) -> (H, N, d, T) -> (H*N, d, T): head-major on the batch axis
+        return x.view(n, self.heads, c // self.heads, t).transpose(0, 1).reshape(self.heads * n, c // self.heads, t)
+
+    def _unfold_heads(self, x: torch.Tensor) -> torch.Tensor:
+        hn, d, t = x.shape
+        n = hn // self.heads
+        return x.view(self.heads, n, d, t).transpose(0, 1).reshape(n, self.heads * d, t)
+
+    def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        k, v, q = (self._fold_heads(p) for p in self.linear_kvq(input).chunk(3, 1))
+        if mask is not None:
+            mask = mask.repeat(self.heads, 1)
+        x, att = self.scale_dot_att(k, v, q, att_mask=mask)
+        x = self.linear(self._unfold_heads(x))
+        if self.drop_out is not None:
+            x = self.drop_out(x)
+        return self.layernorm(x + input), att
+
+    @staticmethod
+    def scale_dot_att(k: torch.Tensor, v: torch.Tensor, q: torch.Tensor,
+                      att_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """k, v, q: (B, d, T); att_mask: (B, T) bool or None -> (B, d, T), (B, T_key, T_query)."""
+        scores = torch.bmm(k.transpose(1, 2), q) / math.sqrt(k.size(1))
+        if att_mask is not None:
+            scores = scores.masked_fill(att_mask.unsqueeze(2), -float('inf'))     # padded keys
+        att = F.softmax(scores, 1)
+        if att_mask is not None:
+            att = att.masked_fill(att_mask.unsqueeze(1), 0.)                      # padded queries
+        return torch.bmm(v, att), att
+
+
+class PointwiseFeedForward(nn.Module):
+    """Conv1d(C,4C,1) -> ReLU -> Conv1d(4C,C,1) -> [dropout] -> GroupNorm(1,C)(x + input) -> ReLU
+    (modules.py:82-116)."""
+
+    def __init__(self, hidden_dim: int, dropout_rate: float):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.ff = nn.Sequential(
+            nn.Conv1d(hidden_dim, hidden_dim * 4, 1),
+            nn.ReLU(),
+            nn.Conv1d(hidden_dim * 4, hidden_dim, 1),
+        )
+        self.layernorm = nn.GroupNorm(1, hidden_dim)
+        self.act = nn.ReLU()
+        self.drop_out = nn.Dropout(dropout_rate) if 0 < dropout_rate < 1 else None
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        x = self.ff(input)
+        if self.drop_out is not None:
+            x = self.drop_out(x)
+        return self.act(self.layernorm(x + input))
+
+
+class PositionalEncoding(nn.Module):
+    """x * sqrt(C) + pe[..., :T], pe (1, C, max_len): angle = pos / 10000^(2*(c//2)/C), sin on even
+    channels, cos on odd ones (modules.py:119-145)."""
+
+    def __init__(self, dim: int, max_seq_len: int):
+        super().__init__()
+        self.dim = dim
+        self.register_buffer('pe', self.get_embedding(max_seq_len, dim).T.unsqueeze(0))
+
+    @staticmethod
+    def get_embedding(num_embeddings: int, embedding_dim: int) -> torch.Tensor:
+        chan = torch.arange(embedding_dim, dtype=torch.float32)
+        denom = (10000 ** (2 * (chan // 2) / embedding_dim)).unsqueeze(0)                 # (1, C)
+        pos = torch.arange(num_embeddings, dtype=torch.float32).unsqueeze(1).repeat(1, embedding_dim)
+        table = pos / denom
+        table[:, 0::2] = torch.sin(table[:, 0::2])
+        table[:, 1::2] = torch.cos(table[:, 1::2])
+        return table
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x * (self.dim ** 0.5) + self.pe[..., :x.size(-1)]

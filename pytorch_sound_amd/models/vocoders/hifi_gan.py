@@ -1,0 +1,189 @@
+"""HiFi-GAN generator: the Conv1d / ConvTranspose1d stack of pytorch_sound/models/vocoders/hifi_gan.py.
+
+Checkpoint layout is the reference's (every conv carries ``weight_g`` / ``weight_v`` [/ ``bias``], as
+the old-style ``weight_norm`` hook produces; shipped ``hifi_gan_v2.pt`` loads unchanged).  Semantics
+pinned by tests/golden/hifigan.npz:
+  * weight norm over dim 0: w = g * v / ||v||, norm per output channel for Conv1d and per INPUT channel
+    for ConvTranspose1d (its dim 0), recomputed every forward
+  * ResBlock1: 3 x [lrelu(0.1) -> dilated conv -> lrelu(0.1) -> conv -> + x]  (hifi_gan.py:55-63)
+  * ResBlock2: 2 x [lrelu(0.1) -> dilated conv -> + x]                         (hifi_gan.py:83-89)
+  * Generator: conv_pre(80 -> C, k7) ; per stage lrelu(0.1) -> ConvTranspose1d(k, stride u,
+    pad (k-u)//2) -> mean of the stage's resblocks ; then leaky_relu with the DEFAULT slope 0.01
+    (hifi_gan.py:134), conv_post(C -> 1, k7), tanh.
+"""
+from argparse import Namespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from pytorch_sound_amd.models import register_model, register_model_architecture
+
+LRELU_SLOPE = 0.1
+
+
+def get_padding(kernel_size: int, dilation: int = 1) -> int:
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+class _WNConvBase(nn.Module):
+    """Conv with an explicit weight-norm parametrisation (parameters ``weight_g``, ``weight_v``)."""
+
+    def _init_params(self, weight_shape, bias_features, std):
+        v = torch.empty(weight_shape)
+        if std is None:
+            # nn.Conv1d default init (kaiming_uniform(a=sqrt(5))) for layers the reference leaves alone
+            nn.init.kaiming_uniform_(v, a=5 ** 0.5)
+        else:
+            v.normal_(0.0, std)
+        self.weight_v = nn.Parameter(v)
+        self.weight_g = nn.Parameter(self._norm(v).detach().clone())
+        fan_in = weight_shape[1] * weight_shape[2]
+        bound = 1.0 / fan_in ** 0.5 if fan_in > 0 else 0.0
+        self.bias = nn.Parameter(torch.empty(bias_features).uniform_(-bound, bound))
+        self._folded = False
+
+    @staticmethod
+    def _norm(v):
+        return v.flatten(1).norm(dim=1).view(-1, 1, 1)
+
+    def effective_weight(self):
+        if self._folded:
+            return self.weight
+        return self.weight_v * (self.weight_g / self._norm(self.weight_v))
+
+    def remove_weight_norm(self):
+        """fold g * v/||v|| into a plain ``weight`` parameter (inference; hifi_gan.py:65-69)."""
+        if self._folded:
+            return
+        w = self.effective_weight().detach()
+        del self.weight_g
+        del self.weight_v
+        self.weight = nn.Parameter(w)
+        self._folded = True
+
+
+class WNConv1d(_WNConvBase):
+    def __init__(self, cin, cout, kernel_size, dilation=1, padding=0, init_std=None):
+        super().__init__()
+        self.dilation, self.padding = dilation, padding
+        self._init_params((cout, cin, kernel_size), cout, init_std)
+
+    def forward(self, x):
+        return F.conv1d(x, self.effective_weight(), self.bias, 1, self.padding, self.dilation)
+
+
+class WNConvTranspose1d(_WNConvBase):
+    def __init__(self, cin, cout, kernel_size, stride, padding, init_std=None):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self._init_params((cin, cout, kernel_size), cout, init_std)
+        # nn.ConvTranspose1d computes its bias bound from weight.size(1) * k = cout * k
+        bound = 1.0 / (cout * kernel_size) ** 0.5
+        with torch.no_grad():
+            self.bias.uniform_(-bound, bound)
+
+    def forward(self, x):
+        return F.conv_transpose1d(x, self.effective_weight(), self.bias, self.stride, self.padding)
+
+
+class ResBlock1(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3, 5)):
+        super().__init__()
+        self.h = h
+        self.convs1 = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, d, get_padding(kernel_size, d), init_std=0.01) for d in dilation])
+        self.convs2 = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, 1, get_padding(kernel_size, 1), init_std=0.01) for _ in dilation])
+
+    def forward(self, x):
+        for c1, c2 in zip(self.convs1, self.convs2):
+            xt = c1(F.leaky_relu(x, LRELU_SLOPE))
+            xt = c2(F.leaky_relu(xt, LRELU_SLOPE))
+            x = xt + x
+        return x
+
+    def remove_weight_norm(self):
+        for c in list(self.convs1) + list(self.convs2):
+            c.remove_weight_norm()
+
+
+class ResBlock2(nn.Module):
+    def __init__(self, h, channels, kernel_size=3, dilation=(1, 3)):
+        super().__init__()
+        self.h = h
+        self.convs = nn.ModuleList([
+            WNConv1d(channels, channels, kernel_size, d, get_padding(kernel_size, d), init_std=0.01) for d in dilation])
+
+    def forward(self, x):
+        for c in self.convs:
+            x = c(F.leaky_relu(x, LRELU_SLOPE)) + x
+        return x
+
+    def remove_weight_norm(self):
+        for c in self.convs:
+            c.remove_weight_norm()
+
+
+@register_model('hifi_gan')
+class Generator(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.h = h
+        self.num_kernels = len(h.resblock_kernel_sizes)
+        self.num_upsamples = len(h.upsample_rates)
+        c0 = h.upsample_initial_channel
+        self.conv_pre = WNConv1d(80, c0, 7, 1, 3)
+        block_cls = ResBlock1 if h.resblock == '1' else ResBlock2
+        self.ups = nn.ModuleList([
+            WNConvTranspose1d(c0 // (2 ** i), c0 // (2 ** (i + 1)), k, u, (k - u) // 2, init_std=0.01)
+            for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes))])
+        self.resblocks = nn.ModuleList()
+        ch = c0
+        for i in range(len(self.ups)):
+            ch = c0 // (2 ** (i + 1))
+            for k, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
+                self.resblocks.append(block_cls(h, ch, k, d))
+        self.conv_post = WNConv1d(ch, 1, 7, 1, 3, init_std=0.01)
+
+    def forward(self, x):
+        x = self.conv_pre(x)
+        for i, up in enumerate(self.ups):
+            x = up(F.leaky_relu(x, LRELU_SLOPE))
+            stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            xs = stage[0](x)
+            for block in stage[1:]:
+                xs = xs + block(x)
+            x = xs / self.num_kernels
+        x = F.leaky_relu(x)            # default slope 0.01, as the reference
+        return torch.tanh(self.conv_post(x))
+
+    def remove_weight_norm(self):
+        for up in self.ups:
+            up.remove_weight_norm()
+        for block in self.resblocks:
+            block.remove_weight_norm()
+        self.conv_pre.remove_weight_norm()
+        self.conv_post.remove_weight_norm()
+
+
+@register_model_architecture('hifi_gan', 'hifi_gan_v1')
+def hifi_gan_v1():
+    return {'h': Namespace(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4],
+                           upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+                           resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])}
+
+
+@register_model_architecture('hifi_gan', 'hifi_gan_v2')
+def hifi_gan_v2():
+    return {'h': Namespace(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4],
+                           upsample_initial_channel=128, resblock_kernel_sizes=[3, 7, 11],
+                           resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                           resblock_initial_channel=64)}
+
+
+@register_model_architecture('hifi_gan', 'hifi_gan_v3')
+def hifi_gan_v3():
+    return {'h': Namespace(resblock='2', upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8],
+                           upsample_initial_channel=256, resblock_kernel_sizes=[3, 5, 7],
+                           resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]])}

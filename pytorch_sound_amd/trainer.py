@@ -1,0 +1,354 @@
+"""Training loop with the public surface of pytorch_sound/trainer.py (drop-in surface #2).
+
+Same constructor signature, same overridable ``forward(*inputs, is_logging=False) -> (loss, meta)``,
+same checkpoint layout ({save_dir}/models/{save_prefix}/{ModelClass}/step_{step:06d}.chkpt with keys
+step / model / optim / pretrained_step / seed [/ scheduler], plus {ModelClass}.best.chkpt), same log
+lines.  What is new sits behind that surface:
+
+* data parallelism: when a torch.distributed process group exists (one process per GPU, RCCL over
+  xGMI), gradients are all-reduced through ``FlatGradReducer`` overlapped with backward, rank 0 alone
+  logs and saves, the validation loss is averaged over ranks and the NaN-skip decision is made
+  collectively (every rank skips or none does - otherwise the ranks would deadlock in the all-reduce);
+* the H2D copy of the batch stays ``to_device`` (lazy ``.cuda(non_blocking=True)``); on a machine
+  without a GPU the batch is passed through unchanged so the loop is testable on CPU.
+"""
+import abc
+import enum
+import glob
+import os
+from collections import defaultdict
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from pytorch_sound_amd import distributed as pdist
+from pytorch_sound_amd.settings import SAMPLE_RATE
+from pytorch_sound_amd.utils.commons import get_loadable_checkpoint, log
+from pytorch_sound_amd.utils.tensor import to_device, to_numpy
+
+
+class LogType(enum.Enum):
+    SCALAR: int = 1
+    IMAGE: int = 2
+    ENG: int = 3
+    AUDIO: int = 4
+    PLOT: int = 5
+    TEXT: int = 6
+
+
+class _MemoryWriter:
+    """Stand-in used when neither tensorboardX nor torch.utils.tensorboard is importable (and on
+    non-zero ranks): keeps scalars in memory so behaviour stays observable."""
+
+    def __init__(self, log_dir=None, flush_secs=10):
+        self.log_dir = log_dir
+        self.scalars = []
+
+    def add_scalar(self, tag, value, global_step=None):
+        self.scalars.append((tag, float(value), global_step))
+
+    def add_image(self, *args, **kwargs):
+        pass
+
+    add_audio = add_text = add_image
+
+
+def _make_writer(log_dir: str, active: bool):
+    if active:
+        try:
+            from tensorboardX import SummaryWriter
+            return SummaryWriter(log_dir=log_dir, flush_secs=10)
+        except ImportError:
+            pass
+    return _MemoryWriter(log_dir=log_dir)
+
+
+def _to_buf(kind: str, value):
+    """matplotlib rendering for IMAGE / PLOT metas (utils/plots.py of the reference) - cosmetic,
+    only on logging steps; skipped silently when matplotlib is unavailable."""
+    try:
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return None
+    fig = plt.figure(figsize=(8, 4))
+    if kind == 'image':
+        plt.imshow(value, aspect='auto', origin='lower')
+        plt.colorbar()
+    else:
+        plt.plot(value)
+    fig.canvas.draw()
+    buf = np.asarray(fig.canvas.buffer_rgba())[..., :3].transpose(2, 0, 1).copy()
+    plt.close(fig)
+    return buf
+
+
+class Trainer:
+
+    def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer,
+                 train_dataset, valid_dataset,
+                 max_step: int, valid_max_step: int, save_interval: int, log_interval: int,
+                 save_dir: str, save_prefix: str = 'save',
+                 grad_clip: float = 0.0, grad_norm: float = 0.0,
+                 pretrained_path: str = None, sr: int = None, scheduler=None,
+                 seed: int = None):
+        self.pretrained_path = pretrained_path
+        self.model = model
+        self.optimizer = optimizer
+        self.scheduler = scheduler
+
+        n_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+        self._log('Model {} was loaded. Total {} params.'.format(self.model.__class__.__name__, n_params))
+
+        self.train_dataset = self.repeat(train_dataset)
+        self.valid_dataset = self.repeat(valid_dataset)
+
+        self.step = 0
+        self.sr = sr if sr else SAMPLE_RATE
+        self.max_step = max_step
+        self.save_interval = save_interval
+        self.log_interval = log_interval
+        self.save_dir = save_dir
+        self.save_prefix = save_prefix
+        self.grad_clip = grad_clip
+        self.grad_norm = grad_norm
+        self.valid_max_step = valid_max_step
+
+        self.log_dir = os.path.join(save_dir, 'logs', self.save_prefix)
+        self.model_dir = os.path.join(save_dir, 'models')
+        os.makedirs(self.model_dir, exist_ok=True)
+        os.makedirs(self.log_dir, exist_ok=True)
+        self.writer = _make_writer(self.log_dir, pdist.is_main())
+
+        self.seed = None
+        self.load()                                   # restores step / weights (and a seed, see below)
+        # as in the reference (trainer.py:124-130) the constructor argument wins over a restored seed
+        self.seed = seed
+        if not self.seed:
+            self.seed = np.random.randint(np.iinfo(np.int32).max)
+            if pdist.is_dist():                        # every rank must initialise identically
+                self.seed = int(pdist.all_reduce_scalar(self.seed if pdist.is_main() else 0, 'sum'))
+        np.random.seed(self.seed)
+        torch.manual_seed(self.seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(self.seed)
+
+        if self.step == 0 and pretrained_path:
+            self.load_pretrained_model()
+
+        self.best_valid_loss = np.finfo(np.float32).max
+        self.cur_best_valid_loss = self.best_valid_loss
+        self.save_valid_loss = np.finfo(np.float32).max
+
+        # data parallel: identical start on every rank, overlapped gradient all-reduce
+        self._reducer = None
+        if pdist.is_dist():
+            pdist.broadcast_module(self._bare_model)
+            self._reducer = pdist.FlatGradReducer(self._bare_model)
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def _bare_model(self) -> nn.Module:
+        m = self.model
+        return m.module if isinstance(m, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else m
+
+    @staticmethod
+    def _log(msg: str):
+        if pdist.is_main():
+            log(msg)
+
+    @abc.abstractmethod
+    def forward(self, *inputs, is_logging: bool = False) -> Tuple[torch.Tensor, Dict]:
+        """override: returns (loss tensor, {name: (value, LogType)})"""
+        raise NotImplementedError
+
+    def _next_batch(self, iterator):
+        batch = next(iterator)
+        if torch.cuda.is_available():
+            return to_device(batch)
+        return batch if isinstance(batch, (tuple, list)) else (batch,)
+
+    # ------------------------------------------------------------------------------------------
+    def run(self) -> float:
+        try:
+            for i in range(self.step + 1, self.max_step + 1):
+                self.step = i
+                if i % self.save_interval == 1:
+                    self._log('------------- TRAIN step : %d -------------' % i)
+                self.model.train()
+                self.train(i)
+                if i % self.save_interval == 0:
+                    self._log('------------- VALID step : %d -------------' % i)
+                    self.model.eval()
+                    self.validate(i)
+                    self.save(i)
+        except KeyboardInterrupt:
+            self._log('Train is canceled !!')
+        return self.best_valid_loss
+
+    def clip_grad(self):
+        if self.grad_clip:
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    p.grad = p.grad.clamp(-self.grad_clip, self.grad_clip)
+        if self.grad_norm:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.grad_norm)
+
+    def _loss_is_nan(self, loss: torch.Tensor) -> bool:
+        bad = bool(loss != loss)                       # host sync, as in the reference (trainer.py:205)
+        if self._reducer is not None:
+            bad = pdist.all_reduce_scalar(1.0 if bad else 0.0, 'max', loss.device if loss.is_cuda else None) > 0
+        return bad
+
+    def train(self, step: int):
+        if self._reducer is not None:
+            self._reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad()
+        log_flag = step % self.log_interval == 0
+
+        loss, meta = self.forward(*self._next_batch(self.train_dataset), is_logging=log_flag)
+
+        if self._loss_is_nan(loss):
+            self._log('{} cur step NAN is occured'.format(step))
+            return
+
+        loss.backward()
+        if self._reducer is not None:
+            self._reducer.finish()
+        self.clip_grad()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+        if log_flag and pdist.is_main():
+            self.console_log('train', meta, step)
+            try:
+                self.tensorboard_log('train', meta, step)
+            except OverflowError:
+                pass
+
+    def validate(self, step: int):
+        loss = 0.
+        stat = defaultdict(float)
+        for i in range(self.valid_max_step):
+            with torch.no_grad():
+                batch_loss, meta = self.forward(*self._next_batch(self.valid_dataset), is_logging=True)
+                loss += batch_loss
+            for key, (value, log_type) in meta.items():
+                if log_type == LogType.SCALAR:
+                    stat[key] += value
+            if (i % self.log_interval == 0 or i == self.valid_max_step - 1) and pdist.is_main():
+                self.console_log('valid', meta, i + 1)
+
+        loss /= self.valid_max_step
+        for key in stat.keys():
+            if key == 'loss':
+                continue
+            stat[key] = stat[key] / self.valid_max_step
+        if pdist.is_dist():                            # mean over ranks
+            w = pdist.world_size()
+            dev = loss.device if isinstance(loss, torch.Tensor) and loss.is_cuda else None
+            loss = pdist.all_reduce_scalar(float(loss), 'sum', dev) / w
+            for key in sorted(stat.keys()):
+                if key != 'loss':
+                    stat[key] = pdist.all_reduce_scalar(float(stat[key]), 'sum', dev) / w
+        stat['loss'] = loss
+
+        if loss < self.best_valid_loss:
+            self.best_valid_loss = loss
+
+        msg = 'step {} / total stat'.format(step)
+        for key, value in sorted(stat.items()):
+            msg += '\t{}: {:.6f}'.format(key, value)
+        self._log(msg)
+        for key, value in stat.items():
+            self.writer.add_scalar('valid/{}'.format(key), value, global_step=step)
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def save_name(self) -> str:
+        return self.save_prefix + '/' + self._bare_model.__class__.__name__
+
+    def load(self, load_optim: bool = True):
+        save_path = os.path.join(self.model_dir, self.save_name)
+        check_files = glob.glob(os.path.join(save_path, '*'))
+        if not check_files:
+            self._log('No any checkpoint in {}. Loading network skipped.'.format(save_path))
+            return
+        latest_file = max(check_files, key=os.path.getctime)
+        state_dict = torch.load(latest_file, map_location='cpu', weights_only=False)
+        if 'seed' in state_dict:
+            self.seed = state_dict['seed']
+        self._bare_model.load_state_dict(get_loadable_checkpoint(state_dict['model']))
+        if load_optim:
+            self.optimizer.load_state_dict(state_dict['optim'])
+        if self.scheduler is not None:
+            self.scheduler.load_state_dict(state_dict['scheduler'])
+        self.step = state_dict['step']
+        self._log('checkpoint \'{}\' is loaded. previous step={}'.format(latest_file, self.step))
+
+    def save(self, step: int):
+        if not pdist.is_main():
+            self.cur_best_valid_loss = self.best_valid_loss
+            return
+        state_dict = {
+            'step': step,
+            'model': get_loadable_checkpoint(self.model.state_dict()),
+            'optim': self.optimizer.state_dict(),
+            'pretrained_step': step,
+            'seed': self.seed,
+        }
+        if self.scheduler is not None:
+            state_dict['scheduler'] = self.scheduler.state_dict()
+
+        save_path = os.path.join(self.model_dir, self.save_name)
+        os.makedirs(save_path, exist_ok=True)
+        torch.save(state_dict, os.path.join(save_path, 'step_{:06d}.chkpt'.format(step)))
+
+        if self.best_valid_loss != self.cur_best_valid_loss:
+            torch.save(state_dict, os.path.join(self.model_dir, self.save_name + '.best.chkpt'))
+            self.cur_best_valid_loss = self.best_valid_loss
+        self._log('step %d / saved model.' % step)
+
+    def load_pretrained_model(self):
+        assert os.path.exists(self.pretrained_path), 'You must define pretrained path!'
+        ckpt = torch.load(self.pretrained_path, map_location='cpu', weights_only=False)
+        self._bare_model.load_state_dict(get_loadable_checkpoint(ckpt['model']))
+
+    # ------------------------------------------------------------------------------------------
+    def console_log(self, tag: str, meta: Dict[str, Any], step: int):
+        msg = '{}\t{:06d} it'.format(tag, step)
+        for key, (value, log_type) in sorted(meta.items()):
+            if log_type == LogType.SCALAR:
+                msg += '\t{}: {:.6f}'.format(key, value)
+        log(msg)
+
+    def tensorboard_log(self, tag: str, meta: Dict[str, Any], step: int):
+        for key, (value, log_type) in meta.items():
+            if log_type != LogType.SCALAR and type(value) == torch.Tensor:
+                value = to_numpy(value)
+            name = '{}/{}'.format(tag, key)
+            if log_type == LogType.IMAGE:
+                buf = _to_buf('image', value)
+                if buf is not None:
+                    self.writer.add_image(name, buf, global_step=step)
+            elif log_type == LogType.AUDIO:
+                self.writer.add_audio(name, value, global_step=step, sample_rate=self.sr)
+            elif log_type == LogType.SCALAR:
+                self.writer.add_scalar(name, value, global_step=step)
+            elif log_type == LogType.PLOT:
+                buf = _to_buf('plot', value)
+                if buf is not None:
+                    self.writer.add_image(name, buf, global_step=step)
+            elif log_type == LogType.TEXT:
+                self.writer.add_text(name, value, global_step=step)
+
+    @staticmethod
+    def repeat(iterable):
+        while True:
+            for x in iterable:
+                yield x

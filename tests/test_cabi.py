@@ -1,0 +1,93 @@
+"""libpsnd_hip.so: loads without a GPU, exports every symbol include/psnd.h declares, host-side
+entry points (integer framing contract, plan builders, argument validation) behave."""
+import ctypes
+import os
+import re
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import features as ofe
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'psnd.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(psnd_[a-z0-9_]+)\s*\(', txt)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    from pytorch_sound_amd import _build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _build.build(verbose=False)
+    return _lib
+
+
+def test_exports_every_declared_symbol(L):
+    h = ctypes.CDLL(L.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(h, n), 'include/psnd.h declares %s but the library does not export it' % n
+    assert sorted(L.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert L.lib().psnd_version() >= 100
+
+
+def test_frame_contract_matches_oracle(L):
+    lib = L.lib()
+    for T, n, h in [(44100, 1024, 256), (8192, 1024, 256), (1323000, 4096, 1024), (700, 256, 64), (2049, 1024, 255),
+                    (513, 1024, 256), (100, 1024, 256)]:
+        for framing in (0, 1):
+            F = ofe.frame_count(T, n, h, framing)
+            assert lib.psnd_frame_count(T, n, h, framing) == F
+            if T <= ofe.pad_amount(n, h, framing):
+                continue
+            for f in sorted({0, 1, 2, F // 2, max(F - 2, 0), max(F - 1, 0)}):
+                ms = np.array([0, 1, n // 2 - 1, n // 2, n - 1])
+                want = ofe.frame_sample_index(f, ms, T, n, h, framing)
+                got = [lib.psnd_frame_sample_index(f, int(m), T, n, h, framing) for m in ms]
+                assert list(want) == got
+
+
+def test_plans_build_on_host(L):
+    for n in (64, 256, 512, 1024, 2048, 4096):
+        w = ofe.analysis_window(n)
+        plan = L.build_stft_plan(n, w)
+        assert plan.nbytes == L.lib().psnd_stft_plan_bytes(n) > 0
+        tail = plan.view(np.float32)[-n:]
+        assert np.array_equal(tail, w)                               # raw window closes every plan
+    assert L.lib().psnd_stft_plan_bytes(1000) == 0                   # not a power of two
+    W = ofe.mel_filterbank(22050, 1024, 80, 0, 8000)
+    mp = L.build_mel_plan(W).view(np.int32)
+    assert list(mp[:6]) == [80, 513, 5, 129, 33, 20]
+    bands = mp[8:8 + 10].reshape(5, 2)
+    nz = [np.nonzero(W[16 * t:16 * t + 16].sum(0))[0] for t in range(5)]
+    for t in range(5):
+        assert bands[t, 0] == nz[t].min() // 4 and bands[t, 1] == nz[t].max() // 4 + 1
+    assert (bands[:, 1] - bands[:, 0]).sum() < 0.25 * 5 * 129        # band sparsity is real
+
+
+def test_argument_validation_without_gpu(L):
+    lib = L.lib()
+    assert lib.psnd_stft_fwd(None, 1, 100, 1024, 256, 0, None, 0.0, None, None, None, None, None) == -1
+    assert b'null' in lib.psnd_last_error()
+    buf = (ctypes.c_float * 4)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.psnd_stft_fwd(p, 1, 100, 1024, 256, 0, p, 0.0, p, None, None, None, None) == -2     # T <= pad
+    assert lib.psnd_stft_fwd(p, 1, 5000, 1000, 256, 0, p, 0.0, p, None, None, None, None) == -4    # n_fft unsupported
+    assert lib.psnd_stft_fwd(p, 1, 5000, 1024, 256, 7, p, 0.0, p, None, None, None, None) == -1    # framing enum
+    assert lib.psnd_mel_fwd(None, 1, 1, 80, 513, None, 1, 0.0, -1.0, 0.0, 0.0, None, None, None) == -1
+    assert lib.psnd_stft_bwd(p, 1, 5000, 1024, 256, 0, p, 0.0, None, None, None, p, None) == -1    # no gradient source
+
+
+def test_product_has_no_fallback(L, monkeypatch):
+    """a CPU tensor or a missing library must raise, never compute on the host."""
+    import torch
+    from pytorch_sound_amd import kernels
+    with pytest.raises(L.PsndError):
+        kernels.stft_forward(torch.zeros(1, 4096), 1024, 256, torch.zeros(8, dtype=torch.uint8))
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/libpsnd_hip.so')
+    with pytest.raises(L.PsndError):
+        L.lib()

