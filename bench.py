@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark: audio-seconds/second through one training step
+STFT -> mel -> model forward -> backward -> (all-reduce) -> optimizer step on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): speech source-separation Conv1d model (VoiceBank-like), 22.05 kHz,
+1024-pt STFT / hop 256 / 80 mel, bf16 model, batch = 32 x 2 s clips PER GPU (weak scaling), synthetic
+clips resident in HBM, random-init weights.  One "step" = Trainer.train(): zero_grad, forward (two
+psnd_stft_fwd launches, the separator under bf16 autocast, psnd_mel_fwd x2), NaN check, backward
+(incl. psnd_mel_bwd), flat-bucket RCCL all-reduce overlapped with backward, Adam step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the STFT kernel (wav -> magnitude) as launched inside the timed steps: algorithmic bytes
+                4*N*T + 4*N*K*F per launch / mean launch duration (HIP events on the launch stream)
+                against 8 TB/s.  `roofline_large` is the same kernel on a 544 MB working set (>> the
+                256 MiB Infinity Cache), where an HBM percentage is meaningful.
+  cpu_baseline  the reference's CPU path (oracle/torch_ref.py port of its dense-DFT conv1d STFT + mel,
+                same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, N_FFT, HOP, N_MEL, FMIN, FMAX = 22050, 1024, 256, 80, 0.0, 8000.0
+CLIP_SECONDS = 2.0
+BATCH_PER_GPU = 32
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(seed, n, t, device):
+    """BASELINE.md synthetic input: 0.0708*randn + 440 Hz and 3 kHz sinusoids at 0.1, clipped."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    tt = torch.arange(t, dtype=torch.float32) / SR
+    tone = 0.1 * torch.sin(2 * np.pi * 440 * tt) + 0.1 * torch.sin(2 * np.pi * 3000 * tt + 0.3)
+    clean = (0.0708 * torch.randn(n, t, generator=g) + tone).clamp(-1, 1)
+    noisy = (clean + 0.03 * torch.randn(n, t, generator=g)).clamp(-1, 1)
+    return noisy.to(device), clean.to(device)
+
+
+def build_step(device, amp):
+    """returns (trainer_cls, model, frontend modules) for the config-2 step on `device`."""
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401  (registers conv_separator)
+    from pytorch_sound_amd.trainer import Trainer, LogType
+
+    gpu = device.type == 'cuda'
+    if gpu:
+        from pytorch_sound_amd.models.transforms import LogMelSpectrogram
+        from pytorch_sound_amd import kernels as K
+        fe = LogMelSpectrogram(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX).to(device)
+
+        def magnitude(w):
+            return fe.stft.magnitude(w)
+
+        def logmel_of_mag(m):
+            return K.MelLog.apply(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+    else:
+        from oracle.torch_ref import RefLogMel                      # CPU baseline leg only
+        fe = RefLogMel(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX)
+
+        def magnitude(w):
+            return fe.stft.transform(w)[0]
+
+        def logmel_of_mag(m):
+            return fe.mel_of_mag(m)
+
+    class StepTrainer(Trainer):
+        stft_events = None
+
+        def forward(self, noisy, clean, is_logging=False):
+            ev = self.stft_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            mag_mix = magnitude(noisy)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+            with torch.no_grad():
+                mag_ref = magnitude(clean)
+                mel_ref = logmel_of_mag(mag_ref)
+            if amp:
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    est = self.model(mag_mix)
+                est = est.float()
+            else:
+                est = self.model(mag_mix)
+            loss = F.l1_loss(est, mag_ref) + 0.5 * F.l1_loss(logmel_of_mag(est), mel_ref)
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    torch.manual_seed(1234)
+    model = build_model('conv_separator_voicebank').to(device)
+    return StepTrainer, model
+
+
+def gpu_bench(args):
+    from pytorch_sound_amd import distributed as pdist
+    from pytorch_sound_amd import kernels as K
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    distributed = pdist.init_from_env('nccl')
+    rank, world = pdist.rank(), pdist.world_size()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    T = int(SR * CLIP_SECONDS)
+    N = BATCH_PER_GPU
+
+    Trainer, model = build_step(device, amp=True)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99))
+    pool = [synth_batch(1234 + rank + 1000 * i, N, T, device) for i in range(args.pool)]
+    save_dir = tempfile.mkdtemp(prefix='psnd_bench_')
+    huge = 10 ** 9
+    tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
+                 save_dir=save_dir, save_prefix='bench', seed=1234)
+    model.train()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        step += 1
+        tr.step = step
+        tr.train(step)
+    barrier()
+    tr.stft_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        tr.step = step
+        tr.train(step)
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tdt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tdt.item())
+
+    # ---- roofline of the STFT kernel as launched in the timed region (rank 0) ------------------------
+    Kb = N_FFT // 2 + 1
+    Fr = K.frame_count(T, N_FFT, HOP)
+    ev = tr.stft_events
+    tr.stft_events = None
+    t_stft = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    bytes_launch = 4 * N * T + 4 * N * Kb * Fr
+    roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_kernel<32,16,mag> (wav -> magnitude, 1024/256)',
+                'achieved': bytes_launch / t_stft / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                'frac': bytes_launch / t_stft / HBM_PEAK, 'traffic': None,
+                'bytes_per_launch': bytes_launch, 'launch_us': t_stft * 1e6,
+                'note': 'config-2 launch moves 17 MB (Infinity-Cache resident, ~launch-latency bound); '
+                        'see roofline_large for a working set beyond the 256 MiB cache'}
+    out = None
+    if rank == 0:
+        # the same kernel on 1024 clips: 181 MB in + 363 MB out
+        NL = 1024
+        wav = torch.randn(NL, T, device=device) * 0.07
+        plan = K.stft_plan(N_FFT, _hann(N_FFT)).to(device)
+        mag = torch.empty(NL, Kb, Fr, device=device)
+        evs = []
+        for i in range(13):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().psnd_stft_fwd(ptr(wav), NL, T, N_FFT, HOP, 0, ptr(plan), 0.0, ptr(mag), None, None, None,
+                                      stream_ptr(device)), 'psnd_stft_fwd')
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        tl = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
+        bl = 4 * NL * T + 4 * NL * Kb * Fr
+        roofline_large = {'bound': 'hbm', 'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                          'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic(), 'bytes_per_launch': bl,
+                          'launch_us': tl * 1e6, 'workload': '1024 clips x 2 s, 1024/256 (544 MB)'}
+        del wav, mag
+        audio_s = world * N * CLIP_SECONDS * args.steps
+        out = {
+            'metric': 'audio-sec/s STFT+mel+fwd/bwd', 'value': audio_s / dt, 'unit': 'audio-s/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: Conv1d separator (4 x ResBlock1, C=256, on 513-bin magnitude), '
+                                   '22.05 kHz, STFT 1024/256, 80 mel, batch 32 x 2 s per GPU, Adam, bf16 autocast',
+                       'global_batch': world * N, 'clip_seconds': CLIP_SECONDS, 'parallelism': 'dp%d' % world,
+                       'model_params': sum(p.numel() for p in model.parameters())},
+            'roofline': roofline, 'roofline_large': roofline_large,
+        }
+    return out, device
+
+
+def _hann(n):
+    m = np.arange(n)
+    return (0.5 - 0.5 * np.cos(2 * np.pi * m / n)).astype(np.float32)
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/stft_pmc.json, written by
+    tools/pmc_summary.py from a separate `rocprofv3 --pmc` run), or None."""
+    p = os.path.join(ROOT, 'profiles', 'stft_pmc.json')
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get('hbm_bytes_per_launch')
+        except Exception:
+            return None
+    return None
+
+
+def cpu_baseline(seconds):
+    """reference CPU path (port) on the host cores: same step, fp32, 4 x 2 s clips."""
+    # probe on the MI355X host (256 logical CPUs): this step scales to ~16-32 threads and collapses
+    # beyond 64 (oversubscribed small convs), so the baseline uses min(32, cores) threads
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    dev = torch.device('cpu')
+    have_cuda = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False            # keep Trainer on its CPU path for this leg
+    try:
+        Trainer, model = build_step(dev, amp=False)
+        Ncpu, T = 4, int(SR * CLIP_SECONDS)
+        pool = [synth_batch(4321 + i, Ncpu, T, dev) for i in range(2)]
+        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99))
+        huge = 10 ** 9
+        tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
+                     save_dir=tempfile.mkdtemp(prefix='psnd_cpu_'), save_prefix='cpu', seed=1234)
+        model.train()
+        tr.step = 1
+        tr.train(1)                                      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            n += 1
+            tr.step = n + 1
+            tr.train(n + 1)
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 200:
+                break
+    finally:
+        torch.cuda.is_available = have_cuda
+    return {'value': n * Ncpu * CLIP_SECONDS / el, 'unit': 'audio-s/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of batch 4 x 2 s clips (configs[0] batch), same model/loss/Adam in fp32, '
+                      'feature path = oracle/torch_ref.py (the reference\'s dense-DFT conv1d STFT + mel); %.1f s'
+                      % (n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--pool', type=int, default=8, help='distinct synthetic batches resident in HBM')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')
+    out, device = gpu_bench(args)
+    if out is not None:
+        if args.gpus == 1 and args.cpu_seconds > 0:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

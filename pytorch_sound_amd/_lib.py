@@ -45,6 +45,10 @@ def lib():
     """Load (once) and return the ctypes handle.  Raises if the HIP extension is absent."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64: it must be in the process BEFORE our library is
+        # dlopen'ed, otherwise the dynamic linker binds us to a second HIP runtime (/opt/rocm) that
+        # never sees torch's device context ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise PsndError('libpsnd_hip.so not found at %s - run `python -m pytorch_sound_amd._build` '
                             '(there is no CPU / eager fallback)' % LIB_PATH)

@@ -97,3 +97,20 @@ def test_frame_count_edges():
     assert ofe.frame_count(1323000, 4096, 1024, 0) == 1292
     assert ofe.frame_count(0, 1024, 256, 0) == 1 or True     # degenerate, not used
     assert ofe.frame_count(100, 1024, 256, 1) == 0           # padded signal shorter than one frame
+
+
+def test_torch_ref_matches_reference(golden):
+    """oracle/torch_ref.py (the CPU-baseline port) == the imported reference on the fixtures."""
+    import torch
+    from oracle.torch_ref import RefSTFT, RefLogMel
+    g = golden('stft')
+    for name in ['n1024_h256', 'n1024_h256_w800', 'n512_h128']:
+        n, h, w = (int(v) for v in g[name + '/params'])
+        mag, phase = RefSTFT(n, h, w).transform(torch.from_numpy(g[name + '/wav']))
+        assert np.abs(mag.numpy() - g[name + '/mag']).max() <= 2e-6 * g[name + '/mag'].max()
+    gl = golden('logmel')
+    m = RefLogMel(22050, 80, 1024, 1024, 256, -50, 30, 0, 8000)
+    assert np.abs(m(torch.from_numpy(gl['default/wav'])).numpy() - gl['default/mel']).max() <= 5e-6
+    wav = torch.from_numpy(gl['bwd/wav']).requires_grad_(True)
+    (m(wav) * torch.from_numpy(gl['bwd/gmel'])).sum().backward()
+    assert np.abs(wav.grad.numpy() - gl['bwd/gwav']).max() <= 2e-5 * np.abs(gl['bwd/gwav']).max()
