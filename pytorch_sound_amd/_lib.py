@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpsnd_hip.so')
+LIB_PATH = os.environ.get('PSND_LIB', os.path.join(_HERE, 'libpsnd_hip.so'))   # PSND_LIB: A/B builds of the same ABI
 
 PSND_OK = 0
 FRAMING_CENTER = 0

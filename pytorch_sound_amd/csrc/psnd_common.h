@@ -157,3 +157,13 @@ __device__ __forceinline__ int reflect_idx32(int i, int T) {
     i = i < 0 ? 0 : i;
     return i >= T ? T - 1 : i;
 }
+
+// wave-uniform buffer resource descriptor.  The inputs ARE uniform (kernel arguments, tile index);
+// readfirstlane makes that provable, otherwise hipcc wraps every buffer op in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_uniform_rsrc(const void *p, int bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}

@@ -22,7 +22,12 @@
 #include "psnd_stft_pass.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
+
+#ifndef PSND_STORE_AUX
+#define PSND_STORE_AUX 0   // cache-policy bits of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 
 namespace {
 using namespace psnd_stft;
@@ -34,23 +39,111 @@ struct StftFwdParams {
     long long T, F;
     int hop, pad, ntile, total_tiles;
     float mag_eps;
+    int ablate;   // debug only (PSND_ABLATE): bit1 skip global stores
 };
 
+// Output writer.  Buffer stores: the resource descriptor (clip base + first frame of the tile) and the
+// row offset (soff = bin * F * 4, wave-uniform) live in SGPRs, the per-thread part (voff) is ONE
+// 32-bit VGPR - no 64-bit address arithmetic or per-row address registers.
 template <bool MAG, bool PHASE, bool REIM>
 struct Emit {
-    float *mag, *phase, *re, *im;
+    __amdgpu_buffer_rsrc_t rmag, rphase, rre, rim;
     float eps;
     bool valid;
-    __device__ __forceinline__ void operator()(int off, float xr, float xi) const {
-        if (!valid) return;
-        if constexpr (MAG) mag[off] = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, eps)));
-        if constexpr (PHASE) phase[off] = atan2f(xi, xr);
+    __device__ __forceinline__ Emit(float *mag, float *phase, float *re, float *im, size_t base, int bytes, float eps_,
+                                    bool valid_)
+        : eps(eps_), valid(valid_) {
+        if constexpr (MAG) rmag = make_uniform_rsrc(mag + base, bytes);
+        if constexpr (PHASE) rphase = make_uniform_rsrc(phase + base, bytes);
         if constexpr (REIM) {
-            re[off] = xr;
-            im[off] = xi;
+            rre = make_uniform_rsrc(re + base, bytes);
+            rim = make_uniform_rsrc(im + base, bytes);
+        }
+    }
+    // callers run the whole post-processing under ONE `if (emit.valid)` (frames past F in a last tile)
+    __device__ __forceinline__ void operator()(int voff, int soff, float xr, float xi) const {
+        if constexpr (MAG) {
+            const float m = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, eps)));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), rmag, voff, soff, PSND_STORE_AUX);
+        }
+        if constexpr (PHASE)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, atan2f(xi, xr)), rphase, voff, soff, PSND_STORE_AUX);
+        if constexpr (REIM) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xr), rre, voff, soff, PSND_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xi), rim, voff, soff, PSND_STORE_AUX);
         }
     }
 };
+
+// real-FFT split of the two butterflies a thread holds + output: Z'[q + R1 p] sits in slot bitrev(p).
+// Every pair yields one bin in the lower half of the spectrum and its mirror in the upper half.  The
+// lower bins are stored at once, the upper ones are parked and stored afterwards in ASCENDING order, so
+// a workgroup writes the (N,K,F) output as one upward sweep over the rows (measured on MI355X: the
+// two-converging-sweeps order streams ~25 % slower into HBM).
+template <int R1, int L, class EmitT>
+__device__ __forceinline__ void post_emit(float (&ar)[L], float (&ai)[L], float (&br)[L], float (&bi)[L], bool special,
+                                          int qA, int qB, const float *s_vk, const EmitT &emit, int iF, int col) {
+    constexpr int LB = ct::ilog2(L);
+    const int stepF = R1 * iF * 4;                 // bytes between bins q and q + R1 (wave-uniform)
+    const int offA = qA * iF * 4 + col, offB = qB * iF * 4 + col;   // per-thread byte offsets
+    float xkr, xki;
+    float h1r[L / 2], h1i[L / 2], h2r[L / 2], h2i[L / 2];
+    if (!special) {
+        // qA < qB: ascending rows are  qA + R1 p,  qB + R1 p  for p = 0 .. L-1
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+            {   // primary A[pp]: k = qA + R1*pp (< C/2), partner B[L-1-pp] -> bin qB + R1 (L-1-pp)
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qA + R1 * pp));
+                rfft_pair(ar[sa], ai[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, h1r[pp], h1i[pp]);
+                emit(offA, pp * stepF, xkr, xki);
+            }
+            {   // primary B[pp]: k = qB + R1*pp (< C/2), partner A[L-1-pp] -> bin qA + R1 (L-1-pp)
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qB + R1 * pp));
+                rfft_pair(br[sa], bi[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, h2r[pp], h2i[pp]);
+                emit(offB, pp * stepF, xkr, xki);
+            }
+        });
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = L / 2 - 1 - decltype(pc)::value;          // upper half, ascending
+            emit(offA, (L - 1 - pp) * stepF, h2r[pp], h2i[pp]);
+            emit(offB, (L - 1 - pp) * stepF, h1r[pp], h1i[pp]);
+        });
+    } else {
+        // butterfly q = 0: bins R1*p pair with C - R1*p = R1*(L-p); p = 0 gives X[0] and X[C]
+        // butterfly q = R1/2: bins R1/2 + R1*p pair with R1/2 + R1*(L-1-p)
+        float hcr, hci;
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            {
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * pp));
+                if constexpr (pp == 0) rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, hcr, hci);
+                else rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, h1r[pp], h1i[pp]);
+                emit(col, pp * stepF, xkr, xki);
+            }
+            {
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 / 2 + R1 * pp));
+                rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, h2r[pp], h2i[pp]);
+                emit(offB, pp * stepF, xkr, xki);
+            }
+        });
+        {   // middle bin C/2 (self-paired)
+            constexpr int sm = ct::bitrev(L / 2, LB);
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * (L / 2)));
+            float ur, ui;
+            rfft_pair(ar[sm], ai[sm], ar[sm], ai[sm], v.x, v.y, xkr, xki, ur, ui);
+            emit(col, (L / 2) * stepF, xkr, xki);
+        }
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = L / 2 - 1 - decltype(pc)::value;
+            emit(offB, (L - 1 - pp) * stepF, h2r[pp], h2i[pp]);                 // bin R1/2 + R1 (L-1-pp)
+            if constexpr (pp != 0) emit(col, (L - pp) * stepF, h1r[pp], h1i[pp]);   // bin R1 (L-pp)
+        });
+        emit(col, L * stepF, hcr, hci);                                         // bin C (Nyquist)
+    }
+}
 
 template <int R1, int L, bool MAG, bool PHASE, bool REIM>
 __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
@@ -89,54 +182,202 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
             fwd_pass2_fft<R1, L>(s, f2, qA, qB, ar, ai, br, bi);
 
             const long long F = p.F;
-            const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
-            Emit<MAG, PHASE, REIM> emit{MAG ? p.mag + cbase : nullptr, PHASE ? p.phase + cbase : nullptr,
-                                        REIM ? p.re + cbase : nullptr, REIM ? p.im + cbase : nullptr,
-                                        p.mag_eps, (f0 + f2) < F};
-            const int iF = (int)F;
-            const int stepF = R1 * iF;
-            const int offA = qA * iF, offB = qB * iF;
-            const float *s_vk = s.vk;
-            float xkr, xki, xcr, xci;
-            if (!special) {
-                static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-                    constexpr int pp = decltype(pc)::value;
-                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
-                    {   // primary A[pp]: k = qA + R1*pp (< C/2), partner B[L-1-pp]
-                        const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qA + R1 * pp));
-                        rfft_pair(ar[sa], ai[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
-                        emit(offA + pp * stepF, xkr, xki);
-                        emit(offB + (L - 1 - pp) * stepF, xcr, xci);
-                    }
-                    {   // primary B[pp]: k = qB + R1*pp (< C/2), partner A[L-1-pp]
-                        const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qB + R1 * pp));
-                        rfft_pair(br[sa], bi[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                        emit(offB + pp * stepF, xkr, xki);
-                        emit(offA + (L - 1 - pp) * stepF, xcr, xci);
-                    }
-                });
-            } else {
-                // butterfly q = 0: bins R1*p pair with C - R1*p = R1*(L-p); p = 0 gives X[0] and X[C]
-                static_for<0, L / 2 + 1>([&](auto pc) __attribute__((always_inline)) {
-                    constexpr int pp = decltype(pc)::value;
-                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
-                    const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * pp));
-                    rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                    emit(pp * stepF, xkr, xki);
-                    if constexpr (2 * pp != L) emit((L - pp) * stepF, xcr, xci);
-                });
-                // butterfly q = R1/2: bins R1/2 + R1*p pair with R1/2 + R1*(L-1-p)
-                static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-                    constexpr int pp = decltype(pc)::value;
-                    constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
-                    const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 / 2 + R1 * pp));
-                    rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
-                    emit(offB + pp * stepF, xkr, xki);
-                    emit(offB + (L - 1 - pp) * stepF, xcr, xci);
-                });
-            }
+            // descriptor base = (clip, bin 0, frame f0): wave-uniform; per-thread part = frame column f2
+            const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
+            const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
+            Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, (f0 + f2) < F);
+            if (emit.valid) post_emit<R1, L>(ar, ai, br, bi, special, qA, qB, s.vk, emit, (int)F, f2 * 4);
         }
         __syncthreads();  // exchange buffer is reused by the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// n_fft = 1024 kernel (C = 32 x 16), restructured around the VECTOR-MEMORY pipeline, which is what
+// bounded the first version (rocprof: ~300 L1 accesses per frame - every sample fetched by 4
+// overlapping frames with 8-byte loads - while VALU sat at 24 %):
+//   * the tile's contiguous waveform span ((FT-1)*hop + n samples, 19 KB) is fetched ONCE with
+//     16-byte loads and parked in LDS (reflect indexing is resolved in this fill, so there is no
+//     per-frame edge path); pass-1 lanes take their taps with ds_read_b64.  The span is laid out
+//     with 32 pad floats per 256 so that the 2 frames of a ds_read_b64 half-wave hit disjoint banks;
+//   * the 32 q-rows of the exchange travel in two halves (rows 0..15, then 16..31): every pass-2
+//     thread (pair qq) needs one row of each half (qq and 32-qq); the span buffer aliases the
+//     exchange area -> 44 KB LDS per workgroup, 3 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+template <bool MAG, bool PHASE, bool REIM, int SPV>
+__global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p) {
+    constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5;
+    constexpr int HR = R1 / 2;          // rows per exchange half
+    constexpr int SFH = HR * L + 4;     // frame stride of a half (260; 260/4 odd -> b128 conflict-free)
+    constexpr int TAB = 2 * L * ROW + VKP;
+    constexpr int SPV_MAX = SPV;        // 16-byte span pieces per thread (5 covers hop <= 256)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_wt = smem;
+    float *s_tw = s_wt + L * ROW;
+    float *s_vk = s_tw + L * ROW;
+    float *s_xr = s_vk + VKP;           // exchange (re plane), also the span buffer
+    float *s_xi = s_xr + FT * SFH;
+    float *s_span = s_xr;
+    const int t = threadIdx.x;
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.plan);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        for (int i = t; i < TAB / 4; i += 256) dst[i] = src[i];
+    }
+
+    const int fl = t >> 4, l = t & 15;                 // pass-1 identity
+    const int f2 = t & 15;                             // pass-2 identity
+    const int qq = (t >> 6) + 4 * ((t >> 4) & 3);
+    const bool special = (qq == 0);
+    const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
+    const int rowA = qq, rowB = special ? 0 : HR - qq; // row inside its half
+    const int hop = p.hop;
+    const int span_len = (FT - 1) * hop + NFFT;        // samples a tile touches
+    // span position of sample s: s + skew * (s / 256); skew = 32 floats when frames start on 256-sample
+    // boundaries (the two frames of a ds_read_b64 half-wave then hit disjoint banks), else 0
+    const int skew = (hop % 256 == 0) ? 32 : 0;
+
+    // The span of tile t+1 is REQUESTED (into SPV registers) before the stores of tile t are issued:
+    // gfx9 has one in-order vmcnt for loads and stores, so a wait for loads issued AFTER the stores
+    // would also wait for the stores; this way the stores drain under the next tile's pass 1.
+    f32x4 spv[SPV];
+    auto request_span = [&](int tile_) __attribute__((always_inline)) {
+        const int clip_ = tile_ / p.ntile;
+        const float *x_ = p.wav + (size_t)clip_ * p.T;
+        const long long g0 = (long long)(tile_ - clip_ * p.ntile) * FT * hop - p.pad;   // sample index of span[0]
+        const int Ti = (int)p.T;
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 256 * j) * 4;
+            if (s4 < span_len) {
+                const long long g = g0 + s4;
+                if (g >= 0 && g + 3 < p.T) {
+                    spv[j] = *reinterpret_cast<const f32x4_u *>(x_ + g);
+                } else {
+                    const int gi = (int)g;
+                    spv[j].x = x_[reflect_idx32(gi, Ti)];
+                    spv[j].y = x_[reflect_idx32(gi + 1, Ti)];
+                    spv[j].z = x_[reflect_idx32(gi + 2, Ti)];
+                    spv[j].w = x_[reflect_idx32(gi + 3, Ti)];
+                }
+            }
+        });
+    };
+
+    auto commit_span = [&]() __attribute__((always_inline)) {
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 256 * j) * 4;
+            if (s4 < span_len) *reinterpret_cast<f32x4 *>(s_span + s4 + skew * (s4 >> 8)) = spv[j];
+        });
+    };
+
+    // Schedule per tile (every wait on the span loads happens BEFORE this tile's stores are issued, so
+    // the stores - single in-order vmcnt on gfx9 - are never on a wave's critical path):
+    //   [span(t) is in LDS] barrier | taps, window, radix-32 | barrier | rows 0..15 -> LDS | barrier | read row A
+    //   request span(t+1) -> registers | barrier | rows 16..31 -> LDS, radix-16 A | barrier | read row B
+    //   barrier | commit span(t+1) -> LDS (aliases the exchange area) | radix-16 B, real split, STORES
+    // strided XCD-contiguous walk: neighbouring tiles run at the SAME time on neighbouring CUs of one XCD.
+    // (a contiguous run per workgroup - neighbours written ~10 us apart by one CU - measured 45 % slower:
+    // L2 keeps partially written lines only briefly; PSND_ABLATE=8 selects it for A/B runs)
+    const TileWalk tw = p.ablate & 8 ? tile_run(p.total_tiles) : tile_walk(p.total_tiles);
+    if (tw.first < tw.end) {
+        request_span(tw.first);
+        __syncthreads();                 // tables staged
+        commit_span();
+    }
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+        const int clip = tile / p.ntile;
+        const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+        const bool more = tile + tw.step < tw.end;
+        float zr[R1], zi[R1];
+
+        __syncthreads();                 // span(t) visible to every wave
+        {   // taps of lane l of frame fl: samples fl*hop + 2*(l + 16 a) + {0,1}.  Affine addressing: one base
+            // per group of 8 taps (the bank skew steps once per 256 samples), immediates inside the group.
+            const int sb = fl * hop + 2 * l;
+            const float *tb0 = s_span + sb + skew * (sb >> 8);
+            static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                const float *tb = tb0 + g * (256 + skew);
+                static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = 8 * g + decltype(ac)::value;
+                    const f32x2 v = *reinterpret_cast<const f32x2 *>(tb + 2 * L * (a - 8 * g));
+                    zr[a] = v.x;
+                    zi[a] = v.y;
+                });
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float *wrow = s_wt + l * ROW;
+            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+                zr[2 * i] *= w.x;
+                zi[2 * i] *= w.y;
+                zr[2 * i + 1] *= w.z;
+                zi[2 * i + 1] *= w.w;
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft_inreg<R1>(zr, zi);
+        __builtin_amdgcn_sched_barrier(0);
+
+        const float *trow = s_tw + l * ROW;
+        float *oxr = s_xr + fl * SFH + l, *oxi = s_xi + fl * SFH + l;
+        auto write_half = [&](auto hc) __attribute__((always_inline)) {
+            constexpr int Q0 = decltype(hc)::value;
+            static_for<0, HR / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int q0 = Q0 + 2 * i, q1 = q0 + 1;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
+                constexpr int s0_ = ct::bitrev(q0, RB), s1_ = ct::bitrev(q1, RB);
+                if constexpr (q0 == 0) {
+                    oxr[0] = zr[s0_];
+                    oxi[0] = zi[s0_];
+                } else {
+                    oxr[(q0 - Q0) * L] = __builtin_fmaf(zr[s0_], w.x, -zi[s0_] * w.y);
+                    oxi[(q0 - Q0) * L] = __builtin_fmaf(zr[s0_], w.y, zi[s0_] * w.x);
+                }
+                oxr[(q1 - Q0) * L] = __builtin_fmaf(zr[s1_], w.z, -zi[s1_] * w.w);
+                oxi[(q1 - Q0) * L] = __builtin_fmaf(zr[s1_], w.w, zi[s1_] * w.z);
+            });
+        };
+        auto read_row = [&](int row, float (&rr)[L], float (&ri)[L]) __attribute__((always_inline)) {
+            const float *pr = s_xr + f2 * SFH + row * L, *pi = s_xi + f2 * SFH + row * L;
+            static_for<0, L / 4>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pi + 4 * i);
+                rr[4 * i] = v0.x, rr[4 * i + 1] = v0.y, rr[4 * i + 2] = v0.z, rr[4 * i + 3] = v0.w;
+                ri[4 * i] = v1.x, ri[4 * i + 1] = v1.y, ri[4 * i + 2] = v1.z, ri[4 * i + 3] = v1.w;
+            });
+        };
+
+        float ar[L], ai[L], br[L], bi[L];
+        __syncthreads();                 // every lane holds its taps: the span area becomes the exchange
+        write_half(std::integral_constant<int, 0>{});
+        __syncthreads();
+        read_row(rowA, ar, ai);
+        if (more) request_span(tile + tw.step);
+        __syncthreads();                 // first-half rows consumed: the buffer may take rows 16..31
+        write_half(std::integral_constant<int, HR>{});
+        __builtin_amdgcn_sched_barrier(0);
+        fft_inreg<L>(ar, ai);
+        __syncthreads();
+        read_row(rowB, br, bi);
+        __syncthreads();                 // exchange fully consumed: it becomes the span buffer of tile t+1
+        if (more) commit_span();
+        __builtin_amdgcn_sched_barrier(0);
+        fft_inreg<L>(br, bi);
+        __builtin_amdgcn_sched_barrier(0);
+
+        const long long F = p.F;
+        const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
+        const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
+        Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
+        if (emit.valid) post_emit<R1, L>(ar, ai, br, bi, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
     }
 }
 
@@ -181,8 +422,7 @@ __global__ __launch_bounds__(256) void stft_fwd_generic_kernel(StftFwdParams p, 
         __syncthreads();
     }
     const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)p.F + (size_t)f;
-    Emit<MAG, PHASE, REIM> emit{MAG ? p.mag + cbase : nullptr, PHASE ? p.phase + cbase : nullptr,
-                                REIM ? p.re + cbase : nullptr, REIM ? p.im + cbase : nullptr, p.mag_eps, true};
+    Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, (int)(((long long)(C + 1) * p.F - f) * 4), p.mag_eps, true);
     for (int k = t; k <= C / 2; k += 256) {
         const int kc = (C - k) % C;
         float sn, cs;
@@ -190,8 +430,8 @@ __global__ __launch_bounds__(256) void stft_fwd_generic_kernel(StftFwdParams p, 
         // v_k = -i W_n^k = sn - i cs ; inputs here are unscaled -> halve
         float xkr, xki, xcr, xci;
         rfft_pair(0.5f * sr[k], 0.5f * si[k], 0.5f * sr[kc], 0.5f * si[kc], sn, -cs, xkr, xki, xcr, xci);
-        emit((int)((long long)k * p.F), xkr, xki);
-        if (k != C - k) emit((int)((long long)(C - k) * p.F), xcr, xci);
+        emit((int)((long long)k * p.F * 4), 0, xkr, xki);
+        if (k != C - k) emit((int)((long long)(C - k) * p.F * 4), 0, xcr, xci);
     }
 }
 
@@ -219,6 +459,31 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
     else PSND_LAUNCH(true, true, true);
 #undef PSND_LAUNCH
     PSND_CHECK_LAUNCH("stft_fwd");
+    return PSND_OK;
+}
+
+int launch_n1024(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * (2 * 16 * 68 + 516 + 2 * 16 * 260);
+    int grid = p.total_tiles;
+    int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
+                             // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
+    if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
+    if (grid > cap) grid = cap;
+    grid = (grid + 7) & ~7;
+#define PSND_LAUNCH(M_, P_, R_)                                                                                   \
+    do {                                                                                                          \
+        if (15 * p.hop + 1024 <= 5 * 1024)                                                                        \
+            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5>), dim3(grid), dim3(256), lds, stream, p);    \
+        else                                                                                                      \
+            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8>), dim3(grid), dim3(256), lds, stream, p);    \
+    } while (0)
+    if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
+    else if (mag && phase && !reim) PSND_LAUNCH(true, true, false);
+    else if (!mag && !phase && reim) PSND_LAUNCH(false, false, true);
+    else if (mag && !phase && reim) PSND_LAUNCH(true, false, true);
+    else PSND_LAUNCH(true, true, true);
+#undef PSND_LAUNCH
+    PSND_CHECK_LAUNCH("stft_fwd(n1024)");
     return PSND_OK;
 }
 
@@ -263,6 +528,12 @@ extern "C" int psnd_stft_plan_build(int n_fft, const float *window_host, void *p
         pl[lay.vk + 2 * k + 1] = (float)(-cos(th));
     }
     memcpy(pl + lay.win, window_host, sizeof(float) * n_fft);
+    for (int i = 0; i < R1 / 2; ++i)
+        for (int l = 0; l < L; ++l)
+            for (int c = 0; c < 4; ++c) {
+                const int a = 2 * i + (c >> 1);
+                pl[lay.wtg + (i * L + l) * 4 + c] = 0.5f * window_host[2 * (l + L * a) + (c & 1)];
+            }
     return PSND_OK;
 }
 
@@ -287,6 +558,10 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     p.wav = wav, p.plan = static_cast<const float *>(plan);
     p.mag = mag, p.phase = phase, p.re = re, p.im = im;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    {
+        const char *ab = getenv("PSND_ABLATE");
+        p.ablate = ab ? atoi(ab) : 0;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Decomp *d = find_decomp(n_fft);
     if (d) {
@@ -297,7 +572,14 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         switch (n_fft) {
             case 256: return launch_tuned<16, 8>(p, mag, phase, re, s);
             case 512: return launch_tuned<16, 16>(p, mag, phase, re, s);
-            case 1024: return launch_tuned<32, 16>(p, mag, phase, re, s);
+            case 1024: {
+                // span-staged kernel: hop multiple of 4 and the tile's span (+ bank padding) must fit the
+                // exchange area; anything else takes the generic two-pass kernel
+                const long long span = 15ll * hop + 1024;
+                const bool span_ok = (hop % 4 == 0) && (span + 32 * (span / 256 + 1) <= 2 * 16 * 260) && span <= 8 * 1024;
+                if (!span_ok || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
+                return launch_n1024(p, mag, phase, re, s);
+            }
             case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
         }
     }

@@ -49,6 +49,16 @@ __device__ __forceinline__ void load_tables(const float *plan, float *smem, int 
 struct TileWalk {
     int first, end, step;
 };
+// contiguous run of tiles per workgroup: consecutive frame tiles of a clip share the 128-B output lines
+// at their common edge; written a few microseconds apart by the SAME CU they are merged in L2 before
+// eviction (non-temporal / write-through stores, which defeat that merging, measured 35-60 % slower).
+__device__ __forceinline__ TileWalk tile_run(int total_tiles) {
+    TileWalk w;
+    w.first = (int)((long long)blockIdx.x * total_tiles / gridDim.x);
+    w.end = (int)((long long)(blockIdx.x + 1) * total_tiles / gridDim.x);
+    w.step = 1;
+    return w;
+}
 __device__ __forceinline__ TileWalk tile_walk(int total_tiles) {
     const int nb = gridDim.x, xcd = blockIdx.x & 7, bx = blockIdx.x >> 3;
     const int nbx = (nb - xcd + 7) >> 3;
@@ -74,15 +84,15 @@ __device__ __forceinline__ void pass2_identity(int t, int &f2, int &qq) {
     }
 }
 
-// ---- forward pass 1 for one task (frame fl of the tile, lane l): load, window, radix-R1, twiddle,
-//      write Y[q][l] to the exchange buffer.
+// ---- forward pass 1, split in two: load_frame (global -> registers) and pass1_compute.
+//
+// load_frame: raw (un-windowed) samples of lane l of frame f0+fl into registers.  Interior frames:
+// R1 8-byte loads at compile-time offsets.  Clip-edge frames (rare): per-sample reflect indexing.
 template <int R1, int L>
-__device__ __forceinline__ void fwd_pass1(const Smem &s, const float *x, long long T, long long F, long long f0,
-                                          int hop, int pad, int fl, int l) {
-    using G = Cfg<R1, L>;
-    constexpr int C = G::C, NFFT = G::NFFT, ROW = G::ROW, SF = G::SF, RB = G::RB;
+__device__ __forceinline__ void load_frame(const float *x, long long T, long long F, long long f0, int hop, int pad,
+                                           int fl, int l, float (&zr)[R1], float (&zi)[R1]) {
+    constexpr int NFFT = Cfg<R1, L>::NFFT;
     const long long f = f0 + fl;
-    float zr[R1], zi[R1];
     if (f < F) {
         const long long s0 = f * hop - pad;
         if (s0 >= 0 && s0 + NFFT <= T) {
@@ -94,26 +104,12 @@ __device__ __forceinline__ void fwd_pass1(const Smem &s, const float *x, long lo
                 zi[a] = v.y;
             });
         } else {
-            // clip edge: reflect-gather the frame into its own (still unused) exchange slot with a
-            // small runtime loop, then pick it up with compile-time offsets.  The L lanes of a frame
-            // sit in one wave, whose LDS operations execute in order.
-            float *gr = s.xr + fl * SF, *gi = s.xi + fl * SF;
-            const int Ti = (int)T, s0i = (int)s0;
-#pragma unroll 2
-            for (int m = l; m < C; m += L) {
-                gr[m] = x[reflect_idx32(s0i + 2 * m, Ti)];
-                gi[m] = x[reflect_idx32(s0i + 2 * m + 1, Ti)];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int Ti = (int)T, b0 = (int)s0 + 2 * l;
             static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                 constexpr int a = decltype(ac)::value;
-                zr[a] = gr[l + L * a];
-                zi[a] = gi[l + L * a];
+                zr[a] = x[reflect_idx32(b0 + 2 * L * a, Ti)];
+                zi[a] = x[reflect_idx32(b0 + 2 * L * a + 1, Ti)];
             });
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     } else {
         static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
@@ -121,6 +117,13 @@ __device__ __forceinline__ void fwd_pass1(const Smem &s, const float *x, long lo
             zi[decltype(ac)::value] = 0.f;
         });
     }
+}
+
+// pass1_compute: window (LDS table), radix-R1 FFT in VGPRs, inter-pass twiddle, write Y[q][l].
+template <int R1, int L>
+__device__ __forceinline__ void pass1_compute(const Smem &s, int fl, int l, float (&zr)[R1], float (&zi)[R1]) {
+    using G = Cfg<R1, L>;
+    constexpr int ROW = G::ROW, SF = G::SF, RB = G::RB;
     const float *wrow = s.wt + l * ROW;
     static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
@@ -148,6 +151,14 @@ __device__ __forceinline__ void fwd_pass1(const Smem &s, const float *x, long lo
         oxr[(2 * i + 1) * L] = __builtin_fmaf(zr[s1_], w.z, -zi[s1_] * w.w);
         oxi[(2 * i + 1) * L] = __builtin_fmaf(zr[s1_], w.w, zi[s1_] * w.z);
     });
+}
+
+template <int R1, int L>
+__device__ __forceinline__ void fwd_pass1(const Smem &s, const float *x, long long T, long long F, long long f0,
+                                          int hop, int pad, int fl, int l) {
+    float zr[R1], zi[R1];
+    load_frame<R1, L>(x, T, F, f0, hop, pad, fl, l, zr, zi);
+    pass1_compute<R1, L>(s, fl, l, zr, zi);
 }
 
 // ---- forward pass 2, first half: read rows qA / qB of frame f2 and run the two radix-L FFTs.

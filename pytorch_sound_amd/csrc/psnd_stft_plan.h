@@ -10,6 +10,8 @@ namespace psnd_stft {
 //   [L*ROW, 2 L*ROW)      tw[l][2q+{0,1}] = (cos, -sin)(2 pi l q / C)
 //   [2 L*ROW, +VKP)       vk[k] = (-sin, -cos)(2 pi k / n), k = 0..C/2      VKP = round4(2(C/2+1))
 //   [.., +n)              win[n] raw analysis window
+//   [.., +n)              wtg[i][l][4] = 0.5*win at taps 2(l+L*2i), +1, 2(l+L*(2i+1)), +1  (window for
+//                         kernels that read it from global/L1 with one coalesced 16-B piece per lane)
 // Sizes without a tuned decomposition use plan = win[n] only.
 // ---------------------------------------------------------------------------------------------
 struct Decomp {
@@ -27,7 +29,7 @@ inline bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 inline bool generic_ok(int n_fft) { return is_pow2(n_fft) && n_fft >= 16 && n_fft <= 8192; }
 
 struct PlanLayout {
-    int row, tab, vk, vkp, win, total;  // offsets in floats
+    int row, tab, vk, vkp, win, wtg, total;  // offsets in floats
 };
 inline PlanLayout plan_layout(int n_fft, int R1, int L) {
     PlanLayout p;
@@ -37,7 +39,8 @@ inline PlanLayout plan_layout(int n_fft, int R1, int L) {
     p.vk = 2 * p.tab;
     p.vkp = round4(2 * (C / 2 + 1));
     p.win = p.vk + p.vkp;
-    p.total = p.win + n_fft;
+    p.wtg = p.win + n_fft;
+    p.total = p.wtg + n_fft;
     return p;
 }
 
