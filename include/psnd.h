@@ -101,6 +101,36 @@ int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, 
                  const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
                  float clamp_lo, float clamp_hi, float *gmag, void *stream);
 
+/* ---- Conv1d stacks of models/vocoders/hifi_gan.py:32-147 on channels-last bf16 ("CL") matrices -------------
+ *  CL buffer: (N, Lp, Cp) bf16, row r = clip*Lp + l; rows l in [HP, HP+L) hold the clip, every other row is
+ *  zero (they are the conv zero padding), channels [C, Cp) are zero padding up to a multiple of 32.
+ *  psnd_conv1d_cl:  Y[r][co] = sum_j sum_ci A_eff[r + off0 + j*dstep][ci] * W[j][co][ci]   (stride 1)
+ *      forward       : W = pack [j][co][ci] of the weight, off0 = -pad, dstep = +dil
+ *      backward-data : A = gY,  W = pack [j][ci][co],       off0 = +pad, dstep = -dil
+ *    A_eff = A + A2 * (AM > 0 ? 1 : a2_slope): the gradient of a conv output that was handed out both raw (A)
+ *            and through leaky_relu (A2, with AM the activated output) is combined while it is staged.
+ *    epilogue: v = acc (+ bias[co]); v *= (mask_src > 0 ? 1 : mask_slope) when mask_src; v += res when res;
+ *              rows outside the clip -> 0; out_raw = v, out_act = leaky_relu(v, act_slope) (either may be NULL).
+ *    replaces F.leaky_relu + Conv1d + bias (+ residual add)  (hifi_gan.py:56-62, 84-88) and their backward.
+ *  psnd_conv1d_cl_wgrad: gw[j][co][ci] = sum_r g[r][co] * xa[r + off0 + j*dstep][ci] (fp32, [k][Cb][Ca]),
+ *              gbias[co] = sum_r g[r][co] (may be NULL), g_out = g materialised (may be NULL); g = G1 + G2*leaky'(GM).
+ *  psnd_conv1d_prep: weight norm w = g*v/||v|| (norm over dim 0, as torch weight_norm) -> bf16 packs
+ *              wf [k][Cb][Ca] and wb [k][Ca][Cb], zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: its backward
+ *              from gw to (g_v, g_g).
+ *  psnd_to_cl / psnd_from_cl: (N,C,T) fp32 <-> CL bf16 (preop 1 = log1p on the way in). */
+int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
+                   const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
+                   int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act, void *stream);
+int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
+                         int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw, float *gbias, void *g_out,
+                         void *stream);
+int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout, int Cin, int k, int Cb, int Ca,
+                     void *wf, void *wb, float *bias_padded, void *stream);
+int psnd_conv1d_wnorm_bwd(const float *gw, const float *v, const float *g, int Cout, int Cin, int k, int Cb, int Ca,
+                          float *gv, float *gg, void *stream);
+int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);
+int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+"""Channels-last ("CL") execution of the Conv1d stacks on the gfx950 implicit-GEMM kernel
+(csrc/psnd_conv.hip, psnd_conv1d_cl).
+
+A CL activation is a bf16 tensor (N, Lp, Cp): rows HP..HP+L of every clip hold the data, the other rows
+are zero (they ARE the conv zero padding), channels are zero-padded to a multiple of 32.  Module
+parameters stay exactly the reference's (weight_g / weight_v / bias per conv); this file only changes how
+``leaky_relu -> conv -> bias -> (+ residual)`` of hifi_gan.py:56-62 / 84-88 is executed:
+
+    fused_conv(xa, conv, res, want_raw, want_act):   y = conv(xa) + bias (+ res);  ya = leaky_relu(y)
+
+entirely on hand-written kernels: weight prep (weight norm + bf16 packs), implicit-GEMM conv (forward and input
+gradient), split-K weight gradient with all taps / bias gradient fused, weight-norm backward.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+
+ALIGN_C = 32
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class CLShape:
+    """geometry shared by every CL buffer of one forward pass"""
+
+    def __init__(self, N, L, HP):
+        self.N, self.L, self.HP = int(N), int(L), int(HP)
+        self.Lp = round_up(self.L + 2 * self.HP, 8)
+
+    @property
+    def R(self):
+        return self.N * self.Lp
+
+
+def _need(t, dtype):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise _lib.PsndError('CL kernels need contiguous %s CUDA tensors (got %s, %s, contiguous=%s)'
+                             % (dtype, t.device, t.dtype, t.is_contiguous()))
+
+
+class ToCL(torch.autograd.Function):
+    """(N, C, T) fp32 -> CL bf16 (optionally through log1p); backward is the inverse gather."""
+
+    @staticmethod
+    def forward(ctx, x, shape, preop):
+        x = x.contiguous()
+        _need(x, torch.float32)
+        N, C, T = x.shape
+        Cp = round_up(C, ALIGN_C)
+        out = torch.empty((N, shape.Lp, Cp), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_to_cl(ptr(x), N, C, T, shape.Lp, shape.HP, Cp, int(preop), ptr(out), stream_ptr(x.device)),
+                  'psnd_to_cl')
+        ctx.shape, ctx.C, ctx.T, ctx.preop = shape, C, T, preop
+        if preop:
+            ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gx = from_cl_raw(g, ctx.C, ctx.T, ctx.shape)
+        if ctx.preop == 1:
+            (x,) = ctx.saved_tensors
+            gx = gx / (1.0 + x)
+        return gx, None, None
+
+
+def from_cl_raw(buf, C, T, shape):
+    _need(buf, torch.bfloat16)
+    N, Lp, Cp = buf.shape
+    out = torch.empty((N, C, T), dtype=torch.float32, device=buf.device)
+    with torch.cuda.device(buf.device):
+        check(lib().psnd_from_cl(ptr(buf), N, C, T, Lp, shape.HP, Cp, ptr(out), stream_ptr(buf.device)), 'psnd_from_cl')
+    return out
+
+
+class FromCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buf, C, T, shape):
+        ctx.shape, ctx.Cp = shape, buf.shape[2]
+        return from_cl_raw(buf.contiguous(), C, T, shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, C, T = g.shape
+        out = torch.empty((N, ctx.shape.Lp, ctx.Cp), dtype=torch.bfloat16, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib().psnd_to_cl(ptr(g), N, C, T, ctx.shape.Lp, ctx.shape.HP, ctx.Cp, 0, ptr(out), stream_ptr(g.device)),
+                  'psnd_to_cl')
+        return out, None, None, None
+
+
+def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, off0, dstep, act_slope, mask_slope,
+                 want_raw, want_act):
+    dev = W.device
+    raw = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if want_raw else None
+    act = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if want_act else None
+    with torch.cuda.device(dev):
+        check(lib().psnd_conv1d_cl(ptr(A), ptr(A2), ptr(AM), float(a2_slope), ptr(W), ptr(bias), ptr(res), ptr(mask_src),
+                                   shape.N, shape.Lp, shape.L, shape.HP, Ca, Cb, k, off0, dstep, float(act_slope),
+                                   float(mask_slope), ptr(raw), ptr(act), stream_ptr(dev)), 'psnd_conv1d_cl')
+    return raw, act
+
+
+class FusedConvCL(torch.autograd.Function):
+    """y = conv1d(xa; weight-normed w, dilation) + bias (+ res); ya = leaky_relu(y, act_slope).
+    xa is an ALREADY activated CL buffer.  Returns (y or None, ya or None).
+
+    Launches: forward = weight prep (norm + two bf16 packs) + conv; backward = input-gradient conv (the
+    gradient combine g_raw + g_act*leaky'(y) happens while the operand is staged) + weight gradient (all
+    taps, bias gradient and the residual's gradient in one kernel) + weight-norm backward."""
+
+    @staticmethod
+    def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope):
+        _need(xa, torch.bfloat16)
+        Cout, Cin, k = weight_v.shape
+        Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
+        if Ca != round_up(Cin, ALIGN_C):
+            raise _lib.PsndError('CL conv: buffer has %d channels, weight expects %d' % (Ca, Cin))
+        pad = (k * dil - dil) // 2
+        dev = xa.device
+        wf = torch.empty((k, Cb, Ca), dtype=torch.bfloat16, device=dev)      # [j][co][ci]
+        wb = torch.empty((k, Ca, Cb), dtype=torch.bfloat16, device=dev)      # [j][ci][co]
+        bp = torch.empty(Cb, dtype=torch.float32, device=dev)
+        v32, g32 = weight_v.detach().contiguous(), weight_g.detach().contiguous()
+        b32 = None if bias is None else bias.detach().contiguous()
+        with torch.cuda.device(dev):
+            check(lib().psnd_conv1d_prep(ptr(v32), ptr(g32), ptr(b32), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
+                                         stream_ptr(dev)), 'psnd_conv1d_prep')
+        raw, act = _launch_conv(xa, None, None, 1.0, wf, bp, res, None, shape, Ca, Cb, k, -pad, dil, act_slope, 1.0,
+                                want_raw, want_act)
+        ctx.shape, ctx.dil, ctx.k, ctx.pad, ctx.act_slope = shape, dil, k, pad, act_slope
+        ctx.dims = (Cout, Cin, Ca, Cb)
+        ctx.has_res, ctx.has_bias = res is not None, bias is not None
+        ctx.save_for_backward(xa, v32, g32, wb, act if want_act else None)
+        return raw, act
+
+    @staticmethod
+    def backward(ctx, g_raw, g_act):
+        xa, v32, g32, wb, act = ctx.saved_tensors
+        shape, dil, k, pad = ctx.shape, ctx.dil, ctx.k, ctx.pad
+        Cout, Cin, Ca, Cb = ctx.dims
+        dev = xa.device
+        g_raw = None if g_raw is None else g_raw.contiguous()
+        g_act = None if g_act is None else g_act.contiguous()
+        # input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) formed on load
+        gx, _ = _launch_conv(g_raw, g_act, act if g_act is not None else None, ctx.act_slope, wb, None, None, None, shape,
+                             Cb, Ca, k, pad, -dil, 1.0, 1.0, True, False)
+        gw = torch.empty((k, Cb, Ca), dtype=torch.float32, device=dev)
+        gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+        need_gout = ctx.has_res and (g_act is not None)
+        g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
+        gv = torch.empty_like(v32)
+        gg = torch.empty_like(g32)
+        with torch.cuda.device(dev):
+            check(lib().psnd_conv1d_cl_wgrad(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None),
+                                             float(ctx.act_slope), ptr(xa), shape.N, shape.Lp, Ca, Cb, k, -pad, dil,
+                                             ptr(gw), ptr(gb), ptr(g_out), stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
+            check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv), ptr(gg),
+                                              stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
+        g_res = None
+        if ctx.has_res:
+            g_res = g_out if need_gout else g_raw
+        g_bias = gb[:Cout] if ctx.has_bias else None
+        return gx, gv, gg, g_bias, g_res, None, None, None, None, None
+
+
+def fused_conv(xa, conv, shape, res=None, want_raw=False, want_act=True, act_slope=0.1):
+    """conv: a WNConv1d module (weight_v, weight_g, bias, dilation)."""
+    return FusedConvCL.apply(xa, conv.weight_v, conv.weight_g, conv.bias, res, shape, conv.dilation, want_raw, want_act,
+                             act_slope)
+
+
+def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True):
+    """ResBlock1 (hifi_gan.py:55-63) on CL buffers.  x: residual stream (raw), xa = leaky_relu(x, 0.1).
+    Returns (x_out raw or None, leaky_relu(x_out, last_act_slope))."""
+    n = len(block.convs1)
+    for i, (c1, c2) in enumerate(zip(block.convs1, block.convs2)):
+        _, ta = fused_conv(xa, c1, shape, None, False, True, 0.1)
+        last = i == n - 1
+        x, xa = fused_conv(ta, c2, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1)
+    return x, xa

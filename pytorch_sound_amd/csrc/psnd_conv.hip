@@ -1,0 +1,519 @@
+// psnd_conv.hip - Conv1d stacks of pytorch_sound/models/vocoders/hifi_gan.py:32-147 (ResBlock1/2, conv_pre /
+// conv_post) as ONE implicit-GEMM bf16 MFMA kernel with fused epilogue, for gfx950.
+//
+// Layout ("CL"): activations are channels-last bf16 matrices  X[r][c],  r = clip * Lp + l,  Lp >= L + 2*HP,
+// rows l in [HP, HP+L) hold the clip, all other rows are ZERO.  A stride-1 dilated convolution is then
+//      Y[r][co] = sum_j sum_ci  X[r + off_j][ci] * W[j][co][ci],        off_j = off0 + j * dstep
+// i.e. every tap is a row shift of the same matrix: clip boundaries need no special case (the halo rows
+// supply the zero padding), both MFMA operands are K(=ci)-contiguous, and the SAME kernel computes
+//      forward        A = X,  W = weight[co][ci][j] packed [j][co][ci],  off_j =  j*dil - pad
+//      backward-data  A = gY, W = weight packed [j][ci][co],             off_j = pad - j*dil
+// Epilogue (fused, replaces 3-4 elementwise passes per conv of the reference):
+//      v = acc (+ bias[co]) ; v *= leaky'(mask_src) ; v += res ; rows outside the clip -> 0
+//      out_raw = bf16(v) (optional) ; out_act = bf16(leaky_relu(v, slope)) (optional)
+//
+// Tiling: 256 threads = 2 x 2 waves, block tile 64 rows x 64 output channels, one v_mfma_f32_32x32x16_bf16
+// accumulator (32 x 32) per wave; K walks input channels in chunks of 32 staged through LDS together with
+// the chunk's weights for all taps (row stride 80 B = conflict-free ds_read_b128 fragments).  The A tile
+// carries its +-HM halo rows, so the k taps re-use one staged tile (that is the implicit-GEMM saving).
+#include "psnd_common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = 16 B MFMA operand
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (NaN stays NaN)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+struct ConvParams {
+    const bf16_t *A;         // (R, Ca)
+    const bf16_t *A2;        // (R, Ca) or null: A_eff = A + A2 * (AM > 0 ? 1 : a2_slope)  (A may be null -> 0)
+    const bf16_t *AM;        // (R, Ca) sign source for A2
+    const bf16_t *W;         // [k][Cb][Ca]
+    const float *bias;       // Cb or null
+    const bf16_t *res;       // (R, Cb) or null
+    const bf16_t *mask_src;  // (R, Cb) or null: v *= (mask_src > 0 ? 1 : mask_slope)
+    bf16_t *out_raw;         // (R, Cb) or null
+    bf16_t *out_act;         // (R, Cb) or null
+    long long R;
+    int Lp, L, HP, Ca, Cb, k, off0, dstep, hm;
+    float act_slope, mask_slope, a2_slope;
+};
+
+constexpr int BM = 64, BN = 64, RS = 40;   // RS: LDS row stride in bf16 (80 B) of the 32-channel tiles (wgrad)
+
+// 8 consecutive bf16 of  g = G1 + G2 * leaky'(M)  (either term optional): the gradient wrt a conv output that
+// was handed out both raw and through leaky_relu (sign(M) == sign of the pre-activation).
+__device__ __forceinline__ uint4 load_combined(const bf16_t *G1, const bf16_t *G2, const bf16_t *M, float slope, size_t o) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (G1) v = *reinterpret_cast<const uint4 *>(G1 + o);
+    if (G2) {
+        const uint4 g2 = *reinterpret_cast<const uint4 *>(G2 + o);
+        const uint4 m = *reinterpret_cast<const uint4 *>(M + o);
+        const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
+                       *pm = reinterpret_cast<const unsigned *>(&m);
+        unsigned out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a0 = bf2f((bf16_t)(pv[i] & 0xffff)), a1 = bf2f((bf16_t)(pv[i] >> 16));
+            const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
+            const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
+            const float r0 = a0 + b0 * (m0 > 0.f ? 1.f : slope), r1 = a1 + b1 * (m1 > 0.f ? 1.f : slope);
+            out[i] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+        }
+        v = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+    return v;
+}
+
+constexpr int MAXK = 16;
+
+// KC: input channels per pipeline stage (32 or 64); LDS row stride KC + 8 bf16 (80 / 144 B: odd multiples of
+// 16 B -> the 16 lanes of a ds_read_b128 group land on 16 distinct 16-B slots)
+template <int KC>
+__global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
+    constexpr int RS = KC + 8, PCS = KC / 8;   // pieces of 16 B per row
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_c[];
+    const int rowsA = BM + 2 * p.hm;
+    bf16_t *sA = smem_c;
+    bf16_t *sB = sA + rowsA * RS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long r0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int li = lane & 31, kg = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    // software pipeline: the global loads of chunk c+1 are in flight while chunk c is multiplied.
+    // per thread: <= 2 pieces of the A tile (rows r0-hm .. r0+BM+hm, 4 x 16 B each) and k pieces of weights.
+    constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;      // A pieces per thread (hm <= 25)
+    constexpr int NB = BN * PCS / 256;                      // weight pieces per thread per tap
+    uint4 ra[NA], rb[MAXK * NB];
+    const int nA = rowsA * PCS;
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + 256 * u;
+            ra[u] = make_uint4(0, 0, 0, 0);
+            if (idx < nA) {
+                const int rr = idx / PCS, pc = idx % PCS;
+                const long long r = r0 - p.hm + rr;
+                if (r >= 0 && r < p.R) ra[u] = load_combined(p.A, p.A2, p.AM, p.a2_slope, (size_t)r * p.Ca + c0 + 8 * pc);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) {
+            if (j < p.k) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int idx = tid + 256 * u, n = idx / PCS, pc = idx % PCS;
+                    rb[j * NB + u] = make_uint4(0, 0, 0, 0);
+                    if (n0 + n < p.Cb)
+                        rb[j * NB + u] = *reinterpret_cast<const uint4 *>(p.W + ((size_t)j * p.Cb + n0 + n) * p.Ca + c0 + 8 * pc);
+                }
+            }
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < nA) *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = ra[u];
+        }
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j)
+            if (j < p.k) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int idx = tid + 256 * u;
+                    *reinterpret_cast<uint4 *>(sB + (j * BN + idx / PCS) * RS + 8 * (idx % PCS)) = rb[j * NB + u];
+                }
+            }
+    };
+
+    fetch(0);
+    for (int c0 = 0; c0 < p.Ca; c0 += KC) {
+        commit();
+        __syncthreads();
+        if (c0 + KC < p.Ca) fetch(c0 + KC);
+        for (int tap = 0; tap < p.k; ++tap) {
+            const int off = p.off0 + tap * p.dstep + p.hm;
+            const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
+            const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
+#pragma unroll
+            for (int kk = 0; kk < KC / 16; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i][j], j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+    const int col = n0 + wn * 32 + li;
+    if (col >= p.Cb) return;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int i = (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+        const long long r = r0 + wm * 32 + i;
+        if (r >= p.R) continue;
+        const int l = (int)(r % p.Lp);
+        const size_t o = (size_t)r * p.Cb + col;
+        float v = 0.f;
+        if (l >= p.HP && l < p.HP + p.L) {
+            v = acc[rg] + bv;
+            if (p.mask_src) v *= (bf2f(p.mask_src[o]) > 0.f) ? 1.f : p.mask_slope;
+            if (p.res) v += bf2f(p.res[o]);
+        }
+        if (p.out_raw) p.out_raw[o] = f2bf(v);
+        if (p.out_act) p.out_act[o] = f2bf(v > 0.f ? v : v * p.act_slope);
+    }
+}
+
+// ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
+// to_cl: optional pre-op  0: none, 1: log1p(x)
+__global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out, int N, int C, int T, int Lp, int HP, int Cp,
+                                                    int preop) {
+    // tile 32 (t) x 32 (c) through LDS so both sides are coalesced
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    const int n = blockIdx.z;
+    const int t0 = blockIdx.x * 32 - HP, c0 = blockIdx.y * 32;  // rows of the CL buffer: l = t + HP
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, t = t0 + tx;
+        float v = 0.f;
+        if (c < C && t >= 0 && t < T) {
+            v = x[((size_t)n * C + c) * T + t];
+            if (preop == 1) v = log1pf(v);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int l = blockIdx.x * 32 + j, c = c0 + tx;
+        if (l < Lp && c < Cp) out[((size_t)n * Lp + l) * Cp + c] = f2bf(tile[tx][j]);
+    }
+}
+
+// from_cl: (N, Lp, Cp) bf16 -> (N, C, T) fp32
+__global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int t = t0 + j, c = c0 + tx;
+        float v = 0.f;
+        if (t < T && c < Cp) v = bf2f(x[((size_t)n * Lp + t + HP) * Cp + c]);
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, t = t0 + tx;
+        if (c < C && t < T) out[((size_t)n * C + c) * T + t] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradient:  gw[j][co][ci] += sum_r g[r][co] * xa[r + off_j][ci]   (fp32, split over row ranges, atomics)
+//                   gbias[co]     += sum_r g[r][co] ;  g_out[r][co] = g (optional materialisation, for the residual)
+// The reduction runs over ROWS, the non-contiguous dimension of both CL operands, so tiles are transposed on
+// their way into LDS (T[c][row], row-contiguous) and MFMA fragments are read with ds_read_b128.  All taps
+// of a group share the staged g tile; each tap stages its own row-shifted copy of xa.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WKT = 4;     // taps per pass (accumulators: WKT x 16 VGPRs)
+struct WgradParams {
+    const bf16_t *G1, *G2, *GM;   // g = G1 + G2 * leaky'(GM)
+    const bf16_t *xa;
+    float *gw, *gbias;
+    bf16_t *g_out;
+    long long R;
+    int Ca, Cb, k, off0, dstep, rows_per_split;
+    float g2_slope;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sT[(1 + WKT) * 64 * RS];
+    bf16_t *sA = sT, *sB = sT + 64 * RS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const long long rs = (long long)blockIdx.z * p.rows_per_split;
+    const long long re = min(rs + p.rows_per_split, p.R);
+    const int rr = tid & 31, cg = tid >> 5;          // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
+    const bool do_bias = (blockIdx.y == 0);
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = 0; t0 < p.k; t0 += WKT) {
+        const int nt = min(WKT, p.k - t0);
+        f32x16 acc[WKT];
+#pragma unroll
+        for (int j = 0; j < WKT; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        // software pipeline over 32-row chunks: chunk c+1 is being loaded while chunk c is multiplied
+        uint4 vg, vx[WKT];
+        auto fetch = [&](long long r0) __attribute__((always_inline)) {
+            const long long r = r0 + rr;
+            vg = make_uint4(0, 0, 0, 0);
+            if (r < re && co0 + 8 * cg < p.Cb) vg = load_combined(p.G1, p.G2, p.GM, p.g2_slope, (size_t)r * p.Cb + co0 + 8 * cg);
+#pragma unroll
+            for (int j = 0; j < WKT; ++j) {
+                vx[j] = make_uint4(0, 0, 0, 0);
+                if (j < nt) {
+                    const long long rx = r + p.off0 + (t0 + j) * p.dstep;
+                    if (r < re && rx >= 0 && rx < p.R && ci0 + 8 * cg < p.Ca)
+                        vx[j] = *reinterpret_cast<const uint4 *>(p.xa + (size_t)rx * p.Ca + ci0 + 8 * cg);
+                }
+            }
+        };
+        fetch(rs);
+        for (long long r0 = rs; r0 < re; r0 += 32) {
+            const long long r = r0 + rr;
+            {   // g tile, transposed on its way into LDS
+                const unsigned *pv = reinterpret_cast<const unsigned *>(&vg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16_t h = (bf16_t)((pv[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                    sA[(8 * cg + e) * RS + rr] = h;
+                    if (do_bias && t0 == 0) bsum[e] += bf2f(h);
+                }
+                if (p.g_out && do_bias && t0 == 0 && r < re && co0 + 8 * cg < p.Cb)
+                    *reinterpret_cast<uint4 *>(p.g_out + (size_t)r * p.Cb + co0 + 8 * cg) = vg;
+            }
+#pragma unroll
+            for (int j = 0; j < WKT; ++j)
+                if (j < nt) {   // row-shifted xa tiles, transposed
+                    const unsigned *pv = reinterpret_cast<const unsigned *>(&vx[j]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        sB[(j * 64 + 8 * cg + e) * RS + rr] = (bf16_t)((pv[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            __syncthreads();
+            if (r0 + 32 < re) fetch(r0 + 32);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(sA + (wm * 32 + li) * RS + 16 * kk + 8 * kg);
+#pragma unroll
+                for (int j = 0; j < WKT; ++j)
+                    if (j < nt) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(sB + (j * 64 + wn * 32 + li) * RS + 16 * kk + 8 * kg);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+        // D[i = co][j = ci]: col = lane & 31 -> ci, rows -> co
+        const int ci = ci0 + wn * 32 + li;
+        if (ci < p.Ca) {
+#pragma unroll
+            for (int j = 0; j < WKT; ++j)
+                if (j < nt) {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int co = co0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+                        if (co < p.Cb) unsafeAtomicAdd(p.gw + ((size_t)(t0 + j) * p.Cb + co) * p.Ca + ci, acc[j][rg]);
+                    }
+                }
+        }
+    }
+    if (do_bias && p.gbias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (rr == 0 && co0 + 8 * cg + e < p.Cb) unsafeAtomicAdd(p.gbias + co0 + 8 * cg + e, v);
+        }
+    }
+}
+
+// ---- weight prep: weight norm (dim 0) + both bf16 packs + padded bias, one block per output channel ------
+//   w = g * v / ||v|| ; wf[j][co][ci] (forward), wb[j][ci][co] (input gradient) ; pads are zero-filled by the caller
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const float *g, const float *bias, int Cout, int Cin, int k,
+                                                        int Cb, int Ca, bf16_t *wf, bf16_t *wb, float *bp) {
+    __shared__ float red[4];
+    const int co = blockIdx.x, n = Cin * k;
+    const float *vr = v + (size_t)co * n;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) ss += vr[i] * vr[i];
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float scale = g[co] / __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / k, j = i - ci * k;
+        const bf16_t w = f2bf(vr[i] * scale);
+        wf[((size_t)j * Cb + co) * Ca + ci] = w;
+        wb[((size_t)j * Ca + ci) * Cb + co] = w;
+    }
+    if (threadIdx.x == 0) bp[co] = bias ? bias[co] : 0.f;
+}
+
+// ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
+//   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
+__global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw, const float *v, const float *g, int Cout, int Cin, int k,
+                                                          int Cb, int Ca, float *gv, float *gg) {
+    __shared__ float red[8];
+    const int co = blockIdx.x, n = Cin * k;
+    const float *vr = v + (size_t)co * n;
+    float ss = 0.f, dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / k, j = i - ci * k;
+        const float vv = vr[i];
+        ss += vv * vv;
+        dot += vv * gw[((size_t)j * Cb + co) * Ca + ci];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        ss += __shfl_xor(ss, m, 64);
+        dot += __shfl_xor(dot, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss, red[4 + (threadIdx.x >> 6)] = dot;
+    __syncthreads();
+    const float nrm = __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float d = (red[4] + red[5] + red[6] + red[7]) / nrm;      // sum(gw * vhat)
+    const float gs = g[co] / nrm;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / k, j = i - ci * k;
+        gv[(size_t)co * n + i] = gs * (gw[((size_t)j * Cb + co) * Ca + ci] - vr[i] / nrm * d);
+    }
+    if (threadIdx.x == 0) gg[co] = d;
+}
+
+}  // namespace
+
+extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
+                              const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
+                              int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
+                              void *stream) {
+    if ((!A && !A2) || !W || (!out_raw && !out_act) || (A2 && !AM)) PSND_FAIL(PSND_E_ARG, "conv1d_cl: null pointer");
+    if (Ca % 32 != 0 || Cb % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: Ca=%d must be a multiple of 32, Cb=%d of 8", Ca, Cb);
+    if (k < 1 || k > 16 || N < 0 || Lp < L + 2 * HP || L <= 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d N=%lld Lp=%d L=%d HP=%d", k, (long long)N, Lp, L, HP);
+    int hm = 0;
+    for (int j = 0; j < k; ++j) {
+        const int o = off0 + j * dstep;
+        hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
+    }
+    if (hm > HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: tap reach %d exceeds the halo HP=%d", hm, HP);
+    if (N == 0) return PSND_OK;
+    ConvParams p;
+    p.A = static_cast<const bf16_t *>(A), p.A2 = static_cast<const bf16_t *>(A2), p.AM = static_cast<const bf16_t *>(AM);
+    p.a2_slope = a2_slope;
+    p.W = static_cast<const bf16_t *>(W), p.bias = bias;
+    p.res = static_cast<const bf16_t *>(res), p.mask_src = static_cast<const bf16_t *>(mask_src);
+    p.out_raw = static_cast<bf16_t *>(out_raw), p.out_act = static_cast<bf16_t *>(out_act);
+    p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.hm = hm;
+    p.act_slope = act_slope, p.mask_slope = mask_slope;
+    // 64-channel stages measured SLOWER on the config-2 model (253 VGPRs -> 1 block/CU: 14.8k vs 16.9k audio-s/s);
+    // kept behind PSND_CONV_KC64 for A/B runs
+    const size_t rows = (size_t)(BM + 2 * hm) + (size_t)k * BN;
+    const bool wide = (Ca % 64 == 0) && (sizeof(bf16_t) * 72 * rows <= 64 * 1024) && k <= 8 && getenv("PSND_CONV_KC64");
+    const size_t lds = sizeof(bf16_t) * (wide ? 72 : 40) * rows;
+    if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: LDS %zu too large", lds);
+    dim3 grid((unsigned)((p.R + BM - 1) / BM), (unsigned)((Cb + BN - 1) / BN));
+    if (wide) {
+        hipLaunchKernelGGL(conv_cl_kernel<64>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    } else {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cl_kernel<32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl: set LDS size: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(conv_cl_kernel<32>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    }
+    PSND_CHECK_LAUNCH("conv1d_cl");
+    return PSND_OK;
+}
+
+extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out,
+                          void *stream) {
+    if (!x || !out) PSND_FAIL(PSND_E_ARG, "to_cl: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "to_cl: Lp=%d T=%lld HP=%d Cp=%d C=%d", Lp, (long long)T, HP, Cp, C);
+    if (N == 0) return PSND_OK;
+    dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(to_cl_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<bf16_t *>(out),
+                       (int)N, C, (int)T, Lp, HP, Cp, preop);
+    PSND_CHECK_LAUNCH("to_cl");
+    return PSND_OK;
+}
+
+extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream) {
+    if (!x || !out) PSND_FAIL(PSND_E_ARG, "from_cl: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "from_cl: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(from_cl_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
+                       (int)N, C, (int)T, Lp, HP, Cp);
+    PSND_CHECK_LAUNCH("from_cl");
+    return PSND_OK;
+}
+
+extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
+                                    int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw, float *gbias, void *g_out,
+                                    void *stream) {
+    if ((!G1 && !G2) || (G2 && !GM) || !xa || !gw) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad: null pointer");
+    if (Ca % 8 != 0 || Cb % 8 != 0 || k < 1 || k > 16 || N < 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: Ca=%d Cb=%d k=%d", Ca, Cb, k);
+    if (N == 0) return PSND_OK;
+    WgradParams p;
+    p.G1 = static_cast<const bf16_t *>(G1), p.G2 = static_cast<const bf16_t *>(G2), p.GM = static_cast<const bf16_t *>(GM);
+    p.xa = static_cast<const bf16_t *>(xa), p.gw = gw, p.gbias = gbias, p.g_out = static_cast<bf16_t *>(g_out);
+    p.R = N * (int64_t)Lp, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.g2_slope = g2_slope;
+    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64;
+    int64_t target = 512;                       // ~2 workgroups per CU; every split costs k*64*64 fp32 atomics per tile
+    if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
+    int64_t splits = target / ((int64_t)tx * ty);
+    if (splits < 1) splits = 1;
+    int64_t rps = (p.R + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 64) rps = 64;
+    splits = (p.R + rps - 1) / rps;
+    p.rows_per_split = (int)rps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)k * Cb * Ca, s);
+    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Cb, s);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl_wgrad: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)splits), dim3(256), 0, s, p);
+    PSND_CHECK_LAUNCH("conv1d_cl_wgrad");
+    return PSND_OK;
+}
+
+extern "C" int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout, int Cin, int k, int Cb, int Ca,
+                                void *wf, void *wb, float *bias_padded, void *stream) {
+    if (!v || !g || !wf || !wb || !bias_padded) PSND_FAIL(PSND_E_ARG, "conv1d_prep: null pointer");
+    if (Cb < Cout || Ca < Cin) PSND_FAIL(PSND_E_SHAPE, "conv1d_prep: padded sizes too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nw = sizeof(bf16_t) * (size_t)k * Cb * Ca;
+    hipError_t e = hipSuccess;
+    if (Cb != Cout || Ca != Cin) {
+        e = hipMemsetAsync(wf, 0, nw, s);
+        if (e == hipSuccess) e = hipMemsetAsync(wb, 0, nw, s);
+        if (e == hipSuccess) e = hipMemsetAsync(bias_padded, 0, sizeof(float) * Cb, s);
+    }
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_prep: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(conv_prep_kernel, dim3(Cout), dim3(256), 0, s, v, g, bias, Cout, Cin, k, Cb, Ca,
+                       static_cast<bf16_t *>(wf), static_cast<bf16_t *>(wb), bias_padded);
+    PSND_CHECK_LAUNCH("conv1d_prep");
+    return PSND_OK;
+}
+
+extern "C" int psnd_conv1d_wnorm_bwd(const float *gw, const float *v, const float *g, int Cout, int Cin, int k, int Cb, int Ca,
+                                     float *gv, float *gg, void *stream) {
+    if (!gw || !v || !g || !gv || !gg) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd: null pointer");
+    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), gw, v, g, Cout, Cin, k, Cb, Ca,
+                       gv, gg);
+    PSND_CHECK_LAUNCH("conv1d_wnorm_bwd");
+    return PSND_OK;
+}

@@ -25,11 +25,29 @@ class ConvSeparator(nn.Module):
         self.conv_post = WNConv1d(channels, spec_size, 3, 1, 1, init_std=0.01)
 
     def forward(self, mag: torch.Tensor) -> torch.Tensor:
+        if mag.is_cuda:
+            return self.forward_cl(mag)
         x = self.conv_pre(torch.log1p(mag))
         for block in self.blocks:
             x = block(x)
         mask = torch.sigmoid(self.conv_post(F.leaky_relu(x, LRELU_SLOPE)))
         return mask * mag
+
+
+    def forward_cl(self, mag: torch.Tensor) -> torch.Tensor:
+        """the same function on the gfx950 implicit-GEMM conv kernel (channels-last bf16, fp32 accumulate):
+        one launch per conv forward, leaky-relu / bias / residual fused, log1p fused into the layout change."""
+        from pytorch_sound_amd import cl
+        N, C, T = mag.shape
+        halo = max(c.padding for b in self.blocks for c in list(b.convs1) + list(b.convs2))
+        shape = cl.CLShape(N, T, max(halo, self.conv_pre.padding, self.conv_post.padding))
+        x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
+        x, xa = cl.fused_conv(x0, self.conv_pre, shape, None, True, True, LRELU_SLOPE)
+        for block in self.blocks:
+            x, xa = cl.resblock1_cl(block, x, xa, shape)
+        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False)
+        logits = cl.FromCL.apply(y, C, T, shape)
+        return torch.sigmoid(logits) * mag
 
 
 @register_model_architecture('conv_separator', 'conv_separator_voicebank')

@@ -1,0 +1,93 @@
+"""CL implicit-GEMM conv kernel (psnd_conv1d_cl) and the separator fast path against the fp32 torch
+formulation of the same ops (the module's own reference path, which the golden tests pin on CPU).
+bf16 storage with fp32 accumulation: tolerance 2e-2 of the tensor's max (bf16 has 8 mantissa bits and the
+activations are re-quantised after every conv)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    """max-abs error relative to the tensor's max (forward values)"""
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def relf(a, b):
+    """relative Frobenius error (gradients: single elements whose pre-activation sits within bf16 round-off
+    of 0 legitimately take the other leaky-relu slope, so a max-norm is not meaningful there)"""
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize('Cin,Cout,k,dil,L,N', [(64, 64, 3, 1, 50, 2), (96, 64, 3, 5, 173, 3), (64, 40, 7, 3, 61, 2),
+                                               (513, 256, 3, 1, 173, 2), (256, 513, 3, 1, 45, 2), (32, 32, 11, 5, 200, 1)])
+def test_fused_conv_fwd_bwd(Cin, Cout, k, dil, L, N):
+    from pytorch_sound_amd import cl
+    from pytorch_sound_amd.models.vocoders.hifi_gan import WNConv1d
+    dev = torch.device('cuda:0')
+    torch.manual_seed(Cin + k)
+    pad = (k * dil - dil) // 2
+    conv = WNConv1d(Cin, Cout, k, dil, pad, init_std=0.05).to(dev)
+    with torch.no_grad():
+        conv.weight_g.mul_(1.0 + 0.3 * torch.rand_like(conv.weight_g))
+    x = torch.randn(N, Cin, L, device=dev)
+    r = torch.randn(N, Cout, L, device=dev)
+    gy = torch.randn(N, Cout, L, device=dev)
+    gya = torch.randn(N, Cout, L, device=dev)
+    # reference (fp32 torch ops): y = conv(x) + r ; ya = leaky(y)
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True)
+    y = conv(xr) + rr
+    ya = F.leaky_relu(y, 0.1)
+    (y * gy).sum().backward(retain_graph=True)
+    (ya * gya).sum().backward()
+    ref = {'y': y.detach(), 'ya': ya.detach(), 'gx': xr.grad.clone(), 'gr': rr.grad.clone(),
+           'gv': conv.weight_v.grad.clone(), 'gg': conv.weight_g.grad.clone(), 'gb': conv.bias.grad.clone()}
+    conv.zero_grad()
+    # CL path
+    shape = cl.CLShape(N, L, pad + 1)
+    xc = x.clone().requires_grad_(True)
+    rc = r.clone().requires_grad_(True)
+    xb = cl.ToCL.apply(xc, shape, 0)
+    rb = cl.ToCL.apply(rc, shape, 0)
+    yb, yab = cl.fused_conv(xb, conv, shape, rb, True, True, 0.1)
+    y2 = cl.FromCL.apply(yb, Cout, L, shape)
+    ya2 = cl.FromCL.apply(yab, Cout, L, shape)
+    ((y2 * gy).sum() + (ya2 * gya).sum()).backward()
+    torch.cuda.synchronize()
+    assert rel(y2, ref['y']) < 2e-2 and rel(ya2, ref['ya']) < 2e-2
+    assert relf(xc.grad, ref['gx']) < 3e-2 and relf(rc.grad, ref['gr']) < 3e-2
+    assert relf(conv.weight_v.grad, ref['gv']) < 3e-2 and relf(conv.weight_g.grad, ref['gg']) < 3e-2
+    assert relf(conv.bias.grad, ref['gb']) < 3e-2
+    # halo rows and padded channels stay exactly zero
+    yb_ = yb.detach().float()
+    assert float(yb_[:, :shape.HP].abs().max()) == 0 and float(yb_[:, shape.HP + L:].abs().max()) == 0
+    assert float(yb_[:, :, Cout:].abs().max()) == 0 if yb_.shape[2] > Cout else True
+
+
+def test_separator_cl_matches_torch_path():
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = build_model('conv_separator_voicebank', {'channels': 64, 'num_blocks': 2}).to(dev)
+    mag = torch.rand(3, 513, 90, device=dev) * 4
+    tgt = torch.rand(3, 513, 90, device=dev)
+    # fp32 torch formulation (the CPU-tested module path, forced on the GPU)
+    x = model.conv_pre(torch.log1p(mag))
+    for b in model.blocks:
+        x = b(x)
+    ref = torch.sigmoid(model.conv_post(F.leaky_relu(x, 0.1))) * mag
+    (ref - tgt).abs().mean().backward()
+    gref = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    out = model(mag)
+    (out - tgt).abs().mean().backward()
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 2e-2
+    for k, p in model.named_parameters():
+        assert relf(p.grad, gref[k]) < 5e-2, k
