@@ -78,17 +78,8 @@ def build_step(device, amp):
             return fe.mel_of_mag(m)
 
     class StepTrainer(Trainer):
-        stft_events = None
-
         def forward(self, noisy, clean, is_logging=False):
-            ev = self.stft_events
-            if ev is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             mag_mix = magnitude(noisy)
-            if ev is not None:
-                e1.record()
-                ev.append((e0, e1))
             with torch.no_grad():
                 mag_ref = magnitude(clean)
                 mel_ref = logmel_of_mag(mag_ref)
@@ -121,7 +112,7 @@ def gpu_bench(args):
     N = BATCH_PER_GPU
 
     Trainer, model = build_step(device, amp=True)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True)
     pool = [synth_batch(1234 + rank + 1000 * i, N, T, device) for i in range(args.pool)]
     save_dir = tempfile.mkdtemp(prefix='psnd_bench_')
     huge = 10 ** 9
@@ -141,7 +132,7 @@ def gpu_bench(args):
         tr.step = step
         tr.train(step)
     barrier()
-    tr.stft_events = []
+    K.STFT_FWD_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step += 1
@@ -160,16 +151,18 @@ def gpu_bench(args):
     # ---- roofline of the STFT kernel as launched in the timed region (rank 0) ------------------------
     Kb = N_FFT // 2 + 1
     Fr = K.frame_count(T, N_FFT, HOP)
-    ev = tr.stft_events
-    tr.stft_events = None
-    t_stft = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    ev = K.STFT_FWD_EVENTS
+    K.STFT_FWD_EVENTS = None
+    t_stft = float(np.mean([a.elapsed_time(b) for a, b, _ in ev])) * 1e-3
     bytes_launch = 4 * N * T + 4 * N * Kb * Fr
-    roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_kernel<32,16,mag> (wav -> magnitude, 1024/256)',
+    roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
                 'achieved': bytes_launch / t_stft / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': bytes_launch / t_stft / HBM_PEAK, 'traffic': None,
                 'bytes_per_launch': bytes_launch, 'launch_us': t_stft * 1e6,
-                'note': 'config-2 launch moves 17 MB (Infinity-Cache resident, ~launch-latency bound); '
-                        'see roofline_large for a working set beyond the 256 MiB cache'}
+                'launches_timed': len(ev),
+                'note': 'config-2 launch moves 17 MB (Infinity-Cache resident); HIP events sit directly around the '
+                        'launch, so when the stream is empty they include its dispatch latency; see roofline_large '
+                        'for a working set beyond the 256 MiB cache'}
     out = None
     if rank == 0:
         # the same kernel on 1024 clips: 181 MB in + 363 MB out

@@ -13,6 +13,10 @@ from ._lib import lib, check, ptr, stream_ptr, FRAMING_CENTER, FRAMING_HIFIGAN, 
 
 _INF = float('inf')
 
+# bench.py sets this to a list to collect (start, end) HIP event pairs recorded on the launch stream directly
+# around every psnd_stft_fwd call (magnitude-only launches), i.e. without the Python work around it.
+STFT_FWD_EVENTS = None
+
 
 def _need_cuda(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -56,9 +60,16 @@ def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
     phase = mk() if want_phase else None
     re = mk() if want_reim else None
     im = mk() if want_reim else None
+    ev = STFT_FWD_EVENTS
     with torch.cuda.device(wav.device):
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(lib().psnd_stft_fwd(ptr(wav), N, T, n_fft, hop, framing, ptr(plan), float(mag_eps),
                                   ptr(mag), ptr(phase), ptr(re), ptr(im), stream_ptr(wav.device)), 'psnd_stft_fwd')
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, N))
     return {'mag': mag, 'phase': phase, 're': re, 'im': im}
 
 

@@ -197,6 +197,58 @@ class Trainer:
         if self.grad_norm:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], self.grad_norm)
 
+    # ---- NaN skip without a host sync --------------------------------------------------------------
+    # The reference tests `loss != loss` on the host every step (trainer.py:205): a device->host sync that
+    # idles the GPU between forward and backward.  When the optimizer implements the AMP `found_inf`
+    # protocol (fused Adam/AdamW/SGD) and no scheduler is attached, the same decision is taken ON THE DEVICE:
+    # the flag isnan(loss) (MAX-all-reduced under DDP, asynchronously) is handed to the optimizer kernel, which
+    # skips the update (and its step count) itself; the log line is emitted as soon as the flag has reached the
+    # host on its own.  Anything else falls back to the reference's synchronous check.
+    async_nan_check = True
+
+    def _can_skip_on_device(self, loss: torch.Tensor) -> bool:
+        return (self.async_nan_check and loss.is_cuda and self.scheduler is None
+                and getattr(self.optimizer, '_step_supports_amp_scaling', False))
+
+    def _poll_nan_log(self, block: bool = False):
+        pending = getattr(self, '_nan_pending', None)
+        if not pending:
+            return
+        keep = []
+        for step, host_flag, event in pending:
+            if block:
+                event.synchronize()
+            if event.query():
+                if float(host_flag.item()) > 0:
+                    self._log('{} cur step NAN is occured'.format(step))
+            else:
+                keep.append((step, host_flag, event))
+        self._nan_pending = keep
+
+    def _train_device_skip(self, step: int, loss: torch.Tensor):
+        flag = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+        if self._reducer is not None:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
+        host_flag.copy_(flag, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        if not hasattr(self, '_nan_pending'):
+            self._nan_pending = []
+        self._nan_pending.append((step, host_flag, event))
+        loss.backward()
+        if self._reducer is not None:
+            self._reducer.finish()
+        self.clip_grad()
+        self.optimizer.found_inf = flag
+        self.optimizer.grad_scale = None
+        try:
+            self.optimizer.step()
+        finally:
+            del self.optimizer.found_inf
+            del self.optimizer.grad_scale
+        self._poll_nan_log()
+
     def _loss_is_nan(self, loss: torch.Tensor) -> bool:
         bad = bool(loss != loss)                       # host sync, as in the reference (trainer.py:205)
         if self._reducer is not None:
@@ -211,6 +263,16 @@ class Trainer:
         log_flag = step % self.log_interval == 0
 
         loss, meta = self.forward(*self._next_batch(self.train_dataset), is_logging=log_flag)
+
+        if self._can_skip_on_device(loss):
+            self._train_device_skip(step, loss)
+            if log_flag and pdist.is_main():
+                self.console_log('train', meta, step)
+                try:
+                    self.tensorboard_log('train', meta, step)
+                except OverflowError:
+                    pass
+            return
 
         if self._loss_is_nan(loss):
             self._log('{} cur step NAN is occured'.format(step))
@@ -232,6 +294,7 @@ class Trainer:
                 pass
 
     def validate(self, step: int):
+        self._poll_nan_log(block=True)
         loss = 0.
         stat = defaultdict(float)
         for i in range(self.valid_max_step):

@@ -91,3 +91,50 @@ def test_separator_cl_matches_torch_path():
     assert rel(out, ref) < 2e-2
     for k, p in model.named_parameters():
         assert relf(p.grad, gref[k]) < 5e-2, k
+
+
+def test_trainer_device_side_nan_skip():
+    """fused optimizer + no scheduler: the NaN step is skipped by the optimizer kernel (no host sync); the
+    parameters after the run equal those of a run that never saw the poisoned batch; the log line still appears."""
+    import io
+    import logging
+    import tempfile
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    from pytorch_sound_amd.utils.commons import LOGGER
+    dev = torch.device('cuda:0')
+
+    class T(Trainer):
+        poison = -1
+
+        def forward(self, x, y, is_logging=False):
+            loss = F.mse_loss(self.model(x), y)
+            if self.step == self.poison and self.model.training:
+                loss = loss * float('nan')
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    def run(poison, async_mode):
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1)).to(dev)
+        g = torch.Generator().manual_seed(5)
+        data = [(torch.randn(4, 8, generator=g).to(dev), torch.randn(4, 1, generator=g).to(dev)) for _ in range(4)]
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+        T.poison = poison
+        T.async_nan_check = async_mode
+        tr = T(net, opt, data, data, max_step=4, valid_max_step=1, save_interval=100, log_interval=100,
+               save_dir=tempfile.mkdtemp(), seed=1)
+        tr.run()
+        tr._poll_nan_log(block=True)
+        return [p.detach().clone() for p in net.parameters()]
+
+    buf = io.StringIO()
+    hdl = logging.StreamHandler(buf)
+    LOGGER.addHandler(hdl)
+    try:
+        a = run(2, True)      # device-side skip
+        b = run(2, False)     # reference's host check
+    finally:
+        LOGGER.removeHandler(hdl)
+        T.async_nan_check = True
+    for pa, pb in zip(a, b):
+        assert torch.isfinite(pa).all() and torch.equal(pa, pb)
+    assert buf.getvalue().count('2 cur step NAN is occured') == 2
