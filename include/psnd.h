@@ -39,6 +39,8 @@ extern "C" {
 #define PSND_FRAMING_CENTER 0  /* reflect-pad n_fft/2       : transforms.py:55-60, :298-301   */
 #define PSND_FRAMING_HIFIGAN 1 /* reflect-pad (n_fft-hop)/2 : transforms.py:352-353,
                                   interface/hifi_gan.py:37,49 */
+#define PSND_FRAMING_NONE 2    /* no padding: frame f covers samples [f*hop, f*hop + n_fft)  (used by the
+                                  backward of psnd_istft)                                          */
 
 int psnd_version(void);
 const char *psnd_last_error(void);
@@ -80,6 +82,12 @@ int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, in
                   const void *plan, float mag_eps,
                   const float *gmag, const float *gre, const float *gim,
                   float *gwav, void *stream);
+
+/* ---- inverse STFT: replaces STFT.inverse (transforms.py:71-101): per frame (hop/n) * window * irDFT(mag e^{i phase})
+ *      (what the pinv synthesis basis computes), overlap-add, divide by the squared-window envelope + eps,
+ *      scale n/hop, trim n/2 on both sides.   mag, phase : (N,K,F);  out : (N, (F-1)*hop) fp32, fully overwritten. */
+int psnd_istft(const float *mag, const float *phase, int64_t N, int64_t F, int n_fft, int hop,
+               const void *plan, float eps, float *out, void *stream);
 
 /* ---- mel projection + log + clamp: replaces transforms.py:235-243, :364-365,
  *      interface/hifi_gan.py:58-61 -------------------------------------------------------- */

@@ -14,6 +14,7 @@ Frame indexing is integer arithmetic and has exactly one flavour (bit-exact).
 import numpy as np
 
 CENTER = 0   # STFT.transform / torch.stft(center=True): pad n_fft//2, reflect
+NOPAD = 2    # no padding (kernel-internal: backward of the inverse STFT)
 HIFIGAN = 1  # Audio2Mel / interface MelSpectrogram: pad (n_fft-hop)//2, reflect, center=False
 
 
@@ -22,6 +23,8 @@ HIFIGAN = 1  # Audio2Mel / interface MelSpectrogram: pad (n_fft-hop)//2, reflect
 # ----------------------------------------------------------------------------
 def pad_amount(n_fft: int, hop: int, framing: int) -> int:
     """pytorch_sound/models/transforms.py:25 (n/2) and :352 / interface/hifi_gan.py:37 ((n-h)/2)."""
+    if framing == NOPAD:
+        return 0
     return n_fft // 2 if framing == CENTER else (n_fft - hop) // 2
 
 

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get('PSND_LIB', os.path.join(_HERE, 'libpsnd_hip.so'))   #
 PSND_OK = 0
 FRAMING_CENTER = 0
 FRAMING_HIFIGAN = 1
+FRAMING_NONE = 2
 LOG_NONE, LOG_E, LOG_10 = 0, 1, 2
 
 _c = ctypes
@@ -28,6 +29,7 @@ SIGNATURES = {
     'psnd_stft_plan_build': (_INT, [_INT, _P, _P]),
     'psnd_stft_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
     'psnd_stft_bwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
+    'psnd_istft': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _P, _F, _P, _P]),
     'psnd_mel_plan_bytes': (_c.c_size_t, [_INT, _INT]),
     'psnd_mel_plan_build': (_INT, [_INT, _INT, _P, _P]),
     'psnd_mel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P]),

@@ -15,6 +15,7 @@ extern "C" int psnd_version(void) { return 100; }  // 0.1.0
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
 static inline int64_t pad_of(int n_fft, int hop, int framing) {
+    if (framing == PSND_FRAMING_NONE) return 0;
     return framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2;
 }
 

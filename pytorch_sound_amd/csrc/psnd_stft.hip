@@ -543,10 +543,10 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     if (!wav || !plan) PSND_FAIL(PSND_E_ARG, "stft_fwd: null wav/plan");
     if ((re == nullptr) != (im == nullptr)) PSND_FAIL(PSND_E_ARG, "stft_fwd: re and im must be given together");
     if (!mag && !phase && !re) PSND_FAIL(PSND_E_ARG, "stft_fwd: no output requested");
-    if (framing != PSND_FRAMING_CENTER && framing != PSND_FRAMING_HIFIGAN) PSND_FAIL(PSND_E_ARG, "stft_fwd: framing=%d", framing);
+    if (framing < PSND_FRAMING_CENTER || framing > PSND_FRAMING_NONE) PSND_FAIL(PSND_E_ARG, "stft_fwd: framing=%d", framing);
     if (hop <= 0 || N < 0) PSND_FAIL(PSND_E_ARG, "stft_fwd: hop=%d N=%lld", hop, (long long)N);
     if (psnd_stft_plan_bytes(n_fft) == 0) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_fwd: n_fft=%d unsupported", n_fft);
-    const int pad = framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2;
+    const int pad = framing == PSND_FRAMING_NONE ? 0 : (framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2);
     if (pad < 0 || T <= pad) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: reflect padding %d needs T > pad (T=%lld)", pad, (long long)T);
     if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: T=%lld exceeds 2^31 samples per clip", (long long)T);
     const int64_t F = psnd_frame_count(T, n_fft, hop, framing);

@@ -27,17 +27,30 @@ struct StftBwdParams {
     long long T, F;
     int hop, pad, ntile, total_tiles;
     float mag_eps;
+    // inverse-STFT mode (psnd_istft): gmag = magnitude, gre = phase, gwav = output (N, T = (F-1)*hop)
+    int win_off;        // float offset of the raw window inside the plan
+    float inv_n, env_eps;
 };
 
-template <bool FROM_MAG, bool FROM_REIM>
+template <bool FROM_MAG, bool FROM_REIM, bool ISTFT>
 struct GLoad {
     const float *gmag, *gre, *gim;
-    float eps;
+    float eps, inv_n;
     bool valid;
-    // gradient wrt (re, im) of bin at offset `off`, given the recomputed X there
-    __device__ __forceinline__ void operator()(int off, float xr, float xi, float &gr, float &gi) const {
+    // gradient wrt (re, im) of bin at offset `off`, given the recomputed X there.
+    // ISTFT: the "gradient" is the spectrum itself, X = mag * e^{i phase}, scaled so that the adjoint
+    // transform below IS the inverse real DFT: 1/n for the DC / Nyquist bins (`edge`), 2/n otherwise.
+    __device__ __forceinline__ void operator()(int off, float xr, float xi, float &gr, float &gi, bool edge = false) const {
         gr = 0.f, gi = 0.f;
         if (!valid) return;
+        if constexpr (ISTFT) {
+            float sn, cs;
+            sincosf(gre[off], &sn, &cs);
+            const float m = gmag[off] * (edge ? inv_n : 2.f * inv_n);
+            gr = m * cs;
+            gi = m * sn;
+            return;
+        }
         if constexpr (FROM_MAG) {
             const float m = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, eps)));
             const float g = gmag[off] / m;   // 0/0 -> NaN exactly like autograd of sqrt at 0
@@ -51,13 +64,27 @@ struct GLoad {
     }
 };
 
+// squared-window overlap-add envelope at padded sample tp (STFT.inverse, transforms.py:85-98)
+__device__ __forceinline__ float ola_envelope(const float *win, long long tp, int n, int hop, long long F) {
+    long long f_hi = tp / hop;
+    if (f_hi > F - 1) f_hi = F - 1;
+    long long f_lo = (tp - n + hop) / hop;      // ceil((tp - n + 1) / hop) for tp - n + 1 > 0
+    if (tp - n + 1 <= 0) f_lo = 0;
+    float e = 0.f;
+    for (long long f = f_lo; f <= f_hi; ++f) {
+        const float w = win[tp - f * hop];
+        e = __builtin_fmaf(w, w, e);
+    }
+    return e;
+}
+
 __device__ __forceinline__ long long reflect64(long long i, long long T) {
     if (i < 0) i = -i;
     if (i >= T) i = 2 * (T - 1) - i;
     return i;
 }
 
-template <int R1, int L, bool FROM_MAG, bool FROM_REIM>
+template <int R1, int L, bool FROM_MAG, bool FROM_REIM, bool ISTFT = false>
 __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
     using G = Cfg<R1, L>;
     constexpr int C = G::C, NFFT = G::NFFT, FT = G::FT, P1R = G::P1R, LB = G::LB, RB = G::RB, SF = G::SF, ROW = G::ROW;
@@ -108,8 +135,9 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
             }
             const long long F = p.F;
             const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
-            GLoad<FROM_MAG, FROM_REIM> gload{FROM_MAG ? p.gmag + cbase : nullptr, FROM_REIM ? p.gre + cbase : nullptr,
-                                             FROM_REIM ? p.gim + cbase : nullptr, p.mag_eps, (f0 + f2) < F};
+            GLoad<FROM_MAG, FROM_REIM, ISTFT> gload{(FROM_MAG || ISTFT) ? p.gmag + cbase : nullptr,
+                                                    (FROM_REIM || ISTFT) ? p.gre + cbase : nullptr,
+                                                    FROM_REIM ? p.gim + cbase : nullptr, p.mag_eps, p.inv_n, (f0 + f2) < F};
             const int iF = (int)F;
             const int stepF = R1 * iF;
             const int offA = qA * iF, offB = qB * iF;
@@ -141,12 +169,12 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                     constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
                     const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * pp));
                     if constexpr (FROM_MAG) rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                    gload(pp * stepF, xkr, xki, gkr, gki);
+                    gload(pp * stepF, xkr, xki, gkr, gki, pp == 0);
                     float z0r, z0i, z1r, z1i;
                     if constexpr (pp == 0) {
                         // H[0] = 2 Re G[0], H[C] = 2 Re G[C] (the imaginary parts of the DC / Nyquist
                         // bins do not reach the real signal)
-                        gload(L * stepF, xcr, xci, gcr, gci);
+                        gload(L * stepF, xcr, xci, gcr, gci, true);
                         irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
                         uAr[0] = z0r, uAi[0] = z0i;
                     } else if constexpr (2 * pp == L) {
@@ -238,9 +266,15 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                 __syncthreads();
                 const int int_lo = NFFT - p.hop, int_hi = FT * p.hop;
                 for (int i = t; i < span_len; i += 256) {
-                    const float v = span[i];
+                    float v = span[i];
                     const long long tg = t_start + i;
-                    if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {
+                    if constexpr (ISTFT) {
+                        // no reflection: samples outside [0, T) are the trimmed n/2 margins; divide by the envelope
+                        if (tg < 0 || tg >= p.T) continue;
+                        v /= ola_envelope(p.plan + p.win_off, tg + p.pad, NFFT, p.hop, p.F) + p.env_eps;
+                        if (i >= int_lo && i < int_hi) gw[tg] = v;
+                        else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
+                    } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {
                         gw[tg] = v;
                     } else if (v != 0.f) {
                         const long long tr = reflect64(tg, p.T);
@@ -251,9 +285,17 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                 const long long tb = (f0 + fl) * p.hop - p.pad + 2 * l;
                 static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
-                    const long long t0 = reflect64(tb + 2 * L * a, p.T), t1 = reflect64(tb + 2 * L * a + 1, p.T);
-                    if (t0 >= 0 && t0 < p.T) unsafeAtomicAdd(gw + t0, zr[sl]);
-                    if (t1 >= 0 && t1 < p.T) unsafeAtomicAdd(gw + t1, zi[sl]);
+                    if constexpr (ISTFT) {
+                        const long long t0 = tb + 2 * L * a, t1 = t0 + 1;
+                        if (t0 >= 0 && t0 < p.T)
+                            unsafeAtomicAdd(gw + t0, zr[sl] / (ola_envelope(p.plan + p.win_off, t0 + p.pad, NFFT, p.hop, p.F) + p.env_eps));
+                        if (t1 >= 0 && t1 < p.T)
+                            unsafeAtomicAdd(gw + t1, zi[sl] / (ola_envelope(p.plan + p.win_off, t1 + p.pad, NFFT, p.hop, p.F) + p.env_eps));
+                    } else {
+                        const long long t0 = reflect64(tb + 2 * L * a, p.T), t1 = reflect64(tb + 2 * L * a + 1, p.T);
+                        if (t0 >= 0 && t0 < p.T) unsafeAtomicAdd(gw + t0, zr[sl]);
+                        if (t1 >= 0 && t1 < p.T) unsafeAtomicAdd(gw + t1, zi[sl]);
+                    }
                 });
             }
         }
@@ -281,7 +323,7 @@ __device__ __forceinline__ void lds_fft_radix2(float *sr, float *si, int C, int 
     }
 }
 
-template <bool FROM_MAG, bool FROM_REIM>
+template <bool FROM_MAG, bool FROM_REIM, bool ISTFT = false>
 __global__ __launch_bounds__(256) void stft_bwd_generic_kernel(StftBwdParams p, int n_fft) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = n_fft / 2;
@@ -320,6 +362,12 @@ __global__ __launch_bounds__(256) void stft_bwd_generic_kernel(StftBwdParams p, 
             gr = g * xkr, gi = g * xki;
         }
         if (FROM_REIM) gr += p.gre[off], gi += p.gim[off];
+        if (ISTFT) {
+            float sn, cs;
+            sincosf(p.gre[off], &sn, &cs);
+            const float m = p.gmag[off] * ((k == 0 || k == C) ? p.inv_n : 2.f * p.inv_n);
+            gr = m * cs, gi = m * sn;
+        }
         if (k == 0 || k == C) gr *= 2.f, gi = 0.f;
         hr[k] = gr, hi[k] = gi;
     }
@@ -335,6 +383,14 @@ __global__ __launch_bounds__(256) void stft_bwd_generic_kernel(StftBwdParams p, 
     __syncthreads();
     lds_fft_radix2(sr, si, C, t, 1.f);
     for (int m = t; m < C; m += 256) {
+        if (ISTFT) {
+            const long long t0 = s0 + 2 * m, t1 = t0 + 1;
+            if (t0 >= 0 && t0 < p.T)
+                unsafeAtomicAdd(gw + t0, 0.5f * sr[m] * win[2 * m] / (ola_envelope(win, t0 + p.pad, n_fft, p.hop, p.F) + p.env_eps));
+            if (t1 >= 0 && t1 < p.T)
+                unsafeAtomicAdd(gw + t1, 0.5f * si[m] * win[2 * m + 1] / (ola_envelope(win, t1 + p.pad, n_fft, p.hop, p.F) + p.env_eps));
+            continue;
+        }
         const long long t0 = reflect_idx(s0 + 2 * m, p.T), t1 = reflect_idx(s0 + 2 * m + 1, p.T);
         unsafeAtomicAdd(gw + t0, 0.5f * sr[m] * win[2 * m]);
         unsafeAtomicAdd(gw + t1, 0.5f * si[m] * win[2 * m + 1]);
@@ -365,6 +421,22 @@ int launch_bwd(const StftBwdParams &p, bool from_mag, bool from_reim, hipStream_
     return PSND_OK;
 }
 
+template <int R1, int L>
+int launch_istft(const StftBwdParams &p, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * Cfg<R1, L>::LDS_FLOATS;
+    int grid = p.total_tiles;
+    if (grid > 2048) grid = 2048;
+    grid = (grid + 7) & ~7;
+    auto kern = stft_bwd_kernel<R1, L, false, false, true>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: set LDS size: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    PSND_CHECK_LAUNCH("istft");
+    return PSND_OK;
+}
+
 }  // namespace
 
 using namespace psnd_stft;
@@ -376,10 +448,10 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     if ((gre == nullptr) != (gim == nullptr)) PSND_FAIL(PSND_E_ARG, "stft_bwd: gre and gim must be given together");
     if (!gmag && !gre) PSND_FAIL(PSND_E_ARG, "stft_bwd: no gradient source");
     if (gmag && !wav) PSND_FAIL(PSND_E_ARG, "stft_bwd: gmag needs wav (recompute)");
-    if (framing != PSND_FRAMING_CENTER && framing != PSND_FRAMING_HIFIGAN) PSND_FAIL(PSND_E_ARG, "stft_bwd: framing=%d", framing);
+    if (framing < PSND_FRAMING_CENTER || framing > PSND_FRAMING_NONE) PSND_FAIL(PSND_E_ARG, "stft_bwd: framing=%d", framing);
     if (hop <= 0 || N < 0) PSND_FAIL(PSND_E_ARG, "stft_bwd: hop=%d N=%lld", hop, (long long)N);
     if (psnd_stft_plan_bytes(n_fft) == 0) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd: n_fft=%d unsupported", n_fft);
-    const int pad = framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2;
+    const int pad = framing == PSND_FRAMING_NONE ? 0 : (framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2);
     if (pad < 0 || T <= pad) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: reflect padding %d needs T > pad (T=%lld)", pad, (long long)T);
     if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: T too large");
     if (N == 0) return PSND_OK;
@@ -393,6 +465,7 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     StftBwdParams p;
     p.wav = wav, p.plan = static_cast<const float *>(plan), p.gmag = gmag, p.gre = gre, p.gim = gim, p.gwav = gwav;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    p.win_off = 0, p.inv_n = 0.f, p.env_eps = 0.f;
     const Decomp *d = find_decomp(n_fft);
     if (d) {
         const int FT = 512 / d->R1;
@@ -414,5 +487,47 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     else if (!gmag && gre) hipLaunchKernelGGL((stft_bwd_generic_kernel<false, true>), grid, dim3(256), lds, s, p, n_fft);
     else hipLaunchKernelGGL((stft_bwd_generic_kernel<true, true>), grid, dim3(256), lds, s, p, n_fft);
     PSND_CHECK_LAUNCH("stft_bwd(generic)");
+    return PSND_OK;
+}
+
+// STFT.inverse (pytorch_sound/models/transforms.py:71-101): conv_transpose1d with pinv(n/h * basis)^T * window
+// == (h/n) * window * irDFT per frame, overlap-added, divided by the squared-window envelope (+eps), scaled
+// by n/h and trimmed by n/2 on both sides: out[t] = OLA(w * irfft(X_f))[t + n/2] / (env[t + n/2] + eps).
+extern "C" int psnd_istft(const float *mag, const float *phase, int64_t N, int64_t F, int n_fft, int hop,
+                          const void *plan, float eps, float *out, void *stream) {
+    if (!mag || !phase || !plan || !out) PSND_FAIL(PSND_E_ARG, "istft: null pointer");
+    if (hop <= 0 || N < 0 || F < 0) PSND_FAIL(PSND_E_ARG, "istft: hop=%d N=%lld F=%lld", hop, (long long)N, (long long)F);
+    if (psnd_stft_plan_bytes(n_fft) == 0) PSND_FAIL(PSND_E_UNSUPPORTED, "istft: n_fft=%d unsupported", n_fft);
+    const int64_t T = (F - 1) * hop;
+    if (N == 0 || F <= 1) return PSND_OK;
+    const int64_t K = n_fft / 2 + 1;
+    if (K * F >= (int64_t)1 << 31 || T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "istft: clip too long");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t me = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * (size_t)T, s);
+    if (me != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: memset: %s", hipGetErrorString(me));
+    StftBwdParams p;
+    p.wav = nullptr, p.plan = static_cast<const float *>(plan), p.gmag = mag, p.gre = phase, p.gim = nullptr, p.gwav = out;
+    p.T = T, p.F = F, p.hop = hop, p.pad = n_fft / 2, p.mag_eps = 0.f;
+    p.inv_n = 1.0f / (float)n_fft, p.env_eps = eps;
+    const Decomp *d = find_decomp(n_fft);
+    if (d) {
+        const PlanLayout lay = plan_layout(n_fft, d->R1, d->L);
+        p.win_off = lay.win;
+        const int FT = 512 / d->R1;
+        const int64_t ntile = (F + FT - 1) / FT;
+        if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "istft: too many tiles");
+        p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+        switch (n_fft) {
+            case 256: return launch_istft<16, 8>(p, s);
+            case 512: return launch_istft<16, 16>(p, s);
+            case 1024: return launch_istft<32, 16>(p, s);
+            case 2048: return launch_istft<32, 32>(p, s);
+        }
+    }
+    if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "istft(generic): grid too large");
+    p.win_off = 0, p.ntile = 0, p.total_tiles = 0;
+    const size_t lds = sizeof(float) * (size_t)(2 * n_fft + 2);
+    hipLaunchKernelGGL((stft_bwd_generic_kernel<false, false, true>), dim3((unsigned)F, (unsigned)N), dim3(256), lds, s, p, n_fft);
+    PSND_CHECK_LAUNCH("istft(generic)");
     return PSND_OK;
 }

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, ptr, stream_ptr, FRAMING_CENTER, FRAMING_HIFIGAN, LOG_NONE, LOG_E, LOG_10  # noqa: F401
+from ._lib import lib, check, ptr, stream_ptr, FRAMING_CENTER, FRAMING_HIFIGAN, FRAMING_NONE, LOG_NONE, LOG_E, LOG_10  # noqa: F401
 
 _INF = float('inf')
 
@@ -197,17 +197,56 @@ def db_to_ln(db):
     return math.log(math.pow(10.0, db / 10.0))
 
 
-def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9):
-    """STFT.inverse (transforms.py:71-101) - "next" row f1; kernel psnd_istft."""
-    fn = getattr(lib(), 'psnd_istft', None)
-    if fn is None:
-        raise _lib.PsndError('psnd_istft is not built into libpsnd_hip.so yet')
+def istft_forward(magnitude, phase, n_fft, hop, plan, eps=1e-9):
     _need_cuda(magnitude, 'magnitude')
     _need_cuda(phase, 'phase')
     magnitude, phase = magnitude.contiguous(), phase.contiguous()
     N, Kb, F = magnitude.shape
-    out = torch.empty((N, (F - 1) * hop), dtype=torch.float32, device=magnitude.device)
+    if Kb != n_fft // 2 + 1 or phase.shape != magnitude.shape:
+        raise _lib.PsndError('istft: expected (N, %d, F) magnitude and phase, got %s / %s'
+                             % (n_fft // 2 + 1, tuple(magnitude.shape), tuple(phase.shape)))
+    out = torch.empty((N, max((F - 1) * hop, 0)), dtype=torch.float32, device=magnitude.device)
     with torch.cuda.device(magnitude.device):
-        check(fn(ptr(magnitude), ptr(phase), N, F, n_fft, hop, ptr(plan), float(eps), ptr(out),
-                 stream_ptr(magnitude.device)), 'psnd_istft')
+        check(lib().psnd_istft(ptr(magnitude), ptr(phase), N, F, n_fft, hop, ptr(plan), float(eps), ptr(out),
+                               stream_ptr(magnitude.device)), 'psnd_istft')
     return out
+
+
+class IStft(torch.autograd.Function):
+    """STFT.inverse (transforms.py:71-101).  Backward: the map is linear in G = s_k * mag * e^{i phase}
+    (s = 1/n for DC/Nyquist, 2/n otherwise; their imaginary parts do not reach the signal), and its adjoint is a
+    plain windowed forward DFT (no padding) of the envelope-scaled output gradient - psnd_stft_fwd again."""
+
+    @staticmethod
+    def forward(ctx, magnitude, phase, window, plan, n_fft, hop, eps):
+        out = istft_forward(magnitude, phase, n_fft, hop, plan, eps)
+        ctx.save_for_backward(magnitude, phase, window, plan)
+        ctx.cfg = (n_fft, hop, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        magnitude, phase, window, plan = ctx.saved_tensors
+        n_fft, hop, eps = ctx.cfg
+        N, Kb, F = magnitude.shape
+        w2 = (window * window).view(1, 1, n_fft)
+        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, F, device=g.device), w2, stride=hop).view(-1)
+        p = n_fft // 2
+        gp = torch.nn.functional.pad(g.contiguous(), (p, p)) / (env + eps)
+        o = stft_forward(gp, n_fft, hop, plan, FRAMING_NONE, 0.0, False, False, True)
+        s = torch.full((Kb,), 2.0 / n_fft, device=g.device)
+        s[0] = s[-1] = 1.0 / n_fft
+        are, aim = o['re'] * s.view(1, -1, 1), o['im'] * s.view(1, -1, 1)
+        aim[:, 0] = 0
+        aim[:, -1] = 0
+        cs, sn = torch.cos(phase), torch.sin(phase)
+        g_mag = cs * are + sn * aim
+        g_phase = magnitude * (cs * aim - sn * are)
+        return g_mag, g_phase, None, None, None, None, None
+
+
+def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9, window=None):
+    """STFT.inverse - differentiable when `window` (n_fft taps, on the device) is given."""
+    if window is not None and (magnitude.requires_grad or phase.requires_grad):
+        return IStft.apply(magnitude, phase, window, plan, n_fft, hop, eps)
+    return istft_forward(magnitude, phase, n_fft, hop, plan, eps)

@@ -101,7 +101,9 @@ class STFT(nn.Module):
                                     K.FRAMING_CENTER, 0.0, False)[0]
 
     def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
-        return K.istft(magnitude, phase, self.filter_length, self.hop_length, self._plan(magnitude.device), eps)
+        # square_window = window ** 2 is the reference's buffer; the window itself comes from the plan's source
+        win = torch.from_numpy(self._window_np).to(magnitude.device)
+        return K.istft(magnitude, phase, self.filter_length, self.hop_length, self._plan(magnitude.device), eps, win)
 
     def forward(self, wav: torch.Tensor) -> torch.Tensor:  # the reference defines no forward
         raise NotImplementedError

@@ -309,3 +309,80 @@ def test_stft_adjoint_identity_full_size():
     lhs = (o['re'].double() * gre.double()).sum() + (o['im'].double() * gim.double()).sum()
     rhs = (x.double() * gw.double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs)) + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# inverse STFT - psnd_istft (STFT.inverse, "next" row f1) and the no-padding framing it needs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_fft,hop,win,N,T', [(1024, 256, None, 2, 4096), (1024, 256, 800, 2, 2816), (512, 128, None, 3, 1024),
+                                               (256, 64, 200, 2, 640), (2048, 512, None, 1, 6144), (4096, 1024, None, 1, 8192),
+                                               (1024, 256, None, 5, 9000)])
+def test_istft_vs_oracle_and_roundtrip(n_fft, hop, win, N, T):
+    K = _k()
+    dev = _dev()
+    wav = seeded_wav(T + n_fft, N, T)
+    re, im = ofe.stft_reim_f64(wav, n_fft, hop, win)
+    mag, phase = np.sqrt(re * re + im * im), np.arctan2(im, re)
+    ref = ofe.istft_f64(mag, phase, n_fft, hop, win)
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft, win)).to(dev)
+    got = K.istft(torch.from_numpy(mag.astype(np.float32)).to(dev), torch.from_numpy(phase.astype(np.float32)).to(dev),
+                  n_fft, hop, plan).cpu().numpy()
+    assert got.shape == ref.shape == (N, (mag.shape[2] - 1) * hop)
+    assert np.abs(got - ref).max() <= 5e-6 * max(np.abs(ref).max(), 1.0)
+    if win is None:      # COLA window: the inverse reproduces the waveform it came from
+        L = got.shape[1]
+        assert np.abs(got[:, :min(L, T)] - wav[:, :min(L, T)]).max() <= 1e-5
+
+
+def test_istft_golden_reference(golden):
+    """STFT.inverse of the imported reference (pinv synthesis basis + envelope), G3."""
+    K = _k()
+    dev = _dev()
+    g = golden('stft')
+    for name in ['n1024_h256', 'n1024_h256_w800', 'n512_h128', 'n256_h64_w200']:
+        n, h, w = (int(v) for v in g[name + '/params'])
+        plan = K.stft_plan(n, ofe.analysis_window(n, w)).to(dev)
+        got = K.istft(torch.from_numpy(g[name + '/mag']).to(dev), torch.from_numpy(g[name + '/phase']).to(dev), n, h, plan)
+        assert np.abs(got.cpu().numpy() - g[name + '/inverse']).max() <= 5e-6, name
+
+
+def test_stft_nopad_framing_and_istft_backward():
+    K = _k()
+    dev = _dev()
+    n_fft, hop = 1024, 256
+    wav = seeded_wav(77, 2, 5000)
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(dev)
+    o = K.stft_forward(torch.from_numpy(wav).to(dev), n_fft, hop, plan, K.FRAMING_NONE, want_mag=False, want_reim=True)
+    re, im = ofe.stft_reim_f64(wav, n_fft, hop, None, ofe.NOPAD)
+    assert o['re'].shape == re.shape == (2, 513, (5000 - 1024) // 256 + 1)
+    tol = FFT_RTOL * np.sqrt(re * re + im * im).max()
+    assert np.abs(o['re'].cpu().numpy() - re).max() <= tol and np.abs(o['im'].cpu().numpy() - im).max() <= tol
+    # gradient of sum(g * istft(mag, phase)) wrt mag and phase vs finite differences of the float64 oracle
+    F = 9
+    rs = np.random.RandomState(1)
+    mag = np.abs(rs.randn(1, 513, F)) + 0.1
+    phase = rs.uniform(-3, 3, (1, 513, F))
+    gout = rs.randn(1, (F - 1) * hop)
+    mt = torch.from_numpy(mag.astype(np.float32)).to(dev).requires_grad_(True)
+    pt = torch.from_numpy(phase.astype(np.float32)).to(dev).requires_grad_(True)
+    win = torch.from_numpy(ofe.analysis_window(n_fft)).to(dev)
+    out = K.istft(mt, pt, n_fft, hop, plan, 1e-9, win)
+    (out * torch.from_numpy(gout.astype(np.float32)).to(dev)).sum().backward()
+    f = lambda m, p: float((ofe.istft_f64(m, p, n_fft, hop) * gout).sum())  # noqa: E731
+    for (k, fr) in [(0, 0), (5, 3), (100, 4), (512, 8), (256, 1)]:
+        for arr, grad in ((mag, mt.grad), (phase, pt.grad)):
+            d = np.zeros_like(arr)
+            d[0, k, fr] = 1e-4
+            num = (f(mag + d if arr is mag else mag, phase + d if arr is phase else phase)
+                   - f(mag - d if arr is mag else mag, phase - d if arr is phase else phase)) / 2e-4
+            assert abs(float(grad[0, k, fr]) - num) <= 2e-3 * max(1.0, abs(num)), (k, fr)
+
+
+def test_stft_module_inverse_roundtrip():
+    from pytorch_sound_amd.models.transforms import STFT
+    dev = _dev()
+    m = STFT(1024, 256).to(dev)
+    wav = torch.from_numpy(seeded_wav(3, 2, 8192)).to(dev)
+    mag, phase = m.transform(wav)
+    rec = m.inverse(mag, phase)
+    assert rec.shape == (2, 8192) and float((rec - wav).abs().max()) <= 1e-5
