@@ -139,6 +139,23 @@ int psnd_conv1d_wnorm_bwd(const float *gw, const float *v, const float *g, int C
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);
 int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
 
+/* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
+ *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over
+ *      (C x T) per sample (accumulated in double), per-channel affine.  x, res (may be NULL), y : (N,C,T) fp32;
+ *      stats : (N,2) {mean, rstd} saved for backward; ws : (N,2) double scratch (caller owned, overwritten).
+ *  psnd_groupnorm1_bwd: gx (gradient wrt x and wrt res), ggamma, gbeta (C) - all fully overwritten.
+ *  psnd_softmax_keys_fwd: in place on scores (B,Tk,Tq): a = softmax over Tk of scale*s with key-padded rows at -inf,
+ *      query-padded columns set to 0 (modules.py:66-76); mask (B,T) uint8, 1 = padded, or NULL.
+ *  psnd_softmax_keys_bwd: gscores = scale * a * (gatt - sum_tk gatt*a). */
+int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
+                        int64_t T, float eps, int relu, float *y, float *stats, double *ws, void *stream);
+int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma, const float *y,
+                        const float *stats, int64_t N, int C, int64_t T, int relu, float *gx, float *ggamma,
+                        float *gbeta, double *ws, void *stream);
+int psnd_softmax_keys_fwd(float *scores, const uint8_t *mask, int64_t B, int64_t T, float scale, void *stream);
+int psnd_softmax_keys_bwd(const float *att, const float *gatt, int64_t B, int64_t T, float scale, float *gscores,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,240 @@
+// psnd_norm.hip - the non-GEMM parts of pytorch_sound/models/modules.py on gfx950:
+//   * GroupNorm(1, C)(x + residual) [+ ReLU]  (modules.py:30,58 / :98,114-116): statistics over (C x T) jointly per
+//     sample, per-channel affine - forward and backward;
+//   * the masked softmax over KEYS of MultiHeadAttention.scale_dot_att (modules.py:66-76): scale, -inf on padded
+//     key rows, softmax along dim 1 of the (B, T_key, T_query) score tensor, zero on padded query columns -
+//     forward (in place) and backward.
+// All HBM-bound, fp32, (N, C, T) / (B, T, T) layouts with the last axis contiguous.
+#include "psnd_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm(1, C): one workgroup per (channel row chunk, sample); rows are contiguous T floats.
+// pass A: ws[n] = {sum, sum of squares} of s = x + res   (double atomics: E[s^2] - mean^2 is formed in double)
+// pass B: y = (s - mean) * rstd * gamma[c] + beta[c] (ReLU optional); stats[n] = {mean, rstd}
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *x, const float *res, int C, long long T, double *ws) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const size_t base = ((size_t)n * C + c) * T;
+    float s1 = 0.f, s2 = 0.f;
+    for (long long t = threadIdx.x; t < T; t += 256) {
+        float v = x[base + t];
+        if (res) v += res[base + t];
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+    }
+    double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d1, red[4 + (threadIdx.x >> 6)] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(ws + 2 * n, red[0] + red[1] + red[2] + red[3]);
+        unsafeAtomicAdd(ws + 2 * n + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, const float *res, const float *gamma, const float *beta,
+                                                       int C, long long T, float eps, int relu, const double *ws, float *y,
+                                                       float *stats) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const double M = (double)C * (double)T;
+    const double mean = ws[2 * n] / M;
+    double var = ws[2 * n + 1] / M - mean * mean;
+    if (var < 0) var = 0;
+    const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (c == 0 && threadIdx.x == 0) stats[2 * n] = mu, stats[2 * n + 1] = rstd;
+    const float g = gamma[c] * rstd, b = beta[c] - mu * g;
+    const size_t base = ((size_t)n * C + c) * T;
+    for (long long t = threadIdx.x; t < T; t += 256) {
+        float v = x[base + t];
+        if (res) v += res[base + t];
+        v = __builtin_fmaf(v, g, b);
+        if (relu) v = fmaxf(v, 0.f);
+        y[base + t] = v;
+    }
+}
+
+// backward pass A: per row (n, c):  a = sum_t gy',  b = sum_t gy' * xhat   (gy' = gy * [y > 0] under ReLU)
+//   ggamma[c] += b ; gbeta[c] += a ; ws[n] += {gamma[c] * a, gamma[c] * b}
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *gy, const float *x, const float *res, const float *gamma,
+                                                            const float *y, const float *stats, int C, long long T, int relu,
+                                                            double *ws, float *ggamma, float *gbeta) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const float mu = stats[2 * n], rstd = stats[2 * n + 1];
+    const size_t base = ((size_t)n * C + c) * T;
+    float a = 0.f, b = 0.f;
+    for (long long t = threadIdx.x; t < T; t += 256) {
+        float g = gy[base + t];
+        if (relu && !(y[base + t] > 0.f)) g = 0.f;
+        float v = x[base + t];
+        if (res) v += res[base + t];
+        a += g;
+        b = __builtin_fmaf(g, (v - mu) * rstd, b);
+    }
+    a = wave_sum(a), b = wave_sum(b);
+    __shared__ float red[8];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a, red[4 + (threadIdx.x >> 6)] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ta = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
+        unsafeAtomicAdd(gbeta + c, ta);
+        unsafeAtomicAdd(ggamma + c, tb);
+        unsafeAtomicAdd(ws + 2 * n, (double)gamma[c] * (double)ta);
+        unsafeAtomicAdd(ws + 2 * n + 1, (double)gamma[c] * (double)tb);
+    }
+}
+
+// backward pass B: gx = rstd * (gamma gy' - S1/M - xhat * S2/M)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *gy, const float *x, const float *res, const float *gamma,
+                                                           const float *y, const float *stats, int C, long long T, int relu,
+                                                           const double *ws, float *gx) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const double M = (double)C * (double)T;
+    const float mu = stats[2 * n], rstd = stats[2 * n + 1];
+    const float m1 = (float)(ws[2 * n] / M), m2 = (float)(ws[2 * n + 1] / M);
+    const float gc = gamma[c];
+    const size_t base = ((size_t)n * C + c) * T;
+    for (long long t = threadIdx.x; t < T; t += 256) {
+        float g = gy[base + t];
+        if (relu && !(y[base + t] > 0.f)) g = 0.f;
+        float v = x[base + t];
+        if (res) v += res[base + t];
+        const float xh = (v - mu) * rstd;
+        gx[base + t] = rstd * (g * gc - m1 - xh * m2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// softmax over keys.  s: (B, Tk, Tq), query axis contiguous.  One workgroup = 64 query columns x all key rows;
+// thread (row group rg = tid / 64, column c = tid % 64): online (max, sum) over its rows, combined through LDS.
+//   fwd:  a = softmax_tk( scale * s[tk][tq] with key-padded rows -> -inf ), query-padded columns -> 0   (in place)
+//   bwd:  gs = scale * a * (ga - sum_tk ga * a)     (masked positions have a = 0 -> gs = 0, as in the reference where
+//          the masks are written through .data)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_keys_fwd_kernel(float *s, const unsigned char *mask, long long T, float scale) {
+    const int b = blockIdx.y;
+    const long long tq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    float *sb = s + (size_t)b * T * T;
+    const unsigned char *mb = mask ? mask + (size_t)b * T : nullptr;
+    float mx = -INFINITY, sum = 0.f;
+    if (tq < T) {
+        for (long long tk = rg; tk < T; tk += 4) {
+            if (mb && mb[tk]) continue;
+            const float v = sb[tk * T + tq] * scale;
+            if (v > mx) {
+                sum = sum * __expf(mx - v) + 1.f;
+                mx = v;
+            } else {
+                sum += __expf(v - mx);
+            }
+        }
+    }
+    __shared__ float smx[4][64], ssum[4][64];
+    smx[rg][threadIdx.x & 63] = mx;
+    ssum[rg][threadIdx.x & 63] = sum;
+    __syncthreads();
+    const int cc = threadIdx.x & 63;
+    float gm = fmaxf(fmaxf(smx[0][cc], smx[1][cc]), fmaxf(smx[2][cc], smx[3][cc]));
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ssum[i][cc] > 0.f) gs += ssum[i][cc] * __expf(smx[i][cc] - gm);
+    if (tq >= T) return;
+    const bool qpad = mb && mb[tq];
+    const float inv = 1.f / gs;     // every key padded -> 0/0 = NaN, exactly what softmax of an all -inf column gives
+    for (long long tk = rg; tk < T; tk += 4) {
+        float a = 0.f;
+        if (!qpad && !(mb && mb[tk])) a = __expf(sb[tk * T + tq] * scale - gm) * inv;
+        else if (!qpad && gs == 0.f) a = NAN;
+        sb[tk * T + tq] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_keys_bwd_kernel(const float *a, const float *ga, long long T, float scale, float *gs) {
+    const int b = blockIdx.y;
+    const long long tq = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const size_t base = (size_t)b * T * T;
+    float dot = 0.f;
+    if (tq < T)
+        for (long long tk = rg; tk < T; tk += 4) dot = __builtin_fmaf(ga[base + tk * T + tq], a[base + tk * T + tq], dot);
+    __shared__ float sd[4][64];
+    sd[rg][threadIdx.x & 63] = dot;
+    __syncthreads();
+    const int cc = threadIdx.x & 63;
+    const float d = sd[0][cc] + sd[1][cc] + sd[2][cc] + sd[3][cc];
+    if (tq >= T) return;
+    for (long long tk = rg; tk < T; tk += 4) {
+        const size_t o = base + tk * T + tq;
+        gs[o] = scale * a[o] * (ga[o] - d);
+    }
+}
+
+}  // namespace
+
+extern "C" int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
+                                   int64_t T, float eps, int relu, float *y, float *stats, double *ws, void *stream) {
+    if (!x || !gamma || !beta || !y || !stats || !ws) PSND_FAIL(PSND_E_ARG, "groupnorm1_fwd: null pointer");
+    if (N < 0 || C <= 0 || T <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "groupnorm1_fwd: N=%lld C=%d T=%lld", (long long)N, C, (long long)T);
+    if (N == 0) return PSND_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)N, s);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "groupnorm1_fwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, x, res, C, (long long)T, ws);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, x, res, gamma, beta, C, (long long)T, eps, relu, ws, y, stats);
+    PSND_CHECK_LAUNCH("groupnorm1_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma, const float *y,
+                                   const float *stats, int64_t N, int C, int64_t T, int relu, float *gx, float *ggamma,
+                                   float *gbeta, double *ws, void *stream) {
+    if (!gy || !x || !gamma || !stats || !gx || !ggamma || !gbeta || !ws || (relu && !y)) PSND_FAIL(PSND_E_ARG, "groupnorm1_bwd: null pointer");
+    if (N < 0 || C <= 0 || T <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "groupnorm1_bwd: bad shape");
+    if (N == 0) return PSND_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)N, s);
+    if (e == hipSuccess) e = hipMemsetAsync(ggamma, 0, sizeof(float) * (size_t)C, s);
+    if (e == hipSuccess) e = hipMemsetAsync(gbeta, 0, sizeof(float) * (size_t)C, s);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "groupnorm1_bwd: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws,
+                       ggamma, gbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws, gx);
+    PSND_CHECK_LAUNCH("groupnorm1_bwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_softmax_keys_fwd(float *scores, const uint8_t *mask, int64_t B, int64_t T, float scale, void *stream) {
+    if (!scores) PSND_FAIL(PSND_E_ARG, "softmax_keys_fwd: null pointer");
+    if (B < 0 || T <= 0 || B > 65535) PSND_FAIL(PSND_E_SHAPE, "softmax_keys_fwd: B=%lld T=%lld", (long long)B, (long long)T);
+    if (B == 0) return PSND_OK;
+    hipLaunchKernelGGL(softmax_keys_fwd_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), scores, mask, (long long)T, scale);
+    PSND_CHECK_LAUNCH("softmax_keys_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_softmax_keys_bwd(const float *att, const float *gatt, int64_t B, int64_t T, float scale, float *gscores,
+                                     void *stream) {
+    if (!att || !gatt || !gscores) PSND_FAIL(PSND_E_ARG, "softmax_keys_bwd: null pointer");
+    if (B < 0 || T <= 0 || B > 65535) PSND_FAIL(PSND_E_SHAPE, "softmax_keys_bwd: bad shape");
+    if (B == 0) return PSND_OK;
+    hipLaunchKernelGGL(softmax_keys_bwd_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), att, gatt, (long long)T, scale, gscores);
+    PSND_CHECK_LAUNCH("softmax_keys_bwd");
+    return PSND_OK;
+}

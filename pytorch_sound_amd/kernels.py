@@ -250,3 +250,69 @@ def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9, window=None):
     if window is not None and (magnitude.requires_grad or phase.requires_grad):
         return IStft.apply(magnitude, phase, window, plan, n_fft, hop, eps)
     return istft_forward(magnitude, phase, n_fft, hop, plan, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# transformer blocks (models/modules.py): GroupNorm(1, C)(x + res) and the masked softmax over keys
+# ---------------------------------------------------------------------------------------------
+class GroupNorm1(torch.autograd.Function):
+    """y = GroupNorm(1, C)(x + res) [-> ReLU]: statistics over (C x T) per sample (modules.py:58, :114-116)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, relu):
+        _need_cuda(x, 'x')
+        x = x.contiguous()
+        res = None if res is None else res.contiguous()
+        N, C, T = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((N, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((N, 2), dtype=torch.float64, device=x.device)
+        g32, b32 = gamma.detach().contiguous(), beta.detach().contiguous()
+        with torch.cuda.device(x.device):
+            check(lib().psnd_groupnorm1_fwd(ptr(x), ptr(res), ptr(g32), ptr(b32), N, C, T, float(eps), int(relu), ptr(y),
+                                            ptr(stats), ptr(ws), stream_ptr(x.device)), 'psnd_groupnorm1_fwd')
+        ctx.relu, ctx.has_res = bool(relu), res is not None
+        ctx.save_for_backward(x, res, g32, y if relu else None, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, res, g32, y, stats = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, T = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty((N, 2), dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_groupnorm1_bwd(ptr(gy), ptr(x), ptr(res), ptr(g32), ptr(y), ptr(stats), N, C, T, int(ctx.relu),
+                                            ptr(gx), ptr(gg), ptr(gb), ptr(ws), stream_ptr(x.device)), 'psnd_groupnorm1_bwd')
+        return gx, (gx if ctx.has_res else None), gg, gb, None, None
+
+
+class SoftmaxKeys(torch.autograd.Function):
+    """att = softmax over keys (dim 1) of scale * scores, key-padded rows -> -inf before, query-padded columns -> 0
+    after (modules.py:66-76).  Works in place on a fresh copy of `scores`."""
+
+    @staticmethod
+    def forward(ctx, scores, mask_u8, scale):
+        _need_cuda(scores, 'scores')
+        att = scores.contiguous().clone()
+        B, T, _ = att.shape
+        with torch.cuda.device(att.device):
+            check(lib().psnd_softmax_keys_fwd(ptr(att), ptr(mask_u8), B, T, float(scale), stream_ptr(att.device)),
+                  'psnd_softmax_keys_fwd')
+        ctx.scale = float(scale)
+        ctx.save_for_backward(att)
+        return att
+
+    @staticmethod
+    def backward(ctx, gatt):
+        (att,) = ctx.saved_tensors
+        gatt = gatt.contiguous()
+        B, T, _ = att.shape
+        gs = torch.empty_like(att)
+        with torch.cuda.device(att.device):
+            check(lib().psnd_softmax_keys_bwd(ptr(att), ptr(gatt), B, T, ctx.scale, ptr(gs), stream_ptr(att.device)),
+                  'psnd_softmax_keys_bwd')
+        return gs, None, None

@@ -17,6 +17,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _hip_ok(x: torch.Tensor) -> bool:
+    """fp32 CUDA tensors take the hand-written kernels (psnd_groupnorm1_*, psnd_softmax_keys_*); CPU tensors use the
+    torch formulation that the golden tests pin (tests/test_modules_golden.py)."""
+    return x.is_cuda and x.dtype == torch.float32
+
+
+def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """GroupNorm(1, C)(x + residual) [-> ReLU]"""
+    if _hip_ok(x):
+        from pytorch_sound_amd import kernels as K
+        return K.GroupNorm1.apply(x, residual, norm.weight, norm.bias, norm.eps, relu)
+    y = norm(x + residual)
+    return F.relu(y) if relu else y
+
+
 class MultiHeadAttention(nn.Module):
 
     def __init__(self, hidden_dim: int, heads: int, dropout_rate: float):
@@ -46,12 +61,17 @@ class MultiHeadAttention(nn.Module):
         x = self.linear(self._unfold_heads(x))
         if self.drop_out is not None:
             x = self.drop_out(x)
-        return self.layernorm(x + input), att
+        return _add_norm(self.layernorm, x, input), att
 
     @staticmethod
     def scale_dot_att(k: torch.Tensor, v: torch.Tensor, q: torch.Tensor,
                       att_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         """k, v, q: (B, d, T); att_mask: (B, T) bool or None -> (B, d, T), (B, T_key, T_query)."""
+        if _hip_ok(q):
+            from pytorch_sound_amd import kernels as K
+            mask_u8 = None if att_mask is None else att_mask.to(torch.uint8).contiguous()
+            att = K.SoftmaxKeys.apply(torch.bmm(k.transpose(1, 2), q), mask_u8, 1.0 / math.sqrt(k.size(1)))
+            return torch.bmm(v, att), att
         scores = torch.bmm(k.transpose(1, 2), q) / math.sqrt(k.size(1))
         if att_mask is not None:
             scores = scores.masked_fill(att_mask.unsqueeze(2), -float('inf'))     # padded keys
@@ -81,7 +101,7 @@ class PointwiseFeedForward(nn.Module):
         x = self.ff(input)
         if self.drop_out is not None:
             x = self.drop_out(x)
-        return self.act(self.layernorm(x + input))
+        return _add_norm(self.layernorm, x, input, relu=True)
 
 
 class PositionalEncoding(nn.Module):

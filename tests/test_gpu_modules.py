@@ -1,0 +1,97 @@
+"""Transformer blocks on the GPU: psnd_groupnorm1_* and psnd_softmax_keys_* inside MultiHeadAttention /
+PointwiseFeedForward against the imported reference's outputs and gradients (tests/golden/modules.npz) and against
+the torch formulation at BASELINE config-4-like sizes.  fp32 throughout: tolerance 2e-5 of max (outputs),
+1e-4 (gradients; library GEMM reassociation + fast exp)."""
+import numpy as np
+import pytest
+import torch
+
+from test_modules_golden import sd_from, close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mha_ffn_golden_on_gpu(golden):
+    from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward
+    dev = torch.device('cuda:0')
+    g = golden('modules')
+    for tag in ('nomask', 'mask'):
+        mha = MultiHeadAttention(16, 4, 0.0)
+        mha.load_state_dict(sd_from(g, 'mha/sd/'))
+        mha.to(dev)
+        x = torch.from_numpy(g['mha/x']).to(dev).requires_grad_(True)
+        mask = torch.from_numpy(g['mha/mask']).to(dev) if tag == 'mask' else None
+        y, att = mha(x, mask)
+        (y * torch.from_numpy(g['mha/g']).to(dev)).sum().backward()
+        assert close(y, g['mha/%s/y' % tag]) and close(att, g['mha/%s/att' % tag])
+        assert close(x.grad, g['mha/%s/gx' % tag], 1e-4)
+        for k, p in mha.named_parameters():
+            assert close(p.grad, g['mha/%s/g/%s' % (tag, k)], 1e-4), k
+    ffn = PointwiseFeedForward(16, 0.0)
+    ffn.load_state_dict(sd_from(g, 'ffn/sd/'))
+    ffn.to(dev)
+    x = torch.from_numpy(g['mha/x']).to(dev).requires_grad_(True)
+    y = ffn(x)
+    (y * torch.from_numpy(g['mha/g']).to(dev)).sum().backward()
+    assert close(y, g['ffn/y']) and close(x.grad, g['ffn/gx'], 1e-4)
+    for k, p in ffn.named_parameters():
+        assert close(p.grad, g['ffn/g/' + k], 1e-4), k
+
+
+@pytest.mark.parametrize('N,C,T,relu,with_res', [(3, 256, 700, False, True), (2, 64, 1292, True, True), (4, 16, 33, False, False)])
+def test_groupnorm1_vs_torch(N, C, T, relu, with_res):
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N + C)
+    x = (torch.randn(N, C, T, device=dev) * 2 + 0.7).requires_grad_(True)
+    r = torch.randn(N, C, T, device=dev).requires_grad_(True) if with_res else None
+    gn = torch.nn.GroupNorm(1, C).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(C) * 0.3 + 1)
+        gn.bias.copy_(torch.randn(C) * 0.2)
+    g = torch.randn(N, C, T, device=dev)
+    ref = gn((x + r).double() if with_res else x.double()) if False else None
+    xs = x.double() + (r.double() if with_res else 0)
+    gd = torch.nn.GroupNorm(1, C).to(dev).double()
+    gd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    rr = r.detach().double().requires_grad_(True) if with_res else None
+    yr = gd(xr + rr if with_res else xr)
+    if relu:
+        yr = torch.relu(yr)
+    (yr * g.double()).sum().backward()
+    y = K.GroupNorm1.apply(x, r, gn.weight, gn.bias, gn.eps, relu)
+    (y * g).sum().backward()
+    torch.cuda.synchronize()
+    tol = lambda a, b, rt: float((a.double() - b).abs().max()) <= rt * float(b.abs().max())  # noqa: E731
+    assert tol(y, yr, 3e-6)
+    assert tol(x.grad, xr.grad, 2e-5)
+    if with_res:
+        assert tol(r.grad, rr.grad, 2e-5)
+    assert tol(gn.weight.grad, gd.weight.grad, 2e-5) and tol(gn.bias.grad, gd.bias.grad, 2e-5)
+
+
+def test_softmax_keys_large_with_mask():
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(1)
+    B, T = 8, 1292
+    s = torch.randn(B, T, T, device=dev) * 3
+    lens = [1292, 1000, 700, 173, 1292, 64, 900, 500]
+    mask = torch.zeros(B, T, dtype=torch.bool, device=dev)
+    for i, L in enumerate(lens):
+        mask[i, L:] = True
+    ga = torch.randn(B, T, T, device=dev)
+    sd = s.double().requires_grad_(True)
+    sc = (sd / 8.0).masked_fill(mask.unsqueeze(2), -float('inf'))
+    ref = torch.softmax(sc, 1).masked_fill(mask.unsqueeze(1), 0.0)
+    (ref * ga.double()).sum().backward()
+    sx = s.clone().requires_grad_(True)
+    att = K.SoftmaxKeys.apply(sx, mask.to(torch.uint8), 1.0 / 8.0)
+    (att * ga).sum().backward()
+    torch.cuda.synchronize()
+    assert float((att.double() - ref).abs().max()) <= 2e-6
+    assert float((sx.grad.double() - sd.grad).abs().max()) <= 2e-6 * max(1.0, float(sd.grad.abs().max()))
+    a = att[3]
+    assert float(a[173:, :].abs().max()) == 0 and float(a[:, 173:].abs().max()) == 0
+    assert torch.allclose(a[:, :173].sum(0), torch.ones(173, device=dev), atol=1e-5)
