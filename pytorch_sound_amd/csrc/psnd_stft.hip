@@ -20,6 +20,7 @@
 //           instruction writes 64-B (128-B) runs of the (N,K,F) frame-fastest output.
 // The only LDS round trip is the transposing exchange between the passes (4 KB/frame each way).
 #include "psnd_stft_pass.h"
+#include "psnd_pk.h"
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
@@ -40,7 +41,20 @@ struct StftFwdParams {
     int hop, pad, ntile, total_tiles;
     float mag_eps;
     int ablate;   // debug only (PSND_ABLATE): bit1 skip global stores
+#ifdef PSND_TRACE
+    long long *trace;   // tools/trace_stft.py: 8 s_memtime stamps per wave
+    int trace_iter;     // which tile iteration of a persistent workgroup is stamped
+#endif
 };
+#ifdef PSND_TRACE
+#define PSND_STAMP(i_)                                                                               \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0 && p.trace && psnd_it == p.trace_iter)                           \
+            p.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PSND_STAMP(i_)
+#endif
 
 // Output writer.  Buffer stores: the resource descriptor (clip base + first frame of the tile) and the
 // row offset (soff = bin * F * 4, wave-uniform) live in SGPRs, the per-thread part (voff) is ONE
@@ -193,49 +207,189 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(StftFwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// n_fft = 1024 kernel (C = 32 x 16), restructured around the VECTOR-MEMORY pipeline, which is what
-// bounded the first version (rocprof: ~300 L1 accesses per frame - every sample fetched by 4
-// overlapping frames with 8-byte loads - while VALU sat at 24 %):
+// n_fft = 1024 kernel (C = 32 x 16).  Two findings shaped it:
+//  (1) the VECTOR-MEMORY pipeline bounded the first version (rocprof: ~300 L1 accesses per frame - every
+//      sample fetched by 4 overlapping frames with 8-byte loads):
 //   * the tile's contiguous waveform span ((FT-1)*hop + n samples, 19 KB) is fetched ONCE with
 //     16-byte loads and parked in LDS (reflect indexing is resolved in this fill, so there is no
-//     per-frame edge path); pass-1 lanes take their taps with ds_read_b64.  The span is laid out
-//     with 32 pad floats per 256 so that the 2 frames of a ds_read_b64 half-wave hit disjoint banks;
+//     per-frame edge path); pass-1 lanes take their taps with ds_read_b64.  The span carries 4 pad
+//     floats per 256 so that the 2 frames of a ds_read_b64 half-wave (frames fl and fl+8) hit
+//     disjoint banks;
 //   * the 32 q-rows of the exchange travel in two halves (rows 0..15, then 16..31): every pass-2
 //     thread (pair qq) needs one row of each half (qq and 32-qq); the span buffer aliases the
 //     exchange area -> 44 KB LDS per workgroup, 3 workgroups per CU.
+//  (2) all complex arithmetic is PACKED (psnd_pk.h: one VGPR pair per complex value, v_pk_add/mul/fma_f32):
+//      1426 scalar fp32 instructions per thread became 725 packed ones, VALU busy time per wave fell from
+//      6.2 k to 3.6 k cycles (SQ_ACTIVE_INST_VALU).  Measured issue cost on gfx950 (tools/mb/mb_valu.hip, 4
+//      waves/SIMD): v_add_f32 2.8, v_fma_f32 4.2, v_pk_* 5.1, v_sqrt_f32 8.2 cycles per wave instruction - a
+//      packed op is worth 1.2 ... 1.9 scalar ones, not 2.  The exchange holds (re, im) pairs:
+//      ds_write_b64 per value, ds_read_b128 per two values, zero bank conflicts (SQ_LDS_BANK_CONFLICT = 0).
+//  (3) what is left (tools/trace_stft.py, s_memtime stamps per phase; PSND_ABLATE A/B runs, 1024 clips x 2 s):
+//      everything but the real split + magnitude + stores runs in 78 us, adding that arithmetic WITHOUT its
+//      stores 143 us, the full kernel 180 us (3.0 TB/s).  A workgroup lives ~20 k cycles of which ~7 k are the
+//      prologue (its loads queue behind the stores of the workgroups finishing on the same CU), and the three
+//      waves a SIMD holds are rarely all runnable, so a VALU instruction costs ~8 cycles instead of 4-5.
+//      Tried and measured WORSE: persistent workgroups with the next span prefetched (the prefetch loads stall
+//      ~9 k cycles behind the previous tile's stores in the CU's in-order vector-memory queue: 200 us), four
+//      exchange rounds of 8 rows for 30 KB LDS and 4 workgroups/CU (8 barriers per tile: 200 us), an L2
+//      prefetch of the span of a later workgroup (185 us).
 // ---------------------------------------------------------------------------------------------
-template <bool MAG, bool PHASE, bool REIM, int SPV>
+// Output of one bin in registers (only the requested members are ever touched).
+struct OutVal {
+    float m, ph, re, im;
+};
+
+template <bool MAG, bool PHASE, bool REIM>
+struct EmitPk {
+    __amdgpu_buffer_rsrc_t rmag, rphase, rre, rim;
+    v2f eps2;
+    bool valid;
+    bool nostore = false;   // PSND_ABLATE bit 2 (value 4): all the arithmetic, no store reaches memory
+    __device__ __forceinline__ EmitPk(float *mag, float *phase, float *re, float *im, size_t base, int bytes, float eps_,
+                                      bool valid_)
+        : eps2(v2f{eps_, 0.f}), valid(valid_) {
+        if constexpr (MAG) rmag = make_uniform_rsrc(mag + base, bytes);
+        if constexpr (PHASE) rphase = make_uniform_rsrc(phase + base, bytes);
+        if constexpr (REIM) {
+            rre = make_uniform_rsrc(re + base, bytes);
+            rim = make_uniform_rsrc(im + base, bytes);
+        }
+    }
+    // x (or its conjugate) -> the values to store
+    template <bool CONJ>
+    __device__ __forceinline__ OutVal make(v2f x) const {
+        OutVal o;
+        if constexpr (MAG) {
+            const v2f sq = pk::fma(x, x, eps2);
+            o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        }
+        if constexpr (PHASE) o.ph = atan2f(CONJ ? -x.y : x.y, x.x);
+        if constexpr (REIM) {
+            o.re = x.x;
+            o.im = CONJ ? -x.y : x.y;
+        }
+        return o;
+    }
+    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+        if constexpr (MAG) if (nostore && o.m > -1.f) return;
+        if constexpr (MAG) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.m), rmag, voff, soff, PSND_STORE_AUX);
+        if constexpr (PHASE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.ph), rphase, voff, soff, PSND_STORE_AUX);
+        if constexpr (REIM) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.re), rre, voff, soff, PSND_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.im), rim, voff, soff, PSND_STORE_AUX);
+        }
+    }
+};
+
+// za = Z'[k], zb = Z'[C-k], v = v_k  ->  xk = X[k] = S + E,  xc = S - E with X[C-k] = conj(xc)
+__device__ __forceinline__ void rfft_pair_pk(v2f za, v2f zb, v2f v, v2f &xk, v2f &xc) {
+    const v2f s = pk::fma(zb, v2f{1.f, -1.f}, za);     // za + conj(zb)
+    const v2f d = pk::fma(zb, v2f{-1.f, 1.f}, za);     // za - conj(zb)
+    const v2f e = pk::cmul(d, v);
+    xk = s + e;
+    xc = s - e;
+}
+
+// real-FFT split of the two butterflies a thread holds + output (packed twin of post_emit): lower bins are
+// stored at once, their mirrors are parked (already reduced to the values to store) and written
+// afterwards in ASCENDING row order.
+template <int R1, int L, class EmitT>
+__device__ __forceinline__ void post_emit_pk(v2f (&za)[L], v2f (&zb)[L], bool special, int qA, int qB, const float *s_vk,
+                                             const EmitT &emit, int iF, int col) {
+    constexpr int LB = ct::ilog2(L);
+    const int stepF = R1 * iF * 4;
+    const int offA = qA * iF * 4 + col, offB = qB * iF * 4 + col;
+    auto vk = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const v2f *>(s_vk + 2 * k); };
+    OutVal h1[L / 2], h2[L / 2];
+    v2f xk, xc;
+    if (!special) {
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+            rfft_pair_pk(za[sa], zb[sb], vk(qA + R1 * pp), xk, xc);      // bins qA + R1 pp | qB + R1 (L-1-pp)
+            emit.store(offA, pp * stepF, emit.template make<false>(xk));
+            h1[pp] = emit.template make<true>(xc);
+            rfft_pair_pk(zb[sa], za[sb], vk(qB + R1 * pp), xk, xc);      // bins qB + R1 pp | qA + R1 (L-1-pp)
+            emit.store(offB, pp * stepF, emit.template make<false>(xk));
+            h2[pp] = emit.template make<true>(xc);
+        });
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = L / 2 - 1 - decltype(pc)::value;
+            emit.store(offA, (L - 1 - pp) * stepF, h2[pp]);
+            emit.store(offB, (L - 1 - pp) * stepF, h1[pp]);
+        });
+    } else {
+        // butterfly q = 0: bins R1*p pair with R1*(L-p); p = 0 gives X[0] and X[C].  butterfly q = R1/2: bins
+        // R1/2 + R1*p pair with R1/2 + R1*(L-1-p)
+        OutVal hc;
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            {
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
+                rfft_pair_pk(za[sa], za[sb], vk(R1 * pp), xk, xc);
+                emit.store(col, pp * stepF, emit.template make<false>(xk));
+                if constexpr (pp == 0) hc = emit.template make<true>(xc);
+                else h1[pp] = emit.template make<true>(xc);
+            }
+            {
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                rfft_pair_pk(zb[sa], zb[sb], vk(R1 / 2 + R1 * pp), xk, xc);
+                emit.store(offB, pp * stepF, emit.template make<false>(xk));
+                h2[pp] = emit.template make<true>(xc);
+            }
+        });
+        {   // middle bin C/2 (self-paired)
+            constexpr int sm = ct::bitrev(L / 2, LB);
+            rfft_pair_pk(za[sm], za[sm], vk(R1 * (L / 2)), xk, xc);
+            emit.store(col, (L / 2) * stepF, emit.template make<false>(xk));
+        }
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = L / 2 - 1 - decltype(pc)::value;
+            emit.store(offB, (L - 1 - pp) * stepF, h2[pp]);                       // bin R1/2 + R1 (L-1-pp)
+            if constexpr (pp != 0) emit.store(col, (L - pp) * stepF, h1[pp]);     // bin R1 (L-pp)
+        });
+        emit.store(col, L * stepF, hc);                                           // bin C (Nyquist)
+    }
+}
+
+constexpr int kN1024Sfh = 16 * 16 * 2 + 4;   // exchange frame stride (floats): 516/4 odd -> b128 reads conflict-free,
+                                             // 8*516 = 32 (mod 64) -> the b64 writes of frames fl, fl+8 disjoint
+constexpr int kN1024TabFloats = 2 * 16 * 68 + 516;
+// exchange area (floats): half of the q-rows for 16 frames, or the tile's waveform span (+ 4 pad floats per 256)
+inline int n1024_area_floats(int hop) {
+    const int span = 15 * hop + 1024;
+    const int spanp = span + 4 * (span / 256 + 1);
+    return spanp > 16 * kN1024Sfh ? spanp : 16 * kN1024Sfh;
+}
+
+template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST>
 __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p) {
     constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5;
     constexpr int HR = R1 / 2;          // rows per exchange half
-    constexpr int SFH = HR * L + 4;     // frame stride of a half (260; 260/4 odd -> b128 conflict-free)
+    constexpr int SFH = kN1024Sfh;
     constexpr int TAB = 2 * L * ROW + VKP;
-    constexpr int SPV_MAX = SPV;        // 16-byte span pieces per thread (5 covers hop <= 256)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wt = smem;
     float *s_tw = s_wt + L * ROW;
     float *s_vk = s_tw + L * ROW;
-    float *s_xr = s_vk + VKP;           // exchange (re plane), also the span buffer
-    float *s_xi = s_xr + FT * SFH;
-    float *s_span = s_xr;
+    float *s_x = s_vk + VKP;            // exchange [frame][row][l] of (re, im), also the span buffer
+    float *s_span = s_x;
     const int t = threadIdx.x;
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.plan);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
-        for (int i = t; i < TAB / 4; i += 256) dst[i] = src[i];
-    }
+#ifdef PSND_TRACE
+    int psnd_it = p.trace_iter;      // prologue stamps always taken
+#endif
+    PSND_STAMP(0);
 
-    const int fl = t >> 4, l = t & 15;                 // pass-1 identity
-    const int f2 = t & 15;                             // pass-2 identity
+    const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);   // pass-1 identity: half-waves hold frames fl, fl+8
+    const int f2 = t & 15;                                      // pass-2 identity
     const int qq = (t >> 6) + 4 * ((t >> 4) & 3);
     const bool special = (qq == 0);
     const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
     const int rowA = qq, rowB = special ? 0 : HR - qq; // row inside its half
     const int hop = p.hop;
     const int span_len = (FT - 1) * hop + NFFT;        // samples a tile touches
-    // span position of sample s: s + skew * (s / 256); skew = 32 floats when frames start on 256-sample
-    // boundaries (the two frames of a ds_read_b64 half-wave then hit disjoint banks), else 0
-    const int skew = (hop % 256 == 0) ? 32 : 0;
+    // span position of sample s: s + skew * (s / 256)
+    const int skew = (hop % 256 == 0) ? 4 : 0;
 
     // The span of tile t+1 is REQUESTED (into SPV registers) before the stores of tile t are issued:
     // gfx9 has one in-order vmcnt for loads and stores, so a wait for loads issued AFTER the stores
@@ -282,17 +436,40 @@ __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p)
     // L2 keeps partially written lines only briefly; PSND_ABLATE=8 selects it for A/B runs)
     const TileWalk tw = p.ablate & 8 ? tile_run(p.total_tiles) : tile_walk(p.total_tiles);
     if (tw.first < tw.end) {
+        // every global load of the prologue is in flight before the first wait: span first (HBM), then the
+        // tables (L2); the first barrier of the tile loop publishes both
         request_span(tw.first);
-        __syncthreads();                 // tables staged
+        constexpr int TV = (TAB / 4 + 255) / 256;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.plan);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        f32x4 tv[TV];
+        static_for<0, TV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if (t + 256 * j < TAB / 4) tv[j] = src[t + 256 * j];
+        });
+        static_for<0, TV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if (t + 256 * j < TAB / 4) dst[t + 256 * j] = tv[j];
+        });
         commit_span();
+        PSND_STAMP(1);
     }
-    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+    int tile = tw.first;
+    if (tile < tw.end) do {              // one trip when !PERSIST (one tile per workgroup): no loop, nothing hoisted
         const int clip = tile / p.ntile;
         const long long f0 = (long long)(tile - clip * p.ntile) * FT;
-        const bool more = tile + tw.step < tw.end;
-        float zr[R1], zi[R1];
+        const bool more = PERSIST && (tile + tw.step < tw.end);
+        v2f z[R1];
+#ifdef PSND_TRACE
+        psnd_it = (tile - tw.first) / tw.step;
+#endif
 
         __syncthreads();                 // span(t) visible to every wave
+        PSND_STAMP(2);
+#ifdef PSND_TRACE
+        if (PERSIST && (threadIdx.x & 63) == 0 && p.trace && psnd_it == p.trace_iter + 1)   // slot 7 = next tile may start
+            p.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
         {   // taps of lane l of frame fl: samples fl*hop + 2*(l + 16 a) + {0,1}.  Affine addressing: one base
             // per group of 8 taps (the bank skew steps once per 256 samples), immediates inside the group.
             const int sb = fl * hop + 2 * l;
@@ -302,30 +479,30 @@ __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p)
                 const float *tb = tb0 + g * (256 + skew);
                 static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = 8 * g + decltype(ac)::value;
-                    const f32x2 v = *reinterpret_cast<const f32x2 *>(tb + 2 * L * (a - 8 * g));
-                    zr[a] = v.x;
-                    zi[a] = v.y;
+                    z[a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
                 });
             });
         }
+        if (more && (p.ablate & 16)) request_span(tile + tw.step);   // A/B: prefetch a whole tile ahead
         __builtin_amdgcn_sched_barrier(0);
         {
             const float *wrow = s_wt + l * ROW;
             static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-                zr[2 * i] *= w.x;
-                zi[2 * i] *= w.y;
-                zr[2 * i + 1] *= w.z;
-                zi[2 * i + 1] *= w.w;
+                z[2 * i] *= pk::lo(w);
+                z[2 * i + 1] *= pk::hi(w);
+                // at most 4 window pieces (16 VGPRs) in flight: left alone the scheduler hoists all 16 reads
+                if constexpr (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
         }
         __builtin_amdgcn_sched_barrier(0);
-        fft_inreg<R1>(zr, zi);
+        pk::fft<R1>(z);
         __builtin_amdgcn_sched_barrier(0);
+        PSND_STAMP(3);
 
         const float *trow = s_tw + l * ROW;
-        float *oxr = s_xr + fl * SFH + l, *oxi = s_xi + fl * SFH + l;
+        float *oz = s_x + fl * SFH + 2 * l;
         auto write_half = [&](auto hc) __attribute__((always_inline)) {
             constexpr int Q0 = decltype(hc)::value;
             static_for<0, HR / 2>([&](auto ic) __attribute__((always_inline)) {
@@ -333,52 +510,58 @@ __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p)
                 constexpr int q0 = Q0 + 2 * i, q1 = q0 + 1;
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
                 constexpr int s0_ = ct::bitrev(q0, RB), s1_ = ct::bitrev(q1, RB);
-                if constexpr (q0 == 0) {
-                    oxr[0] = zr[s0_];
-                    oxi[0] = zi[s0_];
-                } else {
-                    oxr[(q0 - Q0) * L] = __builtin_fmaf(zr[s0_], w.x, -zi[s0_] * w.y);
-                    oxi[(q0 - Q0) * L] = __builtin_fmaf(zr[s0_], w.y, zi[s0_] * w.x);
-                }
-                oxr[(q1 - Q0) * L] = __builtin_fmaf(zr[s1_], w.z, -zi[s1_] * w.w);
-                oxi[(q1 - Q0) * L] = __builtin_fmaf(zr[s1_], w.w, zi[s1_] * w.z);
+                if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[s0_];
+                else *reinterpret_cast<v2f *>(oz + (q0 - Q0) * 2 * L) = pk::cmul(z[s0_], pk::lo(w));
+                *reinterpret_cast<v2f *>(oz + (q1 - Q0) * 2 * L) = pk::cmul(z[s1_], pk::hi(w));
             });
         };
-        auto read_row = [&](int row, float (&rr)[L], float (&ri)[L]) __attribute__((always_inline)) {
-            const float *pr = s_xr + f2 * SFH + row * L, *pi = s_xi + f2 * SFH + row * L;
-            static_for<0, L / 4>([&](auto ic) __attribute__((always_inline)) {
+        auto read_row = [&](int row, v2f (&r)[L]) __attribute__((always_inline)) {
+            const float *pr = s_x + f2 * SFH + row * 2 * L;
+            static_for<0, L / 2>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(pi + 4 * i);
-                rr[4 * i] = v0.x, rr[4 * i + 1] = v0.y, rr[4 * i + 2] = v0.z, rr[4 * i + 3] = v0.w;
-                ri[4 * i] = v1.x, ri[4 * i + 1] = v1.y, ri[4 * i + 2] = v1.z, ri[4 * i + 3] = v1.w;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
+                r[2 * i] = pk::lo(v);
+                r[2 * i + 1] = pk::hi(v);
             });
         };
 
-        float ar[L], ai[L], br[L], bi[L];
+        v2f za[L], zb[L];
         __syncthreads();                 // every lane holds its taps: the span area becomes the exchange
         write_half(std::integral_constant<int, 0>{});
         __syncthreads();
-        read_row(rowA, ar, ai);
-        if (more) request_span(tile + tw.step);
+        read_row(rowA, za);
+        if (more && !(p.ablate & 16)) request_span(tile + tw.step);
         __syncthreads();                 // first-half rows consumed: the buffer may take rows 16..31
+        PSND_STAMP(4);
         write_half(std::integral_constant<int, HR>{});
         __builtin_amdgcn_sched_barrier(0);
-        fft_inreg<L>(ar, ai);
+        pk::fft<L>(za);
         __syncthreads();
-        read_row(rowB, br, bi);
-        __syncthreads();                 // exchange fully consumed: it becomes the span buffer of tile t+1
-        if (more) commit_span();
+        read_row(rowB, zb);
+        if constexpr (PERSIST) {
+            __syncthreads();             // exchange fully consumed: it becomes the span buffer of tile t+1
+            if (more) commit_span();
+        }
         __builtin_amdgcn_sched_barrier(0);
-        fft_inreg<L>(br, bi);
+        PSND_STAMP(5);
+        pk::fft<L>(zb);
         __builtin_amdgcn_sched_barrier(0);
 
         const long long F = p.F;
         const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
         const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
-        Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
-        if (emit.valid) post_emit<R1, L>(ar, ai, br, bi, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
-    }
+        EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
+        emit.nostore = p.ablate & 4;
+        if (emit.valid) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
+#ifdef PSND_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        PSND_STAMP(6);
+        if constexpr (!PERSIST) {
+            __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every store acknowledged
+            PSND_STAMP(7);
+        }
+#endif
+    } while (PERSIST && (tile += tw.step) < tw.end);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,19 +646,22 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
 }
 
 int launch_n1024(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
-    constexpr size_t lds = sizeof(float) * (2 * 16 * 68 + 516 + 2 * 16 * 260);
+    const size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(p.hop));
     int grid = p.total_tiles;
     int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
                              // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
     if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
     if (grid > cap) grid = cap;
     grid = (grid + 7) & ~7;
-#define PSND_LAUNCH(M_, P_, R_)                                                                                   \
-    do {                                                                                                          \
-        if (15 * p.hop + 1024 <= 5 * 1024)                                                                        \
-            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5>), dim3(grid), dim3(256), lds, stream, p);    \
-        else                                                                                                      \
-            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8>), dim3(grid), dim3(256), lds, stream, p);    \
+    const bool persist = grid < p.total_tiles;
+#define PSND_LAUNCH(M_, P_, R_)                                                                                          \
+    do {                                                                                                                 \
+        if (15 * p.hop + 1024 <= 5 * 1024) {                                                                             \
+            if (persist) hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, true>), dim3(grid), dim3(256), lds, stream, p);  \
+            else hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, false>), dim3(grid), dim3(256), lds, stream, p);         \
+        } else {                                                                                                         \
+            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8, true>), dim3(grid), dim3(256), lds, stream, p);     \
+        }                                                                                                                \
     } while (0)
     if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
     else if (mag && phase && !reim) PSND_LAUNCH(true, true, false);
@@ -561,6 +747,12 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     {
         const char *ab = getenv("PSND_ABLATE");
         p.ablate = ab ? atoi(ab) : 0;
+#ifdef PSND_TRACE
+        const char *tp = getenv("PSND_TRACE_PTR");
+        p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
+        const char *ti = getenv("PSND_TRACE_ITER");
+        p.trace_iter = ti ? atoi(ti) : 0;
+#endif
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Decomp *d = find_decomp(n_fft);
@@ -576,7 +768,7 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
                 // span-staged kernel: hop multiple of 4 and the tile's span (+ bank padding) must fit the
                 // exchange area; anything else takes the generic two-pass kernel
                 const long long span = 15ll * hop + 1024;
-                const bool span_ok = (hop % 4 == 0) && (span + 32 * (span / 256 + 1) <= 2 * 16 * 260) && span <= 8 * 1024;
+                const bool span_ok = (hop % 4 == 0) && (sizeof(float) * (kN1024TabFloats + n1024_area_floats(hop)) <= 64 * 1024) && span <= 8 * 1024;
                 if (!span_ok || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
                 return launch_n1024(p, mag, phase, re, s);
             }
