@@ -355,6 +355,7 @@ __device__ __forceinline__ void post_emit_pk(v2f (&za)[L], v2f (&zb)[L], bool sp
 constexpr int kN1024Sfh = 16 * 16 * 2 + 4;   // exchange frame stride (floats): 516/4 odd -> b128 reads conflict-free,
                                              // 8*516 = 32 (mod 64) -> the b64 writes of frames fl, fl+8 disjoint
 constexpr int kN1024TabFloats = 2 * 16 * 68 + 516;
+constexpr int kN1024WtOff = 16 * kN1024Sfh - 16 * 68;   // window table at the tail of the exchange area (one-tile mode)
 // exchange area (floats): half of the q-rows for 16 frames, or the tile's waveform span (+ 4 pad floats per 256)
 inline int n1024_area_floats(int hop) {
     const int span = 15 * hop + 1024;
@@ -363,16 +364,19 @@ inline int n1024_area_floats(int hop) {
 }
 
 template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST>
-__global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p) {
+__global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(StftFwdParams p) {
     constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5;
     constexpr int HR = R1 / 2;          // rows per exchange half
     constexpr int SFH = kN1024Sfh;
     constexpr int TAB = 2 * L * ROW + VKP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *s_wt = smem;
-    float *s_tw = s_wt + L * ROW;
+    // One tile per workgroup (!PERSIST): the window table is only needed before the first exchange write, so
+    // it sits in the tail of the exchange area that the span leaves free: 39.4 KB of LDS, 4 workgroups per CU.
+    constexpr int WT_IN_AREA = kN1024WtOff;
+    float *s_tw = PERSIST ? smem + L * ROW : smem;
     float *s_vk = s_tw + L * ROW;
     float *s_x = s_vk + VKP;            // exchange [frame][row][l] of (re, im), also the span buffer
+    float *s_wt = PERSIST ? smem : s_x + WT_IN_AREA;
     float *s_span = s_x;
     const int t = threadIdx.x;
 #ifdef PSND_TRACE
@@ -440,8 +444,9 @@ __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p)
         // tables (L2); the first barrier of the tile loop publishes both
         request_span(tw.first);
         constexpr int TV = (TAB / 4 + 255) / 256;
+        constexpr int WT4 = L * ROW / 4;         // 16-byte pieces of the window table (first in the plan)
         const f32x4 *src = reinterpret_cast<const f32x4 *>(p.plan);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(smem);
+        f32x4 *dst_wt = reinterpret_cast<f32x4 *>(s_wt), *dst_tw = reinterpret_cast<f32x4 *>(s_tw);
         f32x4 tv[TV];
         static_for<0, TV>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -449,7 +454,9 @@ __global__ __launch_bounds__(256, 3) void stft_fwd_n1024_kernel(StftFwdParams p)
         });
         static_for<0, TV>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            if (t + 256 * j < TAB / 4) dst[t + 256 * j] = tv[j];
+            const int i = t + 256 * j;
+            if (i < WT4) dst_wt[i] = tv[j];
+            else if (i < TAB / 4) dst_tw[i - WT4] = tv[j];
         });
         commit_span();
         PSND_STAMP(1);
@@ -646,14 +653,17 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
 }
 
 int launch_n1024(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
-    const size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(p.hop));
+    size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(p.hop));
     int grid = p.total_tiles;
     int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
                              // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
     if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
     if (grid > cap) grid = cap;
     grid = (grid + 7) & ~7;
-    const bool persist = grid < p.total_tiles;
+    // one tile per workgroup needs hop <= 256 (5 span pieces per thread, span + window table inside the exchange area)
+    const bool persist = grid < p.total_tiles || 15 * p.hop + 1024 > 5 * 1024 ||
+                         15 * p.hop + 1024 + 4 * ((15 * p.hop + 1024) / 256 + 1) > kN1024WtOff;
+    if (!persist) lds -= sizeof(float) * 16 * 68;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                          \
     do {                                                                                                                 \
         if (15 * p.hop + 1024 <= 5 * 1024) {                                                                             \
