@@ -46,7 +46,19 @@ struct ConvParams {
     long long R;
     int Lp, L, HP, Ca, Cb, k, off0, dstep, hm;
     float act_slope, mask_slope, a2_slope;
+#ifdef PSND_TRACE
+    long long *trace;
+#endif
 };
+#ifdef PSND_TRACE
+#define PSND_CSTAMP(i_)                                                                                         \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) == 0 && p.trace)                                                                 \
+            p.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PSND_CSTAMP(i_)
+#endif
 
 constexpr int BM = 64, BN = 64, RS = 40;   // RS: LDS row stride in bf16 (80 B) of the 32-channel tiles (wgrad)
 
@@ -75,16 +87,24 @@ __device__ __forceinline__ uint4 load_combined(const bf16_t *G1, const bf16_t *G
 }
 
 constexpr int MAXK = 16;
+constexpr int KC = 32;                     // input channels per pipeline stage
+constexpr int PCS = KC / 8;                // 16-byte pieces per staged row
+constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per stage (tap reach hm <= 25)
 
-// KC: input channels per pipeline stage (32 or 64); LDS row stride KC + 8 bf16 (80 / 144 B: odd multiples of
-// 16 B -> the 16 lanes of a ds_read_b128 group land on 16 distinct 16-B slots)
-template <int KC>
+// One conv = 384 workgroups of ~6 MFLOP at the config-2 shape: every workgroup is a LATENCY chain, not a
+// throughput problem (first version: one stage prefetched ahead, 8 stages x ~2.5 k cycles of load latency =
+// 24 us per launch with the MFMA pipe 4 % busy).  So the loads run D stages ahead in a register ring (the
+// kernel only ever has 1-2 workgroups per CU: registers are free), the raw pieces of the on-load gradient
+// combine are kept apart until the commit (the arithmetic would otherwise wait for its loads inside the
+// fetch), LDS is double buffered (one barrier per stage).
+//   KT: taps the register ring is sized for (k <= KT);  D: stages in flight;  COMBINE: A = A + A2 * leaky'(AM)
+template <int KT, int D, bool COMBINE, int NBUF>
 __global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
-    constexpr int RS = KC + 8, PCS = KC / 8;   // pieces of 16 B per row
+    constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
+    constexpr int NB = BN * PCS / 256;     // weight pieces per thread per tap (= 1)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_c[];
     const int rowsA = BM + 2 * p.hm;
-    bf16_t *sA = smem_c;
-    bf16_t *sB = sA + rowsA * RS;
+    const int buf_elems = (rowsA + p.k * BN) * RS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const long long r0 = (long long)blockIdx.x * BM;
@@ -94,93 +114,185 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    PSND_CSTAMP(0);
 
-    // software pipeline: the global loads of chunk c+1 are in flight while chunk c is multiplied.
-    // per thread: <= 2 pieces of the A tile (rows r0-hm .. r0+BM+hm, 4 x 16 B each) and k pieces of weights.
-    constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;      // A pieces per thread (hm <= 25)
-    constexpr int NB = BN * PCS / 256;                      // weight pieces per thread per tap
-    uint4 ra[NA], rb[MAXK * NB];
+    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rb[D][KT * NB];
     const int nA = rowsA * PCS;
-    auto fetch = [&](int c0) __attribute__((always_inline)) {
+    // per-thread piece coordinates are stage independent
+    size_t aoff[NA];
+    bool aok[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int idx = tid + 256 * u;
+        const int rr = idx / PCS, pc = idx % PCS;
+        const long long r = r0 - p.hm + rr;
+        aok[u] = idx < nA && r >= 0 && r < p.R;
+        aoff[u] = aok[u] ? (size_t)r * p.Ca + 8 * pc : 0;
+    }
+    const int wn_ = tid / PCS, wpc = tid % PCS;       // weight piece of this thread (NB == 1)
+    const bool wok = n0 + wn_ < p.Cb;
+    const size_t woff = ((size_t)(n0 + wn_)) * p.Ca + 8 * wpc;
+    const size_t wtap = (size_t)p.Cb * p.Ca;
+
+    auto fetch = [&](auto sc, int c0) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int idx = tid + 256 * u;
-            ra[u] = make_uint4(0, 0, 0, 0);
-            if (idx < nA) {
-                const int rr = idx / PCS, pc = idx % PCS;
-                const long long r = r0 - p.hm + rr;
-                if (r >= 0 && r < p.R) ra[u] = load_combined(p.A, p.A2, p.AM, p.a2_slope, (size_t)r * p.Ca + c0 + 8 * pc);
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            ra[s][u] = z4;
+            if constexpr (COMBINE) ra2[s][u] = z4, ram[s][u] = z4;
+            if (aok[u]) {
+                if (!COMBINE || p.A) ra[s][u] = *reinterpret_cast<const uint4 *>(p.A + aoff[u] + c0);
+                if constexpr (COMBINE) {
+                    ra2[s][u] = *reinterpret_cast<const uint4 *>(p.A2 + aoff[u] + c0);
+                    ram[s][u] = *reinterpret_cast<const uint4 *>(p.AM + aoff[u] + c0);
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < MAXK; ++j) {
-            if (j < p.k) {
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int idx = tid + 256 * u, n = idx / PCS, pc = idx % PCS;
-                    rb[j * NB + u] = make_uint4(0, 0, 0, 0);
-                    if (n0 + n < p.Cb)
-                        rb[j * NB + u] = *reinterpret_cast<const uint4 *>(p.W + ((size_t)j * p.Cb + n0 + n) * p.Ca + c0 + 8 * pc);
-                }
-            }
+        for (int j = 0; j < KT; ++j) {
+            rb[s][j] = make_uint4(0, 0, 0, 0);
+            if (j < p.k && wok) rb[s][j] = *reinterpret_cast<const uint4 *>(p.W + j * wtap + woff + c0);
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto combine = [&](uint4 v, uint4 g2, uint4 m) __attribute__((always_inline)) {
+        const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
+                       *pm = reinterpret_cast<const unsigned *>(&m);
+        unsigned out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a0 = bf2f((bf16_t)(pv[i] & 0xffff)), a1 = bf2f((bf16_t)(pv[i] >> 16));
+            const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
+            const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
+            const float r0_ = a0 + b0 * (m0 > 0.f ? 1.f : p.a2_slope), r1_ = a1 + b1 * (m1 > 0.f ? 1.f : p.a2_slope);
+            out[i] = (unsigned)f2bf(r0_) | ((unsigned)f2bf(r1_) << 16);
+        }
+        return make_uint4(out[0], out[1], out[2], out[3]);
+    };
+    auto commit = [&](auto sc, bf16_t *sA, bf16_t *sB) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int idx = tid + 256 * u;
-            if (idx < nA) *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = ra[u];
+            if (idx < nA) {
+                uint4 v = ra[s][u];
+                if constexpr (COMBINE) v = combine(v, ra2[s][u], ram[s][u]);
+                *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = v;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < MAXK; ++j)
-            if (j < p.k) {
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int idx = tid + 256 * u;
-                    *reinterpret_cast<uint4 *>(sB + (j * BN + idx / PCS) * RS + 8 * (idx % PCS)) = rb[j * NB + u];
-                }
-            }
+        for (int j = 0; j < KT; ++j)
+            if (j < p.k) *reinterpret_cast<uint4 *>(sB + (j * BN + wn_) * RS + 8 * wpc) = rb[s][j];
     };
 
-    fetch(0);
-    for (int c0 = 0; c0 < p.Ca; c0 += KC) {
-        commit();
-        __syncthreads();
-        if (c0 + KC < p.Ca) fetch(c0 + KC);
-        for (int tap = 0; tap < p.k; ++tap) {
-            const int off = p.off0 + tap * p.dstep + p.hm;
-            const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
-            const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
+    const int nchunk = p.Ca / KC;
+    static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
+        if (decltype(sc)::value < nchunk) fetch(sc, decltype(sc)::value * KC);
+    });
+    for (int c = 0; c < nchunk; c += D) {
+        static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            const int ch = c + s;
+            if (ch < nchunk) {                                   // uniform
+                bf16_t *sA = smem_c + (NBUF == 2 ? (ch & 1) * buf_elems : 0);
+                bf16_t *sB = sA + rowsA * RS;
+                if constexpr (NBUF == 1) __syncthreads();        // the previous stage's fragments are consumed
+                commit(sc, sA, sB);
+                if (ch == 0) PSND_CSTAMP(1);
+                __syncthreads();
+                if (ch == 0) PSND_CSTAMP(2);
+                if (ch + D < nchunk) fetch(sc, (ch + D) * KC);
+                for (int tap = 0; tap < p.k; ++tap) {
+                    const int off = p.off0 + tap * p.dstep + p.hm;
+                    const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
+                    const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
 #pragma unroll
-            for (int kk = 0; kk < KC / 16; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                    for (int kk = 0; kk < KC / 16; ++kk) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                    }
+                }
             }
-        }
-        __syncthreads();
+        });
     }
 
-    // ---- epilogue: D[i][j], j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
-    const int col = n0 + wn * 32 + li;
-    if (col >= p.Cb) return;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    PSND_CSTAMP(3);
+    // ---- epilogue.  D[i][j]: j = lane & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The fp32 tile goes
+    // through LDS so that every thread finishes 8 consecutive channels of one row: 16-byte loads of the mask /
+    // residual operands and 16-byte stores (the first version stored 2 bytes per lane and paid a 64-bit
+    // modulo per element: 8.9 k of the workgroup's 22 k cycles).
+    constexpr int OS = BN + 8;                                   // fp32 row stride: 4 rows apart = 32 banks apart
+    float *sO = reinterpret_cast<float *>(smem_c);
+    __syncthreads();                                             // every fragment read of the last stage is done
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
         const int i = (rg & 3) + 8 * (rg >> 2) + 4 * kg;
-        const long long r = r0 + wm * 32 + i;
-        if (r >= p.R) continue;
-        const int l = (int)(r % p.Lp);
-        const size_t o = (size_t)r * p.Cb + col;
-        float v = 0.f;
-        if (l >= p.HP && l < p.HP + p.L) {
-            v = acc[rg] + bv;
-            if (p.mask_src) v *= (bf2f(p.mask_src[o]) > 0.f) ? 1.f : p.mask_slope;
-            if (p.res) v += bf2f(p.res[o]);
-        }
-        if (p.out_raw) p.out_raw[o] = f2bf(v);
-        if (p.out_act) p.out_act[o] = f2bf(v > 0.f ? v : v * p.act_slope);
+        sO[(wm * 32 + i) * OS + wn * 32 + li] = acc[rg];
     }
+    __syncthreads();
+    const int l0 = (int)(r0 % p.Lp);                             // uniform
+#pragma unroll
+    for (int u = 0; u < BM * BN / 8 / 256; ++u) {
+        const int idx = tid + 256 * u, row = idx >> 3, cg = idx & 7;
+        const long long r = r0 + row;
+        const int col = n0 + 8 * cg;
+        if (r >= p.R || col >= p.Cb) continue;
+        const int l = (l0 + row) % p.Lp;
+        const size_t o = (size_t)r * p.Cb + col;
+        float v[8];
+        const bool inside = l >= p.HP && l < p.HP + p.L;
+        if (inside) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(sO + row * OS + 8 * cg);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(sO + row * OS + 8 * cg + 4);
+            v[0] = a0.x, v[1] = a0.y, v[2] = a0.z, v[3] = a0.w, v[4] = a1.x, v[5] = a1.y, v[6] = a1.z, v[7] = a1.w;
+            if (p.bias) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(p.bias + col), b1 = *reinterpret_cast<const f32x4 *>(p.bias + col + 4);
+                v[0] += b0.x, v[1] += b0.y, v[2] += b0.z, v[3] += b0.w, v[4] += b1.x, v[5] += b1.y, v[6] += b1.z, v[7] += b1.w;
+            }
+            if (p.mask_src) {
+                const uint4 m = *reinterpret_cast<const uint4 *>(p.mask_src + o);
+                const unsigned *pm = reinterpret_cast<const unsigned *>(&m);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] *= bf2f((bf16_t)(pm[e] & 0xffff)) > 0.f ? 1.f : p.mask_slope;
+                    v[2 * e + 1] *= bf2f((bf16_t)(pm[e] >> 16)) > 0.f ? 1.f : p.mask_slope;
+                }
+            }
+            if (p.res) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(p.res + o);
+                const unsigned *pq = reinterpret_cast<const unsigned *>(&q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf2f((bf16_t)(pq[e] & 0xffff));
+                    v[2 * e + 1] += bf2f((bf16_t)(pq[e] >> 16));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        if (p.out_raw) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+            *reinterpret_cast<uint4 *>(p.out_raw + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (p.out_act) {
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = v[2 * e], x1 = v[2 * e + 1];
+                w[e] = (unsigned)f2bf(x0 > 0.f ? x0 : x0 * p.act_slope) | ((unsigned)f2bf(x1 > 0.f ? x1 : x1 * p.act_slope) << 16);
+            }
+            *reinterpret_cast<uint4 *>(p.out_act + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+#ifdef PSND_TRACE
+    PSND_CSTAMP(4);
+    __builtin_amdgcn_s_waitcnt(0);
+    PSND_CSTAMP(5);
+#endif
 }
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
@@ -417,23 +529,36 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     p.out_raw = static_cast<bf16_t *>(out_raw), p.out_act = static_cast<bf16_t *>(out_act);
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.hm = hm;
     p.act_slope = act_slope, p.mask_slope = mask_slope;
-    // 64-channel stages measured SLOWER on the config-2 model (253 VGPRs -> 1 block/CU: 14.8k vs 16.9k audio-s/s);
-    // kept behind PSND_CONV_KC64 for A/B runs
-    const size_t rows = (size_t)(BM + 2 * hm) + (size_t)k * BN;
-    const bool wide = (Ca % 64 == 0) && (sizeof(bf16_t) * 72 * rows <= 64 * 1024) && k <= 8 && getenv("PSND_CONV_KC64");
-    const size_t lds = sizeof(bf16_t) * (wide ? 72 : 40) * rows;
+#ifdef PSND_TRACE
+    {
+        const char *tp = getenv("PSND_TRACE_PTR");
+        p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
+    }
+#endif
+    const size_t buf = sizeof(bf16_t) * 40 * ((size_t)(BM + 2 * hm) + (size_t)k * BN);
+    const int nbuf = 2 * buf <= 150 * 1024 ? 2 : 1;
+    size_t lds = nbuf * buf;
+    if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: LDS %zu too large", lds);
     dim3 grid((unsigned)((p.R + BM - 1) / BM), (unsigned)((Cb + BN - 1) / BN));
-    if (wide) {
-        hipLaunchKernelGGL(conv_cl_kernel<64>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
-    } else {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_cl_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl: set LDS size: %s", hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL(conv_cl_kernel<32>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), p);
-    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PSND_CONV_LAUNCH(KT_, D_, NBUF_)                                                                              \
+    do {                                                                                                              \
+        auto kern = A2 ? conv_cl_kernel<KT_, D_, true, NBUF_> : conv_cl_kernel<KT_, D_, false, NBUF_>;                \
+        if (lds > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl: set LDS size: %s", hipGetErrorString(e));          \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                                        \
+    } while (0)
+    if (k <= 3 && nbuf == 2 && !A2) PSND_CONV_LAUNCH(3, 8, 2);
+    else if (k <= 3 && nbuf == 2) PSND_CONV_LAUNCH(3, 5, 2);
+    else if (k <= 7 && nbuf == 2) PSND_CONV_LAUNCH(7, 3, 2);
+    else if (k <= 11 && nbuf == 2) PSND_CONV_LAUNCH(11, 2, 2);
+    else if (nbuf == 2) PSND_CONV_LAUNCH(16, 2, 2);
+    else PSND_CONV_LAUNCH(16, 2, 1);
+#undef PSND_CONV_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl");
     return PSND_OK;
 }
