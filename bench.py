@@ -78,11 +78,15 @@ def build_step(device, amp):
             return fe.mel_of_mag(m)
 
     class StepTrainer(Trainer):
-        def forward(self, noisy, clean, is_logging=False):
-            mag_mix = magnitude(noisy)
+        def prepare(self, noisy, clean):
+            # feature extraction of the batch (no parameters, no gradient): eager, ahead of the captured graph
             with torch.no_grad():
+                mag_mix = magnitude(noisy)
                 mag_ref = magnitude(clean)
                 mel_ref = logmel_of_mag(mag_ref)
+            return mag_mix, mag_ref, mel_ref
+
+        def forward(self, mag_mix, mag_ref, mel_ref, is_logging=False):
             if amp:
                 with torch.autocast('cuda', dtype=torch.bfloat16):
                     est = self.model(mag_mix)
@@ -118,6 +122,7 @@ def gpu_bench(args):
     huge = 10 ** 9
     tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
                  save_dir=save_dir, save_prefix='bench', seed=1234)
+    tr.graph_steps = not args.no_graph          # forward + backward replayed as one hipGraph (Trainer.graph_steps)
     model.train()
 
     def barrier():
@@ -127,6 +132,11 @@ def gpu_bench(args):
             torch.cuda.synchronize()
 
     step = 0
+    if tr.graph_steps:                  # set-up, like building the model: eager steps + the one-off graph capture
+        for _ in range(tr.graph_warmup + 1):
+            step += 1
+            tr.step = step
+            tr.train(step)
     for _ in range(args.warmup):
         step += 1
         tr.step = step
@@ -259,6 +269,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pool', type=int, default=8, help='distinct synthetic batches resident in HBM')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')

@@ -120,22 +120,25 @@ int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, 
  *    epilogue: v = acc (+ bias[co]); v *= (mask_src > 0 ? 1 : mask_slope) when mask_src; v += res when res;
  *              rows outside the clip -> 0; out_raw = v, out_act = leaky_relu(v, act_slope) (either may be NULL).
  *    replaces F.leaky_relu + Conv1d + bias (+ residual add)  (hifi_gan.py:56-62, 84-88) and their backward.
- *  psnd_conv1d_cl_wgrad: gw[j][co][ci] = sum_r g[r][co] * xa[r + off0 + j*dstep][ci] (fp32, [k][Cb][Ca]),
- *              gbias[co] = sum_r g[r][co] (may be NULL), g_out = g materialised (may be NULL); g = G1 + G2*leaky'(GM).
+ *  psnd_conv1d_cl_wgrad: gw[j][co][ci] = sum_r g[r][co] * xa[r + off0 + j*dstep][ci] as S partial slabs over row
+ *              ranges, gw_part fp32 [S][k][Cb][Ca] and gbias_part [S][Cb] (may be NULL), every element written (no
+ *              zero fill, no atomics); S = psnd_conv1d_cl_wgrad_splits(N, Lp, Ca, Cb) (host helper).
+ *              g_out = g materialised (may be NULL); g = G1 + G2*leaky'(GM).
  *  psnd_conv1d_prep: weight norm w = g*v/||v|| (norm over dim 0, as torch weight_norm) -> bf16 packs
- *              wf [k][Cb][Ca] and wb [k][Ca][Cb], zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: its backward
- *              from gw to (g_v, g_g).
+ *              wf [k][Cb][Ca] and wb [k][Ca][Cb], zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: adds the S
+ *              slabs up and runs the weight-norm backward: (g_v, g_g) and gbias (Cb, may be NULL).
  *  psnd_to_cl / psnd_from_cl: (N,C,T) fp32 <-> CL bf16 (preop 1 = log1p on the way in). */
 int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
                    const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
                    int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act, void *stream);
+int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb);
 int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
-                         int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw, float *gbias, void *g_out,
-                         void *stream);
+                         int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,
+                         void *g_out, void *stream);
 int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout, int Cin, int k, int Cb, int Ca,
                      void *wf, void *wb, float *bias_padded, void *stream);
-int psnd_conv1d_wnorm_bwd(const float *gw, const float *v, const float *g, int Cout, int Cin, int k, int Cb, int Ca,
-                          float *gv, float *gg, void *stream);
+int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
+                          int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);
 int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
 

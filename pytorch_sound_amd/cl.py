@@ -151,7 +151,9 @@ class FusedConvCL(torch.autograd.Function):
         # input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) formed on load
         gx, _ = _launch_conv(g_raw, g_act, act if g_act is not None else None, ctx.act_slope, wb, None, None, None, shape,
                              Cb, Ca, k, pad, -dil, 1.0, 1.0, True, False)
-        gw = torch.empty((k, Cb, Ca), dtype=torch.float32, device=dev)
+        S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb)
+        gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)     # partial slabs, summed in wnorm_bwd
+        gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
         gb = torch.empty(Cb, dtype=torch.float32, device=dev)
         need_gout = ctx.has_res and (g_act is not None)
         g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
@@ -160,9 +162,9 @@ class FusedConvCL(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib().psnd_conv1d_cl_wgrad(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None),
                                              float(ctx.act_slope), ptr(xa), shape.N, shape.Lp, Ca, Cb, k, -pad, dil,
-                                             ptr(gw), ptr(gb), ptr(g_out), stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
-            check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv), ptr(gg),
-                                              stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
+                                             ptr(gw), ptr(gbp), ptr(g_out), stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
+            check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv), ptr(gg),
+                                              ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
         g_res = None
         if ctx.has_res:
             g_res = g_out if need_gout else g_raw

@@ -99,7 +99,7 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 // fetch), LDS is double buffered (one barrier per stage).
 //   KT: taps the register ring is sized for (k <= KT);  D: stages in flight;  COMBINE: A = A + A2 * leaky'(AM)
 template <int KT, int D, bool COMBINE, int NBUF>
-__global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
     constexpr int NB = BN * PCS / 256;     // weight pieces per thread per tap (= 1)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_c[];
@@ -118,42 +118,51 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
 
     uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rb[D][KT * NB];
     const int nA = rowsA * PCS;
-    // per-thread piece coordinates are stage independent
-    size_t aoff[NA];
-    bool aok[NA];
+    // Every load is a buffer load with a 32-bit byte offset; an offset of OOB (or any offset past the tensor)
+    // returns zeros.  That supplies the rows before / after the tensor, the channels past Ca of a padding stage
+    // and the taps past k WITHOUT a branch around the load: hipcc's s_waitcnt insertion counts outstanding loads
+    // exactly only in straight-line code - one conditional fetch and every later wait degrades to vmcnt(0),
+    // which serialises the whole ring (measured: 1.7 k cycles per stage instead of 0.5 k).
+    constexpr unsigned OOB = 0xffffffffu;
+    const unsigned a_bytes = (unsigned)((size_t)p.R * p.Ca * sizeof(bf16_t));
+    const unsigned w_bytes = (unsigned)((size_t)p.k * p.Cb * p.Ca * sizeof(bf16_t));
+    const __amdgpu_buffer_rsrc_t rA = make_uniform_rsrc(p.A ? p.A : p.A2, (int)a_bytes);
+    __amdgpu_buffer_rsrc_t rA2 = rA, rAM = rA;
+    if constexpr (COMBINE) rA2 = make_uniform_rsrc(p.A2, (int)a_bytes), rAM = make_uniform_rsrc(p.AM, (int)a_bytes);
+    const __amdgpu_buffer_rsrc_t rW = make_uniform_rsrc(p.W, (int)w_bytes);
+    const bool haveA = p.A != nullptr;
+    unsigned aoff[NA];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int idx = tid + 256 * u;
         const int rr = idx / PCS, pc = idx % PCS;
         const long long r = r0 - p.hm + rr;
-        aok[u] = idx < nA && r >= 0 && r < p.R;
-        aoff[u] = aok[u] ? (size_t)r * p.Ca + 8 * pc : 0;
+        aoff[u] = (idx < nA && r >= 0 && r < p.R) ? (unsigned)(((size_t)r * p.Ca + 8 * pc) * sizeof(bf16_t)) : OOB;
     }
     const int wn_ = tid / PCS, wpc = tid % PCS;       // weight piece of this thread (NB == 1)
-    const bool wok = n0 + wn_ < p.Cb;
-    const size_t woff = ((size_t)(n0 + wn_)) * p.Ca + 8 * wpc;
-    const size_t wtap = (size_t)p.Cb * p.Ca;
+    const unsigned woff = (n0 + wn_ < p.Cb) ? (unsigned)((((size_t)(n0 + wn_)) * p.Ca + 8 * wpc) * sizeof(bf16_t)) : OOB;
+    const unsigned wtap = (unsigned)((size_t)p.Cb * p.Ca * sizeof(bf16_t));
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) __attribute__((always_inline)) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return __builtin_bit_cast(uint4, v);
+    };
 
     auto fetch = [&](auto sc, int c0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
+        const bool live = c0 < p.Ca;                  // false for the padding stages of the last ring turn
+        const unsigned cb = (unsigned)c0 * (unsigned)sizeof(bf16_t);
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const uint4 z4 = make_uint4(0, 0, 0, 0);
-            ra[s][u] = z4;
-            if constexpr (COMBINE) ra2[s][u] = z4, ram[s][u] = z4;
-            if (aok[u]) {
-                if (!COMBINE || p.A) ra[s][u] = *reinterpret_cast<const uint4 *>(p.A + aoff[u] + c0);
-                if constexpr (COMBINE) {
-                    ra2[s][u] = *reinterpret_cast<const uint4 *>(p.A2 + aoff[u] + c0);
-                    ram[s][u] = *reinterpret_cast<const uint4 *>(p.AM + aoff[u] + c0);
-                }
+            const unsigned o = (live && aoff[u] != OOB) ? aoff[u] + cb : OOB;
+            ra[s][u] = ld16(rA, haveA ? o : OOB);
+            if constexpr (COMBINE) {
+                ra2[s][u] = ld16(rA2, o);
+                ram[s][u] = ld16(rAM, o);
             }
         }
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
-            rb[s][j] = make_uint4(0, 0, 0, 0);
-            if (j < p.k && wok) rb[s][j] = *reinterpret_cast<const uint4 *>(p.W + j * wtap + woff + c0);
-        }
+        for (int j = 0; j < KT; ++j)
+            rb[s][j] = ld16(rW, (live && j < p.k && woff != OOB) ? woff + (unsigned)j * wtap + cb : OOB);
     };
     auto combine = [&](uint4 v, uint4 g2, uint4 m) __attribute__((always_inline)) {
         const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
@@ -185,15 +194,14 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
             if (j < p.k) *reinterpret_cast<uint4 *>(sB + (j * BN + wn_) * RS + 8 * wpc) = rb[s][j];
     };
 
-    const int nchunk = p.Ca / KC;
-    static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
-        if (decltype(sc)::value < nchunk) fetch(sc, decltype(sc)::value * KC);
-    });
+    // the ring turns whole: stages past Ca / KC load and multiply zeros (at most D - 1 of them)
+    const int nchunk = (p.Ca / KC + D - 1) / D * D;
+    static_for<0, D>([&](auto sc) __attribute__((always_inline)) { fetch(sc, decltype(sc)::value * KC); });
     for (int c = 0; c < nchunk; c += D) {
         static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             const int ch = c + s;
-            if (ch < nchunk) {                                   // uniform
+            {
                 bf16_t *sA = smem_c + (NBUF == 2 ? (ch & 1) * buf_elems : 0);
                 bf16_t *sB = sA + rowsA * RS;
                 if constexpr (NBUF == 1) __syncthreads();        // the previous stage's fragments are consumed
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_cl_kernel(ConvParams p) {
                 if (ch == 0) PSND_CSTAMP(1);
                 __syncthreads();
                 if (ch == 0) PSND_CSTAMP(2);
-                if (ch + D < nchunk) fetch(sc, (ch + D) * KC);
+                fetch(sc, (ch + D) * KC);
                 for (int tap = 0; tap < p.k; ++tap) {
                     const int off = p.off0 + tap * p.dstep + p.hm;
                     const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
@@ -340,13 +348,13 @@ __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *ou
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// weight gradient:  gw[j][co][ci] += sum_r g[r][co] * xa[r + off_j][ci]   (fp32, split over row ranges, atomics)
-//                   gbias[co]     += sum_r g[r][co] ;  g_out[r][co] = g (optional materialisation, for the residual)
+// weight gradient:  gw[j][co][ci] = sum_r g[r][co] * xa[r + off_j][ci]   (fp32, one partial slab per row range)
+//                   gbias[co]     = sum_r g[r][co] ;  g_out[r][co] = g (optional materialisation, for the residual)
 // The reduction runs over ROWS, the non-contiguous dimension of both CL operands, so tiles are transposed on
 // their way into LDS (T[c][row], row-contiguous) and MFMA fragments are read with ds_read_b128.  All taps
 // of a group share the staged g tile; each tap stages its own row-shifted copy of xa.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int WKT = 4;     // taps per pass (accumulators: WKT x 16 VGPRs)
+constexpr int WKT = 3;     // taps per pass (accumulators: WKT x 16 VGPRs); the register ring must leave 2 workgroups per CU
 struct WgradParams {
     const bf16_t *G1, *G2, *GM;   // g = G1 + G2 * leaky'(GM)
     const bf16_t *xa;
@@ -355,19 +363,60 @@ struct WgradParams {
     long long R;
     int Ca, Cb, k, off0, dstep, rows_per_split;
     float g2_slope;
+#ifdef PSND_TRACE
+    long long *trace;
+#endif
 };
+#ifdef PSND_TRACE
+#define PSND_WSTAMP(i_)                                                                                         \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) == 0 && p.trace)                                                                 \
+            p.trace[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PSND_WSTAMP(i_)
+#endif
 
+// Each workgroup owns one 64 (co) x 64 (ci) tile of all k taps over ONE range of rows and writes its partial sums
+// as a plain slab gw_part[split][j][co][ci]; the weight-norm backward kernel adds the slabs up.  (The first
+// version accumulated with fp32 atomics: 6.3 M of them per launch at the config-2 shape = 65 % of a
+// workgroup's 52 k cycles, the L2 retiring about one fp32 atomic per channel per clock.)
+// Row chunks (32 rows) are fetched WD chunks ahead as raw pieces (the gradient combine is done at staging).
+// Transposed staging: lanes rr and rr^1 swap halves (DPP) so every lane writes 4-byte (2 rows x 1 channel) words.
+constexpr int WD = 3;
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t sT[(1 + WKT) * 64 * RS];
-    bf16_t *sA = sT, *sB = sT + 64 * RS;
+    __shared__ __attribute__((aligned(16))) bf16_t sT[2 * (1 + WKT) * 64 * RS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
     const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
-    const long long rs = (long long)blockIdx.z * p.rows_per_split;
+    const int split = blockIdx.z;
+    const long long rs = (long long)split * p.rows_per_split;
     const long long re = min(rs + p.rows_per_split, p.R);
     const int rr = tid & 31, cg = tid >> 5;          // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
     const bool do_bias = (blockIdx.y == 0);
+    const bool comb = p.G2 != nullptr;
+    const bool gok = co0 + 8 * cg < p.Cb, xok = ci0 + 8 * cg < p.Ca;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    PSND_WSTAMP(0);
+    constexpr unsigned OOB = 0xffffffffu;
+    const int g_bytes = (int)((size_t)p.R * p.Cb * sizeof(bf16_t)), x_bytes = (int)((size_t)p.R * p.Ca * sizeof(bf16_t));
+    const bool haveG1 = p.G1 != nullptr;
+    const __amdgpu_buffer_rsrc_t rG1 = make_uniform_rsrc(haveG1 ? p.G1 : p.G2, g_bytes);
+    const __amdgpu_buffer_rsrc_t rG2 = make_uniform_rsrc(comb ? p.G2 : p.G1, g_bytes);
+    const __amdgpu_buffer_rsrc_t rGM = make_uniform_rsrc(comb ? p.GM : p.G1, g_bytes);
+    const __amdgpu_buffer_rsrc_t rX = make_uniform_rsrc(p.xa, x_bytes);
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) __attribute__((always_inline)) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return __builtin_bit_cast(uint4, v);
+    };
+
+    // (own, neighbour) dwords -> one dword holding rows (rr & ~1, rr | 1) of channel 2*i + (rr & 1)
+    auto pair_rows = [&](unsigned own) __attribute__((always_inline)) {
+        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        // v_perm_b32(hi, lo, sel): byte i of the result = byte sel[i] of {hi, lo} (0-3 = lo, 4-7 = hi)
+        // even lane: (own.lo16 | nb.lo16 << 16) = channel 2i, rows (rr, rr+1); odd: (nb.hi16 | own.hi16 << 16) = channel 2i+1
+        return (rr & 1) ? __builtin_amdgcn_perm(own, nb, 0x07060302u) : __builtin_amdgcn_perm(nb, own, 0x05040100u);
+    };
 
     for (int t0 = 0; t0 < p.k; t0 += WKT) {
         const int nt = min(WKT, p.k - t0);
@@ -376,79 +425,115 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         for (int j = 0; j < WKT; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-        // software pipeline over 32-row chunks: chunk c+1 is being loaded while chunk c is multiplied
-        uint4 vg, vx[WKT];
-        auto fetch = [&](long long r0) __attribute__((always_inline)) {
+        uint4 vg[WD], vg2[WD], vgm[WD], vx[WD][WKT];
+        // branch-free buffer loads (offset OOB -> zeros), see conv_cl_kernel
+        auto fetch = [&](auto sc, long long r0) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
             const long long r = r0 + rr;
-            vg = make_uint4(0, 0, 0, 0);
-            if (r < re && co0 + 8 * cg < p.Cb) vg = load_combined(p.G1, p.G2, p.GM, p.g2_slope, (size_t)r * p.Cb + co0 + 8 * cg);
+            const bool rok = r < re;
+            const unsigned og = (rok && gok) ? (unsigned)(((size_t)r * p.Cb + co0 + 8 * cg) * sizeof(bf16_t)) : OOB;
+            vg[s] = ld16(rG1, haveG1 ? og : OOB);
+            vg2[s] = ld16(rG2, comb ? og : OOB);
+            vgm[s] = ld16(rGM, comb ? og : OOB);
 #pragma unroll
             for (int j = 0; j < WKT; ++j) {
-                vx[j] = make_uint4(0, 0, 0, 0);
-                if (j < nt) {
-                    const long long rx = r + p.off0 + (t0 + j) * p.dstep;
-                    if (r < re && rx >= 0 && rx < p.R && ci0 + 8 * cg < p.Ca)
-                        vx[j] = *reinterpret_cast<const uint4 *>(p.xa + (size_t)rx * p.Ca + ci0 + 8 * cg);
-                }
+                const long long rx = r + p.off0 + (t0 + j) * p.dstep;
+                const bool ok = j < nt && rok && rx >= 0 && rx < p.R && xok;
+                vx[s][j] = ld16(rX, ok ? (unsigned)(((size_t)rx * p.Ca + ci0 + 8 * cg) * sizeof(bf16_t)) : OOB);
             }
         };
-        fetch(rs);
-        for (long long r0 = rs; r0 < re; r0 += 32) {
-            const long long r = r0 + rr;
-            {   // g tile, transposed on its way into LDS
-                const unsigned *pv = reinterpret_cast<const unsigned *>(&vg);
+        auto stage = [&](auto sc, long long r0, bf16_t *sA, bf16_t *sB) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            uint4 g = vg[s];
+            if (comb) {
+                const unsigned *pv = reinterpret_cast<const unsigned *>(&vg[s]), *pg = reinterpret_cast<const unsigned *>(&vg2[s]),
+                               *pm = reinterpret_cast<const unsigned *>(&vgm[s]);
+                unsigned out[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const bf16_t h = (bf16_t)((pv[e >> 1] >> (16 * (e & 1))) & 0xffff);
-                    sA[(8 * cg + e) * RS + rr] = h;
-                    if (do_bias && t0 == 0) bsum[e] += bf2f(h);
+                for (int i = 0; i < 4; ++i) {
+                    const float a0 = bf2f((bf16_t)(pv[i] & 0xffff)), a1 = bf2f((bf16_t)(pv[i] >> 16));
+                    const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
+                    const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
+                    out[i] = (unsigned)f2bf(a0 + b0 * (m0 > 0.f ? 1.f : p.g2_slope)) |
+                             ((unsigned)f2bf(a1 + b1 * (m1 > 0.f ? 1.f : p.g2_slope)) << 16);
                 }
-                if (p.g_out && do_bias && t0 == 0 && r < re && co0 + 8 * cg < p.Cb)
-                    *reinterpret_cast<uint4 *>(p.g_out + (size_t)r * p.Cb + co0 + 8 * cg) = vg;
+                g = make_uint4(out[0], out[1], out[2], out[3]);
             }
+            const unsigned *pg4 = reinterpret_cast<const unsigned *>(&g);
+            if (do_bias && t0 == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += bf2f((bf16_t)((pg4[e >> 1] >> (16 * (e & 1))) & 0xffff));
+                const long long r = r0 + rr;
+                if (p.g_out && r < re && gok) *reinterpret_cast<uint4 *>(p.g_out + (size_t)r * p.Cb + co0 + 8 * cg) = g;
+            }
+            const int r2 = rr & ~1, par = rr & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)   // channel 8cg + 2i + par, rows r2, r2+1
+                *reinterpret_cast<unsigned *>(sA + (8 * cg + 2 * i + par) * RS + r2) = pair_rows(pg4[i]);
 #pragma unroll
             for (int j = 0; j < WKT; ++j)
-                if (j < nt) {   // row-shifted xa tiles, transposed
-                    const unsigned *pv = reinterpret_cast<const unsigned *>(&vx[j]);
+                if (j < nt) {
+                    const unsigned *px = reinterpret_cast<const unsigned *>(&vx[s][j]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        sB[(j * 64 + 8 * cg + e) * RS + rr] = (bf16_t)((pv[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<unsigned *>(sB + (j * 64 + 8 * cg + 2 * i + par) * RS + r2) = pair_rows(px[i]);
                 }
-            __syncthreads();
-            if (r0 + 32 < re) fetch(r0 + 32);
+        };
+        // whole ring turns: chunks past the row range load and multiply zeros (at most WD - 1 of them)
+        const int nchunk = ((int)((re - rs + 31) / 32) + WD - 1) / WD * WD;
+        static_for<0, WD>([&](auto sc) __attribute__((always_inline)) { fetch(sc, rs + 32ll * decltype(sc)::value); });
+        for (int c = 0; c < nchunk; c += WD) {
+            static_for<0, WD>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc)::value;
+                const int ch = c + s;
+                {
+                    bf16_t *sA = sT + (ch & 1) * (1 + WKT) * 64 * RS, *sB = sA + 64 * RS;
+                    stage(sc, rs + 32ll * ch, sA, sB);
+                    if (ch == 0) PSND_WSTAMP(1);
+                    __syncthreads();
+                    fetch(sc, rs + 32ll * (ch + WD));
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(sA + (wm * 32 + li) * RS + 16 * kk + 8 * kg);
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(sA + (wm * 32 + li) * RS + 16 * kk + 8 * kg);
 #pragma unroll
-                for (int j = 0; j < WKT; ++j)
-                    if (j < nt) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(sB + (j * 64 + wn * 32 + li) * RS + 16 * kk + 8 * kg);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                        for (int j = 0; j < WKT; ++j)
+                            if (j < nt) {
+                                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(sB + (j * 64 + wn * 32 + li) * RS + 16 * kk + 8 * kg);
+                                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                            }
                     }
-            }
-            __syncthreads();
+                }
+            });
         }
-        // D[i = co][j = ci]: col = lane & 31 -> ci, rows -> co
+        __syncthreads();                      // a second tap group restarts in LDS buffer 0
+        PSND_WSTAMP(2);
+        // D[i = co][j = ci]: col = lane & 31 -> ci, rows -> co.  128-B runs per (co, tap): plain stores.
         const int ci = ci0 + wn * 32 + li;
         if (ci < p.Ca) {
 #pragma unroll
             for (int j = 0; j < WKT; ++j)
                 if (j < nt) {
+                    float *dst = p.gw + (((size_t)split * p.k + t0 + j) * p.Cb) * p.Ca + ci;
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
                         const int co = co0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
-                        if (co < p.Cb) unsafeAtomicAdd(p.gw + ((size_t)(t0 + j) * p.Cb + co) * p.Ca + ci, acc[j][rg]);
+                        if (co < p.Cb) dst[(size_t)co * p.Ca] = acc[j][rg];
                     }
                 }
         }
     }
+    PSND_WSTAMP(3);
+#ifdef PSND_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    PSND_WSTAMP(4);
+#endif
     if (do_bias && p.gbias) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = bsum[e];
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (rr == 0 && co0 + 8 * cg + e < p.Cb) unsafeAtomicAdd(p.gbias + co0 + 8 * cg + e, v);
+            if (rr == 0 && co0 + 8 * cg + e < p.Cb) p.gbias[(size_t)split * p.Cb + co0 + 8 * cg + e] = v;
         }
     }
 }
@@ -477,17 +562,33 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const fl
 
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
 //   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
-__global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw, const float *v, const float *g, int Cout, int Cin, int k,
-                                                          int Cb, int Ca, float *gv, float *gg) {
+__global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
+                                                          const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
+                                                          float *gg, float *gbias) {
+    // one workgroup per output channel: sums the wgrad slabs (coalesced over ci), then the weight-norm backward
+    extern __shared__ float s_gw[];                    // Cin * k summed gradients of this channel, [j][ci]
     __shared__ float red[8];
     const int co = blockIdx.x, n = Cin * k;
+    const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int ci = i / k, j = i - ci * k;
-        const float vv = vr[i];
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int j = e / Cin, ci = e - j * Cin;
+        const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= splits; sp += 4) {
+            a0 += src[(size_t)sp * slab];
+            a1 += src[(size_t)(sp + 1) * slab];
+            a2 += src[(size_t)(sp + 2) * slab];
+            a3 += src[(size_t)(sp + 3) * slab];
+        }
+        for (; sp < splits; ++sp) a0 += src[(size_t)sp * slab];
+        const float gsum = (a0 + a1) + (a2 + a3);
+        s_gw[e] = gsum;
+        const float vv = vr[ci * k + j];
         ss += vv * vv;
-        dot += vv * gw[((size_t)j * Cb + co) * Ca + ci];
+        dot += vv * gsum;
     }
     for (int m = 32; m >= 1; m >>= 1) {
         ss += __shfl_xor(ss, m, 64);
@@ -500,9 +601,16 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw, const
     const float gs = g[co] / nrm;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int ci = i / k, j = i - ci * k;
-        gv[(size_t)co * n + i] = gs * (gw[((size_t)j * Cb + co) * Ca + ci] - vr[i] / nrm * d);
+        gv[(size_t)co * n + i] = gs * (s_gw[j * Cin + ci] - vr[i] / nrm * d);
     }
-    if (threadIdx.x == 0) gg[co] = d;
+    if (threadIdx.x == 0) {
+        gg[co] = d;
+        if (gbias && gb_part) {
+            float b = 0.f;
+            for (int sp = 0; sp < splits; ++sp) b += gb_part[(size_t)sp * Cb + co];
+            gbias[co] = b;
+        }
+    }
 }
 
 }  // namespace
@@ -552,8 +660,10 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         }                                                                                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                                        \
     } while (0)
+    if ((size_t)p.R * Ca * 2 >= ((size_t)1 << 32) || (size_t)k * Cb * Ca * 2 >= ((size_t)1 << 32))
+        PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: operand larger than 4 GB (32-bit buffer offsets)");
     if (k <= 3 && nbuf == 2 && !A2) PSND_CONV_LAUNCH(3, 8, 2);
-    else if (k <= 3 && nbuf == 2) PSND_CONV_LAUNCH(3, 5, 2);
+    else if (k <= 3 && nbuf == 2) PSND_CONV_LAUNCH(3, 4, 2);
     else if (k <= 7 && nbuf == 2) PSND_CONV_LAUNCH(7, 3, 2);
     else if (k <= 11 && nbuf == 2) PSND_CONV_LAUNCH(11, 2, 2);
     else if (nbuf == 2) PSND_CONV_LAUNCH(16, 2, 2);
@@ -586,31 +696,48 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
     return PSND_OK;
 }
 
-extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
-                                    int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw, float *gbias, void *g_out,
-                                    void *stream) {
-    if ((!G1 && !G2) || (G2 && !GM) || !xa || !gw) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad: null pointer");
-    if (Ca % 8 != 0 || Cb % 8 != 0 || k < 1 || k > 16 || N < 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: Ca=%d Cb=%d k=%d", Ca, Cb, k);
-    if (N == 0) return PSND_OK;
-    WgradParams p;
-    p.G1 = static_cast<const bf16_t *>(G1), p.G2 = static_cast<const bf16_t *>(G2), p.GM = static_cast<const bf16_t *>(GM);
-    p.xa = static_cast<const bf16_t *>(xa), p.gw = gw, p.gbias = gbias, p.g_out = static_cast<bf16_t *>(g_out);
-    p.R = N * (int64_t)Lp, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.g2_slope = g2_slope;
+static int wgrad_splits(int64_t R, int Ca, int Cb, int64_t *rps_out) {
     const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64;
-    int64_t target = 512;                       // ~2 workgroups per CU; every split costs k*64*64 fp32 atomics per tile
+    int64_t target = 256;                       // one workgroup per CU: the register ring (320 VGPRs incl. AGPRs) leaves room
+                                                // for one; 512 blocks = two rounds measured 22 us vs 17 us at the config-2 shape
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
-    int64_t rps = (p.R + splits - 1) / splits;
+    int64_t rps = (R + splits - 1) / splits;
     rps = (rps + 31) / 32 * 32;
     if (rps < 64) rps = 64;
-    splits = (p.R + rps - 1) / rps;
+    splits = (R + rps - 1) / rps;
+    if (rps_out) *rps_out = rps;
+    return (int)splits;
+}
+
+extern "C" int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb) {
+    if (N <= 0 || Lp <= 0 || Ca <= 0 || Cb <= 0) return 0;
+    return wgrad_splits(N * (int64_t)Lp, Ca, Cb, nullptr);
+}
+
+extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
+                                    int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,
+                                    void *g_out, void *stream) {
+    if ((!G1 && !G2) || (G2 && !GM) || !xa || !gw_part) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad: null pointer");
+    if (Ca % 8 != 0 || Cb % 8 != 0 || k < 1 || k > 16 || N < 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: Ca=%d Cb=%d k=%d", Ca, Cb, k);
+    if (N == 0) return PSND_OK;
+    if ((size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 32)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: operand larger than 4 GB");
+    WgradParams p;
+    p.G1 = static_cast<const bf16_t *>(G1), p.G2 = static_cast<const bf16_t *>(G2), p.GM = static_cast<const bf16_t *>(GM);
+    p.xa = static_cast<const bf16_t *>(xa), p.gw = gw_part, p.gbias = gbias_part, p.g_out = static_cast<bf16_t *>(g_out);
+    p.R = N * (int64_t)Lp, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.g2_slope = g2_slope;
+    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64;
+    int64_t rps;
+    const int splits = wgrad_splits(p.R, Ca, Cb, &rps);
     p.rows_per_split = (int)rps;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * (size_t)k * Cb * Ca, s);
-    if (e == hipSuccess && gbias) e = hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)Cb, s);
-    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl_wgrad: memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)splits), dim3(256), 0, s, p);
+#ifdef PSND_TRACE
+    {
+        const char *tp = getenv("PSND_TRACE_PTR");
+        p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
+    }
+#endif
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)splits), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("conv1d_cl_wgrad");
     return PSND_OK;
 }
@@ -634,11 +761,13 @@ extern "C" int psnd_conv1d_prep(const float *v, const float *g, const float *bia
     return PSND_OK;
 }
 
-extern "C" int psnd_conv1d_wnorm_bwd(const float *gw, const float *v, const float *g, int Cout, int Cin, int k, int Cb, int Ca,
-                                     float *gv, float *gg, void *stream) {
-    if (!gw || !v || !g || !gv || !gg) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd: null pointer");
-    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), gw, v, g, Cout, Cin, k, Cb, Ca,
-                       gv, gg);
+extern "C" int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
+                                     int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream) {
+    if (!gw_part || !v || !g || !gv || !gg || splits < 1) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd: null pointer / splits");
+    const size_t lds = sizeof(float) * (size_t)Cin * k;
+    if (lds > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd: Cin*k=%d too large", Cin * k);
+    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream), gw_part, gbias_part, splits,
+                       v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd");
     return PSND_OK;
 }

@@ -74,6 +74,7 @@ def all_reduce_scalar(value, op: str = 'sum', device=None) -> float:
 class FlatGradReducer:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20):
         self.world = world_size()
+        self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []            # dicts: flat, params, pending, work
         self._bucket_of = {}
@@ -119,6 +120,8 @@ class FlatGradReducer:
                 off += p.numel()
 
     def _on_grad(self, p):
+        if self.deferred:            # backward is being captured / replayed as a hipGraph: no collective from inside it
+            return
         b = self._bucket_of[p]
         b['pending'] -= 1
         if b['pending'] == 0:

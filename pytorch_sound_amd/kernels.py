@@ -60,7 +60,7 @@ def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
     phase = mk() if want_phase else None
     re = mk() if want_reim else None
     im = mk() if want_reim else None
-    ev = STFT_FWD_EVENTS
+    ev = STFT_FWD_EVENTS if not torch.cuda.is_current_stream_capturing() else None   # no timing events inside a hipGraph capture
     with torch.cuda.device(wav.device):
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -165,6 +165,12 @@ class Trainer:
         """override: returns (loss tensor, {name: (value, LogType)})"""
         raise NotImplementedError
 
+    def prepare(self, *inputs):
+        """Optional override (not in the reference): parameter-free preprocessing of a batch (feature extraction)
+        that runs eagerly BEFORE forward() - in graph mode it stays outside the captured graph, so its kernels can
+        be timed individually and it may change shapes from step to step.  Returns the inputs of forward()."""
+        return inputs
+
     def _next_batch(self, iterator):
         batch = next(iterator)
         if torch.cuda.is_available():
@@ -227,7 +233,68 @@ class Trainer:
 
     def _train_device_skip(self, step: int, loss: torch.Tensor):
         flag = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+        loss.backward()
+        self._finish_device_skip(step, flag)
+
+    def _loss_is_nan(self, loss: torch.Tensor) -> bool:
+        bad = bool(loss != loss)                       # host sync, as in the reference (trainer.py:205)
         if self._reducer is not None:
+            bad = pdist.all_reduce_scalar(1.0 if bad else 0.0, 'max', loss.device if loss.is_cuda else None) > 0
+        return bad
+
+    # ---- hipGraph mode ---------------------------------------------------------------------------------------
+    # A config-2 step is ~300 kernel launches of 5-20 us each: enqueueing them one by one costs the host more
+    # (3.7 ms) than the GPU needs to run them (~2 ms).  With `graph_steps = True` the launch-bound part of a
+    # non-logging step - gradient zeroing, forward(), the NaN flag and backward - is captured ONCE per input
+    # signature into a hipGraph (torch.cuda.CUDAGraph) and replayed; prepare() before it and the tail after it
+    # (gradient all-reduce over RCCL, clipping, the fused optimizer step with its on-device NaN skip) stay
+    # eager, so nothing of RCCL is ever captured.  Gradients live in the flat buckets of FlatGradReducer (static
+    # addresses; the per-bucket backward hooks are deferred to one all-reduce after the replay).  Requirements:
+    # CUDA inputs, no scheduler, an optimizer with the found_inf protocol (fused Adam/AdamW/SGD), a forward()
+    # free of host synchronisation.  Logging steps and the first `graph_warmup` steps of a signature run eagerly.
+    graph_steps = False
+    graph_warmup = 3
+
+    def _train_graph(self, step: int, batch) -> bool:
+        if not (self.async_nan_check and self.scheduler is None
+                and getattr(self.optimizer, '_step_supports_amp_scaling', False)
+                and all(isinstance(t, torch.Tensor) and t.is_cuda for t in batch)):
+            return False
+        if not hasattr(self, '_graphs'):
+            self._graphs = {}
+        sig = tuple((tuple(t.shape), t.dtype) for t in batch)
+        st = self._graphs.setdefault(sig, {'seen': 0})
+        if 'graph' not in st:
+            if st['seen'] < self.graph_warmup:
+                st['seen'] += 1
+                return False
+            self._capture(st, batch)
+        for dst, src in zip(st['inputs'], batch):
+            dst.copy_(src, non_blocking=True)
+        st['graph'].replay()
+        self._finish_device_skip(step, st['flag'])
+        return True
+
+    def _capture(self, st, batch):
+        if self._reducer is None:                      # single GPU: the same flat, static gradient buffers
+            self._reducer = pdist.FlatGradReducer(self._bare_model)
+        self._reducer.deferred = True
+        st['inputs'] = tuple(t.clone() for t in batch)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._reducer.zero_grad()
+            loss, _ = self.forward(*st['inputs'], is_logging=False)
+            st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+            loss.backward()
+        st['graph'] = graph
+        self._log('captured the training step as a hipGraph for inputs %s' % (
+            ', '.join('x'.join(map(str, t.shape)) for t in batch)))
+
+    def _finish_device_skip(self, step: int, flag: torch.Tensor):
+        """eager tail of a step whose backward has run: NaN flag to the host (asynchronously), gradient all-reduce,
+        clipping, optimizer step with on-device skip"""
+        if pdist.is_dist():
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
         host_flag.copy_(flag, non_blocking=True)
@@ -236,7 +303,6 @@ class Trainer:
         if not hasattr(self, '_nan_pending'):
             self._nan_pending = []
         self._nan_pending.append((step, host_flag, event))
-        loss.backward()
         if self._reducer is not None:
             self._reducer.finish()
         self.clip_grad()
@@ -249,20 +315,16 @@ class Trainer:
             del self.optimizer.grad_scale
         self._poll_nan_log()
 
-    def _loss_is_nan(self, loss: torch.Tensor) -> bool:
-        bad = bool(loss != loss)                       # host sync, as in the reference (trainer.py:205)
-        if self._reducer is not None:
-            bad = pdist.all_reduce_scalar(1.0 if bad else 0.0, 'max', loss.device if loss.is_cuda else None) > 0
-        return bad
-
     def train(self, step: int):
+        log_flag = step % self.log_interval == 0
+        batch = self.prepare(*self._next_batch(self.train_dataset))
+        if self.graph_steps and not log_flag and self._train_graph(step, batch):
+            return
         if self._reducer is not None:
             self._reducer.zero_grad()
         else:
             self.optimizer.zero_grad()
-        log_flag = step % self.log_interval == 0
-
-        loss, meta = self.forward(*self._next_batch(self.train_dataset), is_logging=log_flag)
+        loss, meta = self.forward(*batch, is_logging=log_flag)
 
         if self._can_skip_on_device(loss):
             self._train_device_skip(step, loss)
@@ -299,7 +361,7 @@ class Trainer:
         stat = defaultdict(float)
         for i in range(self.valid_max_step):
             with torch.no_grad():
-                batch_loss, meta = self.forward(*self._next_batch(self.valid_dataset), is_logging=True)
+                batch_loss, meta = self.forward(*self.prepare(*self._next_batch(self.valid_dataset)), is_logging=True)
                 loss += batch_loss
             for key, (value, log_type) in meta.items():
                 if log_type == LogType.SCALAR:

@@ -30,7 +30,7 @@ def _batches(n):
     return [(torch.randn(4, 4, 16, generator=g), torch.randn(4, 2, 16, generator=g)) for _ in range(n)]
 
 
-def _worker(rank, world, port, tmp, q):
+def _worker(rank, world, port, tmp, q, deferred):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
     torch.cuda.is_available = lambda: False
@@ -56,6 +56,7 @@ def _worker(rank, world, port, tmp, q):
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
     tr = T(net, opt, mine, mine[:2], max_step=4, valid_max_step=2, save_interval=2, log_interval=1,
            save_dir=tmp, save_prefix='dp', seed=3)
+    tr._reducer.deferred = deferred        # graph mode: no collective from the backward hooks, one reduction in finish()
     tr.run()
     q.put((rank, {k: v.numpy() for k, v in net.state_dict().items()}, float(tr.best_valid_loss)))
     dist.barrier()
@@ -63,11 +64,12 @@ def _worker(rank, world, port, tmp, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_training(tmp_path):
+@pytest.mark.parametrize('deferred', [False, True])
+def test_two_rank_gloo_training(tmp_path, deferred):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, deferred)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

@@ -1,0 +1,68 @@
+"""Trainer.graph_steps on the GPU: a run whose steps are replayed from a hipGraph must follow the eager run
+(same seeds, same batches) - parameters after 12 steps equal to fp32 reassociation noise - and must skip a NaN step
+on the device exactly like the eager path."""
+import tempfile
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(graph, steps=12, poison_step=None):
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    from pytorch_sound_amd.models.transforms import STFT
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    model = build_model('conv_separator_voicebank').to(dev)
+    stft = STFT(1024, 256).to(dev)
+    g = torch.Generator().manual_seed(3)
+    pool = [(torch.randn(4, 8192, generator=g) * 0.1, torch.randn(4, 8192, generator=g) * 0.1) for _ in range(steps)]
+    if poison_step is not None:                     # batch i is consumed by step i + 1
+        bad = pool[poison_step - 1][0].clone()
+        bad[0, 100] = float('nan')
+        pool[poison_step - 1] = (bad, pool[poison_step - 1][1])
+
+    class T(Trainer):
+        def prepare(self, noisy, clean):
+            with torch.no_grad():
+                return stft.magnitude(noisy), stft.magnitude(clean)
+
+        def forward(self, mag_mix, mag_ref, is_logging=False):
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                est = self.model(mag_mix)
+            loss = F.l1_loss(est.float(), mag_ref)
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    tr = T(model, opt, pool, pool, max_step=10 ** 9, valid_max_step=1, save_interval=10 ** 9, log_interval=10 ** 9,
+           save_dir=tempfile.mkdtemp(prefix='psnd_graph_'), seed=11)
+    tr.graph_steps = graph
+    model.train()
+    for i in range(1, steps + 1):
+        tr.step = i
+        tr.train(i)
+    torch.cuda.synchronize()
+    tr._poll_nan_log(block=True)
+    captured = len(getattr(tr, '_graphs', {}))
+    return [p.detach().float().clone() for p in model.parameters()], captured, opt
+
+
+def test_graph_steps_follow_eager_steps():
+    eager, n0, _ = _run(False)
+    graph, n1, _ = _run(True)
+    assert n0 == 0 and n1 == 1
+    for a, b in zip(eager, graph):
+        scale = float(a.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-2 * scale     # bf16 model, Adam: a few ulp of bf16 after 12 steps
+
+
+def test_graph_step_skips_nan_on_device():
+    params, n, opt = _run(True, steps=8, poison_step=7)        # step 7 is a replayed step with a NaN input
+    assert n == 1
+    assert all(bool(torch.isfinite(p).all()) for p in params)
+    steps = {int(s['step'].item()) for s in opt.state.values() if 'step' in s}
+    assert steps == {7}                                        # 8 steps, one skipped by the optimizer kernel itself
