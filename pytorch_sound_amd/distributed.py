@@ -91,15 +91,18 @@ class FlatGradReducer:
         if cur:
             groups.append(cur)
         for g in groups:
-            total = sum(p.numel() for p in g)
-            flat = torch.zeros(total, dtype=torch.float32, device=g[0].device)
-            off = 0
+            # every view starts on a 256-byte boundary: the fused optimizer kernels take their vectorised path only
+            # for 16-byte aligned gradients (measured on MI355X: 92 us vs 46 us per multi_tensor_apply launch)
+            offs, off = [], 0
             for p in g:
                 if p.dtype != torch.float32:
                     raise TypeError('FlatGradReducer keeps fp32 master gradients; got %s' % p.dtype)
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-            b = {'flat': flat, 'params': g, 'pending': len(g), 'work': None}
+                offs.append(off)
+                off += (p.numel() + 63) // 64 * 64
+            flat = torch.zeros(off, dtype=torch.float32, device=g[0].device)
+            for p, o in zip(g, offs):
+                p.grad = flat[o:o + p.numel()].view_as(p)
+            b = {'flat': flat, 'params': g, 'offs': offs, 'pending': len(g), 'work': None}
             self.buckets.append(b)
             for p in g:
                 self._bucket_of[p] = b
@@ -113,11 +116,29 @@ class FlatGradReducer:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
             b['work'] = None
-            off = 0
-            for p in b['params']:
-                if p.grad is None or p.grad.data_ptr() != b['flat'].data_ptr() + off * 4:
-                    p.grad = b['flat'][off:off + p.numel()].view_as(p)
-                off += p.numel()
+            self._repoint(b)
+
+    def _repoint(self, b):
+        for p, off in zip(b['params'], b['offs']):
+            if p.grad is None or p.grad.data_ptr() != b['flat'].data_ptr() + off * 4:
+                p.grad = b['flat'][off:off + p.numel()].view_as(p)
+
+    def load_grads(self, grads):
+        """graph mode: the replayed backward left its gradients in the graph's own static tensors (`grads[p]`, None for
+        an unused parameter); copy them into the buckets (one multi-tensor copy per bucket) and make the buckets'
+        views the parameters' .grad again, ready for finish()."""
+        for b in self.buckets:
+            b['pending'] = len(b['params'])
+            b['work'] = None
+            views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
+            src = [grads.get(p) for p in b['params']]
+            have = [(v, g) for v, g in zip(views, src) if g is not None]
+            if len(have) != len(views):
+                b['flat'].zero_()
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for p, v in zip(b['params'], views):
+                p.grad = v
 
     def _on_grad(self, p):
         if self.deferred:            # backward is being captured / replayed as a hipGraph: no collective from inside it

@@ -248,8 +248,9 @@ class Trainer:
     # non-logging step - gradient zeroing, forward(), the NaN flag and backward - is captured ONCE per input
     # signature into a hipGraph (torch.cuda.CUDAGraph) and replayed; prepare() before it and the tail after it
     # (gradient all-reduce over RCCL, clipping, the fused optimizer step with its on-device NaN skip) stay
-    # eager, so nothing of RCCL is ever captured.  Gradients live in the flat buckets of FlatGradReducer (static
-    # addresses; the per-bucket backward hooks are deferred to one all-reduce after the replay).  Requirements:
+    # eager, so nothing of RCCL is ever captured.  The replayed backward writes its gradients into static tensors of
+    # the graph's memory pool; under DDP they are copied into the flat buckets of FlatGradReducer (one multi-tensor
+    # copy, the per-bucket backward hooks are deferred to one all-reduce after the replay).  Requirements:
     # CUDA inputs, no scheduler, an optimizer with the found_inf protocol (fused Adam/AdamW/SGD), a forward()
     # free of host synchronisation.  Logging steps and the first `graph_warmup` steps of a signature run eagerly.
     graph_steps = False
@@ -272,22 +273,29 @@ class Trainer:
         for dst, src in zip(st['inputs'], batch):
             dst.copy_(src, non_blocking=True)
         st['graph'].replay()
+        if self._reducer is not None:                  # DDP: into the flat buckets, reduced in _finish_device_skip
+            self._reducer.load_grads(st['grads'])
+        else:
+            for p, g in st['grads'].items():
+                p.grad = g
         self._finish_device_skip(step, st['flag'])
         return True
 
     def _capture(self, st, batch):
-        if self._reducer is None:                      # single GPU: the same flat, static gradient buffers
-            self._reducer = pdist.FlatGradReducer(self._bare_model)
-        self._reducer.deferred = True
+        if self._reducer is not None:
+            self._reducer.deferred = True              # no collective from inside the captured backward
         st['inputs'] = tuple(t.clone() for t in batch)
+        params = [p for p in self._bare_model.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = None                              # backward then WRITES its gradients (no zero fill, no += kernels)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._reducer.zero_grad()
             loss, _ = self.forward(*st['inputs'], is_logging=False)
             st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
             loss.backward()
         st['graph'] = graph
+        st['grads'] = {p: p.grad for p in params}      # static tensors of the graph's memory pool
         self._log('captured the training step as a hipGraph for inputs %s' % (
             ', '.join('x'.join(map(str, t.shape)) for t in batch)))
 

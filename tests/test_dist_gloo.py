@@ -100,3 +100,24 @@ def test_two_rank_gloo_training(tmp_path, deferred):
     # rank 0 alone wrote checkpoints
     ck = sorted(os.listdir(tmp_path / 'models' / 'dp' / 'Sequential'))
     assert ck == ['step_000002.chkpt', 'step_000004.chkpt']
+
+
+def test_flat_reducer_load_grads_and_alignment():
+    """graph mode hands the reducer gradients that live outside the buckets: they must land in the (256-byte aligned)
+    bucket views, unused parameters must read as zero, and .grad must point into the bucket afterwards"""
+    from pytorch_sound_amd.distributed import FlatGradReducer
+    net = _net()
+    red = FlatGradReducer(net, bucket_bytes=1 << 10)          # several buckets
+    params = [p for p in net.parameters()]
+    grads = {p: torch.full_like(p, float(i + 1)) for i, p in enumerate(params)}
+    grads[params[1]] = None                                   # an unused parameter
+    for b in red.buckets:
+        b['flat'].fill_(7.0)                                  # stale content must not survive for the unused one
+    red.load_grads(grads)
+    for i, p in enumerate(params):
+        assert p.grad.data_ptr() % 256 == red._bucket_of[p]['flat'].data_ptr() % 256
+        lo, hi = red._bucket_of[p]['flat'].data_ptr(), red._bucket_of[p]['flat'].data_ptr() + red._bucket_of[p]['flat'].numel() * 4
+        assert lo <= p.grad.data_ptr() < hi
+        want = 0.0 if i == 1 else float(i + 1)
+        assert bool((p.grad == want).all()), i
+    red.finish()                                              # world 1: a no-op
