@@ -109,6 +109,14 @@ int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, int64_t F, 
                  const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
                  float clamp_lo, float clamp_hi, float *gmag, void *stream);
 
+/* Fused wav -> log-mel: psnd_stft_fwd (magnitude) + psnd_mel_fwd in ONE kernel - the (N,K,F) magnitude lives only in
+ * LDS.  Forward only (LogMelSpectrogram.forward transforms.py:229-244 discards the magnitude and the phase; Audio2Mel
+ * :351-366; interface/hifi_gan.py:46-63).  Covers n_fft = 1024, hop <= 256, hop % 4 == 0 (PSND_E_UNSUPPORTED otherwise:
+ * call the two functions above).  Arguments as in psnd_stft_fwd / psnd_mel_fwd; out : (N,M,F) fp32. */
+int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *stft_plan,
+                    float mag_eps, int M, const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
+                    float clamp_lo, float clamp_hi, float *out, void *stream);
+
 /* ---- Conv1d stacks of models/vocoders/hifi_gan.py:32-147 on channels-last bf16 ("CL") matrices -------------
  *  CL buffer: (N, Lp, Cp) bf16, row r = clip*Lp + l; rows l in [HP, HP+L) hold the clip, every other row is
  *  zero (they are the conv zero padding), channels [C, Cp) are zero padding up to a multiple of 32.

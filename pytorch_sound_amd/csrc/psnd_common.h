@@ -167,3 +167,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_uniform_rsrc(const void *
     void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
+
+// log epilogue of the mel kernels: log(max(mel, pre) + off), pre < 0 disables the inner max
+__device__ __forceinline__ float log_apply(float mel, int kind, float off, float pre) {
+    float v = mel;
+    if (pre >= 0.f) v = fmaxf(v, pre);
+    v += off;
+    if (kind == PSND_LOG_E) return logf(v);
+    if (kind == PSND_LOG_10) return log10f(v);
+    return v;
+}

@@ -47,15 +47,6 @@ struct MelParams {
     float log_offset, pre_clamp_min, clamp_lo, clamp_hi;
 };
 
-__device__ __forceinline__ float log_apply(float mel, int kind, float off, float pre) {
-    float v = mel;
-    if (pre >= 0.f) v = fmaxf(v, pre);
-    v += off;
-    if (kind == PSND_LOG_E) return logf(v);
-    if (kind == PSND_LOG_10) return log10f(v);
-    return v;
-}
-
 // derivative of the forward epilogue wrt mel (0 where any clamp is active; matches autograd of
 // torch.clamp(min=): gradient passes where input >= min / <= max).
 __device__ __forceinline__ float log_grad(float mel, int kind, float off, float pre, float lo, float hi) {

@@ -41,6 +41,11 @@ struct StftFwdParams {
     int hop, pad, ntile, total_tiles;
     float mag_eps;
     int ablate;   // debug only (PSND_ABLATE): bit1 skip global stores
+    // fused wav -> log-mel (psnd_logmel_fwd): the magnitude tile stays in LDS and is projected there
+    const int *mel_plan;
+    float *mel_out;
+    int mel_M, log_kind;
+    float log_offset, pre_clamp_min, clamp_lo, clamp_hi;
 #ifdef PSND_TRACE
     long long *trace;   // tools/trace_stft.py: 8 s_memtime stamps per wave
     int trace_iter;     // which tile iteration of a persistent workgroup is stamped
@@ -281,6 +286,24 @@ struct EmitPk {
     }
 };
 
+// magnitude-only writer into an LDS tile [bin][16 frames]: with iF = 16 and col = 4 * frame the byte offsets that
+// post_emit_pk computes for the (N,K,F) tensor ARE the offsets into that tile
+struct EmitLds {
+    float *tile;
+    v2f eps2;
+    bool valid;
+    template <bool CONJ>
+    __device__ __forceinline__ OutVal make(v2f x) const {
+        OutVal o;
+        const v2f sq = pk::fma(x, x, eps2);
+        o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        return o;
+    }
+    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(tile) + voff + soff) = o.m;
+    }
+};
+
 // za = Z'[k], zb = Z'[C-k], v = v_k  ->  xk = X[k] = S + E,  xc = S - E with X[C-k] = conj(xc)
 __device__ __forceinline__ void rfft_pair_pk(v2f za, v2f zb, v2f v, v2f &xk, v2f &xc) {
     const v2f s = pk::fma(zb, v2f{1.f, -1.f}, za);     // za + conj(zb)
@@ -363,8 +386,9 @@ inline int n1024_area_floats(int hop) {
     return spanp > 16 * kN1024Sfh ? spanp : 16 * kN1024Sfh;
 }
 
-template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST>
+template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false>
 __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(StftFwdParams p) {
+    static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST), "fused log-mel: magnitude only, one tile per workgroup");
     constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5;
     constexpr int HR = R1 / 2;          // rows per exchange half
     constexpr int SFH = kN1024Sfh;
@@ -386,7 +410,9 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
 
     const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);   // pass-1 identity: half-waves hold frames fl, fl+8
     const int f2 = t & 15;                                      // pass-2 identity
-    const int qq = (t >> 6) + 4 * ((t >> 4) & 3);
+    // pairs of a wave: 4 apart (stores: one upward sweep per wave) or, for the LDS magnitude tile of the fused
+    // log-mel kernel, consecutive (4 consecutive bins x 16 frames = 64 distinct banks per ds_write)
+    const int qq = FUSE_MEL ? 4 * (t >> 6) + ((t >> 4) & 3) : (t >> 6) + 4 * ((t >> 4) & 3);
     const bool special = (qq == 0);
     const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
     const int rowA = qq, rowB = special ? 0 : HR - qq; // row inside its half
@@ -555,11 +581,58 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
         __builtin_amdgcn_sched_barrier(0);
 
         const long long F = p.F;
+        if constexpr (FUSE_MEL) {
+            // ---- magnitude tile [513][16] in LDS (the exchange area, 32.8 KB), then the band-sparse mel product on the
+            //      fp32 matrix cores straight out of LDS: the (N,K,F) magnitude never exists in HBM (transforms.py:232-243
+            //      computes and then discards it) - 1344 B per frame end to end instead of 3076 + 2372.
+            float *s_mag = s_x;
+            __syncthreads();                 // every wave has taken its second row out of the exchange
+            EmitLds emit{s_mag, v2f{p.mag_eps, 0.f}, true};
+            post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, FT, f2 * 4);
+            __syncthreads();
+            const int lane = t & 63, wave = t >> 6;
+            const int *plan = p.mel_plan;
+            const int MT = plan[2], KS = plan[3];
+            const float *Wf = reinterpret_cast<const float *>(plan) + plan[6];
+            const int fn = lane & 15, kq = lane >> 4;
+            const bool fvalid = (f0 + fn) < F;
+            const __amdgpu_buffer_rsrc_t rout = make_uniform_rsrc(p.mel_out + ((size_t)clip * p.mel_M) * (size_t)F + (size_t)f0,
+                                                                  (int)(((long long)p.mel_M * F - f0) * 4));
+            // mel row tiles from the top (longest band) down, round-robin over the 4 waves
+            for (int mt = MT - 1 - wave; mt >= 0; mt -= 4) {
+                const int lo = plan[8 + 2 * mt], hi = plan[8 + 2 * mt + 1];
+                const float *W = Wf + (size_t)mt * KS * 64 + lane;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                // 8 weight loads (L2) and 8 magnitude reads (LDS) in flight per batch: the chain of dependent MFMAs
+                // would otherwise wait for one global load per step
+                for (int s0 = lo; s0 < hi; s0 += 8) {
+                    float wv[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int s = s0 + u, k = 4 * s + kq;
+                        wv[u] = s < hi ? W[(size_t)s * 64] : 0.f;
+                        bv[u] = (s < hi && k <= C) ? s_mag[k * FT + fn] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u], bv[u], acc, 0, 0, 0);
+                }
+                // D: row = 4 * (lane >> 4) + reg, column = lane & 15 = frame
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * kq + r;
+                    if (row < p.mel_M && fvalid) {
+                        const float y = fminf(fmaxf(log_apply(acc[r], p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rout, fn * 4, row * (int)F * 4, 0);
+                    }
+                }
+            }
+        } else {
         const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
         const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
         EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
         emit.nostore = p.ablate & 4;
         if (emit.valid) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
+        }
 #ifdef PSND_TRACE
         __builtin_amdgcn_sched_barrier(0);
         PSND_STAMP(6);
@@ -797,5 +870,39 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     else if (m && !ph && ri) hipLaunchKernelGGL((stft_fwd_generic_kernel<true, false, true>), grid, dim3(256), lds, s, p, n_fft);
     else hipLaunchKernelGGL((stft_fwd_generic_kernel<true, true, true>), grid, dim3(256), lds, s, p, n_fft);
     PSND_CHECK_LAUNCH("stft_fwd(generic)");
+    return PSND_OK;
+}
+
+// Fused wav -> log-mel for LogMelSpectrogram.forward (transforms.py:229-244), Audio2Mel.forward (:351-366) and the
+// interface's MelSpectrogram (interface/hifi_gan.py:46-63): n_fft = 1024, hop <= 256 (the span-staged tile kernel).
+extern "C" int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *stft_plan,
+                               float mag_eps, int M, const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min,
+                               float clamp_lo, float clamp_hi, float *out, void *stream) {
+    if (!wav || !stft_plan || !mel_plan || !out) PSND_FAIL(PSND_E_ARG, "logmel_fwd: null pointer");
+    if (n_fft != 1024 || hop <= 0 || hop > 256 || hop % 4 != 0)
+        PSND_FAIL(PSND_E_UNSUPPORTED, "logmel_fwd: fused kernel covers n_fft=1024, hop<=256 (multiple of 4); got %d/%d", n_fft, hop);
+    if (framing < PSND_FRAMING_CENTER || framing > PSND_FRAMING_NONE) PSND_FAIL(PSND_E_ARG, "logmel_fwd: framing=%d", framing);
+    if (M <= 0 || N < 0) PSND_FAIL(PSND_E_ARG, "logmel_fwd: M=%d N=%lld", M, (long long)N);
+    if (log_kind < PSND_LOG_NONE || log_kind > PSND_LOG_10) PSND_FAIL(PSND_E_ARG, "logmel_fwd: log_kind=%d", log_kind);
+    const int pad = framing == PSND_FRAMING_NONE ? 0 : (framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2);
+    if (T <= pad) PSND_FAIL(PSND_E_SHAPE, "logmel_fwd: reflect padding %d needs T > pad (T=%lld)", pad, (long long)T);
+    if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "logmel_fwd: T=%lld exceeds 2^31 samples per clip", (long long)T);
+    const int64_t F = psnd_frame_count(T, n_fft, hop, framing);
+    if (N == 0 || F <= 0) return PSND_OK;
+    if ((int64_t)M * F >= (int64_t)1 << 29) PSND_FAIL(PSND_E_SHAPE, "logmel_fwd: M*F too large");
+    StftFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.wav = wav, p.plan = static_cast<const float *>(stft_plan);
+    p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    p.mel_plan = static_cast<const int *>(mel_plan), p.mel_out = out, p.mel_M = M, p.log_kind = log_kind;
+    p.log_offset = log_offset, p.pre_clamp_min = pre_clamp_min, p.clamp_lo = clamp_lo, p.clamp_hi = clamp_hi;
+    const int64_t ntile = (F + 15) / 16;
+    if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "logmel_fwd: too many tiles");
+    p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+    const size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(hop) - 16 * 68);
+    const int grid = (p.total_tiles + 7) & ~7;
+    hipLaunchKernelGGL((stft_fwd_n1024_kernel<true, false, false, 5, false, true>), dim3(grid), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), p);
+    PSND_CHECK_LAUNCH("logmel_fwd");
     return PSND_OK;
 }

@@ -110,6 +110,28 @@ def mel_forward(mag, mel_plan_t, M, log_kind=LOG_E, log_offset=0.0, pre_clamp_mi
     return out, lin
 
 
+def logmel_fused_ok(wav, n_fft, hop):
+    """the fused wav -> log-mel kernel covers the span-staged tile size and needs no gradient (forward only)"""
+    return (n_fft == 1024 and 0 < hop <= 256 and hop % 4 == 0 and wav.is_cuda
+            and not (torch.is_grad_enabled() and wav.requires_grad))
+
+
+def logmel_forward(wav, n_fft, hop, stft_plan_t, mel_plan_t, M, framing=FRAMING_CENTER, mag_eps=0.0, log_kind=LOG_E,
+                   log_offset=0.0, pre_clamp_min=None, clamp_lo=None, clamp_hi=None):
+    """psnd_logmel_fwd: (N,T) waveform -> (N,M,F) log-mel, magnitude kept on chip"""
+    _need_cuda(wav, 'wav')
+    wav = wav.detach().contiguous()
+    N, T = wav.shape
+    F = frame_count(T, n_fft, hop, framing)
+    lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+    out = torch.empty((N, M, max(F, 0)), dtype=torch.float32, device=wav.device)
+    with torch.cuda.device(wav.device):
+        check(lib().psnd_logmel_fwd(ptr(wav), N, T, n_fft, hop, framing, ptr(stft_plan_t), float(mag_eps), M,
+                                    ptr(mel_plan_t), log_kind, float(log_offset), pre, lo, hi, ptr(out),
+                                    stream_ptr(wav.device)), 'psnd_logmel_fwd')
+    return out
+
+
 def mel_backward(gout, mel_lin, mel_plan_t, K, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None,
                  clamp_lo=None, clamp_hi=None):
     _need_cuda(gout, 'gout')

@@ -163,6 +163,13 @@ class LogMelSpectrogram(nn.Module):
         return self._plans.get(key, mf.device, lambda: K.mel_plan(mf.detach().cpu().numpy()))
 
     def forward(self, wav: torch.Tensor, log_offset: float = 1e-6) -> torch.Tensor:
+        st = self.stft
+        if (st.filter_length // 2 + 1 == self.mel_filter.shape[1]
+                and K.logmel_fused_ok(wav, st.filter_length, st.hop_length)):
+            w2 = _as_2d(wav)                           # one kernel, the magnitude never leaves the chip
+            return K.logmel_forward(w2, st.filter_length, st.hop_length, st._plan(w2.device), self._mel_plan(),
+                                    self.mel_size, K.FRAMING_CENTER, 0.0, K.LOG_E, float(log_offset), None,
+                                    self.min_db if self.min_db else None, self.max_db if self.max_db else None)
         mag = self.stft.magnitude(wav)
         if mag.shape[1] != self.mel_filter.shape[1]:
             raise RuntimeError('mel_filter has %d bins but the STFT (filter_length=win_length) produced %d: '
@@ -230,6 +237,10 @@ class _HifiGanMel(nn.Module):
         return self._plans.get(key, mf.device, lambda: K.mel_plan(mf.detach().cpu().numpy()))
 
     def _logmel(self, wav2d, framing, mag_eps, log_kind):
+        if K.logmel_fused_ok(wav2d, self.n_fft, self.hop_length):
+            M = getattr(self, self._filter_buf).shape[0]
+            return K.logmel_forward(wav2d, self.n_fft, self.hop_length, self._stft_plan(wav2d.device), self._mel_plan(), M,
+                                    framing, mag_eps, log_kind, 0.0, 1e-5, None, None)
         mag = K.StftMagPhase.apply(wav2d, self._stft_plan(wav2d.device), self.n_fft, self.hop_length,
                                    framing, mag_eps, False)[0]
         M = getattr(self, self._filter_buf).shape[0]

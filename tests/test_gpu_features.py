@@ -227,6 +227,67 @@ def test_logmel_golden_reference(golden):
         assert np.abs(out.cpu().numpy() - g[name + '/mel']).max() <= 2e-4, name
 
 
+def test_logmel_fused_golden_reference(golden):
+    """the same golden cases through the ONE-kernel path psnd_logmel_fwd (magnitude kept in LDS)"""
+    K = _k()
+    dev = _dev()
+    g = golden('logmel')
+    ran = 0
+    for name in ['default', 'noclamp', 'zero_db_disables', 'silence']:
+        kw = g[name + '/kw']
+        sr, M, n_fft, win, hop = (int(v) for v in kw[:5])
+        if win != 1024 or hop > 256:
+            continue
+        min_db = None if np.isnan(kw[5]) else kw[5]
+        max_db = None if np.isnan(kw[6]) else kw[6]
+        wav = torch.from_numpy(g[name + '/wav']).to(dev)
+        plan = K.stft_plan(win, ofe.analysis_window(win)).to(dev)
+        mplan = K.mel_plan(g[name + '/mel_filter']).to(dev)
+        out = K.logmel_forward(wav, win, hop, plan, mplan, M, K.FRAMING_CENTER, 0.0, K.LOG_E, 1e-6, None,
+                               ofe.db_to_ln(min_db) if min_db else None, ofe.db_to_ln(max_db) if max_db else None)
+        assert np.abs(out.cpu().numpy() - g[name + '/mel']).max() <= 2e-4, name
+        ran += 1
+    assert ran >= 2
+
+
+@pytest.mark.parametrize('N,T,hop,framing,M', [(3, 44100, 256, 0, 80), (2, 8192, 256, 1, 80), (1, 5000, 200, 0, 40),
+                                                (5, 2 * 4096 + 77, 128, 0, 80), (1, 600, 256, 0, 80)])
+def test_logmel_fused_equals_two_kernel_path(N, T, hop, framing, M):
+    """psnd_logmel_fwd == psnd_stft_fwd -> psnd_mel_fwd on the same inputs (same arithmetic, same summation order in the
+    mel product: <= 1 ulp-level differences, 2e-6 abs on the log scale) and vs the float64 oracle (2e-5, as the unfused path)"""
+    K = _k()
+    dev = _dev()
+    wav_np = seeded_wav(N + hop, N, T)
+    wav = torch.from_numpy(wav_np).to(dev)
+    plan = K.stft_plan(1024, ofe.analysis_window(1024)).to(dev)
+    W = ofe.mel_filterbank(22050, 1024, M, 0.0, 8000.0)
+    mplan = K.mel_plan(W).to(dev)
+    lo, hi = ofe.db_to_ln(-50), ofe.db_to_ln(30)
+    fused = K.logmel_forward(wav, 1024, hop, plan, mplan, M, framing, 1e-9, K.LOG_E, 1e-6, None, lo, hi)
+    mag = K.stft_forward(wav, 1024, hop, plan, framing=framing, mag_eps=1e-9)['mag']
+    two, _ = K.mel_forward(mag, mplan, M, K.LOG_E, 1e-6, None, lo, hi)
+    assert fused.shape == two.shape
+    assert float((fused - two).abs().max()) <= 2e-6
+    mag64 = ofe.stft_mag_f64(wav_np, 1024, hop, framing=framing, eps=1e-9)
+    ref = np.clip(np.log(np.matmul(W.astype(np.float64), mag64) + 1e-6), lo, hi)
+    assert np.abs(fused.cpu().numpy() - ref).max() <= 2e-5
+
+
+def test_logmel_module_takes_the_fused_path():
+    from pytorch_sound_amd.models.transforms import LogMelSpectrogram
+    K = _k()
+    dev = _dev()
+    m = LogMelSpectrogram(22050, 80, 1024, 1024, 256, -50, 30, 0.0, 8000.0).to(dev)
+    wav = torch.from_numpy(seeded_wav(5, 2, 22050)).to(dev)
+    y = m(wav)                                         # no grad wanted -> fused
+    wg = wav.clone().requires_grad_(True)
+    y2 = m(wg)                                         # differentiable -> stft_fwd + mel_fwd with autograd
+    assert y2.requires_grad and not y.requires_grad
+    assert float((y - y2.detach()).abs().max()) <= 2e-6
+    y2.sum().backward()
+    assert bool(torch.isfinite(wg.grad).all())
+
+
 # ------------------------------------------------------------------------------------------------
 # STFT backward (adjoint) - psnd_stft_bwd
 # ------------------------------------------------------------------------------------------------
