@@ -187,3 +187,12 @@ def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True):
         last = i == n - 1
         x, xa = fused_conv(ta, c2, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1)
     return x, xa
+
+
+def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True):
+    """ResBlock2 (hifi_gan.py:84-88) on CL buffers: x = conv(leaky_relu(x)) + x per conv."""
+    n = len(block.convs)
+    for i, c in enumerate(block.convs):
+        last = i == n - 1
+        x, xa = fused_conv(xa, c, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1)
+    return x, xa

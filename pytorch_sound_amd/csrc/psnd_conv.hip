@@ -632,6 +632,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
     }
     if (hm > HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: tap reach %d exceeds the halo HP=%d", hm, HP);
+    if (hm > 25) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl: tap reach %d > 25 (size of the staged A tile)", hm);
     if (N == 0) return PSND_OK;
     ConvParams p;
     p.A = static_cast<const bf16_t *>(A), p.A2 = static_cast<const bf16_t *>(A2), p.AM = static_cast<const bf16_t *>(AM);

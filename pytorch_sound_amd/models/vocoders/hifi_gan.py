@@ -147,6 +147,8 @@ class Generator(nn.Module):
         self.conv_post = WNConv1d(ch, 1, 7, 1, 3, init_std=0.01)
 
     def forward(self, x):
+        if self._cl_ok(x):
+            return self.forward_cl(x)
         x = self.conv_pre(x)
         for i, up in enumerate(self.ups):
             x = up(F.leaky_relu(x, LRELU_SLOPE))
@@ -157,6 +159,58 @@ class Generator(nn.Module):
             x = xs / self.num_kernels
         x = F.leaky_relu(x)            # default slope 0.01, as the reference
         return torch.tanh(self.conv_post(x))
+
+    # ---- gfx950 path: every Conv1d of the generator (conv_pre, all ResBlocks, conv_post = 74 of the 78 convs of v1,
+    #      >95 % of its FLOPs) runs on the channels-last bf16 implicit-GEMM kernels with leaky-relu / bias / residual /
+    #      weight norm fused (pytorch_sound_amd/cl.py); the 3-4 ConvTranspose1d upsamplers are still library calls,
+    #      bracketed by the layout kernels.  fp32 in / fp32 out, fp32 accumulation, bf16 activations between convs.
+    use_cl = True
+    _CL_MAX_REACH = 25          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for
+
+    def _cl_ok(self, x) -> bool:
+        if not (self.use_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+            return False
+        if any(not hasattr(c, 'weight_v') for c in [self.conv_pre, self.conv_post]):
+            return False                     # weight norm removed (inference wrapper): plain torch path
+        reach = 0
+        for block in self.resblocks:
+            convs = list(block.convs1) + list(block.convs2) if hasattr(block, 'convs1') else list(block.convs)
+            if any(not hasattr(c, 'weight_v') for c in convs):
+                return False
+            reach = max([reach] + [c.padding for c in convs])
+        return reach <= self._CL_MAX_REACH
+
+    def forward_cl(self, x):
+        from pytorch_sound_amd import cl
+        N, _, T = x.shape
+        halo = max([self.conv_pre.padding, self.conv_post.padding] + [
+            c.padding for b in self.resblocks
+            for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))])
+        shape = cl.CLShape(N, T, halo)
+        _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE)
+        c = self.conv_pre.weight_v.shape[0]
+        h = cl.FromCL.apply(xa, c, T, shape)                       # leaky_relu(conv_pre(x), 0.1), (N, C, T) fp32
+        for i, up in enumerate(self.ups):
+            h = up(h)                                              # ConvTranspose1d (library)
+            c, T = h.shape[1], h.shape[2]
+            shape = cl.CLShape(N, T, halo)
+            x_raw = cl.ToCL.apply(h, shape, 0)
+            x_act = cl.ToCL.apply(F.leaky_relu(h, LRELU_SLOPE), shape, 0)
+            stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            acc = None
+            for block in stage:
+                if hasattr(block, 'convs1'):
+                    r, _ = cl.resblock1_cl(block, x_raw, x_act, shape)
+                else:
+                    r, _ = cl.resblock2_cl(block, x_raw, x_act, shape)
+                r = cl.FromCL.apply(r, c, T, shape)
+                acc = r if acc is None else acc + r
+            h = acc / self.num_kernels
+            if i + 1 < len(self.ups):
+                h = F.leaky_relu(h, LRELU_SLOPE)
+        xa = cl.ToCL.apply(F.leaky_relu(h), shape, 0)              # default slope 0.01, as the reference
+        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False)
+        return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
 
     def remove_weight_norm(self):
         for up in self.ups:
