@@ -645,6 +645,171 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
 }
 
 // ---------------------------------------------------------------------------------------------
+// n_fft = 4096 kernel (config 5: 44.1 kHz music, 30 s clips).  C = 2048 = 8 x 16 x 16 complex points, three passes,
+// one 512-thread workgroup per tile of 8 consecutive frames; the frames live in LDS between the passes
+// (X[frame][q_a][...], 142 KB: one workgroup of 16 waves per CU), the waveform span of the tile (7*hop + 4096 samples)
+// is staged once into the same area.
+//   pass A  thread = (column j < 256, half of the frames): taps z[j + 256 a] from the span (ds_read_b64), window and W_2048^(j q_a)
+//           straight from the plan (the same for the 4 frames), radix-8 in VGPRs   -> X[f][q_a][j]
+//   pass B  thread = (f, q_a, j2): radix-16 over b of X[f][q_a][j2 + 16 b], twiddle W_256^(j2 q_b), IN PLACE
+//                                                                                  -> X[f][q_a][16 q_b + j2]
+//   pass C  thread = (f, pair qq): rows r = q_a + 8 q_b = qq and 128 - qq (16 contiguous values each, ds_read_b128),
+//           two radix-16 FFTs -> Z'[r + 128 q_c]; the real-FFT split pairs (r, q_c) with (128 - r, 15 - q_c): exactly
+//           post_emit_pk<128, 16>, the packed split + magnitude + ascending-sweep stores of the n = 1024 kernel.
+// Packed fp32 arithmetic throughout (psnd_pk.h).  Stores are 32-B runs (8 frames) per bin - LDS capacity, not the
+// algorithm, limits the frames per workgroup (16 frames of 2048 complex points would need 256 KB).
+// plan(4096) = [win[4096] | wA[256][16] | twA[256][8](re,im) | twB[16][16](re,im) | vk[1025](re,im), padded]
+// ---------------------------------------------------------------------------------------------
+// LDS pitches (complex values): q_a blocks 274*8 B = 144 (mod 256), frames 2212*8 B = 32 (mod 256):
+//   pass C, ds_read_b128 by 16 lanes = 8 frames x 2 consecutive q_a -> 32 f + 144 q_a (mod 256) = 16 distinct 16-B slots
+//   pass B, ds_read/write_b64 by 32 lanes = 16 j2 x frames (f, f+4)  -> the two 128-B runs are 128 B apart (mod 256)
+constexpr int k4096FT = 8;
+constexpr int k4096QP = 256 + 18;
+constexpr int k4096FP = 8 * k4096QP + 20;
+constexpr int k4096VK = 2052;                      // floats of the vk table (1025 entries, padded)
+constexpr int k4096LdsFloats = k4096FT * k4096FP * 2 + k4096VK + 512;
+constexpr int k4096PlanFloats = 4096 * 3 + 512 + k4096VK;
+
+template <bool MAG, bool PHASE, bool REIM>
+__global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p) {
+    constexpr int C = 2048, NFFT = 4096, FT = k4096FT, QP = k4096QP, FP = k4096FP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_x = smem;                               // X[f][q_a][QP] of (re, im); first the waveform span
+    float *s_vk = s_x + FT * FP * 2;
+    float *s_twb = s_vk + k4096VK;
+    const int t = threadIdx.x;
+    const float *plan = p.plan;
+    const float *g_wa = plan + NFFT, *g_twa = plan + 2 * NFFT, *g_twb = plan + 3 * NFFT, *g_vk = plan + 3 * NFFT + 512;
+
+    // XCD-contiguous tile map, one tile per workgroup
+    const int chunk = (p.total_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile >= p.total_tiles) return;
+    const int clip = tile / p.ntile;
+    const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+    const float *x = p.wav + (size_t)clip * p.T;
+    const int hop = p.hop;
+    const int span_len = (FT - 1) * hop + NFFT;
+
+    // ---- prologue: span (HBM) and tables (L2) ------------------------------------------------------------------
+    {
+        const long long g0 = f0 * hop - p.pad;
+        const int Ti = (int)p.T;
+        for (int s4 = t * 4; s4 < span_len; s4 += 2048) {
+            const long long g = g0 + s4;
+            f32x4 v;
+            if (g >= 0 && g + 3 < p.T) {
+                v = *reinterpret_cast<const f32x4_u *>(x + g);
+            } else {
+                const int gi = (int)g;
+                v.x = x[reflect_idx32(gi, Ti)], v.y = x[reflect_idx32(gi + 1, Ti)];
+                v.z = x[reflect_idx32(gi + 2, Ti)], v.w = x[reflect_idx32(gi + 3, Ti)];
+            }
+            *reinterpret_cast<f32x4 *>(s_x + s4) = v;
+        }
+        for (int i = t; i < (k4096VK + 512) / 4; i += 512) {
+            const f32x4 v = i < k4096VK / 4 ? reinterpret_cast<const f32x4 *>(g_vk)[i]
+                                            : reinterpret_cast<const f32x4 *>(g_twb)[i - k4096VK / 4];
+            reinterpret_cast<f32x4 *>(s_vk)[i] = v;      // s_twb follows s_vk
+        }
+    }
+    // window and pass-A twiddles of column j: the same for all frames
+    const int ja = t & 255, fa0 = 4 * (t >> 8);      // pass-A identity: column, first of its 4 frames
+    f32x4 wv[4], tv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
+        tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
+    }
+    __syncthreads();
+
+    // ---- pass A ----------------------------------------------------------------------------------------------
+    v2f z[4][8];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const v2f w = (a & 1) ? pk::hi(wv[a >> 1]) : pk::lo(wv[a >> 1]);
+            z[f][a] = *reinterpret_cast<const v2f *>(s_x + (fa0 + f) * hop + 2 * (ja + 256 * a)) * w;
+        }
+    __syncthreads();                                 // span consumed: the area becomes X
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        pk::fft<8>(z[f]);
+        v2f *o = reinterpret_cast<v2f *>(s_x) + (fa0 + f) * FP + ja;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const v2f w = (q & 1) ? pk::hi(tv[q >> 1]) : pk::lo(tv[q >> 1]);
+            o[q * QP] = q == 0 ? z[f][0] : pk::cmul(z[f][ct::bitrev(q, 3)], w);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B (in place) -------------------------------------------------------------------------------------
+    {
+        const int j2 = t & 15;
+        const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2 * 16;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int f = 4 * ((t >> 4) & 1) + 2 * (t >> 8) + h, qa = (t >> 5) & 7;   // a half-wave: frames f, f + 4 of one q_a
+            v2f *base = reinterpret_cast<v2f *>(s_x) + f * FP + qa * QP + j2;
+            v2f y[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) y[b] = base[16 * b];
+            pk::fft<16>(y);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[q]);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass C + real split + output ---------------------------------------------------------------------------
+    const int f = t & 7, qq = t >> 3;
+    const bool special = (qq == 0);
+    const int rA = qq, rB = special ? 64 : 128 - qq;
+    v2f za[16], zb[16];
+    auto read_row = [&](int r, v2f (&dst)[16]) __attribute__((always_inline)) {
+        const float *pr = s_x + 2 * (f * FP + (r & 7) * QP + (r >> 3) * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
+            dst[2 * i] = pk::lo(v);
+            dst[2 * i + 1] = pk::hi(v);
+        }
+    };
+    read_row(rA, za);
+    read_row(rB, zb);
+    pk::fft<16>(za);
+    pk::fft<16>(zb);
+    const long long F = p.F;
+    const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
+    const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
+    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f) < F) && !(p.ablate & 2));
+    emit.nostore = p.ablate & 4;
+    if (emit.valid) post_emit_pk<128, 16>(za, zb, special, rA, rB, s_vk, emit, (int)F, f * 4);
+}
+
+int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * k4096LdsFloats;
+    const int grid = (p.total_tiles + 7) & ~7;
+#define PSND_LAUNCH(M_, P_, R_)                                                                                     \
+    do {                                                                                                            \
+        auto kern = stft_fwd_n4096_kernel<M_, P_, R_>;                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_fwd(n4096): set LDS size: %s", hipGetErrorString(e));       \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);                                            \
+    } while (0)
+    if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
+    else if (mag && phase && !reim) PSND_LAUNCH(true, true, false);
+    else if (!mag && !phase && reim) PSND_LAUNCH(false, false, true);
+    else if (mag && !phase && reim) PSND_LAUNCH(true, false, true);
+    else PSND_LAUNCH(true, true, true);
+#undef PSND_LAUNCH
+    PSND_CHECK_LAUNCH("stft_fwd(n4096)");
+    return PSND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic fallback: any power-of-two n_fft in [16, 8192] without a tuned decomposition.
 // One workgroup per (clip, frame); radix-2 FFT of the packed C-point signal in LDS.
 // Correct, not fast (strided 4-byte stores) - tuned sizes never come here.
@@ -762,6 +927,7 @@ using namespace psnd_stft;
 
 extern "C" size_t psnd_stft_plan_bytes(int n_fft) {
     if (const Decomp *d = find_decomp(n_fft)) return sizeof(float) * (size_t)plan_layout(n_fft, d->R1, d->L).total;
+    if (n_fft == 4096) return sizeof(float) * (size_t)k4096PlanFloats;
     if (generic_ok(n_fft)) return sizeof(float) * (size_t)n_fft;
     return 0;
 }
@@ -772,7 +938,31 @@ extern "C" int psnd_stft_plan_build(int n_fft, const float *window_host, void *p
     float *pl = static_cast<float *>(plan_host);
     const Decomp *d = find_decomp(n_fft);
     if (!d) {
-        memcpy(pl, window_host, sizeof(float) * n_fft);
+        memcpy(pl, window_host, sizeof(float) * n_fft);      // every kernel without a tuned decomposition reads this
+        if (n_fft == 4096) {                                  // tables of stft_fwd_n4096_kernel behind the raw window
+            const double two_pi = 6.283185307179586476925286766559;
+            float *wa = pl + 4096, *twa = pl + 2 * 4096, *twb = pl + 3 * 4096, *vk = pl + 3 * 4096 + 512;
+            memset(wa, 0, sizeof(float) * (k4096PlanFloats - 4096));
+            for (int j = 0; j < 256; ++j)
+                for (int a = 0; a < 8; ++a) {
+                    wa[16 * j + 2 * a] = 0.5f * window_host[2 * (j + 256 * a)];
+                    wa[16 * j + 2 * a + 1] = 0.5f * window_host[2 * (j + 256 * a) + 1];
+                    const double th = two_pi * (double)(j * a) / 2048.0;          // a doubles as q_a here
+                    twa[16 * j + 2 * a] = (float)cos(th);
+                    twa[16 * j + 2 * a + 1] = (float)(-sin(th));
+                }
+            for (int j2 = 0; j2 < 16; ++j2)
+                for (int q = 0; q < 16; ++q) {
+                    const double th = two_pi * (double)(j2 * q) / 256.0;
+                    twb[2 * (16 * j2 + q)] = (float)cos(th);
+                    twb[2 * (16 * j2 + q) + 1] = (float)(-sin(th));
+                }
+            for (int k = 0; k <= 1024; ++k) {
+                const double th = two_pi * (double)k / 4096.0;
+                vk[2 * k] = (float)(-sin(th));
+                vk[2 * k + 1] = (float)(-cos(th));
+            }
+        }
         return PSND_OK;
     }
     const int R1 = d->R1, L = d->L, C = n_fft / 2;
@@ -857,6 +1047,12 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
             }
             case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
         }
+    }
+    if (n_fft == 4096 && hop % 2 == 0 && hop <= 4096 && !getenv("PSND_STFT_GENERIC")) {
+        const int64_t ntile = (F + k4096FT - 1) / k4096FT;
+        if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: too many tiles");
+        p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+        return launch_n4096(p, mag, phase, re, s);
     }
     // generic path
     if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_fwd(generic): grid too large");

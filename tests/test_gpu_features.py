@@ -52,7 +52,11 @@ CASES = [
     (256, 64, None, 1, 5, 1000),
     (2048, 512, None, 0, 1, 6000),
     (2048, 512, 1200, 1, 2, 9000),
-    (4096, 1024, None, 0, 1, 9000),       # generic path until the tuned 4096 kernel lands
+    (4096, 1024, None, 0, 1, 9000),       # three-pass 4096 kernel (config 5), clip shorter than a few frames
+    (4096, 1024, None, 0, 3, 44100),      # several tiles per clip, partial last tile (F = 44: 11 tiles)
+    (4096, 1024, 3000, 1, 2, 30000),      # HiFi-GAN framing, short window
+    (4096, 1022, None, 0, 1, 20000),      # even hop that is not a multiple of 4
+    (4096, 1023, None, 0, 1, 20000),      # odd hop -> generic path
     (128, 32, None, 0, 2, 500),           # generic path
     (64, 16, None, 1, 2, 200),            # generic path
     (1024, 256, None, 0, 1, 513),         # minimum-ish T (> pad): every frame touches an edge

@@ -7,7 +7,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     import numpy as np, torch
     from pytorch_sound_amd import kernels as K
     from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
-    n, h, N, T = 1024, 256, int(os.environ.get('NCLIPS', '1024')), 44100
+    n = int(os.environ.get('NFFT', '1024'))
+    h, N, T = n // 4, int(os.environ.get('NCLIPS', '1024')), int(os.environ.get('TLEN', '44100'))
     dev = torch.device('cuda:0')
     m = np.arange(n); w = (0.5 - 0.5*np.cos(2*np.pi*m/n)).astype(np.float32)
     wav = torch.randn(N, T, device=dev) * 0.07
