@@ -748,7 +748,9 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
     // ---- pass B (in place) -------------------------------------------------------------------------------------
     {
         const int j2 = t & 15;
-        const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2 * 16;
+        // W_256^(j2 q) is symmetric in (j2, q): reading the table as [q][j2] puts the 16 j2 lanes on consecutive 8-B
+        // words (as [j2][q] the rows are 128 B apart: an 8-way bank conflict on every twiddle read)
+        const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             const int f = 4 * ((t >> 4) & 1) + 2 * (t >> 8) + h, qa = (t >> 5) & 7;   // a half-wave: frames f, f + 4 of one q_a
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
             for (int b = 0; b < 16; ++b) y[b] = base[16 * b];
             pk::fft<16>(y);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[q]);
+            for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[16 * q]);
         }
     }
     __syncthreads();
