@@ -18,6 +18,13 @@ def main(path, top=40, out=None):
         lines.append('%-90s %7d %12.1f %10.2f %10.2f %10.2f %6.2f' % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
                                                                       r[5] / 1e3, 100.0 * r[2] / total))
     lines.append('TOTAL kernel time %.1f us over %d dispatches, %d distinct kernels' % (total / 1e3, sum(r[1] for r in rows), len(rows)))
+    # the STFT forward kernel is launched on two workloads in bench.py (in-step: 32 clips; roofline_large: 1024 clips):
+    # report them apart, split at 50 us
+    for r in cur.execute("select %s, sum(end-start < 50000), avg(case when end-start < 50000 then end-start end), "
+                         "sum(end-start >= 50000), avg(case when end-start >= 50000 then end-start end) from kernels "
+                         "where %s like '%%stft_fwd_n1024%%' group by %s" % (namecol, namecol, namecol)).fetchall():
+        lines.append('stft_fwd_n1024 split: %d launches < 50 us, avg %.2f us (in-step, 32 clips) | %d launches >= 50 us, avg %.2f us (1024 clips)'
+                     % (r[1] or 0, (r[2] or 0) / 1e3, r[3] or 0, (r[4] or 0) / 1e3))
     txt = '\n'.join(lines)
     print(txt)
     if out:
