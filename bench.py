@@ -109,7 +109,7 @@ def gpu_bench(args):
     rank, world = pdist.rank(), pdist.world_size()
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if os.environ.get('PSND_DIST_SHARE_GPU') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     T = int(SR * CLIP_SECONDS)

@@ -46,9 +46,14 @@ def init_from_env(backend: str = None) -> bool:
     if dist.is_initialized():
         return True
     use_gpu = torch.cuda.is_available()
+    # PSND_DIST_SHARE_GPU=1 (testing only): every rank on device 0 over gloo - exercises the multi-process step loop
+    # (graph replay + flat-bucket all-reduce) on a single-GPU box, where RCCL refuses two ranks on one device
+    share = os.environ.get('PSND_DIST_SHARE_GPU') == '1'
     if use_gpu:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(0 if share else int(os.environ.get('LOCAL_RANK', '0')))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if share:
+        backend = 'gloo'
     dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
     return True
 
