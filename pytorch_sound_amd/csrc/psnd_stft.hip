@@ -323,56 +323,53 @@ __device__ __forceinline__ void post_emit_pk(v2f (&za)[L], v2f (&zb)[L], bool sp
     const int stepF = R1 * iF * 4;
     const int offA = qA * iF * 4 + col, offB = qB * iF * 4 + col;
     auto vk = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const v2f *>(s_vk + 2 * k); };
+    // The pair of a `special` lane (qA = 0, qB = R1/2) is two SELF-paired rows: row 0 pairs p with L - p (p = 0 gives X[0] and
+    // X[C], p = L/2 the middle bin), row R1/2 pairs p with L-1-p.  A second code path for them made the wave holding those
+    // 16 lanes run the whole split twice (10 % of the kernel: one SIMD per CU carried 1.45x the work).  Instead the
+    // registers of those lanes are re-arranged so that the general code below computes exactly their outputs:
+    //   A' = [ row0[0 .. L/2) | rowH[L/2 .. L) ],   B' = [ rowH[0 .. L/2) | row0[(p + 1) % L] for p in [L/2, L) ]
+    //   first evaluation  f(A'[pp], B'[L-1-pp]) = f(row0[pp], row0[(L - pp) % L])  -> bins R1 pp        | R1 (L - pp)
+    //   second evaluation f(B'[pp], A'[L-1-pp]) = f(rowH[pp], rowH[L-1-pp])        -> bins R1/2 + R1 pp | R1/2 + R1 (L-1-pp)
+    // only the mirror rows differ (offsets below) and the middle bin of row 0 is one extra evaluation.
+    v2f mid = za[ct::bitrev(L / 2, LB)];
+    if (__builtin_amdgcn_ballot_w64(special) != 0) {                 // wave-uniform: only the wave that holds special lanes
+        v2f ta[L / 2];
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {    // row0[(p + 1) % L], p = L/2 + i
+            constexpr int p = L / 2 + decltype(pc)::value;
+            ta[decltype(pc)::value] = za[ct::bitrev((p + 1) % L, LB)];
+        });
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int i = decltype(pc)::value, sl = ct::bitrev(L / 2 + i, LB);
+            const v2f oa = za[sl], ob = zb[sl];
+            za[sl] = special ? ob : oa;
+            zb[sl] = special ? ta[i] : ob;
+        });
+    }
+    const int off1m = special ? R1 * iF * 4 + col : offB;           // mirror rows of the first / second evaluation
+    const int off2m = special ? offB : offA;
     OutVal h1[L / 2], h2[L / 2];
     v2f xk, xc;
-    if (!special) {
-        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int pp = decltype(pc)::value;
-            constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
-            rfft_pair_pk(za[sa], zb[sb], vk(qA + R1 * pp), xk, xc);      // bins qA + R1 pp | qB + R1 (L-1-pp)
-            emit.store(offA, pp * stepF, emit.template make<false>(xk));
-            h1[pp] = emit.template make<true>(xc);
-            rfft_pair_pk(zb[sa], za[sb], vk(qB + R1 * pp), xk, xc);      // bins qB + R1 pp | qA + R1 (L-1-pp)
-            emit.store(offB, pp * stepF, emit.template make<false>(xk));
-            h2[pp] = emit.template make<true>(xc);
-        });
-        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int pp = L / 2 - 1 - decltype(pc)::value;
-            emit.store(offA, (L - 1 - pp) * stepF, h2[pp]);
-            emit.store(offB, (L - 1 - pp) * stepF, h1[pp]);
-        });
-    } else {
-        // butterfly q = 0: bins R1*p pair with R1*(L-p); p = 0 gives X[0] and X[C].  butterfly q = R1/2: bins
-        // R1/2 + R1*p pair with R1/2 + R1*(L-1-p)
-        OutVal hc;
-        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int pp = decltype(pc)::value;
-            {
-                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
-                rfft_pair_pk(za[sa], za[sb], vk(R1 * pp), xk, xc);
-                emit.store(col, pp * stepF, emit.template make<false>(xk));
-                if constexpr (pp == 0) hc = emit.template make<true>(xc);
-                else h1[pp] = emit.template make<true>(xc);
+    static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pp = decltype(pc)::value;
+        constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+        rfft_pair_pk(za[sa], zb[sb], vk(qA + R1 * pp), xk, xc);      // bins qA + R1 pp | qB + R1 (L-1-pp)
+        emit.store(offA, pp * stepF, emit.template make<false>(xk));
+        h1[pp] = emit.template make<true>(xc);
+        rfft_pair_pk(zb[sa], za[sb], vk(qB + R1 * pp), xk, xc);      // bins qB + R1 pp | qA + R1 (L-1-pp)
+        emit.store(offB, pp * stepF, emit.template make<false>(xk));
+        h2[pp] = emit.template make<true>(xc);
+        if constexpr (pp == L / 2 - 1) {
+            if (special) {                                           // middle bin C/2 of row 0 (self-paired), in sweep order
+                rfft_pair_pk(mid, mid, vk(R1 * (L / 2)), xk, xc);
+                emit.store(col, (L / 2) * stepF, emit.template make<false>(xk));
             }
-            {
-                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
-                rfft_pair_pk(zb[sa], zb[sb], vk(R1 / 2 + R1 * pp), xk, xc);
-                emit.store(offB, pp * stepF, emit.template make<false>(xk));
-                h2[pp] = emit.template make<true>(xc);
-            }
-        });
-        {   // middle bin C/2 (self-paired)
-            constexpr int sm = ct::bitrev(L / 2, LB);
-            rfft_pair_pk(za[sm], za[sm], vk(R1 * (L / 2)), xk, xc);
-            emit.store(col, (L / 2) * stepF, emit.template make<false>(xk));
         }
-        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
-            constexpr int pp = L / 2 - 1 - decltype(pc)::value;
-            emit.store(offB, (L - 1 - pp) * stepF, h2[pp]);                       // bin R1/2 + R1 (L-1-pp)
-            if constexpr (pp != 0) emit.store(col, (L - pp) * stepF, h1[pp]);     // bin R1 (L-pp)
-        });
-        emit.store(col, L * stepF, hc);                                           // bin C (Nyquist)
-    }
+    });
+    static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pp = L / 2 - 1 - decltype(pc)::value;
+        emit.store(off2m, (L - 1 - pp) * stepF, h2[pp]);
+        emit.store(off1m, (L - 1 - pp) * stepF, h1[pp]);
+    });
 }
 
 constexpr int kN1024Sfh = 16 * 16 * 2 + 4;   // exchange frame stride (floats): 516/4 odd -> b128 reads conflict-free,
@@ -631,7 +628,7 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
         const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
         EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
         emit.nostore = p.ablate & 4;
-        if (emit.valid) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
+        if (emit.valid && !((p.ablate & 32) && special)) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
         }
 #ifdef PSND_TRACE
         __builtin_amdgcn_sched_barrier(0);
