@@ -678,37 +678,48 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
     const float *plan = p.plan;
     const float *g_wa = plan + NFFT, *g_twa = plan + 2 * NFFT, *g_twb = plan + 3 * NFFT, *g_vk = plan + 3 * NFFT + 512;
 
-    // XCD-contiguous tile map, one tile per workgroup
-    const int chunk = (p.total_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || tile >= p.total_tiles) return;
-    const int clip = tile / p.ntile;
-    const long long f0 = (long long)(tile - clip * p.ntile) * FT;
-    const float *x = p.wav + (size_t)clip * p.T;
+    // One workgroup per CU (142 KB of LDS) walks its tiles (XCD-contiguous strided walk, as tile_walk).  With a single
+    // resident workgroup nothing else hides the HBM latency of the next span, so it is prefetched into registers
+    // (SPV 16-byte pieces per thread) while pass B / C of the current tile run, and committed to LDS once the last row
+    // has been taken out of X - every wait on those loads precedes this tile's stores (one in-order vmcnt).
+    constexpr int SPV = 8;                               // 512 threads x 8 x 16 B = 64 KB >= span of hop <= 1792
+    const TileWalk tw = tile_walk(p.total_tiles);
+    if (tw.first >= tw.end) return;
     const int hop = p.hop;
     const int span_len = (FT - 1) * hop + NFFT;
-
-    // ---- prologue: span (HBM) and tables (L2) ------------------------------------------------------------------
-    {
-        const long long g0 = f0 * hop - p.pad;
+    f32x4 spv[SPV];
+    auto request_span = [&](int tile_) __attribute__((always_inline)) {
+        const int clip_ = tile_ / p.ntile;
+        const float *x_ = p.wav + (size_t)clip_ * p.T;
+        const long long g0 = (long long)(tile_ - clip_ * p.ntile) * FT * hop - p.pad;
         const int Ti = (int)p.T;
-        for (int s4 = t * 4; s4 < span_len; s4 += 2048) {
-            const long long g = g0 + s4;
-            f32x4 v;
-            if (g >= 0 && g + 3 < p.T) {
-                v = *reinterpret_cast<const f32x4_u *>(x + g);
-            } else {
-                const int gi = (int)g;
-                v.x = x[reflect_idx32(gi, Ti)], v.y = x[reflect_idx32(gi + 1, Ti)];
-                v.z = x[reflect_idx32(gi + 2, Ti)], v.w = x[reflect_idx32(gi + 3, Ti)];
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 512 * j) * 4;
+            if (s4 < span_len) {
+                const long long g = g0 + s4;
+                if (g >= 0 && g + 3 < p.T) {
+                    spv[j] = *reinterpret_cast<const f32x4_u *>(x_ + g);
+                } else {
+                    const int gi = (int)g;
+                    spv[j].x = x_[reflect_idx32(gi, Ti)], spv[j].y = x_[reflect_idx32(gi + 1, Ti)];
+                    spv[j].z = x_[reflect_idx32(gi + 2, Ti)], spv[j].w = x_[reflect_idx32(gi + 3, Ti)];
+                }
             }
-            *reinterpret_cast<f32x4 *>(s_x + s4) = v;
-        }
-        for (int i = t; i < (k4096VK + 512) / 4; i += 512) {
-            const f32x4 v = i < k4096VK / 4 ? reinterpret_cast<const f32x4 *>(g_vk)[i]
-                                            : reinterpret_cast<const f32x4 *>(g_twb)[i - k4096VK / 4];
-            reinterpret_cast<f32x4 *>(s_vk)[i] = v;      // s_twb follows s_vk
-        }
+        });
+    };
+    auto commit_span = [&]() __attribute__((always_inline)) {
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 512 * j) * 4;
+            if (s4 < span_len) *reinterpret_cast<f32x4 *>(s_x + s4) = spv[j];
+        });
+    };
+    request_span(tw.first);
+    for (int i = t; i < (k4096VK + 512) / 4; i += 512) {
+        const f32x4 v = i < k4096VK / 4 ? reinterpret_cast<const f32x4 *>(g_vk)[i]
+                                        : reinterpret_cast<const f32x4 *>(g_twb)[i - k4096VK / 4];
+        reinterpret_cast<f32x4 *>(s_vk)[i] = v;          // s_twb follows s_vk
     }
     // window and pass-A twiddles of column j: the same for all frames
     const int ja = t & 255, fa0 = 4 * (t >> 8);      // pass-A identity: column, first of its 4 frames
@@ -718,7 +729,13 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
         wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
         tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
     }
-    __syncthreads();
+    commit_span();
+
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+    const int clip = tile / p.ntile;
+    const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+    const bool more = tile + tw.step < tw.end;
+    __syncthreads();                                 // span(tile) (and, the first time, the tables) visible
 
     // ---- pass A ----------------------------------------------------------------------------------------------
     v2f z[4][8];
@@ -740,6 +757,7 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
             o[q * QP] = q == 0 ? z[f][0] : pk::cmul(z[f][ct::bitrev(q, 3)], w);
         }
     }
+    if (more) request_span(tile + tw.step);          // in flight during pass B and the row reads of pass C
     __syncthreads();
 
     // ---- pass B (in place) -------------------------------------------------------------------------------------
@@ -778,6 +796,10 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
     };
     read_row(rA, za);
     read_row(rB, zb);
+    if (more) {
+        __syncthreads();                             // X fully consumed: it takes the next span
+        commit_span();
+    }
     pk::fft<16>(za);
     pk::fft<16>(zb);
     const long long F = p.F;
@@ -786,11 +808,14 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
     EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f) < F) && !(p.ablate & 2));
     emit.nostore = p.ablate & 4;
     if (emit.valid) post_emit_pk<128, 16>(za, zb, special, rA, rB, s_vk, emit, (int)F, f * 4);
+    }   // tile loop
 }
 
 int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * k4096LdsFloats;
-    const int grid = (p.total_tiles + 7) & ~7;
+    int grid = p.total_tiles < 256 ? p.total_tiles : 256;      // one persistent workgroup per CU
+    if (const char *e = getenv("PSND_STFT4096_GRID")) grid = atoi(e);
+    grid = (grid + 7) & ~7;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                     \
     do {                                                                                                            \
         auto kern = stft_fwd_n4096_kernel<M_, P_, R_>;                                                              \
@@ -1047,7 +1072,7 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
             case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
         }
     }
-    if (n_fft == 4096 && hop % 2 == 0 && hop <= 4096 && !getenv("PSND_STFT_GENERIC")) {
+    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1792 && !getenv("PSND_STFT_GENERIC")) {   // span <= 8 pieces per thread
         const int64_t ntile = (F + k4096FT - 1) / k4096FT;
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: too many tiles");
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
