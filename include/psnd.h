@@ -145,6 +145,11 @@ int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g
                          void *g_out, void *stream);
 int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout, int Cin, int k, int Cb, int Ca,
                      void *wf, void *wb, float *bias_padded, void *stream);
+/* psnd_conv1d_prep for n convs in ONE launch.  descs_dev: device array of n records
+ *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cout, Cin, k, Cb, Ca, blk0; }   (72 bytes, blk0 = sum of
+ *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written
+ *   (zero them once when allocating). */
+int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
 int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);

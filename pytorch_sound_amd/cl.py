@@ -116,7 +116,7 @@ class FusedConvCL(torch.autograd.Function):
     taps, bias gradient and the residual's gradient in one kernel) + weight-norm backward."""
 
     @staticmethod
-    def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope):
+    def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope, prepped=None):
         _need(xa, torch.bfloat16)
         Cout, Cin, k = weight_v.shape
         Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
@@ -124,14 +124,17 @@ class FusedConvCL(torch.autograd.Function):
             raise _lib.PsndError('CL conv: buffer has %d channels, weight expects %d' % (Ca, Cin))
         pad = (k * dil - dil) // 2
         dev = xa.device
-        wf = torch.empty((k, Cb, Ca), dtype=torch.bfloat16, device=dev)      # [j][co][ci]
-        wb = torch.empty((k, Ca, Cb), dtype=torch.bfloat16, device=dev)      # [j][ci][co]
-        bp = torch.empty(Cb, dtype=torch.float32, device=dev)
         v32, g32 = weight_v.detach().contiguous(), weight_g.detach().contiguous()
-        b32 = None if bias is None else bias.detach().contiguous()
-        with torch.cuda.device(dev):
-            check(lib().psnd_conv1d_prep(ptr(v32), ptr(g32), ptr(b32), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
-                                         stream_ptr(dev)), 'psnd_conv1d_prep')
+        if prepped is not None:                      # packs made by prep_all() for the whole model in one launch
+            wf, wb, bp = prepped
+        else:
+            wf = torch.empty((k, Cb, Ca), dtype=torch.bfloat16, device=dev)      # [j][co][ci]
+            wb = torch.empty((k, Ca, Cb), dtype=torch.bfloat16, device=dev)      # [j][ci][co]
+            bp = torch.empty(Cb, dtype=torch.float32, device=dev)
+            b32 = None if bias is None else bias.detach().contiguous()
+            with torch.cuda.device(dev):
+                check(lib().psnd_conv1d_prep(ptr(v32), ptr(g32), ptr(b32), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
+                                             stream_ptr(dev)), 'psnd_conv1d_prep')
         raw, act = _launch_conv(xa, None, None, 1.0, wf, bp, res, None, shape, Ca, Cb, k, -pad, dil, act_slope, 1.0,
                                 want_raw, want_act)
         ctx.shape, ctx.dil, ctx.k, ctx.pad, ctx.act_slope = shape, dil, k, pad, act_slope
@@ -169,30 +172,64 @@ class FusedConvCL(torch.autograd.Function):
         if ctx.has_res:
             g_res = g_out if need_gout else g_raw
         g_bias = gb[:Cout] if ctx.has_bias else None
-        return gx, gv, gg, g_bias, g_res, None, None, None, None, None
+        return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None
 
 
-def fused_conv(xa, conv, shape, res=None, want_raw=False, want_act=True, act_slope=0.1):
-    """conv: a WNConv1d module (weight_v, weight_g, bias, dilation)."""
+def prep_all(owner, convs):
+    """weight norm + both bf16 packs + padded bias of every conv in `convs` (WNConv1d modules) in ONE launch
+    (psnd_conv1d_prep_multi).  The pack buffers and the device descriptor table are cached on `owner` and rebuilt only
+    when a parameter moved; returns {id(conv): (wf, wb, bp)} for fused_conv(..., prepped=...)."""
+    import struct
+    key = tuple((c.weight_v.data_ptr(), c.weight_g.data_ptr(), 0 if c.bias is None else c.bias.data_ptr(),
+                 tuple(c.weight_v.shape)) for c in convs)
+    cache = getattr(owner, '_cl_prep_cache', None)
+    if cache is None or cache['key'] != key:
+        dev = convs[0].weight_v.device
+        packs, recs, blk0 = {}, [], 0
+        for c in convs:
+            Cout, Cin, k = c.weight_v.shape
+            Ca, Cb = round_up(Cin, ALIGN_C), round_up(Cout, ALIGN_C)
+            wf = torch.zeros((k, Cb, Ca), dtype=torch.bfloat16, device=dev)
+            wb = torch.zeros((k, Ca, Cb), dtype=torch.bfloat16, device=dev)
+            bp = torch.zeros(Cb, dtype=torch.float32, device=dev)
+            packs[id(c)] = (wf, wb, bp)
+            recs.append(struct.pack('<6Q6i', c.weight_v.data_ptr(), c.weight_g.data_ptr(),
+                                    0 if c.bias is None else c.bias.data_ptr(), wf.data_ptr(), wb.data_ptr(), bp.data_ptr(),
+                                    Cout, Cin, k, Cb, Ca, blk0))
+            blk0 += Cout
+        table = torch.frombuffer(bytearray(b''.join(recs)), dtype=torch.uint8).to(dev)
+        cache = {'key': key, 'packs': packs, 'table': table, 'n': len(convs), 'blocks': blk0, 'dev': dev}
+        owner._cl_prep_cache = cache
+    for c in convs:
+        if not (c.weight_v.is_contiguous() and c.weight_g.is_contiguous() and c.weight_v.dtype == torch.float32):
+            raise _lib.PsndError('prep_all: fp32 contiguous weight_v / weight_g expected')
+    with torch.cuda.device(cache['dev']):
+        check(lib().psnd_conv1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], stream_ptr(cache['dev'])),
+              'psnd_conv1d_prep_multi')
+    return cache['packs']
+
+
+def fused_conv(xa, conv, shape, res=None, want_raw=False, want_act=True, act_slope=0.1, prep=None):
+    """conv: a WNConv1d module (weight_v, weight_g, bias, dilation); prep: the dict returned by prep_all()."""
     return FusedConvCL.apply(xa, conv.weight_v, conv.weight_g, conv.bias, res, shape, conv.dilation, want_raw, want_act,
-                             act_slope)
+                             act_slope, None if prep is None else prep[id(conv)])
 
 
-def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True):
+def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):
     """ResBlock1 (hifi_gan.py:55-63) on CL buffers.  x: residual stream (raw), xa = leaky_relu(x, 0.1).
     Returns (x_out raw or None, leaky_relu(x_out, last_act_slope))."""
     n = len(block.convs1)
     for i, (c1, c2) in enumerate(zip(block.convs1, block.convs2)):
-        _, ta = fused_conv(xa, c1, shape, None, False, True, 0.1)
+        _, ta = fused_conv(xa, c1, shape, None, False, True, 0.1, prep)
         last = i == n - 1
-        x, xa = fused_conv(ta, c2, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1)
+        x, xa = fused_conv(ta, c2, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1, prep)
     return x, xa
 
 
-def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True):
+def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):
     """ResBlock2 (hifi_gan.py:84-88) on CL buffers: x = conv(leaky_relu(x)) + x per conv."""
     n = len(block.convs)
     for i, c in enumerate(block.convs):
         last = i == n - 1
-        x, xa = fused_conv(xa, c, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1)
+        x, xa = fused_conv(xa, c, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1, prep)
     return x, xa

@@ -562,6 +562,41 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const fl
     if (threadIdx.x == 0) bp[co] = bias ? bias[co] : 0.f;
 }
 
+// the same for MANY convs in one launch (one descriptor per conv, one block per output channel): a model's 26 prep
+// launches of ~5 us each were launch latency, not work.  Pads of wf / wb / bp are never written: zero them once.
+struct PrepDesc {                 // 72 bytes, mirrored by pytorch_sound_amd/cl.py (struct format '<6Q6i')
+    const float *v, *g, *bias;
+    bf16_t *wf, *wb;
+    float *bp;
+    int Cout, Cin, k, Cb, Ca, blk0;
+};
+__global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *descs, int n) {
+    __shared__ float red[4];
+    int lo = 0, hi = n - 1;                                  // last descriptor with blk0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const PrepDesc d = descs[lo];
+    const int co = blockIdx.x - d.blk0, nn = d.Cin * d.k;
+    if (co >= d.Cout) return;
+    const float *vr = d.v + (size_t)co * nn;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < nn; i += 256) ss += vr[i] * vr[i];
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float scale = d.g[co] / __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x; i < nn; i += 256) {
+        const int ci = i / d.k, j = i - ci * d.k;
+        const bf16_t w = f2bf(vr[i] * scale);
+        d.wf[((size_t)j * d.Cb + co) * d.Ca + ci] = w;
+        d.wb[((size_t)j * d.Ca + ci) * d.Cb + co] = w;
+    }
+    if (threadIdx.x == 0) d.bp[co] = d.bias ? d.bias[co] : 0.f;
+}
+
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
 //   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
@@ -763,6 +798,14 @@ extern "C" int psnd_conv1d_prep(const float *v, const float *g, const float *bia
     hipLaunchKernelGGL(conv_prep_kernel, dim3(Cout), dim3(256), 0, s, v, g, bias, Cout, Cin, k, Cb, Ca,
                        static_cast<bf16_t *>(wf), static_cast<bf16_t *>(wb), bias_padded);
     PSND_CHECK_LAUNCH("conv1d_prep");
+    return PSND_OK;
+}
+
+extern "C" int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream) {
+    if (!descs_dev || n <= 0 || total_blocks <= 0) PSND_FAIL(PSND_E_ARG, "conv1d_prep_multi: bad arguments");
+    hipLaunchKernelGGL(conv_prep_multi_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PrepDesc *>(descs_dev), n);
+    PSND_CHECK_LAUNCH("conv1d_prep_multi");
     return PSND_OK;
 }
 

@@ -41,11 +41,13 @@ class ConvSeparator(nn.Module):
         N, C, T = mag.shape
         halo = max(c.padding for b in self.blocks for c in list(b.convs1) + list(b.convs2))
         shape = cl.CLShape(N, T, max(halo, self.conv_pre.padding, self.conv_post.padding))
+        convs = [self.conv_pre] + [c for b in self.blocks for c in list(b.convs1) + list(b.convs2)] + [self.conv_post]
+        prep = cl.prep_all(self, convs)                                            # all weight-norm packs: one launch
         x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
-        x, xa = cl.fused_conv(x0, self.conv_pre, shape, None, True, True, LRELU_SLOPE)
+        x, xa = cl.fused_conv(x0, self.conv_pre, shape, None, True, True, LRELU_SLOPE, prep)
         for block in self.blocks:
-            x, xa = cl.resblock1_cl(block, x, xa, shape)
-        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False)
+            x, xa = cl.resblock1_cl(block, x, xa, shape, prep=prep)
+        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         logits = cl.FromCL.apply(y, C, T, shape)
         return torch.sigmoid(logits) * mag
 

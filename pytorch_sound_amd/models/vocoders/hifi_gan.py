@@ -187,7 +187,10 @@ class Generator(nn.Module):
             c.padding for b in self.resblocks
             for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))])
         shape = cl.CLShape(N, T, halo)
-        _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE)
+        convs = [self.conv_pre, self.conv_post] + [
+            c for b in self.resblocks for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))]
+        prep = cl.prep_all(self, convs)                            # all weight-norm packs of the model: one launch
+        _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE, prep)
         c = self.conv_pre.weight_v.shape[0]
         h = cl.FromCL.apply(xa, c, T, shape)                       # leaky_relu(conv_pre(x), 0.1), (N, C, T) fp32
         for i, up in enumerate(self.ups):
@@ -200,16 +203,16 @@ class Generator(nn.Module):
             acc = None
             for block in stage:
                 if hasattr(block, 'convs1'):
-                    r, _ = cl.resblock1_cl(block, x_raw, x_act, shape)
+                    r, _ = cl.resblock1_cl(block, x_raw, x_act, shape, prep=prep)
                 else:
-                    r, _ = cl.resblock2_cl(block, x_raw, x_act, shape)
+                    r, _ = cl.resblock2_cl(block, x_raw, x_act, shape, prep=prep)
                 r = cl.FromCL.apply(r, c, T, shape)
                 acc = r if acc is None else acc + r
             h = acc / self.num_kernels
             if i + 1 < len(self.ups):
                 h = F.leaky_relu(h, LRELU_SLOPE)
         xa = cl.ToCL.apply(F.leaky_relu(h), shape, 0)              # default slope 0.01, as the reference
-        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False)
+        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
 
     def remove_weight_norm(self):
