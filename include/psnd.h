@@ -125,6 +125,7 @@ int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, 
  *      backward-data : A = gY,  W = pack [j][ci][co],       off0 = +pad, dstep = -dil
  *    A_eff = A + A2 * (AM > 0 ? 1 : a2_slope): the gradient of a conv output that was handed out both raw (A)
  *            and through leaky_relu (A2, with AM the activated output) is combined while it is staged.
+ *            a_eff_out (N, Lp, Ca) or NULL: A_eff written back (the gradient that continues along a residual branch).
  *    epilogue: v = acc (+ bias[co]); v *= (mask_src > 0 ? 1 : mask_slope) when mask_src; v += res when res;
  *              rows outside the clip -> 0; out_raw = v, out_act = leaky_relu(v, act_slope) (either may be NULL).
  *    replaces F.leaky_relu + Conv1d + bias (+ residual add)  (hifi_gan.py:56-62, 84-88) and their backward.
@@ -138,7 +139,8 @@ int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, 
  *  psnd_to_cl / psnd_from_cl: (N,C,T) fp32 <-> CL bf16 (preop 1 = log1p on the way in). */
 int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
                    const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
-                   int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act, void *stream);
+                   int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
+                   void *a_eff_out, void *stream);
 int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb);
 int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
                          int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,

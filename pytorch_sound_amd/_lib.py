@@ -35,7 +35,7 @@ SIGNATURES = {
     'psnd_mel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P]),
     'psnd_mel_bwd': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
     'psnd_logmel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
-    'psnd_conv1d_cl': (_INT, [_P, _P, _P, _F, _P, _P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _P]),
+    'psnd_conv1d_cl': (_INT, [_P, _P, _P, _F, _P, _P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _P, _P]),
     'psnd_conv1d_cl_wgrad': (_INT, [_P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd': (_INT, [_P, _P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),

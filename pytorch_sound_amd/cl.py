@@ -96,15 +96,49 @@ class FromCL(torch.autograd.Function):
 
 
 def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, off0, dstep, act_slope, mask_slope,
-                 want_raw, want_act):
+                 want_raw, want_act, a_eff_out=None):
     dev = W.device
     raw = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if want_raw else None
     act = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if want_act else None
     with torch.cuda.device(dev):
         check(lib().psnd_conv1d_cl(ptr(A), ptr(A2), ptr(AM), float(a2_slope), ptr(W), ptr(bias), ptr(res), ptr(mask_src),
                                    shape.N, shape.Lp, shape.L, shape.HP, Ca, Cb, k, off0, dstep, float(act_slope),
-                                   float(mask_slope), ptr(raw), ptr(act), stream_ptr(dev)), 'psnd_conv1d_cl')
+                                   float(mask_slope), ptr(raw), ptr(act), ptr(a_eff_out), stream_ptr(dev)), 'psnd_conv1d_cl')
     return raw, act
+
+
+# ---- the weight-gradient branch of a conv's backward runs on a second stream --------------------------------------------
+# Per conv the backward is  (a) input gradient, needed by the next layer's backward, and  (b) weight gradient + weight-norm
+# backward, needed only by the optimizer.  Each of these kernels fills a fraction of the chip for 10-20 us (latency chains,
+# DESIGN.md 4.4), so (b) is enqueued on a side stream and overlaps the (a) chain; one callback at the end of the backward pass
+# joins the side stream (torch's engine callback, the mechanism DDP uses).  Inside a hipGraph capture the side stream is
+# captured as a parallel branch.  OFF by default (PSND_CL_SIDE_STREAM=1 enables it): measured on the config-2 step it LOSES
+# 5 % (2.28 vs 2.16 ms) - the two kernels cannot share a CU (wgrad 320 + conv 216-256 VGPRs per lane exceed the 512-entry
+# register file), so the branches serialise anyway and the graph pays for the fork/join.
+_SIDE = {}
+_JOIN_PENDING = {}
+
+
+def _side_stream(dev):
+    import os
+    if os.environ.get('PSND_CL_SIDE_STREAM', '0') != '1':
+        return None
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def _join_side_at_end_of_backward(dev, side):
+    if _JOIN_PENDING.get(dev.index):
+        return
+    _JOIN_PENDING[dev.index] = True
+
+    def join():
+        _JOIN_PENDING[dev.index] = False
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
 class FusedConvCL(torch.autograd.Function):
@@ -151,23 +185,38 @@ class FusedConvCL(torch.autograd.Function):
         dev = xa.device
         g_raw = None if g_raw is None else g_raw.contiguous()
         g_act = None if g_act is None else g_act.contiguous()
-        # input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) formed on load
-        gx, _ = _launch_conv(g_raw, g_act, act if g_act is not None else None, ctx.act_slope, wb, None, None, None, shape,
-                             Cb, Ca, k, pad, -dil, 1.0, 1.0, True, False)
         S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb)
-        gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)     # partial slabs, summed in wnorm_bwd
-        gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
-        gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+        am = act if g_act is not None else None
         need_gout = ctx.has_res and (g_act is not None)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        if side is not None:
+            side.wait_stream(main)                          # the incoming gradients are complete on the main stream
+        with torch.cuda.stream(side if side is not None else main):
+            # (b) weight gradient (partial slabs) + weight-norm backward; temporaries belong to the side stream's pool
+            gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
+            gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
+            gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+            gv = torch.empty_like(v32)
+            gg = torch.empty_like(g32)
+            with torch.cuda.device(dev):
+                check(lib().psnd_conv1d_cl_wgrad(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(xa), shape.N,
+                                                 shape.Lp, Ca, Cb, k, -pad, dil, ptr(gw), ptr(gbp), None, stream_ptr(dev)),
+                      'psnd_conv1d_cl_wgrad')
+                check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
+                                                  ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
+        if side is not None:
+            for t in (g_raw, g_act, am, xa, v32, g32):      # allocated on the main stream, still read by the side stream
+                if t is not None:
+                    t.record_stream(side)
+            for t in (gv, gg, gb):                          # allocated on the side stream, consumed on the main one
+                t.record_stream(main)
+            _join_side_at_end_of_backward(dev, side)
+        # (a) input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) is formed on load
+        #     and written back for the residual branch when both parts exist
         g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
-        gv = torch.empty_like(v32)
-        gg = torch.empty_like(g32)
-        with torch.cuda.device(dev):
-            check(lib().psnd_conv1d_cl_wgrad(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None),
-                                             float(ctx.act_slope), ptr(xa), shape.N, shape.Lp, Ca, Cb, k, -pad, dil,
-                                             ptr(gw), ptr(gbp), ptr(g_out), stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
-            check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv), ptr(gg),
-                                              ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
+        gx, _ = _launch_conv(g_raw, g_act, am, ctx.act_slope, wb, None, None, None, shape, Cb, Ca, k, pad, -dil, 1.0, 1.0,
+                             True, False, g_out)
         g_res = None
         if ctx.has_res:
             g_res = g_out if need_gout else g_raw

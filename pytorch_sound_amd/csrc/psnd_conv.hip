@@ -43,6 +43,7 @@ struct ConvParams {
     const bf16_t *mask_src;  // (R, Cb) or null: v *= (mask_src > 0 ? 1 : mask_slope)
     bf16_t *out_raw;         // (R, Cb) or null
     bf16_t *out_act;         // (R, Cb) or null
+    bf16_t *a_eff_out;       // (R, Ca) or null: the combined operand A + A2 * leaky'(AM), materialised (COMBINE only)
     long long R;
     int Lp, L, HP, Ca, Cb, k, off0, dstep, hm;
     float act_slope, mask_slope, a2_slope;
@@ -132,6 +133,10 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     __amdgpu_buffer_rsrc_t rA2 = rA, rAM = rA;
     if constexpr (COMBINE) rA2 = make_uniform_rsrc(p.A2, (int)a_bytes), rAM = make_uniform_rsrc(p.AM, (int)a_bytes);
     const __amdgpu_buffer_rsrc_t rW = make_uniform_rsrc(p.W, (int)w_bytes);
+    // the combined operand is written back by the first column block only; a null pointer gives a zero-sized buffer,
+    // lanes that must not store use the OOB offset: the store instruction itself is unconditional (see above)
+    const __amdgpu_buffer_rsrc_t rG = make_uniform_rsrc(p.a_eff_out ? p.a_eff_out : p.W,
+                                                        (COMBINE && p.a_eff_out && blockIdx.y == 0) ? (int)a_bytes : 0);
     const bool haveA = p.A != nullptr;
     unsigned aoff[NA];
 #pragma unroll
@@ -180,16 +185,20 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
         }
         return make_uint4(out[0], out[1], out[2], out[3]);
     };
-    auto commit = [&](auto sc, bf16_t *sA, bf16_t *sB) __attribute__((always_inline)) {
+    auto commit = [&](auto sc, bf16_t *sA, bf16_t *sB, int c0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int idx = tid + 256 * u;
-            if (idx < nA) {
-                uint4 v = ra[s][u];
-                if constexpr (COMBINE) v = combine(v, ra2[s][u], ram[s][u]);
-                *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = v;
+            uint4 v = ra[s][u];
+            if constexpr (COMBINE) {
+                v = combine(v, ra2[s][u], ram[s][u]);
+                const int rr = idx / PCS;
+                const bool own = rr >= p.hm && rr < p.hm + BM && aoff[u] != OOB && c0 < p.Ca;     // rows of this tile
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rG,
+                                                       (int)(own ? aoff[u] + (unsigned)c0 * 2u : OOB), 0, 0);
             }
+            if (idx < nA) *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = v;
         }
 #pragma unroll
         for (int j = 0; j < KT; ++j)
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
                 bf16_t *sA = smem_c + (NBUF == 2 ? (ch & 1) * buf_elems : 0);
                 bf16_t *sB = sA + rowsA * RS;
                 if constexpr (NBUF == 1) __syncthreads();        // the previous stage's fragments are consumed
-                commit(sc, sA, sB);
+                commit(sc, sA, sB, ch * KC);
                 if (ch == 0) PSND_CSTAMP(1);
                 __syncthreads();
                 if (ch == 0) PSND_CSTAMP(2);
@@ -657,8 +666,9 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw_part, 
 extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
                               const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
                               int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
-                              void *stream) {
+                              void *a_eff_out, void *stream) {
     if ((!A && !A2) || !W || (!out_raw && !out_act) || (A2 && !AM)) PSND_FAIL(PSND_E_ARG, "conv1d_cl: null pointer");
+    if (a_eff_out && !A2) PSND_FAIL(PSND_E_ARG, "conv1d_cl: a_eff_out needs the combined operand (A2, AM)");
     if (Ca % 32 != 0 || Cb % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: Ca=%d must be a multiple of 32, Cb=%d of 8", Ca, Cb);
     if (k < 1 || k > 16 || N < 0 || Lp < L + 2 * HP || L <= 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d N=%lld Lp=%d L=%d HP=%d", k, (long long)N, Lp, L, HP);
     int hm = 0;
@@ -675,6 +685,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     p.W = static_cast<const bf16_t *>(W), p.bias = bias;
     p.res = static_cast<const bf16_t *>(res), p.mask_src = static_cast<const bf16_t *>(mask_src);
     p.out_raw = static_cast<bf16_t *>(out_raw), p.out_act = static_cast<bf16_t *>(out_act);
+    p.a_eff_out = static_cast<bf16_t *>(a_eff_out);
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.hm = hm;
     p.act_slope = act_slope, p.mask_slope = mask_slope;
 #ifdef PSND_TRACE

@@ -16,7 +16,7 @@ nwg = ((N * Lp + 63) // 64) * (C // 64)
 trace = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
 def run():
     check(lib().psnd_conv1d_cl(ptr(x), None, None, 0.0, ptr(w), ptr(bias), None, None, N, Lp, L, HP, C, C, k, -dil, dil, 0.1, 0.0,
-                               ptr(out), None, stream_ptr(dev)), 'conv')
+                               ptr(out), None, None, stream_ptr(dev)), "conv")
 for _ in range(5): run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
