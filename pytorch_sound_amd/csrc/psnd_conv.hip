@@ -618,25 +618,32 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw_part, 
     const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
-    // slab sums: 8 independent loads in flight per element (the loop is latency bound: 16 slabs x 3 elements per thread)
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int j = e / Cin, ci = e - j * Cin;
-        const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
-        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= splits; sp += 8) {
-            float t[8];
+    // slab sums.  The kernel is one latency chain per workgroup (256 blocks x 48 KB): every load a thread needs - 16
+    // slabs of up to 4 elements - is issued before the first add.
+    for (int e0 = threadIdx.x; e0 < n; e0 += 4 * 256) {
+        float t[4][16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(sp + u) * slab];
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + 256 * q;
+            const int j = e / Cin, ci = e - j * Cin;
+            const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc8[u] += t[u];
+            for (int u = 0; u < 16; ++u) t[q][u] = (e < n && u < splits) ? src[(size_t)u * slab] : 0.f;
         }
-        for (; sp < splits; ++sp) acc8[0] += src[(size_t)sp * slab];
-        const float gsum = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-        s_gw[e] = gsum;
-        const float vv = vr[ci * k + j];
-        ss += vv * vv;
-        dot += vv * gsum;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + 256 * q;
+            if (e >= n) continue;
+            const int j = e / Cin, ci = e - j * Cin;
+            float gsum = ((t[q][0] + t[q][1]) + (t[q][2] + t[q][3])) + ((t[q][4] + t[q][5]) + (t[q][6] + t[q][7])) +
+                         (((t[q][8] + t[q][9]) + (t[q][10] + t[q][11])) + ((t[q][12] + t[q][13]) + (t[q][14] + t[q][15])));
+            const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
+            for (int sp = 16; sp < splits; ++sp) gsum += src[(size_t)sp * slab];
+            s_gw[e] = gsum;
+            const float vv = vr[ci * k + j];
+            ss += vv * vv;
+            dot += vv * gsum;
+        }
     }
     for (int m = 32; m >= 1; m >>= 1) {
         ss += __shfl_xor(ss, m, 64);
