@@ -131,7 +131,7 @@ int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, 
  *    replaces F.leaky_relu + Conv1d + bias (+ residual add)  (hifi_gan.py:56-62, 84-88) and their backward.
  *  psnd_conv1d_cl_wgrad: gw[j][co][ci] = sum_r g[r][co] * xa[r + off0 + j*dstep][ci] as S partial slabs over row
  *              ranges, gw_part fp32 [S][k][Cb][Ca] and gbias_part [S][Cb] (may be NULL), every element written (no
- *              zero fill, no atomics); S = psnd_conv1d_cl_wgrad_splits(N, Lp, Ca, Cb) (host helper).
+ *              zero fill, no atomics); S = psnd_conv1d_cl_wgrad_splits(N, Lp, Ca, Cb, k) (host helper).
  *              g_out = g materialised (may be NULL); g = G1 + G2*leaky'(GM).
  *  psnd_conv1d_prep: weight norm w = g*v/||v|| (norm over dim 0, as torch weight_norm) -> bf16 packs
  *              wf [k][Cb][Ca] and wb [k][Ca][Cb], zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: adds the S
@@ -141,7 +141,7 @@ int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope
                    const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
                    int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
                    void *a_eff_out, void *stream);
-int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb);
+int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb, int k);
 int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
                          int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,
                          void *g_out, void *stream);

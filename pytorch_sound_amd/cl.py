@@ -150,13 +150,14 @@ class FusedConvCL(torch.autograd.Function):
     taps, bias gradient and the residual's gradient in one kernel) + weight-norm backward."""
 
     @staticmethod
-    def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope, prepped=None):
+    def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope, prepped=None, pad=None):
         _need(xa, torch.bfloat16)
         Cout, Cin, k = weight_v.shape
         Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
         if Ca != round_up(Cin, ALIGN_C):
             raise _lib.PsndError('CL conv: buffer has %d channels, weight expects %d' % (Ca, Cin))
-        pad = (k * dil - dil) // 2
+        if pad is None:
+            pad = (k * dil - dil) // 2           # "same" convolution; an explicit pad gives taps at -pad .. -pad + (k-1)*dil
         dev = xa.device
         v32, g32 = weight_v.detach().contiguous(), weight_g.detach().contiguous()
         if prepped is not None:                      # packs made by prep_all() for the whole model in one launch
@@ -185,7 +186,7 @@ class FusedConvCL(torch.autograd.Function):
         dev = xa.device
         g_raw = None if g_raw is None else g_raw.contiguous()
         g_act = None if g_act is None else g_act.contiguous()
-        S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb)
+        S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb, k)
         am = act if g_act is not None else None
         need_gout = ctx.has_res and (g_act is not None)
         main = torch.cuda.current_stream(dev)
@@ -221,7 +222,26 @@ class FusedConvCL(torch.autograd.Function):
         if ctx.has_res:
             g_res = g_out if need_gout else g_raw
         g_bias = gb[:Cout] if ctx.has_bias else None
-        return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None
+        return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None, None
+
+
+def conv_transpose_cl(xa, up, shape, act_slope=0.1):
+    """ConvTranspose1d of hifi_gan.py:118-121 (stride s, kernel k, padding p) on CL buffers, without leaving the layout:
+    the input rows are spread s apart in a zeroed buffer and a plain k-tap convolution with the flipped, transposed
+    weight (taps at -(k-1-p) .. +p) runs on the implicit-GEMM kernel - s-1 of every s products are zeros, which costs
+    ~17 % extra FLOPs on the whole generator and saves the layout round trip and the library call.  The weight norm of
+    the transposed weight (norm over dim 0 = input channels) is taken by torch; the kernel's own weight-norm
+    parametrisation is fed g = ||w|| so that it reproduces w, and autograd adds the derivative through that norm.
+    xa: activated CL input (N, Lp, Cin_p).  Returns (raw, leaky_relu(raw, act_slope), CLShape of the output)."""
+    s, k, p = up.stride, up.weight_v.shape[2] if hasattr(up, 'weight_v') else up.weight.shape[2], up.padding
+    N, T, HP = shape.N, shape.L, shape.HP
+    out_shape = CLShape(N, T * s, HP)
+    xu = torch.zeros((N, out_shape.Lp, xa.shape[2]), dtype=xa.dtype, device=xa.device)
+    xu[:, HP:HP + T * s:s, :] = xa[:, HP:HP + T, :]
+    w_c = up.effective_weight().permute(1, 0, 2).flip(2).contiguous()            # (Cout, Cin, k) of the equivalent conv
+    g = w_c.flatten(1).norm(dim=1).view(-1, 1, 1)
+    raw, act = FusedConvCL.apply(xu, w_c, g, up.bias, None, out_shape, 1, True, True, act_slope, None, k - 1 - p)
+    return raw, act, out_shape
 
 
 def prep_all(owner, convs):
@@ -229,6 +249,9 @@ def prep_all(owner, convs):
     (psnd_conv1d_prep_multi).  The pack buffers and the device descriptor table are cached on `owner` and rebuilt only
     when a parameter moved; returns {id(conv): (wf, wb, bp)} for fused_conv(..., prepped=...)."""
     import struct
+    import os
+    if os.environ.get('PSND_NO_PREP_ALL') == '1':      # A/B switch: one prep launch per conv
+        return None
     key = tuple((c.weight_v.data_ptr(), c.weight_g.data_ptr(), 0 if c.bias is None else c.bias.data_ptr(),
                  tuple(c.weight_v.shape)) for c in convs)
     cache = getattr(owner, '_cl_prep_cache', None)

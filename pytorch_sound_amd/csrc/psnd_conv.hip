@@ -394,17 +394,24 @@ struct WgradParams {
 // workgroup's 52 k cycles, the L2 retiring about one fp32 atomic per channel per clock.)
 // Row chunks (32 rows) are fetched WD chunks ahead as raw pieces (the gradient combine is done at staging).
 // Transposed staging: lanes rr and rr^1 swap halves (DPP) so every lane writes 4-byte (2 rows x 1 channel) words.
-constexpr int WD = 2;
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
+#ifndef PSND_WD
+#define PSND_WD 2
+#endif
+constexpr int WD = PSND_WD;
+#ifndef PSND_WGRAD_WAVES
+#define PSND_WGRAD_WAVES 2
+#endif
+__global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t sT[2 * (1 + WKT) * 64 * RS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
     const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
-    const int split = blockIdx.z;
+    const int ntg = (p.k + WKT - 1) / WKT;               // tap groups: one per workgroup (blockIdx.z = split * ntg + group)
+    const int split = blockIdx.z / ntg, tgrp = blockIdx.z - split * ntg;
     const long long rs = (long long)split * p.rows_per_split;
     const long long re = min(rs + p.rows_per_split, p.R);
     const int rr = tid & 31, cg = tid >> 5;          // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
-    const bool do_bias = (blockIdx.y == 0);
+    const bool do_bias = (blockIdx.y == 0) && tgrp == 0;
     const bool comb = p.G2 != nullptr;
     const bool gok = co0 + 8 * cg < p.Cb, xok = ci0 + 8 * cg < p.Ca;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -429,7 +436,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         return (rr & 1) ? __builtin_amdgcn_perm(own, nb, 0x07060302u) : __builtin_amdgcn_perm(nb, own, 0x05040100u);
     };
 
-    for (int t0 = 0; t0 < p.k; t0 += WKT) {
+    {
+        const int t0 = tgrp * WKT;
         const int nt = min(WKT, p.k - t0);
         f32x16 acc[WKT];
 #pragma unroll
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
                 g = make_uint4(out[0], out[1], out[2], out[3]);
             }
             const unsigned *pg4 = reinterpret_cast<const unsigned *>(&g);
-            if (do_bias && t0 == 0) {
+            if (do_bias) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[e] += bf2f((bf16_t)((pg4[e >> 1] >> (16 * (e & 1))) & 0xffff));
                 const long long r = r0 + rr;
@@ -608,57 +616,66 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *de
 
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
 //   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
-__global__ __launch_bounds__(256) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
-                                                          const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
-                                                          float *gg, float *gbias) {
-    // one workgroup per output channel: sums the wgrad slabs (coalesced over ci), then the weight-norm backward
-    extern __shared__ float s_gw[];                    // Cin * k summed gradients of this channel, [j][ci]
-    __shared__ float red[8];
-    const int co = blockIdx.x, n = Cin * k;
+__global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
+                                                           const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
+                                                           float *gg, float *gbias, unsigned kmagic, unsigned cmagic) {
+    // one workgroup (256 or 1024 threads) per output channel: sums the wgrad slabs (coalesced over ci), then the weight-norm
+    // backward.  s_gw holds the summed gradients as [j][Cin + 1] (the +1 keeps the k-strided reads of the second loop on
+    // different banks); i / k by multiplication with kmagic = ceil(2^32 / k) (exact for i < 2^32 / k).
+    extern __shared__ float s_gw[];
+    __shared__ float red[32];
+    const int co = blockIdx.x, n = Cin * k, BD = blockDim.x, tid = threadIdx.x;
+    const int pitch = Cin + 1;
     const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
-    // slab sums.  The kernel is one latency chain per workgroup (256 blocks x 48 KB): every load a thread needs - 16
-    // slabs of up to 4 elements - is issued before the first add.
-    for (int e0 = threadIdx.x; e0 < n; e0 += 4 * 256) {
+    for (int e0 = tid; e0 < n; e0 += 4 * BD) {           // (j, ci) order: coalesced slab reads, 4 x 16 loads in flight
         float t[4][16];
+        int jj[4], cc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = e0 + 256 * q;
-            const int j = e / Cin, ci = e - j * Cin;
-            const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
+            const int e = e0 + BD * q;
+            jj[q] = (int)__umulhi((unsigned)e, cmagic);
+            cc[q] = e - jj[q] * Cin;
+            const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q];
 #pragma unroll
             for (int u = 0; u < 16; ++u) t[q][u] = (e < n && u < splits) ? src[(size_t)u * slab] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = e0 + 256 * q;
+            const int e = e0 + BD * q;
             if (e >= n) continue;
-            const int j = e / Cin, ci = e - j * Cin;
             float gsum = ((t[q][0] + t[q][1]) + (t[q][2] + t[q][3])) + ((t[q][4] + t[q][5]) + (t[q][6] + t[q][7])) +
                          (((t[q][8] + t[q][9]) + (t[q][10] + t[q][11])) + ((t[q][12] + t[q][13]) + (t[q][14] + t[q][15])));
-            const float *src = gw_part + ((size_t)j * Cb + co) * Ca + ci;
+            const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q];
             for (int sp = 16; sp < splits; ++sp) gsum += src[(size_t)sp * slab];
-            s_gw[e] = gsum;
-            const float vv = vr[ci * k + j];
-            ss += vv * vv;
-            dot += vv * gsum;
+            s_gw[jj[q] * pitch + cc[q]] = gsum;
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BD) {                  // natural (ci, j) order: coalesced reads of v
+        const int ci = (int)__umulhi((unsigned)i, kmagic), j = i - ci * k;
+        const float vv = vr[i];
+        ss += vv * vv;
+        dot += vv * s_gw[j * pitch + ci];
     }
     for (int m = 32; m >= 1; m >>= 1) {
         ss += __shfl_xor(ss, m, 64);
         dot += __shfl_xor(dot, m, 64);
     }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss, red[4 + (threadIdx.x >> 6)] = dot;
+    const int nw = BD >> 6;
+    if ((tid & 63) == 0) red[tid >> 6] = ss, red[16 + (tid >> 6)] = dot;
     __syncthreads();
-    const float nrm = __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
-    const float d = (red[4] + red[5] + red[6] + red[7]) / nrm;      // sum(gw * vhat)
-    const float gs = g[co] / nrm;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int ci = i / k, j = i - ci * k;
-        gv[(size_t)co * n + i] = gs * (s_gw[j * Cin + ci] - vr[i] / nrm * d);
+    float sst = 0.f, dott = 0.f;
+    for (int w = 0; w < nw; ++w) sst += red[w], dott += red[16 + w];
+    const float inv = 1.f / __builtin_sqrtf(sst);
+    const float d = dott * inv;                                     // sum(gw * vhat)
+    const float gs = g[co] * inv;
+    for (int i = tid; i < n; i += BD) {
+        const int ci = (int)__umulhi((unsigned)i, kmagic), j = i - ci * k;
+        gv[(size_t)co * n + i] = gs * (s_gw[j * pitch + ci] - vr[i] * inv * d);
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         gg[co] = d;
         if (gbias && gb_part) {
             float b = 0.f;
@@ -754,8 +771,8 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
     return PSND_OK;
 }
 
-static int wgrad_splits(int64_t R, int Ca, int Cb, int64_t *rps_out) {
-    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64;
+static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
+    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * ((k + WKT - 1) / WKT);   // tap groups are workgroups too
     int64_t target = 256;                       // ~one workgroup per CU: 512 blocks make this kernel 7 % faster (15.6 vs 16.8 us)
                                                 // but double the slabs the weight-norm backward has to add up (step 2.31 vs 2.13 ms)
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
@@ -769,9 +786,9 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int64_t *rps_out) {
     return (int)splits;
 }
 
-extern "C" int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb) {
-    if (N <= 0 || Lp <= 0 || Ca <= 0 || Cb <= 0) return 0;
-    return wgrad_splits(N * (int64_t)Lp, Ca, Cb, nullptr);
+extern "C" int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb, int k) {
+    if (N <= 0 || Lp <= 0 || Ca <= 0 || Cb <= 0 || k <= 0) return 0;
+    return wgrad_splits(N * (int64_t)Lp, Ca, Cb, k, nullptr);
 }
 
 extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
@@ -787,7 +804,7 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
     p.R = N * (int64_t)Lp, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.g2_slope = g2_slope;
     const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64;
     int64_t rps;
-    const int splits = wgrad_splits(p.R, Ca, Cb, &rps);
+    const int splits = wgrad_splits(p.R, Ca, Cb, k, &rps);
     p.rows_per_split = (int)rps;
 #ifdef PSND_TRACE
     {
@@ -795,7 +812,8 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)splits), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)(splits * ((k + WKT - 1) / WKT))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("conv1d_cl_wgrad");
     return PSND_OK;
 }
@@ -830,10 +848,13 @@ extern "C" int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_bl
 extern "C" int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                                      int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream) {
     if (!gw_part || !v || !g || !gv || !gg || splits < 1) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd: null pointer / splits");
-    const size_t lds = sizeof(float) * (size_t)Cin * k;
+    const size_t lds = sizeof(float) * (size_t)(Cin + 1) * k;
     if (lds > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd: Cin*k=%d too large", Cin * k);
-    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream), gw_part, gbias_part, splits,
-                       v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias);
+    const unsigned kmagic = (unsigned)((0x100000000ull + (unsigned)k - 1) / (unsigned)k);
+    const unsigned cmagic = (unsigned)((0x100000000ull + (unsigned)Cin - 1) / (unsigned)Cin);
+    const int threads = Cin * k >= 2048 ? 1024 : 256;         // big rows: 4x the loads in flight per output channel
+    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part, gbias_part,
+                       splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd");
     return PSND_OK;
 }

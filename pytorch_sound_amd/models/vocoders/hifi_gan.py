@@ -160,11 +160,13 @@ class Generator(nn.Module):
         x = F.leaky_relu(x)            # default slope 0.01, as the reference
         return torch.tanh(self.conv_post(x))
 
-    # ---- gfx950 path: every Conv1d of the generator (conv_pre, all ResBlocks, conv_post = 74 of the 78 convs of v1,
-    #      >95 % of its FLOPs) runs on the channels-last bf16 implicit-GEMM kernels with leaky-relu / bias / residual /
-    #      weight norm fused (pytorch_sound_amd/cl.py); the 3-4 ConvTranspose1d upsamplers are still library calls,
-    #      bracketed by the layout kernels.  fp32 in / fp32 out, fp32 accumulation, bf16 activations between convs.
+    # ---- gfx950 path: conv_pre, all ResBlocks and conv_post (74 of the 78 convs of v1, > 95 % of the FLOPs) run on the
+    #      channels-last bf16 implicit-GEMM kernels with leaky-relu / bias / residual / weight norm fused
+    #      (pytorch_sound_amd/cl.py).  The ConvTranspose1d upsamplers: library call between the layout kernels (default), or
+    #      `cl_upsample = 'kernel'`: a convolution over zero-spread rows on the same kernel (cl.conv_transpose_cl), the
+    #      whole generator then stays in the CL layout.  fp32 in / fp32 out, fp32 accumulation, bf16 between convs.
     use_cl = True
+    cl_upsample = 'library'     # 'kernel': ConvTranspose1d on the CL conv kernel too (cl.conv_transpose_cl)
     _CL_MAX_REACH = 25          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for
 
     def _cl_ok(self, x) -> bool:
@@ -178,6 +180,9 @@ class Generator(nn.Module):
             if any(not hasattr(c, 'weight_v') for c in convs):
                 return False
             reach = max([reach] + [c.padding for c in convs])
+        if any(not hasattr(u, 'weight_v') for u in self.ups):
+            return False
+        reach = max([reach] + [u.weight_v.shape[2] - 1 - u.padding for u in self.ups])
         return reach <= self._CL_MAX_REACH
 
     def forward_cl(self, x):
@@ -185,20 +190,31 @@ class Generator(nn.Module):
         N, _, T = x.shape
         halo = max([self.conv_pre.padding, self.conv_post.padding] + [
             c.padding for b in self.resblocks
-            for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))])
+            for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))] + [
+            u.weight_v.shape[2] - 1 - u.padding for u in self.ups])
         shape = cl.CLShape(N, T, halo)
         convs = [self.conv_pre, self.conv_post] + [
             c for b in self.resblocks for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))]
         prep = cl.prep_all(self, convs)                            # all weight-norm packs of the model: one launch
         _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE, prep)
-        c = self.conv_pre.weight_v.shape[0]
-        h = cl.FromCL.apply(xa, c, T, shape)                       # leaky_relu(conv_pre(x), 0.1), (N, C, T) fp32
+        kernel_ups = self.cl_upsample == 'kernel'
+        h = None                                                   # library mode: (N, C, T) fp32 between the stages
         for i, up in enumerate(self.ups):
-            h = up(h)                                              # ConvTranspose1d (library)
-            c, T = h.shape[1], h.shape[2]
-            shape = cl.CLShape(N, T, halo)
-            x_raw = cl.ToCL.apply(h, shape, 0)
-            x_act = cl.ToCL.apply(F.leaky_relu(h, LRELU_SLOPE), shape, 0)
+            last = i + 1 == len(self.ups)
+            if kernel_ups:
+                # ConvTranspose1d as a k-tap convolution over zero-spread rows: the stack never leaves the CL layout
+                x_raw, x_act, shape = cl.conv_transpose_cl(xa, up, shape, LRELU_SLOPE)
+                T = shape.L
+            else:
+                # library ConvTranspose1d between the two layout kernels (faster today: the zero-spread convolution
+                # multiplies s-1 zeros out of s, v1 fwd+bwd 19.1 vs 15.6 ms)
+                if h is None:
+                    h = cl.FromCL.apply(xa, up.weight_v.shape[0], T, shape)      # leaky_relu(conv_pre(x), 0.1)
+                h = up(h)
+                T = h.shape[2]
+                shape = cl.CLShape(N, T, halo)
+                x_raw = cl.ToCL.apply(h, shape, 0)
+                x_act = cl.ToCL.apply(F.leaky_relu(h, LRELU_SLOPE), shape, 0)
             stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
             acc = None
             for block in stage:
@@ -206,12 +222,13 @@ class Generator(nn.Module):
                     r, _ = cl.resblock1_cl(block, x_raw, x_act, shape, prep=prep)
                 else:
                     r, _ = cl.resblock2_cl(block, x_raw, x_act, shape, prep=prep)
-                r = cl.FromCL.apply(r, c, T, shape)
+                r = r.float() if kernel_ups else cl.FromCL.apply(r, up.weight_v.shape[1], T, shape)
                 acc = r if acc is None else acc + r
-            h = acc / self.num_kernels
-            if i + 1 < len(self.ups):
-                h = F.leaky_relu(h, LRELU_SLOPE)
-        xa = cl.ToCL.apply(F.leaky_relu(h), shape, 0)              # default slope 0.01, as the reference
+            h = F.leaky_relu(acc / self.num_kernels, 0.01 if last else LRELU_SLOPE)   # last: default slope, as the reference
+            if kernel_ups:
+                xa = h.to(torch.bfloat16)                          # CL layout, halo rows stay zero
+        if not kernel_ups:
+            xa = cl.ToCL.apply(h, shape, 0)
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
 

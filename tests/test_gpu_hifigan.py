@@ -31,8 +31,10 @@ def _make(resblock, rates, ksz, c0, rk, rd):
     ('1', [4, 2], [8, 4], 64, [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
     ('2', [4, 4], [8, 8], 64, [3, 5], [[1, 2], [2, 6]]),
 ])
-def test_generator_cl_matches_torch_path(cfg):
+@pytest.mark.parametrize('upsample', ['library', 'kernel'])
+def test_generator_cl_matches_torch_path(cfg, upsample):
     g = _make(*cfg)
+    g.cl_upsample = upsample
     x = torch.randn(3, 80, 24, device='cuda')
     assert g._cl_ok(x)
     xr = x.clone().requires_grad_(True)

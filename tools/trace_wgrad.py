@@ -9,7 +9,7 @@ N, L, C, HP, k, dil = 32, 173, 256, 8, 3, int(os.environ.get('DIL', '1'))
 Lp = L + 2 * HP
 x = torch.randn(N, Lp, C, device=dev).to(torch.bfloat16)
 g = torch.randn(N, Lp, C, device=dev).to(torch.bfloat16)
-S = lib().psnd_conv1d_cl_wgrad_splits(N, Lp, C, C)
+S = lib().psnd_conv1d_cl_wgrad_splits(N, Lp, C, C, k)
 gw = torch.empty(S, k, C, C, device=dev)
 gb = torch.empty(S, C, device=dev)
 nwg = 4096
