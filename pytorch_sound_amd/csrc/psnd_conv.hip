@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *de
 
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
 //   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
+template <bool MANY>   // MANY: more than 16 slabs (narrow layers over long clips) - batches of 16; else one straight batch
 __global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
                                                            const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
                                                            float *gg, float *gbias, unsigned kmagic, unsigned cmagic) {
@@ -630,27 +631,30 @@ __global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part,
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
     for (int e0 = tid; e0 < n; e0 += 4 * BD) {           // (j, ci) order: coalesced slab reads, 4 x 16 loads in flight
-        float t[4][16];
         int jj[4], cc[4];
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = e0 + BD * q;
             jj[q] = (int)__umulhi((unsigned)e, cmagic);
             cc[q] = e - jj[q] * Cin;
-            const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q];
+        }
+        for (int sp0 = 0; sp0 < (MANY ? splits : 1); sp0 += 16) {
+            float t[4][16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[q][u] = (e < n && u < splits) ? src[(size_t)u * slab] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q] + (size_t)sp0 * slab;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[q][u] = (e0 + BD * q < n && sp0 + u < splits) ? src[(size_t)u * slab] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                gsum[q] += ((t[q][0] + t[q][1]) + (t[q][2] + t[q][3])) + ((t[q][4] + t[q][5]) + (t[q][6] + t[q][7])) +
+                           (((t[q][8] + t[q][9]) + (t[q][10] + t[q][11])) + ((t[q][12] + t[q][13]) + (t[q][14] + t[q][15])));
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + BD * q;
-            if (e >= n) continue;
-            float gsum = ((t[q][0] + t[q][1]) + (t[q][2] + t[q][3])) + ((t[q][4] + t[q][5]) + (t[q][6] + t[q][7])) +
-                         (((t[q][8] + t[q][9]) + (t[q][10] + t[q][11])) + ((t[q][12] + t[q][13]) + (t[q][14] + t[q][15])));
-            const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q];
-            for (int sp = 16; sp < splits; ++sp) gsum += src[(size_t)sp * slab];
-            s_gw[jj[q] * pitch + cc[q]] = gsum;
-        }
+        for (int q = 0; q < 4; ++q)
+            if (e0 + BD * q < n) s_gw[jj[q] * pitch + cc[q]] = gsum[q];
     }
     __syncthreads();
     for (int i = tid; i < n; i += BD) {                  // natural (ci, j) order: coalesced reads of v
@@ -853,8 +857,12 @@ extern "C" int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_pa
     const unsigned kmagic = (unsigned)((0x100000000ull + (unsigned)k - 1) / (unsigned)k);
     const unsigned cmagic = (unsigned)((0x100000000ull + (unsigned)Cin - 1) / (unsigned)Cin);
     const int threads = Cin * k >= 2048 ? 1024 : 256;         // big rows: 4x the loads in flight per output channel
-    hipLaunchKernelGGL(conv_finish_kernel, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part, gbias_part,
-                       splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
+    if (splits > 16)
+        hipLaunchKernelGGL(conv_finish_kernel<true>, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part,
+                           gbias_part, splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
+    else
+        hipLaunchKernelGGL(conv_finish_kernel<false>, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part,
+                           gbias_part, splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd");
     return PSND_OK;
 }
