@@ -137,13 +137,14 @@ def test_frame_indexing_golden(golden):
         assert np.array_equal(got['re'][:, 0, :], taps.sum(axis=1).astype(np.float32))
 
 
-def test_stft_linearity_and_parseval_full_size():
-    """BASELINE config 2 size (32 x 2 s): size-independent properties instead of the slow oracle."""
+@pytest.mark.parametrize('n_fft,hop,N,T,sr', [(1024, 256, 32, 44100, 22050),        # BASELINE config 2: 32 x 2 s
+                                               (4096, 1024, 4, 1323000, 44100)])     # config 5: 30 s clips at 44.1 kHz
+def test_stft_linearity_and_parseval_full_size(n_fft, hop, N, T, sr):
+    """BASELINE full sizes: size-independent properties instead of the slow oracle."""
     K = _k()
     dev = _dev()
-    n_fft, hop = 1024, 256
-    a = torch.from_numpy(seeded_wav(1, 32, 44100)).to(dev)
-    b = torch.from_numpy(seeded_wav(2, 32, 44100)).to(dev)
+    a = torch.from_numpy(seeded_wav(1, N, T, sr)).to(dev)
+    b = torch.from_numpy(seeded_wav(2, N, T, sr)).to(dev)
     plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(dev)
     A = K.stft_forward(a, n_fft, hop, plan, want_mag=True, want_reim=True)
     B = K.stft_forward(b, n_fft, hop, plan, want_mag=False, want_reim=True)
@@ -159,7 +160,7 @@ def test_stft_linearity_and_parseval_full_size():
     m2 = A['mag'].double() ** 2
     lhs = m2[:, 0] + m2[:, -1] + 2 * m2[:, 1:-1].sum(1)
     assert float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-12)).max()) <= 2e-5
-    assert A['mag'].shape == (32, 513, 173)
+    assert A['mag'].shape == (N, n_fft // 2 + 1, T // hop + 1)
 
 
 def _mel(mag_np, W, **kw):
