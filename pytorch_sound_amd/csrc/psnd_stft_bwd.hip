@@ -32,34 +32,52 @@ struct StftBwdParams {
     float inv_n, env_eps;
 };
 
+// The gradient (or, for the inverse transform, the spectrum) values of a thread's bins are loaded into registers BEFORE
+// anything is computed from them: read one at a time where they are used, the 33-66 dependent global loads of a thread
+// were a serial latency chain (~55 us per tile at one wave per SIMD).
+struct GVal {
+    float a, b;      // FROM_MAG: a = gmag ; FROM_REIM: a = gre (+ gmag in c), b = gim ; ISTFT: a = magnitude, b = phase
+    float c;
+};
 template <bool FROM_MAG, bool FROM_REIM, bool ISTFT>
 struct GLoad {
     const float *gmag, *gre, *gim;
     float eps, inv_n;
     bool valid;
-    // gradient wrt (re, im) of bin at offset `off`, given the recomputed X there.
+    __device__ __forceinline__ GVal fetch(int off) const {
+        GVal v{0.f, 0.f, 0.f};
+        if (!valid) return v;
+        if constexpr (ISTFT) {
+            v.a = gmag[off], v.b = gre[off];
+        } else {
+            if constexpr (FROM_MAG) v.c = gmag[off];
+            if constexpr (FROM_REIM) v.a = gre[off], v.b = gim[off];
+        }
+        return v;
+    }
+    // gradient wrt (re, im) of a bin from its preloaded values, given the recomputed X there.
     // ISTFT: the "gradient" is the spectrum itself, X = mag * e^{i phase}, scaled so that the adjoint
     // transform below IS the inverse real DFT: 1/n for the DC / Nyquist bins (`edge`), 2/n otherwise.
-    __device__ __forceinline__ void operator()(int off, float xr, float xi, float &gr, float &gi, bool edge = false) const {
+    __device__ __forceinline__ void operator()(const GVal &v, float xr, float xi, float &gr, float &gi, bool edge = false) const {
         gr = 0.f, gi = 0.f;
         if (!valid) return;
         if constexpr (ISTFT) {
             float sn, cs;
-            sincosf(gre[off], &sn, &cs);
-            const float m = gmag[off] * (edge ? inv_n : 2.f * inv_n);
+            sincosf(v.b, &sn, &cs);
+            const float m = v.a * (edge ? inv_n : 2.f * inv_n);
             gr = m * cs;
             gi = m * sn;
             return;
         }
         if constexpr (FROM_MAG) {
             const float m = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, eps)));
-            const float g = gmag[off] / m;   // 0/0 -> NaN exactly like autograd of sqrt at 0
+            const float g = v.c / m;   // 0/0 -> NaN exactly like autograd of sqrt at 0
             gr = g * xr;
             gi = g * xi;
         }
         if constexpr (FROM_REIM) {
-            gr += gre[off];
-            gi += gim[off];
+            gr += v.a;
+            gi += v.b;
         }
     }
 };
@@ -125,14 +143,6 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
         {
             float ar[L], ai[L], br[L], bi[L];      // forward butterflies (slot = bitrev(p))
             float uAr[L], uAi[L], uBr[L], uBi[L];  // adjoint inputs Zs[q + R1 p] in natural p order
-            if constexpr (FROM_MAG) {
-                fwd_pass2_fft<R1, L>(s, f2, qA, qB, ar, ai, br, bi);
-            } else {
-                static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    ar[i] = ai[i] = br[i] = bi[i] = 0.f;
-                });
-            }
             const long long F = p.F;
             const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
             GLoad<FROM_MAG, FROM_REIM, ISTFT> gload{(FROM_MAG || ISTFT) ? p.gmag + cbase : nullptr,
@@ -141,6 +151,25 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
             const int iF = (int)F;
             const int stepF = R1 * iF;
             const int offA = qA * iF, offB = qB * iF;
+            // rows of this thread, all in flight now: A row bins qA + R1 pp (lo: pp < L/2, hi: the mirrored half), same
+            // for the B row; the special pair (qA = 0, qB = R1/2) needs exactly the same bins plus the Nyquist one
+            GVal gAl[L / 2], gAh[L / 2], gBl[L / 2], gBh[L / 2], gNy;
+            static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int pp = decltype(pc)::value;
+                gAl[pp] = gload.fetch(offA + pp * stepF);
+                gBh[pp] = gload.fetch(offB + (L - 1 - pp) * stepF);
+                gBl[pp] = gload.fetch(offB + pp * stepF);
+                gAh[pp] = gload.fetch(offA + (L - 1 - pp) * stepF);
+            });
+            gNy = gload.fetch(special ? L * stepF : offA);
+            if constexpr (FROM_MAG) {
+                fwd_pass2_fft<R1, L>(s, f2, qA, qB, ar, ai, br, bi);
+            } else {
+                static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    ar[i] = ai[i] = br[i] = bi[i] = 0.f;
+                });
+            }
             const float *s_vk = s.vk;
             float xkr = 0.f, xki = 0.f, xcr = 0.f, xci = 0.f, gkr, gki, gcr, gci;
             if (!special) {
@@ -150,15 +179,15 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                     {   // bins k = qA + R1*pp  and  C-k = qB + R1*(L-1-pp)
                         const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qA + R1 * pp));
                         if constexpr (FROM_MAG) rfft_pair(ar[sa], ai[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
-                        gload(offA + pp * stepF, xkr, xki, gkr, gki);
-                        gload(offB + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                        gload(gAl[pp], xkr, xki, gkr, gki);
+                        gload(gBh[pp], xcr, xci, gcr, gci);
                         irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uAr[pp], uAi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
                     }
                     {   // bins k = qB + R1*pp  and  C-k = qA + R1*(L-1-pp)
                         const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (qB + R1 * pp));
                         if constexpr (FROM_MAG) rfft_pair(br[sa], bi[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                        gload(offB + pp * stepF, xkr, xki, gkr, gki);
-                        gload(offA + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                        gload(gBl[pp], xkr, xki, gkr, gki);
+                        gload(gAh[pp], xcr, xci, gcr, gci);
                         irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uAr[L - 1 - pp], uAi[L - 1 - pp]);
                     }
                 });
@@ -169,19 +198,19 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                     constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
                     const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 * pp));
                     if constexpr (FROM_MAG) rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                    gload(pp * stepF, xkr, xki, gkr, gki, pp == 0);
+                    gload(pp < L / 2 ? gAl[pp < L / 2 ? pp : 0] : gAh[L / 2 - 1], xkr, xki, gkr, gki, pp == 0);
                     float z0r, z0i, z1r, z1i;
                     if constexpr (pp == 0) {
                         // H[0] = 2 Re G[0], H[C] = 2 Re G[C] (the imaginary parts of the DC / Nyquist
                         // bins do not reach the real signal)
-                        gload(L * stepF, xcr, xci, gcr, gci, true);
+                        gload(gNy, xcr, xci, gcr, gci, true);
                         irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
                         uAr[0] = z0r, uAi[0] = z0i;
                     } else if constexpr (2 * pp == L) {
                         irfft_pair(gkr, gki, gkr, gki, v.x, v.y, z0r, z0i, z1r, z1i);
                         uAr[pp] = z0r, uAi[pp] = z0i;
                     } else {
-                        gload((L - pp) * stepF, xcr, xci, gcr, gci);
+                        gload(gAh[(pp >= 1 && pp <= L / 2) ? pp - 1 : 0], xcr, xci, gcr, gci);      // bin R1 (L - pp) = row 0, index L-1-(pp-1)
                         irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
                         uAr[pp] = z0r, uAi[pp] = z0i;
                         uAr[L - pp] = z1r, uAi[L - pp] = z1i;
@@ -193,8 +222,8 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                     constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
                     const f32x2 v = *reinterpret_cast<const f32x2 *>(s_vk + 2 * (R1 / 2 + R1 * pp));
                     if constexpr (FROM_MAG) rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
-                    gload(offB + pp * stepF, xkr, xki, gkr, gki);
-                    gload(offB + (L - 1 - pp) * stepF, xcr, xci, gcr, gci);
+                    gload(gBl[pp], xkr, xki, gkr, gki);
+                    gload(gBh[pp], xcr, xci, gcr, gci);
                     irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
                 });
             }
