@@ -88,4 +88,56 @@ __device__ __forceinline__ void fft(v2f (&z)[R]) {
     stage<R, R / 2, SIGN>(z);
 }
 
+// ---------------------------------------------------------------------------------------
+// decimation in TIME: input element p sits in slot bitrev(p), output X[q] lands in slot q (natural order) - the
+// counterpart of fft<> for data that an earlier DIF transform (or an in-place pairing) left in bit-reversed slots.
+// SIGN = -1 forward (e^{-i..}), +1 inverse.  Twiddle on the second operand before the butterfly; +-i is folded
+// into the two v_pk_fma of the butterfly.
+// ---------------------------------------------------------------------------------------
+template <int R, int H, int BLK, int J, int SIGN>
+__device__ __forceinline__ void bfly_dit(v2f (&z)[R]) {
+    constexpr int i0 = BLK + J, i1 = BLK + J + H;
+    constexpr float sg = SIGN > 0 ? 1.f : -1.f;       // w = c + i sg s,  (c, s) = (cos, sin)(2 pi J / (2H))
+    const v2f a = z[i0], b = z[i1];
+    if constexpr (J == 0) {
+        z[i0] = a + b;
+        z[i1] = a - b;
+    } else if constexpr (2 * J == H) {                // w = sg * i: t = sg * (-b.y, b.x)
+        const v2f bs = swp(b);
+        z[i0] = fma(bs, v2f{-sg, sg}, a);
+        z[i1] = fma(bs, v2f{sg, -sg}, a);
+    } else {                                          // t = b * w = (bx c - sg by s, by c + sg bx s)
+        constexpr float c = (float)ct::cos2pi(J, 2 * H);
+        constexpr float s = sg * (float)ct::sin2pi(J, 2 * H);
+        const v2f t = fma(swp(b), v2f{-s, s}, b * v2f{c, c});
+        z[i0] = a + t;
+        z[i1] = a - t;
+    }
+}
+
+template <int R, int H, int SIGN>
+__device__ __forceinline__ void stage_dit(v2f (&z)[R]) {
+    if constexpr (H < R) {
+        static_for<0, R / (2 * H)>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int blk = decltype(bc)::value * 2 * H;
+            static_for<0, H>([&](auto jc) __attribute__((always_inline)) { bfly_dit<R, H, blk, decltype(jc)::value, SIGN>(z); });
+        });
+        stage_dit<R, 2 * H, SIGN>(z);
+    }
+}
+
+template <int R, int SIGN = -1>
+__device__ __forceinline__ void fft_dit(v2f (&z)[R]) {
+    stage_dit<R, 1, SIGN>(z);
+}
+
 }  // namespace pk
+
+// za = Z'[k], zb = Z'[C-k], v = v_k  ->  xk = X[k] = S + E,  xc = S - E with X[C-k] = conj(xc)
+__device__ __forceinline__ void rfft_pair_pk(v2f za, v2f zb, v2f v, v2f &xk, v2f &xc) {
+    const v2f s = pk::fma(zb, v2f{1.f, -1.f}, za);     // za + conj(zb)
+    const v2f d = pk::fma(zb, v2f{-1.f, 1.f}, za);     // za - conj(zb)
+    const v2f e = pk::cmul(d, v);
+    xk = s + e;
+    xc = s - e;
+}

@@ -304,14 +304,6 @@ struct EmitLds {
     }
 };
 
-// za = Z'[k], zb = Z'[C-k], v = v_k  ->  xk = X[k] = S + E,  xc = S - E with X[C-k] = conj(xc)
-__device__ __forceinline__ void rfft_pair_pk(v2f za, v2f zb, v2f v, v2f &xk, v2f &xc) {
-    const v2f s = pk::fma(zb, v2f{1.f, -1.f}, za);     // za + conj(zb)
-    const v2f d = pk::fma(zb, v2f{-1.f, 1.f}, za);     // za - conj(zb)
-    const v2f e = pk::cmul(d, v);
-    xk = s + e;
-    xc = s - e;
-}
 
 // real-FFT split of the two butterflies a thread holds + output (packed twin of post_emit): lower bins are
 // stored at once, their mirrors are parked (already reduced to the values to store) and written

@@ -16,6 +16,7 @@
 //            tile are stored plainly (coalesced), the n-hop head/tail and reflected samples are
 //            atomically added to the zero-initialised gwav.
 #include "psnd_stft_pass.h"
+#include "psnd_pk.h"
 #include <math.h>
 
 namespace {
@@ -30,7 +31,19 @@ struct StftBwdParams {
     // inverse-STFT mode (psnd_istft): gmag = magnitude, gre = phase, gwav = output (N, T = (F-1)*hop)
     int win_off;        // float offset of the raw window inside the plan
     float inv_n, env_eps;
+#ifdef PSND_TRACE
+    long long *trace;
+#endif
 };
+#ifdef PSND_TRACE
+#define PSND_BSTAMP(i_)                                                                              \
+    do {                                                                                             \
+        if ((threadIdx.x & 63) == 0 && p.trace)                                                      \
+            p.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PSND_BSTAMP(i_)
+#endif
 
 // The gradient (or, for the inverse transform, the spectrum) values of a thread's bins are loaded into registers BEFORE
 // anything is computed from them: read one at a time where they are used, the 33-66 dependent global loads of a thread
@@ -333,6 +346,270 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// n_fft = 1024, gradient of the magnitude (the path LogMelSpectrogram / magnitude losses take): the adjoint on the
+// structure of stft_fwd_n1024_kernel - span staged once in LDS, packed fp32 (psnd_pk.h), every gmag value of a thread
+// loaded before the first FLOP, the adjoint split written IN PLACE over the forward butterflies (element p of a row
+// stays in slot bitrev(p)), inverse transforms as decimation-in-time FFTs (bit-reversed in, natural out), so the
+// kernel needs ~130 VGPRs instead of 294 and two workgroups share a CU.  (The general kernel above - one wave per SIMD,
+// scalar, frame taps from global memory - runs this case at 4-5 % of the HBM roof.)
+// LDS: tables + one FULL exchange [16 frames][32 rows][16 l] of (re, im) (65.8 KB); the forward span, the forward
+// exchange, the adjoint exchange and the overlap-add span all live in it, one after the other.
+// ---------------------------------------------------------------------------------------------
+constexpr int kB1024Sf = 32 * 16 * 2 + 4;        // exchange frame stride (floats): 1028/4 odd, 8*1028 = 32 (mod 64)
+constexpr int kB1024LdsFloats = 2 * 16 * 68 + 516 + 16 * kB1024Sf;
+
+__global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParams p) {
+    constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5, LB = 4, SF = kB1024Sf;
+    constexpr int TAB = 2 * L * ROW + VKP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_wt = smem, *s_tw = s_wt + L * ROW, *s_vk = s_tw + L * ROW, *s_x = s_vk + VKP;
+    const int t = threadIdx.x;
+    const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);     // lane identity (passes over a): half-waves hold frames fl, fl+8
+    const int f2 = t & 15, qq = (t >> 6) + 4 * ((t >> 4) & 3);    // pair identity (passes over l)
+    const bool special = (qq == 0);
+    const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
+    const int hop = p.hop;
+    const int span_len = (FT - 1) * hop + NFFT;
+    const int skew = (hop % 256 == 0) ? 4 : 0;
+
+    const int chunk = (p.total_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || tile >= p.total_tiles) return;
+    const int clip = tile / p.ntile;
+    const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+    const float *x = p.wav + (size_t)clip * p.T;
+    float *gw = p.gwav + (size_t)clip * p.T;
+    const long long F = p.F;
+    const int iF = (int)F;
+    PSND_BSTAMP(0);
+
+    // ---- prologue: span, tables, and every gmag value of this thread (bins qA + 32 pp, qB + 32 pp and their mirrors) ----
+    {
+        const long long g0 = f0 * hop - p.pad;
+        const int Ti = (int)p.T;
+        for (int s4 = t * 4; s4 < span_len; s4 += 1024) {
+            const long long g = g0 + s4;
+            f32x4 v;
+            if (g >= 0 && g + 3 < p.T) {
+                v = *reinterpret_cast<const f32x4_u *>(x + g);
+            } else {
+                const int gi = (int)g;
+                v.x = x[reflect_idx32(gi, Ti)], v.y = x[reflect_idx32(gi + 1, Ti)];
+                v.z = x[reflect_idx32(gi + 2, Ti)], v.w = x[reflect_idx32(gi + 3, Ti)];
+            }
+            *reinterpret_cast<f32x4 *>(s_x + s4 + skew * (s4 >> 8)) = v;
+        }
+        for (int i = t; i < TAB / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(p.plan)[i];
+    }
+    const bool fvalid2 = (f0 + f2) < F;
+    const float *gbase = p.gmag + (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
+    const int stepF = R1 * iF, offA = qA * iF, offB = qB * iF;
+    float gAl[L / 2], gAh[L / 2], gBl[L / 2], gBh[L / 2], gNy = 0.f;
+    static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pp = decltype(pc)::value;
+        gAl[pp] = fvalid2 ? gbase[offA + pp * stepF] : 0.f;
+        gBh[pp] = fvalid2 ? gbase[offB + (L - 1 - pp) * stepF] : 0.f;
+        gBl[pp] = fvalid2 ? gbase[offB + pp * stepF] : 0.f;
+        gAh[pp] = fvalid2 ? gbase[offA + (L - 1 - pp) * stepF] : 0.f;
+    });
+    if (special && fvalid2) gNy = gbase[L * stepF];
+    __syncthreads();
+    PSND_BSTAMP(1);
+
+    // ---- forward pass 1 (recompute X): taps, window, radix-32, twiddle, all 32 rows to the exchange -------------------
+    {
+        v2f z[R1];
+        const int sb = fl * hop + 2 * l;
+        const float *tb0 = s_x + sb + skew * (sb >> 8);
+        static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            const float *tb = tb0 + g * (256 + skew);
+            static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = 8 * g + decltype(ac)::value;
+                z[a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+            });
+        });
+        const float *wrow = s_wt + l * ROW;
+        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+            z[2 * i] *= pk::lo(w);
+            z[2 * i + 1] *= pk::hi(w);
+            if constexpr (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        });
+        pk::fft<R1>(z);
+        __syncthreads();                             // every lane holds its taps: the span area becomes the exchange
+        const float *trow = s_tw + l * ROW;
+        float *oz = s_x + fl * SF + 2 * l;
+        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int q0 = 2 * decltype(ic)::value, q1 = q0 + 1;
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
+            if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[0];
+            else *reinterpret_cast<v2f *>(oz + q0 * 2 * L) = pk::cmul(z[ct::bitrev(q0, RB)], pk::lo(w));
+            *reinterpret_cast<v2f *>(oz + q1 * 2 * L) = pk::cmul(z[ct::bitrev(q1, RB)], pk::hi(w));
+        });
+    }
+    __syncthreads();
+    PSND_BSTAMP(2);
+
+    // ---- pair threads: forward radix-16 -> X, G = gmag X / |X|, adjoint split in place, inverse radix-16, conj twiddle ----
+    {
+        v2f za[L], zb[L];
+        float *rowA = s_x + f2 * SF + qA * 2 * L, *rowB = s_x + f2 * SF + qB * 2 * L;
+        static_for<0, L / 2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(rowA + 4 * i), vb = *reinterpret_cast<const f32x4 *>(rowB + 4 * i);
+            za[2 * i] = pk::lo(va), za[2 * i + 1] = pk::hi(va);
+            zb[2 * i] = pk::lo(vb), zb[2 * i + 1] = pk::hi(vb);
+        });
+        pk::fft<L>(za);
+        pk::fft<L>(zb);
+        auto vk = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const v2f *>(s_vk + 2 * k); };
+        const v2f eps2 = v2f{p.mag_eps, 0.f};
+        // (Z'[k], Z'[C-k]) -> adjoint inputs (Zs[k], Zs[C-k]) for the gradient magnitudes gk, gc of the two bins
+        auto pair = [&](v2f &a, v2f &b, v2f v, float gk, float gc) __attribute__((always_inline)) {
+            v2f xk, xc;
+            rfft_pair_pk(a, b, v, xk, xc);                           // X[k] = xk, X[C-k] = conj(xc)
+            const v2f sk = pk::fma(xk, xk, eps2), sc = pk::fma(xc, xc, eps2);
+            const float rk = gk * __builtin_amdgcn_rsqf(sk.x + sk.y);   // 0 * inf = NaN for a zero bin, as autograd of sqrt
+            const float rc = gc * __builtin_amdgcn_rsqf(sc.x + sc.y);
+            const v2f ha = xk * v2f{rk, rk}, hbc = xc * v2f{rc, rc};  // G[k] and conj(G[C-k])
+            const v2f s = ha + hbc, d = ha - hbc;
+            const v2f e = pk::cmul_conj(d, v);
+            a = s + e;                                               // Zs[k]
+            b = (s - e) * v2f{1.f, -1.f};                            // Zs[C-k] = conj(S - conj(v) D)
+        };
+        if (!special) {
+            static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int pp = decltype(pc)::value;
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                pair(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], gBh[pp]);      // bins qA + 32 pp | qB + 32 (15-pp)
+                pair(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], gAh[pp]);      // bins qB + 32 pp | qA + 32 (15-pp)
+            });
+        } else {
+            // rows 0 and 16 are self-paired (scalar formulation of the general kernel, divergent for these 16 lanes only)
+            float ar[L], ai[L], br[L], bi[L], uAr[L], uAi[L], uBr[L], uBi[L];
+            static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                ar[i] = za[i].x, ai[i] = za[i].y, br[i] = zb[i].x, bi[i] = zb[i].y;
+            });
+            auto gof = [&](float gm, float xr, float xi, float &gr, float &gi) __attribute__((always_inline)) {
+                const float g = gm / __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, p.mag_eps)));
+                gr = g * xr, gi = g * xi;
+            };
+            float xkr, xki, xcr, xci, gkr, gki, gcr, gci;
+            static_for<0, L / 2 + 1>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int pp = decltype(pc)::value;
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
+                const v2f v = vk(R1 * pp);
+                rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
+                gof(pp < L / 2 ? gAl[pp < L / 2 ? pp : 0] : gAh[L / 2 - 1], xkr, xki, gkr, gki);
+                float z0r, z0i, z1r, z1i;
+                if constexpr (pp == 0) {
+                    gof(gNy, xcr, xci, gcr, gci);
+                    irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
+                    uAr[0] = z0r, uAi[0] = z0i;
+                } else if constexpr (2 * pp == L) {
+                    irfft_pair(gkr, gki, gkr, gki, v.x, v.y, z0r, z0i, z1r, z1i);
+                    uAr[pp] = z0r, uAi[pp] = z0i;
+                } else {
+                    gof(gAh[(pp >= 1 && pp <= L / 2) ? pp - 1 : 0], xcr, xci, gcr, gci);
+                    irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
+                    uAr[pp] = z0r, uAi[pp] = z0i;
+                    uAr[L - pp] = z1r, uAi[L - pp] = z1i;
+                }
+            });
+            static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int pp = decltype(pc)::value;
+                constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
+                const v2f v = vk(R1 / 2 + R1 * pp);
+                rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
+                gof(gBl[pp], xkr, xki, gkr, gki);
+                gof(gBh[pp], xcr, xci, gcr, gci);
+                irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
+            });
+            static_for<0, L>([&](auto ic) __attribute__((always_inline)) {       // natural index p -> slot bitrev(p)
+                constexpr int pq = decltype(ic)::value, sl = ct::bitrev(pq, LB);
+                za[sl] = v2f{uAr[pq], uAi[pq]};
+                zb[sl] = v2f{uBr[pq], uBi[pq]};
+            });
+        }
+        pk::fft_dit<L, 1>(za);                                        // inverse over p: U[q][l] in slot l
+        pk::fft_dit<L, 1>(zb);
+        static_for<0, L / 2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const v2f ta0 = *reinterpret_cast<const v2f *>(s_tw + (2 * i) * ROW + 2 * qA), ta1 = *reinterpret_cast<const v2f *>(s_tw + (2 * i + 1) * ROW + 2 * qA);
+            const v2f tb0 = *reinterpret_cast<const v2f *>(s_tw + (2 * i) * ROW + 2 * qB), tb1 = *reinterpret_cast<const v2f *>(s_tw + (2 * i + 1) * ROW + 2 * qB);
+            const v2f a0 = pk::cmul_conj(za[2 * i], ta0), a1 = pk::cmul_conj(za[2 * i + 1], ta1);
+            const v2f b0 = pk::cmul_conj(zb[2 * i], tb0), b1 = pk::cmul_conj(zb[2 * i + 1], tb1);
+            *reinterpret_cast<f32x4 *>(rowA + 4 * i) = f32x4{a0.x, a0.y, a1.x, a1.y};
+            *reinterpret_cast<f32x4 *>(rowB + 4 * i) = f32x4{b0.x, b0.y, b1.x, b1.y};
+        });
+    }
+    __syncthreads();
+    PSND_BSTAMP(3);
+
+    // ---- lane threads: inverse radix-32 over q, window, overlap-add of the tile in LDS, one pass over the span ---------
+    {
+        v2f z[R1];
+        const float *iz = s_x + fl * SF + 2 * l;
+        static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            z[ct::bitrev(q, RB)] = *reinterpret_cast<const v2f *>(iz + q * 2 * L);
+        });
+        pk::fft_dit<R1, 1>(z);                                        // z[l + 16 a] in slot a
+        const float *wrow = s_wt + l * ROW;
+        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+            z[2 * i] *= pk::lo(w);
+            z[2 * i + 1] *= pk::hi(w);
+        });
+        __syncthreads();                             // exchange consumed: it takes the frames' time samples Y[frame][m]
+        PSND_BSTAMP(4);
+        // Overlap-add WITHOUT LDS atomics: ds_add_f32 retires about one lane per 12 cycles on gfx950 (measured: the 64
+        // atomics of a thread were 51 k of the workgroup's 126 k cycles and stalled the co-resident workgroup's LDS
+        // traffic as well).  Every lane parks its 64 windowed samples, then each span sample gathers its <= n/hop frames.
+        {
+            float *yo = s_x + fl * SF + 2 * l;
+            static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = decltype(ac)::value;
+                *reinterpret_cast<v2f *>(yo + 2 * L * a) = z[a];
+            });
+        }
+        __syncthreads();
+        PSND_BSTAMP(5);
+        const int t_start = (int)(f0 * hop - p.pad);               // clips are shorter than 2^31 samples (checked on the host)
+        const int int_lo = NFFT - hop, int_hi = FT * hop;
+        const int nfr = (int)((F - f0) < FT ? (F - f0) : FT);      // valid frames of this tile
+        const unsigned hmagic = 0xffffffffu / (unsigned)hop + 1u;  // i / hop = umulhi(i, hmagic) for i < 2^32 / hop
+        const int Ti = (int)p.T;
+        for (int i = t; i < span_len; i += 256) {
+            // frames f with 0 <= i - f*hop < n
+            int f_hi = (int)__umulhi((unsigned)i, hmagic);
+            if (f_hi > nfr - 1) f_hi = nfr - 1;
+            const int above = i - NFFT + hop;                      // f_lo = ceil((i - n + 1) / hop) = floor(above / hop) when > 0
+            const int f_lo = above > 0 ? (int)__umulhi((unsigned)above, hmagic) : 0;
+            float v = 0.f;
+            for (int f = f_lo; f <= f_hi; ++f) v += s_x[f * SF + (i - f * hop)];
+            const int tg = t_start + i;
+            if (i >= int_lo && i < int_hi && tg > p.pad && tg < Ti - 1 - p.pad) {
+                gw[tg] = v;
+            } else if (v != 0.f) {
+                int tr = tg < 0 ? -tg : tg;                        // reflect
+                tr = tr >= Ti ? 2 * (Ti - 1) - tr : tr;
+                if (tr >= 0 && tr < Ti) unsafeAtomicAdd(gw + tr, v);
+            }
+        }
+    }
+#ifdef PSND_TRACE
+    PSND_BSTAMP(6);
+    __builtin_amdgcn_s_waitcnt(0);
+    PSND_BSTAMP(7);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic fallback (power-of-two n_fft without a tuned decomposition): one workgroup per
 // (clip, frame), radix-2 FFTs in LDS, global atomics.  plan = win[n].
 // ---------------------------------------------------------------------------------------------
@@ -495,6 +772,12 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     p.wav = wav, p.plan = static_cast<const float *>(plan), p.gmag = gmag, p.gre = gre, p.gim = gim, p.gwav = gwav;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
     p.win_off = 0, p.inv_n = 0.f, p.env_eps = 0.f;
+#ifdef PSND_TRACE
+    {
+        const char *tp = getenv("PSND_TRACE_PTR");
+        p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
+    }
+#endif
     const Decomp *d = find_decomp(n_fft);
     if (d) {
         const int FT = 512 / d->R1;
@@ -504,7 +787,17 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         switch (n_fft) {
             case 256: return launch_bwd<16, 8>(p, gmag, gre, s);
             case 512: return launch_bwd<16, 16>(p, gmag, gre, s);
-            case 1024: return launch_bwd<32, 16>(p, gmag, gre, s);
+            case 1024:
+                if (gmag && !gre && hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
+                    constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e));
+                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
+                    PSND_CHECK_LAUNCH("stft_bwd(n1024, mag)");
+                    return PSND_OK;
+                }
+                return launch_bwd<32, 16>(p, gmag, gre, s);
             case 2048: return launch_bwd<32, 32>(p, gmag, gre, s);
         }
     }
