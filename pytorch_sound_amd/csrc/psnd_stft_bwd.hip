@@ -294,26 +294,46 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
             });
             const bool fvalid = (f0 + fl) < p.F;
             if (use_span) {
+                // overlap-add by GATHER (no LDS atomics: ds_add_f32 retires ~one lane per 12 cycles on gfx950): every lane
+                // parks its 2*R1 windowed samples as Y[frame][m], then each span sample sums its <= n/hop frames
+                constexpr int YS = NFFT + 4;       // FT * YS floats fit the exchange area (2 * FT * (C + 4))
                 __syncthreads();   // every lane holds its inputs in registers: the exchange area is free
-                for (int i = t; i < span_len; i += 256) span[i] = 0.f;
-                __syncthreads();
-                if (fvalid) {
-                    float *sp = span + fl * p.hop + 2 * l;
+                {
+                    float *yo = span + fl * YS + 2 * l;
                     static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                         constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
-                        atomicAdd(sp + 2 * L * a, zr[sl]);
-                        atomicAdd(sp + 2 * L * a + 1, zi[sl]);
+                        yo[2 * L * a] = zr[sl];
+                        yo[2 * L * a + 1] = zi[sl];
                     });
                 }
                 __syncthreads();
                 const int int_lo = NFFT - p.hop, int_hi = FT * p.hop;
+                const int nfr = (int)((p.F - f0) < FT ? (p.F - f0) : FT);
+                const unsigned hmagic = 0xffffffffu / (unsigned)p.hop + 1u;
                 for (int i = t; i < span_len; i += 256) {
-                    float v = span[i];
+                    int f_hi = (int)__umulhi((unsigned)i, hmagic);
+                    if (f_hi > nfr - 1) f_hi = nfr - 1;
+                    const int above = i - NFFT + p.hop;
+                    const int f_lo = above > 0 ? (int)__umulhi((unsigned)above, hmagic) : 0;
+                    float v = 0.f;
+                    for (int f = f_lo; f <= f_hi; ++f) v += span[f * YS + (i - f * p.hop)];
                     const long long tg = t_start + i;
                     if constexpr (ISTFT) {
                         // no reflection: samples outside [0, T) are the trimmed n/2 margins; divide by the envelope
                         if (tg < 0 || tg >= p.T) continue;
-                        v /= ola_envelope(p.plan + p.win_off, tg + p.pad, NFFT, p.hop, p.F) + p.env_eps;
+                        // squared-window envelope from the LDS copy of the window (wt[l][2a+c] = win[2(l + L a) + c] / 2)
+                        const long long tp = tg + p.pad;
+                        long long e_hi = tp < (1ll << 24) ? (long long)__umulhi((unsigned)tp, hmagic) : tp / p.hop;
+                        if (e_hi > p.F - 1) e_hi = p.F - 1;
+                        const long long ab = tp - NFFT + p.hop;
+                        const long long e_lo = ab > 0 ? (ab < (1ll << 24) ? (long long)__umulhi((unsigned)ab, hmagic) : ab / p.hop) : 0;
+                        float env = 0.f;
+                        for (long long f = e_lo; f <= e_hi; ++f) {
+                            const int m = (int)(tp - f * p.hop), h2 = m >> 1;
+                            const float w = 2.f * s.wt[(h2 % L) * ROW + 2 * (h2 / L) + (m & 1)];
+                            env = __builtin_fmaf(w, w, env);
+                        }
+                        v /= env + p.env_eps;
                         if (i >= int_lo && i < int_hi) gw[tg] = v;
                         else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
                     } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {

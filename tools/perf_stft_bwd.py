@@ -28,3 +28,19 @@ for n, h, N, T in [(1024, 256, 32, 44100), (1024, 256, 1024, 44100), (4096, 1024
     b = 4 * N * Kb * F + 8 * N * T
     print('stft_bwd n=%d N=%d T=%d: %.1f us  %.0f GB/s (%.1f%% of 8 TB/s)' % (n, N, T, t * 1e6, b / t / 1e9, b / t / 8e12 * 100), flush=True)
     del wav, gmag
+for n, h, N, F in [(1024, 256, 32, 173), (1024, 256, 1024, 173)]:
+    plan = K.stft_plan(n, hann(n)).to(dev)
+    mag = torch.rand(N, n // 2 + 1, F, device=dev)
+    ph = torch.rand(N, n // 2 + 1, F, device=dev) * 6.28
+    win = torch.from_numpy(hann(n)).to(dev)
+    t = timeit(lambda: K.istft(mag, ph, n, h, plan, 1e-9, win))
+    b = 8 * N * (n // 2 + 1) * F + 4 * N * (F - 1) * h
+    print('istft n=%d N=%d F=%d: %.1f us  %.0f GB/s' % (n, N, F, t * 1e6, b / t / 1e9), flush=True)
+# (re, im) gradient path (STFTTorchAudio)
+for n, h, N, T in [(1024, 256, 1024, 44100)]:
+    wav = torch.randn(N, T, device=dev) * 0.07
+    plan = K.stft_plan(n, hann(n)).to(dev)
+    F = K.frame_count(T, n, h); Kb = n // 2 + 1
+    gre = torch.randn(N, Kb, F, device=dev); gim = torch.randn(N, Kb, F, device=dev)
+    t = timeit(lambda: K.stft_backward(wav, n, h, plan, gre=gre, gim=gim))
+    print('stft_bwd(re,im) n=%d N=%d: %.1f us' % (n, N, t * 1e6), flush=True)
