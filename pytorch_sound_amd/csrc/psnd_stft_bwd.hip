@@ -378,6 +378,20 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
 constexpr int kB1024Sf = 32 * 16 * 2 + 4;        // exchange frame stride (floats): 1028/4 odd, 8*1028 = 32 (mod 64)
 constexpr int kB1024LdsFloats = 2 * 16 * 68 + 516 + 16 * kB1024Sf;
 
+// ISTFT = true: the same kernel as the inverse transform of psnd_istft - no forward recompute, the "gradient" is the spectrum
+// mag * e^{i phase} scaled to make the adjoint the inverse real DFT, and the overlap-added signal is divided by the squared-
+// window envelope (STFT.inverse, transforms.py:71-101); no reflection (the n/2 margins are trimmed).
+
+// sin / cos on the hardware units (v_sin_f32 / v_cos_f32 work in revolutions): |error| < 2e-6 after the fract() range
+// reduction, inside the 1e-5 round-trip tolerance of the inverse transform; the libm sincosf costs ~10x the instructions.
+__device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs) {
+    const float r = x * 0.15915494309189535f;
+    const float f = r - __builtin_floorf(r);
+    sn = __builtin_amdgcn_sinf(f);
+    cs = __builtin_amdgcn_cosf(f);
+}
+
+template <bool ISTFT>
 __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParams p) {
     constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5, LB = 4, SF = kB1024Sf;
     constexpr int TAB = 2 * L * ROW + VKP;
@@ -405,24 +419,27 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
 
     // ---- prologue: span, tables, and every gmag value of this thread (bins qA + 32 pp, qB + 32 pp and their mirrors) ----
     {
-        const long long g0 = f0 * hop - p.pad;
-        const int Ti = (int)p.T;
-        for (int s4 = t * 4; s4 < span_len; s4 += 1024) {
-            const long long g = g0 + s4;
-            f32x4 v;
-            if (g >= 0 && g + 3 < p.T) {
-                v = *reinterpret_cast<const f32x4_u *>(x + g);
-            } else {
-                const int gi = (int)g;
-                v.x = x[reflect_idx32(gi, Ti)], v.y = x[reflect_idx32(gi + 1, Ti)];
-                v.z = x[reflect_idx32(gi + 2, Ti)], v.w = x[reflect_idx32(gi + 3, Ti)];
+        if constexpr (!ISTFT) {
+            const long long g0 = f0 * hop - p.pad;
+            const int Ti = (int)p.T;
+            for (int s4 = t * 4; s4 < span_len; s4 += 1024) {
+                const long long g = g0 + s4;
+                f32x4 v;
+                if (g >= 0 && g + 3 < p.T) {
+                    v = *reinterpret_cast<const f32x4_u *>(x + g);
+                } else {
+                    const int gi = (int)g;
+                    v.x = x[reflect_idx32(gi, Ti)], v.y = x[reflect_idx32(gi + 1, Ti)];
+                    v.z = x[reflect_idx32(gi + 2, Ti)], v.w = x[reflect_idx32(gi + 3, Ti)];
+                }
+                *reinterpret_cast<f32x4 *>(s_x + s4 + skew * (s4 >> 8)) = v;
             }
-            *reinterpret_cast<f32x4 *>(s_x + s4 + skew * (s4 >> 8)) = v;
         }
         for (int i = t; i < TAB / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(p.plan)[i];
     }
     const bool fvalid2 = (f0 + f2) < F;
-    const float *gbase = p.gmag + (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
+    const size_t goff = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
+    const float *gbase = p.gmag + goff;
     const int stepF = R1 * iF, offA = qA * iF, offB = qB * iF;
     float gAl[L / 2], gAh[L / 2], gBl[L / 2], gBh[L / 2], gNy = 0.f;
     static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
@@ -433,11 +450,24 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         gAh[pp] = fvalid2 ? gbase[offA + (L - 1 - pp) * stepF] : 0.f;
     });
     if (special && fvalid2) gNy = gbase[L * stepF];
+    // inverse transform: the phases of the same bins
+    float pAl[ISTFT ? L / 2 : 1], pAh[ISTFT ? L / 2 : 1], pBl[ISTFT ? L / 2 : 1], pBh[ISTFT ? L / 2 : 1], pNy = 0.f;
+    if constexpr (ISTFT) {
+        const float *pbase = p.gre + goff;
+        static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            pAl[pp] = fvalid2 ? pbase[offA + pp * stepF] : 0.f;
+            pBh[pp] = fvalid2 ? pbase[offB + (L - 1 - pp) * stepF] : 0.f;
+            pBl[pp] = fvalid2 ? pbase[offB + pp * stepF] : 0.f;
+            pAh[pp] = fvalid2 ? pbase[offA + (L - 1 - pp) * stepF] : 0.f;
+        });
+        if (special && fvalid2) pNy = pbase[L * stepF];
+    }
     __syncthreads();
     PSND_BSTAMP(1);
 
     // ---- forward pass 1 (recompute X): taps, window, radix-32, twiddle, all 32 rows to the exchange -------------------
-    {
+    if constexpr (!ISTFT) {
         v2f z[R1];
         const int sb = fl * hop + 2 * l;
         const float *tb0 = s_x + sb + skew * (sb >> 8);
@@ -468,22 +498,24 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
             else *reinterpret_cast<v2f *>(oz + q0 * 2 * L) = pk::cmul(z[ct::bitrev(q0, RB)], pk::lo(w));
             *reinterpret_cast<v2f *>(oz + q1 * 2 * L) = pk::cmul(z[ct::bitrev(q1, RB)], pk::hi(w));
         });
+        __syncthreads();
     }
-    __syncthreads();
     PSND_BSTAMP(2);
 
     // ---- pair threads: forward radix-16 -> X, G = gmag X / |X|, adjoint split in place, inverse radix-16, conj twiddle ----
     {
         v2f za[L], zb[L];
         float *rowA = s_x + f2 * SF + qA * 2 * L, *rowB = s_x + f2 * SF + qB * 2 * L;
-        static_for<0, L / 2>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            const f32x4 va = *reinterpret_cast<const f32x4 *>(rowA + 4 * i), vb = *reinterpret_cast<const f32x4 *>(rowB + 4 * i);
-            za[2 * i] = pk::lo(va), za[2 * i + 1] = pk::hi(va);
-            zb[2 * i] = pk::lo(vb), zb[2 * i + 1] = pk::hi(vb);
-        });
-        pk::fft<L>(za);
-        pk::fft<L>(zb);
+        if constexpr (!ISTFT) {
+            static_for<0, L / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 va = *reinterpret_cast<const f32x4 *>(rowA + 4 * i), vb = *reinterpret_cast<const f32x4 *>(rowB + 4 * i);
+                za[2 * i] = pk::lo(va), za[2 * i + 1] = pk::hi(va);
+                zb[2 * i] = pk::lo(vb), zb[2 * i + 1] = pk::hi(vb);
+            });
+            pk::fft<L>(za);
+            pk::fft<L>(zb);
+        }
         auto vk = [&](int k) __attribute__((always_inline)) { return *reinterpret_cast<const v2f *>(s_vk + 2 * k); };
         const v2f eps2 = v2f{p.mag_eps, 0.f};
         // (Z'[k], Z'[C-k]) -> adjoint inputs (Zs[k], Zs[C-k]) for the gradient magnitudes gk, gc of the two bins
@@ -499,23 +531,49 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
             a = s + e;                                               // Zs[k]
             b = (s - e) * v2f{1.f, -1.f};                            // Zs[C-k] = conj(S - conj(v) D)
         };
+        // inverse transform: spectrum values instead of gradients.  H[k] = m_k e^{i phi_k} * 2/n, conj(H[C-k]) likewise
+        auto pair_inv = [&](v2f &a, v2f &b, v2f v, float mk, float phk, float mc, float phc) __attribute__((always_inline)) {
+            float sk, ck, sc, cc;
+            fast_sincos(phk, sk, ck);
+            fast_sincos(phc, sc, cc);
+            const float ak = mk * 2.f * p.inv_n, ac = mc * 2.f * p.inv_n;
+            const v2f ha = v2f{ak * ck, ak * sk}, hbc = v2f{ac * cc, -ac * sc};
+            const v2f s = ha + hbc, d = ha - hbc;
+            const v2f e = pk::cmul_conj(d, v);
+            a = s + e;
+            b = (s - e) * v2f{1.f, -1.f};
+        };
         if (!special) {
             static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
                 constexpr int pp = decltype(pc)::value;
                 constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
-                pair(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], gBh[pp]);      // bins qA + 32 pp | qB + 32 (15-pp)
-                pair(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], gAh[pp]);      // bins qB + 32 pp | qA + 32 (15-pp)
+                if constexpr (ISTFT) {
+                    pair_inv(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], pAl[pp], gBh[pp], pBh[pp]);
+                    pair_inv(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], pBl[pp], gAh[pp], pAh[pp]);
+                } else {
+                    pair(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], gBh[pp]);      // bins qA + 32 pp | qB + 32 (15-pp)
+                    pair(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], gAh[pp]);      // bins qB + 32 pp | qA + 32 (15-pp)
+                }
             });
         } else {
             // rows 0 and 16 are self-paired (scalar formulation of the general kernel, divergent for these 16 lanes only)
             float ar[L], ai[L], br[L], bi[L], uAr[L], uAi[L], uBr[L], uBi[L];
             static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                ar[i] = za[i].x, ai[i] = za[i].y, br[i] = zb[i].x, bi[i] = zb[i].y;
+                if constexpr (ISTFT) ar[i] = ai[i] = br[i] = bi[i] = 0.f;
+                else ar[i] = za[i].x, ai[i] = za[i].y, br[i] = zb[i].x, bi[i] = zb[i].y;
             });
-            auto gof = [&](float gm, float xr, float xi, float &gr, float &gi) __attribute__((always_inline)) {
-                const float g = gm / __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, p.mag_eps)));
-                gr = g * xr, gi = g * xi;
+            // gradient (or spectrum value) of a bin; `ph` and `edge` only matter for the inverse transform
+            auto gof = [&](float gm, float xr, float xi, float &gr, float &gi, float ph = 0.f, bool edge = false) __attribute__((always_inline)) {
+                if constexpr (ISTFT) {
+                    float sn, cs;
+                    fast_sincos(ph, sn, cs);
+                    const float m = gm * (edge ? p.inv_n : 2.f * p.inv_n);
+                    gr = m * cs, gi = m * sn;
+                } else {
+                    const float g = gm / __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, p.mag_eps)));
+                    gr = g * xr, gi = g * xi;
+                }
             };
             float xkr, xki, xcr, xci, gkr, gki, gcr, gci;
             static_for<0, L / 2 + 1>([&](auto pc) __attribute__((always_inline)) {
@@ -523,17 +581,19 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
                 constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
                 const v2f v = vk(R1 * pp);
                 rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
-                gof(pp < L / 2 ? gAl[pp < L / 2 ? pp : 0] : gAh[L / 2 - 1], xkr, xki, gkr, gki);
+                gof(pp < L / 2 ? gAl[pp < L / 2 ? pp : 0] : gAh[L / 2 - 1], xkr, xki, gkr, gki,
+                    ISTFT ? (pp < L / 2 ? pAl[(ISTFT && pp < L / 2) ? pp : 0] : pAh[ISTFT ? L / 2 - 1 : 0]) : 0.f, pp == 0);
                 float z0r, z0i, z1r, z1i;
                 if constexpr (pp == 0) {
-                    gof(gNy, xcr, xci, gcr, gci);
+                    gof(gNy, xcr, xci, gcr, gci, pNy, true);
                     irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
                     uAr[0] = z0r, uAi[0] = z0i;
                 } else if constexpr (2 * pp == L) {
                     irfft_pair(gkr, gki, gkr, gki, v.x, v.y, z0r, z0i, z1r, z1i);
                     uAr[pp] = z0r, uAi[pp] = z0i;
                 } else {
-                    gof(gAh[(pp >= 1 && pp <= L / 2) ? pp - 1 : 0], xcr, xci, gcr, gci);
+                    gof(gAh[(pp >= 1 && pp <= L / 2) ? pp - 1 : 0], xcr, xci, gcr, gci,
+                        ISTFT ? pAh[(ISTFT && pp >= 1 && pp <= L / 2) ? pp - 1 : 0] : 0.f);
                     irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
                     uAr[pp] = z0r, uAi[pp] = z0i;
                     uAr[L - pp] = z1r, uAi[L - pp] = z1i;
@@ -544,8 +604,8 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
                 constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
                 const v2f v = vk(R1 / 2 + R1 * pp);
                 rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
-                gof(gBl[pp], xkr, xki, gkr, gki);
-                gof(gBh[pp], xcr, xci, gcr, gci);
+                gof(gBl[pp], xkr, xki, gkr, gki, ISTFT ? pBl[ISTFT ? pp : 0] : 0.f);
+                gof(gBh[pp], xcr, xci, gcr, gci, ISTFT ? pBh[ISTFT ? pp : 0] : 0.f);
                 irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
             });
             static_for<0, L>([&](auto ic) __attribute__((always_inline)) {       // natural index p -> slot bitrev(p)
@@ -613,7 +673,23 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
             float v = 0.f;
             for (int f = f_lo; f <= f_hi; ++f) v += s_x[f * SF + (i - f * hop)];
             const int tg = t_start + i;
-            if (i >= int_lo && i < int_hi && tg > p.pad && tg < Ti - 1 - p.pad) {
+            if constexpr (ISTFT) {
+                if (tg < 0 || tg >= Ti) continue;                  // the trimmed n/2 margins
+                const int tp = tg + p.pad;                         // squared-window envelope over ALL frames of the clip
+                int e_hi = tp < (1 << 24) ? (int)__umulhi((unsigned)tp, hmagic) : tp / hop;
+                if (e_hi > iF - 1) e_hi = iF - 1;
+                const int ab = tp - NFFT + hop;
+                const int e_lo = ab > 0 ? (ab < (1 << 24) ? (int)__umulhi((unsigned)ab, hmagic) : ab / hop) : 0;
+                float env = 0.f;
+                for (int f = e_lo; f <= e_hi; ++f) {
+                    const int m = tp - f * hop, h2 = m >> 1;
+                    const float w = 2.f * s_wt[(h2 & (L - 1)) * ROW + 2 * (h2 >> LB) + (m & 1)];
+                    env = __builtin_fmaf(w, w, env);
+                }
+                v /= env + p.env_eps;
+                if (i >= int_lo && i < int_hi) gw[tg] = v;
+                else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
+            } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < Ti - 1 - p.pad) {
                 gw[tg] = v;
             } else if (v != 0.f) {
                 int tr = tg < 0 ? -tg : tg;                        // reflect
@@ -810,10 +886,10 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
             case 1024:
                 if (gmag && !gre && hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
                     constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel),
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<false>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e));
-                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
+                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel<false>, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
                     PSND_CHECK_LAUNCH("stft_bwd(n1024, mag)");
                     return PSND_OK;
                 }
@@ -862,7 +938,17 @@ extern "C" int psnd_istft(const float *mag, const float *phase, int64_t N, int64
         switch (n_fft) {
             case 256: return launch_istft<16, 8>(p, s);
             case 512: return launch_istft<16, 16>(p, s);
-            case 1024: return launch_istft<32, 16>(p, s);
+            case 1024:
+                if (hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
+                    constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: set LDS size: %s", hipGetErrorString(e));
+                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel<true>, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
+                    PSND_CHECK_LAUNCH("istft(n1024)");
+                    return PSND_OK;
+                }
+                return launch_istft<32, 16>(p, s);
             case 2048: return launch_istft<32, 32>(p, s);
         }
     }
