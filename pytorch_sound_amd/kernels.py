@@ -314,12 +314,16 @@ class GroupNorm1(torch.autograd.Function):
 
 class SoftmaxKeys(torch.autograd.Function):
     """att = softmax over keys (dim 1) of scale * scores, key-padded rows -> -inf before, query-padded columns -> 0
-    after (modules.py:66-76).  Works in place on a fresh copy of `scores`."""
+    after (modules.py:66-76).  In place on `scores` when it is a non-leaf temporary (the bmm output), else on a copy."""
 
     @staticmethod
     def forward(ctx, scores, mask_u8, scale):
         _need_cuda(scores, 'scores')
-        att = scores.contiguous().clone()
+        if scores.is_contiguous() and not (scores.is_leaf and scores.requires_grad):
+            att = scores                               # the bmm output is a temporary: softmax in place, no extra pass
+            ctx.mark_dirty(scores)
+        else:
+            att = scores.contiguous().clone()
         B, T, _ = att.shape
         with torch.cuda.device(att.device):
             check(lib().psnd_softmax_keys_fwd(ptr(att), ptr(mask_u8), B, T, float(scale), stream_ptr(att.device)),
