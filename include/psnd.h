@@ -174,6 +174,28 @@ int psnd_softmax_keys_fwd(float *scores, const uint8_t *mask, int64_t B, int64_t
 int psnd_softmax_keys_bwd(const float *att, const float *gatt, int64_t B, int64_t T, float scale, float *gscores,
                           void *stream);
 
+/* ---- models/sound.py: PreEmphasis (:66-81) and the reductions of multi_stft_loss (:106-133) -----------------
+ *  psnd_preemphasis_fwd: y[n][t] = x[n][t] - coef * x[n][t-1] with x[n][-1] := x[n][1] (one reflect-padded sample,
+ *      conv1d with the flipped filter [-coef, 1]);  x, y : (N, T) fp32 (the module's (N,1,T) is the same memory).
+ *  psnd_preemphasis_bwd: the adjoint, gx fully overwritten.
+ *  multi_stft_loss on magnitudes p, t : (N, K, F) fp32 per resolution (KF = K*F elements per clip):
+ *  psnd_stft_loss_blocks(KF): workgroups per clip B of the partial pass (host helper).
+ *  psnd_stft_loss_partial: part[(n*B + b)*3 + {0,1,2}] = sum (t-p)^2, sum t^2, sum |log(t+eps) - log(p+eps)| over
+ *      chunk b of clip n (double; every entry written, no atomics).
+ *  psnd_stft_loss_final: combines L <= 8 resolutions (host arrays parts[L] of device pointers, KF[L]) into
+ *      out3 = {loss, sc_loss, mag_loss} (sound.py:119-133) and norms[(i*N + n)*2 + {0,1}] = ||t-p||_F, ||t||_F.
+ *  psnd_stft_loss_bwd: one resolution; norms = that resolution's N pairs; g3 = DEVICE pointer to the upstream gradient
+ *      of (loss, sc_loss, mag_loss); gp / gt (either may be NULL) = gradient wrt p / t, fully overwritten. */
+int psnd_preemphasis_fwd(const float *x, int64_t N, int64_t T, float coef, float *y, void *stream);
+int psnd_preemphasis_bwd(const float *gy, int64_t N, int64_t T, float coef, float *gx, void *stream);
+int64_t psnd_stft_loss_blocks(int64_t KF);
+int psnd_stft_loss_partial(const float *p_mag, const float *t_mag, int64_t N, int64_t KF, float eps, double *part,
+                           void *stream);
+int psnd_stft_loss_final(const double *const *parts, const int64_t *KF, int L, int64_t N, float *norms, float *out3,
+                         void *stream);
+int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_t KF, float eps, const float *norms,
+                       const float *g3, int L, float *gp, float *gt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,12 @@ SIGNATURES = {
     'psnd_groupnorm1_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _P, _P, _P, _P, _P]),
     'psnd_softmax_keys_fwd': (_INT, [_P, _P, _I64, _I64, _F, _P]),
     'psnd_softmax_keys_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
+    'psnd_preemphasis_fwd': (_INT, [_P, _I64, _I64, _F, _P, _P]),
+    'psnd_preemphasis_bwd': (_INT, [_P, _I64, _I64, _F, _P, _P]),
+    'psnd_stft_loss_blocks': (_I64, [_I64]),
+    'psnd_stft_loss_partial': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
+    'psnd_stft_loss_final': (_INT, [_P, _P, _INT, _I64, _P, _P, _P]),
+    'psnd_stft_loss_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P, _INT, _P, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }

@@ -342,3 +342,98 @@ class SoftmaxKeys(torch.autograd.Function):
             check(lib().psnd_softmax_keys_bwd(ptr(att), ptr(gatt), B, T, ctx.scale, ptr(gs), stream_ptr(att.device)),
                   'psnd_softmax_keys_bwd')
         return gs, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# models/sound.py: PreEmphasis and multi_stft_loss
+# ---------------------------------------------------------------------------------------------
+class PreEmphasisFn(torch.autograd.Function):
+    """y[t] = x[t] - coef * x[t-1] with one reflect-padded sample on the left (sound.py:76-81)."""
+
+    @staticmethod
+    def forward(ctx, x, coef):
+        _need_cuda(x, 'input')
+        x = x.contiguous()
+        T = x.shape[-1]
+        N = x.numel() // max(T, 1)
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_preemphasis_fwd(ptr(x), N, T, float(coef), ptr(y), stream_ptr(x.device)), 'psnd_preemphasis_fwd')
+        ctx.coef = float(coef)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        T = gy.shape[-1]
+        N = gy.numel() // max(T, 1)
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            check(lib().psnd_preemphasis_bwd(ptr(gy), N, T, ctx.coef, ptr(gx), stream_ptr(gy.device)), 'psnd_preemphasis_bwd')
+        return gx, None
+
+
+class MultiStftLossFn(torch.autograd.Function):
+    """(loss, sc_loss, mag_loss) of sound.py:106-133 as ONE autograd node: per resolution two psnd_stft_fwd launches
+    (pred, target) and one partial-sum pass, one combining launch for all resolutions; backward: per resolution one
+    gradient pass over the magnitudes and psnd_stft_bwd, the waveform gradients of the resolutions added up.
+    `cfgs`: tuple of (n_fft, hop) per resolution, `plans`: their device plans (window centre-padded to n_fft)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, eps, cfgs, *plans):
+        import ctypes
+        _need_cuda(pred, 'pred')
+        _need_cuda(target, 'target')
+        if pred.shape != target.shape or pred.dim() != 2:
+            raise _lib.PsndError('multi_stft_loss: pred %s and target %s must be equal (N, T) shapes'
+                                 % (tuple(pred.shape), tuple(target.shape)))
+        pred, target = pred.contiguous(), target.contiguous()
+        N = pred.shape[0]
+        L = len(cfgs)
+        dev = pred.device
+        mags, parts, kfs = [], [], []
+        with torch.cuda.device(dev):
+            s = stream_ptr(dev)
+            for (n_fft, hop), plan in zip(cfgs, plans):
+                p = stft_forward(pred, n_fft, hop, plan)['mag']
+                t = stft_forward(target, n_fft, hop, plan)['mag']
+                KF = p.shape[1] * p.shape[2]
+                part = torch.empty((N, int(lib().psnd_stft_loss_blocks(KF)), 3), dtype=torch.float64, device=dev)
+                check(lib().psnd_stft_loss_partial(ptr(p), ptr(t), N, KF, float(eps), ptr(part), s), 'psnd_stft_loss_partial')
+                mags.append((p, t))
+                parts.append(part)
+                kfs.append(KF)
+            norms = torch.empty((L, N, 2), dtype=torch.float32, device=dev)
+            out = torch.empty(3, dtype=torch.float32, device=dev)
+            parr = (ctypes.c_void_p * L)(*[ptr(q) for q in parts])
+            karr = (ctypes.c_int64 * L)(*kfs)
+            check(lib().psnd_stft_loss_final(parr, karr, L, N, ptr(norms), ptr(out), s), 'psnd_stft_loss_final')
+        ctx.cfgs, ctx.eps, ctx.kfs = cfgs, float(eps), kfs
+        ctx.save_for_backward(pred, target, norms, *[m for pt in mags for m in pt], *plans)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        L = len(ctx.cfgs)
+        pred, target, norms = saved[:3]
+        mags, plans = saved[3:3 + 2 * L], saved[3 + 2 * L:]
+        N = pred.shape[0]
+        need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = g.contiguous().float()
+        gpred = gtarget = None
+        with torch.cuda.device(pred.device):
+            s = stream_ptr(pred.device)
+            for i, (n_fft, hop) in enumerate(ctx.cfgs):
+                p, t = mags[2 * i], mags[2 * i + 1]
+                gp = torch.empty_like(p) if need_p else None
+                gt = torch.empty_like(t) if need_t else None
+                check(lib().psnd_stft_loss_bwd(ptr(p), ptr(t), N, ctx.kfs[i], ctx.eps, ptr(norms[i]), ptr(g), L, ptr(gp), ptr(gt), s),
+                      'psnd_stft_loss_bwd')
+                if need_p:
+                    gw = stft_backward(pred, n_fft, hop, plans[i], gmag=gp)
+                    gpred = gw if gpred is None else gpred.add_(gw)
+                if need_t:
+                    gw = stft_backward(target, n_fft, hop, plans[i], gmag=gt)
+                    gtarget = gw if gtarget is None else gtarget.add_(gw)
+        return (gpred, gtarget, None, None) + (None,) * L

@@ -418,10 +418,74 @@ def gen_trainer():
     np.savez_compressed(os.path.join(OUT, 'trainer.npz'), **out)
 
 
+def gen_sound():
+    """f2: models/sound.py PreEmphasis + multi_stft_loss, run from the imported reference on CPU.
+    Environment stubs (this tool only): `.cuda()` is the identity (install_stubs) and torch.stft gets the torch-1.x
+    default the reference was written against (no return_complex argument -> real view of the complex result)."""
+    import contextlib
+    real_stft = torch.stft
+
+    def stft_1x(*a, **k):
+        if 'return_complex' in k:
+            return real_stft(*a, **k)
+        return torch.view_as_real(real_stft(*a, return_complex=True, **k))
+
+    torch.stft = stft_1x
+    try:
+        from pytorch_sound.models import sound as rs
+        out = {}
+        x = torch.from_numpy(seeded_wav(500, 3, 2048)).unsqueeze(1).requires_grad_(True)
+        pe = rs.PreEmphasis(0.97)
+        y = pe(x)
+        gy = torch.from_numpy(np.random.RandomState(501).randn(*y.shape).astype(np.float32))
+        (y * gy).sum().backward()
+        out['preemph/x'] = x.detach().numpy()
+        out['preemph/y'] = y.detach().numpy()
+        out['preemph/gy'] = gy.numpy()
+        out['preemph/gx'] = x.grad.numpy()
+        # VolNormConv forward / reverse and the tanh-RNN InversePreEmphasis (host-side / inference-side utilities)
+        vn = rs.VolNormConv(400, 160, -11.5)
+        w = torch.from_numpy(seeded_wav(506, 1, 4000))
+        nw = vn.forward(w)
+        out['volnorm/wav'] = w.numpy()
+        out['volnorm/norm'] = nw.numpy()
+        out['volnorm/std'] = vn.std_buffer.numpy()
+        out['volnorm/reverse'] = vn.reverse(nw).numpy()
+        ipe = rs.InversePreEmphasis(0.97)
+        with torch.no_grad():
+            out['ipreemph/y'] = ipe(y.detach()[:, :, :256]).numpy()
+        # the three MelGAN / Parallel-WaveGAN style resolutions (n_fft, window size, hop size)
+        params = [(1024, 600, 120), (2048, 1200, 240), (512, 240, 50)]
+        target = torch.from_numpy(seeded_wav(502, 3, 8192))
+        pred = (target + 0.05 * torch.from_numpy(seeded_wav(503, 3, 8192))).requires_grad_(True)
+        with contextlib.redirect_stdout(io.StringIO()) as so:
+            loss, sc, mag = rs.multi_stft_loss(pred, target, params)
+        loss.backward()
+        out['msl/params'] = np.asarray(params, np.int64)
+        out['msl/pred'] = pred.detach().numpy()
+        out['msl/target'] = target.numpy()
+        out['msl/loss'] = np.asarray([float(loss), float(sc), float(mag)], np.float64)
+        out['msl/gpred'] = pred.grad.numpy()
+        out['msl/stdout'] = np.asarray(so.getvalue())
+        # a second, small case: one resolution, batch 1, eps given
+        t2 = torch.from_numpy(seeded_wav(504, 1, 1000))
+        p2 = (0.5 * t2 + 0.1 * torch.from_numpy(seeded_wav(505, 1, 1000))).requires_grad_(True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            l2, s2, m2 = rs.multi_stft_loss(p2, t2, [(256, 200, 64)], eps=1e-3)
+        l2.backward()
+        out['msl1/pred'] = p2.detach().numpy()
+        out['msl1/target'] = t2.numpy()
+        out['msl1/loss'] = np.asarray([float(l2), float(s2), float(m2)], np.float64)
+        out['msl1/gpred'] = p2.grad.numpy()
+    finally:
+        torch.stft = real_stft
+    np.savez_compressed(os.path.join(OUT, 'sound.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer']
+    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound']
     for w in which:
         print('generating', w, flush=True)
         globals()['gen_' + w]()
