@@ -196,6 +196,13 @@ int psnd_stft_loss_final(const double *const *parts, const int64_t *KF, int L, i
 int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_t KF, float eps, const float *norms,
                        const float *g3, int L, float *gp, float *gt, void *stream);
 
+/* ---- data/dataset.py:196-250, SpeechDataLoader.pad_collate_fn on the audio column, device side --------------------
+ *  flat : the batch's clips back to back (device, fp32); offs[n], lens[n] : start / length of clip n in flat (device
+ *  int64).  out : (N, Tmax) fp32 = clip n zero-padded (or cut) to Tmax;  mask (may be NULL) : (N, Tmax) fp32, 1 on valid
+ *  samples and 0 on padding - the reference's np.ones_like(item) after zero padding (dataset.py:70-71, 88-89). */
+int psnd_pad_collate(const float *flat, const int64_t *offs, const int64_t *lens, int64_t N, int64_t Tmax, float *out,
+                     float *mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

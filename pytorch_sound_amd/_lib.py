@@ -51,6 +51,7 @@ SIGNATURES = {
     'psnd_stft_loss_partial': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
     'psnd_stft_loss_final': (_INT, [_P, _P, _INT, _I64, _P, _P, _P]),
     'psnd_stft_loss_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P, _INT, _P, _P, _P]),
+    'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }

@@ -63,6 +63,10 @@ def install_stubs():
 
     mod('tensorboardX', SummaryWriter=_Writer)
     mod('unidecode', unidecode=lambda s: s)
+    # imported at module level by pytorch_sound/utils/sound.py (never called by the fixtures)
+    mod('pretty_midi')
+    mod('pyworld')
+    mod('pysndfx', AudioEffectsChain=object)
 
     class _Engine:
         def number_to_words(self, *a, **k):
@@ -482,10 +486,83 @@ def gen_sound():
     np.savez_compressed(os.path.join(OUT, 'sound.npz'), **out)
 
 
+def gen_data():
+    """f3: data/dataset.py - pad_collate_fn, BucketRandomBatchSampler (seeded np.random), SpeechDataset crops."""
+    import pandas as pd
+    from pytorch_sound.data import dataset as rd
+    from pytorch_sound.data.meta import MetaFrame, MetaType
+    out = {}
+    rs = np.random.RandomState(900)
+    lens = [700, 1000, 333, 1000, 512]
+    batch = [[rs.randn(n).astype(np.float32), rs.randn(80, n // 100).astype(np.float32), int(i * 3),
+              rs.randn(4).astype(np.float32), rs.randn(2, 3, 1 + i).astype(np.float32)] for i, n in enumerate(lens)]
+    for i, item in enumerate(batch):
+        for j, x in enumerate(item):
+            out['collate/in/%d/%d' % (i, j)] = np.asarray(x)
+    res = rd.SpeechDataLoader.pad_collate_fn(batch)
+    for j, x in enumerate(res):
+        out['collate/out/%d' % j] = x.numpy()
+    one = rd.SpeechDataLoader.pad_collate_fn(batch[:1])
+    for j, x in enumerate(one):
+        out['collate/one/%d' % j] = x.numpy()
+
+    class _Src:
+        def __len__(self):
+            return 1000
+
+    for tag, skip in (('all', False), ('skip', True)):
+        np.random.seed(7)
+        smp = rd.BucketRandomBatchSampler(_Src(), n_buckets=5, batch_size=16, skip_last_bucket=skip)
+        out['sampler/%s/batches' % tag] = np.asarray(list(smp), np.int64)
+        out['sampler/%s/len' % tag] = np.asarray(len(smp))
+        out['sampler/%s/bucket_size' % tag] = np.asarray(smp.bucket_size)
+
+    with tempfile.TemporaryDirectory() as d:
+        rows = []
+        for i, n in enumerate([3000, 2500, 4000, 2048]):
+            a, b = os.path.join(d, 'a%d.npy' % i), os.path.join(d, 'b%d.npy' % i)
+            np.save(a, rs.randn(n).astype(np.float32))
+            np.save(b, rs.randn(n).astype(np.float32))
+            rows.append({'mix': a, 'voice': b, 'speaker': i % 2, 'note': 'x'})
+            out['dataset/mix/%d' % i] = np.load(a)
+            out['dataset/voice/%d' % i] = np.load(b)
+
+        class Meta(MetaFrame):
+            sr = 22050
+
+            def __init__(self):
+                self._meta = pd.DataFrame(rows)
+
+            @property
+            def columns(self):
+                return [(MetaType.AUDIO, 'mix'), (MetaType.AUDIO, 'voice'), (MetaType.SCALAR, 'speaker'), (MetaType.META, 'note')]
+
+            @property
+            def meta(self):
+                return self._meta
+
+            def make_meta(self):
+                pass
+
+            def __len__(self):
+                return len(self._meta)
+
+        for tag, kw in (('crop', dict(fix_len=2048, audio_mask=True)),
+                        ('shuffle', dict(fix_len=1024, fix_shuffle=True, extra_features=[('mix', lambda x: np.abs(x).astype(np.float32))])),
+                        ('whole', dict())):
+            np.random.seed(11)
+            ds = rd.SpeechDataset(Meta(), **kw)
+            for i in range(len(ds)):
+                for j, x in enumerate(ds[i]):
+                    out['dataset/%s/%d/%d' % (tag, i, j)] = np.asarray(x)
+            out['dataset/%s/nfields' % tag] = np.asarray(len(ds[0]))
+    np.savez_compressed(os.path.join(OUT, 'data.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound']
+    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data']
     for w in which:
         print('generating', w, flush=True)
         globals()['gen_' + w]()
