@@ -116,7 +116,10 @@ def gpu_bench(args):
     N = BATCH_PER_GPU
 
     Trainer, model = build_step(device, amp=True)
-    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True)
+    from pytorch_sound_amd import optim as poptim
+    # torch.optim.Adam semantics as one HIP launch (psnd_adam_step); --torch-adam keeps torch's fused multi-tensor kernel
+    opt = (torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True) if args.torch_adam
+           else poptim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99)))
     pool = [synth_batch(1234 + rank + 1000 * i, N, T, device) for i in range(args.pool)]
     save_dir = tempfile.mkdtemp(prefix='psnd_bench_')
     huge = 10 ** 9
@@ -289,6 +292,7 @@ def main():
     ap.add_argument('--pool', type=int, default=8, help='distinct synthetic batches resident in HBM')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
+    ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')

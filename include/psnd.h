@@ -203,6 +203,22 @@ int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_
 int psnd_pad_collate(const float *flat, const int64_t *offs, const int64_t *lens, int64_t N, int64_t Tmax, float *out,
                      float *mask, void *stream);
 
+/* ---- the optimizer step of Trainer.train (trainer.py:215-216) for Adam / AdamW: one launch over all tensors ---------
+ *  table : n_tensors records {float *p; const float *g; float *m; float *v; float *step; int64 numel} (device,
+ *      psnd_adam_table_bytes() each); the work list: workgroup b updates elements [chunk_off[b], chunk_off[b] +
+ *      psnd_adam_chunk()) of tensor chunk_tensor[b] (device arrays, built once per parameter set by the caller).
+ *  torch.optim.Adam semantics (amsgrad / maximize off): step += 1; m, v moments; p -= lr / (1 - b1^step) * m /
+ *      (sqrt(v) / sqrt(1 - b2^step) + eps); weight_decay as L2 (decoupled = 0) or AdamW (decoupled = 1).
+ *      Hyper-parameters are doubles: 1 - beta and the bias corrections are formed in double, as torch does.
+ *  found_inf (device, may be NULL): non-zero skips the whole update including the step count (AMP protocol);
+ *  grad_scale (device, may be NULL): gradients are divided by it;  corr : 2 * n_tensors floats of device scratch (the
+ *      bias corrections, formed in double by a first tiny launch that also advances the step counts). */
+int64_t psnd_adam_chunk(void);
+int64_t psnd_adam_table_bytes(void);
+int psnd_adam_step(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
+                   const float *found_inf, const float *grad_scale, float *corr, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

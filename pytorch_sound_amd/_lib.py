@@ -18,6 +18,7 @@ _P = _c.c_void_p
 _I64 = _c.c_int64
 _INT = _c.c_int
 _F = _c.c_float
+_D = _c.c_double
 
 # name -> (restype, argtypes); mirrors include/psnd.h one to one
 SIGNATURES = {
@@ -52,6 +53,9 @@ SIGNATURES = {
     'psnd_stft_loss_final': (_INT, [_P, _P, _INT, _I64, _P, _P, _P]),
     'psnd_stft_loss_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P, _INT, _P, _P, _P]),
     'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
+    'psnd_adam_chunk': (_I64, []),
+    'psnd_adam_table_bytes': (_I64, []),
+    'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }

@@ -1,0 +1,121 @@
+"""Adam / AdamW for ``Trainer`` (pytorch_sound/trainer.py:215-216 calls ``optimizer.step()`` on whatever optimizer the
+recipe built - ``torch.optim.Adam`` in the reference's recipes) as ONE HIP launch over every parameter tensor
+(``psnd_adam_step``), with torch's numerics, state layout (``state[p] = {'step', 'exp_avg', 'exp_avg_sq'}`` - state
+dicts load into ``torch.optim.Adam`` and back) and the AMP ``found_inf`` / ``grad_scale`` protocol, which is what lets the
+Trainer skip a NaN step on the device.  fp32 CUDA parameters only; no CPU fallback.
+"""
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+
+
+class Adam(torch.optim.Optimizer):
+    _step_supports_amp_scaling = True           # honours optimizer.found_inf / optimizer.grad_scale on the device
+    _decoupled = False                          # True: AdamW (weight decay applied to the parameter, not the gradient)
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError('amsgrad is not implemented by the HIP optimizer kernel')
+        if not 0.0 <= lr:
+            raise ValueError('Invalid learning rate: {}'.format(lr))
+        if not 0.0 <= eps:
+            raise ValueError('Invalid epsilon value: {}'.format(eps))
+        if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError('Invalid beta parameters: {}'.format(betas))
+        if not 0.0 <= weight_decay:
+            raise ValueError('Invalid weight_decay value: {}'.format(weight_decay))
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False, fused=True))
+        self._plans = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}                        # state tensors were replaced: cached device pointers are stale
+
+    # ---- launch plan: parameter table + work list; rebuilt when the set of tensors changes, the table re-uploaded when a
+    # gradient lives at a new address (eager steps usually get the same blocks back from the caching allocator, a replayed
+    # hipGraph always does) ----
+    def _build_plan(self, params):
+        device = params[0].device
+        chunk = int(lib().psnd_adam_chunk())
+        which, off, static = [], [], []
+        for i, p in enumerate(params):
+            if not p.is_cuda or p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                raise _lib.PsndError('pytorch_sound_amd.optim: the parameters of a group must be contiguous fp32 tensors on one HIP '
+                                     'device (got %s %s on %s)' % (p.dtype, tuple(p.shape), p.device))
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.zeros((), dtype=torch.float32, device=device)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            else:
+                if not (torch.is_tensor(st['step']) and st['step'].device == device and st['step'].dtype == torch.float32):
+                    # a state dict saved by a non-fused torch optimizer keeps the step count on the host
+                    st['step'] = torch.as_tensor(float(st['step']), dtype=torch.float32, device=device)
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    st[k] = st[k].to(device=device, dtype=torch.float32).contiguous()
+            static.append((p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['step'].data_ptr(), p.numel()))
+            starts = np.arange(0, p.numel(), chunk, dtype=np.int64)
+            which.append(np.full(len(starts), i, dtype=np.int32))
+            off.append(starts)
+        return {'device': device, 'static': static, 'gptrs': None, 'table': None, 'grads': None,
+                'chunk_tensor': torch.from_numpy(np.concatenate(which)).to(device),
+                'chunk_off': torch.from_numpy(np.concatenate(off)).to(device),
+                'corr': torch.empty(2 * len(params), dtype=torch.float32, device=device)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        found_inf = getattr(self, 'found_inf', None)
+        grad_scale = getattr(self, 'grad_scale', None)
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group['params'] if p.grad is not None]
+            if not params:
+                continue
+            key = (gi, tuple(map(id, params)))
+            plan = self._plans.get(key)
+            if plan is None:
+                if len(self._plans) > 16:
+                    self._plans.clear()
+                plan = self._plans[key] = self._build_plan(params)
+            device = plan['device']
+            gptrs = tuple(p.grad.data_ptr() for p in params)
+            if gptrs != plan['gptrs']:
+                grads = []
+                for p in params:
+                    g = p.grad
+                    if g.is_sparse:
+                        raise RuntimeError('sparse gradients are not supported')
+                    if g.device != device:
+                        raise _lib.PsndError('gradient on %s, parameter on %s' % (g.device, device))
+                    grads.append(g if g.is_contiguous() and g.dtype == torch.float32 else g.contiguous().float())
+                raw = b''.join(struct.pack('<5Qq', s[0], g.data_ptr(), s[1], s[2], s[3], s[4]) for s, g in zip(plan['static'], grads))
+                assert len(raw) == len(params) * int(lib().psnd_adam_table_bytes())
+                plan['table'] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+                # converted copies (non-contiguous / non-fp32 gradients) are not stable addresses: look again next step
+                stable = all(g is p.grad for g, p in zip(grads, params))
+                plan['gptrs'] = gptrs if stable else None
+                plan['grads'] = None if stable else grads
+            b1, b2 = group['betas']
+            fi = found_inf.to(device=device, dtype=torch.float32) if found_inf is not None else None
+            gs = grad_scale.to(device=device, dtype=torch.float32) if grad_scale is not None else None
+            with torch.cuda.device(device):
+                check(lib().psnd_adam_step(ptr(plan['table']), len(params), ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
+                                           plan['chunk_off'].numel(), float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                           float(group['weight_decay']), int(self._decoupled), ptr(fi), ptr(gs), ptr(plan['corr']),
+                                           stream_ptr(device)), 'psnd_adam_step')
+        return loss
+
+
+class AdamW(Adam):
+    _decoupled = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
