@@ -152,6 +152,12 @@ int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout
  *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written
  *   (zero them once when allocating). */
 int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
+/* backward of one conv in ONE launch: gx = input gradient (Ca channels, via the transposed pack wb, taps mirrored) and the
+ * partial weight-gradient slabs gw_part / gbias_part (as psnd_conv1d_cl_wgrad), both from g = G1 + G2 * leaky'(GM); g_out (may
+ * be NULL) receives the combined g for the residual branch.  Falls back to the two separate launches when G2 is NULL. */
+int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
+                       int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
+                       float *gw_part, float *gbias_part, void *stream);
 int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);

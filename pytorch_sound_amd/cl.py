@@ -191,6 +191,38 @@ class FusedConvCL(torch.autograd.Function):
         need_gout = ctx.has_res and (g_act is not None)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
+        g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
+        if side is None:
+            # input gradient + weight-gradient slabs in ONE launch (conv_bwd_pair_kernel: both read the same incoming gradient,
+            # each alone only part-fills the chip), then the weight-norm backward over the slabs
+            gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
+            gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
+            gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+            gv = torch.empty_like(v32)
+            gg = torch.empty_like(g32)
+            gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+            with torch.cuda.device(dev):
+                check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(wb), ptr(xa), shape.N,
+                                               shape.Lp, shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(gw), ptr(gbp),
+                                               stream_ptr(dev)), 'psnd_conv1d_cl_bwd')
+                check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
+                                                  ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
+        else:
+            gx, gv, gg, gb = FusedConvCL._backward_two_streams(ctx, g_raw, g_act, am, g_out, S, main, side)
+        g_res = None
+        if ctx.has_res:
+            g_res = g_out if need_gout else g_raw
+        g_bias = gb[:Cout] if ctx.has_bias else None
+        return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None, None
+
+
+    @staticmethod
+    def _backward_two_streams(ctx, g_raw, g_act, am, g_out, S, main, side):
+        """PSND_CL_SIDE_STREAM=1: weight-gradient branch on a second stream (kept for A/B measurements, see above)"""
+        xa, v32, g32, wb, act = ctx.saved_tensors
+        shape, dil, k, pad = ctx.shape, ctx.dil, ctx.k, ctx.pad
+        Cout, Cin, Ca, Cb = ctx.dims
+        dev = xa.device
         if side is not None:
             side.wait_stream(main)                          # the incoming gradients are complete on the main stream
         with torch.cuda.stream(side if side is not None else main):
@@ -215,14 +247,9 @@ class FusedConvCL(torch.autograd.Function):
             _join_side_at_end_of_backward(dev, side)
         # (a) input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) is formed on load
         #     and written back for the residual branch when both parts exist
-        g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
         gx, _ = _launch_conv(g_raw, g_act, am, ctx.act_slope, wb, None, None, None, shape, Cb, Ca, k, pad, -dil, 1.0, 1.0,
                              True, False, g_out)
-        g_res = None
-        if ctx.has_res:
-            g_res = g_out if need_gout else g_raw
-        g_bias = gb[:Cout] if ctx.has_bias else None
-        return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None, None
+        return gx, gv, gg, gb
 
 
 def conv_transpose_cl(xa, up, shape, act_slope=0.1):

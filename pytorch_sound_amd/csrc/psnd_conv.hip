@@ -55,7 +55,7 @@ struct ConvParams {
 #define PSND_CSTAMP(i_)                                                                                         \
     do {                                                                                                        \
         if ((threadIdx.x & 63) == 0 && p.trace)                                                                 \
-            p.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+            p.trace[(tblk * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define PSND_CSTAMP(i_)
@@ -100,16 +100,15 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 // fetch), LDS is double buffered (one barrier per stage).
 //   KT: taps the register ring is sized for (k <= KT);  D: stages in flight;  COMBINE: A = A + A2 * leaky'(AM)
 template <int KT, int D, bool COMBINE, int NBUF>
-__global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
     constexpr int NB = BN * PCS / 256;     // weight pieces per thread per tap (= 1)
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem_c[];
     const int rowsA = BM + 2 * p.hm;
     const int buf_elems = (rowsA + p.k * BN) * RS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long r0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const long long r0 = (long long)bx * BM;
+    const int n0 = by * BN;
     const int li = lane & 31, kg = lane >> 5;
 
     f32x16 acc;
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     // the combined operand is written back by the first column block only; a null pointer gives a zero-sized buffer,
     // lanes that must not store use the OOB offset: the store instruction itself is unconditional (see above)
     const __amdgpu_buffer_rsrc_t rG = make_uniform_rsrc(p.a_eff_out ? p.a_eff_out : p.W,
-                                                        (COMBINE && p.a_eff_out && blockIdx.y == 0) ? (int)a_bytes : 0);
+                                                        (COMBINE && p.a_eff_out && by == 0) ? (int)a_bytes : 0);
     const bool haveA = p.A != nullptr;
     unsigned aoff[NA];
 #pragma unroll
@@ -314,6 +313,12 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
 #endif
 }
 
+template <int KT, int D, bool COMBINE, int NBUF>
+__global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
+    conv_cl_body<KT, D, COMBINE, NBUF>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
 // to_cl: optional pre-op  0: none, 1: log1p(x)
 __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out, int N, int C, int T, int Lp, int HP, int Cp,
@@ -382,7 +387,7 @@ struct WgradParams {
 #define PSND_WSTAMP(i_)                                                                                         \
     do {                                                                                                        \
         if ((threadIdx.x & 63) == 0 && p.trace)                                                                 \
-            p.trace[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
+            p.trace[(tblk * 4 + (threadIdx.x >> 6)) * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define PSND_WSTAMP(i_)
@@ -401,17 +406,17 @@ constexpr int WD = PSND_WD;
 #ifndef PSND_WGRAD_WAVES
 #define PSND_WGRAD_WAVES 2
 #endif
-__global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) bf16_t sT[2 * (1 + WKT) * 64 * RS];
+constexpr int kWgradLdsBytes = 2 * (1 + WKT) * 64 * RS * (int)sizeof(bf16_t);
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
-    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
-    const int ntg = (p.k + WKT - 1) / WKT;               // tap groups: one per workgroup (blockIdx.z = split * ntg + group)
-    const int split = blockIdx.z / ntg, tgrp = blockIdx.z - split * ntg;
+    const int co0 = bx * 64, ci0 = by * 64;
+    const int ntg = (p.k + WKT - 1) / WKT;               // tap groups: one per workgroup (bz = split * ntg + group)
+    const int split = bz / ntg, tgrp = bz - split * ntg;
     const long long rs = (long long)split * p.rows_per_split;
     const long long re = min(rs + p.rows_per_split, p.R);
     const int rr = tid & 31, cg = tid >> 5;          // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
-    const bool do_bias = (blockIdx.y == 0) && tgrp == 0;
+    const bool do_bias = (by == 0) && tgrp == 0;
     const bool comb = p.G2 != nullptr;
     const bool gok = co0 + 8 * cg < p.Cb, xok = ci0 + 8 * cg < p.Ca;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -556,6 +561,28 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
         }
     }
 }
+__global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
+    conv_wgrad_body(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn, ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// The two independent kernels of a conv's backward - weight gradient (partial slabs) and input gradient (with the on-load
+// gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
+// at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
+// role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
+template <int KT, int D, int NBUF>
+__global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
+    const int b = blockIdx.x;
+    if (b < nw) {
+        const int bx = b % wgx, r = b / wgx;
+        conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
+    } else {
+        const int c = b - nw;
+        conv_cl_body<KT, D, true, NBUF>(pc, c % cgx, c / cgx, smem_dyn, 0);
+    }
+}
+
 
 // ---- weight prep: weight norm (dim 0) + both bf16 packs + padded bias, one block per output channel ------
 //   w = g * v / ||v|| ; wf[j][co][ci] (forward), wb[j][ci][co] (input gradient) ; pads are zero-filled by the caller
@@ -777,8 +804,11 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
 
 static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * ((k + WKT - 1) / WKT);   // tap groups are workgroups too
-    int64_t target = 256;                       // ~one workgroup per CU: 512 blocks make this kernel 7 % faster (15.6 vs 16.8 us)
-                                                // but double the slabs the weight-norm backward has to add up (step 2.31 vs 2.13 ms)
+    // workgroups of the weight-gradient role.  Measured on the config-2 step with the paired backward launch (256 CUs, 2
+    // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
+    // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
+    // second partial wave of workgroups)
+    int64_t target = 192;
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
@@ -816,9 +846,76 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)(splits * ((k + WKT - 1) / WKT))), dim3(256), 0,
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tx, ty, (unsigned)(splits * ((k + WKT - 1) / WKT))), dim3(256), kWgradLdsBytes,
                        static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("conv1d_cl_wgrad");
+    return PSND_OK;
+}
+
+// Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
+// taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Without a combined operand (G2 == NULL)
+// or outside the paired instances the two kernels are enqueued one after the other, same results.
+extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
+                                  int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
+                                  float *gw_part, float *gbias_part, void *stream) {
+    static const bool no_pair = getenv("PSND_NO_BWD_PAIR") != nullptr;
+    int hm = 0;
+    for (int j = 0; j < k; ++j) {
+        const int o = pad - j * dil;
+        hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
+    }
+    const size_t buf = sizeof(bf16_t) * 40 * ((size_t)(BM + 2 * hm) + (size_t)k * BN);
+    const bool pairable = !no_pair && G2 && GM && gx && wb && xa && gw_part && k >= 1 && k <= 16 && hm <= 25 && hm <= HP && N > 0 &&
+                          2 * buf <= 150 * 1024 && Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
+                          (size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 < ((size_t)1 << 32) && (size_t)k * Cb * Ca * 2 < ((size_t)1 << 32);
+    if (!pairable) {
+        int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
+        if (rc != PSND_OK) return rc;
+        return psnd_conv1d_cl(G1, G2, GM, g2_slope, wb, nullptr, nullptr, nullptr, N, Lp, L, HP, Cb, Ca, k, pad, -dil, 1.f, 1.f, gx, nullptr,
+                              g_out, stream);
+    }
+    // input-gradient role: a conv from Cb to Ca channels
+    ConvParams pc;
+    pc.A = static_cast<const bf16_t *>(G1), pc.A2 = static_cast<const bf16_t *>(G2), pc.AM = static_cast<const bf16_t *>(GM);
+    pc.a2_slope = g2_slope;
+    pc.W = static_cast<const bf16_t *>(wb), pc.bias = nullptr, pc.res = nullptr, pc.mask_src = nullptr;
+    pc.out_raw = static_cast<bf16_t *>(gx), pc.out_act = nullptr, pc.a_eff_out = static_cast<bf16_t *>(g_out);
+    pc.R = N * (int64_t)Lp, pc.Lp = Lp, pc.L = L, pc.HP = HP, pc.Ca = Cb, pc.Cb = Ca, pc.k = k, pc.off0 = pad, pc.dstep = -dil, pc.hm = hm;
+    pc.act_slope = 1.f, pc.mask_slope = 1.f;
+    // weight-gradient role
+    WgradParams pw;
+    pw.G1 = pc.A, pw.G2 = pc.A2, pw.GM = pc.AM;
+    pw.xa = static_cast<const bf16_t *>(xa), pw.gw = gw_part, pw.gbias = gbias_part, pw.g_out = nullptr;
+    pw.R = pc.R, pw.Ca = Ca, pw.Cb = Cb, pw.k = k, pw.off0 = -pad, pw.dstep = dil, pw.g2_slope = g2_slope;
+    int64_t rps;
+    const int splits = wgrad_splits(pw.R, Ca, Cb, k, &rps);
+    pw.rows_per_split = (int)rps;
+#ifdef PSND_TRACE
+    pc.trace = nullptr, pw.trace = nullptr;
+#endif
+    const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
+    const int cgx = (int)((pc.R + BM - 1) / BM), cgy = (Ca + BN - 1) / BN;
+    const int nw = wgx * wgy * wgz;
+    size_t lds = 2 * buf;
+    if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);
+    if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PSND_PAIR_LAUNCH(KT_, D_)                                                                                     \
+    do {                                                                                                              \
+        auto kern = conv_bwd_pair_kernel<KT_, D_, 2>;                                                                 \
+        if (lds > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl_bwd: set LDS size: %s", hipGetErrorString(e));      \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);    \
+    } while (0)
+    if (k <= 3) PSND_PAIR_LAUNCH(3, 4);
+    else if (k <= 7) PSND_PAIR_LAUNCH(7, 3);
+    else if (k <= 11) PSND_PAIR_LAUNCH(11, 2);
+    else PSND_PAIR_LAUNCH(16, 2);
+#undef PSND_PAIR_LAUNCH
+    PSND_CHECK_LAUNCH("conv1d_cl_bwd");
     return PSND_OK;
 }
 
