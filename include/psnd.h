@@ -152,6 +152,16 @@ int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout
  *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written
  *   (zero them once when allocating). */
 int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
+/* psnd_conv1d_wnorm_bwd for up to PSND_WNORM_MAX convs (e.g. the six of a ResBlock1) in one launch; descs is a HOST array,
+ * passed to the kernel by value (nothing is uploaded, the launch can be captured in a hipGraph). */
+#define PSND_WNORM_MAX 8
+typedef struct psnd_wnorm_desc {
+    const float *gw_part, *gbias_part;      /* slabs of psnd_conv1d_cl_wgrad / psnd_conv1d_cl_bwd (gbias_part may be NULL) */
+    const float *v, *g;                     /* weight_v (Cout,Cin,k), weight_g (Cout)                                      */
+    float *gv, *gg, *gbias;                 /* outputs (gbias may be NULL)                                                 */
+    int splits, Cout, Cin, k, Cb, Ca;
+} psnd_wnorm_desc;
+int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, void *stream);
 /* backward of one conv in ONE launch: gx = input gradient (Ca channels, via the transposed pack wb, taps mirrored) and the
  * partial weight-gradient slabs gw_part / gbias_part (as psnd_conv1d_cl_wgrad), both from g = G1 + G2 * leaky'(GM); g_out (may
  * be NULL) receives the combined g for the residual branch.  Falls back to the two separate launches when G2 is NULL. */

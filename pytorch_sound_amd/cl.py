@@ -314,10 +314,128 @@ def fused_conv(xa, conv, shape, res=None, want_raw=False, want_act=True, act_slo
                              act_slope, None if prep is None else prep[id(conv)])
 
 
+class ResBlockCL(torch.autograd.Function):
+    """A whole ResBlock1 (pairs conv1 -> conv2 + residual, hifi_gan.py:55-63) or ResBlock2 (conv + residual per conv, :84-88)
+    as ONE autograd node.  Same launches as a chain of FusedConvCL nodes in forward and for the paired input-/weight-gradient
+    kernels in backward, but the weight-norm backward of ALL the block's convs is one launch (psnd_conv1d_wnorm_bwd_multi)
+    instead of one per conv, and the gradient hand-over between the convs (raw / activated parts, residual branch) needs no
+    autograd bookkeeping.  params: (weight_v, weight_g, bias) per conv, flattened; packs: per conv (wf, wb, bp) or None."""
+
+    @staticmethod
+    def forward(ctx, x, xa, shape, pairs, dils, last_act_slope, want_raw, packs, *params):
+        _need(xa, torch.bfloat16)
+        dev = xa.device
+        n = len(dils)
+        steps, saved = [], []
+        cur_x, cur_xa, pending = x, xa, None
+        for i in range(n):
+            wv, wg, b = params[3 * i:3 * i + 3]
+            Cout, Cin, k = wv.shape
+            Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
+            if Ca != round_up(Cin, ALIGN_C) or Cb != Ca:
+                raise _lib.PsndError('CL residual block: %d -> %d channels on a %d-channel buffer' % (Cin, Cout, Ca))
+            dil = dils[i]
+            pad = (k * dil - dil) // 2
+            v32, g32 = wv.detach().contiguous(), wg.detach().contiguous()
+            if packs is not None and packs[i] is not None:
+                wf, wb, bp = packs[i]
+            else:
+                wf = torch.empty((k, Cb, Ca), dtype=torch.bfloat16, device=dev)
+                wb = torch.empty((k, Ca, Cb), dtype=torch.bfloat16, device=dev)
+                bp = torch.empty(Cb, dtype=torch.float32, device=dev)
+                b32 = None if b is None else b.detach().contiguous()
+                with torch.cuda.device(dev):
+                    check(lib().psnd_conv1d_prep(ptr(v32), ptr(g32), ptr(b32), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
+                                                 stream_ptr(dev)), 'psnd_conv1d_prep')
+            first_of_pair = pairs and i % 2 == 0
+            if first_of_pair:                              # conv1: activated output only, no residual
+                inp, slope, has_res = cur_xa, 0.1, False
+                _, act = _launch_conv(inp, None, None, 1.0, wf, bp, None, None, shape, Ca, Cb, k, -pad, dil, slope, 1.0, False, True)
+                pending = act
+            else:
+                last = i == n - 1
+                inp, slope, has_res = (pending if pairs else cur_xa), (last_act_slope if last else 0.1), True
+                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, cur_x, None, shape, Ca, Cb, k, -pad, dil, slope, 1.0,
+                                        (not last) or want_raw, True)
+                cur_x, cur_xa = raw, act
+            steps.append((Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, b is not None))
+            saved += [inp, act, wb, v32, g32]
+        ctx.steps, ctx.shape, ctx.pairs = steps, shape, pairs
+        ctx.save_for_backward(*saved)
+        return cur_x, cur_xa
+
+    @staticmethod
+    def backward(ctx, g_raw, g_act):
+        import struct
+        import ctypes
+        saved, steps, shape = ctx.saved_tensors, ctx.steps, ctx.shape
+        dev = saved[0].device
+        n = len(steps)
+        g_raw = None if g_raw is None else g_raw.contiguous()
+        g_act = None if g_act is None else g_act.contiguous()
+        grads = [None] * (3 * n)
+        descs, keep = [None] * n, []
+        res_pending = None
+        with torch.cuda.device(dev):
+            st = stream_ptr(dev)
+            for i in range(n - 1, -1, -1):
+                Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias = steps[i]
+                inp, act, wb, v32, g32 = saved[5 * i:5 * i + 5]
+                if g_raw is None and g_act is None:
+                    raise _lib.PsndError('CL residual block backward: no incoming gradient')
+                am = act if g_act is not None else None
+                need_gout = has_res and g_act is not None
+                S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb, k)
+                gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
+                gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
+                gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+                gv, gg = torch.empty_like(v32), torch.empty_like(g32)
+                gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+                g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
+                check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
+                                               shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(gw), ptr(gbp), st),
+                      'psnd_conv1d_cl_bwd')
+                descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
+                                       gg.data_ptr(), gb.data_ptr(), S, Cout, Cin, k, Cb, Ca)
+                keep += [gw, gbp]
+                grads[3 * i], grads[3 * i + 1] = gv, gg
+                grads[3 * i + 2] = gb[:Cout] if has_bias else None
+                g_res = (g_out if need_gout else g_raw) if has_res else None
+                if ctx.pairs:
+                    if has_res:                       # conv2 of a pair: its input is conv1's activated output
+                        res_pending, g_raw, g_act = g_res, None, gx
+                    else:                             # conv1: back on the residual stream
+                        g_raw, g_act = res_pending, gx
+                else:
+                    g_raw, g_act = g_res, gx
+            for j0 in range(0, n, 8):
+                chunk = descs[j0:j0 + 8]
+                buf = ctypes.create_string_buffer(b''.join(chunk))
+                check(lib().psnd_conv1d_wnorm_bwd_multi(buf, len(chunk), st), 'psnd_conv1d_wnorm_bwd_multi')
+        return (g_raw, g_act, None, None, None, None, None, None) + tuple(grads)
+
+
+def _block_node(convs, x, xa, shape, pairs, last_act_slope, want_raw, prep):
+    params = []
+    for c in convs:
+        params += [c.weight_v, c.weight_g, c.bias]
+    packs = None if prep is None else [prep[id(c)] for c in convs]
+    return ResBlockCL.apply(x, xa, shape, pairs, tuple(c.dilation for c in convs), last_act_slope, want_raw, packs, *params)
+
+
+def _use_block_node(convs, x):
+    import os
+    return (os.environ.get('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 8
+            and all(c.weight_v.shape[0] == c.weight_v.shape[1] for c in convs))
+
+
 def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):
     """ResBlock1 (hifi_gan.py:55-63) on CL buffers.  x: residual stream (raw), xa = leaky_relu(x, 0.1).
     Returns (x_out raw or None, leaky_relu(x_out, last_act_slope))."""
     n = len(block.convs1)
+    convs = [c for pair in zip(block.convs1, block.convs2) for c in pair]
+    if _use_block_node(convs, x):
+        return _block_node(convs, x, xa, shape, True, last_act_slope, want_raw, prep)
     for i, (c1, c2) in enumerate(zip(block.convs1, block.convs2)):
         _, ta = fused_conv(xa, c1, shape, None, False, True, 0.1, prep)
         last = i == n - 1
@@ -328,6 +446,8 @@ def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=No
 def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):
     """ResBlock2 (hifi_gan.py:84-88) on CL buffers: x = conv(leaky_relu(x)) + x per conv."""
     n = len(block.convs)
+    if _use_block_node(list(block.convs), x):
+        return _block_node(list(block.convs), x, xa, shape, False, last_act_slope, want_raw, prep)
     for i, c in enumerate(block.convs):
         last = i == n - 1
         x, xa = fused_conv(xa, c, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1, prep)

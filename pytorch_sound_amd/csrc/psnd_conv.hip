@@ -644,15 +644,14 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *de
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
 //   vhat = v/||v||, d = sum(gw * vhat), g_g = d, g_v = (g/||v||) * (gw - vhat * d)
 template <bool MANY>   // MANY: more than 16 slabs (narrow layers over long clips) - batches of 16; else one straight batch
-__global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
-                                                           const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
-                                                           float *gg, float *gbias, unsigned kmagic, unsigned cmagic) {
+__device__ __forceinline__ void conv_finish_body(const float *gw_part, const float *gb_part, int splits, const float *v,
+                                                 const float *g, int Cin, int k, int Cb, int Ca, float *gv,
+                                                 float *gg, float *gbias, unsigned kmagic, unsigned cmagic, const int co, float *s_gw,
+                                                 float *red) {
     // one workgroup (256 or 1024 threads) per output channel: sums the wgrad slabs (coalesced over ci), then the weight-norm
     // backward.  s_gw holds the summed gradients as [j][Cin + 1] (the +1 keeps the k-strided reads of the second loop on
     // different banks); i / k by multiplication with kmagic = ceil(2^32 / k) (exact for i < 2^32 / k).
-    extern __shared__ float s_gw[];
-    __shared__ float red[32];
-    const int co = blockIdx.x, n = Cin * k, BD = blockDim.x, tid = threadIdx.x;
+    const int n = Cin * k, BD = blockDim.x, tid = threadIdx.x;
     const int pitch = Cin + 1;
     const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
@@ -714,6 +713,34 @@ __global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part,
             gbias[co] = b;
         }
     }
+}
+
+template <bool MANY>
+__global__ __launch_bounds__(1024) void conv_finish_kernel(const float *gw_part, const float *gb_part, int splits, const float *v,
+                                                           const float *g, int Cout, int Cin, int k, int Cb, int Ca, float *gv,
+                                                           float *gg, float *gbias, unsigned kmagic, unsigned cmagic) {
+    extern __shared__ float s_gw[];
+    __shared__ float red[32];
+    conv_finish_body<MANY>(gw_part, gb_part, splits, v, g, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic, blockIdx.x, s_gw, red);
+}
+
+// the weight-norm backward of up to PSND_WNORM_MAX convs (a residual block's) in one launch; descriptors travel as kernel
+// arguments (no table upload: the launch is capturable in a hipGraph as it is)
+struct FinishArgs {
+    psnd_wnorm_desc d[PSND_WNORM_MAX];
+    unsigned kmagic[PSND_WNORM_MAX], cmagic[PSND_WNORM_MAX];
+    int blk0[PSND_WNORM_MAX + 1];
+    int n;
+};
+template <bool MANY>
+__global__ __launch_bounds__(1024) void conv_finish_multi_kernel(FinishArgs a) {
+    extern __shared__ float s_gw[];
+    __shared__ float red[32];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.blk0[i + 1]) ++i;          // uniform
+    const psnd_wnorm_desc &d = a.d[i];
+    conv_finish_body<MANY>(d.gw_part, d.gbias_part, d.splits, d.v, d.g, d.Cin, d.k, d.Cb, d.Ca, d.gv, d.gg, d.gbias, a.kmagic[i],
+                           a.cmagic[i], (int)blockIdx.x - a.blk0[i], s_gw, red);
 }
 
 }  // namespace
@@ -961,5 +988,36 @@ extern "C" int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_pa
         hipLaunchKernelGGL(conv_finish_kernel<false>, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part,
                            gbias_part, splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, void *stream) {
+    if (!descs || n < 1 || n > PSND_WNORM_MAX) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd_multi: %d descriptors (1..%d)", n, PSND_WNORM_MAX);
+    FinishArgs a;
+    a.n = n;
+    size_t lds = 0;
+    int total = 0, maxn = 0, maxsplits = 0;
+    for (int i = 0; i < n; ++i) {
+        const psnd_wnorm_desc &d = descs[i];
+        if (!d.gw_part || !d.v || !d.g || !d.gv || !d.gg || d.splits < 1 || d.Cout < 1 || d.Cin < 1 || d.k < 1)
+            PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd_multi: descriptor %d: null pointer / bad sizes", i);
+        const size_t l = sizeof(float) * (size_t)(d.Cin + 1) * d.k;
+        if (l > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd_multi: Cin*k=%d too large", d.Cin * d.k);
+        lds = l > lds ? l : lds;
+        a.d[i] = d;
+        a.kmagic[i] = (unsigned)((0x100000000ull + (unsigned)d.k - 1) / (unsigned)d.k);
+        a.cmagic[i] = (unsigned)((0x100000000ull + (unsigned)d.Cin - 1) / (unsigned)d.Cin);
+        a.blk0[i] = total;
+        total += d.Cout;
+        maxn = d.Cin * d.k > maxn ? d.Cin * d.k : maxn;
+        maxsplits = d.splits > maxsplits ? d.splits : maxsplits;
+    }
+    a.blk0[n] = total;
+    const int threads = maxn >= 2048 ? 1024 : 256;
+    if (maxsplits > 16)
+        hipLaunchKernelGGL(conv_finish_multi_kernel<true>, dim3(total), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(conv_finish_multi_kernel<false>, dim3(total), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
+    PSND_CHECK_LAUNCH("conv1d_wnorm_bwd_multi");
     return PSND_OK;
 }
