@@ -164,7 +164,7 @@ typedef struct psnd_wnorm_desc {
 int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, void *stream);
 /* backward of one conv in ONE launch: gx = input gradient (Ca channels, via the transposed pack wb, taps mirrored) and the
  * partial weight-gradient slabs gw_part / gbias_part (as psnd_conv1d_cl_wgrad), both from g = G1 + G2 * leaky'(GM); g_out (may
- * be NULL) receives the combined g for the residual branch.  Falls back to the two separate launches when G2 is NULL. */
+ * be NULL) receives the combined g for the residual branch (needs G2). */
 int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                        int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                        float *gw_part, float *gbias_part, void *stream);
@@ -172,6 +172,12 @@ int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int spl
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);
 int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
+/* mask head of a spectrogram-masking model: est (N,C,T) fp32 = sigmoid(from_cl(y)) * mag in one pass; backward
+ * gy (CL bf16) = to_cl(gest * mag * s (1 - s)), s = sigmoid(y) recomputed (halo rows / padded channels written as zeros). */
+int psnd_mask_head_fwd(const void *y, const float *mag, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *est,
+                       void *stream);
+int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
+                       void *gy, void *stream);
 
 /* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
  *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over

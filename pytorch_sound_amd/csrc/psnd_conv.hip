@@ -321,8 +321,10 @@ __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
 // to_cl: optional pre-op  0: none, 1: log1p(x)
+// MASKBWD: the backward of the mask head below: out = x * mul * s * (1 - s), s = sigmoid(ycl) read at the output position
+template <bool MASKBWD>
 __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out, int N, int C, int T, int Lp, int HP, int Cp,
-                                                    int preop) {
+                                                    int preop, const float *mul, const bf16_t *ycl) {
     // tile 32 (t) x 32 (c) through LDS so both sides are coalesced
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
@@ -334,18 +336,28 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
         if (c < C && t >= 0 && t < T) {
             v = x[((size_t)n * C + c) * T + t];
             if (preop == 1) v = log1pf(v);
+            if constexpr (MASKBWD) v *= mul[((size_t)n * C + c) * T + t];
         }
         tile[j][tx] = v;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int l = blockIdx.x * 32 + j, c = c0 + tx;
-        if (l < Lp && c < Cp) out[((size_t)n * Lp + l) * Cp + c] = f2bf(tile[tx][j]);
+        if (l < Lp && c < Cp) {
+            float v = tile[tx][j];
+            if constexpr (MASKBWD) {
+                const float sg = 1.f / (1.f + __expf(-bf2f(ycl[((size_t)n * Lp + l) * Cp + c])));
+                v *= sg * (1.f - sg);
+            }
+            out[((size_t)n * Lp + l) * Cp + c] = f2bf(v);
+        }
     }
 }
 
-// from_cl: (N, Lp, Cp) bf16 -> (N, C, T) fp32
-__global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp) {
+// from_cl: (N, Lp, Cp) bf16 -> (N, C, T) fp32.   MASK: the separator's mask head, out = sigmoid(x) * mul
+template <bool MASK>
+__global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp,
+                                                      const float *mul) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = blockIdx.z;
@@ -354,12 +366,16 @@ __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *ou
         const int t = t0 + j, c = c0 + tx;
         float v = 0.f;
         if (t < T && c < Cp) v = bf2f(x[((size_t)n * Lp + t + HP) * Cp + c]);
+        if constexpr (MASK) v = 1.f / (1.f + __expf(-v));
         tile[j][tx] = v;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, t = t0 + tx;
-        if (c < C && t < T) out[((size_t)n * C + c) * T + t] = tile[tx][j];
+        if (c < C && t < T) {
+            const size_t o = ((size_t)n * C + c) * T + t;
+            out[o] = MASK ? tile[tx][j] * mul[o] : tile[tx][j];
+        }
     }
 }
 
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF>
+template <int KT, int D, int NBUF, bool COMBINE>
 __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
         conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
-        conv_cl_body<KT, D, true, NBUF>(pc, c % cgx, c / cgx, smem_dyn, 0);
+        conv_cl_body<KT, D, COMBINE, NBUF>(pc, c % cgx, c / cgx, smem_dyn, 0);
     }
 }
 
@@ -812,8 +828,8 @@ extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, i
     if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "to_cl: Lp=%d T=%lld HP=%d Cp=%d C=%d", Lp, (long long)T, HP, Cp, C);
     if (N == 0) return PSND_OK;
     dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
-    hipLaunchKernelGGL(to_cl_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<bf16_t *>(out),
-                       (int)N, C, (int)T, Lp, HP, Cp, preop);
+    hipLaunchKernelGGL(to_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<bf16_t *>(out),
+                       (int)N, C, (int)T, Lp, HP, Cp, preop, nullptr, nullptr);
     PSND_CHECK_LAUNCH("to_cl");
     return PSND_OK;
 }
@@ -823,9 +839,35 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
     if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "from_cl: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
-    hipLaunchKernelGGL(from_cl_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
-                       (int)N, C, (int)T, Lp, HP, Cp);
+    hipLaunchKernelGGL(from_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
+                       (int)N, C, (int)T, Lp, HP, Cp, nullptr);
     PSND_CHECK_LAUNCH("from_cl");
+    return PSND_OK;
+}
+
+// mask head of a spectrogram-masking model: est = sigmoid(from_cl(y)) * mag in one pass, and its backward
+// gy = to_cl(gest * mag * s * (1 - s)) with s recomputed from y (halo rows / padded channels of gy are written as zeros)
+extern "C" int psnd_mask_head_fwd(const void *y, const float *mag, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *est,
+                                  void *stream) {
+    if (!y || !mag || !est) PSND_FAIL(PSND_E_ARG, "mask_head_fwd: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_fwd: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(from_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(y), est,
+                       (int)N, C, (int)T, Lp, HP, Cp, mag);
+    PSND_CHECK_LAUNCH("mask_head_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
+                                  void *gy, void *stream) {
+    if (!gest || !mag || !y || !gy) PSND_FAIL(PSND_E_ARG, "mask_head_bwd: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_bwd: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(to_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), gest, static_cast<bf16_t *>(gy), (int)N, C,
+                       (int)T, Lp, HP, Cp, 0, mag, static_cast<const bf16_t *>(y));
+    PSND_CHECK_LAUNCH("mask_head_bwd");
     return PSND_OK;
 }
 
@@ -880,8 +922,8 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 }
 
 // Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
-// taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Without a combined operand (G2 == NULL)
-// or outside the paired instances the two kernels are enqueued one after the other, same results.
+// taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Outside the paired instances (operands beyond the
+// 32-bit offsets, single-buffered LDS) the two kernels are enqueued one after the other, same results.
 extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                                   int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                                   float *gw_part, float *gbias_part, void *stream) {
@@ -892,7 +934,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
     }
     const size_t buf = sizeof(bf16_t) * 40 * ((size_t)(BM + 2 * hm) + (size_t)k * BN);
-    const bool pairable = !no_pair && G2 && GM && gx && wb && xa && gw_part && k >= 1 && k <= 16 && hm <= 25 && hm <= HP && N > 0 &&
+    const bool pairable = !no_pair && (G1 || G2) && (!G2 || GM) && gx && wb && xa && gw_part && k >= 1 && k <= 16 && hm <= 25 && hm <= HP && N > 0 &&
                           2 * buf <= 150 * 1024 && Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
                           (size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 < ((size_t)1 << 32) && (size_t)k * Cb * Ca * 2 < ((size_t)1 << 32);
     if (!pairable) {
@@ -927,9 +969,9 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define PSND_PAIR_LAUNCH(KT_, D_)                                                                                     \
+#define PSND_PAIR_LAUNCH(KT_, D_, C_)                                                                                  \
     do {                                                                                                              \
-        auto kern = conv_bwd_pair_kernel<KT_, D_, 2>;                                                                 \
+        auto kern = conv_bwd_pair_kernel<KT_, D_, 2, C_>;                                                             \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -937,10 +979,14 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);    \
     } while (0)
-    if (k <= 3) PSND_PAIR_LAUNCH(3, 4);
-    else if (k <= 7) PSND_PAIR_LAUNCH(7, 3);
-    else if (k <= 11) PSND_PAIR_LAUNCH(11, 2);
-    else PSND_PAIR_LAUNCH(16, 2);
+    if (k <= 3 && !G2) PSND_PAIR_LAUNCH(3, 8, false);
+    else if (k <= 3) PSND_PAIR_LAUNCH(3, 4, true);
+    else if (k <= 7 && !G2) PSND_PAIR_LAUNCH(7, 3, false);
+    else if (k <= 7) PSND_PAIR_LAUNCH(7, 3, true);
+    else if (k <= 11 && !G2) PSND_PAIR_LAUNCH(11, 2, false);
+    else if (k <= 11) PSND_PAIR_LAUNCH(11, 2, true);
+    else if (!G2) PSND_PAIR_LAUNCH(16, 2, false);
+    else PSND_PAIR_LAUNCH(16, 2, true);
 #undef PSND_PAIR_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl_bwd");
     return PSND_OK;

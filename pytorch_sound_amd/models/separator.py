@@ -48,6 +48,8 @@ class ConvSeparator(nn.Module):
         for block in self.blocks:
             x, xa = cl.resblock1_cl(block, x, xa, shape, prep=prep)
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
+        if mag.dtype == torch.float32 and not mag.requires_grad:
+            return cl.MaskHeadCL.apply(y, mag, shape)                               # sigmoid(from_cl(y)) * mag, one pass
         logits = cl.FromCL.apply(y, C, T, shape)
         return torch.sigmoid(logits) * mag
 

@@ -138,3 +138,28 @@ def test_trainer_device_side_nan_skip():
     for pa, pb in zip(a, b):
         assert torch.isfinite(pa).all() and torch.equal(pa, pb)
     assert buf.getvalue().count('2 cur step NAN is occured') == 2
+
+
+@pytest.mark.parametrize('N,C,T,HP', [(2, 513, 173, 8), (1, 40, 31, 3)])
+def test_mask_head_matches_torch_formulation(N, C, T, HP):
+    """psnd_mask_head_fwd/bwd == sigmoid(from_cl(y)) * mag and its autograd (bf16 logits in, fp32 out: 1e-6 relative on
+    the forward, bf16 rounding (4e-3) on the gradient written back in CL bf16); halo rows / padded channels of gy are 0."""
+    from pytorch_sound_amd import cl
+    dev = torch.device('cuda:0')
+    shape = cl.CLShape(N, T, HP)
+    Cp = cl.round_up(C, cl.ALIGN_C)
+    torch.manual_seed(N + C)
+    y = (2.0 * torch.randn(N, shape.Lp, Cp, device=dev)).to(torch.bfloat16).requires_grad_(True)
+    mag = torch.rand(N, C, T, device=dev)
+    g = torch.randn(N, C, T, device=dev)
+    est = cl.MaskHeadCL.apply(y, mag, shape)
+    est.backward(g)
+    y2 = y.detach().clone().requires_grad_(True)
+    ref = torch.sigmoid(cl.FromCL.apply(y2, C, T, shape)) * mag
+    ref.backward(g)
+    assert float((est - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-7
+    gy, gy2 = y.grad.float(), y2.grad.float()
+    assert float((gy - gy2).abs().max()) <= 8e-3 * float(gy2.abs().max())
+    assert float(gy[:, :HP].abs().max()) == 0.0 and float(gy[:, HP + T:].abs().max()) == 0.0
+    if Cp > C:
+        assert float(gy[:, :, C:].abs().max()) == 0.0
