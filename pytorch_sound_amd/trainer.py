@@ -171,6 +171,39 @@ class Trainer:
         be timed individually and it may change shapes from step to step.  Returns the inputs of forward()."""
         return inputs
 
+    # (not in the reference) stage the NEXT training batch - host->device copy and prepare() - on a side stream while the
+    # current step computes; the step's stream waits on an event, never the host.  prepare() must then be parameter-free
+    # (it runs one step early).  Off by default: the data iterator is advanced one batch ahead of the step that uses it.
+    prefetch_prepare = False
+
+    def _stage_train_batch(self):
+        side = self._pre_stream
+        try:
+            with torch.cuda.stream(side):
+                batch = self.prepare(*self._next_batch(self.train_dataset))
+                event = torch.cuda.Event()
+                event.record(side)
+            return batch, event
+        except StopIteration as e:                       # surfaces at the step that would have used the batch
+            return e, None
+
+    def _take_train_batch(self):
+        if not (self.prefetch_prepare and torch.cuda.is_available()):
+            return self.prepare(*self._next_batch(self.train_dataset))
+        if getattr(self, '_pre_stream', None) is None:
+            self._pre_stream = torch.cuda.Stream()
+            self._pre = self._stage_train_batch()
+        batch, event = self._pre
+        if event is None:
+            raise batch
+        self._pre = self._stage_train_batch()            # enqueued ahead of this step's own kernels: overlaps with them
+        cur = torch.cuda.current_stream()
+        cur.wait_event(event)
+        for t in batch:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
+        return batch
+
     def _next_batch(self, iterator):
         batch = next(iterator)
         if torch.cuda.is_available():
@@ -325,7 +358,7 @@ class Trainer:
 
     def train(self, step: int):
         log_flag = step % self.log_interval == 0
-        batch = self.prepare(*self._next_batch(self.train_dataset))
+        batch = self._take_train_batch()
         if self.graph_steps and not log_flag and self._train_graph(step, batch):
             return
         if self._reducer is not None:

@@ -1,6 +1,7 @@
 """Trainer.graph_steps on the GPU: a run whose steps are replayed from a hipGraph must follow the eager run
 (same seeds, same batches) - parameters after 12 steps equal to fp32 reassociation noise - and must skip a NaN step
 on the device exactly like the eager path."""
+import numpy as np
 import tempfile
 
 import pytest
@@ -66,3 +67,45 @@ def test_graph_step_skips_nan_on_device():
     assert all(bool(torch.isfinite(p).all()) for p in params)
     steps = {int(s['step'].item()) for s in opt.state.values() if 'step' in s}
     assert steps == {7}                                        # 8 steps, one skipped by the optimizer kernel itself
+
+
+def test_prefetch_prepare_gives_the_same_steps():
+    """Trainer.prefetch_prepare stages batch k+1 (copy + prepare()) on a side stream during step k: same losses, same
+    parameters as the in-line order, in eager and in graph mode."""
+    import tempfile
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    dev = torch.device('cuda:0')
+
+    def run(prefetch, graph):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Conv1d(1, 8, 5, padding=2), torch.nn.Tanh(), torch.nn.Conv1d(8, 1, 5, padding=2)).to(dev)
+        seen = []
+
+        class T(Trainer):
+            def prepare(self, x, y):
+                return x * 2.0, y + 1.0                      # parameter-free preprocessing
+
+            def forward(self, x, y, is_logging=False):
+                loss = torch.nn.functional.mse_loss(self.model(x.unsqueeze(1)).squeeze(1), y)
+                seen.append(loss.detach())
+                return loss, {'loss': (loss, LogType.SCALAR)}
+
+        g = torch.Generator().manual_seed(1)
+        data = [(torch.randn(4, 256, generator=g), torch.randn(4, 256, generator=g)) for _ in range(8)]
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+        tr = T(model, opt, data, data, max_step=8, valid_max_step=1, save_interval=100, log_interval=100,
+               save_dir=tempfile.mkdtemp(prefix='psnd_pf_'), seed=3)
+        tr.prefetch_prepare, tr.graph_steps = prefetch, graph
+        model.train()
+        for i in range(1, 9):
+            tr.step = i
+            tr.train(i)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in model.parameters()], [float(v) for v in seen]
+
+    for graph in (False, True):
+        pa, la = run(False, graph)
+        pb, lb = run(True, graph)
+        assert la == lb or np.allclose(la, lb, rtol=1e-6), (la, lb)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
