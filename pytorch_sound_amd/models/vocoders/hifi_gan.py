@@ -61,6 +61,10 @@ class _WNConvBase(nn.Module):
         del self.weight_v
         self.weight = nn.Parameter(w)
         self._folded = True
+        # the gfx950 conv kernels keep working on the folded weight: (v, g) = (w, ||w||) reproduces w.  Non-persistent buffers -
+        # the state dict holds `weight` / `bias` only, as the reference's does after remove_weight_norm
+        self.register_buffer('weight_v', self.weight.detach(), persistent=False)
+        self.register_buffer('weight_g', self._norm(w).clone(), persistent=False)
 
 
 class WNConv1d(_WNConvBase):
@@ -173,7 +177,7 @@ class Generator(nn.Module):
         if not (self.use_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
             return False
         if any(not hasattr(c, 'weight_v') for c in [self.conv_pre, self.conv_post]):
-            return False                     # weight norm removed (inference wrapper): plain torch path
+            return False
         reach = 0
         for block in self.resblocks:
             convs = list(block.convs1) + list(block.convs2) if hasattr(block, 'convs1') else list(block.convs)

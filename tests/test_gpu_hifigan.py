@@ -68,3 +68,29 @@ def test_generator_v3_dilation_falls_back_to_library_path():
     x = torch.randn(1, 80, 8, device='cuda')
     assert not g._cl_ok(x)
     assert g(x).shape == (1, 1, 8 * 256)
+
+
+@pytest.mark.parametrize('arch', ['hifi_gan_v2', 'hifi_gan_v3'])
+def test_folded_generator_decodes_on_the_cl_kernels(arch):
+    """InterfaceHifiGAN's decoder (interface/hifi_gan.py:66-117): weight norm removed, torch.no_grad - still on the gfx950 conv
+    kernels ((v, g) = (w, ||w||)), equal to the fp32 torch path within the bf16 tolerance; state dict = weight / bias only."""
+    from pytorch_sound_amd.models import build_model
+    import pytorch_sound_amd.models.vocoders.hifi_gan  # noqa: F401
+    torch.manual_seed(5)
+    gen = build_model(arch)
+    mel = torch.randn(2, 80, 24)
+    gen.eval()
+    with torch.no_grad():
+        want = gen(mel)                                   # CPU, fp32, weight-normed
+    gen.remove_weight_norm()
+    assert all(k.endswith('.weight') or k.endswith('.bias') for k in gen.state_dict())
+    with torch.no_grad():
+        assert float((gen(mel) - want).abs().max()) < 1e-5       # folding itself changes nothing (CPU)
+    gen = gen.to('cuda:0')
+    on_cl = gen._cl_ok(mel.to('cuda:0'))
+    assert on_cl == (arch != 'hifi_gan_v3')                # v3's dilated 7-tap convs reach 36 rows: beyond the staged tile, library path
+    with torch.no_grad():
+        got = gen(mel.to('cuda:0')).cpu()
+    assert got.shape == want.shape
+    err = float((got - want).norm() / want.norm())
+    assert err < (4e-2 if on_cl else 1e-4), err
