@@ -241,6 +241,20 @@ int psnd_adam_step(const void *table, int n_tensors, const int *chunk_tensor, co
                    double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
                    const float *found_inf, const float *grad_scale, float *corr, void *stream);
 
+/* ---- PQMF (models/transforms.py:492-560), polyphase --------------------------------------------------------------
+ *  filt : (subbands, taps + 1) fp32 (analysis_filter / synthesis_filter of the module), taps even, P = taps / 2.
+ *  psnd_pqmf_analysis : x (B, T) -> out (B, subbands, T / subbands):  out[b][k][m] = scale * sum_j F[k][j] x[b][m S + j - P]
+ *      = F.conv1d(pad(x), analysis_filter) followed by the stride-S pick (transforms.py:541-542), zeros outside the signal.
+ *  psnd_pqmf_synthesis: x (B, subbands, M) -> y (B, T_out), T_out = M * subbands for the module's synthesis (the adjoint of an
+ *      analysis over T samples asks for T_out = T: the tail samples past M * subbands still reach the last frames):
+ *      y[b][t] = scale * sum_k sum_{j: (t + j - P) % S == 0} F[k][j] x[b][k][(t + j - P) / S]
+ *      = zero-stuffing conv_transpose1d (x S) + F.conv1d(pad(.), synthesis_filter) (transforms.py:552-553) with scale = S.
+ *  flip = 1 reverses the taps: each op is then the adjoint of the other (the backward passes). */
+int psnd_pqmf_analysis(const float *x, const float *filt, int64_t B, int64_t T, int subbands, int taps, int flip, float scale,
+                       float *out, void *stream);
+int psnd_pqmf_synthesis(const float *x, const float *filt, int64_t B, int64_t M, int64_t T_out, int subbands, int taps, int flip,
+                        float scale, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

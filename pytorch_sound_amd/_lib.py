@@ -60,6 +60,8 @@ SIGNATURES = {
     'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _P]),
     'psnd_mask_head_fwd': (_INT, [_P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
     'psnd_mask_head_bwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
+    'psnd_pqmf_analysis': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _INT, _F, _P, _P]),
+    'psnd_pqmf_synthesis': (_INT, [_P, _P, _I64, _I64, _I64, _INT, _INT, _INT, _F, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }

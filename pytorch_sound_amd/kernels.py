@@ -437,3 +437,53 @@ class MultiStftLossFn(torch.autograd.Function):
                     gw = stft_backward(target, n_fft, hop, plans[i], gmag=gt)
                     gtarget = gw if gtarget is None else gtarget.add_(gw)
         return (gpred, gtarget, None, None) + (None,) * L
+
+
+# ---------------------------------------------------------------------------------------------
+# PQMF (models/transforms.py:492-560): polyphase analysis / synthesis, each the other's adjoint with reversed taps
+# ---------------------------------------------------------------------------------------------
+def _pqmf(op, x, filt, subbands, taps, flip, scale, t_out=None):
+    _need_cuda(x, 'input')
+    x, filt = x.contiguous(), filt.contiguous()
+    dev = x.device
+    with torch.cuda.device(dev):
+        if op == 'analysis':                        # (B, T) -> (B, S, T // S)
+            B, T = x.shape
+            out = torch.empty((B, subbands, T // subbands), dtype=torch.float32, device=dev)
+            check(lib().psnd_pqmf_analysis(ptr(x), ptr(filt), B, T, subbands, taps, int(flip), float(scale), ptr(out), stream_ptr(dev)),
+                  'psnd_pqmf_analysis')
+        else:                                       # (B, S, M) -> (B, M * S)
+            B, S, M = x.shape
+            t_out = M * S if t_out is None else t_out
+            out = torch.empty((B, t_out), dtype=torch.float32, device=dev)
+            check(lib().psnd_pqmf_synthesis(ptr(x), ptr(filt), B, M, t_out, subbands, taps, int(flip), float(scale), ptr(out), stream_ptr(dev)),
+                  'psnd_pqmf_synthesis')
+    return out
+
+
+class PqmfAnalysis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, filt, subbands, taps):
+        ctx.save_for_backward(filt)
+        ctx.cfg = (subbands, taps, x.shape[1])
+        return _pqmf('analysis', x, filt, subbands, taps, 0, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (filt,) = ctx.saved_tensors
+        S, taps, T = ctx.cfg
+        return _pqmf('synthesis', g.contiguous(), filt, S, taps, 1, 1.0, t_out=T), None, None, None   # tail samples reach the last frames
+
+
+class PqmfSynthesis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, filt, subbands, taps):
+        ctx.save_for_backward(filt)
+        ctx.cfg = (subbands, taps)
+        return _pqmf('synthesis', x, filt, subbands, taps, 0, float(subbands))
+
+    @staticmethod
+    def backward(ctx, g):
+        (filt,) = ctx.saved_tensors
+        S, taps = ctx.cfg
+        return _pqmf('analysis', g.contiguous(), filt, S, taps, 1, float(S)), None, None, None

@@ -10,6 +10,7 @@ Audio2Mel            forward (N,1,T) -> log10 mel           psnd_stft_fwd(HIFIGA
 """
 from typing import Optional, Tuple
 
+import math
 import numpy as np
 import torch
 import torch.nn as nn
@@ -263,3 +264,136 @@ class Audio2Mel(_HifiGanMel):
         if audio.dim() != 3 or audio.shape[1] != 1:
             raise RuntimeError('Audio2Mel expects (N, 1, T), got %s' % (tuple(audio.shape),))
         return self._logmel(audio.squeeze(1), K.FRAMING_HIFIGAN, 0.0, K.LOG_10)
+
+
+#
+# MFCC (transforms.py:419-459)
+#
+def create_dct(n_mfcc: int, n_mels: int, norm: str = 'ortho') -> torch.Tensor:
+    """DCT-II basis (n_mels, n_mfcc) as torchaudio.functional.create_dct builds it (norm None: x2, 'ortho': orthonormal)."""
+    n = torch.arange(float(n_mels), dtype=torch.float64)
+    k = torch.arange(float(n_mfcc), dtype=torch.float64).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    if norm is None:
+        dct *= 2.0
+    else:
+        assert norm == 'ortho'
+        dct[0] *= 1.0 / math.sqrt(2.0)
+        dct *= math.sqrt(2.0 / float(n_mels))
+    return dct.t().float()
+
+
+class MelToMFCC(nn.Module):
+    """Mel-frequency cepstrum coefficients from a (log-)mel spectrogram (transforms.py:419-432): dct_mat @ mel_spec.  On a
+    HIP device the product runs on the fp32 matrix-core kernel of the mel projection (psnd_mel_fwd / psnd_mel_bwd, no log)."""
+
+    def __init__(self, n_mfcc: int, mel_size: int, norm: str = 'ortho'):
+        super().__init__()
+        self.n_mfcc = n_mfcc
+        self.register_buffer('dct_mat', create_dct(n_mfcc, mel_size, norm).transpose(0, 1).contiguous())
+        self._plans = _PlanCache()
+
+    def forward(self, mel_spec: torch.Tensor) -> torch.Tensor:
+        assert len(mel_spec.size()) == 3
+        if mel_spec.is_cuda and mel_spec.dtype == torch.float32:
+            d = self.dct_mat
+            plan = self._plans.get(('dct', d._version, d.data_ptr()), mel_spec.device,
+                                   lambda: K.mel_plan(d.detach().cpu().numpy()))
+            return K.MelLog.apply(mel_spec.contiguous(), plan, self.n_mfcc, K.LOG_NONE, 0.0, None, None, None)
+        return torch.matmul(self.dct_mat, mel_spec)
+
+
+class MFCC(nn.Module):
+    """MFCC of a waveform (transforms.py:435-459): LogMelSpectrogram, then the DCT.  The reference asserts a 3-D input
+    and hands it to a front end that only takes (N, T); here (N, 1, T) is accepted and squeezed."""
+
+    def __init__(self, sample_rate: int, mel_size: int, n_fft: int, win_length: int, n_mfcc: int, hop_length: int,
+                 min_db: float, max_db: float, mel_min: float = 0., mel_max: float = None, norm: str = 'ortho'):
+        super().__init__()
+        self.n_mfcc = n_mfcc
+        self.mel_func = LogMelSpectrogram(sample_rate, mel_size, n_fft, win_length, hop_length, min_db, max_db, mel_min, mel_max)
+        self.to_mfcc = MelToMFCC(n_mfcc, mel_size, norm)
+
+    @property
+    def dct_mat(self):
+        return self.to_mfcc.dct_mat
+
+    def forward(self, wav: torch.Tensor) -> torch.Tensor:
+        assert len(wav.size()) == 3
+        return self.to_mfcc(self.mel_func(wav.squeeze(1)))
+
+
+class SpectrogramMasker(nn.Module):
+    """wave-level mask -> frame-level mask (transforms.py:397-416): a frame is valid when any of its samples is - the mean of
+    the window (a conv with constant 1 / win_length), rounded up.  The reference builds its conv on the GPU at
+    construction; here it follows the input's device."""
+
+    def __init__(self, win_length: int, hop_length: int):
+        super().__init__()
+        self.win_length = win_length
+        self.conv = nn.Conv1d(1, 1, self.win_length, stride=hop_length, padding=0, bias=False)
+        torch.nn.init.constant_(self.conv.weight, 1. / self.win_length)
+
+    def forward(self, wav_mask: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            if self.conv.weight.device != wav_mask.device:
+                self.conv.to(wav_mask.device)
+            wav_mask = torch.nn.functional.pad(wav_mask, [0, self.win_length // 2], value=0.)
+            wav_mask = torch.nn.functional.pad(wav_mask, [self.win_length // 2, 0], value=1.)
+            mel_mask = self.conv(wav_mask.float().unsqueeze(1)).squeeze(1)
+            mel_mask = torch.ceil(mel_mask)
+        return mel_mask
+
+
+#
+# Pseudo-QMF bank (transforms.py:462-560)
+#
+def design_prototype_filter(taps=62, cutoff_ratio=0.15, beta=9.0):
+    """Kaiser-windowed sinc prototype of the cosine-modulated bank, taps + 1 coefficients (transforms.py:462-489)."""
+    assert taps % 2 == 0, "The number of taps mush be even number."
+    assert 0.0 < cutoff_ratio < 1.0, "Cutoff ratio must be > 0.0 and < 1.0."
+    n = np.arange(taps + 1) - 0.5 * taps
+    with np.errstate(invalid='ignore', divide='ignore'):
+        h = np.sin(np.pi * cutoff_ratio * n) / (np.pi * n)
+    h[taps // 2] = cutoff_ratio                              # the 0/0 at the centre tap
+    return h * np.kaiser(taps + 1, beta)
+
+
+class PQMF(torch.nn.Module):
+    """Near-perfect-reconstruction pseudo-QMF bank (transforms.py:492-560): ``analysis`` (B, 1, T) -> (B, subbands,
+    T // subbands), ``synthesis`` back.  Buffers ``analysis_filter`` / ``synthesis_filter`` / ``updown_filter`` as in the
+    reference.  On a HIP device both directions are polyphase kernels (psnd_pqmf_analysis / psnd_pqmf_synthesis: only the
+    kept outputs are computed, no zero-stuffed intermediate) with autograd; CPU tensors take the reference's conv formulation."""
+
+    def __init__(self, subbands=4, taps=62, cutoff_ratio=0.15, beta=9.0):
+        super().__init__()
+        h = design_prototype_filter(taps, cutoff_ratio, beta)
+        n = np.arange(taps + 1) - ((taps - 1) / 2)
+        bank = np.zeros((2, subbands, len(h)))
+        for k in range(subbands):
+            phase = (2 * k + 1) * (np.pi / (2 * subbands)) * n
+            bank[0, k] = 2 * h * np.cos(phase + (-1) ** k * np.pi / 4)
+            bank[1, k] = 2 * h * np.cos(phase - (-1) ** k * np.pi / 4)
+        self.register_buffer('analysis_filter', torch.from_numpy(bank[0]).float().unsqueeze(1))
+        self.register_buffer('synthesis_filter', torch.from_numpy(bank[1]).float().unsqueeze(0))
+        updown = torch.zeros((subbands, subbands, subbands)).float()
+        for k in range(subbands):
+            updown[k, k, 0] = 1.0
+        self.register_buffer('updown_filter', updown)
+        self.subbands, self.taps = subbands, taps
+        self.pad_fn = torch.nn.ConstantPad1d(taps // 2, 0.0)
+
+    def _hip(self, x):
+        return x.is_cuda and x.dtype == torch.float32 and self.subbands <= 16 and self.taps <= 255
+
+    def analysis(self, x):
+        if self._hip(x) and x.dim() == 3 and x.size(1) == 1:
+            return K.PqmfAnalysis.apply(x.squeeze(1), self.analysis_filter.squeeze(1), self.subbands, self.taps)
+        x = torch.nn.functional.conv1d(self.pad_fn(x), self.analysis_filter)
+        return torch.nn.functional.conv1d(x, self.updown_filter, stride=self.subbands)
+
+    def synthesis(self, x):
+        if self._hip(x) and x.dim() == 3 and x.size(1) == self.subbands:
+            return K.PqmfSynthesis.apply(x, self.synthesis_filter.squeeze(0), self.subbands, self.taps).unsqueeze(1)
+        x = torch.nn.functional.conv_transpose1d(x, self.updown_filter * self.subbands, stride=self.subbands)
+        return torch.nn.functional.conv1d(self.pad_fn(x), self.synthesis_filter)

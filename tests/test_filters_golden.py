@@ -1,0 +1,72 @@
+"""PQMF / MFCC / SpectrogramMasker: oracle and the drop-in's host path against fixtures from the imported
+reference (tests/golden/filters.npz); DCT known answers (values unpinned by the reference - torchaudio is absent)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+from oracle import filters as of
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'filters.npz'))
+CASES = [('s4', dict()), ('s8', dict(subbands=8, taps=126, cutoff_ratio=0.07, beta=10.0))]
+
+
+@pytest.mark.parametrize('tag,kw', CASES)
+def test_oracle_pqmf_matches_reference(tag, kw):
+    ha, hs = of.pqmf_filters(**kw)
+    assert np.abs(ha - G[tag + '/analysis_filter'][:, 0]).max() < 1e-7 and np.abs(hs - G[tag + '/synthesis_filter'][0]).max() < 1e-7
+    assert np.abs(of.pqmf_analysis(G[tag + '/x'], ha) - G[tag + '/analysis']).max() < 1e-6
+    assert np.abs(of.pqmf_synthesis(G[tag + '/analysis'], hs) - G[tag + '/synthesis']).max() < 1e-6
+
+
+@pytest.mark.parametrize('tag,kw', CASES)
+def test_module_host_path_matches_reference(tag, kw):
+    from pytorch_sound_amd.models.transforms import PQMF
+    pq = PQMF(**kw)
+    assert set(pq.state_dict()) == {'analysis_filter', 'synthesis_filter', 'updown_filter'}
+    assert np.abs(pq.analysis_filter.numpy() - G[tag + '/analysis_filter']).max() < 1e-7
+    x = torch.from_numpy(G[tag + '/x']).requires_grad_(True)
+    a = pq.analysis(x)
+    (a * torch.from_numpy(G[tag + '/ga'])).sum().backward()
+    assert np.abs(a.detach().numpy() - G[tag + '/analysis']).max() < 1e-6 and np.abs(x.grad.numpy() - G[tag + '/gx']).max() < 1e-5
+    y = pq.synthesis(torch.from_numpy(G[tag + '/analysis']))
+    assert np.abs(y.numpy() - G[tag + '/synthesis']).max() < 1e-6
+    with pytest.raises(AssertionError):
+        PQMF(taps=61)
+
+
+def test_pqmf_reconstruction_property():
+    """synthesis(analysis(x)) reproduces x delayed by one sample (taps even, P = taps / 2 padding on both sides); with the
+    reference's default prototype (cutoff 0.15, 4 bands) the reconstruction is approximate: correlation > 0.98 on white noise"""
+    ha, hs = of.pqmf_filters()
+    x = np.random.RandomState(0).randn(1, 1, 4096)
+    y = of.pqmf_synthesis(of.pqmf_analysis(x, ha), hs)
+    assert np.corrcoef(y[0, 0, 200:-200], x[0, 0, 199:-201])[0, 1] > 0.98
+    assert abs(np.corrcoef(y[0, 0, 200:-200], x[0, 0, 200:-200])[0, 1]) < 0.1
+
+
+def test_dct_known_answers_and_mfcc_host_path():
+    from pytorch_sound_amd.models.transforms import MelToMFCC, create_dct
+    D = of.create_dct(13, 80)
+    assert np.abs(D.T @ D - np.eye(13)).max() < 1e-12                       # orthonormal columns
+    assert np.allclose(D[:, 0], 1.0 / np.sqrt(80))                          # first basis vector constant
+    assert np.allclose(of.create_dct(4, 8, None)[:, 1], 2 * np.cos(np.pi / 8 * (np.arange(8) + 0.5)))
+    assert np.abs(create_dct(13, 80).numpy() - D).max() < 1e-7
+    m = MelToMFCC(13, 80)
+    assert m.dct_mat.shape == (13, 80) and set(m.state_dict()) == {'dct_mat'}
+    mel = torch.randn(2, 80, 17)
+    assert np.abs(m(mel).numpy() - of.mel_to_mfcc(mel.numpy(), 13)).max() < 1e-5
+    with pytest.raises(AssertionError):
+        m(torch.randn(80, 17))
+
+
+def test_spectrogram_masker_host():
+    from pytorch_sound_amd.models.transforms import SpectrogramMasker
+    sm = SpectrogramMasker(win_length=8, hop_length=4)
+    mask = torch.zeros(2, 32)
+    mask[0, :10] = 1
+    mask[1, :] = 1
+    out = sm(mask)
+    # frames = (32 + 8 - 8) / 4 + 1 = 9; clip 0: frames touching a valid sample (or the ones-padded left edge) are 1
+    assert out.shape == (2, 9) and out[1].tolist() == [1.0] * 9
+    assert out[0].tolist() == [1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0]

@@ -559,10 +559,37 @@ def gen_data():
     np.savez_compressed(os.path.join(OUT, 'data.npz'), **out)
 
 
+def gen_filters():
+    """f4: PQMF (transforms.py:462-560) from the imported reference: filters, analysis, synthesis, autograd gradients."""
+    from pytorch_sound.models import transforms as rt
+    out = {}
+    for tag, kw in (('s4', dict()), ('s8', dict(subbands=8, taps=126, cutoff_ratio=0.07, beta=10.0))):
+        pq = rt.PQMF(**kw)
+        S = pq.subbands
+        x = torch.from_numpy(seeded_wav(950 + S, 2, 2048 + 3)).unsqueeze(1).requires_grad_(True)     # T not a multiple of S
+        a = pq.analysis(x)
+        ga = torch.from_numpy(np.random.RandomState(951).randn(*a.shape).astype(np.float32))
+        (a * ga).sum().backward()
+        sb = a.detach().clone().requires_grad_(True)
+        y = pq.synthesis(sb)
+        gy = torch.from_numpy(np.random.RandomState(952).randn(*y.shape).astype(np.float32))
+        (y * gy).sum().backward()
+        out[tag + '/analysis_filter'] = pq.analysis_filter.numpy()
+        out[tag + '/synthesis_filter'] = pq.synthesis_filter.numpy()
+        out[tag + '/x'] = x.detach().numpy()
+        out[tag + '/analysis'] = a.detach().numpy()
+        out[tag + '/ga'] = ga.numpy()
+        out[tag + '/gx'] = x.grad.numpy()
+        out[tag + '/synthesis'] = y.detach().numpy()
+        out[tag + '/gy'] = gy.numpy()
+        out[tag + '/gsb'] = sb.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'filters.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data']
+    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data', 'filters']
     for w in which:
         print('generating', w, flush=True)
         globals()['gen_' + w]()
