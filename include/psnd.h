@@ -134,7 +134,8 @@ int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, 
  *              zero fill, no atomics); S = psnd_conv1d_cl_wgrad_splits(N, Lp, Ca, Cb, k) (host helper).
  *              g_out = g materialised (may be NULL); g = G1 + G2*leaky'(GM).
  *  psnd_conv1d_prep: weight norm w = g*v/||v|| (norm over dim 0, as torch weight_norm) -> bf16 packs
- *              wf [k][Cb][Ca] and wb [k][Ca][Cb], zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: adds the S
+ *              wf [k][Cb][Ca] and wb [k][Ca][Cb] (for k <= 3 both in MFMA B-fragment order: tap j, 32-column tile, 16-channel
+ *              step, lane (c%16/8)*32 + n%32, 8 channels - an opaque layout shared by prep and conv), zero-padded bias (Cb).  psnd_conv1d_wnorm_bwd: adds the S
  *              slabs up and runs the weight-norm backward: (g_v, g_g) and gbias (Cb, may be NULL).
  *  psnd_to_cl / psnd_from_cl: (N,C,T) fp32 <-> CL bf16 (preop 1 = log1p on the way in). */
 int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,

@@ -87,6 +87,22 @@ __device__ __forceinline__ uint4 load_combined(const bf16_t *G1, const bf16_t *G
     return v;
 }
 
+// Weight packs of convs with k <= KFRAG taps are stored in MFMA B-fragment order: for tap j, 32-column tile nt, 16-channel step
+// ks, lane l = (c % 16 / 8) * 32 + n % 32 holds the 8 consecutive reduction channels 8 * (c % 16 / 8) .. + 7 of column n -
+// one wave reads its whole B operand of a k-step as ONE contiguous 1 KB load, straight from L2 into registers (no LDS).
+// Same bytes as the row-major [j][n][c] pack (n, c multiples of 32).
+constexpr int KFRAG = 3;
+#ifndef PSND_DB_PLAIN
+#define PSND_DB_PLAIN 4
+#endif
+#ifndef PSND_DB_COMBINE
+#define PSND_DB_COMBINE 2
+#endif
+__device__ __host__ __forceinline__ size_t pack_index(int k, int j, int n, int c, int Nn, int Nc) {
+    if (k > KFRAG) return ((size_t)j * Nn + n) * Nc + c;
+    return ((((size_t)j * (Nn >> 5) + (n >> 5)) * (Nc >> 4) + (c >> 4)) * 64 + (((c & 15) >> 3) << 5) + (n & 31)) * 8 + (c & 7);
+}
+
 constexpr int MAXK = 16;
 constexpr int KC = 32;                     // input channels per pipeline stage
 constexpr int PCS = KC / 8;                // 16-byte pieces per staged row
@@ -104,7 +120,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
     constexpr int NB = BN * PCS / 256;     // weight pieces per thread per tap (= 1)
     const int rowsA = BM + 2 * p.hm;
-    const int buf_elems = (rowsA + p.k * BN) * RS;
+    const int buf_elems = (rowsA + (KT <= KFRAG ? 0 : p.k * BN)) * RS;    // fragment-ordered packs (k <= KFRAG) never enter LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const long long r0 = (long long)bx * BM;
@@ -116,9 +132,15 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     PSND_CSTAMP(0);
 
-    // (Tried: B fragments straight from global memory into the ring, no LDS for the weights - each lane's 16 bytes sit
-    // in a different 512-byte row of the pack, 64 separate lines per instruction: 11 -> 18 us.  Weights stay staged.)
-    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rb[D][KT * NB];
+    // B operand.  KT > KFRAG: weights staged through LDS like A (row-major pack).  KT <= KFRAG: the pack is in fragment order
+    // (pack_index) and every wave loads its own B fragments - 2 k-steps x KT taps x 16 B per lane and stage, 1 KB contiguous
+    // per wave instruction - DB stages ahead, straight into the registers the MFMAs read: the stage loop was LDS-bandwidth
+    // bound (48 KB of fragment reads + 17 KB of stage writes per stage and workgroup, half of it weights).
+    // (With a ROW-MAJOR pack the same idea lost, 11 -> 18 us: 64 separate 32-byte pieces per wave instruction.)
+    constexpr bool BFRAG = KT <= KFRAG;
+    constexpr int DB = !BFRAG ? 1 : (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN);   // B ring depth (D % DB == 0: slots are static inside a ring turn)
+    static_assert(!BFRAG || D % DB == 0, "B ring depth must divide the A ring depth");
+    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rb[BFRAG ? 1 : D][KT * NB], rbf[BFRAG ? DB : 1][2 * KT];
     const int nA = rowsA * PCS;
     // Every load is a buffer load with a 32-bit byte offset; an offset of OOB (or any offset past the tensor)
     // returns zeros.  That supplies the rows before / after the tensor, the channels past Ca of a padding stage
@@ -166,9 +188,26 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                 ram[s][u] = ld16(rAM, o);
             }
         }
+        if constexpr (!BFRAG) {
 #pragma unroll
-        for (int j = 0; j < KT; ++j)
-            rb[s][j] = ld16(rW, (live && j < p.k && woff != OOB) ? woff + (unsigned)j * wtap + cb : OOB);
+            for (int j = 0; j < KT; ++j)
+                rb[s][j] = ld16(rW, (live && j < p.k && woff != OOB) ? woff + (unsigned)j * wtap + cb : OOB);
+        }
+    };
+    // fragment-ordered pack: tile (n0 / 32 + wn) of tap j, k-step c0 / 16 + kk  ->  1 KB per wave
+    const unsigned fbase = (n0 + wn * 32 < p.Cb) ? (unsigned)((size_t)((n0 >> 5) + wn) * (size_t)(p.Ca >> 4) * 1024u) + (unsigned)lane * 16u : OOB;
+    const unsigned ftap = (unsigned)((size_t)(p.Cb >> 5) * (size_t)(p.Ca >> 4) * 1024u);
+    auto fetch_b = [&](auto sc, int c0) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (BFRAG) {
+            const bool live = c0 < p.Ca && fbase != OOB;
+            const unsigned ks = (unsigned)(c0 >> 4) * 1024u;
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+                    rbf[s][2 * j + kk] = ld16(rW, (live && j < p.k) ? fbase + (unsigned)j * ftap + ks + (unsigned)kk * 1024u : OOB);
+        }
     };
     auto combine = [&](uint4 v, uint4 g2, uint4 m) __attribute__((always_inline)) {
         const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
@@ -199,14 +238,17 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
             }
             if (idx < nA) *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = v;
         }
+        if constexpr (!BFRAG) {
 #pragma unroll
-        for (int j = 0; j < KT; ++j)
-            if (j < p.k) *reinterpret_cast<uint4 *>(sB + (j * BN + wn_) * RS + 8 * wpc) = rb[s][j];
+            for (int j = 0; j < KT; ++j)
+                if (j < p.k) *reinterpret_cast<uint4 *>(sB + (j * BN + wn_) * RS + 8 * wpc) = rb[s][j];
+        }
     };
 
     // the ring turns whole: stages past Ca / KC load and multiply zeros (at most D - 1 of them)
     const int nchunk = (p.Ca / KC + D - 1) / D * D;
     static_for<0, D>([&](auto sc) __attribute__((always_inline)) { fetch(sc, decltype(sc)::value * KC); });
+    static_for<0, DB>([&](auto sc) __attribute__((always_inline)) { fetch_b(sc, decltype(sc)::value * KC); });
     for (int c = 0; c < nchunk; c += D) {
         static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
@@ -220,15 +262,32 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                 __syncthreads();
                 if (ch == 0) PSND_CSTAMP(2);
                 fetch(sc, (ch + D) * KC);
-                for (int tap = 0; tap < p.k; ++tap) {
-                    const int off = p.off0 + tap * p.dstep + p.hm;
-                    const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
-                    const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
+                if constexpr (BFRAG) {
+                    constexpr int sb = s % DB;
+                    static_for<0, KT>([&](auto jc) __attribute__((always_inline)) {
+                        constexpr int tap = decltype(jc)::value;
+                        if (tap < p.k) {                                     // uniform
+                            const int off = p.off0 + tap * p.dstep + p.hm;
+                            const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
 #pragma unroll
-                    for (int kk = 0; kk < KC / 16; ++kk) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
-                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                            for (int kk = 0; kk < KC / 16; ++kk) {
+                                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, rbf[sb][2 * tap + kk]), acc, 0, 0, 0);
+                            }
+                        }
+                    });
+                    fetch_b(std::integral_constant<int, sb>{}, (ch + DB) * KC);
+                } else {
+                    for (int tap = 0; tap < p.k; ++tap) {
+                        const int off = p.off0 + tap * p.dstep + p.hm;
+                        const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
+                        const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
+#pragma unroll
+                        for (int kk = 0; kk < KC / 16; ++kk) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
+                            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -616,8 +675,8 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const fl
     for (int i = threadIdx.x; i < n; i += 256) {
         const int ci = i / k, j = i - ci * k;
         const bf16_t w = f2bf(vr[i] * scale);
-        wf[((size_t)j * Cb + co) * Ca + ci] = w;
-        wb[((size_t)j * Ca + ci) * Cb + co] = w;
+        wf[pack_index(k, j, co, ci, Cb, Ca)] = w;
+        wb[pack_index(k, j, ci, co, Ca, Cb)] = w;
     }
     if (threadIdx.x == 0) bp[co] = bias ? bias[co] : 0.f;
 }
@@ -651,8 +710,8 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *de
     for (int i = threadIdx.x; i < nn; i += 256) {
         const int ci = i / d.k, j = i - ci * d.k;
         const bf16_t w = f2bf(vr[i] * scale);
-        d.wf[((size_t)j * d.Cb + co) * d.Ca + ci] = w;
-        d.wb[((size_t)j * d.Ca + ci) * d.Cb + co] = w;
+        d.wf[pack_index(d.k, j, co, ci, d.Cb, d.Ca)] = w;
+        d.wb[pack_index(d.k, j, ci, co, d.Ca, d.Cb)] = w;
     }
     if (threadIdx.x == 0) d.bp[co] = d.bias ? d.bias[co] : 0.f;
 }
@@ -768,6 +827,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     if ((!A && !A2) || !W || (!out_raw && !out_act) || (A2 && !AM)) PSND_FAIL(PSND_E_ARG, "conv1d_cl: null pointer");
     if (a_eff_out && !A2) PSND_FAIL(PSND_E_ARG, "conv1d_cl: a_eff_out needs the combined operand (A2, AM)");
     if (Ca % 32 != 0 || Cb % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: Ca=%d must be a multiple of 32, Cb=%d of 8", Ca, Cb);
+    if (k <= KFRAG && Cb % 32 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d uses the fragment-ordered pack, Cb=%d must be a multiple of 32", k, Cb);
     if (k < 1 || k > 16 || N < 0 || Lp < L + 2 * HP || L <= 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d N=%lld Lp=%d L=%d HP=%d", k, (long long)N, Lp, L, HP);
     int hm = 0;
     for (int j = 0; j < k; ++j) {
