@@ -116,22 +116,25 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
     const float *in1 = BWD ? p.in1 + (size_t)clip * p.Cc * F : nullptr;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    if (lo < hi) {
-        float a = W[(size_t)lo * 64];
-        f32x4 b = load_b<BWD>(p, in0, in1, 4 * lo + kk, f, F);
-        for (int s = lo; s < hi; ++s) {
-            float an = 0.f;
-            f32x4 bn = {0.f, 0.f, 0.f, 0.f};
-            if (s + 1 < hi) {
-                an = W[(size_t)(s + 1) * 64];
-                bn = load_b<BWD>(p, in0, in1, 4 * (s + 1) + kk, f, F);
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc3, 0, 0, 0);
-            a = an;
-            b = bn;
+    // the band is walked in batches of MU k-steps with all 2 * MU loads of a batch in flight (the first version prefetched one
+    // step ahead: a ~100-step latency chain per wave on the widest mel tiles - 26 us per launch at 32 clips, where the grid is
+    // only 480 waves and nothing hides it)
+    constexpr int MU = 8;
+    for (int s0 = lo; s0 < hi; s0 += MU) {
+        float a[MU];
+        f32x4 b[MU];
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            const bool ok = s0 + u < hi;                               // uniform
+            a[u] = ok ? W[(size_t)(s0 + u) * 64] : 0.f;
+            b[u] = ok ? load_b<BWD>(p, in0, in1, 4 * (s0 + u) + kk, f, F) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < MU; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, acc3, 0, 0, 0);
         }
     }
     // D layout: col = lane&15 (-> frames f..f+3 across acc0..3), row = 4*(lane>>4) + reg
