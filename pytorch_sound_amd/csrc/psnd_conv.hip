@@ -87,19 +87,18 @@ __device__ __forceinline__ uint4 load_combined(const bf16_t *G1, const bf16_t *G
     return v;
 }
 
-// Weight packs of convs with k <= KFRAG taps are stored in MFMA B-fragment order: for tap j, 32-column tile nt, 16-channel step
+// Weight packs are stored in MFMA B-fragment order: for tap j, 32-column tile nt, 16-channel step
 // ks, lane l = (c % 16 / 8) * 32 + n % 32 holds the 8 consecutive reduction channels 8 * (c % 16 / 8) .. + 7 of column n -
 // one wave reads its whole B operand of a k-step as ONE contiguous 1 KB load, straight from L2 into registers (no LDS).
 // Same bytes as the row-major [j][n][c] pack (n, c multiples of 32).
-constexpr int KFRAG = 3;
+constexpr int KFRAG = 16;     // every k: fragment order (taps are walked in chunks of TC = 3 through the register ring)
 #ifndef PSND_DB_PLAIN
 #define PSND_DB_PLAIN 4
 #endif
 #ifndef PSND_DB_COMBINE
 #define PSND_DB_COMBINE 2
 #endif
-__device__ __host__ __forceinline__ size_t pack_index(int k, int j, int n, int c, int Nn, int Nc) {
-    if (k > KFRAG) return ((size_t)j * Nn + n) * Nc + c;
+__device__ __host__ __forceinline__ size_t pack_index(int /*k*/, int j, int n, int c, int Nn, int Nc) {
     return ((((size_t)j * (Nn >> 5) + (n >> 5)) * (Nc >> 4) + (c >> 4)) * 64 + (((c & 15) >> 3) << 5) + (n & 31)) * 8 + (c & 7);
 }
 
@@ -118,9 +117,8 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 template <int KT, int D, bool COMBINE, int NBUF>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
-    constexpr int NB = BN * PCS / 256;     // weight pieces per thread per tap (= 1)
     const int rowsA = BM + 2 * p.hm;
-    const int buf_elems = (rowsA + (KT <= KFRAG ? 0 : p.k * BN)) * RS;    // fragment-ordered packs (k <= KFRAG) never enter LDS
+    const int buf_elems = rowsA * RS;      // two A stage buffers; the weights never enter LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const long long r0 = (long long)bx * BM;
@@ -132,15 +130,16 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     PSND_CSTAMP(0);
 
-    // B operand.  KT > KFRAG: weights staged through LDS like A (row-major pack).  KT <= KFRAG: the pack is in fragment order
-    // (pack_index) and every wave loads its own B fragments - 2 k-steps x KT taps x 16 B per lane and stage, 1 KB contiguous
-    // per wave instruction - DB stages ahead, straight into the registers the MFMAs read: the stage loop was LDS-bandwidth
-    // bound (48 KB of fragment reads + 17 KB of stage writes per stage and workgroup, half of it weights).
+    // B operand: the pack is in fragment order (pack_index) and every wave loads its own B fragments straight from L2 into the
+    // registers the MFMAs read - 16 B per lane, 1 KB contiguous per wave instruction - in units of TC = 3 taps x 2 k-steps, DB
+    // units ahead.  The weights never enter LDS: with them staged there the stage loop was LDS-bandwidth bound at k = 3 (48 KB of
+    // fragment reads + 17 KB of stage writes per stage and workgroup, half of it weights), and the 7- and 11-tap convs of the
+    // HiFi-GAN blocks (43 / 65 KB of weights per stage buffer) ran ONE workgroup per CU.
     // (With a ROW-MAJOR pack the same idea lost, 11 -> 18 us: 64 separate 32-byte pieces per wave instruction.)
-    constexpr bool BFRAG = KT <= KFRAG;
-    constexpr int DB = !BFRAG ? 1 : (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN);   // B ring depth (D % DB == 0: slots are static inside a ring turn)
-    static_assert(!BFRAG || D % DB == 0, "B ring depth must divide the A ring depth");
-    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rb[BFRAG ? 1 : D][KT * NB], rbf[BFRAG ? DB : 1][2 * KT];
+    constexpr int TC = 3, NCH = (KT + TC - 1) / TC, UNITS = D * NCH;
+    constexpr int DB = KT <= 3 ? (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN) : (UNITS % 4 == 0 ? 4 : (UNITS % 3 == 0 ? 3 : 2));
+    static_assert(UNITS % DB == 0, "B ring depth must divide the units of a ring turn (slots are static inside a turn)");
+    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rbf[DB][2 * TC];
     const int nA = rowsA * PCS;
     // Every load is a buffer load with a 32-bit byte offset; an offset of OOB (or any offset past the tensor)
     // returns zeros.  That supplies the rows before / after the tensor, the channels past Ca of a padding stage
@@ -167,9 +166,6 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         const long long r = r0 - p.hm + rr;
         aoff[u] = (idx < nA && r >= 0 && r < p.R) ? (unsigned)(((size_t)r * p.Ca + 8 * pc) * sizeof(bf16_t)) : OOB;
     }
-    const int wn_ = tid / PCS, wpc = tid % PCS;       // weight piece of this thread (NB == 1)
-    const unsigned woff = (n0 + wn_ < p.Cb) ? (unsigned)((((size_t)(n0 + wn_)) * p.Ca + 8 * wpc) * sizeof(bf16_t)) : OOB;
-    const unsigned wtap = (unsigned)((size_t)p.Cb * p.Ca * sizeof(bf16_t));
     auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) __attribute__((always_inline)) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
         return __builtin_bit_cast(uint4, v);
@@ -188,26 +184,20 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                 ram[s][u] = ld16(rAM, o);
             }
         }
-        if constexpr (!BFRAG) {
-#pragma unroll
-            for (int j = 0; j < KT; ++j)
-                rb[s][j] = ld16(rW, (live && j < p.k && woff != OOB) ? woff + (unsigned)j * wtap + cb : OOB);
-        }
     };
     // fragment-ordered pack: tile (n0 / 32 + wn) of tap j, k-step c0 / 16 + kk  ->  1 KB per wave
     const unsigned fbase = (n0 + wn * 32 < p.Cb) ? (unsigned)((size_t)((n0 >> 5) + wn) * (size_t)(p.Ca >> 4) * 1024u) + (unsigned)lane * 16u : OOB;
     const unsigned ftap = (unsigned)((size_t)(p.Cb >> 5) * (size_t)(p.Ca >> 4) * 1024u);
-    auto fetch_b = [&](auto sc, int c0) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (BFRAG) {
-            const bool live = c0 < p.Ca && fbase != OOB;
-            const unsigned ks = (unsigned)(c0 >> 4) * 1024u;
+    // unit u of a ring turn = (stage u / NCH, tap chunk u % NCH); slot = u % DB
+    auto fetch_b = [&](auto slotc, auto chunkc, int c0) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value, q = decltype(chunkc)::value;
+        const bool live = c0 < p.Ca && fbase != OOB;
+        const unsigned ks = (unsigned)(c0 >> 4) * 1024u;
 #pragma unroll
-            for (int j = 0; j < KT; ++j)
+        for (int t = 0; t < TC; ++t)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    rbf[s][2 * j + kk] = ld16(rW, (live && j < p.k) ? fbase + (unsigned)j * ftap + ks + (unsigned)kk * 1024u : OOB);
-        }
+            for (int kk = 0; kk < 2; ++kk)
+                rbf[slot][2 * t + kk] = ld16(rW, (live && q * TC + t < p.k) ? fbase + (unsigned)(q * TC + t) * ftap + ks + (unsigned)kk * 1024u : OOB);
     };
     auto combine = [&](uint4 v, uint4 g2, uint4 m) __attribute__((always_inline)) {
         const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
@@ -223,7 +213,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         }
         return make_uint4(out[0], out[1], out[2], out[3]);
     };
-    auto commit = [&](auto sc, bf16_t *sA, bf16_t *sB, int c0) __attribute__((always_inline)) {
+    auto commit = [&](auto sc, bf16_t *sA, int c0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
@@ -238,59 +228,42 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
             }
             if (idx < nA) *reinterpret_cast<uint4 *>(sA + (idx / PCS) * RS + 8 * (idx % PCS)) = v;
         }
-        if constexpr (!BFRAG) {
-#pragma unroll
-            for (int j = 0; j < KT; ++j)
-                if (j < p.k) *reinterpret_cast<uint4 *>(sB + (j * BN + wn_) * RS + 8 * wpc) = rb[s][j];
-        }
     };
 
     // the ring turns whole: stages past Ca / KC load and multiply zeros (at most D - 1 of them)
     const int nchunk = (p.Ca / KC + D - 1) / D * D;
     static_for<0, D>([&](auto sc) __attribute__((always_inline)) { fetch(sc, decltype(sc)::value * KC); });
-    static_for<0, DB>([&](auto sc) __attribute__((always_inline)) { fetch_b(sc, decltype(sc)::value * KC); });
+    static_for<0, DB>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        fetch_b(uc, std::integral_constant<int, u % NCH>{}, (u / NCH) * KC);
+    });
     for (int c = 0; c < nchunk; c += D) {
         static_for<0, D>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             const int ch = c + s;
-            {
-                bf16_t *sA = smem_c + (NBUF == 2 ? (ch & 1) * buf_elems : 0);
-                bf16_t *sB = sA + rowsA * RS;
-                if constexpr (NBUF == 1) __syncthreads();        // the previous stage's fragments are consumed
-                commit(sc, sA, sB, ch * KC);
-                if (ch == 0) PSND_CSTAMP(1);
-                __syncthreads();
-                if (ch == 0) PSND_CSTAMP(2);
-                fetch(sc, (ch + D) * KC);
-                if constexpr (BFRAG) {
-                    constexpr int sb = s % DB;
-                    static_for<0, KT>([&](auto jc) __attribute__((always_inline)) {
-                        constexpr int tap = decltype(jc)::value;
-                        if (tap < p.k) {                                     // uniform
-                            const int off = p.off0 + tap * p.dstep + p.hm;
-                            const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
-#pragma unroll
-                            for (int kk = 0; kk < KC / 16; ++kk) {
-                                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, rbf[sb][2 * tap + kk]), acc, 0, 0, 0);
-                            }
-                        }
-                    });
-                    fetch_b(std::integral_constant<int, sb>{}, (ch + DB) * KC);
-                } else {
-                    for (int tap = 0; tap < p.k; ++tap) {
+            bf16_t *sA = smem_c + (ch & 1) * buf_elems;
+            commit(sc, sA, ch * KC);
+            if (ch == 0) PSND_CSTAMP(1);
+            __syncthreads();
+            if (ch == 0) PSND_CSTAMP(2);
+            fetch(sc, (ch + D) * KC);
+            static_for<0, NCH>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value, u = s * NCH + q, slot = u % DB;
+                static_for<0, TC>([&](auto tc) __attribute__((always_inline)) {
+                    constexpr int tap = q * TC + decltype(tc)::value;
+                    if (tap < KT && tap < p.k) {                             // uniform
                         const int off = p.off0 + tap * p.dstep + p.hm;
                         const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
-                        const bf16_t *pb = sB + (tap * BN + wn * 32 + li) * RS + 8 * kg;
 #pragma unroll
                         for (int kk = 0; kk < KC / 16; ++kk) {
                             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
-                            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(pb + 16 * kk);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, rbf[slot][2 * decltype(tc)::value + kk]), acc, 0, 0, 0);
                         }
                     }
-                }
-            }
+                });
+                // the unit DB ahead: same slot; its stage is ch + (q + DB) / NCH (static part), its chunk (q + DB) % NCH
+                fetch_b(std::integral_constant<int, slot>{}, std::integral_constant<int, (q + DB) % NCH>{}, (ch + (q + DB) / NCH) * KC);
+            });
         });
     }
 
@@ -827,7 +800,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     if ((!A && !A2) || !W || (!out_raw && !out_act) || (A2 && !AM)) PSND_FAIL(PSND_E_ARG, "conv1d_cl: null pointer");
     if (a_eff_out && !A2) PSND_FAIL(PSND_E_ARG, "conv1d_cl: a_eff_out needs the combined operand (A2, AM)");
     if (Ca % 32 != 0 || Cb % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: Ca=%d must be a multiple of 32, Cb=%d of 8", Ca, Cb);
-    if (k <= KFRAG && Cb % 32 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d uses the fragment-ordered pack, Cb=%d must be a multiple of 32", k, Cb);
+    if (Cb % 32 != 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: Cb=%d must be a multiple of 32 (fragment-ordered weight pack)", Cb);
     if (k < 1 || k > 16 || N < 0 || Lp < L + 2 * HP || L <= 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: k=%d N=%lld Lp=%d L=%d HP=%d", k, (long long)N, Lp, L, HP);
     int hm = 0;
     for (int j = 0; j < k; ++j) {
@@ -852,16 +825,14 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    const size_t buf = sizeof(bf16_t) * 40 * ((size_t)(BM + 2 * hm) + (size_t)k * BN);
-    const int nbuf = 2 * buf <= 150 * 1024 ? 2 : 1;
-    size_t lds = nbuf * buf;
+    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(BM + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
     if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: LDS %zu too large", lds);
     dim3 grid((unsigned)((p.R + BM - 1) / BM), (unsigned)((Cb + BN - 1) / BN));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define PSND_CONV_LAUNCH(KT_, D_, NBUF_)                                                                              \
+#define PSND_CONV_LAUNCH(KT_, D_, C_)                                                                                 \
     do {                                                                                                              \
-        auto kern = A2 ? conv_cl_kernel<KT_, D_, true, NBUF_> : conv_cl_kernel<KT_, D_, false, NBUF_>;                \
+        auto kern = conv_cl_kernel<KT_, D_, C_, 2>;                                                                   \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -871,12 +842,14 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     } while (0)
     if ((size_t)p.R * Ca * 2 >= ((size_t)1 << 32) || (size_t)k * Cb * Ca * 2 >= ((size_t)1 << 32))
         PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: operand larger than 4 GB (32-bit buffer offsets)");
-    if (k <= 3 && nbuf == 2 && !A2) PSND_CONV_LAUNCH(3, 8, 2);
-    else if (k <= 3 && nbuf == 2) PSND_CONV_LAUNCH(3, 4, 2);
-    else if (k <= 7 && nbuf == 2) PSND_CONV_LAUNCH(7, 3, 2);
-    else if (k <= 11 && nbuf == 2) PSND_CONV_LAUNCH(11, 2, 2);
-    else if (nbuf == 2) PSND_CONV_LAUNCH(16, 2, 2);
-    else PSND_CONV_LAUNCH(16, 2, 1);
+    if (k <= 3 && !A2) PSND_CONV_LAUNCH(3, 8, false);
+    else if (k <= 3) PSND_CONV_LAUNCH(3, 4, true);
+    else if (k <= 7 && !A2) PSND_CONV_LAUNCH(7, 3, false);
+    else if (k <= 7) PSND_CONV_LAUNCH(7, 3, true);
+    else if (k <= 11 && !A2) PSND_CONV_LAUNCH(11, 2, false);
+    else if (k <= 11) PSND_CONV_LAUNCH(11, 2, true);
+    else if (!A2) PSND_CONV_LAUNCH(16, 2, false);
+    else PSND_CONV_LAUNCH(16, 2, true);
 #undef PSND_CONV_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl");
     return PSND_OK;
@@ -983,7 +956,7 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 
 // Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
 // taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Outside the paired instances (operands beyond the
-// 32-bit offsets, single-buffered LDS) the two kernels are enqueued one after the other, same results.
+// 32-bit offsets) the two kernels are enqueued one after the other, same results.
 extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                                   int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                                   float *gw_part, float *gbias_part, void *stream) {
@@ -993,9 +966,9 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         const int o = pad - j * dil;
         hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
     }
-    const size_t buf = sizeof(bf16_t) * 40 * ((size_t)(BM + 2 * hm) + (size_t)k * BN);
+    const size_t buf = sizeof(bf16_t) * 40 * (size_t)(BM + 2 * hm);
     const bool pairable = !no_pair && (G1 || G2) && (!G2 || GM) && gx && wb && xa && gw_part && k >= 1 && k <= 16 && hm <= 25 && hm <= HP && N > 0 &&
-                          2 * buf <= 150 * 1024 && Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
+                          Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
                           (size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 < ((size_t)1 << 32) && (size_t)k * Cb * Ca * 2 < ((size_t)1 << 32);
     if (!pairable) {
         int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
