@@ -114,20 +114,25 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 // combine are kept apart until the commit (the arithmetic would otherwise wait for its loads inside the
 // fetch), LDS is double buffered (one barrier per stage).
 //   KT: taps the register ring is sized for (k <= KT);  D: stages in flight;  COMBINE: A = A + A2 * leaky'(AM)
-template <int KT, int D, bool COMBINE, int NBUF>
+//   MT: 32-row MFMA tiles per wave (1: 64-row workgroup tile; 2: 128 rows - every B fragment feeds two MFMAs, for launches with
+//   enough rows to fill the chip anyway: the stage loop is bound by the B fragment loads, whose bytes per FLOP go with 1 / rows)
+template <int KT, int D, bool COMBINE, int NBUF, int MT>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
-    const int rowsA = BM + 2 * p.hm;
+    constexpr int BMt = 64 * MT, NAt = (BMt + 2 * 25) * PCS / 256 + 1;
+    const int rowsA = BMt + 2 * p.hm;
     const int buf_elems = rowsA * RS;      // two A stage buffers; the weights never enter LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long r0 = (long long)bx * BM;
+    const long long r0 = (long long)bx * BMt;
     const int n0 = by * BN;
     const int li = lane & 31, kg = lane >> 5;
 
-    f32x16 acc;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
     PSND_CSTAMP(0);
 
     // B operand: the pack is in fragment order (pack_index) and every wave loads its own B fragments straight from L2 into the
@@ -139,7 +144,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     constexpr int TC = 3, NCH = (KT + TC - 1) / TC, UNITS = D * NCH;
     constexpr int DB = KT <= 3 ? (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN) : (UNITS % 4 == 0 ? 4 : (UNITS % 3 == 0 ? 3 : 2));
     static_assert(UNITS % DB == 0, "B ring depth must divide the units of a ring turn (slots are static inside a turn)");
-    uint4 ra[D][NA], ra2[COMBINE ? D : 1][NA], ram[COMBINE ? D : 1][NA], rbf[DB][2 * TC];
+    uint4 ra[D][NAt], ra2[COMBINE ? D : 1][NAt], ram[COMBINE ? D : 1][NAt], rbf[DB][2 * TC];
     const int nA = rowsA * PCS;
     // Every load is a buffer load with a 32-bit byte offset; an offset of OOB (or any offset past the tensor)
     // returns zeros.  That supplies the rows before / after the tensor, the channels past Ca of a padding stage
@@ -158,9 +163,9 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     const __amdgpu_buffer_rsrc_t rG = make_uniform_rsrc(p.a_eff_out ? p.a_eff_out : p.W,
                                                         (COMBINE && p.a_eff_out && by == 0) ? (int)a_bytes : 0);
     const bool haveA = p.A != nullptr;
-    unsigned aoff[NA];
+    unsigned aoff[NAt];
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
+    for (int u = 0; u < NAt; ++u) {
         const int idx = tid + 256 * u;
         const int rr = idx / PCS, pc = idx % PCS;
         const long long r = r0 - p.hm + rr;
@@ -176,7 +181,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         const bool live = c0 < p.Ca;                  // false for the padding stages of the last ring turn
         const unsigned cb = (unsigned)c0 * (unsigned)sizeof(bf16_t);
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
+        for (int u = 0; u < NAt; ++u) {
             const unsigned o = (live && aoff[u] != OOB) ? aoff[u] + cb : OOB;
             ra[s][u] = ld16(rA, haveA ? o : OOB);
             if constexpr (COMBINE) {
@@ -216,13 +221,13 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     auto commit = [&](auto sc, bf16_t *sA, int c0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
+        for (int u = 0; u < NAt; ++u) {
             const int idx = tid + 256 * u;
             uint4 v = ra[s][u];
             if constexpr (COMBINE) {
                 v = combine(v, ra2[s][u], ram[s][u]);
                 const int rr = idx / PCS;
-                const bool own = rr >= p.hm && rr < p.hm + BM && aoff[u] != OOB && c0 < p.Ca;     // rows of this tile
+                const bool own = rr >= p.hm && rr < p.hm + BMt && aoff[u] != OOB && c0 < p.Ca;     // rows of this tile
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rG,
                                                        (int)(own ? aoff[u] + (unsigned)c0 * 2u : OOB), 0, 0);
             }
@@ -253,11 +258,15 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                     constexpr int tap = q * TC + decltype(tc)::value;
                     if (tap < KT && tap < p.k) {                             // uniform
                         const int off = p.off0 + tap * p.dstep + p.hm;
-                        const bf16_t *pa = sA + (wm * 32 + li + off) * RS + 8 * kg;
+                        const bf16_t *pa = sA + (wm * 32 * MT + li + off) * RS + 8 * kg;
 #pragma unroll
                         for (int kk = 0; kk < KC / 16; ++kk) {
-                            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + 16 * kk);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, rbf[slot][2 * decltype(tc)::value + kk]), acc, 0, 0, 0);
+                            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, rbf[slot][2 * decltype(tc)::value + kk]);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + m * 32 * RS + 16 * kk);
+                                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[m], 0, 0, 0);
+                            }
                         }
                     }
                 });
@@ -276,14 +285,16 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     float *sO = reinterpret_cast<float *>(smem_c);
     __syncthreads();                                             // every fragment read of the last stage is done
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-        const int i = (rg & 3) + 8 * (rg >> 2) + 4 * kg;
-        sO[(wm * 32 + i) * OS + wn * 32 + li] = acc[rg];
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int i = (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+            sO[(wm * 32 * MT + m * 32 + i) * OS + wn * 32 + li] = acc[m][rg];
+        }
     __syncthreads();
     const int l0 = (int)(r0 % p.Lp);                             // uniform
 #pragma unroll
-    for (int u = 0; u < BM * BN / 8 / 256; ++u) {
+    for (int u = 0; u < BMt * BN / 8 / 256; ++u) {
         const int idx = tid + 256 * u, row = idx >> 3, cg = idx & 7;
         const long long r = r0 + row;
         const int col = n0 + 8 * cg;
@@ -345,10 +356,10 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #endif
 }
 
-template <int KT, int D, bool COMBINE, int NBUF>
+template <int KT, int D, bool COMBINE, int NBUF, int MT>
 __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    conv_cl_body<KT, D, COMBINE, NBUF>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    conv_cl_body<KT, D, COMBINE, NBUF, MT>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF, bool COMBINE>
+template <int KT, int D, int NBUF, bool COMBINE, int MT>
 __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
         conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
-        conv_cl_body<KT, D, COMBINE, NBUF>(pc, c % cgx, c / cgx, smem_dyn, 0);
+        conv_cl_body<KT, D, COMBINE, NBUF, MT>(pc, c % cgx, c / cgx, smem_dyn, 0);
     }
 }
 
@@ -793,6 +804,13 @@ __global__ __launch_bounds__(1024) void conv_finish_multi_kernel(FinishArgs a) {
 
 }  // namespace
 
+// 128-row workgroup tiles once 64-row tiles would make >= 1024 workgroups (two full rounds of the chip's 512 slots)
+static int conv_row_tiles(int64_t R, int Cb) {
+    static const int force = getenv("PSND_CONV_MT") ? atoi(getenv("PSND_CONV_MT")) : 0;
+    if (force == 1 || force == 2) return force;
+    return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;
+}
+
 extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
                               const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
                               int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
@@ -825,14 +843,16 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(BM + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
-    if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);   // the epilogue's fp32 tile
+    const int mt = conv_row_tiles(p.R, Cb);
+    const int bm = 64 * mt;
+    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
+    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: LDS %zu too large", lds);
-    dim3 grid((unsigned)((p.R + BM - 1) / BM), (unsigned)((Cb + BN - 1) / BN));
+    dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + BN - 1) / BN));
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define PSND_CONV_LAUNCH(KT_, D_, C_)                                                                                 \
     do {                                                                                                              \
-        auto kern = conv_cl_kernel<KT_, D_, C_, 2>;                                                                   \
+        auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2> : conv_cl_kernel<KT_, D_, C_, 2, 1>;           \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -996,15 +1016,17 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     pc.trace = nullptr, pw.trace = nullptr;
 #endif
     const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
-    const int cgx = (int)((pc.R + BM - 1) / BM), cgy = (Ca + BN - 1) / BN;
+    const int mt = conv_row_tiles(pc.R, Ca);
+    const int bm = 64 * mt;
+    const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
     const int nw = wgx * wgy * wgz;
-    size_t lds = 2 * buf;
-    if (lds < sizeof(float) * BM * (BN + 8)) lds = sizeof(float) * BM * (BN + 8);
+    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);
+    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define PSND_PAIR_LAUNCH(KT_, D_, C_)                                                                                  \
     do {                                                                                                              \
-        auto kern = conv_bwd_pair_kernel<KT_, D_, 2, C_>;                                                             \
+        auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1>;   \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
