@@ -764,13 +764,12 @@ __device__ __forceinline__ void conv_finish_body(const float *gw_part, const flo
         const int ci = (int)__umulhi((unsigned)i, kmagic), j = i - ci * k;
         gv[(size_t)co * n + i] = gs * (s_gw[j * pitch + ci] - vr[i] * inv * d);
     }
-    if (tid == 0) {
-        gg[co] = d;
-        if (gbias && gb_part) {
-            float b = 0.f;
-            for (int sp = 0; sp < splits; ++sp) b += gb_part[(size_t)sp * Cb + co];
-            gbias[co] = b;
-        }
+    if (tid == 0) gg[co] = d;
+    if (tid < 64 && gbias && gb_part) {              // the first wave adds up the bias slabs (one serial chain of `splits` loads before)
+        float b = 0.f;
+        for (int sp = tid; sp < splits; sp += 64) b += gb_part[(size_t)sp * Cb + co];
+        for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
+        if (tid == 0) gbias[co] = b;
     }
 }
 
