@@ -137,14 +137,13 @@ def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, 
     return raw, act
 
 
-# ---- the weight-gradient branch of a conv's backward runs on a second stream --------------------------------------------
+# ---- optional: the weight-gradient branch of a conv's backward on a second stream (PSND_CL_SIDE_STREAM=1) ---------------------
 # Per conv the backward is  (a) input gradient, needed by the next layer's backward, and  (b) weight gradient + weight-norm
-# backward, needed only by the optimizer.  Each of these kernels fills a fraction of the chip for 10-20 us (latency chains,
-# DESIGN.md 4.4), so (b) is enqueued on a side stream and overlaps the (a) chain; one callback at the end of the backward pass
-# joins the side stream (torch's engine callback, the mechanism DDP uses).  Inside a hipGraph capture the side stream is
-# captured as a parallel branch.  OFF by default (PSND_CL_SIDE_STREAM=1 enables it): measured on the config-2 step it LOSES
-# 5 % (2.28 vs 2.16 ms) - the two kernels cannot share a CU (wgrad 320 + conv 216-256 VGPRs per lane exceed the 512-entry
-# register file), so the branches serialise anyway and the graph pays for the fork/join.
+# backward, needed only by the optimizer; each fills a fraction of the chip for 10-20 us (latency chains).
+# The default runs (a) and (b) as ONE launch (psnd_conv1d_cl_bwd, conv_bwd_pair_kernel).  This A/B switch instead enqueues (b)
+# on a side stream, joined by one engine callback at the end of the backward pass (inside a hipGraph capture: a parallel
+# branch); measured on the config-2 step it loses 3 % against separate launches on one stream - the graph pays a fork/join
+# per conv - and 18 % against the paired launch.
 _SIDE = {}
 _JOIN_PENDING = {}
 
