@@ -11,6 +11,11 @@
 
 namespace {
 
+// rows are walked with 16-byte accesses when their length and every pointer involved allow it
+__device__ __forceinline__ bool row_is_vec4(const void *a, const void *b, const void *c, long long T) {
+    return (T & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -31,11 +36,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *x, const flo
     const int c = blockIdx.x, n = blockIdx.y;
     const size_t base = ((size_t)n * C + c) * T;
     float s1 = 0.f, s2 = 0.f;
-    for (long long t = threadIdx.x; t < T; t += 256) {
-        float v = x[base + t];
-        if (res) v += res[base + t];
-        s1 += v;
-        s2 = __builtin_fmaf(v, v, s2);
+    if (row_is_vec4(x + base, res ? res + base : nullptr, nullptr, T)) {           // 16-byte accesses (rows of T % 4 == 0 floats)
+        const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + base), *r4 = res ? reinterpret_cast<const f32x4 *>(res + base) : nullptr;
+        for (long long t = threadIdx.x; t < (T >> 2); t += 256) {
+            f32x4 v = x4[t];
+            if (r4) v += r4[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s1 += v[j], s2 = __builtin_fmaf(v[j], v[j], s2);
+        }
+    } else {
+        for (long long t = threadIdx.x; t < T; t += 256) {
+            float v = x[base + t];
+            if (res) v += res[base + t];
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+        }
     }
     double d1 = wave_sum((double)s1), d2 = wave_sum((double)s2);
     __shared__ double red[8];
@@ -59,6 +74,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, const flo
     if (c == 0 && threadIdx.x == 0) stats[2 * n] = mu, stats[2 * n + 1] = rstd;
     const float g = gamma[c] * rstd, b = beta[c] - mu * g;
     const size_t base = ((size_t)n * C + c) * T;
+    if (row_is_vec4(x + base, res ? res + base : nullptr, y + base, T)) {
+        const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + base), *r4 = res ? reinterpret_cast<const f32x4 *>(res + base) : nullptr;
+        f32x4 *y4 = reinterpret_cast<f32x4 *>(y + base);
+        for (long long t = threadIdx.x; t < (T >> 2); t += 256) {
+            f32x4 v = x4[t];
+            if (r4) v += r4[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = __builtin_fmaf(v[j], g, b);
+                if (relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            y4[t] = v;
+        }
+        return;
+    }
     for (long long t = threadIdx.x; t < T; t += 256) {
         float v = x[base + t];
         if (res) v += res[base + t];
@@ -77,13 +107,30 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *gy, con
     const float mu = stats[2 * n], rstd = stats[2 * n + 1];
     const size_t base = ((size_t)n * C + c) * T;
     float a = 0.f, b = 0.f;
-    for (long long t = threadIdx.x; t < T; t += 256) {
-        float g = gy[base + t];
-        if (relu && !(y[base + t] > 0.f)) g = 0.f;
-        float v = x[base + t];
-        if (res) v += res[base + t];
-        a += g;
-        b = __builtin_fmaf(g, (v - mu) * rstd, b);
+    if (row_is_vec4(gy + base, x + base, res ? res + base : nullptr, T) && row_is_vec4(relu ? y + base : nullptr, nullptr, nullptr, T)) {
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gy + base), *x4 = reinterpret_cast<const f32x4 *>(x + base);
+        const f32x4 *r4 = res ? reinterpret_cast<const f32x4 *>(res + base) : nullptr, *y4 = relu ? reinterpret_cast<const f32x4 *>(y + base) : nullptr;
+        for (long long t = threadIdx.x; t < (T >> 2); t += 256) {
+            f32x4 g = g4[t], v = x4[t];
+            if (r4) v += r4[t];
+            if (y4) {
+                const f32x4 yy = y4[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(yy[j] > 0.f)) g[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a += g[j], b = __builtin_fmaf(g[j], (v[j] - mu) * rstd, b);
+        }
+    } else {
+        for (long long t = threadIdx.x; t < T; t += 256) {
+            float g = gy[base + t];
+            if (relu && !(y[base + t] > 0.f)) g = 0.f;
+            float v = x[base + t];
+            if (res) v += res[base + t];
+            a += g;
+            b = __builtin_fmaf(g, (v - mu) * rstd, b);
+        }
     }
     a = wave_sum(a), b = wave_sum(b);
     __shared__ float red[8];
@@ -108,6 +155,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *gy, cons
     const float m1 = (float)(ws[2 * n] / M), m2 = (float)(ws[2 * n + 1] / M);
     const float gc = gamma[c];
     const size_t base = ((size_t)n * C + c) * T;
+    if (row_is_vec4(gy + base, x + base, res ? res + base : nullptr, T) && row_is_vec4(relu ? y + base : nullptr, gx + base, nullptr, T)) {
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gy + base), *x4 = reinterpret_cast<const f32x4 *>(x + base);
+        const f32x4 *r4 = res ? reinterpret_cast<const f32x4 *>(res + base) : nullptr, *y4 = relu ? reinterpret_cast<const f32x4 *>(y + base) : nullptr;
+        f32x4 *o4 = reinterpret_cast<f32x4 *>(gx + base);
+        for (long long t = threadIdx.x; t < (T >> 2); t += 256) {
+            f32x4 g = g4[t], v = x4[t], o;
+            if (r4) v += r4[t];
+            if (y4) {
+                const f32x4 yy = y4[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!(yy[j] > 0.f)) g[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (g[j] * gc - m1 - (v[j] - mu) * rstd * m2);
+            o4[t] = o;
+        }
+        return;
+    }
     for (long long t = threadIdx.x; t < T; t += 256) {
         float g = gy[base + t];
         if (relu && !(y[base + t] > 0.f)) g = 0.f;
