@@ -297,12 +297,15 @@ class Trainer:
         if not hasattr(self, '_graphs'):
             self._graphs = {}
         sig = tuple((tuple(t.shape), t.dtype) for t in batch)
-        st = self._graphs.setdefault(sig, {'seen': 0})
+        st = self._graphs.pop(sig, None) or {'seen': 0}
+        self._graphs[sig] = st                         # most recently used last
         if 'graph' not in st:
             if st['seen'] < self.graph_warmup:
                 st['seen'] += 1
+                self._trim_graph_cache()
                 return False
             self._capture(st, batch)
+            self._trim_graph_cache()
         for dst, src in zip(st['inputs'], batch):
             dst.copy_(src, non_blocking=True)
         st['graph'].replay()
@@ -313,6 +316,18 @@ class Trainer:
                 p.grad = g
         self._finish_device_skip(step, st['flag'])
         return True
+
+    # every captured signature owns a memory pool with that shape's activations: variable-length batches (bucketed loaders)
+    # must not pile them up.  Least recently used graphs go first; bare counters of shapes still warming up are capped too.
+    graph_cache_size = 8
+
+    def _trim_graph_cache(self):
+        captured = [k for k, v in self._graphs.items() if 'graph' in v]
+        for k in captured[:max(0, len(captured) - self.graph_cache_size)]:
+            del self._graphs[k]
+        if len(self._graphs) > 64 * max(1, self.graph_cache_size):
+            for k in [k for k, v in self._graphs.items() if 'graph' not in v][:len(self._graphs) // 2]:
+                del self._graphs[k]
 
     def _capture(self, st, batch):
         if self._reducer is not None:

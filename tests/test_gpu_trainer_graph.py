@@ -109,3 +109,40 @@ def test_prefetch_prepare_gives_the_same_steps():
         assert la == lb or np.allclose(la, lb, rtol=1e-6), (la, lb)
         for a, b in zip(pa, pb):
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_graph_cache_is_bounded_and_recaptures():
+    """variable-length batches: one captured graph per input signature, least recently used ones dropped beyond
+    Trainer.graph_cache_size; a dropped shape is captured again when it comes back; same parameters as eager steps."""
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    dev = torch.device('cuda:0')
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Conv1d(1, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv1d(4, 1, 3, padding=1)).to(dev)
+
+        class T(Trainer):
+            def forward(self, x, y, is_logging=False):
+                loss = torch.nn.functional.mse_loss(self.model(x.unsqueeze(1)).squeeze(1), y)
+                return loss, {'loss': (loss, LogType.SCALAR)}
+
+        g = torch.Generator().manual_seed(1)
+        lens = [64, 96, 128]
+        data = [(torch.randn(2, lens[i % 3], generator=g), torch.randn(2, lens[i % 3], generator=g)) for i in range(30)]
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+        tr = T(model, opt, data, data, max_step=30, valid_max_step=1, save_interval=100, log_interval=100,
+               save_dir=tempfile.mkdtemp(prefix='psnd_gc_'), seed=3)
+        tr.graph_steps, tr.graph_warmup, tr.graph_cache_size = graph, 1, 2
+        model.train()
+        for i in range(1, 31):
+            tr.step = i
+            tr.train(i)
+        torch.cuda.synchronize()
+        return tr, [p.detach().clone() for p in model.parameters()]
+
+    tr, pg = run(True)
+    captured = [k for k, v in tr._graphs.items() if 'graph' in v]
+    assert 1 <= len(captured) <= 2 and len(tr._graphs) <= 3
+    _, pe = run(False)
+    for a, b in zip(pg, pe):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
