@@ -1015,7 +1015,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     pc.trace = nullptr, pw.trace = nullptr;
 #endif
     const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
-    const int mt = conv_row_tiles(pc.R, Ca);
+    static const int pair_mt = getenv("PSND_PAIR_MT") ? atoi(getenv("PSND_PAIR_MT")) : 0;
+    const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : conv_row_tiles(pc.R, Ca);
     const int bm = 64 * mt;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
     const int nw = wgx * wgy * wgz;

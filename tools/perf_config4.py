@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_sound_amd.data import dataset as D  # noqa: E402
-from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding  # noqa: E402
+from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding, _conv1x1  # noqa: E402
 from pytorch_sound_amd.models.transforms import LogMelSpectrogram, SpectrogramMasker  # noqa: E402
 from pytorch_sound_amd.trainer import Trainer, LogType  # noqa: E402
 from pytorch_sound_amd import optim as poptim  # noqa: E402
@@ -46,9 +46,9 @@ class Net(torch.nn.Module):
         self.out = torch.nn.Conv1d(C, 80, 1)
 
     def forward(self, mel, pad_mask):
-        x = self.pe(self.inp(mel))
+        x = self.pe(_conv1x1(self.inp, mel))
         x, _ = self.mha(x, pad_mask)
-        return self.out(self.ffn(x))
+        return _conv1x1(self.out, self.ffn(x))
 
 
 def main():
