@@ -2,7 +2,6 @@
 formulation of the same ops (the module's own reference path, which the golden tests pin on CPU).
 bf16 storage with fp32 accumulation: tolerance 2e-2 of the tensor's max (bf16 has 8 mantissa bits and the
 activations are re-quantised after every conv)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -2,7 +2,6 @@
 PointwiseFeedForward against the imported reference's outputs and gradients (tests/golden/modules.npz) and against
 the torch formulation at BASELINE config-4-like sizes.  fp32 throughout: tolerance 2e-5 of max (outputs),
 1e-4 (gradients; library GEMM reassociation + fast exp)."""
-import numpy as np
 import pytest
 import torch
 

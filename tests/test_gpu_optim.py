@@ -2,7 +2,6 @@
 the same gradients: parameters and both moments after 1, 2 and 25 steps (tolerance 2e-6 relative to each tensor's max:
 fp32 kernel vs f64), odd sizes and unaligned views, weight decay of both kinds, the AMP found_inf / grad_scale protocol,
 state_dict exchange with torch.optim.Adam."""
-import numpy as np
 import pytest
 import torch
 
