@@ -3,6 +3,7 @@
 bytes 4*N*T + 4*N*M*F (1344 B per frame)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from pytorch_sound_amd import kernels as K
 from oracle import features as ofe
 dev = torch.device('cuda:0')
