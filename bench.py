@@ -68,6 +68,8 @@ def build_step(device, amp):
 
         def logmel_of_mag(m):
             return K.MelLog.apply(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+
+        l1 = K.l1_loss                                              # F.l1_loss as psnd_l1_loss_fwd / _bwd
     else:
         from oracle.torch_ref import RefLogMel                      # CPU baseline leg only
         fe = RefLogMel(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX)
@@ -77,6 +79,8 @@ def build_step(device, amp):
 
         def logmel_of_mag(m):
             return fe.mel_of_mag(m)
+
+        l1 = F.l1_loss
 
     class StepTrainer(Trainer):
         def prepare(self, noisy, clean):
@@ -94,7 +98,7 @@ def build_step(device, amp):
                 est = est.float()
             else:
                 est = self.model(mag_mix)
-            loss = F.l1_loss(est, mag_ref) + 0.5 * F.l1_loss(logmel_of_mag(est), mel_ref)
+            loss = l1(est, mag_ref) + 0.5 * l1(logmel_of_mag(est), mel_ref)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
     torch.manual_seed(1234)

@@ -256,6 +256,14 @@ int psnd_pqmf_analysis(const float *x, const float *filt, int64_t B, int64_t T, 
 int psnd_pqmf_synthesis(const float *x, const float *filt, int64_t B, int64_t M, int64_t T_out, int subbands, int taps, int flip,
                         float scale, float *y, void *stream);
 
+/* ---- F.l1_loss (reduction 'mean') as used by the training recipes' spectral losses --------------------------------
+ *  psnd_l1_loss_fwd: out[0] = mean |a - b| over n fp32 elements; part: psnd_l1_loss_blocks(n) doubles of scratch (one partial
+ *      per 16384-element chunk, summed in a fixed order by a second tiny launch: bit-reproducible).
+ *  psnd_l1_loss_bwd: ga = g[0] * sign(a - b) / n, gb = -ga (either NULL); g = device pointer to the upstream gradient. */
+int64_t psnd_l1_loss_blocks(int64_t n);
+int psnd_l1_loss_fwd(const float *a, const float *b, int64_t n, double *part, float *out, void *stream);
+int psnd_l1_loss_bwd(const float *a, const float *b, int64_t n, const float *g, float *ga, float *gb, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,48 @@ __global__ __launch_bounds__(256) void preemph_bwd_kernel(const float *gy, long 
     }
 }
 
+// ---- mean absolute error (F.l1_loss, reduction 'mean') as two launches forward, one backward ---------------------------
+constexpr int L1CH = 16384;             // elements per workgroup
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float *a, const float *b, long long n, double *part) {
+    const long long e0 = (long long)blockIdx.x * L1CH, e1 = min(e0 + L1CH, n);
+    float s = 0.f;
+    if ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        const long long v1 = e0 + ((e1 - e0) & ~3ll);
+        for (long long e = e0 + 4 * threadIdx.x; e < v1; e += 1024) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(a + e), y = *reinterpret_cast<const f32x4 *>(b + e);
+            s += fabsf(x.x - y.x) + fabsf(x.y - y.y) + fabsf(x.z - y.z) + fabsf(x.w - y.w);
+        }
+        for (long long e = v1 + threadIdx.x; e < e1; e += 256) s += fabsf(a[e] - b[e]);
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += 256) s += fabsf(a[e] - b[e]);
+    }
+    const double d = wave_sum_d((double)s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const double *part, int nb, double inv_n, float *out) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    s = wave_sum_d(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+// ga = g * sign(a - b) / n,  gb = -ga   (either may be NULL); g: device scalar
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float *a, const float *b, long long n, const float *g, float inv_n, float *ga,
+                                                     float *gb) {
+    const float c = g[0] * inv_n;
+    for (long long e = (long long)blockIdx.x * 1024 + threadIdx.x; e < min((long long)(blockIdx.x + 1) * 1024, n); e += 256) {
+        const float d = a[e] - b[e];
+        const float v = d > 0.f ? c : (d < 0.f ? -c : 0.f);
+        if (ga) ga[e] = v;
+        if (gb) gb[e] = -v;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t psnd_stft_loss_blocks(int64_t KF) { return KF <= 0 ? 0 : (KF + LCHUNK - 1) / LCHUNK; }
@@ -216,5 +258,27 @@ extern "C" int psnd_preemphasis_bwd(const float *gy, int64_t N, int64_t T, float
     hipLaunchKernelGGL(preemph_bwd_kernel, dim3((unsigned)((T + 1023) / 1024), (unsigned)N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        gy, (long long)T, coef, gx);
     PSND_CHECK_LAUNCH("preemphasis_bwd");
+    return PSND_OK;
+}
+
+extern "C" int64_t psnd_l1_loss_blocks(int64_t n) { return n <= 0 ? 0 : (n + L1CH - 1) / L1CH; }
+
+extern "C" int psnd_l1_loss_fwd(const float *a, const float *b, int64_t n, double *part, float *out, void *stream) {
+    if (!a || !b || !part || !out) PSND_FAIL(PSND_E_ARG, "l1_loss_fwd: null pointer");
+    if (n <= 0 || psnd_l1_loss_blocks(n) > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "l1_loss_fwd: n=%lld", (long long)n);
+    const int nb = (int)psnd_l1_loss_blocks(n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, (long long)n, part);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, part, nb, 1.0 / (double)n, out);
+    PSND_CHECK_LAUNCH("l1_loss_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_l1_loss_bwd(const float *a, const float *b, int64_t n, const float *g, float *ga, float *gb, void *stream) {
+    if (!a || !b || !g || (!ga && !gb)) PSND_FAIL(PSND_E_ARG, "l1_loss_bwd: null pointer");
+    if (n <= 0 || (n + 1023) / 1024 > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "l1_loss_bwd: n=%lld", (long long)n);
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, (long long)n, g,
+                       (float)(1.0 / (double)n), ga, gb);
+    PSND_CHECK_LAUNCH("l1_loss_bwd");
     return PSND_OK;
 }

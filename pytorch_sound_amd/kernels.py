@@ -487,3 +487,37 @@ class PqmfSynthesis(torch.autograd.Function):
         (filt,) = ctx.saved_tensors
         S, taps = ctx.cfg
         return _pqmf('analysis', g.contiguous(), filt, S, taps, 1, float(S)), None, None, None
+
+
+class L1Loss(torch.autograd.Function):
+    """F.l1_loss(a, b) (mean): one pass + a tiny combine forward, one pass backward (torch: sub, abs, mean / sign, scale, neg)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_cuda(a, 'input')
+        _need_cuda(b, 'target')
+        if a.shape != b.shape:
+            raise _lib.PsndError('l1_loss: shapes %s and %s differ' % (tuple(a.shape), tuple(b.shape)))
+        a, b = a.contiguous(), b.contiguous()
+        n = a.numel()
+        part = torch.empty(int(lib().psnd_l1_loss_blocks(n)), dtype=torch.float64, device=a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib().psnd_l1_loss_fwd(ptr(a), ptr(b), n, ptr(part), ptr(out), stream_ptr(a.device)), 'psnd_l1_loss_fwd')
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        g = g.contiguous().float()
+        with torch.cuda.device(a.device):
+            check(lib().psnd_l1_loss_bwd(ptr(a), ptr(b), a.numel(), ptr(g), ptr(ga), ptr(gb), stream_ptr(a.device)), 'psnd_l1_loss_bwd')
+        return ga, gb
+
+
+def l1_loss(input, target):
+    """drop-in for torch.nn.functional.l1_loss(input, target) (reduction 'mean') on fp32 HIP tensors"""
+    return L1Loss.apply(input, target)

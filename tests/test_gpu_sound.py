@@ -113,3 +113,23 @@ def test_loss_kernels_reject_bad_arguments():
         multi_stft_loss(torch.zeros(2, 4096, device=DEV), torch.zeros(2, 4000, device=DEV), PARAMS)
     with pytest.raises(_lib.PsndError):
         multi_stft_loss(torch.zeros(2, 4096, device=DEV), torch.zeros(2, 4096, device=DEV), [(1000, 600, 120)])   # n_fft not 2^k
+
+
+@pytest.mark.parametrize('shape', [(32, 513, 173), (3, 7), (1, 16385), (5,)])
+def test_l1_loss_matches_torch(shape):
+    """psnd_l1_loss_fwd/bwd == F.l1_loss (mean) in float64 and its autograd (sign(a - b) / n, 0 at ties)"""
+    from pytorch_sound_amd import kernels as K
+    torch.manual_seed(len(shape))
+    a = torch.randn(*shape, device=DEV, requires_grad=True)
+    b = torch.randn(*shape, device=DEV, requires_grad=True)
+    with torch.no_grad():
+        b.view(-1)[0] = a.view(-1)[0]                     # a tie: gradient 0 there, as torch.sign gives
+    out = K.l1_loss(a, b)
+    (3.0 * out).backward()
+    a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.l1_loss(a64, b64)
+    (3.0 * ref).backward()
+    assert abs(float(out) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert torch.allclose(a.grad.double(), a64.grad, rtol=1e-6, atol=0) and torch.allclose(b.grad.double(), b64.grad, rtol=1e-6, atol=0)
+    with pytest.raises(Exception):
+        K.l1_loss(a, torch.zeros(2, device=DEV))
