@@ -253,8 +253,9 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
                                    ptr(out), ptr(act), None, st), 'psnd_conv1d_cl')
 
     def bwd():
-        check(lib().psnd_conv1d_cl_bwd(ptr(g1), ptr(g2), ptr(act), 0.1, ptr(w), ptr(x), N, Lp, Fr, HP, C, C, k, dil, dil, ptr(gx), None,
-                                       ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
+        # the launch as it runs inside a residual block: one plain incoming gradient, epilogue forms the next conv's
+        check(lib().psnd_conv1d_cl_bwd(ptr(g1), None, None, 0.1, ptr(w), ptr(x), N, Lp, Fr, HP, C, C, k, dil, dil, ptr(gx), None,
+                                       ptr(act), 0.1, ptr(g1), ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
 
     res = {}
     for name, f, gemms in (('forward', fwd, 1), ('backward_pair', bwd, 2)):

@@ -165,10 +165,13 @@ typedef struct psnd_wnorm_desc {
 int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, void *stream);
 /* backward of one conv in ONE launch: gx = input gradient (Ca channels, via the transposed pack wb, taps mirrored) and the
  * partial weight-gradient slabs gw_part / gbias_part (as psnd_conv1d_cl_wgrad), both from g = G1 + G2 * leaky'(GM); g_out (may
- * be NULL) receives the combined g for the residual branch (needs G2). */
+ * be NULL) receives the combined g for the residual branch (needs G2).  gx_mask / gx_res (CL bf16, Ca channels, may be NULL):
+ * epilogue of the input gradient, gx = gx * leaky'(gx_mask; gx_mask_slope) + gx_res - i.e. the NEXT conv's combined incoming gradient
+ * (its own leaky-relu derivative and the residual branch) is formed here, so that conv's backward needs no combine on load. */
 int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                        int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
-                       float *gw_part, float *gbias_part, void *stream);
+                       const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
+                       void *stream);
 int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);

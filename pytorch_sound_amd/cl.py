@@ -232,8 +232,8 @@ class FusedConvCL(torch.autograd.Function):
             gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
             with torch.cuda.device(dev):
                 check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(wb), ptr(xa), shape.N,
-                                               shape.Lp, shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(gw), ptr(gbp),
-                                               stream_ptr(dev)), 'psnd_conv1d_cl_bwd')
+                                               shape.Lp, shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), None, 1.0, None,
+                                               ptr(gw), ptr(gbp), stream_ptr(dev)), 'psnd_conv1d_cl_bwd')
                 check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
                                                   ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
         else:
@@ -407,13 +407,23 @@ class ResBlockCL(torch.autograd.Function):
         res_pending = None
         with torch.cuda.device(dev):
             st = stream_ptr(dev)
+            # The gradient a conv receives is  g = g_raw + g_act * leaky'(own activated output).  Only the block's LAST conv gets
+            # the two parts from outside and combines them on load; every earlier conv's g is formed in the EPILOGUE of the input-
+            # gradient role that produces g_act (mask by the activation, add the residual branch's gradient), so its own backward
+            # reads ONE plain tensor in both roles - and that tensor also is the gradient handed on along the residual stream.
+            g_comb = None                      # combined incoming gradient of conv i (None for the block's last conv)
+            res_pending = None                 # pairs: gradient on the residual stream behind the pair being walked
             for i in range(n - 1, -1, -1):
                 Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias = steps[i]
                 inp, act, wb, v32, g32 = saved[5 * i:5 * i + 5]
-                if g_raw is None and g_act is None:
-                    raise _lib.PsndError('CL residual block backward: no incoming gradient')
-                am = act if g_act is not None else None
-                need_gout = has_res and g_act is not None
+                if g_comb is None:
+                    if g_raw is None and g_act is None:
+                        raise _lib.PsndError('CL residual block backward: no incoming gradient')
+                    G1, G2 = g_raw, g_act
+                    am = act if g_act is not None else None
+                    need_gout = has_res and g_act is not None
+                else:
+                    G1, G2, am, need_gout = g_comb, None, None, False
                 S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb, k)
                 gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
                 gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
@@ -421,22 +431,30 @@ class ResBlockCL(torch.autograd.Function):
                 gv, gg = torch.empty_like(v32), torch.empty_like(g32)
                 gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
                 g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
-                check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
-                                               shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(gw), ptr(gbp), st),
-                      'psnd_conv1d_cl_bwd')
+                g_here = g_out if need_gout else G1          # this conv's combined gradient (= what its residual input receives)
+                # epilogue of the input gradient: the previous conv's activated output is this conv's input `inp`
+                if i == 0:
+                    ep_mask, ep_res = None, None               # leaves the block: (g_x, g_xa) are returned apart
+                elif ctx.pairs and has_res:                    # conv2 -> conv1 of the same pair (no residual in between)
+                    ep_mask, ep_res = inp, None
+                elif ctx.pairs:                                # conv1 -> conv2 of the previous pair: + the residual stream's gradient
+                    ep_mask, ep_res = inp, res_pending
+                else:                                          # ResBlock2: every conv carries the residual
+                    ep_mask, ep_res = inp, g_here
+                check(lib().psnd_conv1d_cl_bwd(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
+                                               shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(ep_mask), float(steps[i - 1][7] if i > 0 else 1.0), ptr(ep_res),
+                                               ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
                                        gg.data_ptr(), gb.data_ptr(), S, Cout, Cin, k, Cb, Ca)
-                keep += [gw, gbp]
+                keep += [gw, gbp, G1, G2, g_out]
                 grads[3 * i], grads[3 * i + 1] = gv, gg
                 grads[3 * i + 2] = gb[:Cout] if has_bias else None
-                g_res = (g_out if need_gout else g_raw) if has_res else None
-                if ctx.pairs:
-                    if has_res:                       # conv2 of a pair: its input is conv1's activated output
-                        res_pending, g_raw, g_act = g_res, None, gx
-                    else:                             # conv1: back on the residual stream
-                        g_raw, g_act = res_pending, gx
-                else:
-                    g_raw, g_act = g_res, gx
+                if ctx.pairs and has_res:
+                    res_pending = g_here
+                if i > 0:
+                    g_comb = gx
+                else:                                          # gradients wrt the block's inputs (x, xa)
+                    g_raw, g_act = (res_pending if ctx.pairs else g_here), gx
             for j0 in range(0, n, 8):
                 chunk = descs[j0:j0 + 8]
                 buf = ctypes.create_string_buffer(b''.join(chunk))

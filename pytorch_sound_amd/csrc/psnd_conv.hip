@@ -978,7 +978,8 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 // 32-bit offsets) the two kernels are enqueued one after the other, same results.
 extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                                   int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
-                                  float *gw_part, float *gbias_part, void *stream) {
+                                  const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
+                                  void *stream) {
     static const bool no_pair = getenv("PSND_NO_BWD_PAIR") != nullptr;
     int hm = 0;
     for (int j = 0; j < k; ++j) {
@@ -992,17 +993,18 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     if (!pairable) {
         int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
         if (rc != PSND_OK) return rc;
-        return psnd_conv1d_cl(G1, G2, GM, g2_slope, wb, nullptr, nullptr, nullptr, N, Lp, L, HP, Cb, Ca, k, pad, -dil, 1.f, 1.f, gx, nullptr,
-                              g_out, stream);
+        return psnd_conv1d_cl(G1, G2, GM, g2_slope, wb, nullptr, gx_res, gx_mask, N, Lp, L, HP, Cb, Ca, k, pad, -dil, 1.f, gx_mask_slope, gx,
+                              nullptr, g_out, stream);
     }
     // input-gradient role: a conv from Cb to Ca channels
     ConvParams pc;
     pc.A = static_cast<const bf16_t *>(G1), pc.A2 = static_cast<const bf16_t *>(G2), pc.AM = static_cast<const bf16_t *>(GM);
     pc.a2_slope = g2_slope;
-    pc.W = static_cast<const bf16_t *>(wb), pc.bias = nullptr, pc.res = nullptr, pc.mask_src = nullptr;
+    pc.W = static_cast<const bf16_t *>(wb), pc.bias = nullptr;
+    pc.res = static_cast<const bf16_t *>(gx_res), pc.mask_src = static_cast<const bf16_t *>(gx_mask);
     pc.out_raw = static_cast<bf16_t *>(gx), pc.out_act = nullptr, pc.a_eff_out = static_cast<bf16_t *>(g_out);
     pc.R = N * (int64_t)Lp, pc.Lp = Lp, pc.L = L, pc.HP = HP, pc.Ca = Cb, pc.Cb = Ca, pc.k = k, pc.off0 = pad, pc.dstep = -dil, pc.hm = hm;
-    pc.act_slope = 1.f, pc.mask_slope = 1.f;
+    pc.act_slope = 1.f, pc.mask_slope = gx_mask_slope;
     // weight-gradient role
     WgradParams pw;
     pw.G1 = pc.A, pw.G2 = pc.A2, pw.GM = pc.AM;
