@@ -472,7 +472,7 @@ def _block_node(convs, x, xa, shape, pairs, last_act_slope, want_raw, prep):
 
 def _use_block_node(convs, x):
     import os
-    return (os.environ.get('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 8
+    return (os.environ.get('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 64
             and all(c.weight_v.shape[0] == c.weight_v.shape[1] for c in convs))
 
 
@@ -488,6 +488,23 @@ def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=No
         last = i == n - 1
         x, xa = fused_conv(ta, c2, shape, x, (not last) or want_raw, True, last_act_slope if last else 0.1, prep)
     return x, xa
+
+
+def resblock1_stack_cl(blocks, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):
+    """consecutive ResBlock1 blocks on one residual stream (the separator's body) as ONE autograd node: the chain of
+    (conv1, conv2 + residual) pairs simply continues across the block boundaries."""
+    convs = [c for b in blocks for pair in zip(b.convs1, b.convs2) for c in pair]
+    if _use_block_node(convs, x) and _stack_enabled():
+        return _block_node(convs, x, xa, shape, True, last_act_slope, want_raw, prep)
+    for i, b in enumerate(blocks):
+        last = i == len(blocks) - 1
+        x, xa = resblock1_cl(b, x, xa, shape, last_act_slope if last else 0.1, want_raw or not last, prep)
+    return x, xa
+
+
+def _stack_enabled():
+    import os
+    return os.environ.get('PSND_NO_BLOCK_STACK') != '1'        # A/B switch: one node per block instead
 
 
 def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):

@@ -45,8 +45,7 @@ class ConvSeparator(nn.Module):
         prep = cl.prep_all(self, convs)                                            # all weight-norm packs: one launch
         x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
         x, xa = cl.fused_conv(x0, self.conv_pre, shape, None, True, True, LRELU_SLOPE, prep)
-        for block in self.blocks:
-            x, xa = cl.resblock1_cl(block, x, xa, shape, prep=prep)
+        x, xa = cl.resblock1_stack_cl(list(self.blocks), x, xa, shape, prep=prep)    # all blocks: one autograd node
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         if mag.dtype == torch.float32 and not mag.requires_grad:
             return cl.MaskHeadCL.apply(y, mag, shape)                               # sigmoid(from_cl(y)) * mag, one pass
