@@ -351,7 +351,10 @@ class ResBlockCL(torch.autograd.Function):
     autograd bookkeeping.  params: (weight_v, weight_g, bias) per conv, flattened; packs: per conv (wf, wb, bp) or None."""
 
     @staticmethod
-    def forward(ctx, x, xa, shape, pairs, dils, last_act_slope, want_raw, packs, *params):
+    def forward(ctx, x, xa, shape, roles, dils, last_act_slope, want_raw, packs, *params):
+        """roles[i]:  'c1' / 'c2' the two convs of a ResBlock1 pair, 'r2' a ResBlock2 conv (conv + residual), 'head' a plain conv in
+        front of the chain (input xa, raw + activated output start the residual stream; x is None), 'tail' a plain conv behind it
+        (activated input, raw output only - returned as the first output, the second is None)."""
         _need(xa, torch.bfloat16)
         dev = xa.device
         n = len(dils)
@@ -360,9 +363,11 @@ class ResBlockCL(torch.autograd.Function):
         for i in range(n):
             wv, wg, b = params[3 * i:3 * i + 3]
             Cout, Cin, k = wv.shape
-            Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
-            if Ca != round_up(Cin, ALIGN_C) or Cb != Ca:
-                raise _lib.PsndError('CL residual block: %d -> %d channels on a %d-channel buffer' % (Cin, Cout, Ca))
+            role = roles[i]
+            src = pending if role == 'c2' else cur_xa
+            Ca, Cb = src.shape[2], round_up(Cout, ALIGN_C)
+            if Ca != round_up(Cin, ALIGN_C) or (role in ('c2', 'r2') and Cb != cur_x.shape[2]):
+                raise _lib.PsndError('CL conv chain: %s conv %d -> %d channels on a %d-channel buffer' % (role, Cin, Cout, Ca))
             dil = dils[i]
             pad = (k * dil - dil) // 2
             v32, g32 = wv.detach().contiguous(), wg.detach().contiguous()
@@ -376,20 +381,21 @@ class ResBlockCL(torch.autograd.Function):
                 with torch.cuda.device(dev):
                     check(lib().psnd_conv1d_prep(ptr(v32), ptr(g32), ptr(b32), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
                                                  stream_ptr(dev)), 'psnd_conv1d_prep')
-            first_of_pair = pairs and i % 2 == 0
-            if first_of_pair:                              # conv1: activated output only, no residual
-                inp, slope, has_res = cur_xa, 0.1, False
+            last = i == n - 1
+            inp, slope, has_res = src, (last_act_slope if last else 0.1), role in ('c2', 'r2')
+            if role == 'c1':                               # activated output only, no residual
                 _, act = _launch_conv(inp, None, None, 1.0, wf, bp, None, None, shape, Ca, Cb, k, -pad, dil, slope, 1.0, False, True)
                 pending = act
-            else:
-                last = i == n - 1
-                inp, slope, has_res = (pending if pairs else cur_xa), (last_act_slope if last else 0.1), True
-                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, cur_x, None, shape, Ca, Cb, k, -pad, dil, slope, 1.0,
-                                        (not last) or want_raw, True)
+            elif role == 'tail':                           # raw output only
+                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, None, None, shape, Ca, Cb, k, -pad, dil, 1.0, 1.0, True, False)
+                cur_x, cur_xa = raw, None
+            else:                                          # 'head' (no residual) / 'c2' / 'r2': raw + activated output
+                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, cur_x if has_res else None, None, shape, Ca, Cb, k, -pad, dil,
+                                        slope, 1.0, (not last) or want_raw, True)
                 cur_x, cur_xa = raw, act
-            steps.append((Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, b is not None))
-            saved += [inp, act, wb, v32, g32]
-        ctx.steps, ctx.shape, ctx.pairs = steps, shape, pairs
+            steps.append((Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, b is not None, role))
+            saved += [inp, act if act is not None else inp, wb, v32, g32]
+        ctx.steps, ctx.shape = steps, shape
         ctx.save_for_backward(*saved)
         return cur_x, cur_xa
 
@@ -414,11 +420,11 @@ class ResBlockCL(torch.autograd.Function):
             g_comb = None                      # combined incoming gradient of conv i (None for the block's last conv)
             res_pending = None                 # pairs: gradient on the residual stream behind the pair being walked
             for i in range(n - 1, -1, -1):
-                Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias = steps[i]
+                Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias, role = steps[i]
                 inp, act, wb, v32, g32 = saved[5 * i:5 * i + 5]
                 if g_comb is None:
                     if g_raw is None and g_act is None:
-                        raise _lib.PsndError('CL residual block backward: no incoming gradient')
+                        raise _lib.PsndError('CL conv chain backward: no incoming gradient')
                     G1, G2 = g_raw, g_act
                     am = act if g_act is not None else None
                     need_gout = has_res and g_act is not None
@@ -429,32 +435,44 @@ class ResBlockCL(torch.autograd.Function):
                 gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
                 gb = torch.empty(Cb, dtype=torch.float32, device=dev)
                 gv, gg = torch.empty_like(v32), torch.empty_like(g32)
-                gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
                 g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
                 g_here = g_out if need_gout else G1          # this conv's combined gradient (= what its residual input receives)
-                # epilogue of the input gradient: the previous conv's activated output is this conv's input `inp`
-                if i == 0:
-                    ep_mask, ep_res = None, None               # leaves the block: (g_x, g_xa) are returned apart
-                elif ctx.pairs and has_res:                    # conv2 -> conv1 of the same pair (no residual in between)
-                    ep_mask, ep_res = inp, None
-                elif ctx.pairs:                                # conv1 -> conv2 of the previous pair: + the residual stream's gradient
-                    ep_mask, ep_res = inp, res_pending
-                else:                                          # ResBlock2: every conv carries the residual
-                    ep_mask, ep_res = inp, g_here
-                check(lib().psnd_conv1d_cl_bwd(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
-                                               shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(ep_mask), float(steps[i - 1][7] if i > 0 else 1.0), ptr(ep_res),
-                                               ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
+                if i == 0 and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+                    # the chain's input needs no gradient (features): weight gradient only
+                    gx = None
+                    check(lib().psnd_conv1d_cl_wgrad(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(inp), shape.N, shape.Lp, Ca, Cb, k,
+                                                     -pad, dil, ptr(gw), ptr(gbp), None, st), 'psnd_conv1d_cl_wgrad')
+                    g_raw = g_act = None
+                else:
+                    gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+                    # epilogue of the input gradient: this conv's input `inp` is the previous conv's activated output
+                    if i == 0:
+                        ep_mask, ep_res = None, None           # leaves the chain: (g_x, g_xa) are returned apart
+                    elif role == 'c1':                         # -> conv2 / head before it: + the residual stream's gradient
+                        ep_mask, ep_res = inp, res_pending
+                    elif role == 'r2':                         # ResBlock2: every conv carries the residual
+                        ep_mask, ep_res = inp, g_here
+                    else:                                      # 'c2' -> its conv1, 'tail' -> the last conv of the stack
+                        ep_mask, ep_res = inp, None
+                    check(lib().psnd_conv1d_cl_bwd(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
+                                                   shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(ep_mask),
+                                                   float(steps[i - 1][7] if i > 0 else 1.0), ptr(ep_res), ptr(gw), ptr(gbp), st),
+                          'psnd_conv1d_cl_bwd')
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
                                        gg.data_ptr(), gb.data_ptr(), S, Cout, Cin, k, Cb, Ca)
                 keep += [gw, gbp, G1, G2, g_out]
                 grads[3 * i], grads[3 * i + 1] = gv, gg
                 grads[3 * i + 2] = gb[:Cout] if has_bias else None
-                if ctx.pairs and has_res:
+                if role == 'c2':
                     res_pending = g_here
                 if i > 0:
                     g_comb = gx
+                elif gx is None:
+                    pass
+                elif role == 'head':                           # gradient wrt the chain's input buffer
+                    g_raw, g_act = None, gx
                 else:                                          # gradients wrt the block's inputs (x, xa)
-                    g_raw, g_act = (res_pending if ctx.pairs else g_here), gx
+                    g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
             for j0 in range(0, n, 8):
                 chunk = descs[j0:j0 + 8]
                 buf = ctypes.create_string_buffer(b''.join(chunk))
@@ -467,13 +485,28 @@ def _block_node(convs, x, xa, shape, pairs, last_act_slope, want_raw, prep):
     for c in convs:
         params += [c.weight_v, c.weight_g, c.bias]
     packs = None if prep is None else [prep[id(c)] for c in convs]
-    return ResBlockCL.apply(x, xa, shape, pairs, tuple(c.dilation for c in convs), last_act_slope, want_raw, packs, *params)
+    roles = pairs if isinstance(pairs, tuple) else (('c1', 'c2') * (len(convs) // 2) if pairs else ('r2',) * len(convs))
+    return ResBlockCL.apply(x, xa, shape, roles, tuple(c.dilation for c in convs), last_act_slope, want_raw, packs, *params)
 
 
 def _use_block_node(convs, x):
     import os
     return (os.environ.get('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 64
             and all(c.weight_v.shape[0] == c.weight_v.shape[1] for c in convs))
+
+
+def conv_body_cl(head, blocks, tail, x0, shape, prep=None):
+    """head conv -> ResBlock1 blocks -> tail conv (the separator's whole body: conv_pre, blocks, conv_post) as ONE autograd node.
+    x0: activated CL input of the head conv.  Returns the tail conv's raw output."""
+    import os
+    stack = [c for b in blocks for pair in zip(b.convs1, b.convs2) for c in pair]
+    if os.environ.get('PSND_NO_BODY_NODE') == '1' or os.environ.get('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled():
+        x, xa = fused_conv(x0, head, shape, None, True, True, 0.1, prep)
+        x, xa = resblock1_stack_cl(blocks, x, xa, shape, prep=prep)
+        return fused_conv(xa, tail, shape, None, True, False, prep=prep)[0]
+    convs = [head] + stack + [tail]
+    roles = ('head',) + ('c1', 'c2') * (len(stack) // 2) + ('tail',)
+    return _block_node(convs, None, x0, shape, roles, 0.1, True, prep)[0]
 
 
 def resblock1_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):

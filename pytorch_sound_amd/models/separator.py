@@ -44,9 +44,7 @@ class ConvSeparator(nn.Module):
         convs = [self.conv_pre] + [c for b in self.blocks for c in list(b.convs1) + list(b.convs2)] + [self.conv_post]
         prep = cl.prep_all(self, convs)                                            # all weight-norm packs: one launch
         x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
-        x, xa = cl.fused_conv(x0, self.conv_pre, shape, None, True, True, LRELU_SLOPE, prep)
-        x, xa = cl.resblock1_stack_cl(list(self.blocks), x, xa, shape, prep=prep)    # all blocks: one autograd node
-        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
+        y = cl.conv_body_cl(self.conv_pre, list(self.blocks), self.conv_post, x0, shape, prep)     # 26 convs: one autograd node
         if mag.dtype == torch.float32 and not mag.requires_grad:
             return cl.MaskHeadCL.apply(y, mag, shape)                               # sigmoid(from_cl(y)) * mag, one pass
         logits = cl.FromCL.apply(y, C, T, shape)

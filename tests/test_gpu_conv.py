@@ -92,6 +92,38 @@ def test_separator_cl_matches_torch_path():
         assert relf(p.grad, gref[k]) < 5e-2, k
 
 
+@pytest.mark.parametrize('env', [None, 'PSND_NO_BODY_NODE', 'PSND_NO_BLOCK_STACK', 'PSND_NO_BLOCK_NODE'])
+def test_separator_input_gradient_and_node_granularities(env, monkeypatch):
+    """the separator body as one autograd node (default), as head / block-stack / tail nodes, one node per block, one node per conv:
+    same output and parameter gradients, and the gradient wrt the INPUT magnitude (the head conv's input-gradient role, skipped when
+    the features need no gradient) against the fp32 torch formulation."""
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    if env:
+        monkeypatch.setenv(env, '1')
+    dev = torch.device('cuda:0')
+    torch.manual_seed(1)
+    model = build_model('conv_separator_voicebank', {'channels': 64, 'num_blocks': 2}).to(dev)
+    mag0 = torch.rand(2, 513, 70, device=dev) * 4
+    tgt = torch.rand(2, 513, 70, device=dev)
+    mag = mag0.clone().requires_grad_(True)
+    x = model.conv_pre(torch.log1p(mag))
+    for b in model.blocks:
+        x = b(x)
+    ref = torch.sigmoid(model.conv_post(F.leaky_relu(x, 0.1))) * mag
+    (ref - tgt).abs().mean().backward()
+    gref = {k: p.grad.clone() for k, p in model.named_parameters()}
+    gmag_ref = mag.grad.clone()
+    model.zero_grad()
+    mag2 = mag0.clone().requires_grad_(True)
+    out = model(mag2)
+    (out - tgt).abs().mean().backward()
+    assert rel(out, ref) < 2e-2
+    assert relf(mag2.grad, gmag_ref) < 5e-2
+    for k, p in model.named_parameters():
+        assert relf(p.grad, gref[k]) < 5e-2, k
+
+
 def test_trainer_device_side_nan_skip():
     """fused optimizer + no scheduler: the NaN step is skipped by the optimizer kernel (no host sync); the
     parameters after the run equal those of a run that never saw the poisoned batch; the log line still appears."""
