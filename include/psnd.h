@@ -153,9 +153,9 @@ int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout
  *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written
  *   (zero them once when allocating). */
 int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
-/* psnd_conv1d_wnorm_bwd for up to PSND_WNORM_MAX convs (e.g. the six of a ResBlock1) in one launch; descs is a HOST array,
+/* psnd_conv1d_wnorm_bwd for up to PSND_WNORM_MAX convs (the six of a ResBlock1, the 26 of the separator body) in one launch; descs is a HOST array,
  * passed to the kernel by value (nothing is uploaded, the launch can be captured in a hipGraph). */
-#define PSND_WNORM_MAX 8
+#define PSND_WNORM_MAX 32
 typedef struct psnd_wnorm_desc {
     const float *gw_part, *gbias_part;      /* slabs of psnd_conv1d_cl_wgrad / psnd_conv1d_cl_bwd (gbias_part may be NULL) */
     const float *v, *g;                     /* weight_v (Cout,Cin,k), weight_g (Cout)                                      */

@@ -473,8 +473,8 @@ class ResBlockCL(torch.autograd.Function):
                     g_raw, g_act = None, gx
                 else:                                          # gradients wrt the block's inputs (x, xa)
                     g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
-            for j0 in range(0, n, 8):
-                chunk = descs[j0:j0 + 8]
+            for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
+                chunk = descs[j0:j0 + 32]
                 buf = ctypes.create_string_buffer(b''.join(chunk))
                 check(lib().psnd_conv1d_wnorm_bwd_multi(buf, len(chunk), st), 'psnd_conv1d_wnorm_bwd_multi')
         return (g_raw, g_act, None, None, None, None, None, None) + tuple(grads)
