@@ -82,6 +82,31 @@ def test_argument_validation_without_gpu(L):
     assert lib.psnd_stft_bwd(p, 1, 5000, 1024, 256, 0, p, 0.0, None, None, None, p, None) == -1    # no gradient source
 
 
+def test_argument_validation_of_the_wider_entry_points(L):
+    """every entry point added behind the feature path rejects bad arguments before touching the device (0 work sizes are OK)"""
+    lib = L.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.psnd_preemphasis_fwd(p, 1, 1, 0.97, p, None) == -2                      # reflect pad needs T >= 2
+    assert lib.psnd_preemphasis_fwd(None, 1, 8, 0.97, p, None) == -1
+    assert lib.psnd_stft_loss_blocks(0) == 0 and lib.psnd_stft_loss_blocks(8192) == 1 and lib.psnd_stft_loss_blocks(8193) == 2
+    assert lib.psnd_stft_loss_partial(p, p, 0, 10, 1e-5, p, None) == 0               # empty batch: nothing to do
+    assert lib.psnd_stft_loss_final(p, p, 9, 1, p, p, None) == -1                    # more than 8 resolutions
+    assert lib.psnd_l1_loss_blocks(16384) == 1 and lib.psnd_l1_loss_blocks(16385) == 2
+    assert lib.psnd_l1_loss_fwd(p, p, 0, p, p, None) == -2
+    assert lib.psnd_pad_collate(p, p, p, 0, 100, p, None, None) == 0
+    assert lib.psnd_pad_collate(p, p, p, 70000, 100, p, None, None) == -2
+    assert lib.psnd_pqmf_analysis(p, p, 1, 64, 4, 61, 0, 1.0, p, None) == -2           # odd tap count
+    assert lib.psnd_pqmf_analysis(p, p, 1, 64, 17, 62, 0, 1.0, p, None) == -2          # too many subbands
+    assert lib.psnd_pqmf_synthesis(p, p, 0, 16, 64, 4, 62, 0, 4.0, p, None) == 0
+    assert lib.psnd_adam_step(p, 1, p, p, 1, 1e-3, 1.0, 0.999, 1e-8, 0.0, 0, None, None, p, None) == -1    # beta1 = 1
+    assert lib.psnd_adam_step(p, 0, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, p, None) == 0
+    assert lib.psnd_adam_chunk() == 2048 and lib.psnd_adam_table_bytes() == 48
+    assert lib.psnd_conv1d_wnorm_bwd_multi(p, 0, None) == -1 and lib.psnd_conv1d_wnorm_bwd_multi(p, 33, None) == -1
+    assert lib.psnd_mask_head_fwd(None, p, 1, 8, 8, 8, 0, 32, p, None) == -1
+    assert lib.psnd_conv1d_cl(p, None, None, 0.0, p, None, None, None, 1, 16, 8, 4, 32, 40, 3, -1, 1, 0.1, 1.0, p, None, None, None) == -2   # Cb % 32
+
+
 def test_product_has_no_fallback(L, monkeypatch):
     """a CPU tensor or a missing library must raise, never compute on the host."""
     import torch
