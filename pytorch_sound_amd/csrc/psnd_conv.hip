@@ -12,10 +12,12 @@
 //      v = acc (+ bias[co]) ; v *= leaky'(mask_src) ; v += res ; rows outside the clip -> 0
 //      out_raw = bf16(v) (optional) ; out_act = bf16(leaky_relu(v, slope)) (optional)
 //
-// Tiling: 256 threads = 2 x 2 waves, block tile 64 rows x 64 output channels, one v_mfma_f32_32x32x16_bf16
-// accumulator (32 x 32) per wave; K walks input channels in chunks of 32 staged through LDS together with
-// the chunk's weights for all taps (row stride 80 B = conflict-free ds_read_b128 fragments).  The A tile
-// carries its +-HM halo rows, so the k taps re-use one staged tile (that is the implicit-GEMM saving).
+// Tiling: 256 threads = 2 x 2 waves, block tile 64 (or 128) rows x 64 output channels, one (two) v_mfma_f32_32x32x16_bf16
+// accumulator(s) (32 x 32) per wave; K walks input channels in stages of 32.  The A tile of a stage goes through LDS (row
+// stride 80 B = conflict-free ds_read_b128 fragments) and carries its +-HM halo rows, so the k taps re-use one staged tile
+// (that is the implicit-GEMM saving); the weights are packed in MFMA fragment order by the prep kernels and go straight
+// from L2 into the B operand registers (pack_index, conv_cl_body).  The backward of a conv is ONE launch: input-gradient
+// and weight-gradient roles share the grid (conv_bwd_pair_kernel), the weight-norm backward of a whole chain another one.
 #include "psnd_common.h"
 #include <stdlib.h>
 
@@ -37,7 +39,7 @@ struct ConvParams {
     const bf16_t *A;         // (R, Ca)
     const bf16_t *A2;        // (R, Ca) or null: A_eff = A + A2 * (AM > 0 ? 1 : a2_slope)  (A may be null -> 0)
     const bf16_t *AM;        // (R, Ca) sign source for A2
-    const bf16_t *W;         // [k][Cb][Ca]
+    const bf16_t *W;         // [k][Cb][Ca] in fragment order (pack_index)
     const float *bias;       // Cb or null
     const bf16_t *res;       // (R, Cb) or null
     const bf16_t *mask_src;  // (R, Cb) or null: v *= (mask_src > 0 ? 1 : mask_slope)
