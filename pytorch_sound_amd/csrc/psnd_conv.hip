@@ -35,6 +35,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {   // round to nearest even (Na
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair, round to nearest even, ONE instruction (v_cvt_pk_bf16_f32; the integer f2bf above costs ~6)
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2));
+}
+
 struct ConvParams {
     const bf16_t *A;         // (R, Ca)
     const bf16_t *A2;        // (R, Ca) or null: A_eff = A + A2 * (AM > 0 ? 1 : a2_slope)  (A may be null -> 0)
@@ -82,7 +90,7 @@ __device__ __forceinline__ uint4 load_combined(const bf16_t *G1, const bf16_t *G
             const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
             const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
             const float r0 = a0 + b0 * (m0 > 0.f ? 1.f : slope), r1 = a1 + b1 * (m1 > 0.f ? 1.f : slope);
-            out[i] = (unsigned)f2bf(r0) | ((unsigned)f2bf(r1) << 16);
+            out[i] = pack_bf16(r0, r1);
         }
         v = make_uint4(out[0], out[1], out[2], out[3]);
     }
@@ -216,7 +224,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
             const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
             const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
             const float r0_ = a0 + b0 * (m0 > 0.f ? 1.f : p.a2_slope), r1_ = a1 + b1 * (m1 > 0.f ? 1.f : p.a2_slope);
-            out[i] = (unsigned)f2bf(r0_) | ((unsigned)f2bf(r1_) << 16);
+            out[i] = pack_bf16(r0_, r1_);
         }
         return make_uint4(out[0], out[1], out[2], out[3]);
     };
@@ -338,7 +346,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         if (p.out_raw) {
             unsigned w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (unsigned)f2bf(v[2 * e]) | ((unsigned)f2bf(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) w[e] = pack_bf16(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<uint4 *>(p.out_raw + o) = make_uint4(w[0], w[1], w[2], w[3]);
         }
         if (p.out_act) {
@@ -346,7 +354,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x0 = v[2 * e], x1 = v[2 * e + 1];
-                w[e] = (unsigned)f2bf(x0 > 0.f ? x0 : x0 * p.act_slope) | ((unsigned)f2bf(x1 > 0.f ? x1 : x1 * p.act_slope) << 16);
+                w[e] = pack_bf16(x0 > 0.f ? x0 : x0 * p.act_slope, x1 > 0.f ? x1 : x1 * p.act_slope);
             }
             *reinterpret_cast<uint4 *>(p.out_act + o) = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -539,8 +547,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
                     const float a0 = bf2f((bf16_t)(pv[i] & 0xffff)), a1 = bf2f((bf16_t)(pv[i] >> 16));
                     const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
                     const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
-                    out[i] = (unsigned)f2bf(a0 + b0 * (m0 > 0.f ? 1.f : p.g2_slope)) |
-                             ((unsigned)f2bf(a1 + b1 * (m1 > 0.f ? 1.f : p.g2_slope)) << 16);
+                    out[i] = pack_bf16(a0 + b0 * (m0 > 0.f ? 1.f : p.g2_slope), a1 + b1 * (m1 > 0.f ? 1.f : p.g2_slope));
                 }
                 g = make_uint4(out[0], out[1], out[2], out[3]);
             }
