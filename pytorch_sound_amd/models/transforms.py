@@ -397,3 +397,44 @@ class PQMF(torch.nn.Module):
             return K.PqmfSynthesis.apply(x, self.synthesis_filter.squeeze(0), self.subbands, self.taps).unsqueeze(1)
         x = torch.nn.functional.conv_transpose1d(x, self.updown_filter * self.subbands, stride=self.subbands)
         return torch.nn.functional.conv1d(self.pad_fn(x), self.synthesis_filter)
+
+
+class LearnableSTFT(nn.Module):
+    """STFT whose analysis / synthesis bases are trainable (transforms.py:104-203, marked experimental there): the same dense
+    [cos; -sin] bases as ``STFT`` but WITHOUT the window folded in (``fft_window`` is a buffer, multiplied in at every call), as
+    ``nn.Parameter``s when ``trainable_*``.  With trained bases the transform is no longer an FFT, so it runs as the strided
+    (transposed) convolution it is defined as - library kernels, not the FFT path."""
+
+    def __init__(self, filter_length: int = 1024, hop_length: int = 512, win_length: int = None, window: str = 'hann',
+                 trainable_inverse: bool = True, trainable_forward: bool = True):
+        super().__init__()
+        self.filter_length = filter_length
+        self.hop_length = hop_length
+        self.win_length = win_length if win_length else filter_length
+        self.window = window
+        self.pad_amount = self.filter_length // 2
+        assert filter_length >= self.win_length
+        w = centre_pad(periodic_window(window, self.win_length), filter_length)
+        self.register_buffer('fft_window', torch.from_numpy(w).float())
+        fwd, inv = reference_bases(filter_length, hop_length, np.ones(filter_length))          # bases without the window
+        for name, basis, trainable in (('forward_basis', fwd, trainable_forward), ('inverse_basis', inv, trainable_inverse)):
+            t = torch.from_numpy(np.ascontiguousarray(basis)).float()
+            if trainable:
+                setattr(self, name, nn.Parameter(t))
+            else:
+                self.register_buffer(name, t)
+
+    def transform(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = torch.nn.functional.pad(wav.unsqueeze(1), (self.pad_amount, self.pad_amount), mode='reflect')
+        spec = torch.nn.functional.conv1d(x, self.forward_basis * self.fft_window, stride=self.hop_length)
+        re, im = spec.chunk(2, 1)
+        return torch.sqrt(re ** 2 + im ** 2), torch.atan2(im.data, re.data)
+
+    def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
+        spec = torch.cat([magnitude * torch.cos(phase), magnitude * torch.sin(phase)], dim=1)
+        y = torch.nn.functional.conv_transpose1d(spec, self.inverse_basis * self.fft_window, stride=self.hop_length)
+        # squared-window overlap-add envelope, as STFT.inverse
+        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, spec.size(-1), dtype=y.dtype, device=y.device),
+                                                   (self.fft_window ** 2).view(1, 1, -1), stride=self.hop_length)
+        y = y / (env.squeeze() + eps) * (self.filter_length / self.hop_length)
+        return y[..., self.pad_amount:-self.pad_amount].squeeze(1)

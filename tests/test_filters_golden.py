@@ -70,3 +70,27 @@ def test_spectrogram_masker_host():
     # frames = (32 + 8 - 8) / 4 + 1 = 9; clip 0: frames touching a valid sample (or the ones-padded left edge) are 1
     assert out.shape == (2, 9) and out[1].tolist() == [1.0] * 9
     assert out[0].tolist() == [1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+
+
+def test_learnable_stft_matches_reference():
+    """LearnableSTFT (transforms.py:104-203): buffers / parameters, transform, inverse and the gradients wrt both trainable
+    bases against the imported reference (tests/golden/lstft.npz)."""
+    from pytorch_sound_amd.models.transforms import LearnableSTFT
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'lstft.npz'))
+    m = LearnableSTFT(256, 64, 200)
+    assert sorted(m.state_dict().keys()) == list(g['state_keys'])
+    assert isinstance(m.forward_basis, torch.nn.Parameter) and isinstance(m.inverse_basis, torch.nn.Parameter)
+    mag, phase = m.transform(torch.from_numpy(g['wav']))
+    rec = m.inverse(mag, phase)
+    (mag.sum() + rec.pow(2).sum()).backward()
+    assert np.abs(mag.detach().numpy() - g['mag']).max() < 2e-5 * np.abs(g['mag']).max()
+    strong = g['mag'] > 1e-3 * g['mag'].max()
+    d = np.angle(np.exp(1j * (phase.numpy() - g['phase'])))
+    assert np.abs(d[strong]).max() < 1e-3
+    assert np.abs(rec.detach().numpy() - g['rec']).max() < 1e-4 * np.abs(g['rec']).max()
+    rows = [0, 1, 64, 129, 200, 257]
+    gf, gi = m.forward_basis.grad.numpy()[rows], m.inverse_basis.grad.numpy()[rows]
+    assert np.abs(gf - g['g_forward_basis_rows']).max() < 1e-3 * max(np.abs(g['g_forward_basis_rows']).max(), 1e-6)
+    assert np.abs(gi - g['g_inverse_basis_rows']).max() < 1e-3 * max(np.abs(g['g_inverse_basis_rows']).max(), 1e-6)
+    frozen = LearnableSTFT(256, 64, trainable_inverse=False, trainable_forward=False)
+    assert not list(frozen.parameters()) and len(frozen.state_dict()) == 3

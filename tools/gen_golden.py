@@ -586,10 +586,29 @@ def gen_filters():
     np.savez_compressed(os.path.join(OUT, 'filters.npz'), **out)
 
 
+def gen_lstft():
+    """LearnableSTFT (transforms.py:104-203, experimental in the reference): transform / inverse and the gradient wrt the bases."""
+    from pytorch_sound.models import transforms as rt
+    out = {}
+    m = rt.LearnableSTFT(256, 64, 200)
+    wav = torch.from_numpy(seeded_wav(960, 2, 2048))
+    mag, phase = m.transform(wav)
+    rec = m.inverse(mag, phase)
+    (mag.sum() + rec.pow(2).sum()).backward()
+    out['wav'] = wav.numpy()
+    out['mag'] = mag.detach().numpy()
+    out['phase'] = phase.detach().numpy()
+    out['rec'] = rec.detach().numpy()
+    out['g_forward_basis_rows'] = m.forward_basis.grad.numpy()[[0, 1, 64, 129, 200, 257]]
+    out['g_inverse_basis_rows'] = m.inverse_basis.grad.numpy()[[0, 1, 64, 129, 200, 257]]
+    out['state_keys'] = np.asarray(sorted(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, 'lstft.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data', 'filters']
+    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data', 'filters', 'lstft']
     for w in which:
         print('generating', w, flush=True)
         globals()['gen_' + w]()
