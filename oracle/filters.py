@@ -77,3 +77,18 @@ def pqmf_synthesis(x, hs):
     for j in range(nt):
         y += (hs[None, :, j, None] * up[:, :, j:j + M * S]).sum(1)
     return y[:, None, :]
+
+
+def mel_filterbank_htk(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """torchaudio.functional.melscale_fbanks(n_fft // 2 + 1, fmin, fmax, n_mels, sr, norm=None, mel_scale='htk') transposed to
+    (n_mels, n_freqs): triangles of unit peak between HTK-mel-equidistant corner frequencies (float64).  Values unpinned by the
+    reference (torchaudio absent): known answers in tests/test_filters_golden.py."""
+    fmax = float(sr // 2) if fmax is None else float(fmax)
+    freqs = np.linspace(0.0, sr // 2, n_fft // 2 + 1)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)          # noqa: E731
+    pts = 700.0 * (10.0 ** (np.linspace(mel(float(fmin)), mel(fmax), n_mels + 2) / 2595.0) - 1.0)
+    fb = np.zeros((n_mels, freqs.size))
+    for m in range(n_mels):
+        lo, ce, hi = pts[m], pts[m + 1], pts[m + 2]
+        fb[m] = np.maximum(0.0, np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)))
+    return fb

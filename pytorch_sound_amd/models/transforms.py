@@ -438,3 +438,29 @@ class LearnableSTFT(nn.Module):
                                                    (self.fft_window ** 2).view(1, 1, -1), stride=self.hop_length)
         y = y / (env.squeeze() + eps) * (self.filter_length / self.hop_length)
         return y[..., self.pad_amount:-self.pad_amount].squeeze(1)
+
+
+class LogMelSpectrogramTorchAudio(nn.Module):
+    """Drop-in for transforms.py:369-394: torchaudio's MelSpectrogram (POWER spectrogram of torch.stft with a hann window of
+    ``win_length`` centre-padded to ``n_fft``, HTK mel triangles of unit peak) -> ln(mel + log_offset) -> clamp to the dB range.
+    torchaudio is not needed: the STFT is psnd_stft_fwd/bwd, the filterbank is restated (utils/mel.py:mel_filterbank_htk) and
+    runs on the mel kernel."""
+
+    def __init__(self, sample_rate: int, mel_size: int, n_fft: int, win_length: int, hop_length: int, min_db: float,
+                 max_db: float, mel_min: float = 0., mel_max: float = None):
+        super().__init__()
+        from pytorch_sound_amd.utils.mel import mel_filterbank_htk
+        self.mel_size = mel_size
+        self.min_db = np.log(np.power(10, min_db / 10))
+        self.max_db = np.log(np.power(10, max_db / 10))
+        self.stft = STFTTorchAudio(win_length, hop_length, win_length, n_fft)
+        self.register_buffer('mel_filter', torch.from_numpy(mel_filterbank_htk(sample_rate, n_fft, mel_size, mel_min, mel_max)))
+        self._plans = _PlanCache()
+
+    def forward(self, wav: torch.Tensor, log_offset: float = 1e-6) -> torch.Tensor:
+        st = self.stft
+        wav = _as_2d(wav)
+        mag = K.StftMagPhase.apply(wav, st._plan(wav.device), st.n_fft, st.hop_length, K.FRAMING_CENTER, 0.0, False)[0]
+        mf = self.mel_filter
+        plan = self._plans.get(('mel', mf._version, mf.data_ptr()), mf.device, lambda: K.mel_plan(mf.detach().cpu().numpy()))
+        return K.MelLog.apply(mag * mag, plan, self.mel_size, K.LOG_E, float(log_offset), None, float(self.min_db), float(self.max_db))

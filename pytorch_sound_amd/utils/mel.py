@@ -40,3 +40,20 @@ def mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None) -> np.ndarray:
     tri = np.maximum(0.0, np.minimum(rise, fall)).astype(np.float32)    # librosa stores float32 here
     area_norm = 2.0 / (edges[2:] - edges[:-2])
     return (tri.astype(np.float64) * area_norm[:, None]).astype(np.float32)
+
+
+def mel_filterbank_htk(sr, n_fft, n_mels, fmin=0.0, fmax=None) -> np.ndarray:
+    """(n_mels, n_fft // 2 + 1) float32 triangular filters on the HTK mel scale, peak 1, no area normalisation - what
+    torchaudio.transforms.MelSpectrogram builds by default (melscale_fbanks(norm=None, mel_scale='htk')), used by the
+    reference's LogMelSpectrogramTorchAudio (transforms.py:369-394)."""
+    fmax = float(sr // 2) if fmax is None else float(fmax)
+    n_freqs = n_fft // 2 + 1
+    all_freqs = np.linspace(0.0, sr // 2, n_freqs)
+    to_mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)       # noqa: E731
+    to_hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)      # noqa: E731
+    f_pts = to_hz(np.linspace(to_mel(float(fmin)), to_mel(fmax), n_mels + 2))
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]                  # (n_freqs, n_mels + 2)
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).T.astype(np.float32)

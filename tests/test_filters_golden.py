@@ -94,3 +94,18 @@ def test_learnable_stft_matches_reference():
     assert np.abs(gi - g['g_inverse_basis_rows']).max() < 1e-3 * max(np.abs(g['g_inverse_basis_rows']).max(), 1e-6)
     frozen = LearnableSTFT(256, 64, trainable_inverse=False, trainable_forward=False)
     assert not list(frozen.parameters()) and len(frozen.state_dict()) == 3
+
+
+def test_htk_filterbank_known_answers():
+    from pytorch_sound_amd.utils.mel import mel_filterbank_htk
+    fb = of.mel_filterbank_htk(22050, 1024, 80, 0.0, 8000.0)
+    assert fb.shape == (80, 513) and fb.min() >= 0.0 and fb.max() <= 1.0
+    hz = np.linspace(0, 11025, 513)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)            # noqa: E731
+    centres = 700.0 * (10.0 ** (np.linspace(mel(0.0), mel(8000.0), 82) / 2595.0) - 1.0)[1:-1]
+    peak = hz[fb.argmax(1)]
+    assert np.abs(peak - centres).max() <= 11025 / 512              # every triangle peaks at its centre frequency (bin resolution)
+    assert fb[:, hz > 8000.0 + 22].max() == 0.0                     # nothing above fmax
+    inner = (hz > centres[0]) & (hz < centres[-1])
+    assert np.allclose(fb[:, inner].sum(0), 1.0, atol=1e-9)         # neighbouring unit-peak triangles sum to one in between
+    assert np.abs(mel_filterbank_htk(22050, 1024, 80, 0.0, 8000.0) - fb).max() < 1e-6

@@ -92,3 +92,27 @@ def test_spectrogram_masker_device():
     out = sm(mask)
     assert out.device.type == 'cuda' and out.shape == (3, 87)
     assert out[1].min() == 1 and out[2, 3:].max() == 0 and out[0].sum() == np.ceil((5000 + 512) / 256)
+
+
+def test_logmel_torchaudio_variant_vs_oracle():
+    """LogMelSpectrogramTorchAudio: power spectrogram (hann(win) centre-padded to n_fft) x HTK triangles -> ln -> clamp, against the
+    float64 oracle (STFT magnitude oracle squared, oracle/filters.py filterbank); forward 2e-5 on the log scale, waveform gradient 2e-4."""
+    from pytorch_sound_amd.models.transforms import LogMelSpectrogramTorchAudio
+    from conftest import seeded_wav
+    from oracle import features as fe
+    m = LogMelSpectrogramTorchAudio(22050, 80, 1024, 800, 256, -80.0, 20.0, 0.0, 8000.0).to(DEV)
+    wav = seeded_wav(970, 3, 6000)
+    x = torch.from_numpy(wav).to(DEV).requires_grad_(True)
+    y = m(x)
+    win = fe.pad_center(m.stft.window.cpu().numpy().astype(np.float64), 1024)
+    mag = fe.stft_mag_f64(wav, 1024, 256, framing=fe.CENTER, window=win)
+    fb = of.mel_filterbank_htk(22050, 1024, 80, 0.0, 8000.0)
+    lin = np.matmul(fb, mag ** 2)
+    want = np.clip(np.log(lin + 1e-6), np.log(10 ** -8.0), np.log(10 ** 2.0))
+    assert y.shape == want.shape and np.abs(y.detach().cpu().numpy() - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+    g = np.random.RandomState(1).randn(*want.shape)
+    (y * torch.from_numpy(g).to(DEV)).sum().backward()
+    inside = (np.log(lin + 1e-6) > np.log(10 ** -8.0)) & (np.log(lin + 1e-6) < np.log(10 ** 2.0))
+    gmag = np.matmul(fb.T, g * inside / (lin + 1e-6)) * 2.0 * mag
+    gw = fe.stft_mag_bwd_f64(gmag, wav, 1024, 256, framing=fe.CENTER, window=win)
+    assert np.abs(x.grad.cpu().numpy() - gw).max() <= 2e-4 * np.abs(gw).max()
