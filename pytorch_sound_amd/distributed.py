@@ -95,7 +95,7 @@ class FlatGradReducer:
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
-        for g in groups:
+        for gi, g in enumerate(groups):
             # every view starts on a 256-byte boundary: the fused optimizer kernels take their vectorised path only
             # for 16-byte aligned gradients (measured on MI355X: 92 us vs 46 us per multi_tensor_apply launch)
             offs, off = [], 0
@@ -104,7 +104,12 @@ class FlatGradReducer:
                     raise TypeError('FlatGradReducer keeps fp32 master gradients; got %s' % p.dtype)
                 offs.append(off)
                 off += (p.numel() + 63) // 64 * 64
+            flag_off = None
+            if gi == len(groups) - 1:        # one spare slot behind the last bucket: the step's NaN flag rides along with the
+                flag_off, off = off, off + 64    # gradients (SUM over ranks > 0 <=> some rank saw a NaN) - no collective of its own
             flat = torch.zeros(off, dtype=torch.float32, device=g[0].device)
+            if flag_off is not None:
+                self._flag = flat[flag_off:flag_off + 1]
             for p, o in zip(g, offs):
                 p.grad = flat[o:o + p.numel()].view_as(p)
             b = {'flat': flat, 'params': g, 'offs': offs, 'pending': len(g), 'work': None}
@@ -145,6 +150,15 @@ class FlatGradReducer:
             for p, v in zip(b['params'], views):
                 p.grad = v
 
+    def set_flag(self, flag):
+        """place this rank's NaN flag (0 / 1) in the spare slot BEFORE the last bucket is reduced"""
+        self._flag.copy_(flag.detach().reshape(1).to(self._flag.dtype))
+
+    @property
+    def flag(self):
+        """after finish(): > 0 iff any rank raised its flag"""
+        return self._flag
+
     def _on_grad(self, p):
         if self.deferred:            # backward is being captured / replayed as a hipGraph: no collective from inside it
             return
@@ -153,9 +167,10 @@ class FlatGradReducer:
         if b['pending'] == 0:
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
 
-    def finish(self):
-        """wait for every bucket, average.  Buckets whose hooks did not all fire (unused parameters)
-        are reduced here so that ranks never diverge."""
+    def finish(self, average: bool = True):
+        """wait for every bucket, average (average=False: the buckets keep the SUM - the caller divides, e.g. through the
+        optimizer kernel's grad_scale).  Buckets whose hooks did not all fire (unused parameters) are reduced here so that
+        ranks never diverge."""
         if self.world <= 1:
             return
         for b in self.buckets:
@@ -163,7 +178,8 @@ class FlatGradReducer:
                 b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
         for b in self.buckets:
             b['work'].wait()
-            b['flat'].mul_(1.0 / self.world)
+            if average:
+                b['flat'].mul_(1.0 / self.world)
             b['work'] = None
             b['pending'] = len(b['params'])
 

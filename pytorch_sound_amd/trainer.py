@@ -266,6 +266,8 @@ class Trainer:
 
     def _train_device_skip(self, step: int, loss: torch.Tensor):
         flag = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+        if self._reducer is not None and pdist.is_dist():
+            self._reducer.set_flag(flag)               # rides along with the last gradient bucket
         loss.backward()
         self._finish_device_skip(step, flag)
 
@@ -311,6 +313,8 @@ class Trainer:
         st['graph'].replay()
         if self._reducer is not None:                  # DDP: into the flat buckets, reduced in _finish_device_skip
             self._reducer.load_grads(st['grads'])
+            if pdist.is_dist():
+                self._reducer.set_flag(st['flag'])
         else:
             for p, g in st['grads'].items():
                 p.grad = g
@@ -350,8 +354,19 @@ class Trainer:
     def _finish_device_skip(self, step: int, flag: torch.Tensor):
         """eager tail of a step whose backward has run: NaN flag to the host (asynchronously), gradient all-reduce,
         clipping, optimizer step with on-device skip"""
-        if pdist.is_dist():
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        grad_scale = None
+        if self._reducer is not None and pdist.is_dist():
+            # ONE collective per bucket: the flag sits behind the last bucket (set_flag), and when nothing clips the gradients the
+            # division by the world size is left to the optimizer kernel (grad_scale) instead of a pass over the buckets
+            in_opt = not (self.grad_clip or self.grad_norm)
+            self._reducer.finish(average=not in_opt)
+            flag = (self._reducer.flag > 0).to(torch.float32).reshape(())
+            if in_opt:
+                if getattr(self, '_world_scale', None) is None or self._world_scale.device != flag.device:
+                    self._world_scale = torch.full((), float(pdist.world_size()), dtype=torch.float32, device=flag.device)
+                grad_scale = self._world_scale
+        elif self._reducer is not None:
+            self._reducer.finish()
         host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
         host_flag.copy_(flag, non_blocking=True)
         event = torch.cuda.Event()
@@ -359,11 +374,9 @@ class Trainer:
         if not hasattr(self, '_nan_pending'):
             self._nan_pending = []
         self._nan_pending.append((step, host_flag, event))
-        if self._reducer is not None:
-            self._reducer.finish()
         self.clip_grad()
         self.optimizer.found_inf = flag
-        self.optimizer.grad_scale = None
+        self.optimizer.grad_scale = grad_scale
         try:
             self.optimizer.step()
         finally:

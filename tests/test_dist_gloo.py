@@ -121,3 +121,44 @@ def test_flat_reducer_load_grads_and_alignment():
         want = 0.0 if i == 1 else float(i + 1)
         assert bool((p.grad == want).all()), i
     red.finish()                                              # world 1: a no-op
+
+
+def _flag_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.cuda.is_available = lambda: False
+    from pytorch_sound_amd import distributed as pdist
+    assert pdist.init_from_env('gloo')
+    net = _net()
+    red = pdist.FlatGradReducer(net)
+    out = []
+    for step, raise_on in enumerate((None, 1, 0)):                       # nobody, rank 1, rank 0 raises its flag
+        red.zero_grad()
+        red.set_flag(torch.tensor(1.0 if raise_on == rank else 0.0))
+        for p in net.parameters():
+            p.grad.copy_(torch.full_like(p, float(rank + 1)))
+        for p in reversed(list(net.parameters())):                        # what the backward hooks do
+            red._on_grad(p)
+        red.finish(average=(step == 0))
+        g = next(net.parameters()).grad
+        out.append((float(red.flag), float(g.flatten()[0])))
+    q.put((rank, out))
+
+
+def test_nan_flag_rides_with_the_gradients_and_sum_mode():
+    """FlatGradReducer.set_flag / .flag: the per-rank NaN flag is reduced inside the last gradient bucket (no collective of its
+    own), flag > 0 on EVERY rank iff any rank raised it; finish(average=False) leaves the SUM (the optimizer kernel divides)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (f0, g0), (f1, g1), (f2, g2) = res[rank]
+        assert f0 == 0.0 and f1 > 0.0 and f2 > 0.0
+        assert g0 == 1.5 and g1 == 3.0 and g2 == 3.0                     # mean of (1, 2), then sums
