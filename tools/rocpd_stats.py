@@ -23,7 +23,7 @@ def main(path, top=40, out=None):
     for r in cur.execute("select %s, sum(end-start < 50000), avg(case when end-start < 50000 then end-start end), "
                          "sum(end-start >= 50000), avg(case when end-start >= 50000 then end-start end) from kernels "
                          "where %s like '%%stft_fwd_n1024%%' group by %s" % (namecol, namecol, namecol)).fetchall():
-        lines.append('stft_fwd_n1024 split: %d launches < 50 us, avg %.2f us (in-step, 32 clips) | %d launches >= 50 us, avg %.2f us (1024 clips)'
+        lines.append('stft_fwd_n1024 split: %d launches < 50 us, avg %.2f us (in-step, 64 clips: mixture + reference of a batch) | %d launches >= 50 us, avg %.2f us (1024 clips)'
                      % (r[1] or 0, (r[2] or 0) / 1e3, r[3] or 0, (r[4] or 0) / 1e3))
     txt = '\n'.join(lines)
     print(txt)
