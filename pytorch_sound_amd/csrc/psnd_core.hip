@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 100; }  // 0.1.0
+extern "C" int psnd_version(void) { return 110; }  // 0.1.10: + conv chain / paired backward, optimizer, loss, data, PQMF entry points
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
