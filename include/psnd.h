@@ -143,6 +143,10 @@ int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope
                    int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
                    void *a_eff_out, void *stream);
 int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb, int k);
+/* host-side launch counters of the conv kernels' tile instances: out4 = { forward / input-gradient launches with 64-row
+ * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
+ * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */
+int psnd_conv_stats(int64_t *out4, int reset);
 int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
                          int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,
                          void *g_out, void *stream);

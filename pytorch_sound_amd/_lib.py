@@ -44,6 +44,7 @@ SIGNATURES = {
     'psnd_conv1d_wnorm_bwd_multi': (_INT, [_P, _INT, _P]),
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
+    'psnd_conv_stats': (_INT, [_P, _INT]),
     'psnd_groupnorm1_fwd': (_INT, [_P, _P, _P, _P, _I64, _INT, _I64, _F, _INT, _P, _P, _P, _P]),
     'psnd_groupnorm1_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _P, _P, _P, _P, _P]),
     'psnd_softmax_keys_fwd': (_INT, [_P, _P, _I64, _I64, _F, _P]),

@@ -20,6 +20,7 @@
 // and weight-gradient roles share the grid (conv_bwd_pair_kernel), the weight-norm backward of a whole chain another one.
 #include "psnd_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
@@ -812,9 +813,22 @@ __global__ __launch_bounds__(1024) void conv_finish_multi_kernel(FinishArgs a) {
 
 }  // namespace
 
+// launch statistics (which tile instances ran): [0] forward/input-gradient launches with 64-row tiles, [1] with 128-row tiles,
+// [2] paired backward launches with 64-row tiles, [3] with 128-row tiles.  Host-side counters, read by the parity tests to
+// prove that a test shape reached the instance it is meant to cover.
+static std::atomic<long long> g_conv_stats[4];
+extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
+    if (out4)
+        for (int i = 0; i < 4; ++i) out4[i] = g_conv_stats[i].load();
+    if (reset)
+        for (int i = 0; i < 4; ++i) g_conv_stats[i].store(0);
+    return PSND_OK;
+}
+
 // 128-row workgroup tiles once 64-row tiles would make >= 1024 workgroups (two full rounds of the chip's 512 slots)
 static int conv_row_tiles(int64_t R, int Cb) {
-    static const int force = getenv("PSND_CONV_MT") ? atoi(getenv("PSND_CONV_MT")) : 0;
+    const char *fe = getenv("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
+    const int force = fe ? atoi(fe) : 0;
     if (force == 1 || force == 2) return force;
     return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;
 }
@@ -880,6 +894,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     else PSND_CONV_LAUNCH(16, 2, true);
 #undef PSND_CONV_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl");
+    g_conv_stats[mt == 2 ? 1 : 0]++;
     return PSND_OK;
 }
 
@@ -1026,7 +1041,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     pc.trace = nullptr, pw.trace = nullptr;
 #endif
     const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
-    static const int pair_mt = getenv("PSND_PAIR_MT") ? atoi(getenv("PSND_PAIR_MT")) : 0;
+    const char *pe = getenv("PSND_PAIR_MT");
+    const int pair_mt = pe ? atoi(pe) : 0;
     const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : conv_row_tiles(pc.R, Ca);
     const int bm = 64 * mt;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
@@ -1055,6 +1071,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     else PSND_PAIR_LAUNCH(16, 2, true);
 #undef PSND_PAIR_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl_bwd");
+    g_conv_stats[mt == 2 ? 3 : 2]++;
     return PSND_OK;
 }
 

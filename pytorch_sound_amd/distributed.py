@@ -67,11 +67,29 @@ def broadcast_module(module: torch.nn.Module, src: int = 0):
             dist.broadcast(t.data, src)
 
 
+def _collective_device(device=None):
+    """device a small collective tensor must live on: the process group's backend decides (RCCL has no CPU path,
+    gloo handles both); `device` is honoured when the backend can take it"""
+    backend = dist.get_backend()
+    if backend == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return device or torch.device('cpu')
+
+
+def broadcast_int(value: int, src: int = 0) -> int:
+    """an exact integer (e.g. the seed) from rank `src` to every rank, as int64 on the backend's device"""
+    if not is_dist():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_collective_device())
+    dist.broadcast(t, src)
+    return int(t.item())
+
+
 def all_reduce_scalar(value, op: str = 'sum', device=None) -> float:
     if not is_dist():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64 if device is None or device.type == 'cpu' else torch.float32,
-                     device=device or 'cpu')
+    device = _collective_device(device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op={'sum': dist.ReduceOp.SUM, 'max': dist.ReduceOp.MAX, 'min': dist.ReduceOp.MIN}[op])
     return float(t.item())
 
@@ -82,6 +100,8 @@ class FlatGradReducer:
         self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []            # dicts: flat, params, pending, work
+        self._next = 0               # first bucket whose all-reduce has not been issued in this step
+        self.launch_log = []         # bucket indices in the order their collectives were issued (tests read this)
         self._bucket_of = {}
         self._handles = []
         order = list(reversed(self.params))
@@ -122,6 +142,7 @@ class FlatGradReducer:
 
     # gradients must stay views of the flat buffers: zero in place instead of dropping them
     def zero_grad(self):
+        self._next = 0
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
@@ -137,6 +158,7 @@ class FlatGradReducer:
         """graph mode: the replayed backward left its gradients in the graph's own static tensors (`grads[p]`, None for
         an unused parameter); copy them into the buckets (one multi-tensor copy per bucket) and make the buckets'
         views the parameters' .grad again, ready for finish()."""
+        self._next = 0
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
@@ -164,8 +186,15 @@ class FlatGradReducer:
             return
         b = self._bucket_of[p]
         b['pending'] -= 1
-        if b['pending'] == 0:
-            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+        # collectives are issued in FIXED bucket order on every rank: a completed bucket launches from the hook only when all
+        # earlier buckets have launched (a parameter without a gradient on one rank only - a data-dependent branch - would
+        # otherwise reorder that rank's all-reduces against the others: deadlock or mixed-up gradients); what is left goes
+        # out, in order, in finish()
+        while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
+            nb = self.buckets[self._next]
+            nb['work'] = dist.all_reduce(nb['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            self.launch_log.append(self._next)
+            self._next += 1
 
     def finish(self, average: bool = True):
         """wait for every bucket, average (average=False: the buckets keep the SUM - the caller divides, e.g. through the
@@ -173,15 +202,17 @@ class FlatGradReducer:
         ranks never diverge."""
         if self.world <= 1:
             return
-        for b in self.buckets:
-            if b['work'] is None:
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+        for i in range(self._next, len(self.buckets)):
+            b = self.buckets[i]
+            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            self.launch_log.append(i)
         for b in self.buckets:
             b['work'].wait()
             if average:
                 b['flat'].mul_(1.0 / self.world)
             b['work'] = None
             b['pending'] = len(b['params'])
+        self._next = 0
 
     def remove(self):
         for h in self._handles:

@@ -62,9 +62,29 @@ class _WNConvBase(nn.Module):
         self.weight = nn.Parameter(w)
         self._folded = True
         # the gfx950 conv kernels keep working on the folded weight: (v, g) = (w, ||w||) reproduces w.  Non-persistent buffers -
-        # the state dict holds `weight` / `bias` only, as the reference's does after remove_weight_norm
-        self.register_buffer('weight_v', self.weight.detach(), persistent=False)
+        # the state dict holds `weight` / `bias` only, as the reference's does after remove_weight_norm.  They are DERIVED from
+        # `weight` and re-derived whenever it changed (sync_folded: load_state_dict / .to() / in-place edits after the fold)
+        self.register_buffer('weight_v', self.weight.detach().clone(), persistent=False)
         self.register_buffer('weight_g', self._norm(w).clone(), persistent=False)
+        self._fold_key = (self.weight.data_ptr(), self.weight._version)
+
+    def sync_folded(self):
+        """folded module: make (weight_v, weight_g) = (weight, ||weight||) again if `weight` was replaced or written since
+        the last call (a folded checkpoint loaded after remove_weight_norm, as interface/hifi_gan.py:66-80 allows).  In place:
+        the buffers' addresses - the key of the prepared bf16 packs - do not move."""
+        if not self._folded:
+            return
+        key = (self.weight.data_ptr(), self.weight._version)
+        if key == self._fold_key and self.weight_v.device == self.weight.device:
+            return
+        with torch.no_grad():
+            if self.weight_v.device != self.weight.device or self.weight_v.shape != self.weight.shape:
+                self.weight_v = self.weight.detach().clone()
+                self.weight_g = self._norm(self.weight.detach()).clone()
+            else:
+                self.weight_v.copy_(self.weight.detach())
+                self.weight_g.copy_(self._norm(self.weight.detach()))
+        self._fold_key = key
 
 
 class WNConv1d(_WNConvBase):
@@ -173,9 +193,17 @@ class Generator(nn.Module):
     cl_upsample = 'library'     # 'kernel': ConvTranspose1d on the CL conv kernel too (cl.conv_transpose_cl)
     _CL_MAX_REACH = 25          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for
 
+    def _all_convs(self):
+        out = [self.conv_pre, self.conv_post] + list(self.ups)
+        for b in self.resblocks:
+            out += list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs)
+        return out
+
     def _cl_ok(self, x) -> bool:
         if not (self.use_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
             return False
+        for c in self._all_convs():
+            c.sync_folded()
         if any(not hasattr(c, 'weight_v') for c in [self.conv_pre, self.conv_post]):
             return False
         reach = 0

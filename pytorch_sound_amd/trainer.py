@@ -130,7 +130,7 @@ class Trainer:
         if not self.seed:
             self.seed = np.random.randint(np.iinfo(np.int32).max)
             if pdist.is_dist():                        # every rank must initialise identically
-                self.seed = int(pdist.all_reduce_scalar(self.seed if pdist.is_main() else 0, 'sum'))
+                self.seed = pdist.broadcast_int(self.seed, 0)
         np.random.seed(self.seed)
         torch.manual_seed(self.seed)
         if torch.cuda.is_available():

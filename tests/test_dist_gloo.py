@@ -162,3 +162,72 @@ def test_nan_flag_rides_with_the_gradients_and_sum_mode():
         (f0, g0), (f1, g1), (f2, g2) = res[rank]
         assert f0 == 0.0 and f1 > 0.0 and f2 > 0.0
         assert g0 == 1.5 and g1 == 3.0 and g2 == 3.0                     # mean of (1, 2), then sums
+
+
+def _order_worker(rank, world, port, tmp, q):
+    """ADVICE r1: (i) Trainer(seed=None) under DDP - the seed is drawn on rank 0 and broadcast as an exact int64;
+    (ii) a parameter that gets no gradient on ONE rank only: the bucket collectives must still be issued in the same
+    (fixed) order on both ranks"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.cuda.is_available = lambda: False
+    import torch.distributed as dist
+    from pytorch_sound_amd import distributed as pdist
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    assert pdist.init_from_env('gloo')
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.a = torch.nn.Linear(8, 8)
+            self.b = torch.nn.Linear(8, 8)          # skipped by rank 1
+            self.c = torch.nn.Linear(8, 1)
+
+        def forward(self, x, use_b):
+            h = torch.tanh(self.a(x))
+            if use_b:
+                h = h + self.b(h)
+            return self.c(h)
+
+    class T(Trainer):
+        def forward(self, x, y, is_logging=False):
+            loss = torch.nn.functional.mse_loss(self.model(x, pdist.rank() == 0), y)
+            return loss, {'loss': (loss.item(), LogType.SCALAR)}
+
+    net = Net()
+    g = torch.Generator().manual_seed(100 + rank)
+    data = [(torch.randn(4, 8, generator=g), torch.randn(4, 1, generator=g)) for _ in range(3)]
+    np.random.seed(1000 + rank)                         # different host RNG state per rank: the drawn seeds differ
+    tr = T(net, torch.optim.SGD(net.parameters(), lr=0.05), data, data[:1], max_step=3, valid_max_step=1, save_interval=10,
+           log_interval=10, save_dir=tmp, save_prefix='ord', seed=None)
+    tr._reducer.remove()
+    tr._reducer = pdist.FlatGradReducer(net, bucket_bytes=128)      # one bucket per parameter tensor, more or less
+    tr.run()
+    q.put((rank, int(tr.seed), list(tr._reducer.launch_log), len(tr._reducer.buckets),
+           {k: v.numpy() for k, v in net.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_seed_broadcast_and_fixed_collective_order(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, seed, order, nb, sd = q.get(timeout=240)
+        res[r] = (seed, order, nb, sd)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] and res[0][0] > 0                  # exact, identical seed
+    nb = res[0][2]
+    assert nb >= 4
+    assert res[0][1] == res[1][1] == list(range(nb)) * 3             # every step: buckets 0..nb-1 in order on both ranks
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k

@@ -94,3 +94,58 @@ def test_softmax_keys_large_with_mask():
     a = att[3]
     assert float(a[173:, :].abs().max()) == 0 and float(a[:, 173:].abs().max()) == 0
     assert torch.allclose(a[:, :173].sum(0), torch.ones(173, device=dev), atol=1e-5)
+
+
+@pytest.mark.parametrize('T,N', [(173, 8), (1292, 4)])
+def test_config4_block_vs_float64(T, N):
+    """BASELINE config 4 at module level: MultiHeadAttention(256, 4) + PointwiseFeedForward(256) on bucket-style padded
+    batches (modules.py:32-79, 108-116) against the SAME modules evaluated in float64 with the torch formulation:
+    outputs, the returned attention tensor, the input gradient and every parameter gradient.
+    Tolerance (fp32 kernels, exact-fp32 matrix products): 3e-5 of max on outputs, 2e-4 of max on gradients."""
+    import copy
+    from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding
+    dev = torch.device('cuda:0')
+    torch.manual_seed(T)
+    C, H = 256, 4
+    pe = PositionalEncoding(C, 2048).to(dev)
+    mha = MultiHeadAttention(C, H, 0.0).to(dev)
+    ffn = PointwiseFeedForward(C, 0.0).to(dev)
+    with torch.no_grad():
+        for m in (mha, ffn):
+            m.layernorm.weight.copy_(1 + 0.2 * torch.randn(C))
+            m.layernorm.bias.copy_(0.1 * torch.randn(C))
+    lens = torch.linspace(T, max(T // 3, 8), N).long()             # a length bucket padded to its longest clip
+    mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
+    x0 = (0.3 * torch.randn(N, C, T, device=dev)) * (~mask).unsqueeze(1)
+    gy = torch.randn(N, C, T, device=dev)
+    gatt = torch.randn(H * N, T, T, device=dev) * 0.1
+
+    def run(mods, dt, att_in_loss):
+        pe_, mha_, ffn_ = mods
+        x = x0.to(dt).requires_grad_(True)
+        h, att = mha_(pe_(x), mask)
+        y = ffn_(h)
+        loss = (y * gy.to(dt)).sum()
+        if att_in_loss:
+            loss = loss + (att * gatt.to(dt)).sum()
+        loss.backward()
+        grads = {('mha.' + k): p.grad for k, p in mha_.named_parameters()}
+        grads.update({('ffn.' + k): p.grad for k, p in ffn_.named_parameters()})
+        return y.detach(), att.detach(), x.grad, grads
+
+    ref_mods = tuple(copy.deepcopy(m).double() for m in (pe, mha, ffn))
+    for att_in_loss in (False, True):
+        for m in (mha, ffn) + ref_mods[1:]:
+            m.zero_grad()
+        y, att, gx, gp = run((pe, mha, ffn), torch.float32, att_in_loss)
+        yr, attr, gxr, gpr = run(ref_mods, torch.float64, att_in_loss)
+        tol = lambda a, b, rt: float((a.double() - b).abs().max()) <= rt * float(b.abs().max())   # noqa: E731
+        assert tol(y, yr, 3e-5), float((y.double() - yr).abs().max() / yr.abs().max())
+        assert float((att.double() - attr).abs().max()) <= 3e-6
+        assert tol(gx, gxr, 2e-4), float((gx.double() - gxr).abs().max() / gxr.abs().max())
+        for k in gp:
+            assert tol(gp[k], gpr[k], 2e-4), (k, float((gp[k].double() - gpr[k]).abs().max() / gpr[k].abs().max()))
+        # padded keys get no weight, padded queries are zeroed (modules.py:69-76)
+        a = att.view(H, N, T, T)[:, -1]
+        L = int(lens[-1])
+        assert float(a[:, L:, :].abs().max()) == 0 and float(a[:, :, L:].abs().max()) == 0

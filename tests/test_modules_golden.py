@@ -115,3 +115,23 @@ def test_shipped_v2_checkpoint_output(golden):
     with torch.no_grad():
         y = gen(torch.from_numpy(g['v2ckpt/mel']))
     assert close(y, g['v2ckpt/y'], 1e-4)
+
+
+def test_folded_buffers_follow_a_later_load():
+    """remove_weight_norm() derives the (v, g) pair the gfx950 kernels read from `weight`; a folded checkpoint
+    loaded AFTER the fold (strict=True accepts it) must refresh that pair (sync_folded, called by the CL path)."""
+    torch.manual_seed(0)
+    a, b = hifi_gan.Generator(TINY['tiny1']), hifi_gan.Generator(TINY['tiny1'])
+    a.remove_weight_norm()
+    b.remove_weight_norm()
+    ptrs = [(c.weight_v.data_ptr(), c.weight_g.data_ptr()) for c in b._all_convs()]
+    b.load_state_dict(a.state_dict())
+    for c in b._all_convs():
+        c.sync_folded()
+    for ca, cb, pp in zip(a._all_convs(), b._all_convs(), ptrs):
+        assert torch.equal(cb.weight_v, ca.weight.detach()) and torch.equal(cb.weight, ca.weight)
+        assert torch.allclose(cb.weight_g, ca.weight.detach().flatten(1).norm(dim=1).view(-1, 1, 1))
+        assert (cb.weight_v.data_ptr(), cb.weight_g.data_ptr()) == pp          # refreshed in place: pack cache keys stay valid
+    x = torch.randn(1, 80, 5)
+    with torch.no_grad():
+        assert torch.equal(a(x), b(x))
