@@ -122,7 +122,7 @@ def test_config4_block_vs_float64(T, N):
 
     def run(mods, dt, att_in_loss):
         pe_, mha_, ffn_ = mods
-        x = x0.to(dt).requires_grad_(True)
+        x = x0.detach().clone().to(dt).requires_grad_(True)
         h, att = mha_(pe_(x), mask)
         y = ffn_(h)
         loss = (y * gy.to(dt)).sum()
@@ -141,7 +141,7 @@ def test_config4_block_vs_float64(T, N):
         yr, attr, gxr, gpr = run(ref_mods, torch.float64, att_in_loss)
         tol = lambda a, b, rt: float((a.double() - b).abs().max()) <= rt * float(b.abs().max())   # noqa: E731
         assert tol(y, yr, 3e-5), float((y.double() - yr).abs().max() / yr.abs().max())
-        assert float((att.double() - attr).abs().max()) <= 3e-6
+        assert float((att.double() - attr).abs().max()) <= 2e-5      # probabilities in [0, 1]; logits reach +-60 here
         assert tol(gx, gxr, 2e-4), float((gx.double() - gxr).abs().max() / gxr.abs().max())
         for k in gp:
             assert tol(gp[k], gpr[k], 2e-4), (k, float((gp[k].double() - gpr[k]).abs().max() / gpr[k].abs().max()))

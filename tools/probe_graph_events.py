@@ -104,6 +104,9 @@ def probe_rccl_capture():
 
 if __name__ == '__main__':
     t = time.time()
-    probe_external_event()
+    try:
+        probe_external_event()
+    except Exception as e:           # noqa: BLE001
+        print('EXTERNAL_EVENT: torch refuses:', repr(e))
     probe_rccl_capture()
     print('probe done in %.1f s' % (time.time() - t))
