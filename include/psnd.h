@@ -45,6 +45,16 @@ extern "C" {
 int psnd_version(void);
 const char *psnd_last_error(void);
 
+/* ---- stream events: release points inside a captured step graph (data-parallel training) ------------------------
+ * psnd_event_record_external on a CAPTURING stream adds an external event-record node (hipEventRecordExternal): after the
+ * graph launch, psnd_stream_wait_event(other_stream, ev) makes `other_stream` wait for that node of that launch only - the
+ * gradient all-reduce of a bucket starts while the rest of the replayed backward still runs.  Outside a capture it is a plain
+ * event record.  The reference has no distributed code; north_star: "all-reduce overlapped with backward". */
+void *psnd_event_create(void);                 /* NULL on failure (psnd_last_error) */
+int psnd_event_destroy(void *ev);
+int psnd_event_record_external(void *ev, void *stream);
+int psnd_stream_wait_event(void *stream, void *ev);
+
 /* ---- integer contract: frame indexing (bit-exact) -------------------------------------- */
 /* number of frames of the strided conv over the reflect-padded signal
  * (transforms.py:55-66; F = T/hop + 1 for CENTER, T/hop for HIFIGAN when hop | T). */

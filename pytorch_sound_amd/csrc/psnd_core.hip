@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 110; }  // 0.1.10: + conv chain / paired backward, optimizer, loss, data, PQMF entry points
+extern "C" int psnd_version(void) { return 120; }  // 0.1.20: + stream events for in-graph bucket release, conv launch statistics, second-generation n4096 kernel
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
@@ -34,4 +34,41 @@ extern "C" int64_t psnd_frame_sample_index(int64_t f, int m, int64_t T, int n_ff
     if (i < 0) i = -i;
     if (i >= T) i = 2 * (T - 1) - i;
     return i;
+}
+
+// ---- stream events for the data-parallel step (pytorch_sound_amd/distributed.py) ---------------------------------------
+// The replayed hipGraph of a training step must release the RCCL all-reduce of gradient bucket i as soon as the captured
+// backward has produced it - while the rest of the backward still runs.  A record node of an EXTERNAL event
+// (hipEventRecordWithFlags(..., hipEventRecordExternal)) inside the captured stream does that: after hipGraphLaunch, a
+// hipStreamWaitEvent on another stream waits for exactly that node of THIS launch.  torch's Event wrapper refuses external
+// events on ROCm builds, hence these four entry points (measured on MI355X / ROCm 7: the waiting stream is released at the node,
+// tools/mb/probe_extevent.hip).
+extern "C" void *psnd_event_create(void) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        psnd_set_error("event_create: %s", hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    return ev;
+}
+extern "C" int psnd_event_destroy(void *ev) {
+    if (!ev) return PSND_OK;
+    if (hipEventDestroy(static_cast<hipEvent_t>(ev)) != hipSuccess) PSND_FAIL(PSND_E_HIP, "event_destroy: %s", hipGetErrorString(hipGetLastError()));
+    return PSND_OK;
+}
+extern "C" int psnd_event_record_external(void *ev, void *stream) {
+    if (!ev) PSND_FAIL(PSND_E_ARG, "event_record_external: null event");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) st = hipStreamCaptureStatusNone;
+    const hipError_t e = st == hipStreamCaptureStatusActive ? hipEventRecordWithFlags(static_cast<hipEvent_t>(ev), s, hipEventRecordExternal)
+                                                            : hipEventRecord(static_cast<hipEvent_t>(ev), s);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "event_record_external: %s", hipGetErrorString(e));
+    return PSND_OK;
+}
+extern "C" int psnd_stream_wait_event(void *stream, void *ev) {
+    if (!ev) PSND_FAIL(PSND_E_ARG, "stream_wait_event: null event");
+    const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stream_wait_event: %s", hipGetErrorString(e));
+    return PSND_OK;
 }

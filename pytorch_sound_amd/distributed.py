@@ -15,6 +15,7 @@ Bucket size: gradients here are small (hifi_gan_v1 55.7 MB fp32, v2 3.7 MB): xGM
 per-link bound (~153 GB/s/link), so latency, not bandwidth, dominates -> few large buckets
 (default 32 MiB) rather than DDP's 25 MB chunks per layer group.
 """
+import collections
 import os
 from typing import List
 
@@ -95,13 +96,31 @@ def all_reduce_scalar(value, op: str = 'sum', device=None) -> float:
 
 
 class FlatGradReducer:
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20):
+    """see the module docstring.  Graph mode (Trainer.graph_steps): the captured backward fills the buckets ITSELF and
+    marks, per bucket, the point where it is complete -
+
+      'events'   an external event-record node per bucket (psnd_event_record_external).  After the replay has been enqueued the
+                 host enqueues, per bucket and in fixed order, `side.wait(event_i); all_reduce(bucket_i)` on a side stream:
+                 RCCL runs bucket i while the replayed backward is still producing bucket i+1 (any backend; default)
+      'capture'  the all-reduce itself is captured into the graph on RCCL's stream (fork after the bucket, join at the end):
+                 no host involvement at all (backend nccl only; PSND_DDP_GRAPH=capture)
+      'deferred' round 1's behaviour: every collective after the replay (PSND_DDP_GRAPH=deferred; the fallback when a
+                 capture with one of the other modes fails)
+    """
+
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, force: bool = False):
         self.world = world_size()
+        self.active = self.world > 1 or force   # force: single-rank process group (tests the collective plumbing on one GPU)
         self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
+        self._capturing = None       # graph capture in progress: its mode
+        self._graph_mode = None      # mode of the graph that was replayed last (None: eager step)
+        self._events = None
+        self._side = None
+        self.release_marks = []      # (tests) per bucket: timing event recorded on the side stream when its wait was released
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []            # dicts: flat, params, pending, work
         self._next = 0               # first bucket whose all-reduce has not been issued in this step
-        self.launch_log = []         # bucket indices in the order their collectives were issued (tests read this)
+        self.launch_log = collections.deque(maxlen=4096)   # bucket indices in the order their collectives were issued (tests)
         self._bucket_of = {}
         self._handles = []
         order = list(reversed(self.params))
@@ -136,7 +155,7 @@ class FlatGradReducer:
             self.buckets.append(b)
             for p in g:
                 self._bucket_of[p] = b
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -181,7 +200,103 @@ class FlatGradReducer:
         """after finish(): > 0 iff any rank raised its flag"""
         return self._flag
 
+    # ---- graph mode --------------------------------------------------------------------------------------------------
+    def graph_mode(self) -> str:
+        mode = os.environ.get('PSND_DDP_GRAPH', 'events')
+        if mode not in ('events', 'capture', 'deferred'):
+            raise ValueError('PSND_DDP_GRAPH=%s (events | capture | deferred)' % mode)
+        if mode == 'capture' and dist.get_backend() != 'nccl':
+            mode = 'events'          # only RCCL can be captured
+        return mode
+
+    def capture_begin(self, flag, mode: str):
+        """inside the stream capture, after forward: arm the hooks for the captured backward.  The NaN flag goes into its slot
+        behind the last bucket now (a captured copy), ahead of every bucket's release point."""
+        self._capturing = mode
+        self._next = 0
+        self._cap_works = []
+        for b in self.buckets:
+            b['pending'] = len(b['params'])
+            b['work'] = None
+        self.set_flag(flag)
+        if mode == 'events' and self._events is None:
+            from ._lib import lib
+            self._events = []
+            for _ in self.buckets:
+                ev = lib().psnd_event_create()
+                if not ev:
+                    raise RuntimeError('psnd_event_create failed')
+                self._events.append(ev)
+
+    def _emit_bucket(self, i):
+        """captured: gradients of bucket i (static tensors of the graph's pool) -> its flat buffer, then the release point"""
+        b = self.buckets[i]
+        views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
+        have = [(v, p.grad) for v, p in zip(views, b['params']) if p.grad is not None]
+        for v, p in zip(views, b['params']):
+            if p.grad is None:
+                v.zero_()            # a parameter the captured backward never reached
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        mode = self._capturing
+        if mode == 'capture':
+            self._cap_works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
+        elif mode == 'events':
+            from ._lib import lib, check
+            check(lib().psnd_event_record_external(self._events[i], torch.cuda.current_stream(b['flat'].device).cuda_stream),
+                  'psnd_event_record_external')
+        self.launch_log.append(i)
+
+    def capture_end(self):
+        """still inside the capture, after backward: buckets whose hooks did not all fire, then (mode capture) the join"""
+        while self._next < len(self.buckets):
+            self._emit_bucket(self._next)
+            self._next += 1
+        for w in self._cap_works:
+            w.wait()
+        self._cap_works = []
+        mode, self._capturing = self._capturing, None
+        self._next = 0
+        for b in self.buckets:
+            b['pending'] = len(b['params'])
+        return mode
+
+    def after_replay(self, mode: str, time_marks: bool = False):
+        """the replay of a captured step has just been enqueued on the current stream: make the buckets' views the
+        parameters' .grad again and (mode events) enqueue every bucket's all-reduce behind its release event"""
+        self._graph_mode = mode
+        self._next = 0
+        for b in self.buckets:
+            b['pending'] = len(b['params'])
+            b['work'] = None
+            self._repoint(b)
+        if mode != 'events' or not self.active:
+            return
+        from ._lib import lib, check
+        dev = self.buckets[0]['flat'].device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        self.release_marks = []
+        with torch.cuda.stream(self._side):
+            for i, b in enumerate(self.buckets):
+                check(lib().psnd_stream_wait_event(self._side.cuda_stream, self._events[i]), 'psnd_stream_wait_event')
+                if time_marks:
+                    m = torch.cuda.Event(enable_timing=True)
+                    m.record(self._side)
+                    self.release_marks.append(m)
+                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+                self.launch_log.append(i)
+        self._next = len(self.buckets)
+
     def _on_grad(self, p):
+        if self._capturing is not None:
+            b = self._bucket_of[p]
+            b['pending'] -= 1
+            if self._capturing != 'deferred':
+                while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
+                    self._emit_bucket(self._next)
+                    self._next += 1
+            return
         if self.deferred:            # backward is being captured / replayed as a hipGraph: no collective from inside it
             return
         b = self._bucket_of[p]
@@ -200,8 +315,15 @@ class FlatGradReducer:
         """wait for every bucket, average (average=False: the buckets keep the SUM - the caller divides, e.g. through the
         optimizer kernel's grad_scale).  Buckets whose hooks did not all fire (unused parameters) are reduced here so that
         ranks never diverge."""
-        if self.world <= 1:
+        if not self.active:
             return
+        if self._graph_mode == 'capture':            # reduced inside the replayed graph
+            self._graph_mode = None
+            if average:
+                for b in self.buckets:
+                    b['flat'].mul_(1.0 / self.world)
+            return
+        self._graph_mode = None
         for i in range(self._next, len(self.buckets)):
             b = self.buckets[i]
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
@@ -218,3 +340,8 @@ class FlatGradReducer:
         for h in self._handles:
             h.remove()
         self._handles = []
+        if self._events:
+            from ._lib import lib
+            for ev in self._events:
+                lib().psnd_event_destroy(ev)
+            self._events = None

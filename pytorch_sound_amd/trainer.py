@@ -145,9 +145,10 @@ class Trainer:
 
         # data parallel: identical start on every rank, overlapped gradient all-reduce
         self._reducer = None
-        if pdist.is_dist():
+        force = os.environ.get('PSND_DDP_FORCE') == '1' and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if pdist.is_dist() or force:                   # force: a one-rank process group still runs the whole reducer path
             pdist.broadcast_module(self._bare_model)
-            self._reducer = pdist.FlatGradReducer(self._bare_model)
+            self._reducer = pdist.FlatGradReducer(self._bare_model, force=force)
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -311,9 +312,13 @@ class Trainer:
         for dst, src in zip(st['inputs'], batch):
             dst.copy_(src, non_blocking=True)
         st['graph'].replay()
-        if self._reducer is not None:                  # DDP: into the flat buckets, reduced in _finish_device_skip
+        if self._reducer is not None and st.get('ddp') in ('events', 'capture'):
+            # the captured backward filled the flat buckets itself and marked where each is complete: bucket i is all-reduced
+            # while the replay is still producing bucket i + 1 (FlatGradReducer, graph mode)
+            self._reducer.after_replay(st['ddp'], time_marks=getattr(self, '_ddp_time_marks', False))
+        elif self._reducer is not None:                # deferred: into the flat buckets, reduced in _finish_device_skip
             self._reducer.load_grads(st['grads'])
-            if pdist.is_dist():
+            if self._reducer.active:
                 self._reducer.set_flag(st['flag'])
         else:
             for p, g in st['grads'].items():
@@ -334,19 +339,39 @@ class Trainer:
                 del self._graphs[k]
 
     def _capture(self, st, batch):
-        if self._reducer is not None:
-            self._reducer.deferred = True              # no collective from inside the captured backward
+        red = self._reducer
+        mode = red.graph_mode() if red is not None and red.active else None
         st['inputs'] = tuple(t.clone() for t in batch)
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
-        for p in params:
-            p.grad = None                              # backward then WRITES its gradients (no zero fill, no += kernels)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss, _ = self.forward(*st['inputs'], is_logging=False)
-            st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
-            loss.backward()
+        while True:
+            for p in params:
+                p.grad = None                          # backward then WRITES its gradients (no zero fill, no += kernels)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    loss, _ = self.forward(*st['inputs'], is_logging=False)
+                    st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+                    if mode in ('events', 'capture'):
+                        red.capture_begin(st['flag'], mode)   # the captured backward fills and releases the buckets itself
+                    elif red is not None:
+                        red.deferred = True            # no collective from inside the captured backward
+                    loss.backward()
+                    if mode in ('events', 'capture'):
+                        red.capture_end()
+                break
+            except Exception as e:                     # noqa: BLE001 - e.g. a runtime that cannot capture the release nodes
+                if mode in (None, 'deferred'):
+                    raise
+                self._log('graph capture with DDP mode %s failed (%s): falling back to deferred all-reduce' % (mode, repr(e)[:200]))
+                red._capturing = None
+                mode = 'deferred'
+                torch.cuda.synchronize()
+            finally:
+                if red is not None:
+                    red.deferred = False               # eager (logging) steps keep the overlapped per-bucket all-reduce
         st['graph'] = graph
+        st['ddp'] = mode
         st['grads'] = {p: p.grad for p in params}      # static tensors of the graph's memory pool
         self._log('captured the training step as a hipGraph for inputs %s' % (
             ', '.join('x'.join(map(str, t.shape)) for t in batch)))

@@ -34,8 +34,9 @@ def _batches(n):
 NAN_STEP, STEPS = 5, 9
 
 
-def _worker(rank, world, port, tmp, q, graph, hip_adam):
+def _worker(rank, world, port, tmp, q, graph, hip_adam, ddp_mode='events'):
     try:
+        os.environ['PSND_DDP_GRAPH'] = ddp_mode
         _run(rank, world, port, tmp, q, graph, hip_adam)
     except Exception as e:                                                # the parent must not wait for its timeout
         q.put((rank, repr(e)))
@@ -77,12 +78,13 @@ def _run(rank, world, port, tmp, q, graph, hip_adam):
 
 
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize('graph,hip_adam', [(True, True), (False, True), (True, False)])
-def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam):
+@pytest.mark.parametrize('graph,hip_adam,ddp_mode', [(True, True, 'events'), (False, True, 'events'), (True, False, 'events'),
+                                                     (True, True, 'deferred')])
+def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, graph, hip_adam)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, graph, hip_adam, ddp_mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=150) for _ in procs)
@@ -105,3 +107,149 @@ def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam):
         opt.step()
     for k, v in net.state_dict().items():
         assert np.abs(v.numpy() - res[0][k]).max() <= 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
+
+
+# ---- graph mode: buckets are released INSIDE the replayed backward ------------------------------------------------------------
+def _deep_net():
+    torch.manual_seed(9)
+    layers = []
+    for i in range(10):
+        layers += [torch.nn.Conv1d(64, 64, 5, padding=2), torch.nn.Tanh()]
+    return torch.nn.Sequential(torch.nn.Conv1d(4, 64, 3, padding=1), *layers, torch.nn.Conv1d(64, 2, 1))
+
+
+def _overlap_worker(rank, world, port, tmp, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
+                          PSND_DIST_SHARE_GPU='1', PSND_DDP_GRAPH='events')
+        import torch.distributed as dist
+        from pytorch_sound_amd import distributed as pdist, optim as poptim
+        from pytorch_sound_amd.trainer import Trainer, LogType
+        assert pdist.init_from_env('nccl')
+        dev = torch.device('cuda:0')
+
+        class T(Trainer):
+            def forward(self, x, y, is_logging=False):
+                loss = torch.nn.functional.mse_loss(self.model(x), y)
+                return loss, {'loss': (loss, LogType.SCALAR)}
+
+        net = _deep_net().to(dev)
+        g = torch.Generator().manual_seed(21 + rank)
+        data = [(torch.randn(8, 4, 4096, generator=g), torch.randn(8, 2, 4096, generator=g)) for _ in range(6)]
+        tr = T(net, poptim.Adam(net.parameters(), lr=1e-3), data, data[:1], max_step=6, valid_max_step=1, save_interval=10 ** 6,
+               log_interval=10 ** 6, save_dir=tmp, save_prefix='ov', seed=3)
+        tr._reducer.remove()
+        tr._reducer = pdist.FlatGradReducer(net, bucket_bytes=64 << 10)          # ~4 layers per bucket
+        nb = len(tr._reducer.buckets)
+        tr.graph_steps, tr.graph_warmup, tr._ddp_time_marks = True, 1, True
+        net.train()
+        early = []
+        for i in range(1, 7):
+            tr.step = i
+            tr._reducer.launch_log.clear()
+            tr.train(i)
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()                                  # main stream: behind the replay and the optimizer step
+            torch.cuda.synchronize()
+            log = list(tr._reducer.launch_log)
+            if tr._reducer.release_marks:                  # a replayed step
+                marks = tr._reducer.release_marks
+                # device-side order: bucket 0 was released before the LAST bucket's release point (= the end of the replayed
+                # backward), i.e. its all-reduce could start while the backward was still running
+                early.append((marks[0].elapsed_time(marks[-1]), log))
+                tr._reducer.release_marks = []
+        q.put((rank, nb, early, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+
+
+@pytest.mark.timeout(400)
+def test_graph_mode_releases_bucket_0_before_the_backward_ends(tmp_path):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=200) for _ in procs]
+    assert all(len(g) == 4 for g in got), got
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = {g[0]: g for g in got}
+    nb = res[0][1]
+    assert nb >= 3
+    for r in (0, 1):
+        early = res[r][2]
+        assert len(early) >= 3                                            # steps 3.. are replays (1 warm-up, 1 capture)
+        for ms, log in early:
+            assert log == list(range(nb))                                 # collectives enqueued in fixed bucket order
+            assert ms > 0.0, ms                                           # bucket 0 released strictly before the backward's end
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k              # ranks bit-identical
+
+
+def _capture_worker(port, tmp, q, use_ddp):
+    """one rank, backend nccl (RCCL), PSND_DDP_GRAPH=capture: the all-reduce nodes live INSIDE the replayed hipGraph"""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0',
+                          PSND_DDP_GRAPH='capture', PSND_DDP_FORCE='1' if use_ddp else '0')
+        import torch.distributed as dist
+        from pytorch_sound_amd import optim as poptim
+        from pytorch_sound_amd.trainer import Trainer, LogType
+        if use_ddp:
+            torch.cuda.set_device(0)
+            dist.init_process_group('nccl', rank=0, world_size=1)
+        dev = torch.device('cuda:0')
+
+        class T(Trainer):
+            def forward(self, x, y, is_logging=False):
+                loss = torch.nn.functional.mse_loss(self.model(x), y)
+                return loss, {'loss': (loss, LogType.SCALAR)}
+
+        net = _deep_net().to(dev)
+        g = torch.Generator().manual_seed(5)
+        data = [(torch.randn(4, 4, 512, generator=g), torch.randn(4, 2, 512, generator=g)) for _ in range(6)]
+        tr = T(net, poptim.Adam(net.parameters(), lr=1e-3), data, data[:1], max_step=6, valid_max_step=1, save_interval=10 ** 6,
+               log_interval=10 ** 6, save_dir=tmp, save_prefix='cap' + str(int(use_ddp)), seed=3)
+        modes = []
+        if use_ddp:
+            from pytorch_sound_amd import distributed as pdist
+            assert tr._reducer is not None and tr._reducer.active
+            tr._reducer.remove()
+            tr._reducer = pdist.FlatGradReducer(net, bucket_bytes=64 << 10, force=True)
+        tr.graph_steps, tr.graph_warmup = True, 1
+        net.train()
+        for i in range(1, 7):
+            tr.step = i
+            tr.train(i)
+        torch.cuda.synchronize()
+        if use_ddp:
+            modes = [v.get('ddp') for v in tr._graphs.values() if 'graph' in v]
+            dist.destroy_process_group()
+        q.put((use_ddp, modes, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
+    except Exception as e:
+        q.put((use_ddp, repr(e)))
+        raise
+
+
+@pytest.mark.timeout(400)
+def test_rccl_all_reduce_captured_in_the_step_graph(tmp_path):
+    ctx = mp.get_context('spawn')
+    res = {}
+    for use_ddp in (False, True):
+        q = ctx.Queue()
+        p = ctx.Process(target=_capture_worker, args=(_port(), str(tmp_path), q, use_ddp))
+        p.start()
+        got = q.get(timeout=200)
+        p.join(timeout=120)
+        assert p.exitcode == 0 and len(got) == 3, got
+        res[use_ddp] = got
+    assert res[True][1] == ['capture'], res[True][1]                      # no fallback happened
+    for k in res[False][2]:
+        assert np.array_equal(res[False][2][k], res[True][2][k]), k       # sum over one rank = identity: bit-equal training
