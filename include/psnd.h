@@ -54,6 +54,7 @@ void *psnd_event_create(void);                 /* NULL on failure (psnd_last_err
 int psnd_event_destroy(void *ev);
 int psnd_event_record_external(void *ev, void *stream);
 int psnd_stream_wait_event(void *stream, void *ev);
+int psnd_event_external_supported(void);      /* 1: this HIP runtime captures external event-record nodes (probed once) */
 
 /* ---- integer contract: frame indexing (bit-exact) -------------------------------------- */
 /* number of frames of the strided conv over the reflect-padded signal

@@ -28,6 +28,7 @@ SIGNATURES = {
     'psnd_event_destroy': (_INT, [_P]),
     'psnd_event_record_external': (_INT, [_P, _P]),
     'psnd_stream_wait_event': (_INT, [_P, _P]),
+    'psnd_event_external_supported': (_INT, []),
     'psnd_frame_count': (_I64, [_I64, _INT, _INT, _INT]),
     'psnd_frame_sample_index': (_I64, [_I64, _INT, _I64, _INT, _INT, _INT]),
     'psnd_stft_plan_bytes': (_c.c_size_t, [_INT]),

@@ -63,8 +63,34 @@ extern "C" int psnd_event_record_external(void *ev, void *stream) {
     if (hipStreamIsCapturing(s, &st) != hipSuccess) st = hipStreamCaptureStatusNone;
     const hipError_t e = st == hipStreamCaptureStatusActive ? hipEventRecordWithFlags(static_cast<hipEvent_t>(ev), s, hipEventRecordExternal)
                                                             : hipEventRecord(static_cast<hipEvent_t>(ev), s);
-    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "event_record_external: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();            // do not leave the failure behind as the runtime's sticky "last error"
+        PSND_FAIL(PSND_E_HIP, "event_record_external: %s", hipGetErrorString(e));
+    }
     return PSND_OK;
+}
+// 1 when this HIP runtime accepts an external event-record node inside a stream capture (a throw-away capture on a private stream;
+// nothing is launched), 0 otherwise.  Runtimes differ: ROCm 7.2's does, the 7.0 one bundled with some torch wheels may not.
+extern "C" int psnd_event_external_supported(void) {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    int ok = 0;
+    hipStream_t s = nullptr;
+    hipEvent_t ev = nullptr;
+    hipGraph_t g = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const hipError_t e = hipEventRecordWithFlags(ev, s, hipEventRecordExternal);
+            const hipError_t e2 = hipStreamEndCapture(s, &g);
+            ok = (e == hipSuccess && e2 == hipSuccess) ? 1 : 0;
+            if (g) (void)hipGraphDestroy(g);
+        }
+    }
+    if (ev) (void)hipEventDestroy(ev);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipGetLastError();
+    cached = ok;
+    return ok;
 }
 extern "C" int psnd_stream_wait_event(void *stream, void *ev) {
     if (!ev) PSND_FAIL(PSND_E_ARG, "stream_wait_event: null event");

@@ -202,11 +202,17 @@ class FlatGradReducer:
 
     # ---- graph mode --------------------------------------------------------------------------------------------------
     def graph_mode(self) -> str:
+        """events where the HIP runtime captures external event records, else the captured RCCL all-reduce (backend nccl),
+        else deferred; PSND_DDP_GRAPH overrides the preference (a mode the runtime / backend cannot do is still replaced)"""
+        from ._lib import lib
         mode = os.environ.get('PSND_DDP_GRAPH', 'events')
         if mode not in ('events', 'capture', 'deferred'):
             raise ValueError('PSND_DDP_GRAPH=%s (events | capture | deferred)' % mode)
-        if mode == 'capture' and dist.get_backend() != 'nccl':
-            mode = 'events'          # only RCCL can be captured
+        nccl = dist.get_backend() == 'nccl'
+        if mode == 'events' and not lib().psnd_event_external_supported():
+            mode = 'capture'
+        if mode == 'capture' and not nccl:           # only RCCL can be captured
+            mode = 'events' if lib().psnd_event_external_supported() else 'deferred'
         return mode
 
     def capture_begin(self, flag, mode: str):
@@ -215,6 +221,8 @@ class FlatGradReducer:
         self._capturing = mode
         self._next = 0
         self._cap_works = []
+        self._arrived = 0
+        self.emit_log = []           # (bucket, gradients that had arrived when its release point was captured) - tests
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
@@ -246,6 +254,7 @@ class FlatGradReducer:
             check(lib().psnd_event_record_external(self._events[i], torch.cuda.current_stream(b['flat'].device).cuda_stream),
                   'psnd_event_record_external')
         self.launch_log.append(i)
+        self.emit_log.append((i, self._arrived))
 
     def capture_end(self):
         """still inside the capture, after backward: buckets whose hooks did not all fire, then (mode capture) the join"""
@@ -292,6 +301,7 @@ class FlatGradReducer:
         if self._capturing is not None:
             b = self._bucket_of[p]
             b['pending'] -= 1
+            self._arrived += 1
             if self._capturing != 'deferred':
                 while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
                     self._emit_bucket(self._next)

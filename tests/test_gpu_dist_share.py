@@ -110,6 +110,11 @@ def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode):
 
 
 # ---- graph mode: buckets are released INSIDE the replayed backward ------------------------------------------------------------
+# The HIP runtime bundled with this torch (7.0) refuses external event-record nodes inside a capture (tools/probe_extevent_inproc.py;
+# ROCm 7.2's accepts them, tools/mb/probe_extevent.hip), so FlatGradReducer.graph_mode() resolves to 'capture' under RCCL: the
+# all-reduce of every bucket is captured INTO the step graph on RCCL's stream, forked right behind the bucket's last gradient
+# and joined at the end of the backward.  Two ranks cannot share the test box's single GPU under RCCL, so the captured path is
+# driven with a one-rank process group (PSND_DDP_FORCE=1): same code, same graph topology, the sum over one rank is the identity.
 def _deep_net():
     torch.manual_seed(9)
     layers = []
@@ -118,87 +123,12 @@ def _deep_net():
     return torch.nn.Sequential(torch.nn.Conv1d(4, 64, 3, padding=1), *layers, torch.nn.Conv1d(64, 2, 1))
 
 
-def _overlap_worker(rank, world, port, tmp, q):
-    try:
-        sys.path.insert(0, ROOT)
-        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
-                          PSND_DIST_SHARE_GPU='1', PSND_DDP_GRAPH='events')
-        import torch.distributed as dist
-        from pytorch_sound_amd import distributed as pdist, optim as poptim
-        from pytorch_sound_amd.trainer import Trainer, LogType
-        assert pdist.init_from_env('nccl')
-        dev = torch.device('cuda:0')
-
-        class T(Trainer):
-            def forward(self, x, y, is_logging=False):
-                loss = torch.nn.functional.mse_loss(self.model(x), y)
-                return loss, {'loss': (loss, LogType.SCALAR)}
-
-        net = _deep_net().to(dev)
-        g = torch.Generator().manual_seed(21 + rank)
-        data = [(torch.randn(8, 4, 4096, generator=g), torch.randn(8, 2, 4096, generator=g)) for _ in range(6)]
-        tr = T(net, poptim.Adam(net.parameters(), lr=1e-3), data, data[:1], max_step=6, valid_max_step=1, save_interval=10 ** 6,
-               log_interval=10 ** 6, save_dir=tmp, save_prefix='ov', seed=3)
-        tr._reducer.remove()
-        tr._reducer = pdist.FlatGradReducer(net, bucket_bytes=64 << 10)          # ~4 layers per bucket
-        nb = len(tr._reducer.buckets)
-        tr.graph_steps, tr.graph_warmup, tr._ddp_time_marks = True, 1, True
-        net.train()
-        early = []
-        for i in range(1, 7):
-            tr.step = i
-            tr._reducer.launch_log.clear()
-            tr.train(i)
-            end = torch.cuda.Event(enable_timing=True)
-            end.record()                                  # main stream: behind the replay and the optimizer step
-            torch.cuda.synchronize()
-            log = list(tr._reducer.launch_log)
-            if tr._reducer.release_marks:                  # a replayed step
-                marks = tr._reducer.release_marks
-                # device-side order: bucket 0 was released before the LAST bucket's release point (= the end of the replayed
-                # backward), i.e. its all-reduce could start while the backward was still running
-                early.append((marks[0].elapsed_time(marks[-1]), log))
-                tr._reducer.release_marks = []
-        q.put((rank, nb, early, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
-        dist.barrier()
-        dist.destroy_process_group()
-    except Exception as e:
-        q.put((rank, repr(e)))
-        raise
-
-
-@pytest.mark.timeout(400)
-def test_graph_mode_releases_bucket_0_before_the_backward_ends(tmp_path):
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _port()
-    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=200) for _ in procs]
-    assert all(len(g) == 4 for g in got), got
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    res = {g[0]: g for g in got}
-    nb = res[0][1]
-    assert nb >= 3
-    for r in (0, 1):
-        early = res[r][2]
-        assert len(early) >= 3                                            # steps 3.. are replays (1 warm-up, 1 capture)
-        for ms, log in early:
-            assert log == list(range(nb))                                 # collectives enqueued in fixed bucket order
-            assert ms > 0.0, ms                                           # bucket 0 released strictly before the backward's end
-    for k in res[0][3]:
-        assert np.array_equal(res[0][3][k], res[1][3][k]), k              # ranks bit-identical
-
-
 def _capture_worker(port, tmp, q, use_ddp):
-    """one rank, backend nccl (RCCL), PSND_DDP_GRAPH=capture: the all-reduce nodes live INSIDE the replayed hipGraph"""
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0',
-                          PSND_DDP_GRAPH='capture', PSND_DDP_FORCE='1' if use_ddp else '0')
+                          PSND_DDP_FORCE='1' if use_ddp else '0')
+        os.environ.pop('PSND_DDP_GRAPH', None)
         import torch.distributed as dist
         from pytorch_sound_amd import optim as poptim
         from pytorch_sound_amd.trainer import Trainer, LogType
@@ -215,9 +145,10 @@ def _capture_worker(port, tmp, q, use_ddp):
         net = _deep_net().to(dev)
         g = torch.Generator().manual_seed(5)
         data = [(torch.randn(4, 4, 512, generator=g), torch.randn(4, 2, 512, generator=g)) for _ in range(6)]
+        data[3][0][0, 0, 0] = float('nan')                          # step 4: the NaN flag rides in the last bucket, the step is skipped
         tr = T(net, poptim.Adam(net.parameters(), lr=1e-3), data, data[:1], max_step=6, valid_max_step=1, save_interval=10 ** 6,
                log_interval=10 ** 6, save_dir=tmp, save_prefix='cap' + str(int(use_ddp)), seed=3)
-        modes = []
+        info = {}
         if use_ddp:
             from pytorch_sound_amd import distributed as pdist
             assert tr._reducer is not None and tr._reducer.active
@@ -230,9 +161,11 @@ def _capture_worker(port, tmp, q, use_ddp):
             tr.train(i)
         torch.cuda.synchronize()
         if use_ddp:
-            modes = [v.get('ddp') for v in tr._graphs.values() if 'graph' in v]
+            red = tr._reducer
+            info = {'modes': [v.get('ddp') for v in tr._graphs.values() if 'graph' in v], 'emit': list(red.emit_log),
+                    'nb': len(red.buckets), 'nparams': len(red.params), 'sizes': [len(b['params']) for b in red.buckets]}
             dist.destroy_process_group()
-        q.put((use_ddp, modes, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
+        q.put((use_ddp, info, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
     except Exception as e:
         q.put((use_ddp, repr(e)))
         raise
@@ -250,6 +183,18 @@ def test_rccl_all_reduce_captured_in_the_step_graph(tmp_path):
         p.join(timeout=120)
         assert p.exitcode == 0 and len(got) == 3, got
         res[use_ddp] = got
-    assert res[True][1] == ['capture'], res[True][1]                      # no fallback happened
+    info = res[True][1]
+    assert info['modes'] == ['capture'], info                            # no fallback happened
+    nb = info['nb']
+    assert nb >= 3
+    # launch order inside the captured backward: the all-reduce of bucket i was enqueued (forked onto RCCL's stream) the moment its
+    # last gradient existed - bucket 0 long before the last backward segment - and the buckets went out in fixed order
+    assert [i for i, _ in info['emit']] == list(range(nb))
+    arrived = [a for _, a in info['emit']]
+    assert arrived == list(np.cumsum(info['sizes'])), (arrived, info['sizes'])
+    assert arrived[0] < info['nparams'] // 2
     for k in res[False][2]:
-        assert np.array_equal(res[False][2][k], res[True][2][k]), k       # sum over one rank = identity: bit-equal training
+        # sum over one rank = identity: the same training, NaN step skipped in both (two processes: the convolution library may
+        # pick other algorithms)
+        assert np.isfinite(res[True][2][k]).all()
+        assert np.allclose(res[False][2][k], res[True][2][k], rtol=1e-4, atol=1e-6), k

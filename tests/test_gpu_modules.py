@@ -116,7 +116,7 @@ def test_config4_block_vs_float64(T, N):
             m.layernorm.bias.copy_(0.1 * torch.randn(C))
     lens = torch.linspace(T, max(T // 3, 8), N).long()             # a length bucket padded to its longest clip
     mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
-    x0 = (0.3 * torch.randn(N, C, T, device=dev)) * (~mask).unsqueeze(1)
+    x0 = (0.1 * torch.randn(N, C, T, device=dev)) * (~mask).unsqueeze(1)   # keeps the logits within +-20: a conditioned softmax
     gy = torch.randn(N, C, T, device=dev)
     gatt = torch.randn(H * N, T, T, device=dev) * 0.1
 
@@ -141,7 +141,7 @@ def test_config4_block_vs_float64(T, N):
         yr, attr, gxr, gpr = run(ref_mods, torch.float64, att_in_loss)
         tol = lambda a, b, rt: float((a.double() - b).abs().max()) <= rt * float(b.abs().max())   # noqa: E731
         assert tol(y, yr, 3e-5), float((y.double() - yr).abs().max() / yr.abs().max())
-        assert float((att.double() - attr).abs().max()) <= 2e-5      # probabilities in [0, 1]; logits reach +-60 here
+        assert float((att.double() - attr).abs().max()) <= 1e-5      # probabilities in [0, 1]
         assert tol(gx, gxr, 2e-4), float((gx.double() - gxr).abs().max() / gxr.abs().max())
         for k in gp:
             assert tol(gp[k], gpr[k], 2e-4), (k, float((gp[k].double() - gpr[k]).abs().max() / gpr[k].abs().max()))
