@@ -163,6 +163,34 @@ int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g
                          void *g_out, void *stream);
 int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout, int Cin, int k, int Cb, int Ca,
                      void *wf, void *wb, float *bias_padded, void *stream);
+/* ---- ConvTranspose1d(Cin, Cout, K = 2 * stride, stride, padding <= stride) of the HiFi-GAN upsamplers (hifi_gan.py:109,
+ *  118-121) in polyphase form on the CL kernels:  y[t] = x[i] w[:, :, phi] + x[i-1] w[:, :, phi + stride],  t + padding =
+ *  i * stride + phi.  Low-resolution CL buffer (N, Lp, Cip) with clip rows [HP, HP + L), HP >= 1; high-resolution CL buffer
+ *  (N, LpO, Cr) with clip rows [HPO, HPO + L * stride), HPO >= padding and stride - padding rows behind the clip; rows outside
+ *  the clip of every output are written as zeros or left untouched (allocate the outputs zeroed).
+ *  psnd_convtr1d_prep : weight norm over dim 0 of v (Cin, Cout, K) (per INPUT channel, as torch weight_norm does for
+ *                       nn.ConvTranspose1d) -> bf16 packs wf, wb (2 * stride * Cr * Cip elements each, opaque fragment order) and
+ *                       bias_rep (stride * Cr floats: the bias once per phase).
+ *  psnd_convtr1d_cl_fwd: out_raw = y, out_act = leaky_relu(y, act_slope) (either may be NULL).
+ *  psnd_convtr1d_cl_bwd: g = g_raw + g_act * leaky'(act) (either part may be NULL) -> gx (N, Lp, Cip), g_eff (N, LpO, Cr; the
+ *                       combined gradient, required when g_act is given: its column sums are the bias gradient) and the
+ *                       weight-gradient slabs gw_part fp32 [S][2][Cip][stride * Cr], S = psnd_convtr1d_cl_wgrad_splits(...).
+ *  psnd_convtr1d_wnorm_bwd: slabs -> g_v (Cin, Cout, K), g_g (Cin). */
+int psnd_convtr1d_prep(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int stride, int Cr, int Cip,
+                       void *wf, void *wb, float *bias_rep, void *stream);
+int psnd_convtr1d_cl_fwd(const void *xa, const void *wf, const float *bias_rep, int64_t N, int Lp, int L, int HP, int Cip, int Cr,
+                         int stride, int padding, int LpO, int HPO, float act_slope, void *out_raw, void *out_act, void *stream);
+int psnd_convtr1d_cl_wgrad_splits(int64_t N, int Lp, int Cip, int Cr, int stride);
+int psnd_convtr1d_cl_bwd(const void *g_raw, const void *g_act, const void *act, float act_slope, const void *wb, const void *xa,
+                         int64_t N, int Lp, int L, int HP, int Cip, int Cr, int stride, int padding, int LpO, int HPO, void *gx,
+                         void *g_eff, float *gw_part, void *stream);
+int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const float *v, const float *g, int Cin, int Cout, int K, int stride,
+                            int Cr, int Cip, float *gv, float *gg, void *stream);
+/* out = leaky_relu((a + b + c + d) / count, slope) over `count` (1..4) bf16 buffers of n elements (n % 8 == 0): the mean of a
+ * stage's resblocks and the activation in front of the next upsampler (hifi_gan.py:122-131); backward gin = g * leaky'(y) / count. */
+int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c, const void *d, int count, float slope, void *out, int64_t n,
+                         void *stream);
+int psnd_cl_mean_act_bwd(const void *g, const void *y, int count, float slope, void *gin, int64_t n, void *stream);
 /* psnd_conv1d_prep for n convs in ONE launch.  descs_dev: device array of n records
  *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cout, Cin, k, Cb, Ca, blk0; }   (72 bytes, blk0 = sum of
  *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written

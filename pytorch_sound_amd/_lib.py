@@ -50,6 +50,13 @@ SIGNATURES = {
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
     'psnd_conv_stats': (_INT, [_P, _INT]),
+    'psnd_convtr1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
+    'psnd_convtr1d_cl_fwd': (_INT, [_P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _P, _P, _P]),
+    'psnd_convtr1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
+    'psnd_convtr1d_cl_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
+    'psnd_convtr1d_wnorm_bwd': (_INT, [_P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P]),
+    'psnd_cl_mean_act_fwd': (_INT, [_P, _P, _P, _P, _INT, _F, _P, _I64, _P]),
+    'psnd_cl_mean_act_bwd': (_INT, [_P, _P, _INT, _F, _P, _I64, _P]),
     'psnd_groupnorm1_fwd': (_INT, [_P, _P, _P, _P, _I64, _INT, _I64, _F, _INT, _P, _P, _P, _P]),
     'psnd_groupnorm1_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _P, _P, _P, _P, _P]),
     'psnd_softmax_keys_fwd': (_INT, [_P, _P, _I64, _I64, _F, _P]),

@@ -300,6 +300,99 @@ def conv_transpose_cl(xa, up, shape, act_slope=0.1):
     return raw, act, out_shape
 
 
+class ConvTransposeCL(torch.autograd.Function):
+    """ConvTranspose1d(k = 2 * stride, padding p) of hifi_gan.py:109 / 118-121 in polyphase form on the CL kernels
+    (psnd_convtr1d_*): raw = y, act = leaky_relu(y, act_slope); the activations never leave the CL layout and no zero is
+    multiplied.  weight_v: (Cin, Cout, K), weight_g: (Cin, 1, 1) - weight norm over dim 0, as torch's for nn.ConvTranspose1d."""
+
+    @staticmethod
+    def forward(ctx, xa, weight_v, weight_g, bias, shape, out_shape, stride, padding, act_slope):
+        _need(xa, torch.bfloat16)
+        Cin, Cout, K = weight_v.shape
+        if K != 2 * stride or padding > stride:
+            raise _lib.PsndError('ConvTransposeCL: kernel size %d, stride %d, padding %d (needs K = 2 * stride, padding <= stride)'
+                                 % (K, stride, padding))
+        Cip, Cr = xa.shape[2], round_up(Cout, ALIGN_C)
+        if Cip != round_up(Cin, ALIGN_C) or out_shape.L != shape.L * stride or out_shape.N != shape.N:
+            raise _lib.PsndError('ConvTransposeCL: buffer / geometry mismatch')
+        dev = xa.device
+        v32, g32 = weight_v.detach().contiguous(), weight_g.detach().contiguous()
+        b32 = None if bias is None else bias.detach().contiguous()
+        wf = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+        wb = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+        bp = torch.empty(stride * Cr, dtype=torch.float32, device=dev)
+        raw = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
+        act = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            st = stream_ptr(dev)
+            check(lib().psnd_convtr1d_prep(ptr(v32), ptr(g32), ptr(b32), Cin, Cout, K, stride, Cr, Cip, ptr(wf), ptr(wb), ptr(bp), st),
+                  'psnd_convtr1d_prep')
+            check(lib().psnd_convtr1d_cl_fwd(ptr(xa), ptr(wf), ptr(bp), shape.N, shape.Lp, shape.L, shape.HP, Cip, Cr, stride, padding,
+                                             out_shape.Lp, out_shape.HP, float(act_slope), ptr(raw), ptr(act), st), 'psnd_convtr1d_cl_fwd')
+        ctx.geo = (shape, out_shape, stride, padding, float(act_slope), Cin, Cout, K, Cip, Cr)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xa, v32, g32, wb, act)
+        return raw, act
+
+    @staticmethod
+    def backward(ctx, g_raw, g_act):
+        xa, v32, g32, wb, act = ctx.saved_tensors
+        shape, out_shape, stride, padding, slope, Cin, Cout, K, Cip, Cr = ctx.geo
+        dev = xa.device
+        g_raw = None if g_raw is None else g_raw.contiguous()
+        g_act = None if g_act is None else g_act.contiguous()
+        if g_raw is None and g_act is None:
+            raise _lib.PsndError('ConvTransposeCL backward: no incoming gradient')
+        S = lib().psnd_convtr1d_cl_wgrad_splits(shape.N, shape.Lp, Cip, Cr, stride)
+        gx = torch.empty((shape.N, shape.Lp, Cip), dtype=torch.bfloat16, device=dev)
+        g_eff = torch.empty((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev) if g_act is not None else None
+        gw = torch.empty((S, 2, Cip, stride * Cr), dtype=torch.float32, device=dev)
+        gv, gg = torch.empty_like(v32), torch.empty_like(g32)
+        with torch.cuda.device(dev):
+            st = stream_ptr(dev)
+            check(lib().psnd_convtr1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None), slope, ptr(wb), ptr(xa),
+                                             shape.N, shape.Lp, shape.L, shape.HP, Cip, Cr, stride, padding, out_shape.Lp, out_shape.HP,
+                                             ptr(gx), ptr(g_eff), ptr(gw), st), 'psnd_convtr1d_cl_bwd')
+            check(lib().psnd_convtr1d_wnorm_bwd(ptr(gw), S, ptr(v32), ptr(g32), Cin, Cout, K, stride, Cr, Cip, ptr(gv), ptr(gg), st),
+                  'psnd_convtr1d_wnorm_bwd')
+        g_bias = None
+        if ctx.has_bias:       # column sums of the combined gradient (halo rows are zero)
+            g_bias = torch.sum((g_eff if g_eff is not None else g_raw).view(-1, Cr), 0, dtype=torch.float32)[:Cout]
+        return gx, gv, gg, g_bias, None, None, None, None, None
+
+
+class MeanActCL(torch.autograd.Function):
+    """leaky_relu(mean of the stage's resblock outputs, slope) on CL buffers in one pass each way (hifi_gan.py:122-131:
+    xs / num_kernels, then the leaky_relu in front of the next upsampler / of conv_post)"""
+
+    @staticmethod
+    def forward(ctx, slope, *rs):
+        n = len(rs)
+        if not 1 <= n <= 4:
+            raise _lib.PsndError('MeanActCL: 1..4 branches, got %d' % n)
+        rs = [r.contiguous() for r in rs]
+        for r in rs:
+            _need(r, torch.bfloat16)
+        out = torch.empty_like(rs[0])
+        ps = [ptr(r) for r in rs] + [None] * (4 - n)
+        with torch.cuda.device(out.device):
+            check(lib().psnd_cl_mean_act_fwd(ps[0], ps[1], ps[2], ps[3], n, float(slope), ptr(out), out.numel(), stream_ptr(out.device)),
+                  'psnd_cl_mean_act_fwd')
+        ctx.n, ctx.slope = n, float(slope)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.contiguous()
+        gin = torch.empty_like(out)
+        with torch.cuda.device(out.device):
+            check(lib().psnd_cl_mean_act_bwd(ptr(g), ptr(out), ctx.n, ctx.slope, ptr(gin), out.numel(), stream_ptr(out.device)),
+                  'psnd_cl_mean_act_bwd')
+        return (None,) + (gin,) * ctx.n
+
+
 def prep_all(owner, convs):
     """weight norm + both bf16 packs + padded bias of every conv in `convs` (WNConv1d modules) in ONE launch
     (psnd_conv1d_prep_multi).  The pack buffers and the device descriptor table are cached on `owner` and rebuilt only

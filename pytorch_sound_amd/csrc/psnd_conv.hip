@@ -58,10 +58,25 @@ struct ConvParams {
     long long R;
     int Lp, L, HP, Ca, Cb, k, off0, dstep, hm;
     float act_slope, mask_slope, a2_slope;
+    // transposed-conv ("up") mode, ConvTranspose1d(k = 2u, stride u, padding p) of hifi_gan.py:109 in polyphase form.  The GEMM
+    // rows are the LOW-resolution rows (geometry Lp / L / HP above); the HIGH-resolution CL buffer (N, LpO, Cr), clip rows
+    // [HPO, HPO + LO), is seen as a matrix of u * Cr columns: low row l <-> the u consecutive high rows starting at
+    // HPO - p + (l - HP) * u, i.e. column block phi of row l is high row t = (l - HP) * u + phi - p of the clip.
+    //   up_role 1: the OUTPUT is that view (forward: Y[l][phi, co] = x[l] W[phi] + x[l-1] W[phi + u], Cb = u * Cr)
+    //   up_role 2: the A operand is that view (input gradient: gx[l] = G[l] Wt[phi] + G[l+1] Wt[phi + u], Ca = u * Cr)
+    int up_role, up_u, up_p, up_LpO, up_HPO, up_LO, up_Cr;
 #ifdef PSND_TRACE
     long long *trace;
 #endif
 };
+// first high-resolution row (global row index of the (N, LpO, Cr) buffer) of low-resolution row r, or -1 when the u rows do
+// not lie inside the clip's buffer (such low rows carry no valid output)
+__device__ __forceinline__ long long up_row_base(int Lp, int HP, int u, int pp, int LpO, int HPO, long long r) {
+    const long long n = r / Lp;
+    const int l = (int)(r - n * Lp);
+    const int b = HPO - pp + (l - HP) * u;
+    return (b >= 0 && b + u <= LpO) ? n * (long long)LpO + b : -1;
+}
 #ifdef PSND_TRACE
 #define PSND_CSTAMP(i_)                                                                                         \
     do {                                                                                                        \
@@ -127,10 +142,12 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 //   KT: taps the register ring is sized for (k <= KT);  D: stages in flight;  COMBINE: A = A + A2 * leaky'(AM)
 //   MT: 32-row MFMA tiles per wave (1: 64-row workgroup tile; 2: 128 rows - every B fragment feeds two MFMAs, for launches with
 //   enough rows to fill the chip anyway: the stage loop is bound by the B fragment loads, whose bytes per FLOP go with 1 / rows)
-template <int KT, int D, bool COMBINE, int NBUF, int MT>
+//   HMX: largest tap reach the staged A tile (and its register ring) is sized for: 25 covers every conv of hifi_gan_v1 / v2
+//   (k = 11, dilation 5); the 7-tap instances also exist with 40 (hifi_gan_v3: k = 7, dilation 12 -> 36)
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
-    constexpr int BMt = 64 * MT, NAt = (BMt + 2 * 25) * PCS / 256 + 1;
+    constexpr int BMt = 64 * MT, NAt = (BMt + 2 * HMX) * PCS / 256 + 1;
     const int rowsA = BMt + 2 * p.hm;
     const int buf_elems = rowsA * RS;      // two A stage buffers; the weights never enter LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -163,7 +180,9 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     // exactly only in straight-line code - one conditional fetch and every later wait degrades to vmcnt(0),
     // which serialises the whole ring (measured: 1.7 k cycles per stage instead of 0.5 k).
     constexpr unsigned OOB = 0xffffffffu;
-    const unsigned a_bytes = (unsigned)((size_t)p.R * p.Ca * sizeof(bf16_t));
+    const bool upA = p.up_role == 2;           // the A operand is the high-resolution view
+    const unsigned a_bytes = upA ? (unsigned)((size_t)(p.R / p.Lp) * p.up_LpO * p.up_Cr * sizeof(bf16_t))
+                                 : (unsigned)((size_t)p.R * p.Ca * sizeof(bf16_t));
     const unsigned w_bytes = (unsigned)((size_t)p.k * p.Cb * p.Ca * sizeof(bf16_t));
     const __amdgpu_buffer_rsrc_t rA = make_uniform_rsrc(p.A ? p.A : p.A2, (int)a_bytes);
     __amdgpu_buffer_rsrc_t rA2 = rA, rAM = rA;
@@ -180,7 +199,12 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         const int idx = tid + 256 * u;
         const int rr = idx / PCS, pc = idx % PCS;
         const long long r = r0 - p.hm + rr;
-        aoff[u] = (idx < nA && r >= 0 && r < p.R) ? (unsigned)(((size_t)r * p.Ca + 8 * pc) * sizeof(bf16_t)) : OOB;
+        if (!upA) {
+            aoff[u] = (idx < nA && r >= 0 && r < p.R) ? (unsigned)(((size_t)r * p.Ca + 8 * pc) * sizeof(bf16_t)) : OOB;
+        } else {
+            const long long hb = (idx < nA && r >= 0 && r < p.R) ? up_row_base(p.Lp, p.HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, r) : -1;
+            aoff[u] = hb >= 0 ? (unsigned)(((size_t)hb * p.up_Cr + 8 * pc) * sizeof(bf16_t)) : OOB;
+        }
     }
     auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) __attribute__((always_inline)) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
@@ -311,9 +335,16 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         const int col = n0 + 8 * cg;
         if (r >= p.R || col >= p.Cb) continue;
         const int l = (l0 + row) % p.Lp;
-        const size_t o = (size_t)r * p.Cb + col;
+        size_t o = (size_t)r * p.Cb + col;
         float v[8];
-        const bool inside = l >= p.HP && l < p.HP + p.L;
+        bool inside = l >= p.HP && l < p.HP + p.L;
+        if (p.up_role == 1) {                  // forward of the transposed conv: column block phi of low row l = high row t
+            const long long hb = up_row_base(p.Lp, p.HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, r);
+            if (hb < 0) continue;
+            const int t = (l - p.HP) * p.up_u + col / p.up_Cr - p.up_p;
+            inside = t >= 0 && t < p.up_LO;
+            o = (size_t)hb * p.up_Cr + col;
+        }
         if (inside) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(sO + row * OS + 8 * cg);
             const f32x4 a1 = *reinterpret_cast<const f32x4 *>(sO + row * OS + 8 * cg + 4);
@@ -367,10 +398,10 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #endif
 }
 
-template <int KT, int D, bool COMBINE, int NBUF, int MT>
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25>
 __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    conv_cl_body<KT, D, COMBINE, NBUF, MT>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
@@ -449,6 +480,8 @@ struct WgradParams {
     long long R;
     int Ca, Cb, k, off0, dstep, rows_per_split;
     float g2_slope;
+    // up_u > 0: the `xa` operand is the high-resolution view of a transposed conv (ConvParams, up_role 2): Ca = up_u * up_Cr
+    int up_u, up_p, up_Lp, up_HP, up_LpO, up_HPO, up_Cr;
 #ifdef PSND_TRACE
     long long *trace;
 #endif
@@ -492,7 +525,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     PSND_WSTAMP(0);
     constexpr unsigned OOB = 0xffffffffu;
-    const int g_bytes = (int)((size_t)p.R * p.Cb * sizeof(bf16_t)), x_bytes = (int)((size_t)p.R * p.Ca * sizeof(bf16_t));
+    const int g_bytes = (int)((size_t)p.R * p.Cb * sizeof(bf16_t));
+    const int x_bytes = p.up_u > 0 ? (int)((size_t)(p.R / p.up_Lp) * p.up_LpO * p.up_Cr * sizeof(bf16_t)) : (int)((size_t)p.R * p.Ca * sizeof(bf16_t));
     const bool haveG1 = p.G1 != nullptr;
     const __amdgpu_buffer_rsrc_t rG1 = make_uniform_rsrc(haveG1 ? p.G1 : p.G2, g_bytes);
     const __amdgpu_buffer_rsrc_t rG2 = make_uniform_rsrc(comb ? p.G2 : p.G1, g_bytes);
@@ -532,8 +566,14 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
 #pragma unroll
             for (int j = 0; j < WKT; ++j) {
                 const long long rx = r + p.off0 + (t0 + j) * p.dstep;
-                const bool ok = j < nt && rok && rx >= 0 && rx < p.R && xok;
-                vx[s][j] = ld16(rX, ok ? (unsigned)(((size_t)rx * p.Ca + ci0 + 8 * cg) * sizeof(bf16_t)) : OOB);
+                bool ok = j < nt && rok && rx >= 0 && rx < p.R && xok;
+                size_t xo = (size_t)rx * p.Ca;
+                if (p.up_u > 0) {                       // uniform
+                    const long long hb = ok ? up_row_base(p.up_Lp, p.up_HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, rx) : -1;
+                    ok = hb >= 0;
+                    xo = (size_t)hb * p.up_Cr;
+                }
+                vx[s][j] = ld16(rX, ok ? (unsigned)((xo + ci0 + 8 * cg) * sizeof(bf16_t)) : OOB);
             }
         };
         auto stage = [&](auto sc, long long r0, bf16_t *sA, bf16_t *sB) __attribute__((always_inline)) {
@@ -639,7 +679,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF, bool COMBINE, int MT>
+template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25>
 __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
@@ -648,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
         conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
-        conv_cl_body<KT, D, COMBINE, NBUF, MT>(pc, c % cgx, c / cgx, smem_dyn, 0);
+        conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX>(pc, c % cgx, c / cgx, smem_dyn, 0);
     }
 }
 
@@ -833,6 +873,57 @@ static int conv_row_tiles(int64_t R, int Cb) {
     return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;
 }
 
+// enqueue one conv_cl_kernel launch for a filled ConvParams (tile instance by size, tap count, operand combine, tap reach)
+static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
+    const bool combine = p.A2 != nullptr;
+    const int k = p.k, Cb = p.Cb, hm = p.hm;
+    if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
+    const int mt = conv_row_tiles(p.R, Cb);
+    const int bm = 64 * mt;
+    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
+    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
+    if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "%s: LDS %zu too large", what, lds);
+    dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + BN - 1) / BN));
+#define PSND_CONV_LAUNCH(KT_, D_, C_, H_)                                                                             \
+    do {                                                                                                              \
+        auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_>;   \
+        if (lds > 64 * 1024) {                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: set LDS size: %s", what, hipGetErrorString(e));           \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                                        \
+    } while (0)
+    if (hm > 25 && !combine) PSND_CONV_LAUNCH(7, 3, false, 40);
+    else if (hm > 25) PSND_CONV_LAUNCH(7, 3, true, 40);
+    else if (k <= 3 && !combine) PSND_CONV_LAUNCH(3, 8, false, 25);
+    else if (k <= 3) PSND_CONV_LAUNCH(3, 4, true, 25);
+    else if (k <= 7 && !combine) PSND_CONV_LAUNCH(7, 3, false, 25);
+    else if (k <= 7) PSND_CONV_LAUNCH(7, 3, true, 25);
+    else if (k <= 11 && !combine) PSND_CONV_LAUNCH(11, 2, false, 25);
+    else if (k <= 11) PSND_CONV_LAUNCH(11, 2, true, 25);
+    else if (!combine) PSND_CONV_LAUNCH(16, 2, false, 25);
+    else PSND_CONV_LAUNCH(16, 2, true, 25);
+#undef PSND_CONV_LAUNCH
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e_));
+    g_conv_stats[mt == 2 ? 1 : 0]++;
+    return PSND_OK;
+}
+
+static void conv_params_plain(ConvParams &p) {
+    p.up_role = 0, p.up_u = 0, p.up_p = 0, p.up_LpO = 0, p.up_HPO = 0, p.up_LO = 0, p.up_Cr = 0;
+#ifdef PSND_TRACE
+    p.trace = nullptr;
+#endif
+}
+static void wgrad_params_plain(WgradParams &p) {
+    p.up_u = 0, p.up_p = 0, p.up_Lp = 0, p.up_HP = 0, p.up_LpO = 0, p.up_HPO = 0, p.up_Cr = 0;
+#ifdef PSND_TRACE
+    p.trace = nullptr;
+#endif
+}
+
 extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope, const void *W, const float *bias,
                               const void *res, const void *mask_src, int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k,
                               int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
@@ -848,9 +939,11 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
     }
     if (hm > HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: tap reach %d exceeds the halo HP=%d", hm, HP);
-    if (hm > 25) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl: tap reach %d > 25 (size of the staged A tile)", hm);
     if (N == 0) return PSND_OK;
+    if ((size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 32) || (size_t)k * Cb * Ca * 2 >= ((size_t)1 << 32))
+        PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: operand larger than 4 GB (32-bit buffer offsets)");
     ConvParams p;
+    conv_params_plain(p);
     p.A = static_cast<const bf16_t *>(A), p.A2 = static_cast<const bf16_t *>(A2), p.AM = static_cast<const bf16_t *>(AM);
     p.a2_slope = a2_slope;
     p.W = static_cast<const bf16_t *>(W), p.bias = bias;
@@ -865,37 +958,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    const int mt = conv_row_tiles(p.R, Cb);
-    const int bm = 64 * mt;
-    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
-    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
-    if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: LDS %zu too large", lds);
-    dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + BN - 1) / BN));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-#define PSND_CONV_LAUNCH(KT_, D_, C_)                                                                                 \
-    do {                                                                                                              \
-        auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2> : conv_cl_kernel<KT_, D_, C_, 2, 1>;           \
-        if (lds > 64 * 1024) {                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-            if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_cl: set LDS size: %s", hipGetErrorString(e));          \
-        }                                                                                                             \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                                        \
-    } while (0)
-    if ((size_t)p.R * Ca * 2 >= ((size_t)1 << 32) || (size_t)k * Cb * Ca * 2 >= ((size_t)1 << 32))
-        PSND_FAIL(PSND_E_SHAPE, "conv1d_cl: operand larger than 4 GB (32-bit buffer offsets)");
-    if (k <= 3 && !A2) PSND_CONV_LAUNCH(3, 8, false);
-    else if (k <= 3) PSND_CONV_LAUNCH(3, 4, true);
-    else if (k <= 7 && !A2) PSND_CONV_LAUNCH(7, 3, false);
-    else if (k <= 7) PSND_CONV_LAUNCH(7, 3, true);
-    else if (k <= 11 && !A2) PSND_CONV_LAUNCH(11, 2, false);
-    else if (k <= 11) PSND_CONV_LAUNCH(11, 2, true);
-    else if (!A2) PSND_CONV_LAUNCH(16, 2, false);
-    else PSND_CONV_LAUNCH(16, 2, true);
-#undef PSND_CONV_LAUNCH
-    PSND_CHECK_LAUNCH("conv1d_cl");
-    g_conv_stats[mt == 2 ? 1 : 0]++;
-    return PSND_OK;
+    return conv_launch(p, static_cast<hipStream_t>(stream), "conv1d_cl");
 }
 
 extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out,
@@ -978,6 +1041,7 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
     if (N == 0) return PSND_OK;
     if ((size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 32)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: operand larger than 4 GB");
     WgradParams p;
+    wgrad_params_plain(p);
     p.G1 = static_cast<const bf16_t *>(G1), p.G2 = static_cast<const bf16_t *>(G2), p.GM = static_cast<const bf16_t *>(GM);
     p.xa = static_cast<const bf16_t *>(xa), p.gw = gw_part, p.gbias = gbias_part, p.g_out = static_cast<bf16_t *>(g_out);
     p.R = N * (int64_t)Lp, p.Ca = Ca, p.Cb = Cb, p.k = k, p.off0 = off0, p.dstep = dstep, p.g2_slope = g2_slope;
@@ -1011,7 +1075,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         hm = (o < 0 ? -o : o) > hm ? (o < 0 ? -o : o) : hm;
     }
     const size_t buf = sizeof(bf16_t) * 40 * (size_t)(BM + 2 * hm);
-    const bool pairable = !no_pair && (G1 || G2) && (!G2 || GM) && gx && wb && xa && gw_part && k >= 1 && k <= 16 && hm <= 25 && hm <= HP && N > 0 &&
+    const bool pairable = !no_pair && (G1 || G2) && (!G2 || GM) && gx && wb && xa && gw_part && k >= 1 && k <= 16 && (hm <= 25 || (hm <= 40 && k <= 7)) && hm <= HP && N > 0 &&
                           Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
                           (size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 < ((size_t)1 << 32) && (size_t)k * Cb * Ca * 2 < ((size_t)1 << 32);
     if (!pairable) {
@@ -1022,6 +1086,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     }
     // input-gradient role: a conv from Cb to Ca channels
     ConvParams pc;
+    conv_params_plain(pc);
     pc.A = static_cast<const bf16_t *>(G1), pc.A2 = static_cast<const bf16_t *>(G2), pc.AM = static_cast<const bf16_t *>(GM);
     pc.a2_slope = g2_slope;
     pc.W = static_cast<const bf16_t *>(wb), pc.bias = nullptr;
@@ -1031,15 +1096,13 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     pc.act_slope = 1.f, pc.mask_slope = gx_mask_slope;
     // weight-gradient role
     WgradParams pw;
+    wgrad_params_plain(pw);
     pw.G1 = pc.A, pw.G2 = pc.A2, pw.GM = pc.AM;
     pw.xa = static_cast<const bf16_t *>(xa), pw.gw = gw_part, pw.gbias = gbias_part, pw.g_out = nullptr;
     pw.R = pc.R, pw.Ca = Ca, pw.Cb = Cb, pw.k = k, pw.off0 = -pad, pw.dstep = dil, pw.g2_slope = g2_slope;
     int64_t rps;
     const int splits = wgrad_splits(pw.R, Ca, Cb, k, &rps);
     pw.rows_per_split = (int)rps;
-#ifdef PSND_TRACE
-    pc.trace = nullptr, pw.trace = nullptr;
-#endif
     const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
     const char *pe = getenv("PSND_PAIR_MT");
     const int pair_mt = pe ? atoi(pe) : 0;
@@ -1051,9 +1114,9 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define PSND_PAIR_LAUNCH(KT_, D_, C_)                                                                                  \
+#define PSND_PAIR_LAUNCH(KT_, D_, C_, H_)                                                                              \
     do {                                                                                                              \
-        auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1>;   \
+        auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -1061,14 +1124,16 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);    \
     } while (0)
-    if (k <= 3 && !G2) PSND_PAIR_LAUNCH(3, 8, false);
-    else if (k <= 3) PSND_PAIR_LAUNCH(3, 4, true);
-    else if (k <= 7 && !G2) PSND_PAIR_LAUNCH(7, 3, false);
-    else if (k <= 7) PSND_PAIR_LAUNCH(7, 3, true);
-    else if (k <= 11 && !G2) PSND_PAIR_LAUNCH(11, 2, false);
-    else if (k <= 11) PSND_PAIR_LAUNCH(11, 2, true);
-    else if (!G2) PSND_PAIR_LAUNCH(16, 2, false);
-    else PSND_PAIR_LAUNCH(16, 2, true);
+    if (hm > 25 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 40);
+    else if (hm > 25) PSND_PAIR_LAUNCH(7, 3, true, 40);
+    else if (k <= 3 && !G2) PSND_PAIR_LAUNCH(3, 8, false, 25);
+    else if (k <= 3) PSND_PAIR_LAUNCH(3, 4, true, 25);
+    else if (k <= 7 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 25);
+    else if (k <= 7) PSND_PAIR_LAUNCH(7, 3, true, 25);
+    else if (k <= 11 && !G2) PSND_PAIR_LAUNCH(11, 2, false, 25);
+    else if (k <= 11) PSND_PAIR_LAUNCH(11, 2, true, 25);
+    else if (!G2) PSND_PAIR_LAUNCH(16, 2, false, 25);
+    else PSND_PAIR_LAUNCH(16, 2, true, 25);
 #undef PSND_PAIR_LAUNCH
     PSND_CHECK_LAUNCH("conv1d_cl_bwd");
     g_conv_stats[mt == 2 ? 3 : 2]++;
@@ -1148,5 +1213,247 @@ extern "C" int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, 
     else
         hipLaunchKernelGGL(conv_finish_multi_kernel<false>, dim3(total), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd_multi");
+    return PSND_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ConvTranspose1d(Cin, Cout, K = 2u, stride u, padding p = u/2) of the HiFi-GAN upsamplers (hifi_gan.py:109, 118-121) in
+// POLYPHASE form on the same implicit-GEMM kernels:  y[t] = x[i] w[:, :, phi] + x[i-1] w[:, :, phi + u],  (t + p) = i u + phi.
+// Seen from the low-resolution rows it is ONE 2-tap convolution from Cin to u * Cout channels whose output row l, column
+// block phi IS high-resolution row (l - HP) u + phi - p (ConvParams::up_role); no zero is multiplied, the activations never
+// leave the CL layout.  Weight norm of nn.ConvTranspose1d runs over dim 0 = per INPUT channel.
+//   forward        psnd_convtr1d_cl_fwd : A = xa (low),  W = wf [2][u*Cr][Cip],  taps (0, -1),  output = high view (role 1)
+//   input gradient psnd_convtr1d_cl_bwd : A = g (high view, role 2), W = wb [2][Cip][u*Cr], taps (0, +1) -> gx (low); the combined
+//                  gradient g = g_raw + g_act * leaky'(act) is written back (g_eff) for the weight gradient
+//   weight gradient: the wgrad kernel with the roles of its operands swapped ("g" := xa, "xa" := g_eff as the high view):
+//                  slabs gw[S][2][Cip][u*Cr] - channel-contiguous per input channel, which is the weight-norm group
+//   psnd_convtr1d_wnorm_bwd: slabs -> (g_v, g_g);  the bias gradient is the column sum of g_eff (caller)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// one block per input channel ci: w = g[ci] * v[ci] / ||v[ci]||;  v: (Cin, Cout, K), K = 2u
+__global__ __launch_bounds__(256) void convtr_prep_kernel(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int u,
+                                                          int Cr, int Cip, bf16_t *wf, bf16_t *wb, float *bp) {
+    __shared__ float red[4];
+    const int ci = blockIdx.x, n = Cout * K;
+    const float *vr = v + (size_t)ci * n;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) ss += vr[i] * vr[i];
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float scale = g[ci] / __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const int Nn = u * Cr;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int co = i / K, jk = i - co * K;
+        const int tap = jk / u, phi = jk - tap * u;
+        const bf16_t w = f2bf(vr[i] * scale);
+        wf[pack_index(2, tap, phi * Cr + co, ci, Nn, Cip)] = w;
+        wb[pack_index(2, tap, ci, phi * Cr + co, Cip, Nn)] = w;
+    }
+    if (ci == 0)
+        for (int i = threadIdx.x; i < Nn; i += 256) {
+            const int co = i % Cr;
+            bp[i] = (bias && co < Cout) ? bias[co] : 0.f;
+        }
+}
+
+// one block per input channel ci: s[co][jk] = sum over slabs of gw[tap][ci][phi * Cr + co] (jk = phi + tap * u), then the weight-norm
+// backward of the group v[ci] (Cout * K elements):  g_g = <s, vhat>,  g_v = (g / ||v||) (s - vhat g_g)
+__global__ __launch_bounds__(256) void convtr_finish_kernel(const float *gw_part, int splits, const float *v, const float *g, int Cin,
+                                                            int Cout, int K, int u, int Cr, int Cip, float *gv, float *gg) {
+    extern __shared__ float s_gw[];          // Cout * K
+    __shared__ float red[8];
+    const int ci = blockIdx.x, n = Cout * K, Nn = u * Cr;
+    const size_t slab = (size_t)2 * Cip * Nn;
+    const float *vr = v + (size_t)ci * n;
+    float ss = 0.f, dot = 0.f;
+    for (int e = threadIdx.x; e < 2 * u * Cout; e += 256) {          // (tap, phi, co) with co fastest: coalesced slab reads
+        const int co = e % Cout, tp = e / Cout;                      // tp = tap * u + phi = jk
+        const int tap = tp / u, phi = tp - tap * u;
+        const float *src = gw_part + ((size_t)tap * Cip + ci) * Nn + phi * Cr + co;
+        float a = 0.f;
+        for (int sp = 0; sp < splits; ++sp) a += src[(size_t)sp * slab];
+        s_gw[co * K + tp] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float vv = vr[i];
+        ss += vv * vv;
+        dot += vv * s_gw[i];
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        ss += __shfl_xor(ss, m, 64);
+        dot += __shfl_xor(dot, m, 64);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss, red[4 + (threadIdx.x >> 6)] = dot;
+    __syncthreads();
+    const float sst = red[0] + red[1] + red[2] + red[3], dott = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.f / __builtin_sqrtf(sst);
+    const float d = dott * inv;
+    const float gs = g[ci] * inv;
+    for (int i = threadIdx.x; i < n; i += 256) gv[(size_t)ci * n + i] = gs * (s_gw[i] - vr[i] * inv * d);
+    if (threadIdx.x == 0) gg[ci] = d;
+}
+
+// y = leaky_relu((a + b + c + d) / count, slope) over bf16 buffers (the mean of a stage's resblocks + the next activation,
+// hifi_gan.py:122-131), and its backward g_in = g * leaky'(y) / count (the same tensor for every branch)
+__global__ __launch_bounds__(256) void cl_mean_act_kernel(const bf16_t *a, const bf16_t *b, const bf16_t *c, const bf16_t *d, int count,
+                                                          float slope, bf16_t *out, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const bf16_t *src[4] = {a, b, c, d};
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < count; ++s) {
+        const uint4 q = reinterpret_cast<const uint4 *>(src[s])[i];
+        const unsigned *pq = reinterpret_cast<const unsigned *>(&q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[2 * e] += bf2f((bf16_t)(pq[e] & 0xffff)), acc[2 * e + 1] += bf2f((bf16_t)(pq[e] >> 16));
+    }
+    unsigned w[4];
+    const float cnt = (float)count;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = acc[2 * e] / cnt, x1 = acc[2 * e + 1] / cnt;
+        w[e] = pack_bf16(x0 > 0.f ? x0 : x0 * slope, x1 > 0.f ? x1 : x1 * slope);
+    }
+    reinterpret_cast<uint4 *>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ __launch_bounds__(256) void cl_mean_act_bwd_kernel(const bf16_t *g, const bf16_t *y, int count, float slope, bf16_t *gin, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 qg = reinterpret_cast<const uint4 *>(g)[i], qy = reinterpret_cast<const uint4 *>(y)[i];
+    const unsigned *pg = reinterpret_cast<const unsigned *>(&qg), *py = reinterpret_cast<const unsigned *>(&qy);
+    unsigned w[4];
+    const float cnt = (float)count;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float g0 = bf2f((bf16_t)(pg[e] & 0xffff)), g1 = bf2f((bf16_t)(pg[e] >> 16));
+        const float y0 = bf2f((bf16_t)(py[e] & 0xffff)), y1 = bf2f((bf16_t)(py[e] >> 16));
+        w[e] = pack_bf16(g0 * (y0 > 0.f ? 1.f : slope) / cnt, g1 * (y1 > 0.f ? 1.f : slope) / cnt);
+    }
+    reinterpret_cast<uint4 *>(gin)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+}  // namespace
+
+static int convtr_check(const char *what, int64_t N, int Lp, int L, int HP, int Cip, int Cr, int u, int p, int LpO, int HPO) {
+    if (u < 1 || u > 16 || p < 0 || p > u) PSND_FAIL(PSND_E_SHAPE, "%s: stride %d, padding %d (kernel size must be 2 * stride, padding <= stride)", what, u, p);
+    if (Cip % 32 != 0 || Cr % 32 != 0) PSND_FAIL(PSND_E_SHAPE, "%s: channel counts %d, %d must be multiples of 32", what, Cip, Cr);
+    if (N < 0 || L <= 0 || HP < 1 || Lp < L + 2 * HP) PSND_FAIL(PSND_E_SHAPE, "%s: low-resolution geometry N=%lld Lp=%d L=%d HP=%d (HP >= 1)", what, (long long)N, Lp, L, HP);
+    if (HPO < p || LpO < HPO + L * u + (u - p)) PSND_FAIL(PSND_E_SHAPE, "%s: high-resolution geometry LpO=%d HPO=%d for %d rows (HPO >= p, u - p rows behind the clip)", what, LpO, HPO, L * u);
+    if ((size_t)N * LpO * Cr * 2 >= ((size_t)1 << 32) || (size_t)N * Lp * Cip * 2 >= ((size_t)1 << 32) || (size_t)4 * u * Cr * Cip >= ((size_t)1 << 32))
+        PSND_FAIL(PSND_E_SHAPE, "%s: operand larger than 4 GB (32-bit buffer offsets)", what);
+    return PSND_OK;
+}
+
+extern "C" int psnd_convtr1d_prep(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int stride, int Cr, int Cip,
+                                  void *wf, void *wb, float *bias_rep, void *stream) {
+    if (!v || !g || !wf || !wb || !bias_rep) PSND_FAIL(PSND_E_ARG, "convtr1d_prep: null pointer");
+    if (K != 2 * stride || Cr < Cout || Cip < Cin || Cr % 32 != 0 || Cip % 32 != 0) PSND_FAIL(PSND_E_SHAPE, "convtr1d_prep: K=%d stride=%d Cr=%d Cip=%d", K, stride, Cr, Cip);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cr != Cout || Cip != Cin) {
+        const size_t nb = sizeof(bf16_t) * (size_t)2 * stride * Cr * Cip;
+        hipError_t e = hipMemsetAsync(wf, 0, nb, s);
+        if (e == hipSuccess) e = hipMemsetAsync(wb, 0, nb, s);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "convtr1d_prep: memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(convtr_prep_kernel, dim3(Cin), dim3(256), 0, s, v, g, bias, Cin, Cout, K, stride, Cr, Cip, static_cast<bf16_t *>(wf),
+                       static_cast<bf16_t *>(wb), bias_rep);
+    PSND_CHECK_LAUNCH("convtr1d_prep");
+    return PSND_OK;
+}
+
+extern "C" int psnd_convtr1d_cl_fwd(const void *xa, const void *wf, const float *bias_rep, int64_t N, int Lp, int L, int HP, int Cip, int Cr,
+                                    int stride, int padding, int LpO, int HPO, float act_slope, void *out_raw, void *out_act, void *stream) {
+    if (!xa || !wf || (!out_raw && !out_act)) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_fwd: null pointer");
+    int rc = convtr_check("convtr1d_cl_fwd", N, Lp, L, HP, Cip, Cr, stride, padding, LpO, HPO);
+    if (rc != PSND_OK) return rc;
+    if (N == 0) return PSND_OK;
+    ConvParams p;
+    conv_params_plain(p);
+    p.A = static_cast<const bf16_t *>(xa), p.A2 = nullptr, p.AM = nullptr, p.a2_slope = 1.f;
+    p.W = static_cast<const bf16_t *>(wf), p.bias = bias_rep, p.res = nullptr, p.mask_src = nullptr;
+    p.out_raw = static_cast<bf16_t *>(out_raw), p.out_act = static_cast<bf16_t *>(out_act), p.a_eff_out = nullptr;
+    p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = Cip, p.Cb = stride * Cr, p.k = 2, p.off0 = 0, p.dstep = -1, p.hm = 1;
+    p.act_slope = act_slope, p.mask_slope = 1.f;
+    p.up_role = 1, p.up_u = stride, p.up_p = padding, p.up_LpO = LpO, p.up_HPO = HPO, p.up_LO = L * stride, p.up_Cr = Cr;
+    return conv_launch(p, static_cast<hipStream_t>(stream), "convtr1d_cl_fwd");
+}
+
+extern "C" int psnd_convtr1d_cl_wgrad_splits(int64_t N, int Lp, int Cip, int Cr, int stride) {
+    if (N <= 0 || Lp <= 0 || Cip <= 0 || Cr <= 0 || stride <= 0) return 0;
+    return wgrad_splits(N * (int64_t)Lp, stride * Cr, Cip, 2, nullptr);
+}
+
+extern "C" int psnd_convtr1d_cl_bwd(const void *g_raw, const void *g_act, const void *act, float act_slope, const void *wb, const void *xa,
+                                    int64_t N, int Lp, int L, int HP, int Cip, int Cr, int stride, int padding, int LpO, int HPO, void *gx,
+                                    void *g_eff, float *gw_part, void *stream) {
+    if ((!g_raw && !g_act) || (g_act && !act) || !wb || !xa || !gx || !gw_part) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_bwd: null pointer");
+    if (g_act && !g_eff) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_bwd: g_eff (the combined gradient, N x LpO x Cr) is needed when g_act is given");
+    int rc = convtr_check("convtr1d_cl_bwd", N, Lp, L, HP, Cip, Cr, stride, padding, LpO, HPO);
+    if (rc != PSND_OK) return rc;
+    if (N == 0) return PSND_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvParams p;
+    conv_params_plain(p);
+    p.A = static_cast<const bf16_t *>(g_raw), p.A2 = static_cast<const bf16_t *>(g_act), p.AM = static_cast<const bf16_t *>(act);
+    p.a2_slope = act_slope;
+    p.W = static_cast<const bf16_t *>(wb), p.bias = nullptr, p.res = nullptr, p.mask_src = nullptr;
+    p.out_raw = static_cast<bf16_t *>(gx), p.out_act = nullptr, p.a_eff_out = g_act ? static_cast<bf16_t *>(g_eff) : nullptr;
+    p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = stride * Cr, p.Cb = Cip, p.k = 2, p.off0 = 0, p.dstep = 1, p.hm = 1;
+    p.act_slope = 1.f, p.mask_slope = 1.f;
+    p.up_role = 2, p.up_u = stride, p.up_p = padding, p.up_LpO = LpO, p.up_HPO = HPO, p.up_LO = L * stride, p.up_Cr = Cr;
+    rc = conv_launch(p, st, "convtr1d_cl_bwd(data)");
+    if (rc != PSND_OK) return rc;
+    // weight gradient, operands swapped: gw[tap][ci][phi, co] = sum_l xa[l][ci] * G[l + tap][phi, co]
+    WgradParams w;
+    wgrad_params_plain(w);
+    w.G1 = static_cast<const bf16_t *>(xa), w.G2 = nullptr, w.GM = nullptr;
+    w.xa = g_act ? static_cast<const bf16_t *>(g_eff) : static_cast<const bf16_t *>(g_raw);
+    w.gw = gw_part, w.gbias = nullptr, w.g_out = nullptr;
+    w.R = p.R, w.Ca = stride * Cr, w.Cb = Cip, w.k = 2, w.off0 = 0, w.dstep = 1, w.g2_slope = 1.f;
+    w.up_u = stride, w.up_p = padding, w.up_Lp = Lp, w.up_HP = HP, w.up_LpO = LpO, w.up_HPO = HPO, w.up_Cr = Cr;
+    int64_t rps;
+    const int splits = wgrad_splits(w.R, w.Ca, w.Cb, 2, &rps);
+    w.rows_per_split = (int)rps;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((w.Cb + 63) / 64, (w.Ca + 63) / 64, (unsigned)splits), dim3(256), kWgradLdsBytes, st, w);
+    PSND_CHECK_LAUNCH("convtr1d_cl_bwd(wgrad)");
+    return PSND_OK;
+}
+
+extern "C" int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const float *v, const float *g, int Cin, int Cout, int K, int stride,
+                                       int Cr, int Cip, float *gv, float *gg, void *stream) {
+    if (!gw_part || !v || !g || !gv || !gg || splits < 1) PSND_FAIL(PSND_E_ARG, "convtr1d_wnorm_bwd: null pointer / splits");
+    if (K != 2 * stride) PSND_FAIL(PSND_E_SHAPE, "convtr1d_wnorm_bwd: K=%d stride=%d", K, stride);
+    const size_t lds = sizeof(float) * (size_t)Cout * K;
+    if (lds > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "convtr1d_wnorm_bwd: Cout*K=%d too large", Cout * K);
+    hipLaunchKernelGGL(convtr_finish_kernel, dim3(Cin), dim3(256), lds, static_cast<hipStream_t>(stream), gw_part, splits, v, g, Cin, Cout, K,
+                       stride, Cr, Cip, gv, gg);
+    PSND_CHECK_LAUNCH("convtr1d_wnorm_bwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c, const void *d, int count, float slope, void *out, int64_t n,
+                                    void *stream) {
+    if (!a || !out || count < 1 || count > 4 || (count > 1 && !b) || (count > 2 && !c) || (count > 3 && !d)) PSND_FAIL(PSND_E_ARG, "cl_mean_act_fwd: arguments");
+    if (n % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "cl_mean_act_fwd: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return PSND_OK;
+    const size_t n8 = (size_t)n / 8;
+    hipLaunchKernelGGL(cl_mean_act_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t *>(a), static_cast<const bf16_t *>(b), static_cast<const bf16_t *>(c), static_cast<const bf16_t *>(d),
+                       count, slope, static_cast<bf16_t *>(out), n8);
+    PSND_CHECK_LAUNCH("cl_mean_act_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_cl_mean_act_bwd(const void *g, const void *y, int count, float slope, void *gin, int64_t n, void *stream) {
+    if (!g || !y || !gin || count < 1) PSND_FAIL(PSND_E_ARG, "cl_mean_act_bwd: arguments");
+    if (n % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "cl_mean_act_bwd: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return PSND_OK;
+    const size_t n8 = (size_t)n / 8;
+    hipLaunchKernelGGL(cl_mean_act_bwd_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t *>(g), static_cast<const bf16_t *>(y), count, slope, static_cast<bf16_t *>(gin), n8);
+    PSND_CHECK_LAUNCH("cl_mean_act_bwd");
     return PSND_OK;
 }

@@ -184,62 +184,101 @@ class Generator(nn.Module):
         x = F.leaky_relu(x)            # default slope 0.01, as the reference
         return torch.tanh(self.conv_post(x))
 
-    # ---- gfx950 path: conv_pre, all ResBlocks and conv_post (74 of the 78 convs of v1, > 95 % of the FLOPs) run on the
-    #      channels-last bf16 implicit-GEMM kernels with leaky-relu / bias / residual / weight norm fused
-    #      (pytorch_sound_amd/cl.py).  The ConvTranspose1d upsamplers: library call between the layout kernels (default), or
-    #      `cl_upsample = 'kernel'`: a convolution over zero-spread rows on the same kernel (cl.conv_transpose_cl), the
-    #      whole generator then stays in the CL layout.  fp32 in / fp32 out, fp32 accumulation, bf16 between convs.
+    # ---- gfx950 path: the whole generator on the channels-last bf16 implicit-GEMM kernels (pytorch_sound_amd/cl.py):
+    #      conv_pre, every ResBlock conv and conv_post with leaky-relu / bias / residual / weight norm fused, the ConvTranspose1d
+    #      upsamplers in polyphase form (cl.ConvTransposeCL: k = 2 * stride, no zero multiplied), the mean over a stage's
+    #      resblocks + the next activation in one pass (cl.MeanActCL).  fp32 in / fp32 out, fp32 accumulation, bf16 between convs;
+    #      the activations never leave the CL layout.  A/B switches: cl_upsample = 'library' (round 1: library ConvTranspose1d
+    #      between two layout kernels) or 'kernel' (a convolution over zero-spread rows).
     use_cl = True
-    cl_upsample = 'library'     # 'kernel': ConvTranspose1d on the CL conv kernel too (cl.conv_transpose_cl)
-    _CL_MAX_REACH = 25          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for
+    cl_upsample = 'polyphase'
+    _CL_MAX_REACH = 40          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for (25; 40 for k <= 7)
 
     def _all_convs(self):
         out = [self.conv_pre, self.conv_post] + list(self.ups)
         for b in self.resblocks:
-            out += list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs)
+            out += self._block_convs(b)
         return out
 
+    @staticmethod
+    def _block_convs(block):
+        return list(block.convs1) + list(block.convs2) if hasattr(block, 'convs1') else list(block.convs)
+
     def _cl_ok(self, x) -> bool:
+        """False only for tensors the CL kernels cannot take at all (CPU, other dtypes); a CUDA fp32 input whose model the kernels
+        do not cover RAISES in forward_cl - no silent library path for a tensor that lives on the GPU."""
         if not (self.use_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
             return False
         for c in self._all_convs():
             c.sync_folded()
-        if any(not hasattr(c, 'weight_v') for c in [self.conv_pre, self.conv_post]):
-            return False
-        reach = 0
+        return True
+
+    def _check_cl(self):
+        from pytorch_sound_amd._lib import PsndError
         for block in self.resblocks:
-            convs = list(block.convs1) + list(block.convs2) if hasattr(block, 'convs1') else list(block.convs)
-            if any(not hasattr(c, 'weight_v') for c in convs):
-                return False
-            reach = max([reach] + [c.padding for c in convs])
-        if any(not hasattr(u, 'weight_v') for u in self.ups):
-            return False
-        reach = max([reach] + [u.weight_v.shape[2] - 1 - u.padding for u in self.ups])
-        return reach <= self._CL_MAX_REACH
+            for c in self._block_convs(block):
+                k = c.weight_v.shape[2]
+                if c.padding > self._CL_MAX_REACH or (c.padding > 25 and k > 7) or k > 16:
+                    raise PsndError('hifi_gan: conv with k=%d, dilation %d (tap reach %d) is beyond the gfx950 conv kernels '
+                                    '(reach <= 25, or <= 40 with k <= 7)' % (k, c.dilation, c.padding))
+        if self.cl_upsample == 'polyphase':
+            for u in self.ups:
+                if u.weight_v.shape[2] != 2 * u.stride or u.padding > u.stride:
+                    raise PsndError('hifi_gan: ConvTranspose1d(k=%d, stride=%d, padding=%d): the polyphase kernel needs k = 2 * '
+                                    'stride (set cl_upsample = "kernel" for the zero-spread convolution)'
+                                    % (u.weight_v.shape[2], u.stride, u.padding))
 
     def forward_cl(self, x):
         from pytorch_sound_amd import cl
+        self._check_cl()
+        if self.cl_upsample != 'polyphase':
+            return self._forward_cl_ab(x)
+        N, _, T = x.shape
+        nst = len(self.ups)
+        convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
+        prep = cl.prep_all(self, convs)                            # all weight-norm packs of the Conv1d layers: one launch
+        # halo of a stage's buffers = the widest tap reach of the convs that read them
+        halo = [max(self.conv_pre.padding, 1)]
+        for i in range(nst):
+            stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            h = max([c.padding for b in stage for c in self._block_convs(b)] + [self.ups[i].padding, 1])
+            halo.append(max(h, self.conv_post.padding) if i + 1 == nst else h)
+        shape = cl.CLShape(N, T, halo[0])
+        _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE, prep)
+        for i, up in enumerate(self.ups):
+            last = i + 1 == nst
+            out_shape = cl.CLShape(N, T * up.stride, halo[i + 1])
+            x_raw, x_act = cl.ConvTransposeCL.apply(xa, up.weight_v, up.weight_g, up.bias, shape, out_shape, up.stride, up.padding,
+                                                    LRELU_SLOPE)
+            shape, T = out_shape, out_shape.L
+            stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
+            rs = []
+            for block in stage:
+                fn = cl.resblock1_cl if hasattr(block, 'convs1') else cl.resblock2_cl
+                rs.append(fn(block, x_raw, x_act, shape, prep=prep)[0])
+            xa = cl.MeanActCL.apply(0.01 if last else LRELU_SLOPE, *rs)      # last: F.leaky_relu's default slope, as the reference
+        y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
+        return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
+
+    def _forward_cl_ab(self, x):
+        """round 1's upsampling variants, kept for A/B measurements (cl_upsample = 'library' | 'kernel')"""
+        from pytorch_sound_amd import cl
         N, _, T = x.shape
         halo = max([self.conv_pre.padding, self.conv_post.padding] + [
-            c.padding for b in self.resblocks
-            for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))] + [
+            c.padding for b in self.resblocks for c in self._block_convs(b)] + [
             u.weight_v.shape[2] - 1 - u.padding for u in self.ups])
         shape = cl.CLShape(N, T, halo)
-        convs = [self.conv_pre, self.conv_post] + [
-            c for b in self.resblocks for c in (list(b.convs1) + list(b.convs2) if hasattr(b, 'convs1') else list(b.convs))]
-        prep = cl.prep_all(self, convs)                            # all weight-norm packs of the model: one launch
+        convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
+        prep = cl.prep_all(self, convs)
         _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE, prep)
         kernel_ups = self.cl_upsample == 'kernel'
         h = None                                                   # library mode: (N, C, T) fp32 between the stages
         for i, up in enumerate(self.ups):
             last = i + 1 == len(self.ups)
             if kernel_ups:
-                # ConvTranspose1d as a k-tap convolution over zero-spread rows: the stack never leaves the CL layout
                 x_raw, x_act, shape = cl.conv_transpose_cl(xa, up, shape, LRELU_SLOPE)
                 T = shape.L
             else:
-                # library ConvTranspose1d between the two layout kernels (faster today: the zero-spread convolution
-                # multiplies s-1 zeros out of s, v1 fwd+bwd 19.1 vs 15.6 ms)
                 if h is None:
                     h = cl.FromCL.apply(xa, up.weight_v.shape[0], T, shape)      # leaky_relu(conv_pre(x), 0.1)
                 h = up(h)

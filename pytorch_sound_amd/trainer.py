@@ -349,7 +349,9 @@ class Trainer:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                # thread_local: the process group's watchdog thread keeps querying events of earlier collectives while this
+                # thread captures ("operation not permitted when stream is capturing" under the default global mode)
+                with torch.cuda.graph(graph, capture_error_mode='thread_local' if red is not None else 'global'):
                     loss, _ = self.forward(*st['inputs'], is_logging=False)
                     st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
                     if mode in ('events', 'capture'):

@@ -67,7 +67,7 @@ def _compare(got, want, tol_out, tol_gx, tol_all, tol_each, tag):
     assert each[0][0] <= tol_each, (tag, each[:3])
 
 
-@pytest.mark.parametrize('upsample', ['library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
 def test_hifi_gan_v1_config3_shape(upsample):
     """registered hifi_gan_v1, 16 clips x 32 frames -> 16 x 8192 samples (the config-3 training shape), forward + backward"""
     from pytorch_sound_amd.models import build_model
@@ -91,7 +91,7 @@ def test_hifi_gan_v1_config3_shape(upsample):
     assert st[1] > 0 and st[3] > 0 and st[0] > 0 and st[2] > 0, st
     g.use_cl = False
     ref32 = _run(g, g, x, w)
-    emul = _run(g, lambda t: E.generator(g, t, upsample), x, w)
+    emul = _run(g, lambda t: E.generator(g, t, 'library' if upsample == 'library' else 'kernel'), x, w)
     g.use_cl = True
     _compare(got, ref32, 4e-2, 8e-2, 8e-2, 1.0, 'v1 vs fp32')          # single tensors vs fp32: see the emulation bound below
     # measured: out 7e-4, all parameter gradients together 1.2e-3; the input gradient and single bias gradients 2.4e-2 .. 3.5e-2 -
@@ -100,7 +100,7 @@ def test_hifi_gan_v1_config3_shape(upsample):
 
 
 @pytest.mark.parametrize('name', ['tiny1', 'tiny2'])
-@pytest.mark.parametrize('upsample', ['library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
 def test_reference_golden_on_gpu(golden, name, upsample):
     """the imported reference's outputs and gradients (fp32, CPU) against the CL kernels on the GPU"""
     from pytorch_sound_amd.models.vocoders import hifi_gan
@@ -117,7 +117,7 @@ def test_reference_golden_on_gpu(golden, name, upsample):
             {n: torch.from_numpy(gd['%s/g/%s' % (name, n)]).cuda() for n, _ in g.named_parameters()})
     # fp32 reference vs bf16 kernels: accumulated rounding of the whole stack
     _compare(got, want, 4e-2, 1.5e-1, 1e-1, 0.5, name + ' vs reference golden')
-    emul = _run(g, lambda t: E.generator(g, t, upsample), x, w)
+    emul = _run(g, lambda t: E.generator(g, t, 'library' if upsample == 'library' else 'kernel'), x, w)
     _compare(got, emul, 1e-3, 2e-2, 2e-2, 3e-2, name + ' vs bf16 emulation')      # measured: output bit-exact, gradients 5e-3 .. 9e-3
     _compare(emul, want, 4e-2, 1.5e-1, 1e-1, 0.5, name + ' emulation vs reference golden')   # the emulation itself is the reference's function
 
@@ -226,6 +226,62 @@ def test_fused_conv_exact_on_rounded_operands(Cin, Cout, k, dil, L, N, mt, monke
     assert close(conv.bias.grad, gb), float((conv.bias.grad.double() - gb).abs().max() / gb.abs().max())
     assert close(conv.weight_g.grad, d)
     assert close(conv.weight_v.grad, gv)
+
+
+@pytest.mark.parametrize('Cin,Cout,u,L,N', [(64, 32, 8, 32, 3), (512, 256, 8, 32, 16), (32, 16, 2, 100, 2), (128, 64, 4, 61, 2),
+                                             (16, 8, 2, 24, 1)])
+def test_polyphase_conv_transpose_exact_on_rounded_operands(Cin, Cout, u, L, N):
+    """ConvTranspose1d(k = 2u, stride u, padding u/2) of hifi_gan.py:109 on psnd_convtr1d_*: outputs, input gradient, and the
+    fp32 parameter gradients (weight norm over dim 0 = per input channel) against float64 arithmetic on the bf16-rounded
+    operands.  bf16 outputs to one rounding (+ 4e-4 of max, see above), fp32 results to 2e-4 of max."""
+    from pytorch_sound_amd import cl
+    from pytorch_sound_amd.models.vocoders.hifi_gan import WNConvTranspose1d
+    dev = torch.device('cuda:0')
+    torch.manual_seed(Cin + u)
+    K, pad = 2 * u, u // 2
+    up = WNConvTranspose1d(Cin, Cout, K, u, pad, init_std=0.05).to(dev)
+    with torch.no_grad():
+        up.weight_g.mul_(1.0 + 0.3 * torch.rand_like(up.weight_g))
+    bf = lambda t: t.to(torch.bfloat16).double()                     # noqa: E731
+    x = torch.randn(N, Cin, L, device=dev)
+    gy = torch.randn(N, Cout, L * u, device=dev)
+    gya = torch.randn(N, Cout, L * u, device=dev)
+    shape, out_shape = cl.CLShape(N, L, 3), cl.CLShape(N, L * u, 11)
+    xc = x.clone().requires_grad_(True)
+    raw, act = cl.ConvTransposeCL.apply(cl.ToCL.apply(xc, shape, 0), up.weight_v, up.weight_g, up.bias, shape, out_shape, u, pad, 0.1)
+    y2 = cl.FromCL.apply(raw, Cout, L * u, out_shape)
+    ya2 = cl.FromCL.apply(act, Cout, L * u, out_shape)
+    ((y2 * gy).sum() + (ya2 * gya).sum()).backward()
+    # halo rows and padded channels of the outputs are zero
+    for buf in (raw, act):
+        b_ = buf.detach().float()
+        assert float(b_[:, :out_shape.HP].abs().max()) == 0 and float(b_[:, out_shape.HP + L * u:].abs().max()) == 0
+        if b_.shape[2] > Cout:
+            assert float(b_[:, :, Cout:].abs().max()) == 0
+    v32, g32 = up.weight_v.detach(), up.weight_g.detach()
+    w32 = v32 * (g32 / v32.flatten(1).norm(dim=1).view(-1, 1, 1))
+    wq, xq = bf(w32), bf(x)
+    v = F.conv_transpose1d(xq, wq, up.bias.detach().double(), u, pad)
+    ulp = 2.0 ** -8
+    tol_bf = lambda got, want: bool(((got.double() - want).abs() <= 1.01 * ulp * want.abs() + 4e-4 * float(want.abs().max())).all())  # noqa: E731
+    assert tol_bf(y2.detach(), v)
+    assert tol_bf(ya2.detach(), F.leaky_relu(v, 0.1))
+    gcomb = bf(gy.to(torch.bfloat16).float() + gya.to(torch.bfloat16).float() * torch.where(ya2.detach() > 0, 1.0, 0.1).float())
+    gx = F.conv1d(gcomb, wq, None, u, pad)                            # adjoint of conv_transpose1d wrt its input
+    assert tol_bf(xc.grad, gx), float((xc.grad.double() - gx).norm() / gx.norm())
+    # parameter gradients in float64 through autograd on the rounded operands
+    v64 = v32.double().requires_grad_(True)
+    g64 = g32.double().requires_grad_(True)
+    b64 = up.bias.detach().double().requires_grad_(True)
+    w64 = v64 * (g64 / v64.flatten(1).norm(dim=1).view(-1, 1, 1))
+    # the kernels see bf16(w): gradient wrt w taken at the rounded point, chained through the exact weight norm
+    wq_leaf = wq.clone().requires_grad_(True)
+    (F.conv_transpose1d(xq, wq_leaf, b64, u, pad) * gcomb).sum().backward()
+    w64.backward(wq_leaf.grad)
+    close = lambda got, want: float((got.double() - want).abs().max()) <= 2e-4 * float(want.abs().max())   # noqa: E731
+    assert close(up.bias.grad, b64.grad), float((up.bias.grad.double() - b64.grad).abs().max() / b64.grad.abs().max())
+    assert close(up.weight_g.grad, g64.grad)
+    assert close(up.weight_v.grad, v64.grad)
 
 
 def test_folded_checkpoint_loaded_after_weight_norm_removal():

@@ -1,5 +1,5 @@
 """HiFi-GAN Generator on the GPU: the channels-last bf16 conv path (Generator.forward_cl: conv_pre, every ResBlock,
-conv_post on psnd_conv1d_cl*; ConvTranspose1d from the library) against the fp32 torch formulation of the same module
+conv_post on psnd_conv1d_cl*; ConvTranspose1d polyphase on psnd_convtr1d_*, or the two A/B variants) against the fp32 torch formulation of the same module
 (which the CPU golden tests pin to the reference).  bf16 activations between ~20 convs: tolerance 4e-2 relative
 Frobenius on the output, 8e-2 on gradients."""
 from argparse import Namespace
@@ -31,7 +31,7 @@ def _make(resblock, rates, ksz, c0, rk, rd):
     ('1', [4, 2], [8, 4], 64, [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
     ('2', [4, 4], [8, 8], 64, [3, 5], [[1, 2], [2, 6]]),
 ])
-@pytest.mark.parametrize('upsample', ['library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
 def test_generator_cl_matches_torch_path(cfg, upsample):
     g = _make(*cfg)
     g.cl_upsample = upsample
@@ -62,12 +62,49 @@ def test_generator_cl_matches_torch_path(cfg, upsample):
     assert worst[0] <= 0.3, worst
 
 
-def test_generator_v3_dilation_falls_back_to_library_path():
+def test_generator_v3_runs_on_the_kernels():
+    """hifi_gan_v3 (hifi_gan.py:196-205): ResBlock2, k = 7 with dilation 12 -> tap reach 36, beyond the 25 rows of the default
+    A-tile ring: the 7-tap instances sized for 40 rows take it (round 1 dropped the whole generator to the library here)"""
+    import ctypes
     from pytorch_sound_amd.models import build_model
-    g = build_model('hifi_gan_v3').cuda()       # k=7, dilation 12: tap reach 36 > 25
-    x = torch.randn(1, 80, 8, device='cuda')
-    assert not g._cl_ok(x)
-    assert g(x).shape == (1, 1, 8 * 256)
+    from pytorch_sound_amd._lib import lib
+    import bf16_emul as E
+    torch.manual_seed(2)
+    g = build_model('hifi_gan_v3').cuda()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith('weight_v'):
+                p.mul_(10.0 if p.abs().max() < 0.1 else 1.0)
+    x = torch.randn(2, 80, 12, device='cuda')
+    assert g._cl_ok(x)
+    w = torch.randn(2, 1, 12 * 256, device='cuda')
+    st = (ctypes.c_int64 * 4)()
+    lib().psnd_conv_stats(st, 1)
+
+    def run(fn):
+        g.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        y = fn(xr)
+        (y * w).sum().backward()
+        return y.detach(), xr.grad.clone(), torch.cat([p.grad.flatten() for p in g.parameters()])
+
+    got = run(g)
+    lib().psnd_conv_stats(st, 0)
+    assert sum(st) > 0                                     # conv kernel launches happened (no library path)
+    emul = run(lambda t: E.generator(g, t, 'kernel'))
+    g.use_cl = False
+    ref = run(g)
+    g.use_cl = True
+    assert _rel(got[0], ref[0]) <= 4e-2 and _rel(got[1], ref[1]) <= 1e-1 and _rel(got[2], ref[2]) <= 8e-2
+    assert _rel(got[0], emul[0]) <= 5e-3 and _rel(got[1], emul[1]) <= 5e-2 and _rel(got[2], emul[2]) <= 2e-2
+
+
+def test_unsupported_geometry_fails_loudly():
+    """no silent library path on a GPU tensor: a conv the kernels cannot take raises"""
+    from pytorch_sound_amd._lib import PsndError
+    g = _make('2', [4, 4], [8, 8], 64, [9], [[1, 8]])       # k = 9, dilation 8: reach 32 > 25 and k > 7
+    with pytest.raises(PsndError):
+        g(torch.randn(1, 80, 8, device='cuda'))
 
 
 @pytest.mark.parametrize('arch', ['hifi_gan_v2', 'hifi_gan_v3'])
@@ -88,7 +125,7 @@ def test_folded_generator_decodes_on_the_cl_kernels(arch):
         assert float((gen(mel) - want).abs().max()) < 1e-5       # folding itself changes nothing (CPU)
     gen = gen.to('cuda:0')
     on_cl = gen._cl_ok(mel.to('cuda:0'))
-    assert on_cl == (arch != 'hifi_gan_v3')                # v3's dilated 7-tap convs reach 36 rows: beyond the staged tile, library path
+    assert on_cl
     with torch.no_grad():
         got = gen(mel.to('cuda:0')).cpu()
     assert got.shape == want.shape

