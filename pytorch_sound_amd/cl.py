@@ -345,7 +345,8 @@ class ConvTransposeCL(torch.autograd.Function):
             raise _lib.PsndError('ConvTransposeCL backward: no incoming gradient')
         S = lib().psnd_convtr1d_cl_wgrad_splits(shape.N, shape.Lp, Cip, Cr, stride)
         gx = torch.empty((shape.N, shape.Lp, Cip), dtype=torch.bfloat16, device=dev)
-        g_eff = torch.empty((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev) if g_act is not None else None
+        # zeroed: rows no low-resolution row maps to are never written, and the bias gradient sums every row
+        g_eff = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev) if g_act is not None else None
         gw = torch.empty((S, 2, Cip, stride * Cr), dtype=torch.float32, device=dev)
         gv, gg = torch.empty_like(v32), torch.empty_like(g32)
         with torch.cuda.device(dev):

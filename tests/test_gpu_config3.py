@@ -123,7 +123,8 @@ def test_reference_golden_on_gpu(golden, name, upsample):
 
 
 SHAPES = [(64, 64, 3, 1, 50, 2), (96, 64, 3, 5, 173, 3), (64, 40, 7, 3, 61, 2), (513, 256, 3, 1, 173, 2),
-          (256, 513, 3, 1, 45, 2), (32, 32, 11, 5, 200, 1), (128, 128, 11, 1, 300, 2), (512, 512, 7, 5, 40, 2)]
+          (256, 513, 3, 1, 45, 2), (32, 32, 11, 5, 200, 1), (128, 128, 11, 1, 300, 2), (512, 512, 7, 5, 40, 2),
+          (64, 64, 7, 12, 80, 2), (32, 64, 5, 9, 50, 1)]        # tap reach 36 (hifi_gan_v3's k = 7, dilation 12): the 40-row instances
 
 
 @pytest.mark.parametrize('Cin,Cout,k,dil,L,N', [(80, 512, 7, 1, 32, 16), (64, 64, 3, 1, 50, 2), (128, 128, 11, 5, 64, 2)])

@@ -191,7 +191,9 @@ def test_rccl_all_reduce_captured_in_the_step_graph(tmp_path):
     # last gradient existed - bucket 0 long before the last backward segment - and the buckets went out in fixed order
     assert [i for i, _ in info['emit']] == list(range(nb))
     arrived = [a for _, a in info['emit']]
-    assert arrived == list(np.cumsum(info['sizes'])), (arrived, info['sizes'])
+    need = list(np.cumsum(info['sizes']))
+    assert all(a >= n for a, n in zip(arrived, need)) and arrived == sorted(arrived), (arrived, need)
+    assert arrived[nb // 2] <= need[nb // 2] + 4          # released as the gradients arrive, not at the end
     assert arrived[0] < info['nparams'] // 2
     for k in res[False][2]:
         # sum over one rank = identity: the same training, NaN step skipped in both (two processes: the convolution library may
