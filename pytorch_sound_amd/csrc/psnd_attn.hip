@@ -1,0 +1,612 @@
+// psnd_attn.hip - the dense contractions of pytorch_sound/models/modules.py on the gfx950 matrix cores, exact fp32:
+//   * the 1x1 Conv1d projections (modules.py:21-22 linear_kvq / linear, :93-95 the feed-forward pair) as ONE strided GEMM kernel
+//     (forward, input gradient, weight gradient are the same kernel with other strides) - psnd_linear1x1_*
+//   * MultiHeadAttention.scale_dot_att (modules.py:61-79): k^T q / sqrt(d) -> key mask -> softmax over KEYS -> query mask ->
+//     v att, forward and backward, without the (H*N, T, T) score tensor ever leaving the chip unless the caller wants `att` -
+//     psnd_mha_fwd / psnd_mha_bwd
+// All products run on v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate - bitwise an fmaf chain (MI355X guide: "exact f32 at the
+// vector rate"), so the parity bounds of the fp32 torch formulation (tests/golden/modules.npz, 1e-4) hold unchanged.
+//
+// MFMA operand convention (32x32x2, wave64): lane l holds A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+// D[i][j]: j = l & 31, i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+// The attention kernels lean on one property of that map: the accumulator register s of lane half h holds row
+// rho(s, h) = (s & 3) + 8 * (s >> 2) + 4 * h - so a probability tile P[tk][tq] in accumulator registers IS the B operand of
+// the next product over tk (k-step s <-> row rho(s, h)) without any data movement; only the A operand (V, K, Q or gO from
+// LDS) has to be read in the same permuted order.
+#include "psnd_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ int rho(int s, int half) { return (s & 3) + 8 * (s >> 2) + 4 * half; }
+
+// =====================================================================================================================
+// strided batched GEMM   C_z[m][n] = sum_k A_z[m][k] * B_z[k][n]  (+ bias[m]) (relu),  n contiguous in C
+// =====================================================================================================================
+struct GemmParams {
+    const float *A, *B;
+    float *C;
+    const float *bias;           // [M] or null
+    const float *amask, *bmask;  // null, or same indexing as A / B: the operand element counts only where mask > 0 (relu backward)
+    int M, N, K, Z;
+    long long sAm, sAk, sAz, sBk, sBn, sBz, sCm, sCz;
+    int relu;
+    int zchunk;                  // > 0: weight-gradient mode - a workgroup sums over zchunk batches (and all of K) into slab blockIdx.z
+    long long sCslab;
+};
+
+constexpr int GBM = 128, GBN = 128, GBK = 16, GP = 132;   // LDS pitch of both tiles ([k][m] and [k][n], m / n fastest)
+
+// global -> registers: the thread's two float4 of a (128 x 16) tile.  VEC_MINOR: the 128-direction (m or n) is contiguous in memory.
+template <bool MINOR_CONTIG>
+__device__ __forceinline__ void gemm_fetch(const float *base, const float *mask, long long s_major128, long long s_k, int lim128, int limk,
+                                           int o128, int ok, int tid, f32x4_t (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        f32x4_t r = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MINOR_CONTIG) {            // float4 along the 128-direction: thread -> (k = tid / 32 + 8 u, x4 = tid % 32)
+            const int k = ok + (tid >> 5) + 8 * u, x = o128 + 4 * (tid & 31);
+            if (k < limk) {
+                const float *p = base + (long long)k * s_k + x;
+                const float *pm = mask ? mask + (long long)k * s_k + x : nullptr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (x + e < lim128) {
+                        const float val = p[e];
+                        r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                    }
+            }
+        } else {                                 // float4 along k: thread -> (x = tid / 4 + 64 u, k4 = tid % 4)
+            const int x = o128 + (tid >> 2) + 64 * u, k = ok + 4 * (tid & 3);
+            if (x < lim128) {
+                const float *p = base + (long long)x * s_major128 + k;
+                const float *pm = mask ? mask + (long long)x * s_major128 + k : nullptr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k + e < limk) {
+                        const float val = p[e];
+                        r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                    }
+            }
+        }
+        v[u] = r;
+    }
+}
+template <bool MINOR_CONTIG>
+__device__ __forceinline__ void gemm_commit(float *tile, int tid, const f32x4_t (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if constexpr (MINOR_CONTIG) {
+            *reinterpret_cast<f32x4_t *>(tile + ((tid >> 5) + 8 * u) * GP + 4 * (tid & 31)) = v[u];
+        } else {
+            const int x = (tid >> 2) + 64 * u, k = 4 * (tid & 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(k + e) * GP + x] = v[u][e];
+        }
+    }
+}
+
+template <bool A_MCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GBK * GP], sB[2][GBK * GP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int z0 = p.zchunk > 0 ? blockIdx.z * p.zchunk : blockIdx.z;
+    const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int nk = (p.K + GBK - 1) / GBK;
+    const int steps = (z1 - z0) * nk;
+    f32x4_t va[2], vb[2];
+    auto fetch = [&](int it) __attribute__((always_inline)) {
+        const int z = z0 + it / nk, k0 = (it % nk) * GBK;
+        const float *A = p.A + z * p.sAz, *B = p.B + z * p.sBz;
+        const float *am = p.amask ? p.amask + z * p.sAz : nullptr, *bm = p.bmask ? p.bmask + z * p.sBz : nullptr;
+        gemm_fetch<A_MCONTIG>(A, am, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, va);
+        gemm_fetch<B_NCONTIG>(B, bm, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, vb);
+    };
+    if (steps > 0) fetch(0);
+    for (int it = 0; it < steps; ++it) {
+        float *tA = sA[it & 1], *tB = sB[it & 1];
+        gemm_commit<A_MCONTIG>(tA, tid, va);
+        gemm_commit<B_NCONTIG>(tB, tid, vb);
+        __syncthreads();
+        if (it + 1 < steps) fetch(it + 1);              // in flight while this tile is multiplied
+#pragma unroll
+        for (int s = 0; s < GBK / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = tA[(2 * s + kk) * GP + wm * 64 + t * 32 + li];
+                b[t] = tB[(2 * s + kk) * GP + wn * 64 + t * 32 + li];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+        // the buffer written two iterations from now is this one: the barrier of the NEXT iteration orders its reads before
+    }
+    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : z0 * p.sCz);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + u * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + t * 32 + rho(r, kk);
+                if (m < p.M && n < p.N) {
+                    float v = acc[t][u][r];
+                    if (p.bias) v += p.bias[m];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    C[(long long)m * p.sCm + n] = v;
+                }
+            }
+        }
+}
+
+// out[i] = sum over slabs of part[s][i]
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float *part, int slabs, long long n, float *out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int s = 0; s < slabs; ++s) a += part[(long long)s * n + i];
+    out[i] = a;
+}
+
+// gbias[c] = sum over (z, t) of g[z][c][t] (where mask[z][c][t] > 0 when given): one workgroup per channel
+__global__ __launch_bounds__(256) void rowsum_kernel(const float *g, const float *mask, int Z, int C, long long T, float *out) {
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int z = 0; z < Z; ++z) {
+        const float *pg = g + ((long long)z * C + c) * T;
+        const float *pm = mask ? mask + ((long long)z * C + c) * T : nullptr;
+        for (long long t = threadIdx.x; t < T; t += 256) {
+            const float v = pg[t];
+            acc += (pm && !(pm[t] > 0.f)) ? 0.0 : (double)v;
+        }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = (float)red[0];
+}
+
+// =====================================================================================================================
+// attention.  kvq: (N, 3C, T) - rows [0, C) keys, [C, 2C) values, [2C, 3C) queries, head h = channels [h d, (h+1) d), d = 64.
+// batch index b = h * N + n (heads folded head-major, modules.py:38).  mask: (N, T) bytes, 1 = padding, or null.
+// =====================================================================================================================
+// HDP: head dimension padded to 32 or 64 (template parameter); rows dd >= d of every tile / fragment read as zero
+constexpr int TP = 33;          // LDS pitch of the (HDP x 32) tiles: rows on distinct banks for the permuted-order A reads
+struct AttnParams {
+    const float *kvq;           // (N, 3C, T)
+    const unsigned char *mask;  // (N, T) or null
+    float *out;                 // fwd: (N, C, T)
+    float *att;                 // fwd: (H*N, T, T) or null
+    float *stats;               // (H*N, T, 2): (max, 1 / sum) of every query column
+    const float *gout;          // bwd: (N, C, T)
+    const float *gatt;          // bwd: (H*N, T, T) or null
+    const float *delta;         // bwd: (H*N, T)
+    float *gkvq;                // bwd: (N, 3C, T)
+    int N, H, C, T, d;          // d = C / H, the head dimension (<= HDP)
+    float scale;
+};
+
+// cooperative load of a (64 x 32) tile X[dd][t0 + c] of a (.., T)-pitched matrix into LDS [dd][TP]; columns >= T read as zero
+template <int HDP>
+__device__ __forceinline__ void load_tile(const float *src, long long T, int d, int t0, float *dst, int tid) {
+#pragma unroll
+    for (int u = 0; u < HDP / 8; ++u) {
+        const int idx = tid + 256 * u, dd = idx >> 5, c = idx & 31;
+        const int t = t0 + c;
+        dst[dd * TP + c] = (t < T && dd < d) ? src[(long long)dd * T + t] : 0.f;
+    }
+}
+// B-operand fragment of a (64 x T) matrix for the wave's 32 columns: f[s] = X[2 s + kk][t0 + li]
+template <int HDP>
+__device__ __forceinline__ void load_frag(const float *src, long long T, int d, int t0, int li, int kk, float (&f)[HDP / 2]) {
+    const int t = t0 + li;
+#pragma unroll
+    for (int s = 0; s < HDP / 2; ++s) f[s] = (t < T && 2 * s + kk < d) ? src[(long long)(2 * s + kk) * T + t] : 0.f;
+}
+// 32-bit word: bit i set <=> key t0 + i is masked (padding) or beyond T
+__device__ __forceinline__ unsigned key_bits(const unsigned char *mrow, int T, int t0, int lane) {
+    const int t = t0 + (lane & 31);
+    const bool bad = t >= T || (mrow && mrow[t]);
+    return (unsigned)__builtin_amdgcn_ballot_w64(bad && lane < 32);
+}
+// S tile: acc[i = rows of the LDS tile][j = the fragment's columns] = sum_dd tile[dd][i] * frag[dd][j]
+template <int HDP>
+__device__ __forceinline__ void mma_tile_frag(const float *tile, const float (&frag)[HDP / 2], int li, int kk, f32x16 &acc) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HDP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * s + kk) * TP + li], frag[s], acc, 0, 0, 0);
+}
+// O[dd][j] += sum over the tile's 32 columns c of tile[dd][c] * P[c][j], P in accumulator layout (register s <-> row rho(s, kk))
+template <int HDP>
+__device__ __forceinline__ void mma_tile_acc(const float *tile, const f32x16 &P, int li, int kk, f32x16 (&O)[HDP / 32]) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int c = rho(s, kk);
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt) O[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(mt * 32 + li) * TP + c], P[s], O[mt], 0, 0, 0);
+    }
+}
+
+// forward.  One wave = 32 query columns; pass 1: column statistics (max, sum) over all keys; pass 2: probabilities (written to
+// `att` when asked for) and out = V P.  grid (ceil(T / 128), H * N)
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+    __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    float qf[HDP / 2];
+    load_frag<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    const int ntile = (p.T + 31) / 32;
+    // ---- pass 1
+    float mx = -INFINITY, sum = 0.f;
+    load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
+        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 s;
+        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (bad >> rho(r, kk)) & 1u ? -INFINITY : s[r] * p.scale;
+            s[r] = v;
+            tm = fmaxf(tm, v);
+        }
+        const float m2 = fmaxf(mx, tm);
+        if (m2 > -INFINITY) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += __expf(s[r] - m2);
+            sum = sum * __expf(mx - m2) + a;
+            mx = m2;
+        }
+    }
+    {   // the two lane halves hold different key rows of the same query column
+        const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
+        const float m2 = fmaxf(mx, om);
+        sum = (mx > -INFINITY ? sum * __expf(mx - m2) : 0.f) + (om > -INFINITY ? os * __expf(om - m2) : 0.f);
+        mx = m2;
+    }
+    const bool qpad = tq < p.T && mrow && mrow[tq];
+    const float inv = 1.f / sum;                 // every key padded: 1 / 0 -> the NaN column torch's softmax of all -inf gives
+    if (tq < p.T && kk == 0) {
+        p.stats[((long long)b * T + tq) * 2] = mx;
+        p.stats[((long long)b * T + tq) * 2 + 1] = inv;
+    }
+    // ---- pass 2
+    f32x16 O[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[mt][i] = 0.f;
+    __syncthreads();
+    load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+    load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) {
+            load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
+            load_tile<HDP>(Vp, T, p.d, 32 * (it + 1), sV[(it + 1) & 1], tid);
+        }
+        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 s;
+        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rho(r, kk);
+            float a = 0.f;
+            if (!((bad >> row) & 1u) && !qpad) a = sum > 0.f ? __expf(s[r] * p.scale - mx) * inv : NAN;
+            else if (!qpad && !(sum > 0.f) && 32 * it + row < p.T) a = NAN;
+            s[r] = a;
+            if (p.att && tq < p.T && 32 * it + row < p.T) p.att[((long long)b * T + 32 * it + row) * T + tq] = a;
+        }
+        mma_tile_acc<HDP>(sV[it & 1], s, li, kk, O);
+    }
+    if (tq < p.T) {
+        float *op = p.out + ((long long)n * p.C + h * p.d) * T + tq;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) op[(long long)(mt * 32 + rho(r, kk)) * T] = O[mt][r];
+    }
+}
+
+// delta[b][tq] = sum_dd gout[dd][tq] * out[dd][tq]  (+ sum_tk att[tk][tq] * gatt[tk][tq]): the softmax-backward column term
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float *out, const float *gout, const float *att, const float *gatt, int N, int H,
+                                                         int C, int d, long long T, float *delta) {
+    const int b = blockIdx.y, h = b / N, n = b - h * N;
+    const long long tq = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tq >= T) return;
+    const float *o = out + ((long long)n * C + h * d) * T + tq, *g = gout + ((long long)n * C + h * d) * T + tq;
+    float a = 0.f;
+    for (int dd = 0; dd < d; ++dd) a = __builtin_fmaf(o[dd * T], g[dd * T], a);
+    if (gatt) {
+        const float *pa = att + (long long)b * T * T + tq, *pg = gatt + (long long)b * T * T + tq;
+        for (long long tk = 0; tk < T; ++tk) a = __builtin_fmaf(pa[tk * T], pg[tk * T], a);
+    }
+    delta[(long long)b * T + tq] = a;
+}
+
+// backward, key side.  One wave = 32 keys (its K and V fragments stay in registers), loop over query tiles:
+//   S'[tq][tk], dP'[tq][tk] (+ gatt) -> p', dS' = scale p' (dP' - delta) -> dV += gO p', dK += Q dS'.   grid (ceil(T / 128), H * N)
+template <int HDP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
+    __shared__ float sQ[2][HDP * TP], sG[2][HDP * TP];
+    __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];           // per query of the tile: max, 1 / sum, delta, query padded
+    __shared__ float sT[4][32 * TP];                                     // per wave: a gatt tile, transposed through LDS
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
+    const float *Gp = p.gout + ((long long)n * p.C + h * p.d) * T;
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tk0 = blockIdx.x * 128 + wave * 32, tk = tk0 + li;
+    const bool kbad = tk >= p.T || (mrow && mrow[tk]);
+    float kf[HDP / 2], vf[HDP / 2];
+    load_frag<HDP>(Kp, T, p.d, tk0, li, kk, kf);
+    load_frag<HDP>(Vp, T, p.d, tk0, li, kk, vf);
+    f32x16 dK[HDP / 32], dV[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dK[mt][i] = 0.f, dV[mt][i] = 0.f;
+    const int ntile = (p.T + 31) / 32;
+    auto stage = [&](int it, int buf) __attribute__((always_inline)) {
+        load_tile<HDP>(Qp, T, p.d, 32 * it, sQ[buf], tid);
+        load_tile<HDP>(Gp, T, p.d, 32 * it, sG[buf], tid);
+        if (tid < 32) {
+            const int t = 32 * it + tid;
+            f32x4_t st = {0.f, 0.f, 0.f, 1.f};
+            if (t < p.T) {
+                st[0] = p.stats[((long long)b * T + t) * 2];
+                st[1] = p.stats[((long long)b * T + t) * 2 + 1];
+                st[2] = p.delta[(long long)b * T + t];
+                st[3] = (mrow && mrow[t]) ? 1.f : 0.f;
+            }
+            *reinterpret_cast<f32x4_t *>(&sSt[buf][4 * tid]) = st;
+        }
+    };
+    stage(0, 0);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) stage(it + 1, (it + 1) & 1);
+        const float *tQ = sQ[it & 1], *tG = sG[it & 1], *tS = sSt[it & 1];
+        f32x16 s, dp;
+        mma_tile_frag<HDP>(tQ, kf, li, kk, s);            // rows: queries of the tile, column: this lane's key
+        mma_tile_frag<HDP>(tG, vf, li, kk, dp);
+        if (p.gatt) {                                // gatt[tk][tq] is query-contiguous: through LDS, read transposed
+            float *tt = sT[wave];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = 2 * u + kk, k2 = tk0 + r, q2 = 32 * it + li;     // row r of the wave's key tile, lanes along the queries
+                tt[r * TP + li] = (k2 < p.T && q2 < p.T) ? p.gatt[((long long)b * T + k2) * T + q2] : 0.f;
+            }
+            __builtin_amdgcn_s_waitcnt(0);           // wave-private region: the wave's own writes are ordered by the LDS queue
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] += tt[li * TP + rho(r, kk)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4_t st = *reinterpret_cast<const f32x4_t *>(&tS[4 * rho(r, kk)]);
+            const bool dead = kbad || st[3] > 0.f || 32 * it + rho(r, kk) >= p.T;
+            const float pr = dead ? 0.f : __expf(s[r] * p.scale - st[0]) * st[1];
+            s[r] = pr;
+            dp[r] = p.scale * pr * (dp[r] - st[2]);
+        }
+        mma_tile_acc<HDP>(tG, s, li, kk, dV);
+        mma_tile_acc<HDP>(tQ, dp, li, kk, dK);
+    }
+    if (tk < p.T) {
+        float *gk = p.gkvq + ((long long)n * 3 * p.C + h * p.d) * T + tk, *gv = gk + (long long)p.C * T;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) {
+                    gk[(long long)(mt * 32 + rho(r, kk)) * T] = dK[mt][r];
+                    gv[(long long)(mt * 32 + rho(r, kk)) * T] = dV[mt][r];
+                }
+    }
+}
+
+// backward, query side.  One wave = 32 queries (Q and gO fragments in registers), loop over key tiles:
+//   S, dP (+ gatt) -> p, dS = scale p (dP - delta) -> dQ += K dS.    grid (ceil(T / 128), H * N)
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
+    __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
+    const float *Gp = p.gout + ((long long)n * p.C + h * p.d) * T;
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    float qf[HDP / 2], gf[HDP / 2];
+    load_frag<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    load_frag<HDP>(Gp, T, p.d, tq0, li, kk, gf);
+    const bool qdead = tq >= p.T || (mrow && mrow[tq]);
+    const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 0.f;
+    const float dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
+    f32x16 dQ[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[mt][i] = 0.f;
+    const int ntile = (p.T + 31) / 32;
+    load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+    load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) {
+            load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
+            load_tile<HDP>(Vp, T, p.d, 32 * (it + 1), sV[(it + 1) & 1], tid);
+        }
+        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 s, dp;
+        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
+        mma_tile_frag<HDP>(sV[it & 1], gf, li, kk, dp);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rho(r, kk);
+            const bool dead = qdead || ((bad >> row) & 1u);
+            const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
+            float g = dp[r];
+            if (p.gatt && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            dp[r] = p.scale * pr * (g - dl);
+        }
+        mma_tile_acc<HDP>(sK[it & 1], dp, li, kk, dQ);
+    }
+    if (tq < p.T) {
+        float *gq = p.gkvq + ((long long)n * 3 * p.C + 2 * p.C + h * p.d) * T + tq;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) gq[(long long)(mt * 32 + rho(r, kk)) * T] = dQ[mt][r];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hipStream_t st, const char *what) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || gz <= 0) return PSND_OK;
+    dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, gz);
+    if (grid.y > 65535 || grid.z > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: grid too large", what);
+    if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e_));
+    return PSND_OK;
+}
+
+extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, float *y,
+                                  void *stream) {
+    if (!x || !w || !y) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: null pointer");
+    if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_fwd: N=%lld Cin=%d Cout=%d T=%lld", (long long)N, Cin, Cout, (long long)T);
+    GemmParams p = {};
+    p.A = w, p.B = x, p.C = y, p.bias = bias, p.amask = nullptr, p.bmask = nullptr;
+    p.M = Cout, p.N = (int)T, p.K = Cin, p.Z = (int)N;
+    p.sAm = Cin, p.sAk = 1, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cin * T, p.sCm = T, p.sCz = (long long)Cout * T;
+    p.relu = relu, p.zchunk = 0, p.sCslab = 0;
+    return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd");
+}
+
+extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T) {
+    if (N <= 0) return 0;
+    const int64_t tiles = (int64_t)((Cout + GBM - 1) / GBM) * ((Cin + GBN - 1) / GBN);
+    int64_t want = 512 / (tiles > 0 ? tiles : 1);          // enough workgroups for two per CU
+    if (want < 1) want = 1;
+    if (want > N) want = N;
+    const int64_t chunk = (N + want - 1) / want;
+    return (N + chunk - 1) / chunk;
+}
+
+// gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
+extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                  float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
+    if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
+    if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
+    if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (N == 0) return PSND_OK;
+    int rc = PSND_OK;
+    if (gx) {
+        GemmParams p = {};
+        p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask;
+        p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
+        p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
+        rc = gemm_launch(p, true, true, (int)N, st, "linear1x1_bwd(data)");
+        if (rc != PSND_OK) return rc;
+    }
+    if (gw) {
+        const int64_t slabs = psnd_linear1x1_wgrad_slabs(N, Cin, Cout, T);
+        GemmParams p = {};
+        p.A = gy, p.B = x, p.C = gw_part, p.bias = nullptr, p.amask = ymask, p.bmask = nullptr;
+        p.M = Cout, p.N = Cin, p.K = (int)T, p.Z = (int)N;
+        p.sAm = T, p.sAk = 1, p.sAz = (long long)Cout * T, p.sBk = 1, p.sBn = T, p.sBz = (long long)Cin * T, p.sCm = Cin, p.sCz = 0;
+        p.zchunk = (int)((N + slabs - 1) / slabs), p.sCslab = (long long)Cout * Cin;
+        rc = gemm_launch(p, false, false, (int)slabs, st, "linear1x1_bwd(weight)");
+        if (rc != PSND_OK) return rc;
+        const long long n = (long long)Cout * Cin;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gw_part, (int)slabs, n, gw);
+        PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
+    }
+    if (gbias) {
+        hipLaunchKernelGGL(rowsum_kernel, dim3(Cout), dim3(256), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
+        PSND_CHECK_LAUNCH("linear1x1_bwd(bias)");
+    }
+    return PSND_OK;
+}
+
+static int mha_check(const char *what, int64_t N, int H, int C, int64_t T) {
+    if (N <= 0 || H <= 0 || C % H != 0 || C / H > 64) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: hidden_dim %d / heads %d: head dimensions up to 64 only", what, C, H);
+    if (T <= 0 || T >= ((int64_t)1 << 24) || (int64_t)H * N > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: T=%lld, H*N=%lld", what, (long long)T, (long long)(H * N));
+    return PSND_OK;
+}
+
+extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
+                            void *stream) {
+    if (!kvq || !out || !stats) PSND_FAIL(PSND_E_ARG, "mha_fwd: null pointer");
+    int rc = mha_check("mha_fwd", N, H, C, T);
+    if (rc != PSND_OK) return rc;
+    AttnParams p = {};
+    p.kvq = kvq, p.mask = mask, p.out = out, p.att = att, p.stats = stats;
+    p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
+    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
+    if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    PSND_CHECK_LAUNCH("mha_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
+                            const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, void *stream) {
+    if (!kvq || !out || !stats || !gout || !delta || !gkvq) PSND_FAIL(PSND_E_ARG, "mha_bwd: null pointer");
+    if (gatt && !att) PSND_FAIL(PSND_E_ARG, "mha_bwd: a gradient for `att` needs the att tensor of the forward pass");
+    int rc = mha_check("mha_bwd", N, H, C, T);
+    if (rc != PSND_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st, out, gout, att, gatt, (int)N, H, C,
+                       C / H, (long long)T, delta);
+    PSND_CHECK_LAUNCH("mha_bwd(delta)");
+    AttnParams p = {};
+    p.kvq = kvq, p.mask = mask, p.stats = const_cast<float *>(stats), p.gout = gout, p.gatt = gatt, p.delta = delta, p.gkvq = gkvq;
+    p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
+    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
+    if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(256), 0, st, p);
+    PSND_CHECK_LAUNCH("mha_bwd(kv)");
+    if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_kernel<32>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(256), 0, st, p);
+    PSND_CHECK_LAUNCH("mha_bwd(q)");
+    return PSND_OK;
+}

@@ -65,6 +65,10 @@ struct ConvParams {
     //   up_role 1: the OUTPUT is that view (forward: Y[l][phi, co] = x[l] W[phi] + x[l-1] W[phi + u], Cb = u * Cr)
     //   up_role 2: the A operand is that view (input gradient: gx[l] = G[l] Wt[phi] + G[l+1] Wt[phi + u], Ca = u * Cr)
     int up_role, up_u, up_p, up_LpO, up_HPO, up_LO, up_Cr;
+    // res_is_a_eff: the residual of the epilogue is the combined operand A + A2 * leaky'(AM) of THIS launch (Ca == Cb).  It is
+    // formed again from its three sources - reading a_eff_out back would race with the workgroups that are still writing it
+    // (round 1 did exactly that for ResBlock2 chains wider than one column tile: hifi_gan_v3's 128-channel stage)
+    int res_is_a_eff;
 #ifdef PSND_TRACE
     long long *trace;
 #endif
@@ -360,6 +364,15 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] *= bf2f((bf16_t)(pm[e] & 0xffff)) > 0.f ? 1.f : p.mask_slope;
                     v[2 * e + 1] *= bf2f((bf16_t)(pm[e] >> 16)) > 0.f ? 1.f : p.mask_slope;
+                }
+            }
+            if (p.res_is_a_eff) {
+                const uint4 q = load_combined(p.A, p.A2, p.AM, p.a2_slope, o);
+                const unsigned *pq = reinterpret_cast<const unsigned *>(&q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf2f((bf16_t)(pq[e] & 0xffff));
+                    v[2 * e + 1] += bf2f((bf16_t)(pq[e] >> 16));
                 }
             }
             if (p.res) {
@@ -913,6 +926,7 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
 
 static void conv_params_plain(ConvParams &p) {
     p.up_role = 0, p.up_u = 0, p.up_p = 0, p.up_LpO = 0, p.up_HPO = 0, p.up_LO = 0, p.up_Cr = 0;
+    p.res_is_a_eff = 0;
 #ifdef PSND_TRACE
     p.trace = nullptr;
 #endif
@@ -1081,6 +1095,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     if (!pairable) {
         int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
         if (rc != PSND_OK) return rc;
+        if (gx_res && gx_res == g_out) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_bwd: residual = combined gradient outside the paired launch");
         return psnd_conv1d_cl(G1, G2, GM, g2_slope, wb, nullptr, gx_res, gx_mask, N, Lp, L, HP, Cb, Ca, k, pad, -dil, 1.f, gx_mask_slope, gx,
                               nullptr, g_out, stream);
     }
@@ -1092,6 +1107,10 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     pc.W = static_cast<const bf16_t *>(wb), pc.bias = nullptr;
     pc.res = static_cast<const bf16_t *>(gx_res), pc.mask_src = static_cast<const bf16_t *>(gx_mask);
     pc.out_raw = static_cast<bf16_t *>(gx), pc.out_act = nullptr, pc.a_eff_out = static_cast<bf16_t *>(g_out);
+    if (gx_res && gx_res == g_out) {             // the residual IS the combined gradient this launch materialises
+        if (Ca != Cb) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_bwd: gx_res == g_out needs Ca == Cb");
+        pc.res = nullptr, pc.res_is_a_eff = 1;
+    }
     pc.R = N * (int64_t)Lp, pc.Lp = Lp, pc.L = L, pc.HP = HP, pc.Ca = Cb, pc.Cb = Ca, pc.k = k, pc.off0 = pad, pc.dstep = -dil, pc.hm = hm;
     pc.act_slope = 1.f, pc.mask_slope = gx_mask_slope;
     // weight-gradient role

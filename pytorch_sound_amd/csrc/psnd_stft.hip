@@ -804,11 +804,11 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// n_fft = 4096, second generation (magnitude output): TWO independent 512-thread workgroups per CU, 4-frame half tiles.
+// n_fft = 4096, second generation: TWO independent 512-thread workgroups per CU, 4 frames per tile.
 // The kernel above holds 8 frames in 142 KB of LDS: one workgroup = 2 waves per SIMD that meet at 5 barriers per tile, so the
 // VALU (1050 packed instructions per thread and tile, ~5 cycles each: the roof of this size) idles whenever the whole
-// workgroup sits in an LDS or memory phase - 38 % VALU utilisation, 26-28 % of the HBM roof.  Here the FFT runs on 4 frames at a
-// time (X = 66 KB + 10 KB of tables -> 2 workgroups = 16 waves per CU, 4 per SIMD, phases of the two workgroups overlap):
+// workgroup sits in an LDS or memory phase - 38 % VALU utilisation, 26 % of the HBM roof.  Here a tile is 4 frames
+// (X = 66 KB + 10 KB of tables -> 2 workgroups = 16 waves per CU, 4 per SIMD, phases of the two workgroups overlap):
 //   pass A  thread = (column j < 256, 2 of the 4 frames)            radix-8, as above
 //   pass B  thread = (f, q_a, j2): ONE radix-16 in place             (above: two per thread)
 //   pass C  thread = (f, row r < 128): ONE row (above: the pair r, 128 - r).  The real-FFT split needs Z[C - k] of the partner
@@ -816,18 +816,22 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
 //           half against the partner's UPPER half, which the partner parks in place in its row (4 ds_write_b128, one barrier);
 //           the partner does the complementary 8.  No arithmetic is duplicated.  Row 64 is its own partner (falls out of the
 //           indexing); row 0 pairs q with 16 - q inside itself and owns the two self-paired bins 0 | C and C/2.
-// Stores: a 4-frame tile alone gives 16-B runs per bin row, which measured +82 us on 508 MB (223 us against 141 us with the
-// stores ablated; the 8-frame kernel's 32-B runs cost it 6 us).  So a workgroup walks PAIRS of half tiles: the 17 magnitudes of
-// the first half stay in registers while the second is computed, a quad-permute (DPP) hands every lane two consecutive frames
-// of the 8, and the stores are 8 bytes per lane = 32-B runs per bin.
 // LDS pitches: q_a blocks 258 complex, frames 8 * 258 + 8: pass B's two 128-B runs per 32 lanes are 128 B apart (mod 256),
-// pass C's ds_read_b128 groups (own row and partner half) hit 16 distinct 16-B slots (bank model of MI355X_MICROARCH.md).
+// pass C's ds_read_b128 groups (own row and partner half) hit 16 distinct 16-B slots (tools: bank model in DESIGN.md 4.1).
+// Stores are 16-B runs (4 frames) per bin row; neighbouring tiles run on neighbouring workgroups of one XCD at the same time and
+// their runs merge in that L2.  Measured (32 clips x 30 s, 508 MB): 224 us with the stores, 141 us without (the 8-frame kernel
+// above: 226 us / ~215 us) - the FFT phases now overlap, the write path is what is left.  Tried on top of this kernel and
+// measured WORSE (profiles/r02_stft4096_*): holding the magnitudes of two consecutive tiles in registers and storing 32-B runs
+// (252 us: 25 % of the write requests leave the L2 as 32-B partials, 1.41x the algorithmic write bytes), and walking four
+// consecutive tiles per workgroup so that one CU writes the halves of a 64-B segment a few microseconds apart (299 us, 1.74x):
+// partial lines survive in the L2 only when their neighbours arrive at the same time from other workgroups, not later.
 // ---------------------------------------------------------------------------------------------
 constexpr int k4096bFT = 4;
 constexpr int k4096bQP = 258;
 constexpr int k4096bFP = 8 * k4096bQP + 8;
 constexpr int k4096bLdsFloats = k4096bFT * k4096bFP * 2 + k4096VK + 512;
 
+template <bool MAG, bool PHASE, bool REIM>
 __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p) {
     constexpr int C = 2048, NFFT = 4096, FT = k4096bFT, QP = k4096bQP, FP = k4096bFP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -839,16 +843,15 @@ __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p
     const float *g_wa = plan + NFFT, *g_twa = plan + 2 * NFFT, *g_twb = plan + 3 * NFFT, *g_vk = plan + 3 * NFFT + 512;
 
     constexpr int SPV = 4;                               // 512 threads x 4 x 16 B = 32 KB >= span of hop <= 1364
-    const TileWalk tw = tile_walk(p.total_tiles);        // tiles = QUADS of 4-frame halves (16 frames); p.ntile = pairs per clip (even)
+    const TileWalk tw = tile_walk(p.total_tiles);
     if (tw.first >= tw.end) return;
     const int hop = p.hop;
     const int span_len = (FT - 1) * hop + NFFT;
     f32x4 spv[SPV];
-    // half tile h (0 / 1) of pair `pair_`
-    auto request_span = [&](int pair_, int h_) __attribute__((always_inline)) {
-        const int clip_ = pair_ / p.ntile;
+    auto request_span = [&](int tile_) __attribute__((always_inline)) {
+        const int clip_ = tile_ / p.ntile;
         const float *x_ = p.wav + (size_t)clip_ * p.T;
-        const long long g0 = ((long long)(pair_ - clip_ * p.ntile) * 2 * FT + h_ * FT) * hop - p.pad;
+        const long long g0 = (long long)(tile_ - clip_ * p.ntile) * FT * hop - p.pad;
         const int Ti = (int)p.T;
         static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p
                 const long long g = g0 + s4;
                 if (g >= 0 && g + 3 < p.T) {
                     spv[j] = *reinterpret_cast<const f32x4_u *>(x_ + g);
-                } else {                                  // clip edges (reflect) - also the frames past F of a last half tile
+                } else {
                     const int gi = (int)g;
                     spv[j].x = x_[reflect_idx32(gi, Ti)], spv[j].y = x_[reflect_idx32(gi + 1, Ti)];
                     spv[j].z = x_[reflect_idx32(gi + 2, Ti)], spv[j].w = x_[reflect_idx32(gi + 3, Ti)];
@@ -872,181 +875,130 @@ __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p
             if (s4 < span_len) *reinterpret_cast<f32x4 *>(s_x + s4) = spv[j];
         });
     };
-    request_span(2 * tw.first, 0);
+    request_span(tw.first);
     for (int i = t; i < (k4096VK + 512) / 4; i += 512) {
         const f32x4 v = i < k4096VK / 4 ? reinterpret_cast<const f32x4 *>(g_vk)[i]
                                         : reinterpret_cast<const f32x4 *>(g_twb)[i - k4096VK / 4];
         reinterpret_cast<f32x4 *>(s_vk)[i] = v;          // s_twb follows s_vk
     }
     const int ja = t & 255, fa0 = 2 * (t >> 8);      // pass-A identity: column, first of its 2 frames
-    // window and pass-A twiddles of column ja are re-read from the plan (L2) every half tile: held in registers across the tile
+    // window and pass-A twiddles of column ja are re-read from the plan (L2) every tile: held in registers across the tile
     // loop they cost 32 VGPRs of the 128 that 4 waves per SIMD leave
     // pass-C identity: frame, row; the partner row's upper half
     const int fc = t & 3, r = t >> 2, rp = (128 - r) & 127;
     const bool special = (r == 0);
     float *row_own = s_x + 2 * (fc * FP + (r & 7) * QP + (r >> 3) * 16);
     const float *row_par = s_x + 2 * (fc * FP + (rp & 7) * QP + (rp >> 3) * 16) + 16;
-    const v2f eps2 = v2f{p.mag_eps, 0.f};
-    bool first = true;
 
-    // one 4-frame half tile: span (already requested) -> magnitudes of this thread's 16 bins (+ the middle bin for row 0).
-    // mlo[q] = |X[r + 128 q]|, mhi[q] = |X[128 - r + 128 (15 - q)]|.  `nxt`: request the span of (npair, nh) for the next call.
-    auto half_tile = [&](bool nxt, int npair, int nh, float (&mlo)[8], float (&mhi)[8], float &mmid) __attribute__((always_inline)) {
-        f32x4 wv[4];
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+    const int clip = tile / p.ntile;
+    const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+    const bool more = tile + tw.step < tw.end;
+    f32x4 wv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
-        if (!first) __syncthreads();                     // every partner half of the previous half tile has been read: X is free
-        first = false;
-        commit_span();
-        __syncthreads();                                 // span (and, the first time, the tables) visible
-        // ---- pass A
-        v2f z[2][8];
+    for (int i = 0; i < 4; ++i) wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
+    if (tile != tw.first) __syncthreads();           // every partner half of the previous tile has been read: X is free
+    commit_span();
+    __syncthreads();                                 // span(tile) (and, the first time, the tables) visible
+
+    // ---- pass A ----------------------------------------------------------------------------------------------
+    v2f z[2][8];
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const v2f w = (a & 1) ? pk::hi(wv[a >> 1]) : pk::lo(wv[a >> 1]);
-                z[f][a] = *reinterpret_cast<const v2f *>(s_x + (fa0 + f) * hop + 2 * (ja + 256 * a)) * w;
-            }
-        f32x4 tv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
-        __syncthreads();                                 // span consumed: the area becomes X
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            pk::fft<8>(z[f]);
-            v2f *o = reinterpret_cast<v2f *>(s_x) + (fa0 + f) * FP + ja;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const v2f w = (q & 1) ? pk::hi(tv[q >> 1]) : pk::lo(tv[q >> 1]);
-                o[q * QP] = q == 0 ? z[f][0] : pk::cmul(z[f][ct::bitrev(q, 3)], w);
-            }
+        for (int a = 0; a < 8; ++a) {
+            const v2f w = (a & 1) ? pk::hi(wv[a >> 1]) : pk::lo(wv[a >> 1]);
+            z[f][a] = *reinterpret_cast<const v2f *>(s_x + (fa0 + f) * hop + 2 * (ja + 256 * a)) * w;
         }
-        __syncthreads();
-        // ---- pass B (in place)
-        {
-            const int j2 = t & 15;
-            const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2;      // W_256^(j2 q) read as [q][j2] (symmetric table)
-            const int f = 2 * ((t >> 4) & 1) + (t >> 8), qa = (t >> 5) & 7;     // a half-wave: frames f, f + 2 of one q_a
-            v2f *base = reinterpret_cast<v2f *>(s_x) + f * FP + qa * QP + j2;
-            v2f y[16];
+    f32x4 tv[4];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) y[b] = base[16 * b];
-            pk::fft<16>(y);
+    for (int i = 0; i < 4; ++i) tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
+    __syncthreads();                                 // span consumed: the area becomes X
 #pragma unroll
-            for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[16 * q]);
-        }
-        __syncthreads();
-        // ---- pass C: one row per thread, upper half parked for the partner
-        v2f zr[16];
+    for (int f = 0; f < 2; ++f) {
+        pk::fft<8>(z[f]);
+        v2f *o = reinterpret_cast<v2f *>(s_x) + (fa0 + f) * FP + ja;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(row_own + 4 * i);
-            zr[2 * i] = pk::lo(v);
-            zr[2 * i + 1] = pk::hi(v);
+        for (int q = 0; q < 8; ++q) {
+            const v2f w = (q & 1) ? pk::hi(tv[q >> 1]) : pk::lo(tv[q >> 1]);
+            o[q * QP] = q == 0 ? z[f][0] : pk::cmul(z[f][ct::bitrev(q, 3)], w);
         }
-        pk::fft<16>(zr);                                 // Z[r + 128 q] in slot bitrev(q)
+    }
+    __syncthreads();
+
+    // ---- pass B (in place) -------------------------------------------------------------------------------------
+    {
+        const int j2 = t & 15;
+        const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2;      // W_256^(j2 q) read as [q][j2] (symmetric table)
+        const int f = 2 * ((t >> 4) & 1) + (t >> 8), qa = (t >> 5) & 7;     // a half-wave: frames f, f + 2 of one q_a
+        v2f *base = reinterpret_cast<v2f *>(s_x) + f * FP + qa * QP + j2;
+        v2f y[16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                    // Z[8 + 2i], Z[9 + 2i] -> row positions 8 + 2i, 9 + 2i (natural order)
-            const v2f a = zr[ct::bitrev(8 + 2 * i, 4)], b = zr[ct::bitrev(9 + 2 * i, 4)];
-            *reinterpret_cast<f32x4 *>(row_own + 16 + 4 * i) = f32x4{a.x, a.y, b.x, b.y};
-        }
-        __syncthreads();
-        v2f pz[8];                                       // pz[q] = Z_partner[15 - q]
+        for (int b = 0; b < 16; ++b) y[b] = base[16 * b];
+        pk::fft<16>(y);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(row_par + 4 * i);     // partner Z[8 + 2i], Z[9 + 2i]
-            pz[7 - 2 * i] = pk::lo(v);
-            pz[6 - 2 * i] = pk::hi(v);
-        }
-        if (__builtin_amdgcn_ballot_w64(special) != 0) {                 // the wave holding row 0: pairs q with 16 - q inside the row
-            static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
-                const v2f own = zr[ct::bitrev(q == 0 ? 0 : 16 - q, 4)];
-                pz[q] = special ? own : pz[q];
-            });
-        }
-        if (nxt) request_span(npair, nh);                // in flight during the split, committed at the next half tile's top
-        auto mag = [&](v2f x) __attribute__((always_inline)) {
-            const v2f sq = pk::fma(x, x, eps2);
-            return __builtin_amdgcn_sqrtf(sq.x + sq.y);
-        };
+        for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[16 * q]);
+    }
+    __syncthreads();
+
+    // ---- pass C: one row per thread, upper half parked for the partner -------------------------------------------
+    v2f zr[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row_own + 4 * i);
+        zr[2 * i] = pk::lo(v);
+        zr[2 * i + 1] = pk::hi(v);
+    }
+    pk::fft<16>(zr);                                 // Z[r + 128 q] in slot bitrev(q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                    // Z[8 + 2i], Z[9 + 2i] -> row positions 8 + 2i, 9 + 2i (natural order)
+        const v2f a = zr[ct::bitrev(8 + 2 * i, 4)], b = zr[ct::bitrev(9 + 2 * i, 4)];
+        *reinterpret_cast<f32x4 *>(row_own + 16 + 4 * i) = f32x4{a.x, a.y, b.x, b.y};
+    }
+    __syncthreads();
+    v2f pz[8];                                       // pz[q] = Z_partner[15 - q]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(row_par + 4 * i);     // partner Z[8 + 2i], Z[9 + 2i]
+        pz[7 - 2 * i] = pk::lo(v);
+        pz[6 - 2 * i] = pk::hi(v);
+    }
+    if (__builtin_amdgcn_ballot_w64(special) != 0) {                 // the wave holding row 0: pairs q with 16 - q inside the row
+        static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            const v2f own = zr[ct::bitrev(q == 0 ? 0 : 16 - q, 4)];
+            pz[q] = special ? own : pz[q];
+        });
+    }
+    if (more) request_span(tile + tw.step);          // in flight during the split and the stores, committed at the next tile's top
+    const long long F = p.F;
+    const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
+    const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
+    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + fc) < F) && !(p.ablate & 2));
+    emit.nostore = p.ablate & 4;
+    if (emit.valid) {
+        const int iF = (int)F;
+        const int off_lo = r * iF * 4 + fc * 4, off_hi = (128 - r) * iF * 4 + fc * 4;
+        const int step = 128 * iF * 4;
+        OutVal hold[8];
         v2f xk, xc;
         static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
             rfft_pair_pk(zr[ct::bitrev(q, 4)], pz[q], *reinterpret_cast<const v2f *>(s_vk + 2 * (r + 128 * q)), xk, xc);
-            mlo[q] = mag(xk);
-            mhi[q] = mag(xc);
+            emit.store(off_lo, q * step, emit.template make<false>(xk));      // bin r + 128 q
+            hold[q] = emit.template make<true>(xc);                           // bin 128 - r + 128 (15 - q), stored below in ascending order
         });
-        const v2f mid = zr[ct::bitrev(8, 4)];                            // the middle bin C/2 of row 0 (self-paired)
-        rfft_pair_pk(mid, mid, *reinterpret_cast<const v2f *>(s_vk + 2 * 1024), xk, xc);
-        mmid = mag(xk);
-    };
-
-    // the walk hands out QUADS (16 frames = two pairs, processed back to back): the two 32-B halves of a 64-B segment of a bin
-    // row are written by the same CU a few microseconds apart and merge in its L2 (measured with one pair per step: 25 % of
-    // the write requests left the L2 as 32-B partials, 1.41x the algorithmic write bytes, against 11 % / 1.17x for the
-    // lock-stepped one-workgroup-per-CU kernel above)
-    for (int quad = tw.first; quad < tw.end; quad += tw.step)
-    for (int hq = 0; hq < 2; ++hq) {
-        const int pair = 2 * quad + hq;
-        const int clip = pair / p.ntile;
-        const long long f0 = (long long)(pair - clip * p.ntile) * 2 * FT;
-        if (f0 >= p.F) continue;                          // a clip's last quad may hold one pair only (uniform)
-        const bool more = hq == 0 ? (f0 + 2 * FT < p.F || quad + tw.step < tw.end) : quad + tw.step < tw.end;
-        const int npair_ = hq == 0 ? (f0 + 2 * FT < p.F ? pair + 1 : 2 * (quad + tw.step)) : 2 * (quad + tw.step);
-        float alo[8], ahi[8], amid, blo[8], bhi[8], bmid;
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {                    // ONE copy of the half-tile code (two inlined copies spill 139 VGPRs)
-            half_tile(h == 0 || more, h == 0 ? pair : npair_, h == 0 ? 1 : 0, blo, bhi, bmid);
-            if (h == 0) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) alo[q] = blo[q], ahi[q] = bhi[q];
-                amid = bmid;
-            }
-        }
-        // lane fc of a quad holds frame f0 + fc (a..) and f0 + 4 + fc (b..): hand every lane two CONSECUTIVE frames 2 fc, 2 fc + 1
-        const long long F = p.F;
-        const int iF = (int)F;
-        const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
-        const int cbytes = (p.ablate & 6) ? 0 : (int)(((long long)(C + 1) * F - f0) * 4);
-        const __amdgpu_buffer_rsrc_t rmag = make_uniform_rsrc(p.mag + cbase, cbytes);
-        auto two = [&](float a, float b) __attribute__((always_inline)) {
-            const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
-            const int a0 = __builtin_amdgcn_mov_dpp(ia, 0x88, 0xF, 0xF, true), a1 = __builtin_amdgcn_mov_dpp(ia, 0xDD, 0xF, 0xF, true);
-            const int b0 = __builtin_amdgcn_mov_dpp(ib, 0x88, 0xF, 0xF, true), b1 = __builtin_amdgcn_mov_dpp(ib, 0xDD, 0xF, 0xF, true);
-            typedef unsigned u2 __attribute__((ext_vector_type(2)));
-            return fc < 2 ? u2{(unsigned)a0, (unsigned)a1} : u2{(unsigned)b0, (unsigned)b1};
-        };
-        const long long fr = f0 + 2 * fc;                                // first of this lane's two frames
-        const bool ok0 = fr < F, ok1 = fr + 1 < F;
-        const int OOBV = 0x7ffffff0;
-        const int off_lo = r * iF * 4 + 2 * fc * 4, off_hi = (128 - r) * iF * 4 + 2 * fc * 4;
-        const int step = 128 * iF * 4;
-        auto put = [&](int voff, int soff, float a, float b) __attribute__((always_inline)) {
-            const auto v = two(a, b);
-            if (__builtin_expect(f0 + 8 <= F, 1)) {                      // uniform: the pair lies inside the clip
-                __builtin_amdgcn_raw_buffer_store_b64(v, rmag, voff, soff, PSND_STORE_AUX);
-            } else {                                                     // last pair of a clip: frame by frame
-                __builtin_amdgcn_raw_buffer_store_b32(v.x, rmag, ok0 ? voff : OOBV, soff, PSND_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b32(v.y, rmag, ok1 ? voff + 4 : OOBV, soff, PSND_STORE_AUX);
-            }
-        };
-        static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value;
-            put(off_lo, q * step, alo[q], blo[q]);                       // bin r + 128 q
-        });
-        {
-            const auto v = two(amid, bmid);                              // bin C/2: row 0's lanes only
-            const int vo = special ? 2 * fc * 4 : OOBV;
-            __builtin_amdgcn_raw_buffer_store_b32(v.x, rmag, (special && ok0) ? vo : OOBV, 8 * step, PSND_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b32(v.y, rmag, (special && ok1) ? vo + 4 : OOBV, 8 * step, PSND_STORE_AUX);
+        if (special) {                                                        // the middle bin C/2 = 128 * 8 of row 0 (self-paired)
+            const v2f mid = zr[ct::bitrev(8, 4)];
+            rfft_pair_pk(mid, mid, *reinterpret_cast<const v2f *>(s_vk + 2 * 1024), xk, xc);
+            emit.store(fc * 4, 8 * step, emit.template make<false>(xk));
         }
         static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = 7 - decltype(qc)::value;
-            put(off_hi, (15 - q) * step, ahi[q], bhi[q]);                // bin 128 - r + 128 (15 - q), ascending
+            emit.store(off_hi, (15 - q) * step, hold[q]);
         });
-    }   // pair loop
+    }
+    }   // tile loop
 }
 
 int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
@@ -1071,15 +1023,24 @@ int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
     return PSND_OK;
 }
 
-int launch_n4096b(const StftFwdParams &p, hipStream_t stream) {
+int launch_n4096b(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * k4096bLdsFloats;
     int grid = p.total_tiles < 512 ? p.total_tiles : 512;      // two persistent workgroups per CU
     if (const char *e = getenv("PSND_STFT4096_GRID")) grid = atoi(e);
     grid = (grid + 7) & ~7;
-    auto kern = stft_fwd_n4096b_kernel;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_fwd(n4096b): set LDS size: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+#define PSND_LAUNCH(M_, P_, R_)                                                                                     \
+    do {                                                                                                            \
+        auto kern = stft_fwd_n4096b_kernel<M_, P_, R_>;                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_fwd(n4096b): set LDS size: %s", hipGetErrorString(e));      \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);                                            \
+    } while (0)
+    if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
+    else if (mag && phase && !reim) PSND_LAUNCH(true, true, false);
+    else if (!mag && !phase && reim) PSND_LAUNCH(false, false, true);
+    else if (mag && !phase && reim) PSND_LAUNCH(true, false, true);
+    else PSND_LAUNCH(true, true, true);
+#undef PSND_LAUNCH
     PSND_CHECK_LAUNCH("stft_fwd(n4096b)");
     return PSND_OK;
 }
@@ -1323,13 +1284,12 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
             case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
         }
     }
-    if (n_fft == 4096 && mag && !phase && !re && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {
-        // magnitude only (LogMelSpectrogram / the losses): quads of 4-frame half tiles, two workgroups per CU.
-        // ntile = PAIRS (8 frames) per clip, rounded up to even; the grid walks quads (2 pairs)
-        const int64_t ntile = (F + 4 * k4096bFT - 1) / (4 * k4096bFT) * 2;
+    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {
+        // 4-frame tiles, two workgroups per CU (span <= 4 pieces per thread)
+        const int64_t ntile = (F + k4096bFT - 1) / k4096bFT;
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: too many tiles");
-        p.ntile = (int)ntile, p.total_tiles = (int)(ntile / 2 * N);
-        return launch_n4096b(p, s);
+        p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+        return launch_n4096b(p, mag, phase, re, s);
     }
     if (n_fft == 4096 && hop % 2 == 0 && hop <= 1792 && !getenv("PSND_STFT_GENERIC")) {   // span <= 8 pieces per thread
         const int64_t ntile = (F + k4096FT - 1) / k4096FT;

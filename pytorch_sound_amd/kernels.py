@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._lib import PsndError  # noqa: F401
 from ._lib import lib, check, ptr, stream_ptr, FRAMING_CENTER, FRAMING_HIFIGAN, FRAMING_NONE, LOG_NONE, LOG_E, LOG_10  # noqa: F401
 
 _INF = float('inf')
@@ -347,6 +348,94 @@ class SoftmaxKeys(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # models/sound.py: PreEmphasis and multi_stft_loss
 # ---------------------------------------------------------------------------------------------
+class Linear1x1(torch.autograd.Function):
+    """y = W x + b per time step (a 1x1 Conv1d, modules.py:21-22, 93-95) on the exact-fp32 matrix-core GEMM (psnd_linear1x1_*),
+    optionally with the ReLU that follows it fused (its backward masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        _need_cuda(x, 'input')
+        x = x.contiguous()
+        w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
+        N, Cin, T = x.shape
+        Cout = w2.shape[0]
+        if w2.shape[1] != Cin:
+            raise PsndError('Linear1x1: weight %s does not fit %d input channels' % (tuple(w.shape), Cin))
+        b = None if bias is None else bias.contiguous()
+        y = torch.empty((N, Cout, T), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_linear1x1_fwd(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), ptr(y), stream_ptr(x.device)),
+                  'psnd_linear1x1_fwd')
+        ctx.relu, ctx.has_bias, ctx.wshape = bool(relu), bias is not None, tuple(w.shape)
+        ctx.save_for_backward(x, w2, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w2, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, Cin, T = x.shape
+        Cout = w2.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dev = x.device
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty_like(w2) if need_w else None
+        gb = torch.empty(Cout, dtype=torch.float32, device=dev) if need_b else None
+        part = None
+        if need_w:
+            slabs = int(lib().psnd_linear1x1_wgrad_slabs(N, Cin, Cout, T))
+            part = torch.empty((slabs, Cout, Cin), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, ptr(gx), ptr(gw), ptr(part), ptr(gb),
+                                           stream_ptr(dev)), 'psnd_linear1x1_bwd')
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None
+
+
+class AttentionKVQ(torch.autograd.Function):
+    """MultiHeadAttention.scale_dot_att over all heads at once (modules.py:38-48, 61-79), straight from the fused projection:
+    kvq (N, 3C, T) in the reference's chunk order K | V | Q, heads folded head-major -> out (N, C, T) (heads unfolded, ready for
+    the output projection) and att (H*N, T_key, T_query) when `want_att`.  psnd_mha_fwd / psnd_mha_bwd: the score tensor stays
+    on the chip; exact fp32 products.  mask_u8: (N, T), 1 = padding."""
+
+    @staticmethod
+    def forward(ctx, kvq, mask_u8, heads, want_att):
+        _need_cuda(kvq, 'kvq')
+        kvq = kvq.contiguous()
+        N, C3, T = kvq.shape
+        C = C3 // 3
+        dev = kvq.device
+        out = torch.empty((N, C, T), dtype=torch.float32, device=dev)
+        att = torch.empty((heads * N, T, T), dtype=torch.float32, device=dev) if want_att else None
+        stats = torch.empty((heads * N, T, 2), dtype=torch.float32, device=dev)
+        m = None if mask_u8 is None else mask_u8.contiguous()
+        with torch.cuda.device(dev):
+            check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), stream_ptr(dev)), 'psnd_mha_fwd')
+        ctx.heads = heads
+        ctx.save_for_backward(kvq, m, out, att, stats)
+        if att is None:
+            att = out.new_empty(0)
+            ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, gout, gatt):
+        kvq, m, out, att, stats = ctx.saved_tensors
+        N, C3, T = kvq.shape
+        C, H = C3 // 3, ctx.heads
+        dev = kvq.device
+        gout = gout.contiguous()
+        if gatt is not None and att is None:
+            gatt = None
+        if gatt is not None:
+            gatt = gatt.contiguous()
+        delta = torch.empty((H * N, T), dtype=torch.float32, device=dev)
+        gkvq = torch.empty_like(kvq)
+        with torch.cuda.device(dev):
+            check(lib().psnd_mha_bwd(ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq),
+                                     stream_ptr(dev)), 'psnd_mha_bwd')
+        return gkvq, None, None, None
+
+
 class PreEmphasisFn(torch.autograd.Function):
     """y[t] = x[t] - coef * x[t-1] with one reflect-padded sample on the left (sound.py:76-81)."""
 

@@ -35,15 +35,19 @@ def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu:
     return F.relu(y) if relu else y
 
 
-def _conv1x1(conv: nn.Conv1d, x: torch.Tensor) -> torch.Tensor:
-    """the 1x1 Conv1d projections of modules.py:25-27, 94-96 as what they are - one GEMM over (C_in, N*T).  On a HIP device the
-    convolution library would run its per-shape solver search for every new sequence length (seconds of naive reference kernels
-    per shape with bucketed variable-length batches); the GEMM library has no such step.  CPU tensors keep the conv call."""
-    if not x.is_cuda:
-        return conv(x)
-    # batched GEMM with the weight as a stride-0 batch (measured 32 x 256 -> 768 x 1292, fwd + bwd: 0.57 ms; conv1d 0.77; matmul 0.95)
-    y = torch.bmm(conv.weight.squeeze(-1).unsqueeze(0).expand(x.shape[0], -1, -1), x)
-    return y if conv.bias is None else y + conv.bias.view(1, -1, 1)
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """the 1x1 Conv1d projections of modules.py:21-22, 93-95 as what they are - one GEMM over (C_in, N*T), on the exact-fp32
+    matrix-core kernel (psnd_linear1x1_*, bias and the following ReLU fused).  CPU tensors (and the tests' fp32 yardstick) keep
+    the torch formulation."""
+    if not _hip_ok(x):
+        if not x.is_cuda:
+            y = conv(x)
+        else:
+            y = torch.bmm(conv.weight.squeeze(-1).unsqueeze(0).expand(x.shape[0], -1, -1), x)
+            y = y if conv.bias is None else y + conv.bias.view(1, -1, 1)
+        return F.relu(y) if relu else y
+    from pytorch_sound_amd import kernels as K
+    return K.Linear1x1.apply(x, conv.weight, conv.bias, relu)
 
 
 class MultiHeadAttention(nn.Module):
@@ -67,12 +71,25 @@ class MultiHeadAttention(nn.Module):
         n = hn // self.heads
         return x.view(self.heads, n, d, t).transpose(0, 1).reshape(n, self.heads * d, t)
 
+    # (not in the reference) False: forward returns (x, None) and the (H*N, T, T) attention tensor is never written to memory -
+    # 855 MB per layer at 32 clips x 1292 frames; the reference always materialises and returns it
+    return_att = True
+
     def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        k, v, q = (self._fold_heads(p) for p in _conv1x1(self.linear_kvq, input).chunk(3, 1))
-        if mask is not None:
-            mask = mask.repeat(self.heads, 1)
-        x, att = self.scale_dot_att(k, v, q, att_mask=mask)
-        x = _conv1x1(self.linear, self._unfold_heads(x))
+        kvq = _conv1x1(self.linear_kvq, input)
+        if _hip_ok(input) and self.hidden_dim % self.heads == 0 and self.hidden_dim // self.heads <= 64:
+            # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
+            from pytorch_sound_amd import kernels as K
+            mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
+            x, att = K.AttentionKVQ.apply(kvq, mask_u8, self.heads, self.return_att)
+            att = att if self.return_att else None
+        else:
+            k, v, q = (self._fold_heads(p) for p in kvq.chunk(3, 1))
+            if mask is not None:
+                mask = mask.repeat(self.heads, 1)
+            x, att = self.scale_dot_att(k, v, q, att_mask=mask)
+            x = self._unfold_heads(x)
+        x = _conv1x1(self.linear, x)
         if self.drop_out is not None:
             x = self.drop_out(x)
         return _add_norm(self.layernorm, x, input), att
@@ -112,7 +129,7 @@ class PointwiseFeedForward(nn.Module):
         self.drop_out = nn.Dropout(dropout_rate) if 0 < dropout_rate < 1 else None
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        x = _conv1x1(self.ff[2], F.relu(_conv1x1(self.ff[0], input)))
+        x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True))
         if self.drop_out is not None:
             x = self.drop_out(x)
         return _add_norm(self.layernorm, x, input, relu=True)
