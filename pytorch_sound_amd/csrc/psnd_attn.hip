@@ -51,24 +51,42 @@ __device__ __forceinline__ void gemm_fetch(const float *base, const float *mask,
             if (k < limk) {
                 const float *p = base + (long long)k * s_k + x;
                 const float *pm = mask ? mask + (long long)k * s_k + x : nullptr;
+                if (x + 3 < lim128 && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
+                    r = *reinterpret_cast<const f32x4_t *>(p);                 // one 16-byte load (the common case)
+                    if (pm) {
+                        const f32x4_t m = *reinterpret_cast<const f32x4_t *>(pm);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (x + e < lim128) {
-                        const float val = p[e];
-                        r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                        for (int e = 0; e < 4; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x + e < lim128) {
+                            const float val = p[e];
+                            r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                        }
+                }
             }
         } else {                                 // float4 along k: thread -> (x = tid / 4 + 64 u, k4 = tid % 4)
             const int x = o128 + (tid >> 2) + 64 * u, k = ok + 4 * (tid & 3);
             if (x < lim128) {
                 const float *p = base + (long long)x * s_major128 + k;
                 const float *pm = mask ? mask + (long long)x * s_major128 + k : nullptr;
+                if (k + 3 < limk && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
+                    r = *reinterpret_cast<const f32x4_t *>(p);
+                    if (pm) {
+                        const f32x4_t m = *reinterpret_cast<const f32x4_t *>(pm);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k + e < limk) {
-                        const float val = p[e];
-                        r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                        for (int e = 0; e < 4; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
                     }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < limk) {
+                            const float val = p[e];
+                            r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
+                        }
+                }
             }
         }
         v[u] = r;
@@ -206,14 +224,30 @@ struct AttnParams {
 };
 
 // cooperative load of a (64 x 32) tile X[dd][t0 + c] of a (.., T)-pitched matrix into LDS [dd][TP]; columns >= T read as zero
+// in two halves - fetch (global -> registers, issued BEFORE the tile in flight is multiplied) and commit (registers -> LDS, after) -
+// so the load latency hides behind the MFMAs of the current tile
 template <int HDP>
-__device__ __forceinline__ void load_tile(const float *src, long long T, int d, int t0, float *dst, int tid) {
+__device__ __forceinline__ void fetch_tile(const float *src, long long T, int d, int t0, int tid, float (&v)[HDP / 8]) {
 #pragma unroll
     for (int u = 0; u < HDP / 8; ++u) {
         const int idx = tid + 256 * u, dd = idx >> 5, c = idx & 31;
         const int t = t0 + c;
-        dst[dd * TP + c] = (t < T && dd < d) ? src[(long long)dd * T + t] : 0.f;
+        v[u] = (t < T && dd < d) ? src[(long long)dd * T + t] : 0.f;
     }
+}
+template <int HDP>
+__device__ __forceinline__ void commit_tile(float *dst, int tid, const float (&v)[HDP / 8]) {
+#pragma unroll
+    for (int u = 0; u < HDP / 8; ++u) {
+        const int idx = tid + 256 * u;
+        dst[(idx >> 5) * TP + (idx & 31)] = v[u];
+    }
+}
+template <int HDP>
+__device__ __forceinline__ void load_tile(const float *src, long long T, int d, int t0, float *dst, int tid) {
+    float v[HDP / 8];
+    fetch_tile<HDP>(src, T, d, t0, tid, v);
+    commit_tile<HDP>(dst, tid, v);
 }
 // B-operand fragment of a (64 x T) matrix for the wave's 32 columns: f[s] = X[2 s + kk][t0 + li]
 template <int HDP>
@@ -263,13 +297,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const int ntile = (p.T + 31) / 32;
     // ---- pass 1
     float mx = -INFINITY, sum = 0.f;
+    float pk[HDP / 8], pv[HDP / 8];
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        if (it + 1 < ntile) load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
+        if (it + 1 < ntile) fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
         const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
         f32x16 s;
         mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
+        if (it + 1 < ntile) commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
         float tm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -310,12 +346,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         if (it + 1 < ntile) {
-            load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
-            load_tile<HDP>(Vp, T, p.d, 32 * (it + 1), sV[(it + 1) & 1], tid);
+            fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
+            fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
         }
         const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
         f32x16 s;
         mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
+        if (it + 1 < ntile) {
+            commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
+            commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rho(r, kk);
@@ -345,7 +385,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *out, const
     if (tq >= T) return;
     const float *o = out + ((long long)n * C + h * d) * T + tq, *g = gout + ((long long)n * C + h * d) * T + tq;
     float a = 0.f;
-    for (int dd = 0; dd < d; ++dd) a = __builtin_fmaf(o[dd * T], g[dd * T], a);
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int dd = 0; dd + 3 < d; dd += 4) {          // 8 independent loads in flight
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a4[e] = __builtin_fmaf(o[(dd + e) * T], g[(dd + e) * T], a4[e]);
+    }
+    for (int dd = d & ~3; dd < d; ++dd) a = __builtin_fmaf(o[dd * T], g[dd * T], a);
+    a += (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (gatt) {
         const float *pa = att + (long long)b * T * T + tq, *pg = gatt + (long long)b * T * T + tq;
         for (long long tk = 0; tk < T; ++tk) a = __builtin_fmaf(pa[tk * T], pg[tk * T], a);
@@ -377,9 +424,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) dK[mt][i] = 0.f, dV[mt][i] = 0.f;
     const int ntile = (p.T + 31) / 32;
+    float pq[HDP / 8], pg[HDP / 8];
     auto stage = [&](int it, int buf) __attribute__((always_inline)) {
-        load_tile<HDP>(Qp, T, p.d, 32 * it, sQ[buf], tid);
-        load_tile<HDP>(Gp, T, p.d, 32 * it, sG[buf], tid);
         if (tid < 32) {
             const int t = 32 * it + tid;
             f32x4_t st = {0.f, 0.f, 0.f, 1.f};
@@ -393,13 +439,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
         }
     };
     stage(0, 0);
+    load_tile<HDP>(Qp, T, p.d, 0, sQ[0], tid);
+    load_tile<HDP>(Gp, T, p.d, 0, sG[0], tid);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        if (it + 1 < ntile) stage(it + 1, (it + 1) & 1);
+        if (it + 1 < ntile) {
+            stage(it + 1, (it + 1) & 1);
+            fetch_tile<HDP>(Qp, T, p.d, 32 * (it + 1), tid, pq);
+            fetch_tile<HDP>(Gp, T, p.d, 32 * (it + 1), tid, pg);
+        }
         const float *tQ = sQ[it & 1], *tG = sG[it & 1], *tS = sSt[it & 1];
         f32x16 s, dp;
         mma_tile_frag<HDP>(tQ, kf, li, kk, s);            // rows: queries of the tile, column: this lane's key
         mma_tile_frag<HDP>(tG, vf, li, kk, dp);
+        if (it + 1 < ntile) {
+            commit_tile<HDP>(sQ[(it + 1) & 1], tid, pq);
+            commit_tile<HDP>(sG[(it + 1) & 1], tid, pg);
+        }
         if (p.gatt) {                                // gatt[tk][tq] is query-contiguous: through LDS, read transposed
             float *tt = sT[wave];
 #pragma unroll
@@ -463,14 +519,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
     load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
+        float pk[HDP / 8], pv[HDP / 8];
         if (it + 1 < ntile) {
-            load_tile<HDP>(Kp, T, p.d, 32 * (it + 1), sK[(it + 1) & 1], tid);
-            load_tile<HDP>(Vp, T, p.d, 32 * (it + 1), sV[(it + 1) & 1], tid);
+            fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
+            fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
         }
         const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
         f32x16 s, dp;
         mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
         mma_tile_frag<HDP>(sV[it & 1], gf, li, kk, dp);
+        if (it + 1 < ntile) {
+            commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
+            commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rho(r, kk);

@@ -411,6 +411,7 @@ class AttentionKVQ(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), stream_ptr(dev)), 'psnd_mha_fwd')
         ctx.heads = heads
+        ctx.set_materialize_grads(False)             # an unused `att` must not turn into an (H*N, T, T) tensor of zeros in backward
         ctx.save_for_backward(kvq, m, out, att, stats)
         if att is None:
             att = out.new_empty(0)
@@ -423,6 +424,8 @@ class AttentionKVQ(torch.autograd.Function):
         N, C3, T = kvq.shape
         C, H = C3 // 3, ctx.heads
         dev = kvq.device
+        if gout is None:
+            gout = torch.zeros_like(out)
         gout = gout.contiguous()
         if gatt is not None and att is None:
             gatt = None
