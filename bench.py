@@ -12,13 +12,17 @@ clips resident in HBM, random-init weights.  One "step" = Trainer.train(): zero_
 psnd_stft_fwd launches, the separator under bf16 autocast, psnd_mel_fwd x2), NaN check, backward
 (incl. psnd_mel_bwd), flat-bucket RCCL all-reduce overlapped with backward, Adam step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the STFT kernel (wav -> magnitude) as launched inside the timed steps: algorithmic bytes
-                4*N*T + 4*N*K*F per launch / mean launch duration (HIP events on the launch stream)
-                against 8 TB/s.  `roofline_large` is the same kernel on a 544 MB working set (>> the
-                256 MiB Infinity Cache), where an HBM percentage is meaningful.
-  cpu_baseline  the reference's CPU path (oracle/torch_ref.py port of its dense-DFT conv1d STFT + mel,
-                same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample.
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline         the STFT kernel of the step (wav -> magnitude, stft_fwd_n1024_kernel) on a 544 MB working set (1024 clips,
+                   >> the 256 MiB Infinity Cache): algorithmic bytes 4*N*T + 4*N*K*F per launch / mean launch duration
+                   (HIP events on the launch stream, measured in this run) against 8 TB/s
+  roofline_instep  the same kernel as launched inside the timed steps (64 clips, 34 MB, cache resident): a latency figure
+  roofline_config5 BASELINE config 5: n_fft 4096 / hop 1024, 32 clips x 30 s at 44.1 kHz (508 MB)
+  roofline_conv    the conv kernels that take most of the step, against the dense bf16 MFMA peak
+  h2d_inclusive    the same step with the batches in pinned HOST memory (the reference's loop includes this copy,
+                   trainer.py:202): copied on a side stream one step ahead (Trainer.prefetch_prepare) and in line
+  cpu_baseline     the reference's CPU path (oracle/torch_ref.py port of its dense-DFT conv1d STFT + mel,
+                   same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample.
 """
 import argparse
 import json
@@ -48,7 +52,11 @@ def synth_batch(seed, n, t, device):
     tone = 0.1 * torch.sin(2 * np.pi * 440 * tt) + 0.1 * torch.sin(2 * np.pi * 3000 * tt + 0.3)
     clean = (0.0708 * torch.randn(n, t, generator=g) + tone).clamp(-1, 1)
     noisy = (clean + 0.03 * torch.randn(n, t, generator=g)).clamp(-1, 1)
-    return noisy.to(device), clean.to(device)
+    # mixture clips then reference clips in ONE (2n, t) tensor: the step's single STFT launch reads it as it is (no torch.cat)
+    both = torch.cat([noisy, clean])
+    if device.type == 'cpu' and torch.cuda.is_available():
+        both = both.pin_memory()
+    return (both.to(device),)
 
 
 def build_step(device, amp):
@@ -83,11 +91,11 @@ def build_step(device, amp):
         l1 = F.l1_loss
 
     class StepTrainer(Trainer):
-        def prepare(self, noisy, clean):
+        def prepare(self, both):
             # feature extraction of the batch (no parameters, no gradient): eager, ahead of the captured graph
             with torch.no_grad():
-                n = noisy.shape[0]
-                mag = magnitude(torch.cat([noisy, clean]))        # mixture and reference clips: ONE STFT launch (2 x batch clips)
+                n = both.shape[0] // 2
+                mag = magnitude(both)                             # mixture and reference clips: ONE STFT launch (2 x batch clips)
                 mag_mix, mag_ref = mag[:n], mag[n:]
                 mel_ref = logmel_of_mag(mag_ref)
             return mag_mix, mag_ref, mel_ref
@@ -170,11 +178,45 @@ def gpu_bench(args):
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tdt.item())
 
+    # ---- the same step with the batches in pinned HOST memory (the reference's loop includes this copy: trainer.py:202,
+    #      utils/tensor.py:15).  (a) copied + feature-extracted one step ahead on a side stream (Trainer.prefetch_prepare),
+    #      (b) copied in line on the compute stream as the reference does.  Same K steps each, max over ranks.
+    ev_instep = K.STFT_FWD_EVENTS
+    K.STFT_FWD_EVENTS = None
+    h2d = {}
+    host_pool = [synth_batch(1234 + rank + 1000 * i, N, T, torch.device('cpu')) for i in range(args.pool)]
+    for mode in ('prefetch', 'inline'):
+        tr.train_dataset = tr.repeat(host_pool)
+        tr.prefetch_prepare = mode == 'prefetch'
+        tr._pre_stream = None
+        for _ in range(3):
+            step += 1
+            tr.step = step
+            tr.train(step)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step += 1
+            tr.step = step
+            tr.train(step)
+        barrier()
+        d = time.perf_counter() - t1
+        if distributed:
+            tdt = torch.tensor([d], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+            d = float(tdt.item())
+        h2d[mode] = {'value': world * N * CLIP_SECONDS * args.steps / d, 'ms_per_step': d / args.steps * 1e3}
+    tr.prefetch_prepare = args.prefetch
+    h2d['unit'] = 'audio-s/s'
+    h2d['bytes_per_step'] = 2 * N * T * 4
+    h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch" = copy + feature extraction of the next batch on a side '
+                   'stream while the step computes (Trainer.prefetch_prepare), "inline" = .cuda(non_blocking) on the compute '
+                   'stream as the reference\'s Trainer.train does') % args.steps
+
     # ---- roofline of the STFT kernel as launched in the timed region (rank 0) ------------------------
     Kb = N_FFT // 2 + 1
     Fr = K.frame_count(T, N_FFT, HOP)
-    ev = K.STFT_FWD_EVENTS
-    K.STFT_FWD_EVENTS = None
+    ev = ev_instep
     t_raw = float(np.mean([a.elapsed_time(b) for a, b, _ in ev])) * 1e-3
     # an event pair around NOTHING on a busy stream still reads ~5 us (the two marker packets); on this 12-13 us launch
     # (rocprofv3 kernel time, profiles/) that overhead is reported next to the raw figure, not subtracted - the two
@@ -183,14 +225,13 @@ def gpu_bench(args):
     t_stft = t_raw
     n_launch = int(ev[0][2])                       # clips per in-step launch (mixture + reference clips of a batch together)
     bytes_launch = 4 * n_launch * T + 4 * n_launch * Kb * Fr
-    roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
-                'achieved': bytes_launch / t_stft / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': bytes_launch / t_stft / HBM_PEAK, 'traffic': None,
-                'bytes_per_launch': bytes_launch, 'launch_us': t_stft * 1e6,
-                'empty_event_pair_us': t_ovh * 1e6, 'launches_timed': len(ev),
-                'note': 'config-2 launch (mixture + reference clips of the batch): 704 workgroups, 34 MB (Infinity-Cache resident) - one workgroup lifetime, not a '
-                        'bandwidth measurement; see roofline_large for the same kernel on a working set beyond the '
-                        '256 MiB cache'}
+    roofline_instep = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
+                       'achieved': bytes_launch / t_stft / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                       'frac': bytes_launch / t_stft / HBM_PEAK, 'traffic': None,
+                       'bytes_per_launch': bytes_launch, 'launch_us': t_stft * 1e6,
+                       'empty_event_pair_us': t_ovh * 1e6, 'launches_timed': len(ev),
+                       'note': 'the launch inside the timed steps (mixture + reference clips of the batch): 704 workgroups, 34 MB '
+                               '(Infinity-Cache resident) - one workgroup lifetime, a latency figure, not a bandwidth measurement'}
     out = None
     if rank == 0:
         # the same kernel on 1024 clips: 181 MB in + 363 MB out
@@ -209,10 +250,14 @@ def gpu_bench(args):
         torch.cuda.synchronize()
         tl = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
         bl = 4 * NL * T + 4 * NL * Kb * Fr
-        roofline_large = {'bound': 'hbm', 'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                          'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic(), 'bytes_per_launch': bl,
-                          'launch_us': tl * 1e6, 'workload': '1024 clips x 2 s, 1024/256 (544 MB)'}
+        roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
+                    'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic(), 'traffic_source': 'profiles/stft_pmc.json (separate rocprofv3 --pmc pass of this launch)',
+                    'bytes_per_launch': bl, 'launch_us': tl * 1e6, 'launches_timed': len(evs) - 3,
+                    'workload': '1024 clips x 2 s, 1024/256: 181 MB in + 363 MB out = 544 MB (> the 256 MiB Infinity Cache), the '
+                                'kernel of the step on an HBM-sized working set; HIP events around every launch, measured in this run'}
         del wav, mag
+        roofline_config5 = _config5_roofline(device)
         roofline_conv = _conv_roofline(device, N, Fr)
         audio_s = world * N * CLIP_SECONDS * args.steps
         out = {
@@ -223,9 +268,37 @@ def gpu_bench(args):
                                    '22.05 kHz, STFT 1024/256, 80 mel, batch 32 x 2 s per GPU, Adam, bf16 autocast',
                        'global_batch': world * N, 'clip_seconds': CLIP_SECONDS, 'parallelism': 'dp%d' % world,
                        'model_params': sum(p.numel() for p in model.parameters())},
-            'roofline': roofline, 'roofline_large': roofline_large, 'roofline_conv': roofline_conv,
+            'roofline': roofline, 'roofline_instep': roofline_instep, 'roofline_config5': roofline_config5,
+            'roofline_conv': roofline_conv, 'h2d_inclusive': h2d,
         }
     return out, device
+
+
+def _config5_roofline(device, n_fft=4096, hop=1024, clips=32, seconds=30.0, sr=44100):
+    """BASELINE config 5 (Maestro-like 44.1 kHz music, 4096-pt STFT, 30 s clips): psnd_stft_fwd magnitude on 32 clips
+    (169 MB in + 339 MB out = 508 MB), HIP events around every launch"""
+    from pytorch_sound_amd import kernels as K
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    T = int(sr * seconds)
+    wav = torch.randn(clips, T, device=device) * 0.07
+    plan = K.stft_plan(n_fft, _hann(n_fft)).to(device)
+    Kb, Fr = n_fft // 2 + 1, K.frame_count(T, n_fft, hop)
+    mag = torch.empty(clips, Kb, Fr, device=device)
+    evs = []
+    for i in range(11):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().psnd_stft_fwd(ptr(wav), clips, T, n_fft, hop, 0, ptr(plan), 0.0, ptr(mag), None, None, None, stream_ptr(device)),
+              'psnd_stft_fwd')
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    t = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
+    b = 4 * clips * T + 4 * clips * Kb * Fr
+    return {'bound': 'hbm', 'kernel': 'stft_fwd_n4096b_kernel (wav -> magnitude, 4096/1024)', 'achieved': b / t / 1e9,
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': None, 'bytes_per_launch': b,
+            'launch_us': t * 1e6, 'launches_timed': len(evs) - 3,
+            'workload': 'configs[4]: %d clips x %.0f s at %d Hz, n_fft %d / hop %d (%.0f MB)' % (clips, seconds, sr, n_fft, hop, b / 1e6)}
 
 
 def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
@@ -278,7 +351,7 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
             'achieved': res['forward']['achieved'], 'frac': res['forward']['frac'], **res}
 
 
-def _event_pair_overhead(device, n=200):
+def _event_pair_overhead(device, n=40):
     """median elapsed time of an EMPTY HIP event pair on a stream kept busy by a small kernel in front of it"""
     x = torch.zeros(1 << 22, device=device)
     pairs = []
@@ -316,30 +389,27 @@ def cpu_baseline(seconds):
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     dev = torch.device('cpu')
-    have_cuda = torch.cuda.is_available
-    torch.cuda.is_available = lambda: False            # keep Trainer on its CPU path for this leg
-    try:
-        Trainer, model = build_step(dev, amp=False)
-        Ncpu, T = 4, int(SR * CLIP_SECONDS)
-        pool = [synth_batch(4321 + i, Ncpu, T, dev) for i in range(2)]
-        opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99))
-        huge = 10 ** 9
-        tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
-                     save_dir=tempfile.mkdtemp(prefix='psnd_cpu_'), save_prefix='cpu', seed=1234)
-        model.train()
-        tr.step = 1
-        tr.train(1)                                      # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            n += 1
-            tr.step = n + 1
-            tr.train(n + 1)
-            el = time.perf_counter() - t0
-            if el >= seconds or n >= 200:
-                break
-    finally:
-        torch.cuda.is_available = have_cuda
-    return {'value': n * Ncpu * CLIP_SECONDS / el, 'unit': 'audio-s/s', 'cores': cores, 'kind': 'port',
+    Trainer, model = build_step(dev, amp=False)
+    Trainer.move_batches_to_gpu = False              # this leg stays on the host (Trainer would .cuda() every batch)
+    Ncpu, T = 4, int(SR * CLIP_SECONDS)
+    pool = [synth_batch(4321 + i, Ncpu, T, dev) for i in range(2)]
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99))
+    huge = 10 ** 9
+    tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
+                 save_dir=tempfile.mkdtemp(prefix='psnd_cpu_'), save_prefix='cpu', seed=1234)
+    model.train()
+    tr.step = 1
+    tr.train(1)                                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        n += 1
+        tr.step = n + 1
+        tr.train(n + 1)
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {'value': n * Ncpu * CLIP_SECONDS / el, 'unit': 'audio-s/s', 'cores': cores, 'cpu_count': os.cpu_count(), 'kind': 'port',
+            'threads_note': 'torch.set_num_threads(min(32, cpu_count)): this step scales to ~16-32 threads and collapses beyond 64',
             'sample': '%d steps of batch 4 x 2 s clips (configs[0] batch), same model/loss/Adam in fp32, '
                       'feature path = oracle/torch_ref.py (the reference\'s dense-DFT conv1d STFT + mel); %.1f s'
                       % (n, el)}

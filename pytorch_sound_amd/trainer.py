@@ -205,9 +205,13 @@ class Trainer:
                 t.record_stream(cur)
         return batch
 
+    # (not in the reference) False keeps the batches where the data set put them - a CPU training run on a machine that has a GPU
+    # (the reference moves every batch with .cuda() unconditionally, trainer.py:202)
+    move_batches_to_gpu = True
+
     def _next_batch(self, iterator):
         batch = next(iterator)
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and self.move_batches_to_gpu:
             return to_device(batch)
         return batch if isinstance(batch, (tuple, list)) else (batch,)
 
