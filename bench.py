@@ -185,9 +185,10 @@ def gpu_bench(args):
     K.STFT_FWD_EVENTS = None
     h2d = {}
     host_pool = [synth_batch(1234 + rank + 1000 * i, N, T, torch.device('cpu')) for i in range(args.pool)]
-    for mode in ('prefetch', 'inline'):
+    for mode in ('prefetch_copy', 'inline'):
         tr.train_dataset = tr.repeat(host_pool)
-        tr.prefetch_prepare = mode == 'prefetch'
+        tr.prefetch_prepare = False
+        tr.prefetch_copy = mode == 'prefetch_copy'
         tr._pre_stream = None
         for _ in range(3):
             step += 1
@@ -206,12 +207,12 @@ def gpu_bench(args):
             torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
             d = float(tdt.item())
         h2d[mode] = {'value': world * N * CLIP_SECONDS * args.steps / d, 'ms_per_step': d / args.steps * 1e3}
-    tr.prefetch_prepare = args.prefetch
+    tr.prefetch_prepare, tr.prefetch_copy = args.prefetch, False
     h2d['unit'] = 'audio-s/s'
     h2d['bytes_per_step'] = 2 * N * T * 4
-    h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch" = copy + feature extraction of the next batch on a side '
-                   'stream while the step computes (Trainer.prefetch_prepare), "inline" = .cuda(non_blocking) on the compute '
-                   'stream as the reference\'s Trainer.train does') % args.steps
+    h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch_copy" = the copy of the next batch on a side stream while the '
+                   'step computes (Trainer.prefetch_copy), "inline" = .cuda(non_blocking) on the compute stream as the '
+                   'reference\'s Trainer.train does') % args.steps
 
     # ---- roofline of the STFT kernel as launched in the timed region (rank 0) ------------------------
     Kb = N_FFT // 2 + 1

@@ -148,9 +148,13 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 //   enough rows to fill the chip anyway: the stage loop is bound by the B fragment loads, whose bytes per FLOP go with 1 / rows)
 //   HMX: largest tap reach the staged A tile (and its register ring) is sized for: 25 covers every conv of hifi_gan_v1 / v2
 //   (k = 11, dilation 5); the 7-tap instances also exist with 40 (hifi_gan_v3: k = 7, dilation 12 -> 36)
-template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25>
+//   UPM: the transposed-conv ("up") address maps are compiled in (ConvParams::up_role); the plain instances carry none of it
+//   KCT: input channels per pipeline stage (32, or 64 for the 3-tap instances: half the barriers per conv - the stage loop of
+//   a 64 x 64 tile is a chain of LDS-write -> barrier -> LDS-read latencies around 6 MFMAs, not MFMA time)
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
-    constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B, odd multiple of 16 B
+    constexpr int KC = KCT, PCS = KCT / 8, KS = KCT / 16;
+    constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B / 144 B, odd multiples of 16 B
     constexpr int BMt = 64 * MT, NAt = (BMt + 2 * HMX) * PCS / 256 + 1;
     const int rowsA = BMt + 2 * p.hm;
     const int buf_elems = rowsA * RS;      // two A stage buffers; the weights never enter LDS
@@ -174,9 +178,10 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     // HiFi-GAN blocks (43 / 65 KB of weights per stage buffer) ran ONE workgroup per CU.
     // (With a ROW-MAJOR pack the same idea lost, 11 -> 18 us: 64 separate 32-byte pieces per wave instruction.)
     constexpr int TC = 3, NCH = (KT + TC - 1) / TC, UNITS = D * NCH;
-    constexpr int DB = KT <= 3 ? (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN) : (UNITS % 4 == 0 ? 4 : (UNITS % 3 == 0 ? 3 : 2));
+    constexpr int DB = KCT == 64 ? (UNITS % 2 == 0 ? 2 : 1)          // 64-channel stages: a unit is twice the registers
+                     : KT <= 3 ? (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN) : (UNITS % 4 == 0 ? 4 : (UNITS % 3 == 0 ? 3 : 2));
     static_assert(UNITS % DB == 0, "B ring depth must divide the units of a ring turn (slots are static inside a turn)");
-    uint4 ra[D][NAt], ra2[COMBINE ? D : 1][NAt], ram[COMBINE ? D : 1][NAt], rbf[DB][2 * TC];
+    uint4 ra[D][NAt], ra2[COMBINE ? D : 1][NAt], ram[COMBINE ? D : 1][NAt], rbf[DB][KS * TC];
     const int nA = rowsA * PCS;
     // Every load is a buffer load with a 32-bit byte offset; an offset of OOB (or any offset past the tensor)
     // returns zeros.  That supplies the rows before / after the tensor, the channels past Ca of a padding stage
@@ -184,7 +189,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     // exactly only in straight-line code - one conditional fetch and every later wait degrades to vmcnt(0),
     // which serialises the whole ring (measured: 1.7 k cycles per stage instead of 0.5 k).
     constexpr unsigned OOB = 0xffffffffu;
-    const bool upA = p.up_role == 2;           // the A operand is the high-resolution view
+    const bool upA = UPM && p.up_role == 2;    // the A operand is the high-resolution view
     const unsigned a_bytes = upA ? (unsigned)((size_t)(p.R / p.Lp) * p.up_LpO * p.up_Cr * sizeof(bf16_t))
                                  : (unsigned)((size_t)p.R * p.Ca * sizeof(bf16_t));
     const unsigned w_bytes = (unsigned)((size_t)p.k * p.Cb * p.Ca * sizeof(bf16_t));
@@ -221,7 +226,8 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         const unsigned cb = (unsigned)c0 * (unsigned)sizeof(bf16_t);
 #pragma unroll
         for (int u = 0; u < NAt; ++u) {
-            const unsigned o = (live && aoff[u] != OOB) ? aoff[u] + cb : OOB;
+            const bool chan = KCT == 32 || c0 + 8 * ((tid + 256 * u) % PCS) < p.Ca;     // Ca % 32 == 0: a 64-channel stage may be half empty
+            const unsigned o = (live && chan && aoff[u] != OOB) ? aoff[u] + cb : OOB;
             ra[s][u] = ld16(rA, haveA ? o : OOB);
             if constexpr (COMBINE) {
                 ra2[s][u] = ld16(rA2, o);
@@ -240,8 +246,8 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #pragma unroll
         for (int t = 0; t < TC; ++t)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                rbf[slot][2 * t + kk] = ld16(rW, (live && q * TC + t < p.k) ? fbase + (unsigned)(q * TC + t) * ftap + ks + (unsigned)kk * 1024u : OOB);
+            for (int kk = 0; kk < KS; ++kk)
+                rbf[slot][KS * t + kk] = ld16(rW, (live && q * TC + t < p.k && c0 + 16 * kk < p.Ca) ? fbase + (unsigned)(q * TC + t) * ftap + ks + (unsigned)kk * 1024u : OOB);
     };
     auto combine = [&](uint4 v, uint4 g2, uint4 m) __attribute__((always_inline)) {
         const unsigned *pv = reinterpret_cast<const unsigned *>(&v), *pg = reinterpret_cast<const unsigned *>(&g2),
@@ -266,7 +272,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
             if constexpr (COMBINE) {
                 v = combine(v, ra2[s][u], ram[s][u]);
                 const int rr = idx / PCS;
-                const bool own = rr >= p.hm && rr < p.hm + BMt && aoff[u] != OOB && c0 < p.Ca;     // rows of this tile
+                const bool own = rr >= p.hm && rr < p.hm + BMt && aoff[u] != OOB && c0 + 8 * (idx % PCS) < p.Ca;     // rows of this tile
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rG,
                                                        (int)(own ? aoff[u] + (unsigned)c0 * 2u : OOB), 0, 0);
             }
@@ -300,7 +306,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                         const bf16_t *pa = sA + (wm * 32 * MT + li + off) * RS + 8 * kg;
 #pragma unroll
                         for (int kk = 0; kk < KC / 16; ++kk) {
-                            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, rbf[slot][2 * decltype(tc)::value + kk]);
+                            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, rbf[slot][KS * decltype(tc)::value + kk]);
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
                                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa + m * 32 * RS + 16 * kk);
@@ -342,7 +348,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         size_t o = (size_t)r * p.Cb + col;
         float v[8];
         bool inside = l >= p.HP && l < p.HP + p.L;
-        if (p.up_role == 1) {                  // forward of the transposed conv: column block phi of low row l = high row t
+        if (UPM && p.up_role == 1) {           // forward of the transposed conv: column block phi of low row l = high row t
             const long long hb = up_row_base(p.Lp, p.HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, r);
             if (hb < 0) continue;
             const int t = (l - p.HP) * p.up_u + col / p.up_Cr - p.up_p;
@@ -411,10 +417,10 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #endif
 }
 
-template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25>
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32>
 __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, UPM, KCT>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25>
+template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32>
 __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
         conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
-        conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX>(pc, c % cgx, c / cgx, smem_dyn, 0);
+        conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT>(pc, c % cgx, c / cgx, smem_dyn, 0);
     }
 }
 
@@ -878,6 +884,13 @@ extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
     return PSND_OK;
 }
 
+// input channels per pipeline stage: 64 for the 3-tap convolutions (PSND_CONV_KC=32 switches back: A/B measurements)
+static int conv_stage_channels(int k, int hm, bool up) {
+    const char *e = getenv("PSND_CONV_KC");
+    const int want = e ? atoi(e) : 64;
+    return (want == 64 && k <= 3 && hm <= 25 && !up) ? 64 : 32;
+}
+
 // 128-row workgroup tiles once 64-row tiles would make >= 1024 workgroups (two full rounds of the chip's 512 slots)
 static int conv_row_tiles(int64_t R, int Cb) {
     const char *fe = getenv("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
@@ -893,13 +906,14 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
     const int mt = conv_row_tiles(p.R, Cb);
     const int bm = 64 * mt;
-    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);                    // two A stage buffers (the weights never enter LDS)
+    const int kct = conv_stage_channels(k, hm, p.up_role != 0 || combine);
+    size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
     if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "%s: LDS %zu too large", what, lds);
     dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + BN - 1) / BN));
-#define PSND_CONV_LAUNCH(KT_, D_, C_, H_)                                                                             \
+#define PSND_CONV_LAUNCH(KT_, D_, C_, H_, U_)                                                                         \
     do {                                                                                                              \
-        auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_>;   \
+        auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, U_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_, U_>;   \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -907,16 +921,23 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
         }                                                                                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                                        \
     } while (0)
-    if (hm > 25 && !combine) PSND_CONV_LAUNCH(7, 3, false, 40);
-    else if (hm > 25) PSND_CONV_LAUNCH(7, 3, true, 40);
-    else if (k <= 3 && !combine) PSND_CONV_LAUNCH(3, 8, false, 25);
-    else if (k <= 3) PSND_CONV_LAUNCH(3, 4, true, 25);
-    else if (k <= 7 && !combine) PSND_CONV_LAUNCH(7, 3, false, 25);
-    else if (k <= 7) PSND_CONV_LAUNCH(7, 3, true, 25);
-    else if (k <= 11 && !combine) PSND_CONV_LAUNCH(11, 2, false, 25);
-    else if (k <= 11) PSND_CONV_LAUNCH(11, 2, true, 25);
-    else if (!combine) PSND_CONV_LAUNCH(16, 2, false, 25);
-    else PSND_CONV_LAUNCH(16, 2, true, 25);
+    if (p.up_role != 0) {
+        if (k > 3 || hm > 25) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: transposed-conv mode is a 2-tap convolution", what);
+        if (!combine) PSND_CONV_LAUNCH(3, 8, false, 25, true);
+        else PSND_CONV_LAUNCH(3, 4, true, 25, true);
+    } else if (kct == 64) {                    // 3 taps, plain operand: 64-channel stages (4 / 2 stages in flight)
+        auto kern = mt == 2 ? conv_cl_kernel<3, 2, false, 2, 2, 25, false, 64> : conv_cl_kernel<3, 4, false, 2, 1, 25, false, 64>;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    } else if (hm > 25 && !combine) PSND_CONV_LAUNCH(7, 3, false, 40, false);
+    else if (hm > 25) PSND_CONV_LAUNCH(7, 3, true, 40, false);
+    else if (k <= 3 && !combine) PSND_CONV_LAUNCH(3, 8, false, 25, false);
+    else if (k <= 3) PSND_CONV_LAUNCH(3, 4, true, 25, false);
+    else if (k <= 7 && !combine) PSND_CONV_LAUNCH(7, 3, false, 25, false);
+    else if (k <= 7) PSND_CONV_LAUNCH(7, 3, true, 25, false);
+    else if (k <= 11 && !combine) PSND_CONV_LAUNCH(11, 2, false, 25, false);
+    else if (k <= 11) PSND_CONV_LAUNCH(11, 2, true, 25, false);
+    else if (!combine) PSND_CONV_LAUNCH(16, 2, false, 25, false);
+    else PSND_CONV_LAUNCH(16, 2, true, 25, false);
 #undef PSND_CONV_LAUNCH
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e_));
@@ -1129,7 +1150,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const int bm = 64 * mt;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
     const int nw = wgx * wgy * wgz;
-    size_t lds = 2 * sizeof(bf16_t) * 40 * (size_t)(bm + 2 * hm);
+    const int kct = conv_stage_channels(k, hm, G2 != nullptr);
+    size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);
     if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1143,7 +1165,10 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);    \
     } while (0)
-    if (hm > 25 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 40);
+    if (kct == 64) {
+        auto kern = mt == 2 ? conv_bwd_pair_kernel<3, 2, 2, false, 2, 25, 64> : conv_bwd_pair_kernel<3, 4, 2, false, 1, 25, 64>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);
+    } else if (hm > 25 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 40);
     else if (hm > 25) PSND_PAIR_LAUNCH(7, 3, true, 40);
     else if (k <= 3 && !G2) PSND_PAIR_LAUNCH(3, 8, false, 25);
     else if (k <= 3) PSND_PAIR_LAUNCH(3, 4, true, 25);

@@ -176,12 +176,17 @@ class Trainer:
     # current step computes; the step's stream waits on an event, never the host.  prepare() must then be parameter-free
     # (it runs one step early).  Off by default: the data iterator is advanced one batch ahead of the step that uses it.
     prefetch_prepare = False
+    # (not in the reference) only the host->device COPY of the next batch runs one step ahead on a side stream; prepare() stays
+    # on the compute stream at the step that uses the batch (no second stream competing for the CUs)
+    prefetch_copy = False
 
     def _stage_train_batch(self):
         side = self._pre_stream
         try:
             with torch.cuda.stream(side):
-                batch = self.prepare(*self._next_batch(self.train_dataset))
+                batch = tuple(self._next_batch(self.train_dataset))
+                if self.prefetch_prepare:
+                    batch = self.prepare(*batch)
                 event = torch.cuda.Event()
                 event.record(side)
             return batch, event
@@ -189,7 +194,7 @@ class Trainer:
             return e, None
 
     def _take_train_batch(self):
-        if not (self.prefetch_prepare and torch.cuda.is_available()):
+        if not ((self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available()):
             return self.prepare(*self._next_batch(self.train_dataset))
         if getattr(self, '_pre_stream', None) is None:
             self._pre_stream = torch.cuda.Stream()
@@ -203,6 +208,8 @@ class Trainer:
         for t in batch:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)
+        if not self.prefetch_prepare:
+            batch = self.prepare(*batch)
         return batch
 
     # (not in the reference) False keeps the batches where the data set put them - a CPU training run on a machine that has a GPU
