@@ -149,10 +149,12 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 //   HMX: largest tap reach the staged A tile (and its register ring) is sized for: 25 covers every conv of hifi_gan_v1 / v2
 //   (k = 11, dilation 5); the 7-tap instances also exist with 40 (hifi_gan_v3: k = 7, dilation 12 -> 36)
 //   UPM: the transposed-conv ("up") address maps are compiled in (ConvParams::up_role); the plain instances carry none of it
-//   KCT: input channels per pipeline stage (32, or 64 for the 3-tap instances: half the barriers per conv - the stage loop of
-//   a 64 x 64 tile is a chain of LDS-write -> barrier -> LDS-read latencies around 6 MFMAs, not MFMA time)
+//   KCT: input channels per pipeline stage.  Only 32 is instantiated: 64-channel stages (half the barriers, same bytes in flight)
+//   were built for the 3-tap instances in round 2 and measured no faster - config-2 step 1.242 ms against 1.236 ms, forward
+//   launch 13.8 us against 13.5 us - so the stage loop is not bound by the barrier / LDS hand-over latency per stage
 template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
+    static_assert(KCT == 32, "only 32-channel stages are validated");
     constexpr int KC = KCT, PCS = KCT / 8, KS = KCT / 16;
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B / 144 B, odd multiples of 16 B
     constexpr int BMt = 64 * MT, NAt = (BMt + 2 * HMX) * PCS / 256 + 1;
@@ -884,13 +886,6 @@ extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
     return PSND_OK;
 }
 
-// input channels per pipeline stage: 64 for the 3-tap convolutions (PSND_CONV_KC=32 switches back: A/B measurements)
-static int conv_stage_channels(int k, int hm, bool up) {
-    const char *e = getenv("PSND_CONV_KC");
-    const int want = e ? atoi(e) : 64;
-    return (want == 64 && k <= 3 && hm <= 25 && !up) ? 64 : 32;
-}
-
 // 128-row workgroup tiles once 64-row tiles would make >= 1024 workgroups (two full rounds of the chip's 512 slots)
 static int conv_row_tiles(int64_t R, int Cb) {
     const char *fe = getenv("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
@@ -906,7 +901,7 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
     const int mt = conv_row_tiles(p.R, Cb);
     const int bm = 64 * mt;
-    const int kct = conv_stage_channels(k, hm, p.up_role != 0 || combine);
+    const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
     if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "%s: LDS %zu too large", what, lds);
@@ -925,9 +920,6 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
         if (k > 3 || hm > 25) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: transposed-conv mode is a 2-tap convolution", what);
         if (!combine) PSND_CONV_LAUNCH(3, 8, false, 25, true);
         else PSND_CONV_LAUNCH(3, 4, true, 25, true);
-    } else if (kct == 64) {                    // 3 taps, plain operand: 64-channel stages (4 / 2 stages in flight)
-        auto kern = mt == 2 ? conv_cl_kernel<3, 2, false, 2, 2, 25, false, 64> : conv_cl_kernel<3, 4, false, 2, 1, 25, false, 64>;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
     } else if (hm > 25 && !combine) PSND_CONV_LAUNCH(7, 3, false, 40, false);
     else if (hm > 25) PSND_CONV_LAUNCH(7, 3, true, 40, false);
     else if (k <= 3 && !combine) PSND_CONV_LAUNCH(3, 8, false, 25, false);
@@ -1150,7 +1142,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const int bm = 64 * mt;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
     const int nw = wgx * wgy * wgz;
-    const int kct = conv_stage_channels(k, hm, G2 != nullptr);
+    const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);
     if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
@@ -1165,10 +1157,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);    \
     } while (0)
-    if (kct == 64) {
-        auto kern = mt == 2 ? conv_bwd_pair_kernel<3, 2, 2, false, 2, 25, 64> : conv_bwd_pair_kernel<3, 4, 2, false, 1, 25, 64>;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(nw + cgx * cgy)), dim3(256), lds, st, pc, pw, nw, wgx, wgy, cgx);
-    } else if (hm > 25 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 40);
+    if (hm > 25 && !G2) PSND_PAIR_LAUNCH(7, 3, false, 40);
     else if (hm > 25) PSND_PAIR_LAUNCH(7, 3, true, 40);
     else if (k <= 3 && !G2) PSND_PAIR_LAUNCH(3, 8, false, 25);
     else if (k <= 3) PSND_PAIR_LAUNCH(3, 4, true, 25);
