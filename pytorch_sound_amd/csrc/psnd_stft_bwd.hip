@@ -706,6 +706,289 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
 }
 
 // ---------------------------------------------------------------------------------------------
+// n_fft = 4096 (config 5), gradient of the magnitude: the adjoint on the structure of stft_fwd_n4096b_kernel (psnd_stft.hip) -
+// 4-frame tiles, 512 threads, X[f][q_a][258] in 66 KB of LDS, two workgroups per CU.  Round 1 ran this size on the generic
+// one-frame-per-workgroup LDS FFT (~4 % of the HBM roof).
+//   forward recompute: span -> pass A (radix 8) -> pass B (radix 16, in place) -> pass C (radix 16, one row per thread) ->
+//                      partner exchange -> X[k], X[C-k] for the thread's 8 bin pairs
+//   adjoint split:     G = gmag X / |X| -> Zs[k] (own row, q < 8) and Zs[C-k] (the PARTNER row's upper half, handed over in place)
+//   inverse passes:    C (decimation in time, natural out) -> B (conj twiddle, in place) -> A (conj twiddle, window)
+//   overlap-add:       the 4 frames' 4096 windowed samples parked in LDS, every span sample gathers its <= 4 frames; the hop
+//                      that is complete inside the tile is stored plainly, the rest is added atomically (as the n = 1024 kernel)
+// plan(4096) = [win[4096] | wA[256][16] | twA[256][8](re,im) | twB[16][16](re,im) | vk[1025](re,im), padded]
+// ---------------------------------------------------------------------------------------------
+constexpr int kB4096VK = 2052, kB4096QP = 258, kB4096FP = 8 * kB4096QP + 8, kB4096FT = 4;
+constexpr int kB4096LdsFloats = kB4096FT * kB4096FP * 2 + kB4096VK + 512;
+
+__global__ __launch_bounds__(512, 4) void stft_bwd_n4096_mag_kernel(StftBwdParams p) {
+    constexpr int C = 2048, NFFT = 4096, FT = kB4096FT, QP = kB4096QP, FP = kB4096FP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_x = smem;
+    float *s_vk = s_x + FT * FP * 2;
+    float *s_twb = s_vk + kB4096VK;
+    const int t = threadIdx.x;
+    const float *plan = p.plan;
+    const float *g_wa = plan + NFFT, *g_twa = plan + 2 * NFFT, *g_twb = plan + 3 * NFFT, *g_vk = plan + 3 * NFFT + 512;
+    constexpr int SPV = 4;
+    const TileWalk tw = tile_walk(p.total_tiles);
+    if (tw.first >= tw.end) return;
+    const int hop = p.hop;
+    const int span_len = (FT - 1) * hop + NFFT;
+    f32x4 spv[SPV];
+    auto request_span = [&](int tile_) __attribute__((always_inline)) {
+        const int clip_ = tile_ / p.ntile;
+        const float *x_ = p.wav + (size_t)clip_ * p.T;
+        const long long g0 = (long long)(tile_ - clip_ * p.ntile) * FT * hop - p.pad;
+        const int Ti = (int)p.T;
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 512 * j) * 4;
+            if (s4 < span_len) {
+                const long long g = g0 + s4;
+                if (g >= 0 && g + 3 < p.T) {
+                    spv[j] = *reinterpret_cast<const f32x4_u *>(x_ + g);
+                } else {
+                    const int gi = (int)g;
+                    spv[j].x = x_[reflect_idx32(gi, Ti)], spv[j].y = x_[reflect_idx32(gi + 1, Ti)];
+                    spv[j].z = x_[reflect_idx32(gi + 2, Ti)], spv[j].w = x_[reflect_idx32(gi + 3, Ti)];
+                }
+            }
+        });
+    };
+    auto commit_span = [&]() __attribute__((always_inline)) {
+        static_for<0, SPV>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            const int s4 = (t + 512 * j) * 4;
+            if (s4 < span_len) *reinterpret_cast<f32x4 *>(s_x + s4) = spv[j];
+        });
+    };
+    request_span(tw.first);
+    for (int i = t; i < (kB4096VK + 512) / 4; i += 512) {
+        const f32x4 v = i < kB4096VK / 4 ? reinterpret_cast<const f32x4 *>(g_vk)[i] : reinterpret_cast<const f32x4 *>(g_twb)[i - kB4096VK / 4];
+        reinterpret_cast<f32x4 *>(s_vk)[i] = v;
+    }
+    const int ja = t & 255, fa0 = 2 * (t >> 8);
+    const int fc = t & 3, r = t >> 2, rp = (128 - r) & 127;
+    const bool special = (r == 0);
+    float *row_own = s_x + 2 * (fc * FP + (r & 7) * QP + (r >> 3) * 16);
+    float *row_par = s_x + 2 * (fc * FP + (rp & 7) * QP + (rp >> 3) * 16) + 16;
+    const v2f eps2 = v2f{p.mag_eps, 0.f};
+    const long long F = p.F;
+    const int iF = (int)F, Ti = (int)p.T;
+
+    for (int tile = tw.first; tile < tw.end; tile += tw.step) {
+        const int clip = tile / p.ntile;
+        const long long f0 = (long long)(tile - clip * p.ntile) * FT;
+        const bool more = tile + tw.step < tw.end;
+        float *gw = p.gwav + (size_t)clip * p.T;
+        f32x4 wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
+        if (tile != tw.first) __syncthreads();           // the previous tile's gather has read every parked sample
+        commit_span();
+        __syncthreads();
+        // ---- forward pass A
+        v2f z[2][8];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const v2f w = (a & 1) ? pk::hi(wv[a >> 1]) : pk::lo(wv[a >> 1]);
+                z[f][a] = *reinterpret_cast<const v2f *>(s_x + (fa0 + f) * hop + 2 * (ja + 256 * a)) * w;
+            }
+        f32x4 tv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            pk::fft<8>(z[f]);
+            v2f *o = reinterpret_cast<v2f *>(s_x) + (fa0 + f) * FP + ja;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v2f w = (q & 1) ? pk::hi(tv[q >> 1]) : pk::lo(tv[q >> 1]);
+                o[q * QP] = q == 0 ? z[f][0] : pk::cmul(z[f][ct::bitrev(q, 3)], w);
+            }
+        }
+        // the gradient magnitudes of this thread's 16 bins (+ the middle bin for row 0): in flight during pass B
+        const bool fvalid = (f0 + fc) < F;
+        const float *gbase = p.gmag + (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + fc);
+        float gk[8], gc[8], gmid = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            gk[q] = fvalid ? gbase[(size_t)(r + 128 * q) * F] : 0.f;
+            gc[q] = fvalid ? gbase[(size_t)(128 - r + 128 * (15 - q)) * F] : 0.f;
+        }
+        if (special && fvalid) gmid = gbase[(size_t)1024 * F];
+        __syncthreads();
+        // ---- forward pass B (in place)
+        {
+            const int j2 = t & 15;
+            const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2;
+            const int f = 2 * ((t >> 4) & 1) + (t >> 8), qa = (t >> 5) & 7;
+            v2f *base = reinterpret_cast<v2f *>(s_x) + f * FP + qa * QP + j2;
+            v2f y[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) y[b] = base[16 * b];
+            pk::fft<16>(y);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) base[16 * q] = q == 0 ? y[0] : pk::cmul(y[ct::bitrev(q, 4)], twr[16 * q]);
+        }
+        __syncthreads();
+        // ---- forward pass C, partner exchange
+        v2f zr[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row_own + 4 * i);
+            zr[2 * i] = pk::lo(v), zr[2 * i + 1] = pk::hi(v);
+        }
+        pk::fft<16>(zr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v2f a = zr[ct::bitrev(8 + 2 * i, 4)], b = zr[ct::bitrev(9 + 2 * i, 4)];
+            *reinterpret_cast<f32x4 *>(row_own + 16 + 4 * i) = f32x4{a.x, a.y, b.x, b.y};
+        }
+        __syncthreads();
+        v2f pz[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row_par + 4 * i);
+            pz[7 - 2 * i] = pk::lo(v);
+            pz[6 - 2 * i] = pk::hi(v);
+        }
+        if (__builtin_amdgcn_ballot_w64(special) != 0) {
+            static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                const v2f own = zr[ct::bitrev(q == 0 ? 0 : 16 - q, 4)];
+                pz[q] = special ? own : pz[q];
+            });
+        }
+        // ---- X, G = gmag X / |X|, adjoint split: za <- adjoint of Z[k], zb <- adjoint of Z[C - k]
+        auto pair = [&](v2f &a, v2f &b, v2f v, float gkk, float gcc) __attribute__((always_inline)) {
+            v2f xk, xc;
+            rfft_pair_pk(a, b, v, xk, xc);                           // X[k] = xk, X[C-k] = conj(xc)
+            const v2f sk = pk::fma(xk, xk, eps2), sc = pk::fma(xc, xc, eps2);
+            const float rk = fvalid ? gkk * __builtin_amdgcn_rsqf(sk.x + sk.y) : 0.f;   // 0 * inf = NaN for a zero bin, as autograd of sqrt
+            const float rc = fvalid ? gcc * __builtin_amdgcn_rsqf(sc.x + sc.y) : 0.f;
+            const v2f ha = xk * v2f{rk, rk}, hbc = xc * v2f{rc, rc};
+            const v2f s = ha + hbc, d = ha - hbc;
+            const v2f e = pk::cmul_conj(d, v);
+            a = s + e;
+            b = (s - e) * v2f{1.f, -1.f};
+        };
+        v2f midadj = v2f{0.f, 0.f};
+        {
+            v2f ma = zr[ct::bitrev(8, 4)], mb = ma;                   // middle bin C/2 of row 0: Z[8] paired with itself, only X[k] exists
+            v2f xk, xc;
+            const v2f v = *reinterpret_cast<const v2f *>(s_vk + 2 * 1024);
+            rfft_pair_pk(ma, mb, v, xk, xc);
+            const v2f sk = pk::fma(xk, xk, eps2);
+            const float rk = (fvalid && special) ? gmid * __builtin_amdgcn_rsqf(sk.x + sk.y) : 0.f;
+            const v2f ha = xk * v2f{rk, rk};
+            const v2f e = pk::cmul_conj(ha, v);
+            midadj = (ha + e) + (ha - e) * v2f{1.f, -1.f};           // the same value fed both inputs: the adjoints add
+        }
+        static_for<0, 8>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            pair(zr[ct::bitrev(q, 4)], pz[q], *reinterpret_cast<const v2f *>(s_vk + 2 * (r + 128 * q)), gk[q], gc[q]);
+        });
+        // hand Zs[C - k] over: the partner row's upper half, natural order (index 8 + j <- pz[7 - j]); row 0 keeps its own:
+        // index 16 - q <- pz[q] (q >= 1), index 8 <- the middle bin's adjoint, and Z[0] fed both inputs of its pair
+        {
+            v2f up[8];
+            static_for<0, 8>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                const v2f gen = pz[7 - j];
+                const v2f spc = j == 0 ? midadj : pz[8 - (j == 0 ? 1 : j)];
+                up[j] = special ? spc : gen;
+            });
+            if (special) zr[0] = zr[0] + pz[0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(row_par + 4 * i) = f32x4{up[2 * i].x, up[2 * i].y, up[2 * i + 1].x, up[2 * i + 1].y};
+        }
+        __syncthreads();
+        // ---- inverse pass C: adjoint row, q in slot bitrev(q) -> natural order, back into the row
+        {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(row_own + 16 + 4 * i);
+                zr[ct::bitrev(8 + 2 * i, 4)] = pk::lo(v);
+                zr[ct::bitrev(9 + 2 * i, 4)] = pk::hi(v);
+            }
+            pk::fft_dit<16, 1>(zr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(row_own + 4 * i) = f32x4{zr[2 * i].x, zr[2 * i].y, zr[2 * i + 1].x, zr[2 * i + 1].y};
+        }
+        __syncthreads();
+        // ---- inverse pass B (in place): conj twiddle, inverse radix-16 over q
+        {
+            const int j2 = t & 15;
+            const v2f *twr = reinterpret_cast<const v2f *>(s_twb) + j2;
+            const int f = 2 * ((t >> 4) & 1) + (t >> 8), qa = (t >> 5) & 7;
+            v2f *base = reinterpret_cast<v2f *>(s_x) + f * FP + qa * QP + j2;
+            v2f y[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[ct::bitrev(q, 4)] = q == 0 ? base[0] : pk::cmul_conj(base[16 * q], twr[16 * q]);
+            pk::fft_dit<16, 1>(y);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) base[16 * b] = y[b];
+        }
+        __syncthreads();
+        // ---- inverse pass A: conj twiddle, inverse radix-8 over q, window -> the frames' time samples
+        // (window and twiddles of the column re-read from the plan: 32 VGPRs that must not live through the whole tile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wv[i] = reinterpret_cast<const f32x4 *>(g_wa + 16 * ja)[i];
+            tv[i] = reinterpret_cast<const f32x4 *>(g_twa + 16 * ja)[i];
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const v2f *o = reinterpret_cast<const v2f *>(s_x) + (fa0 + f) * FP + ja;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const v2f w = (q & 1) ? pk::hi(tv[q >> 1]) : pk::lo(tv[q >> 1]);
+                z[f][ct::bitrev(q, 3)] = q == 0 ? o[0] : pk::cmul_conj(o[q * QP], w);
+            }
+            pk::fft_dit<8, 1>(z[f]);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const v2f w = (a & 1) ? pk::hi(wv[a >> 1]) : pk::lo(wv[a >> 1]);
+                z[f][a] *= w;
+            }
+        }
+        __syncthreads();                                 // X consumed: the area takes Y[frame][4096]
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) *reinterpret_cast<v2f *>(s_x + (fa0 + f) * NFFT + 2 * (ja + 256 * a)) = z[f][a];
+        __syncthreads();
+        if (more) request_span(tile + tw.step);          // in flight during the gather, committed at the next tile's top
+        // ---- overlap-add by gathering: span sample i sums the frames f with 0 <= i - f hop < n
+        {
+            const int t_start = (int)(f0 * hop - p.pad);
+            const int int_lo = NFFT - hop, int_hi = FT * hop;
+            const int nfr = (int)((F - f0) < FT ? (F - f0) : FT);
+            for (int i = t; i < span_len; i += 512) {
+                float v = 0.f;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const int m = i - f * hop;
+                    if (f < nfr && m >= 0 && m < NFFT) v += s_x[f * NFFT + m];
+                }
+                const int tg = t_start + i;
+                if (i >= int_lo && i < int_hi && tg > p.pad && tg < Ti - 1 - p.pad) {
+                    gw[tg] = v;
+                } else if (v != 0.f) {
+                    int tr = tg < 0 ? -tg : tg;
+                    tr = tr >= Ti ? 2 * (Ti - 1) - tr : tr;
+                    if (tr >= 0 && tr < Ti) unsafeAtomicAdd(gw + tr, v);
+                }
+            }
+        }
+    }   // tile loop
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic fallback (power-of-two n_fft without a tuned decomposition): one workgroup per
 // (clip, frame), radix-2 FFTs in LDS, global atomics.  plan = win[n].
 // ---------------------------------------------------------------------------------------------
@@ -896,6 +1179,20 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
                 return launch_bwd<32, 16>(p, gmag, gre, s);
             case 2048: return launch_bwd<32, 32>(p, gmag, gre, s);
         }
+    }
+    if (n_fft == 4096 && gmag && !gre && hop % 2 == 0 && hop <= 1364 && 4096 % hop == 0 && !getenv("PSND_STFT_GENERIC")) {
+        // magnitude gradient at the config-5 size: the adjoint of stft_fwd_n4096b_kernel (4-frame tiles, two workgroups per CU)
+        const int64_t ntile = (F + kB4096FT - 1) / kB4096FT;
+        if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: too many tiles");
+        p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+        constexpr size_t lds = sizeof(float) * kB4096LdsFloats;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n4096_mag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd(n4096): set LDS size: %s", hipGetErrorString(e));
+        int grid = p.total_tiles < 512 ? p.total_tiles : 512;
+        grid = (grid + 7) & ~7;
+        hipLaunchKernelGGL(stft_bwd_n4096_mag_kernel, dim3(grid), dim3(512), lds, s, p);
+        PSND_CHECK_LAUNCH("stft_bwd(n4096, mag)");
+        return PSND_OK;
     }
     if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_bwd(generic): grid too large");
     p.ntile = 0, p.total_tiles = 0;

@@ -305,7 +305,11 @@ BWD_CASES = [
     (512, 128, None, 0, 2, 3000),         # two pass-1 rounds: direct atomics path
     (256, 64, 200, 1, 3, 1500),
     (2048, 512, None, 0, 1, 6000),
-    (4096, 1024, None, 0, 1, 9000),       # generic path
+    (4096, 1024, None, 0, 1, 9000),       # magnitude gradient: adjoint of the 4-frame n4096 kernel; (re, im): generic path
+    (4096, 1024, None, 0, 3, 44100),      # several tiles per clip, partial last tile, plain-store interior + atomic rest
+    (4096, 1024, 3000, 1, 2, 30000),      # HiFi-GAN framing, short window
+    (4096, 512, None, 0, 1, 20000),       # hop = n / 8: eight frames per sample
+    (4096, 1022, None, 0, 1, 20000),      # hop does not divide n_fft: generic path
     (64, 16, None, 0, 2, 300),            # generic path
     (1024, 256, None, 0, 1, 513),
 ]
