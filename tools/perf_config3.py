@@ -81,6 +81,7 @@ def run(tr, steps=30, warm=8):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-for name, hip in (('hip', True), ('torch', False)):
+LEGS = (('hip', True),) if '--hip-only' in sys.argv else (('hip', True), ('torch', False))
+for name, hip in LEGS:
     ms = run(make(hip))
     print('config 3%s, %-5s: %.2f ms/step = %.1f k audio-s/s' % (' + multi_stft_loss' if MSL else '', name, ms, N * T / SR / ms), flush=True)
