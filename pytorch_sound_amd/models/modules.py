@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 
 TORCH_FORMULATION_ON_GPU = False    # tests only: evaluate the torch formulation on a CUDA tensor (the fp32 yardstick of a parity test)
+ROUND1_PATH = False                 # A/B measurements only: round 1's path (library bmm / GEMMs around the softmax + GroupNorm kernels)
 
 
 def _hip_ok(x: torch.Tensor) -> bool:
@@ -39,7 +40,7 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tens
     """the 1x1 Conv1d projections of modules.py:21-22, 93-95 as what they are - one GEMM over (C_in, N*T), on the exact-fp32
     matrix-core kernel (psnd_linear1x1_*, bias and the following ReLU fused).  CPU tensors (and the tests' fp32 yardstick) keep
     the torch formulation."""
-    if not _hip_ok(x):
+    if not _hip_ok(x) or ROUND1_PATH:
         if not x.is_cuda:
             y = conv(x)
         else:
@@ -77,7 +78,7 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         kvq = _conv1x1(self.linear_kvq, input)
-        if _hip_ok(input) and self.hidden_dim % self.heads == 0 and self.hidden_dim // self.heads <= 64:
+        if _hip_ok(input) and not ROUND1_PATH and self.hidden_dim % self.heads == 0 and self.hidden_dim // self.heads <= 64:
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
             from pytorch_sound_amd import kernels as K
             mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """config 4 shape: PositionalEncoding -> MultiHeadAttention(C=256, H=4) -> PointwiseFeedForward over an 80-mel input projected
-by a 1x1 conv, batch 32, one length bucket (T frames), padding mask; forward + backward.  HIP kernels (GroupNorm(1,C)+residual,
-masked softmax over keys) vs the torch formulation of the same modules on the same GPU."""
+by a 1x1 conv, batch 32, one length bucket (T frames), padding mask; forward + backward, replayed as a hipGraph (GPU time, no
+host launch overhead).  round 2: psnd_linear1x1_* + psnd_mha_* ; round 1: library GEMMs / bmm around the softmax + GroupNorm
+kernels ; torch: the plain torch formulation."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,24 +15,44 @@ pe = M.PositionalEncoding(C, 2048).to(dev)
 mha = M.MultiHeadAttention(C, H, 0.0).to(dev)
 ffn = M.PointwiseFeedForward(C, 0.0).to(dev)
 params = list(proj.parameters()) + list(mha.parameters()) + list(ffn.parameters())
+
+
 def step(x, mask):
-    for p in params: p.grad = None
-    h = pe(proj(x))
+    for p in params:
+        p.grad = None
+    h = pe(M._conv1x1(proj, x))
     h, att = mha(h, mask)
     y = ffn(h)
-    (y.abs().mean() + 1e-3 * att.mean()).backward()
-def timeit(fn, iters=10, warm=3):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(iters): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / iters * 1e3
-hip_ok = M._hip_ok
-for T in (173, 690, 1292):
+    y.abs().mean().backward()
+
+
+def graph_time(x, mask, iters=10):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step(x, mask)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(x, mask)
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+for T in (173, 431, 690, 1292):
     x = torch.randn(N, 80, T, device=dev)
     lens = torch.linspace(0.8 * T, T, N).long()
     mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
-    M._hip_ok = hip_ok
-    t1 = timeit(lambda: step(x, mask))
-    M._hip_ok = lambda t: False
-    t2 = timeit(lambda: step(x, mask))
-    print('T=%4d frames (att %4.0f MB): HIP norm/softmax kernels %.2f ms | torch formulation %.2f ms | x%.2f' % (T, H * N * T * T * 4 / 1e6, t1, t2, t2 / t1), flush=True)
+    res = {}
+    for name, flags in (('round 2', (False, False, True)), ('round 2, no att', (False, False, False)), ('round 1', (True, False, True)), ('torch', (False, True, True))):
+        M.ROUND1_PATH, M.TORCH_FORMULATION_ON_GPU, mha.return_att = flags
+        res[name] = graph_time(x, mask)
+    M.ROUND1_PATH, M.TORCH_FORMULATION_ON_GPU, mha.return_att = False, False, True
+    print('T=%4d frames (att %4.0f MB): ' % (T, H * N * T * T * 4 / 1e6) + ' | '.join('%s %.2f ms' % kv for kv in res.items()), flush=True)
