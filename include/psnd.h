@@ -229,6 +229,8 @@ int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64
 /* ---- dense contractions of models/modules.py on the matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32) --------------------
  * psnd_linear1x1_fwd: y[n][co][t] = sum_ci w[co][ci] x[n][ci][t] + bias[co] (, relu) - the 1x1 Conv1d projections
  *   (modules.py:21-22 linear_kvq / linear, :93-95 the feed-forward pair).  x (N,Cin,T), w (Cout,Cin), y (N,Cout,T) fp32.
+ *   bf16 != 0: both operands are rounded to bf16 while they are staged (v_mfma_f32_32x32x16_bf16, fp32 accumulate, 16x the matrix
+ *   rate) - what the modules select under torch.autocast(bfloat16); 0: exact fp32 products.
  * psnd_linear1x1_bwd: gy' = gy where ymask > 0 (ymask = the relu output y, or NULL); gx = w^T gy' (NULL: skipped),
  *   gw = sum_{n,t} gy' x^T via S = psnd_linear1x1_wgrad_slabs(...) partial slabs gw_part (S*Cout*Cin floats), gbias = sum gy'.
  * psnd_mha_fwd: MultiHeadAttention.scale_dot_att over all heads (modules.py:38-48, 61-79).  kvq (N, 3C, T): rows [0,C) keys,
@@ -237,11 +239,11 @@ int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64
  *   weight, padded queries are zeroed.  out (N, C, T) (heads unfolded); att (H*N, T_key, T_query) or NULL - the scores never
  *   leave the chip otherwise; stats (H*N, T, 2): per query column (max, 1/sum), kept for the backward.
  * psnd_mha_bwd: gkvq (N, 3C, T) from gout (N, C, T) and, optionally, gatt (needs att).  delta (H*N, T) scratch. */
-int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, float *y,
-                       void *stream);
+int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
+                       float *y, void *stream);
 int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T);
 int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                       float *gx, float *gw, float *gw_part, float *gbias, void *stream);
+                       int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
                  void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,

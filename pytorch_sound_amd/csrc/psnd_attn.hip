@@ -172,6 +172,143 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the same strided GEMM with bf16 OPERANDS (fp32 in HBM, rounded to bf16 while they are staged; fp32 accumulate, fp32 out) on
+// v_mfma_f32_32x32x16_bf16 - 16x the matrix rate of the exact-fp32 form.  Chosen by the caller (torch.autocast(bfloat16) around the
+// modules); tolerance = bf16 rounding of both operands (tests: exact against float64 arithmetic on the rounded operands).
+// LDS holds both tiles as [row (m or n)][k] bf16 with an 80-byte pitch (odd multiple of 16 B: conflict-free ds_read_b128 fragments):
+//   k-contiguous source  : a thread converts 8 consecutive k of one row (2 x 16-byte loads) -> one ds_write_b128
+//   row-contiguous source: a thread gathers 8 consecutive k of ONE row with 8 dword loads (lanes along the rows: coalesced) -> one
+//                          ds_write_b128 - no transposing scatter into LDS
+// With 8 MFMAs of 32 cycles per 32-deep k-tile the kernel is bound by the 32 KB of fp32 operands it stages per tile, not by MFMA time.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    const f32x2_v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2_t));
+}
+constexpr int HBK = 32, HP = 40;      // k-tile depth, LDS row pitch (bf16)
+
+// the thread's share of a (128 rows x 32 k) tile as two uint4 (8 bf16 each).  ROW_CONTIG: the 128-direction is contiguous in memory.
+template <bool ROW_CONTIG>
+__device__ __forceinline__ void hgemm_fetch(const float *base, const float *mask, long long s_row, long long s_k, int limrow, int limk,
+                                            int orow, int ok, int tid, uint4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (!ROW_CONTIG) {             // k contiguous: row = tid / 4 + 64 u, k8 = 8 (tid % 4)
+            const int row = orow + (tid >> 2) + 64 * u, k = ok + 8 * (tid & 3);
+            if (row < limrow) {
+                const float *p = base + (long long)row * s_row + k;
+                const float *pm = mask ? mask + (long long)row * s_row + k : nullptr;
+                if (k + 7 < limk && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
+                    const f32x4_t a = reinterpret_cast<const f32x4_t *>(p)[0], b = reinterpret_cast<const f32x4_t *>(p)[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] = a[e], f[4 + e] = b[e];
+                    if (pm) {
+                        const f32x4_t ma = reinterpret_cast<const f32x4_t *>(pm)[0], mb = reinterpret_cast<const f32x4_t *>(pm)[1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = ma[e] > 0.f ? f[e] : 0.f, f[4 + e] = mb[e] > 0.f ? f[4 + e] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (k + e < limk) f[e] = (pm && !(pm[e] > 0.f)) ? 0.f : p[e];
+                }
+            }
+        } else {                                 // rows contiguous: row = tid % 128, k8 = 8 (tid / 128 + 2 u)
+            const int row = orow + (tid & 127), k = ok + 8 * ((tid >> 7) + 2 * u);
+            if (row < limrow) {
+                const float *p = base + (long long)k * s_k + row;
+                const float *pm = mask ? mask + (long long)k * s_k + row : nullptr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k + e < limk) {
+                        const float val = p[(long long)e * s_k];
+                        f[e] = (pm && !(pm[(long long)e * s_k] > 0.f)) ? 0.f : val;
+                    }
+            }
+        }
+        v[u] = make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7]));
+    }
+}
+template <bool ROW_CONTIG>
+__device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, const uint4 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = ROW_CONTIG ? (tid & 127) : (tid >> 2) + 64 * u;
+        const int k = ROW_CONTIG ? 8 * ((tid >> 7) + 2 * u) : 8 * (tid & 3);
+        *reinterpret_cast<uint4 *>(tile + row * HP + k) = v[u];
+    }
+}
+
+template <bool A_MCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM * HP], sB[2][GBN * HP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int z0 = p.zchunk > 0 ? blockIdx.z * p.zchunk : blockIdx.z;
+    const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int nk = (p.K + HBK - 1) / HBK;
+    const int steps = (z1 - z0) * nk;
+    uint4 va[2], vb[2];
+    auto fetch = [&](int it) __attribute__((always_inline)) {
+        const int z = z0 + it / nk, k0 = (it % nk) * HBK;
+        const float *A = p.A + z * p.sAz, *B = p.B + z * p.sBz;
+        const float *am = p.amask ? p.amask + z * p.sAz : nullptr, *bm = p.bmask ? p.bmask + z * p.sBz : nullptr;
+        hgemm_fetch<A_MCONTIG>(A, am, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, va);
+        hgemm_fetch<B_NCONTIG>(B, bm, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, vb);
+    };
+    if (steps > 0) fetch(0);
+    for (int it = 0; it < steps; ++it) {
+        unsigned short *tA = sA[it & 1], *tB = sB[it & 1];
+        hgemm_commit<A_MCONTIG>(tA, tid, va);
+        hgemm_commit<B_NCONTIG>(tB, tid, vb);
+        __syncthreads();
+        if (it + 1 < steps) fetch(it + 1);
+#pragma unroll
+        for (int s = 0; s < HBK / 16; ++s) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8_t *>(tA + (wm * 64 + t * 32 + li) * HP + 16 * s + 8 * kg);
+                b[t] = *reinterpret_cast<const bf16x8_t *>(tB + (wn * 64 + t * 32 + li) * HP + 16 * s + 8 * kg);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+    }
+    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : z0 * p.sCz);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + u * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + t * 32 + rho(r, kg);
+                if (m < p.M && n < p.N) {
+                    float v = acc[t][u][r];
+                    if (p.bias) v += p.bias[m];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    C[(long long)m * p.sCm + n] = v;
+                }
+            }
+        }
+}
+
 // out[i] = sum over slabs of part[s][i]
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *part, int slabs, long long n, float *out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -556,10 +693,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
-static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hipStream_t st, const char *what) {
+static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hipStream_t st, const char *what, bool bf16 = false) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || gz <= 0) return PSND_OK;
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, gz);
     if (grid.y > 65535 || grid.z > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: grid too large", what);
+    if (bf16) {
+        if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p);
+        else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p);
+        else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, p);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e2));
+        return PSND_OK;
+    }
     if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
     else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
@@ -569,8 +715,8 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
     return PSND_OK;
 }
 
-extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, float *y,
-                                  void *stream) {
+extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
+                                  float *y, void *stream) {
     if (!x || !w || !y) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_fwd: N=%lld Cin=%d Cout=%d T=%lld", (long long)N, Cin, Cout, (long long)T);
     GemmParams p = {};
@@ -578,7 +724,7 @@ extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *b
     p.M = Cout, p.N = (int)T, p.K = Cin, p.Z = (int)N;
     p.sAm = Cin, p.sAk = 1, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cin * T, p.sCm = T, p.sCz = (long long)Cout * T;
     p.relu = relu, p.zchunk = 0, p.sCslab = 0;
-    return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd");
+    return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
 extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T) {
@@ -593,7 +739,7 @@ extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int6
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
 extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                  float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
+                                  int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
     if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
     if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
@@ -605,7 +751,7 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask;
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
-        rc = gemm_launch(p, true, true, (int)N, st, "linear1x1_bwd(data)");
+        rc = gemm_launch(p, true, true, (int)N, st, "linear1x1_bwd(data)", bf16 != 0);
         if (rc != PSND_OK) return rc;
     }
     if (gw) {
@@ -615,7 +761,7 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         p.M = Cout, p.N = Cin, p.K = (int)T, p.Z = (int)N;
         p.sAm = T, p.sAk = 1, p.sAz = (long long)Cout * T, p.sBk = 1, p.sBn = T, p.sBz = (long long)Cin * T, p.sCm = Cin, p.sCz = 0;
         p.zchunk = (int)((N + slabs - 1) / slabs), p.sCslab = (long long)Cout * Cin;
-        rc = gemm_launch(p, false, false, (int)slabs, st, "linear1x1_bwd(weight)");
+        rc = gemm_launch(p, false, false, (int)slabs, st, "linear1x1_bwd(weight)", bf16 != 0);
         if (rc != PSND_OK) return rc;
         const long long n = (long long)Cout * Cin;
         hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gw_part, (int)slabs, n, gw);

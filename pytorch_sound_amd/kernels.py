@@ -349,11 +349,12 @@ class SoftmaxKeys(torch.autograd.Function):
 # models/sound.py: PreEmphasis and multi_stft_loss
 # ---------------------------------------------------------------------------------------------
 class Linear1x1(torch.autograd.Function):
-    """y = W x + b per time step (a 1x1 Conv1d, modules.py:21-22, 93-95) on the exact-fp32 matrix-core GEMM (psnd_linear1x1_*),
-    optionally with the ReLU that follows it fused (its backward masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1)."""
+    """y = W x + b per time step (a 1x1 Conv1d, modules.py:21-22, 93-95) on the matrix-core GEMM (psnd_linear1x1_*): exact fp32
+    products, or bf16 operands / fp32 accumulation with `bf16=True`; optionally with the ReLU that follows it fused (its backward
+    masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1); output and gradients fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu):
+    def forward(ctx, x, w, bias, relu, bf16=False):
         _need_cuda(x, 'input')
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
@@ -364,9 +365,9 @@ class Linear1x1(torch.autograd.Function):
         b = None if bias is None else bias.contiguous()
         y = torch.empty((N, Cout, T), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            check(lib().psnd_linear1x1_fwd(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), ptr(y), stream_ptr(x.device)),
+            check(lib().psnd_linear1x1_fwd(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), int(bool(bf16)), ptr(y), stream_ptr(x.device)),
                   'psnd_linear1x1_fwd')
-        ctx.relu, ctx.has_bias, ctx.wshape = bool(relu), bias is not None, tuple(w.shape)
+        ctx.relu, ctx.has_bias, ctx.wshape, ctx.bf16 = bool(relu), bias is not None, tuple(w.shape), bool(bf16)
         ctx.save_for_backward(x, w2, y if relu else None)
         return y
 
@@ -386,9 +387,9 @@ class Linear1x1(torch.autograd.Function):
             slabs = int(lib().psnd_linear1x1_wgrad_slabs(N, Cin, Cout, T))
             part = torch.empty((slabs, Cout, Cin), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, ptr(gx), ptr(gw), ptr(part), ptr(gb),
+            check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), ptr(gw), ptr(part), ptr(gb),
                                            stream_ptr(dev)), 'psnd_linear1x1_bwd')
-        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None
 
 
 class AttentionKVQ(torch.autograd.Function):

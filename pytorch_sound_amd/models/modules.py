@@ -48,7 +48,10 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tens
             y = y if conv.bias is None else y + conv.bias.view(1, -1, 1)
         return F.relu(y) if relu else y
     from pytorch_sound_amd import kernels as K
-    return K.Linear1x1.apply(x, conv.weight, conv.bias, relu)
+    # under torch.autocast(bfloat16) the products take bf16 operands (fp32 accumulation, fp32 activations in memory): 16x the
+    # matrix rate; without autocast they are exact fp32
+    bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    return K.Linear1x1.apply(x.float(), conv.weight, conv.bias, relu, bf16)
 
 
 class MultiHeadAttention(nn.Module):

@@ -165,3 +165,75 @@ def test_config4_block_vs_float64(T, N):
         a = att.view(H, N, T, T)[:, -1]
         L = int(lens[-1])
         assert float(a[:, L:, :].abs().max()) == 0 and float(a[:, :, L:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('N,Cin,Cout,T,relu', [(3, 80, 256, 173, False), (2, 256, 768, 1292, False), (4, 256, 1024, 431, True),
+                                               (2, 1024, 256, 100, False), (1, 16, 48, 10, True), (5, 33, 65, 131, True)])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_linear1x1_exact(N, Cin, Cout, T, relu, bf16):
+    """psnd_linear1x1_fwd / _bwd (the 1x1 Conv1d projections, modules.py:21-22, 93-95), ragged sizes and unaligned rows included,
+    against float64: exact-fp32 form to 2e-6 of max; bf16-operand form against float64 arithmetic on the bf16-ROUNDED operands
+    to 1e-5 of max (fp32 accumulation), and within 2e-2 of the unrounded result."""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 1000 + T)
+    x = torch.randn(N, Cin, T, device=dev, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 1, device=dev) / Cin ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, device=dev, requires_grad=True)
+    g = torch.randn(N, Cout, T, device=dev)
+    y = K.Linear1x1.apply(x, w, b, relu, bf16)
+    (y * g).sum().backward()
+    rnd = (lambda t: t.to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+
+    def ref(round_fn):
+        xd, wd, bd = x.detach().double(), w.detach().double().squeeze(-1), b.detach().double()
+        yd = torch.einsum('oc,nct->not', round_fn(wd), round_fn(xd)) + bd.view(1, -1, 1)
+        gd = g.double()
+        if relu:
+            gd = gd * (yd > 0)
+            yd = yd.clamp_min(0)
+        gx = torch.einsum('oc,not->nct', round_fn(wd), round_fn(gd))
+        gw = torch.einsum('not,nct->oc', round_fn(gd), round_fn(xd))
+        return yd, gx, gw, gd.sum((0, 2))
+
+    yd, gx, gw, gb = ref(rnd)
+    tol = 1e-5 if bf16 else 2e-6
+    close = lambda a, d, rt: float((a.double() - d).abs().max()) <= rt * float(d.abs().max())   # noqa: E731
+    if relu:            # the kernel masks by ITS y > 0: compare away from the kink (|y| tiny flips with the last bit)
+        keep = (yd.abs() > 1e-4) | (yd == 0)
+        assert float(((y.double() - yd) * keep).abs().max()) <= tol * float(yd.abs().max())
+    else:
+        assert close(y, yd, tol)
+        assert close(x.grad, gx, tol) and close(w.grad.squeeze(-1), gw, tol * 4)
+    assert close(b.grad, gb, 1e-4 if relu else tol * 4)
+    if bf16:
+        y32, gx32, gw32, _ = ref(lambda t: t.double())
+        assert close(y, y32, 2e-2) and (relu or (close(x.grad, gx32, 2e-2) and close(w.grad.squeeze(-1), gw32, 2e-2)))
+
+
+def test_block_under_autocast_uses_bf16_products():
+    """torch.autocast(bfloat16) around the modules: the 1x1 projections take bf16 operands (fp32 accumulation and activations),
+    the attention stays exact - outputs and gradients within bf16 tolerance (3e-2 relative Frobenius) of the fp32 run"""
+    from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    mha, ffn = MultiHeadAttention(256, 4, 0.0).to(dev), PointwiseFeedForward(256, 0.0).to(dev)
+    x0 = 0.3 * torch.randn(4, 256, 300, device=dev)
+    mask = (torch.arange(300)[None, :] >= torch.tensor([300, 250, 200, 120])[:, None]).to(dev)
+    g = torch.randn(4, 256, 300, device=dev)
+
+    def run(ac):
+        for m in (mha, ffn):
+            m.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=ac):
+            h, att = mha(x, mask)
+            y = ffn(h)
+        assert y.dtype == torch.float32
+        (y.float() * g).sum().backward()
+        return y.detach().float(), x.grad.clone(), torch.cat([p.grad.flatten() for m in (mha, ffn) for p in m.parameters()])
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):           # relative Frobenius: single elements behind a sharp softmax move more than the average
+        assert float((u - v).norm() / v.norm()) <= 3e-2, float((u - v).norm() / v.norm())
+    assert float((a[0] - b[0]).abs().max()) > 0          # the bf16 path really ran

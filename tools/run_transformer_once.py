@@ -6,6 +6,7 @@ import torch
 from pytorch_sound_amd.models import modules as M
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1292
 want_att = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
+AC = len(sys.argv) > 3 and sys.argv[3] == 'bf16'
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
 C, H, N = 256, 4, 32
@@ -23,9 +24,10 @@ for it in range(6):
     if it == 2:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     for p in params: p.grad = None
-    h = pe(M._conv1x1(proj, x))
-    h, att = mha(h, mask)
-    y = ffn(h)
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=AC):
+        h = pe(M._conv1x1(proj, x))
+        h, att = mha(h, mask)
+        y = ffn(h)
     y.abs().mean().backward()
 torch.cuda.synchronize()
 print('T=%d want_att=%s: %.2f ms per fwd+bwd' % (T, want_att, (time.perf_counter() - t0) / 4 * 1e3))
