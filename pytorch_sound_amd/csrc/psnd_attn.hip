@@ -35,62 +35,72 @@ struct GemmParams {
     int relu;
     int zchunk;                  // > 0: weight-gradient mode - a workgroup sums over zchunk batches (and all of K) into slab blockIdx.z
     long long sCslab;
+    int flatT;                   // > 0 (n-contiguous B only): the columns of all Z batches form ONE axis of Z * flatT columns,
+                                 // column j = (z = j / flatT, t = j % flatT) - no partly filled column tile per batch (T = 173: 68 % -> 98 %)
 };
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GP = 132;   // LDS pitch of both tiles ([k][m] and [k][n], m / n fastest)
 
-// global -> registers: the thread's two float4 of a (128 x 16) tile.  VEC_MINOR: the 128-direction (m or n) is contiguous in memory.
+// where the (up to) four consecutive columns / rows of a thread live when the 128-direction is contiguous in memory
+struct MinorSpan {
+    long long off;       // element offset of the first one (batch offset included in flat mode)
+    int nval;            // how many of the four exist
+    int wrap_at;         // flat mode: elements e >= wrap_at belong to the next batch ...
+    long long wrap_add;  // ... wrap_add elements further on
+};
+__device__ __forceinline__ MinorSpan minor_span(int x, int lim, int flatT, long long sz) {
+    MinorSpan m;
+    m.nval = min(max(lim - x, 0), 4);
+    if (flatT > 0) {
+        const int z = x / flatT, t = x - z * flatT;
+        m.off = z * sz + t, m.wrap_at = flatT - t, m.wrap_add = sz - flatT;
+    } else {
+        m.off = x, m.wrap_at = 4, m.wrap_add = 0;
+    }
+    return m;
+}
+
+// global -> registers: the thread's two float4 of a (128 x 16) tile.  MINOR_CONTIG: the 128-direction (m or n) is contiguous in memory.
+// 16-byte loads need only 4-byte alignment on gfx9 global memory (f32x4_u), so odd row pitches (T = 173) keep the vector path.
 template <bool MINOR_CONTIG>
-__device__ __forceinline__ void gemm_fetch(const float *base, const float *mask, long long s_major128, long long s_k, int lim128, int limk,
-                                           int o128, int ok, int tid, f32x4_t (&v)[2]) {
+__device__ __forceinline__ void gemm_fetch(const float *base, long long s_major128, long long s_k, int lim128, int limk, int o128, int ok, int tid,
+                                           const MinorSpan &ms, f32x4_t (&v)[2]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         f32x4_t r = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MINOR_CONTIG) {            // float4 along the 128-direction: thread -> (k = tid / 32 + 8 u, x4 = tid % 32)
-            const int k = ok + (tid >> 5) + 8 * u, x = o128 + 4 * (tid & 31);
+            const int k = ok + (tid >> 5) + 8 * u;
             if (k < limk) {
-                const float *p = base + (long long)k * s_k + x;
-                const float *pm = mask ? mask + (long long)k * s_k + x : nullptr;
-                if (x + 3 < lim128 && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
-                    r = *reinterpret_cast<const f32x4_t *>(p);                 // one 16-byte load (the common case)
-                    if (pm) {
-                        const f32x4_t m = *reinterpret_cast<const f32x4_t *>(pm);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
-                    }
+                const float *p = base + (long long)k * s_k + ms.off;
+                if (ms.nval == 4 && ms.wrap_at >= 4) {
+                    r = *reinterpret_cast<const f32x4_u *>(p);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (x + e < lim128) {
-                            const float val = p[e];
-                            r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
-                        }
+                        if (e < ms.nval) r[e] = p[e + (e >= ms.wrap_at ? ms.wrap_add : 0)];
                 }
             }
         } else {                                 // float4 along k: thread -> (x = tid / 4 + 64 u, k4 = tid % 4)
             const int x = o128 + (tid >> 2) + 64 * u, k = ok + 4 * (tid & 3);
             if (x < lim128) {
                 const float *p = base + (long long)x * s_major128 + k;
-                const float *pm = mask ? mask + (long long)x * s_major128 + k : nullptr;
-                if (k + 3 < limk && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
-                    r = *reinterpret_cast<const f32x4_t *>(p);
-                    if (pm) {
-                        const f32x4_t m = *reinterpret_cast<const f32x4_t *>(pm);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r[e] = m[e] > 0.f ? r[e] : 0.f;
-                    }
+                if (k + 3 < limk) {
+                    r = *reinterpret_cast<const f32x4_u *>(p);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (k + e < limk) {
-                            const float val = p[e];
-                            r[e] = (pm && !(pm[e] > 0.f)) ? 0.f : val;
-                        }
+                        if (k + e < limk) r[e] = p[e];
                 }
             }
         }
         v[u] = r;
     }
+}
+__device__ __forceinline__ void gemm_apply_mask(f32x4_t (&v)[2], const f32x4_t (&m)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = m[u][e] > 0.f ? v[u][e] : 0.f;
 }
 template <bool MINOR_CONTIG>
 __device__ __forceinline__ void gemm_commit(float *tile, int tid, const f32x4_t (&v)[2]) {
@@ -106,6 +116,36 @@ __device__ __forceinline__ void gemm_commit(float *tile, int tid, const f32x4_t 
     }
 }
 
+// epilogue shared by both GEMM kernels: bias, relu, store (flat mode: column -> (batch, t))
+__device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0) {
+    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
+    const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int n = n0 + wn * 64 + u * 32 + li;
+        if (n >= ncols) continue;
+        long long coff = n;
+        if (p.flatT > 0) {
+            const int z = n / p.flatT;
+            coff = z * p.sCz + (n - z * p.flatT);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + t * 32 + rho(r, half);
+                if (m < p.M) {
+                    float v = acc[t][u][r];
+                    if (p.bias) v += p.bias[m];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    C[(long long)m * p.sCm + coff] = v;
+                }
+            }
+    }
+}
+
+// Pipeline of both kernels: the operands of k-tiles it + 1 and it + 2 are in flight (raw fp32 in registers, two stages) while
+// k-tile it is multiplied out of LDS (two buffers); masks travel with their operand and are applied when it is committed.
 template <bool A_MCONTIG, bool B_NCONTIG>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float sA[2][GBK * GP], sB[2][GBK * GP];
@@ -123,21 +163,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     const int nk = (p.K + GBK - 1) / GBK;
     const int steps = (z1 - z0) * nk;
-    f32x4_t va[2], vb[2];
-    auto fetch = [&](int it) __attribute__((always_inline)) {
-        const int z = z0 + it / nk, k0 = (it % nk) * GBK;
-        const float *A = p.A + z * p.sAz, *B = p.B + z * p.sBz;
-        const float *am = p.amask ? p.amask + z * p.sAz : nullptr, *bm = p.bmask ? p.bmask + z * p.sBz : nullptr;
-        gemm_fetch<A_MCONTIG>(A, am, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, va);
-        gemm_fetch<B_NCONTIG>(B, bm, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, vb);
+    const MinorSpan msA = minor_span(m0 + 4 * (tid & 31), p.M, 0, 0);
+    const MinorSpan msB = minor_span(n0 + 4 * (tid & 31), p.flatT > 0 ? p.Z * p.flatT : p.N, p.flatT, p.sBz);
+    const bool ma = p.amask != nullptr, mb = p.bmask != nullptr;
+    f32x4_t va[2][2], vb[2][2], vam[2][2], vbm[2][2];
+    auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        const int zi = it / nk, k0 = (it - zi * nk) * GBK;
+        const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
+        gemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, msA, va[S]);
+        gemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, msB, vb[S]);
+        if (ma) gemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, msA, vam[S]);
+        if (mb) gemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, msB, vbm[S]);
     };
-    if (steps > 0) fetch(0);
-    for (int it = 0; it < steps; ++it) {
-        float *tA = sA[it & 1], *tB = sB[it & 1];
-        gemm_commit<A_MCONTIG>(tA, tid, va);
-        gemm_commit<B_NCONTIG>(tB, tid, vb);
+    auto body = [&](int it, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        float *tA = sA[S], *tB = sB[S];
+        if (ma) gemm_apply_mask(va[S], vam[S]);
+        if (mb) gemm_apply_mask(vb[S], vbm[S]);
+        gemm_commit<A_MCONTIG>(tA, tid, va[S]);
+        gemm_commit<B_NCONTIG>(tB, tid, vb[S]);
         __syncthreads();
-        if (it + 1 < steps) fetch(it + 1);              // in flight while this tile is multiplied
+        if (it + 2 < steps) fetch(it + 2, sc);
 #pragma unroll
         for (int s = 0; s < GBK / 2; ++s) {
             float a[2], b[2];
@@ -151,31 +198,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
         }
-        // the buffer written two iterations from now is this one: the barrier of the NEXT iteration orders its reads before
+        // buffer S is written again two k-tiles from now: the barrier of the next k-tile orders these reads before that
+    };
+    if (steps > 0) fetch(0, std::integral_constant<int, 0>{});
+    if (steps > 1) fetch(1, std::integral_constant<int, 1>{});
+    for (int it = 0; it < steps; it += 2) {
+        body(it, std::integral_constant<int, 0>{});
+        if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : z0 * p.sCz);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n = n0 + wn * 64 + u * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + t * 32 + rho(r, kk);
-                if (m < p.M && n < p.N) {
-                    float v = acc[t][u][r];
-                    if (p.bias) v += p.bias[m];
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    C[(long long)m * p.sCm + n] = v;
-                }
-            }
-        }
+    gemm_store(p, acc, m0, n0, wm, wn, li, kk, z0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the same strided GEMM with bf16 OPERANDS (fp32 in HBM, rounded to bf16 while they are staged; fp32 accumulate, fp32 out) on
-// v_mfma_f32_32x32x16_bf16 - 16x the matrix rate of the exact-fp32 form.  Chosen by the caller (torch.autocast(bfloat16) around the
-// modules); tolerance = bf16 rounding of both operands (tests: exact against float64 arithmetic on the rounded operands).
+// the same strided GEMM with bf16 OPERANDS (fp32 in HBM, rounded to bf16 when they are committed to LDS; fp32 accumulate, fp32 out)
+// on v_mfma_f32_32x32x16_bf16 - 16x the matrix rate of the exact-fp32 form.  Chosen by the caller (torch.autocast(bfloat16) around
+// the modules); tolerance = bf16 rounding of both operands (tests: exact against float64 arithmetic on the rounded operands).
 // LDS holds both tiles as [row (m or n)][k] bf16 with an 80-byte pitch (odd multiple of 16 B: conflict-free ds_read_b128 fragments):
 //   k-contiguous source  : a thread converts 8 consecutive k of one row (2 x 16-byte loads) -> one ds_write_b128
 //   row-contiguous source: a thread gathers 8 consecutive k of ONE row with 8 dword loads (lanes along the rows: coalesced) -> one
@@ -191,56 +228,51 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
 }
 constexpr int HBK = 32, HP = 40;      // k-tile depth, LDS row pitch (bf16)
 
-// the thread's share of a (128 rows x 32 k) tile as two uint4 (8 bf16 each).  ROW_CONTIG: the 128-direction is contiguous in memory.
+// the thread's share of a (128 rows x 32 k) tile: two runs of 8 consecutive k of one row, raw fp32.  ROW_CONTIG: the 128-direction is
+// contiguous in memory; `rowoff` is then the element offset of the thread's row (batch offset included in flat mode), < 0 = no such row.
 template <bool ROW_CONTIG>
-__device__ __forceinline__ void hgemm_fetch(const float *base, const float *mask, long long s_row, long long s_k, int limrow, int limk,
-                                            int orow, int ok, int tid, uint4 (&v)[2]) {
+__device__ __forceinline__ void hgemm_fetch(const float *base, long long s_row, long long s_k, int limrow, int limk, int orow, int ok, int tid,
+                                            long long rowoff, float (&f)[2][8]) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
         if constexpr (!ROW_CONTIG) {             // k contiguous: row = tid / 4 + 64 u, k8 = 8 (tid % 4)
             const int row = orow + (tid >> 2) + 64 * u, k = ok + 8 * (tid & 3);
             if (row < limrow) {
                 const float *p = base + (long long)row * s_row + k;
-                const float *pm = mask ? mask + (long long)row * s_row + k : nullptr;
-                if (k + 7 < limk && (reinterpret_cast<size_t>(p) & 15) == 0 && (!pm || (reinterpret_cast<size_t>(pm) & 15) == 0)) {
-                    const f32x4_t a = reinterpret_cast<const f32x4_t *>(p)[0], b = reinterpret_cast<const f32x4_t *>(p)[1];
+                if (k + 7 < limk) {
+                    const f32x4_t a = reinterpret_cast<const f32x4_u *>(p)[0], b = reinterpret_cast<const f32x4_u *>(p)[1];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] = a[e], f[4 + e] = b[e];
-                    if (pm) {
-                        const f32x4_t ma = reinterpret_cast<const f32x4_t *>(pm)[0], mb = reinterpret_cast<const f32x4_t *>(pm)[1];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = ma[e] > 0.f ? f[e] : 0.f, f[4 + e] = mb[e] > 0.f ? f[4 + e] : 0.f;
-                    }
+                    for (int e = 0; e < 4; ++e) f[u][e] = a[e], f[u][4 + e] = b[e];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (k + e < limk) f[e] = (pm && !(pm[e] > 0.f)) ? 0.f : p[e];
+                        if (k + e < limk) f[u][e] = p[e];
                 }
             }
         } else {                                 // rows contiguous: row = tid % 128, k8 = 8 (tid / 128 + 2 u)
-            const int row = orow + (tid & 127), k = ok + 8 * ((tid >> 7) + 2 * u);
-            if (row < limrow) {
-                const float *p = base + (long long)k * s_k + row;
-                const float *pm = mask ? mask + (long long)k * s_k + row : nullptr;
+            const int k = ok + 8 * ((tid >> 7) + 2 * u);
+            if (rowoff >= 0) {
+                const float *p = base + (long long)k * s_k + rowoff;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (k + e < limk) {
-                        const float val = p[(long long)e * s_k];
-                        f[e] = (pm && !(pm[(long long)e * s_k] > 0.f)) ? 0.f : val;
-                    }
+                    if (k + e < limk) f[u][e] = p[(long long)e * s_k];
             }
         }
-        v[u] = make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7]));
     }
 }
 template <bool ROW_CONTIG>
-__device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, const uint4 (&v)[2]) {
+__device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, const float (&f)[2][8], const float (&m)[2][8], bool masked) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = (masked && !(m[u][e] > 0.f)) ? 0.f : f[u][e];
         const int row = ROW_CONTIG ? (tid & 127) : (tid >> 2) + 64 * u;
         const int k = ROW_CONTIG ? 8 * ((tid >> 7) + 2 * u) : 8 * (tid & 3);
-        *reinterpret_cast<uint4 *>(tile + row * HP + k) = v[u];
+        *reinterpret_cast<uint4 *>(tile + row * HP + k) =
+            make_uint4(pack2_bf16(g[0], g[1]), pack2_bf16(g[2], g[3]), pack2_bf16(g[4], g[5]), pack2_bf16(g[6], g[7]));
     }
 }
 
@@ -261,21 +293,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     const int nk = (p.K + HBK - 1) / HBK;
     const int steps = (z1 - z0) * nk;
-    uint4 va[2], vb[2];
-    auto fetch = [&](int it) __attribute__((always_inline)) {
-        const int z = z0 + it / nk, k0 = (it % nk) * HBK;
-        const float *A = p.A + z * p.sAz, *B = p.B + z * p.sBz;
-        const float *am = p.amask ? p.amask + z * p.sAz : nullptr, *bm = p.bmask ? p.bmask + z * p.sBz : nullptr;
-        hgemm_fetch<A_MCONTIG>(A, am, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, va);
-        hgemm_fetch<B_NCONTIG>(B, bm, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, vb);
+    long long rowA = -1, rowB = -1;
+    {
+        const int ra = m0 + (tid & 127), rb = n0 + (tid & 127);
+        if (ra < p.M) rowA = ra;
+        if (p.flatT > 0) {
+            if (rb < p.Z * p.flatT) {
+                const int z = rb / p.flatT;
+                rowB = z * p.sBz + (rb - z * p.flatT);
+            }
+        } else if (rb < p.N) {
+            rowB = rb;
+        }
+    }
+    const bool ma = p.amask != nullptr, mb = p.bmask != nullptr;
+    float fa[2][2][8], fb[2][2][8], fam[2][2][8], fbm[2][2][8];
+    auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        const int zi = it / nk, k0 = (it - zi * nk) * HBK;
+        const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
+        hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fa[S]);
+        hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fb[S]);
+        if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fam[S]);
+        if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fbm[S]);
     };
-    if (steps > 0) fetch(0);
-    for (int it = 0; it < steps; ++it) {
-        unsigned short *tA = sA[it & 1], *tB = sB[it & 1];
-        hgemm_commit<A_MCONTIG>(tA, tid, va);
-        hgemm_commit<B_NCONTIG>(tB, tid, vb);
+    auto body = [&](int it, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        unsigned short *tA = sA[S], *tB = sB[S];
+        hgemm_commit<A_MCONTIG>(tA, tid, fa[S], fam[S], ma);
+        hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[S], mb);
         __syncthreads();
-        if (it + 1 < steps) fetch(it + 1);
+        if (it + 2 < steps) fetch(it + 2, sc);
 #pragma unroll
         for (int s = 0; s < HBK / 16; ++s) {
             bf16x8_t a[2], b[2];
@@ -289,24 +337,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[u], acc[t][u], 0, 0, 0);
         }
+    };
+    if (steps > 0) fetch(0, std::integral_constant<int, 0>{});
+    if (steps > 1) fetch(1, std::integral_constant<int, 1>{});
+    for (int it = 0; it < steps; it += 2) {
+        body(it, std::integral_constant<int, 0>{});
+        if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : z0 * p.sCz);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n = n0 + wn * 64 + u * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + t * 32 + rho(r, kg);
-                if (m < p.M && n < p.N) {
-                    float v = acc[t][u][r];
-                    if (p.bias) v += p.bias[m];
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    C[(long long)m * p.sCm + n] = v;
-                }
-            }
-        }
+    gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0);
 }
 
 // out[i] = sum over slabs of part[s][i]
@@ -696,6 +734,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
 static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hipStream_t st, const char *what, bool bf16 = false) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || gz <= 0) return PSND_OK;
     dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, gz);
+    if (p.flatT > 0) {           // one column axis over all batches
+        if (!b_ncontig || p.zchunk > 0 || p.sAz != 0) PSND_FAIL(PSND_E_ARG, "%s: flat columns need a shared A and an n-contiguous B", what);
+        grid.x = (unsigned)(((long long)p.Z * p.flatT + GBN - 1) / GBN), grid.z = 1;
+    }
     if (grid.y > 65535 || grid.z > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: grid too large", what);
     if (bf16) {
         if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p);
@@ -724,6 +766,7 @@ extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *b
     p.M = Cout, p.N = (int)T, p.K = Cin, p.Z = (int)N;
     p.sAm = Cin, p.sAk = 1, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cin * T, p.sCm = T, p.sCz = (long long)Cout * T;
     p.relu = relu, p.zchunk = 0, p.sCslab = 0;
+    p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
     return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
@@ -751,6 +794,7 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask;
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
+        p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
         rc = gemm_launch(p, true, true, (int)N, st, "linear1x1_bwd(data)", bf16 != 0);
         if (rc != PSND_OK) return rc;
     }

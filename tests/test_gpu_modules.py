@@ -168,7 +168,8 @@ def test_config4_block_vs_float64(T, N):
 
 
 @pytest.mark.parametrize('N,Cin,Cout,T,relu', [(3, 80, 256, 173, False), (2, 256, 768, 1292, False), (4, 256, 1024, 431, True),
-                                               (2, 1024, 256, 100, False), (1, 16, 48, 10, True), (5, 33, 65, 131, True)])
+                                               (2, 1024, 256, 100, False), (1, 16, 48, 10, True), (5, 33, 65, 131, True),
+                                               (7, 20, 24, 5, False), (2, 8, 8, 3, False), (3, 64, 128, 129, False), (40, 16, 16, 7, True)])
 @pytest.mark.parametrize('bf16', [False, True])
 def test_linear1x1_exact(N, Cin, Cout, T, relu, bf16):
     """psnd_linear1x1_fwd / _bwd (the 1x1 Conv1d projections, modules.py:21-22, 93-95), ragged sizes and unaligned rows included,
