@@ -169,6 +169,58 @@ def _join_side_at_end_of_backward(dev, side):
 
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
+# ---- batch sections on parallel streams --------------------------------------------------------------------------------------
+# At the config-2 size every conv launch is a latency chain: ~350 workgroups that all start together, wait for their
+# first stage together, pull their weight fragments through the 64 B/clk vector-memory path together and run their epilogues together.
+# The clips of a batch are independent, so a conv chain can be walked as PSND_CL_SECTIONS independent chains over contiguous groups of
+# clips (views of the same CL buffers: no copies), each on its own stream: the chains drift apart and one section's load phase
+# overlaps another's wait / epilogue.  Inside a hipGraph capture the sections are parallel branches (ONE fork and ONE join per chain
+# and direction - the per-conv fork/join of PSND_CL_SIDE_STREAM above is what made that variant lose).
+_SECTION_STREAMS = {}
+# the default (PSND_CL_SECTIONS unset) only splits while nothing else shares the hardware queues with the step: HIP multiplexes streams
+# onto a few hardware queues, and a host->device prefetch stream that lands on the queue of a section's graph branch waits behind its
+# kernels (measured: prefetch_copy step 1.21 -> 2.9 ms in one run of three).  The Trainer switches it off when it starts a prefetch
+# stream or a gradient reducer (whose collectives are a further graph branch - not measurable on a one-GPU box).
+AUTO_SECTIONS = True
+
+
+def _sections(dev, N, rows):
+    """PSND_CL_SECTIONS = n forces n sections; default: 2 for launches of at most 128 row tiles (N * Lp <= 8192 rows, the config-2
+    regime - measured 1.239 -> 1.194 ms per step), 1 for the long HiFi-GAN stages that fill the chip on their own"""
+    import os
+    e = os.environ.get('PSND_CL_SECTIONS', 'auto')
+    n = (2 if rows <= 8192 and AUTO_SECTIONS else 1) if e == 'auto' else int(e)
+    if n <= 1 or N % n != 0 or N // n < 1:
+        return 1, []
+    pool = _SECTION_STREAMS.setdefault(dev.index, [])
+    while len(pool) < n - 1:
+        pool.append(torch.cuda.Stream(device=dev))
+    return n, pool[:n - 1]
+
+
+def _run_sections(dev, nsec, sides, fn):
+    """fn(h) enqueues section h (0 <= h < nsec) on the CURRENT stream; section 0 stays on the caller's stream"""
+    if nsec == 1:
+        fn(0)
+        return
+    main = torch.cuda.current_stream(dev)
+    for sd in sides:
+        sd.wait_stream(main)
+    fn(0)
+    for h, sd in enumerate(sides, 1):
+        with torch.cuda.stream(sd):
+            fn(h)
+    for sd in sides:
+        main.wait_stream(sd)
+
+
+def _sec(t, h, nsec):
+    """clips [h N/nsec, (h+1) N/nsec) of a (N, ...) buffer (a contiguous view), None stays None"""
+    if t is None or nsec == 1:
+        return t
+    n = t.shape[0] // nsec
+    return t[h * n:(h + 1) * n]
+
 
 class FusedConvCL(torch.autograd.Function):
     """y = conv1d(xa; weight-normed w, dilation) + bias (+ res); ya = leaky_relu(y, act_slope).
@@ -452,7 +504,7 @@ class ResBlockCL(torch.autograd.Function):
         _need(xa, torch.bfloat16)
         dev = xa.device
         n = len(dils)
-        steps, saved = [], []
+        steps, saved, plan = [], [], []
         cur_x, cur_xa, pending = x, xa, None
         for i in range(n):
             wv, wg, b = params[3 * i:3 * i + 3]
@@ -477,18 +529,31 @@ class ResBlockCL(torch.autograd.Function):
                                                  stream_ptr(dev)), 'psnd_conv1d_prep')
             last = i == n - 1
             inp, slope, has_res = src, (last_act_slope if last else 0.1), role in ('c2', 'r2')
+            mk = lambda: torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev)   # noqa: E731
             if role == 'c1':                               # activated output only, no residual
-                _, act = _launch_conv(inp, None, None, 1.0, wf, bp, None, None, shape, Ca, Cb, k, -pad, dil, slope, 1.0, False, True)
+                raw, act, res, oslope = None, mk(), None, slope
                 pending = act
             elif role == 'tail':                           # raw output only
-                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, None, None, shape, Ca, Cb, k, -pad, dil, 1.0, 1.0, True, False)
+                raw, act, res, oslope = mk(), None, None, 1.0
                 cur_x, cur_xa = raw, None
             else:                                          # 'head' (no residual) / 'c2' / 'r2': raw + activated output
-                raw, act = _launch_conv(inp, None, None, 1.0, wf, bp, cur_x if has_res else None, None, shape, Ca, Cb, k, -pad, dil,
-                                        slope, 1.0, (not last) or want_raw, True)
+                raw, act, res, oslope = (mk() if (not last) or want_raw else None), mk(), (cur_x if has_res else None), slope
                 cur_x, cur_xa = raw, act
+            plan.append((inp, wf, bp, res, Ca, Cb, k, -pad, dil, oslope, raw, act))
             steps.append((Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, b is not None, role))
             saved += [inp, act if act is not None else inp, wb, v32, g32]
+        nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
+        Nh = shape.N // nsec
+
+        def run(h):
+            st = stream_ptr(dev)
+            for inp, wf, bp, res, Ca, Cb, k, off0, dil, oslope, raw, act in plan:
+                check(lib().psnd_conv1d_cl(ptr(_sec(inp, h, nsec)), None, None, 1.0, ptr(wf), ptr(bp), ptr(_sec(res, h, nsec)), None,
+                                           Nh, shape.Lp, shape.L, shape.HP, Ca, Cb, k, off0, dil, float(oslope), 1.0,
+                                           ptr(_sec(raw, h, nsec)), ptr(_sec(act, h, nsec)), None, st), 'psnd_conv1d_cl')
+
+        with torch.cuda.device(dev):
+            _run_sections(dev, nsec, sides, run)
         ctx.steps, ctx.shape = steps, shape
         ctx.save_for_backward(*saved)
         return cur_x, cur_xa
@@ -505,8 +570,10 @@ class ResBlockCL(torch.autograd.Function):
         grads = [None] * (3 * n)
         descs, keep = [None] * n, []
         res_pending = None
+        nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
+        Nh = shape.N // nsec
+        plan = []                              # launches, walked once per batch section (_run_sections)
         with torch.cuda.device(dev):
-            st = stream_ptr(dev)
             # The gradient a conv receives is  g = g_raw + g_act * leaky'(own activated output).  Only the block's LAST conv gets
             # the two parts from outside and combines them on load; every earlier conv's g is formed in the EPILOGUE of the input-
             # gradient role that produces g_act (mask by the activation, add the residual branch's gradient), so its own backward
@@ -524,9 +591,9 @@ class ResBlockCL(torch.autograd.Function):
                     need_gout = has_res and g_act is not None
                 else:
                     G1, G2, am, need_gout = g_comb, None, None, False
-                S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb, k)
-                gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
-                gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
+                S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
+                gw = torch.empty((nsec * S, k, Cb, Ca), dtype=torch.float32, device=dev)    # slabs of section h: [h S, (h+1) S)
+                gbp = torch.empty((nsec * S, Cb), dtype=torch.float32, device=dev)
                 gb = torch.empty(Cb, dtype=torch.float32, device=dev)
                 gv, gg = torch.empty_like(v32), torch.empty_like(g32)
                 g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
@@ -534,8 +601,7 @@ class ResBlockCL(torch.autograd.Function):
                 if i == 0 and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                     # the chain's input needs no gradient (features): weight gradient only
                     gx = None
-                    check(lib().psnd_conv1d_cl_wgrad(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(inp), shape.N, shape.Lp, Ca, Cb, k,
-                                                     -pad, dil, ptr(gw), ptr(gbp), None, st), 'psnd_conv1d_cl_wgrad')
+                    plan.append(('w', G1, G2, am, slope, inp, Ca, Cb, k, -pad, dil, gw, gbp, S))
                     g_raw = g_act = None
                 else:
                     gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
@@ -548,12 +614,10 @@ class ResBlockCL(torch.autograd.Function):
                         ep_mask, ep_res = inp, g_here
                     else:                                      # 'c2' -> its conv1, 'tail' -> the last conv of the stack
                         ep_mask, ep_res = inp, None
-                    check(lib().psnd_conv1d_cl_bwd(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(wb), ptr(inp), shape.N, shape.Lp,
-                                                   shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), ptr(ep_mask),
-                                                   float(steps[i - 1][7] if i > 0 else 1.0), ptr(ep_res), ptr(gw), ptr(gbp), st),
-                          'psnd_conv1d_cl_bwd')
+                    plan.append(('b', G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask,
+                                 float(steps[i - 1][7] if i > 0 else 1.0), ep_res, gw, gbp, S))
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
-                                       gg.data_ptr(), gb.data_ptr(), S, Cout, Cin, k, Cb, Ca)
+                                       gg.data_ptr(), gb.data_ptr(), nsec * S, Cout, Cin, k, Cb, Ca)
                 keep += [gw, gbp, G1, G2, g_out]
                 grads[3 * i], grads[3 * i + 1] = gv, gg
                 grads[3 * i + 2] = gb[:Cout] if has_bias else None
@@ -567,6 +631,25 @@ class ResBlockCL(torch.autograd.Function):
                     g_raw, g_act = None, gx
                 else:                                          # gradients wrt the block's inputs (x, xa)
                     g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
+
+            def run(h):
+                st = stream_ptr(dev)
+                q = lambda t: ptr(_sec(t, h, nsec))            # noqa: E731
+                for e in plan:
+                    if e[0] == 'w':
+                        _, G1, G2, am, slope, inp, Ca, Cb, k, off0, dil, gw, gbp, S = e
+                        check(lib().psnd_conv1d_cl_wgrad(q(G1), q(G2), q(am), float(slope), q(inp), Nh, shape.Lp, Ca, Cb, k, off0, dil,
+                                                         ptr(gw[h * S:(h + 1) * S]), ptr(gbp[h * S:(h + 1) * S]), None, st),
+                              'psnd_conv1d_cl_wgrad')
+                    else:
+                        _, G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask, ep_slope, ep_res, gw, gbp, S = e
+                        check(lib().psnd_conv1d_cl_bwd(q(G1), q(G2), q(am), float(slope), ptr(wb), q(inp), Nh, shape.Lp, shape.L,
+                                                       shape.HP, Ca, Cb, k, pad, dil, q(gx), q(g_out), q(ep_mask), ep_slope, q(ep_res),
+                                                       ptr(gw[h * S:(h + 1) * S]), ptr(gbp[h * S:(h + 1) * S]), st),
+                              'psnd_conv1d_cl_bwd')
+
+            _run_sections(dev, nsec, sides, run)
+            st = stream_ptr(dev)
             for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
                 chunk = descs[j0:j0 + 32]
                 buf = ctypes.create_string_buffer(b''.join(chunk))

@@ -398,16 +398,22 @@ struct AttnParams {
     float scale;
 };
 
-// cooperative load of a (64 x 32) tile X[dd][t0 + c] of a (.., T)-pitched matrix into LDS [dd][TP]; columns >= T read as zero
+// cooperative load of a (64 x 32) tile X[dd][t0 + c] of a (d x T) matrix into LDS [dd][TP]; elements outside the matrix read as zero
 // in two halves - fetch (global -> registers, issued BEFORE the tile in flight is multiplied) and commit (registers -> LDS, after) -
-// so the load latency hides behind the MFMAs of the current tile
+// so the load latency hides behind the MFMAs of the current tile.  Buffer loads: an out-of-range offset returns 0 without a branch
+// (a conditional load, or a select after the load that the compiler turns into one, costs an exec-mask branch each and cuts the
+// basic block the MFMA chains are scheduled in).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned kOOB = 0x80000000u;
+__device__ __forceinline__ float buf_f32(rsrc_t r, unsigned off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0)); }
+__device__ __forceinline__ rsrc_t head_rsrc(const float *base, int d, long long T) { return make_uniform_rsrc(base, (int)(d * T * 4)); }
 template <int HDP>
-__device__ __forceinline__ void fetch_tile(const float *src, long long T, int d, int t0, int tid, float (&v)[HDP / 8]) {
+__device__ __forceinline__ void fetch_tile(rsrc_t src, long long T, int d, int t0, int tid, float (&v)[HDP / 8]) {
+    const int c = tid & 31, t = t0 + c;
 #pragma unroll
     for (int u = 0; u < HDP / 8; ++u) {
-        const int idx = tid + 256 * u, dd = idx >> 5, c = idx & 31;
-        const int t = t0 + c;
-        v[u] = (t < T && dd < d) ? src[(long long)dd * T + t] : 0.f;
+        const int dd = (tid >> 5) + 8 * u;
+        v[u] = buf_f32(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 4u : kOOB);
     }
 }
 template <int HDP>
@@ -419,17 +425,20 @@ __device__ __forceinline__ void commit_tile(float *dst, int tid, const float (&v
     }
 }
 template <int HDP>
-__device__ __forceinline__ void load_tile(const float *src, long long T, int d, int t0, float *dst, int tid) {
+__device__ __forceinline__ void load_tile(rsrc_t src, long long T, int d, int t0, float *dst, int tid) {
     float v[HDP / 8];
     fetch_tile<HDP>(src, T, d, t0, tid, v);
     commit_tile<HDP>(dst, tid, v);
 }
-// B-operand fragment of a (64 x T) matrix for the wave's 32 columns: f[s] = X[2 s + kk][t0 + li]
+// B-operand fragment of a (d x T) matrix for the wave's 32 columns: f[s] = X[2 s + kk][t0 + li]
 template <int HDP>
-__device__ __forceinline__ void load_frag(const float *src, long long T, int d, int t0, int li, int kk, float (&f)[HDP / 2]) {
+__device__ __forceinline__ void load_frag(rsrc_t src, long long T, int d, int t0, int li, int kk, float (&f)[HDP / 2]) {
     const int t = t0 + li;
 #pragma unroll
-    for (int s = 0; s < HDP / 2; ++s) f[s] = (t < T && 2 * s + kk < d) ? src[(long long)(2 * s + kk) * T + t] : 0.f;
+    for (int s = 0; s < HDP / 2; ++s) {
+        const int dd = 2 * s + kk;
+        f[s] = buf_f32(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 4u : kOOB);
+    }
 }
 // 32-bit word: bit i set <=> key t0 + i is masked (padding) or beyond T
 __device__ __forceinline__ unsigned key_bits(const unsigned char *mrow, int T, int t0, int lane) {
@@ -464,23 +473,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
     float qf[HDP / 2];
     load_frag<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     const int ntile = (p.T + 31) / 32;
+    // Both passes are software-pipelined inside the wave: the score tile of key tile it + 1 is multiplied (a chain of dependent
+    // MFMAs, 64 cycles each, that leaves the VALU idle) WHILE the exponentials of key tile it are evaluated - independent work in
+    // one basic block, so the scheduler can fill the MFMA shadows.  K therefore runs one tile ahead of V in LDS:
+    //   iteration it: barrier | request K(it+2), V(it+1) | S(it+1) from sK[(it+1)&1]  ||  softmax of S(it) | O += V(it) P from
+    //   sV[it&1] | commit K(it+2) -> sK[it&1] (K(it) was consumed in iteration it-1), V(it+1) -> sV[(it+1)&1]
+    float pk[HDP / 8], pv[HDP / 8];
     // ---- pass 1
     float mx = -INFINITY, sum = 0.f;
-    float pk[HDP / 8], pv[HDP / 8];
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+    load_tile<HDP>(Kp, T, p.d, 32, sK[1], tid);
+    __syncthreads();
+    f32x16 s;
+    mma_tile_frag<HDP>(sK[0], qf, li, kk, s);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        if (it + 1 < ntile) fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
+        fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
         const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
-        f32x16 s;
-        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
-        if (it + 1 < ntile) commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
+        f32x16 sn;
+        mma_tile_frag<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);       // past the last tile: zeros, never used
         float tm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -489,13 +507,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             tm = fmaxf(tm, v);
         }
         const float m2 = fmaxf(mx, tm);
-        if (m2 > -INFINITY) {
-            float a = 0.f;
+        const float m2s = m2 > -INFINITY ? m2 : 0.f;               // every key so far padded: all terms exp(-inf - 0) = 0
+        float a = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a += __expf(s[r] - m2);
-            sum = sum * __expf(mx - m2) + a;
-            mx = m2;
-        }
+        for (int r = 0; r < 16; ++r) a += __expf(s[r] - m2s);
+        sum = sum * __expf(mx - m2s) + a;
+        mx = m2;
+        commit_tile<HDP>(sK[it & 1], tid, pk);
+        s = sn;
     }
     {   // the two lane halves hold different key rows of the same query column
         const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
@@ -515,32 +534,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[mt][i] = 0.f;
+    const bool nancol = !(sum > 0.f);            // no unpadded key at all: torch gives NaN for every entry of the column
+    const float mxs = nancol ? 0.f : mx;
     __syncthreads();
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+    load_tile<HDP>(Kp, T, p.d, 32, sK[1], tid);
     load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
+    __syncthreads();
+    mma_tile_frag<HDP>(sK[0], qf, li, kk, s);
+    float *attp = p.att ? p.att + (long long)b * T * T + tq : nullptr;
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        if (it + 1 < ntile) {
-            fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
-            fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
-        }
+        fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+        fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
         const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
-        f32x16 s;
-        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
-        if (it + 1 < ntile) {
-            commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
-            commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
-        }
+        f32x16 sn;
+        mma_tile_frag<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = rho(r, kk);
-            float a = 0.f;
-            if (!((bad >> row) & 1u) && !qpad) a = sum > 0.f ? __expf(s[r] * p.scale - mx) * inv : NAN;
-            else if (!qpad && !(sum > 0.f) && 32 * it + row < p.T) a = NAN;
-            s[r] = a;
-            if (p.att && tq < p.T && 32 * it + row < p.T) p.att[((long long)b * T + 32 * it + row) * T + tq] = a;
+            const float e = __expf(s[r] * p.scale - mxs) * inv;
+            s[r] = ((bad >> rho(r, kk)) & 1u) || qpad ? 0.f : e;
+        }
+        if (__builtin_amdgcn_ballot_w64(nancol && !qpad) != 0) {   // rare, wave-uniform: the NaN semantics stay out of the pipelined block
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (nancol && !qpad) ? (32 * it + rho(r, kk) < p.T ? NAN : 0.f) : s[r];
+        }
+        if (attp && tq < p.T) {
+            float *ap = attp + (long long)(32 * it + 4 * kk) * T;
+            if (32 * it + 32 <= p.T) {           // whole tile: one predicate for all sixteen stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ap[(long long)rho(r, 0) * T] = s[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * it + rho(r, kk) < p.T) ap[(long long)rho(r, 0) * T] = s[r];
+            }
         }
         mma_tile_acc<HDP>(sV[it & 1], s, li, kk, O);
+        commit_tile<HDP>(sK[it & 1], tid, pk);
+        commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
+        s = sn;
     }
     if (tq < p.T) {
         float *op = p.out + ((long long)n * p.C + h * p.d) * T + tq;
@@ -585,8 +618,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
-    const float *Gp = p.gout + ((long long)n * p.C + h * p.d) * T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tk0 = blockIdx.x * 128 + wave * 32, tk = tk0 + li;
     const bool kbad = tk >= p.T || (mrow && mrow[tk]);
@@ -674,8 +708,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kp = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T, *Vp = Kp + (long long)p.C * T, *Qp = Vp + (long long)p.C * T;
-    const float *Gp = p.gout + ((long long)n * p.C + h * p.d) * T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
     float qf[HDP / 2], gf[HDP / 2];

@@ -1043,7 +1043,9 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
     // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
     // second partial wave of workgroups)
-    int64_t target = 192;
+    // launches of at most 4096 rows are batch sections of a config-2 sized chain running side by side with another section
+    // (cl.py _run_sections): 128 -> 1.194 ms per step, 112 -> 1.214, 96 -> 1.269, 144 .. 192 -> 1.52
+    int64_t target = R <= 4096 ? 128 : 192;
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;

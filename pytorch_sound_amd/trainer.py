@@ -353,6 +353,9 @@ class Trainer:
         red = self._reducer
         mode = red.graph_mode() if red is not None and red.active else None
         st['inputs'] = tuple(t.clone() for t in batch)
+        if (red is not None and red.active) or self.prefetch_copy or self.prefetch_prepare:
+            from . import cl
+            cl.AUTO_SECTIONS = False                   # see cl.py: no batch-section branches next to other live streams
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
         while True:
             for p in params:
