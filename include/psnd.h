@@ -154,6 +154,19 @@ int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope
                    int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
                    void *a_eff_out, void *stream);
 int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb, int k);
+/* Two chained 3-tap convs of a residual pair in one launch (csrc/psnd_conv_pair.hip; hifi_gan.py:56-62 `leaky -> conv(d) -> leaky ->
+ * conv(1) -> + x` and the input-gradient chain of the same pair):
+ *      mid = leaky( (conv(A; W1, taps off1 + t*dstep1) + bias1) * (M1 > 0 ? 1 : m1_slope), act1_slope )   -> mid_out (may be NULL)
+ *      out = (conv(mid; W2, taps off2 + t*dstep2) + bias2) * (M2 > 0 ? 1 : m2_slope) + res               -> out_raw, out_act
+ * A, M1, M2, res, mid_out, out_*: CL bf16 (N, Lp, C); W1, W2: the [3][C][C] packs of psnd_conv1d_prep (forward: the [j][co][ci] pack,
+ * input gradient: the [j][ci][co] pack with mirrored taps); bias / masks / res may be NULL; rows outside the clip are written as zero.
+ * Same values as two psnd_conv1d_cl launches (mid is rounded to bf16 in both).  k = 3, C = 128 or 256, tap reach <= 8 - ask
+ * psnd_conv1d_cl_pair_supported (1 / 0) first; PSND_E_UNSUPPORTED otherwise. */
+int psnd_conv1d_cl_pair_supported(int C, int k, int off1, int dstep1, int off2, int dstep2);
+int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const void *M1, float m1_slope, float act1_slope,
+                        void *mid_out, const void *W2, const float *bias2, const void *M2, float m2_slope, const void *res,
+                        int64_t N, int Lp, int L, int HP, int C, int k, int off1, int dstep1, int off2, int dstep2,
+                        float act2_slope, void *out_raw, void *out_act, void *stream);
 /* host-side launch counters of the conv kernels' tile instances: out4 = { forward / input-gradient launches with 64-row
  * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
  * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */

@@ -42,6 +42,8 @@ SIGNATURES = {
     'psnd_mel_bwd': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
     'psnd_logmel_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
     'psnd_conv1d_cl': (_INT, [_P, _P, _P, _F, _P, _P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _F, _P, _P, _P, _P]),
+    'psnd_conv1d_cl_pair_supported': (_INT, [_INT, _INT, _INT, _INT, _INT, _INT]),
+    'psnd_conv1d_cl_pair': (_INT, [_P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _P, _P, _P]),
     'psnd_conv1d_cl_wgrad': (_INT, [_P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd': (_INT, [_P, _P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),

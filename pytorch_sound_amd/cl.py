@@ -214,6 +214,11 @@ def _run_sections(dev, nsec, sides, fn):
         main.wait_stream(sd)
 
 
+def _pair_enabled():
+    import os
+    return os.environ.get('PSND_CL_PAIR', '1') != '0'
+
+
 def _sec(t, h, nsec):
     """clips [h N/nsec, (h+1) N/nsec) of a (N, ...) buffer (a contiguous view), None stays None"""
     if t is None or nsec == 1:
@@ -539,7 +544,13 @@ class ResBlockCL(torch.autograd.Function):
             else:                                          # 'head' (no residual) / 'c2' / 'r2': raw + activated output
                 raw, act, res, oslope = (mk() if (not last) or want_raw else None), mk(), (cur_x if has_res else None), slope
                 cur_x, cur_xa = raw, act
-            plan.append((inp, wf, bp, res, Ca, Cb, k, -pad, dil, oslope, raw, act))
+            if (role == 'c2' and _pair_enabled() and plan and plan[-1][0] == 'conv' and steps[-1][10] == 'c1' and plan[-1][5] == Ca == Cb
+                    and plan[-1][7] == k and lib().psnd_conv1d_cl_pair_supported(Ca, k, plan[-1][8], plan[-1][9], -pad, dil)):
+                # conv1 -> conv2 of a ResBlock1 pair as ONE launch (psnd_conv1d_cl_pair): the first conv's output stays in LDS
+                _, inp1, wf1, bp1, _, _, _, _, off1, dil1, slope1, _, mid = plan.pop()
+                plan.append(('pair', inp1, wf1, bp1, slope1, mid, wf, bp, res, Ca, k, off1, dil1, -pad, dil, oslope, raw, act))
+            else:
+                plan.append(('conv', inp, wf, bp, res, Ca, Cb, k, -pad, dil, oslope, raw, act))
             steps.append((Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, b is not None, role))
             saved += [inp, act if act is not None else inp, wb, v32, g32]
         nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
@@ -547,10 +558,18 @@ class ResBlockCL(torch.autograd.Function):
 
         def run(h):
             st = stream_ptr(dev)
-            for inp, wf, bp, res, Ca, Cb, k, off0, dil, oslope, raw, act in plan:
-                check(lib().psnd_conv1d_cl(ptr(_sec(inp, h, nsec)), None, None, 1.0, ptr(wf), ptr(bp), ptr(_sec(res, h, nsec)), None,
+            q = lambda t: ptr(_sec(t, h, nsec))                # noqa: E731
+            for e in plan:
+                if e[0] == 'pair':
+                    _, inp1, wf1, bp1, slope1, mid, wf2, bp2, res, C, k, off1, dil1, off2, dil2, oslope, raw, act = e
+                    check(lib().psnd_conv1d_cl_pair(q(inp1), ptr(wf1), ptr(bp1), None, 1.0, float(slope1), q(mid), ptr(wf2), ptr(bp2),
+                                                    None, 1.0, q(res), Nh, shape.Lp, shape.L, shape.HP, C, k, off1, dil1, off2, dil2,
+                                                    float(oslope), q(raw), q(act), st), 'psnd_conv1d_cl_pair')
+                    continue
+                _, inp, wf, bp, res, Ca, Cb, k, off0, dil, oslope, raw, act = e
+                check(lib().psnd_conv1d_cl(q(inp), None, None, 1.0, ptr(wf), ptr(bp), q(res), None,
                                            Nh, shape.Lp, shape.L, shape.HP, Ca, Cb, k, off0, dil, float(oslope), 1.0,
-                                           ptr(_sec(raw, h, nsec)), ptr(_sec(act, h, nsec)), None, st), 'psnd_conv1d_cl')
+                                           q(raw), q(act), None, st), 'psnd_conv1d_cl')
 
         with torch.cuda.device(dev):
             _run_sections(dev, nsec, sides, run)

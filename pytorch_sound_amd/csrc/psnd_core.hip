@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 120; }  // 0.1.20: + stream events for in-graph bucket release, conv launch statistics, second-generation n4096 kernel
+extern "C" int psnd_version(void) { return 121; }  // 0.1.21: + psnd_conv1d_cl_pair (two chained convs per launch)
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 

@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
     const int qB = special ? R1 / 2 : R1 - qq;
 
     const int span_len = (FT - 1) * p.hop + NFFT;
-    const bool use_span = (P1R == 1) && (span_len <= 2 * FT * SF);
-    float *span = s.xr;   // aliases the exchange area once every lane has read its inputs
+    // overlap-add inside the tile by gather (phase 2); false = every sample straight to global atomics (round 1's path for the
+    // instances with two pass-1 rounds, n = 512 / 2048, 1.76 / 1.10 ms at the multi_stft_loss shapes)
+    constexpr bool use_span = true;
 
     const TileWalk tw = tile_walk(p.total_tiles);
     for (int tile = tw.first; tile < tw.end; tile += tw.step) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
             const int task = r * 256 + t;
             const int fl = task / L, l = task % L;
             float zr[R1], zi[R1];
-            const float *ixr = s.xr + fl * SF + l, *ixi = s.xi + fl * SF + l;
+            float *ixr = s.xr + fl * SF + l, *ixi = s.xi + fl * SF + l;
             static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
                 zr[q] = ixr[q * L];
@@ -292,58 +293,16 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                 zr[s1_] *= w.z;
                 zi[s1_] *= w.w;
             });
-            const bool fvalid = (f0 + fl) < p.F;
             if (use_span) {
-                // overlap-add by GATHER (no LDS atomics: ds_add_f32 retires ~one lane per 12 cycles on gfx950): every lane
-                // parks its 2*R1 windowed samples as Y[frame][m], then each span sample sums its <= n/hop frames
-                constexpr int YS = NFFT + 4;       // FT * YS floats fit the exchange area (2 * FT * (C + 4))
-                __syncthreads();   // every lane holds its inputs in registers: the exchange area is free
-                {
-                    float *yo = span + fl * YS + 2 * l;
-                    static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
-                        constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
-                        yo[2 * L * a] = zr[sl];
-                        yo[2 * L * a + 1] = zi[sl];
-                    });
-                }
-                __syncthreads();
-                const int int_lo = NFFT - p.hop, int_hi = FT * p.hop;
-                const int nfr = (int)((p.F - f0) < FT ? (p.F - f0) : FT);
-                const unsigned hmagic = 0xffffffffu / (unsigned)p.hop + 1u;
-                for (int i = t; i < span_len; i += 256) {
-                    int f_hi = (int)__umulhi((unsigned)i, hmagic);
-                    if (f_hi > nfr - 1) f_hi = nfr - 1;
-                    const int above = i - NFFT + p.hop;
-                    const int f_lo = above > 0 ? (int)__umulhi((unsigned)above, hmagic) : 0;
-                    float v = 0.f;
-                    for (int f = f_lo; f <= f_hi; ++f) v += span[f * YS + (i - f * p.hop)];
-                    const long long tg = t_start + i;
-                    if constexpr (ISTFT) {
-                        // no reflection: samples outside [0, T) are the trimmed n/2 margins; divide by the envelope
-                        if (tg < 0 || tg >= p.T) continue;
-                        // squared-window envelope from the LDS copy of the window (wt[l][2a+c] = win[2(l + L a) + c] / 2)
-                        const long long tp = tg + p.pad;
-                        long long e_hi = tp < (1ll << 24) ? (long long)__umulhi((unsigned)tp, hmagic) : tp / p.hop;
-                        if (e_hi > p.F - 1) e_hi = p.F - 1;
-                        const long long ab = tp - NFFT + p.hop;
-                        const long long e_lo = ab > 0 ? (ab < (1ll << 24) ? (long long)__umulhi((unsigned)ab, hmagic) : ab / p.hop) : 0;
-                        float env = 0.f;
-                        for (long long f = e_lo; f <= e_hi; ++f) {
-                            const int m = (int)(tp - f * p.hop), h2 = m >> 1;
-                            const float w = 2.f * s.wt[(h2 % L) * ROW + 2 * (h2 / L) + (m & 1)];
-                            env = __builtin_fmaf(w, w, env);
-                        }
-                        v /= env + p.env_eps;
-                        if (i >= int_lo && i < int_hi) gw[tg] = v;
-                        else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
-                    } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {
-                        gw[tg] = v;
-                    } else if (v != 0.f) {
-                        const long long tr = reflect64(tg, p.T);
-                        if (tr >= 0 && tr < p.T) unsafeAtomicAdd(gw + tr, v);
-                    }
-                }
-            } else if (fvalid) {
+                // The lane's 2*R1 windowed samples go back IN PLACE over the 2*R1 exchange words it has just read (no other lane
+                // touches them): sample m = 2 (l + L a) + c of frame fl lands in (c ? xi : xr)[fl * SF + (m >> 1)], i.e. the
+                // exchange area turns into Y[frame][m] without a second buffer or a barrier per pass-1 round.
+                static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
+                    ixr[a * L] = zr[sl];
+                    ixi[a * L] = zi[sl];
+                });
+            } else if ((f0 + fl) < p.F) {
                 const long long tb = (f0 + fl) * p.hop - p.pad + 2 * l;
                 static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = decltype(ac)::value, sl = ct::bitrev(a, RB);
@@ -359,6 +318,50 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
                         if (t1 >= 0 && t1 < p.T) unsafeAtomicAdd(gw + t1, zi[sl]);
                     }
                 });
+            }
+        }
+        if (use_span) {
+            // overlap-add by GATHER (no LDS atomics: ds_add_f32 retires ~one lane per 12 cycles on gfx950): each span sample sums
+            // its <= n/hop frames out of Y
+            __syncthreads();
+            const int int_lo = NFFT - p.hop, int_hi = FT * p.hop;
+            const int nfr = (int)((p.F - f0) < FT ? (p.F - f0) : FT);
+            const unsigned hmagic = 0xffffffffu / (unsigned)p.hop + 1u;
+            for (int i = t; i < span_len; i += 256) {
+                int f_hi = (int)__umulhi((unsigned)i, hmagic);
+                if (f_hi > nfr - 1) f_hi = nfr - 1;
+                const int above = i - NFFT + p.hop;
+                const int f_lo = above > 0 ? (int)__umulhi((unsigned)above, hmagic) : 0;
+                float v = 0.f;
+                for (int f = f_lo; f <= f_hi; ++f) {
+                    const int m = i - f * p.hop;
+                    v += ((m & 1) ? s.xi : s.xr)[f * SF + (m >> 1)];
+                }
+                const long long tg = t_start + i;
+                if constexpr (ISTFT) {
+                    // no reflection: samples outside [0, T) are the trimmed n/2 margins; divide by the envelope
+                    if (tg < 0 || tg >= p.T) continue;
+                    // squared-window envelope from the LDS copy of the window (wt[l][2a+c] = win[2(l + L a) + c] / 2)
+                    const long long tp = tg + p.pad;
+                    long long e_hi = tp < (1ll << 24) ? (long long)__umulhi((unsigned)tp, hmagic) : tp / p.hop;
+                    if (e_hi > p.F - 1) e_hi = p.F - 1;
+                    const long long ab = tp - NFFT + p.hop;
+                    const long long e_lo = ab > 0 ? (ab < (1ll << 24) ? (long long)__umulhi((unsigned)ab, hmagic) : ab / p.hop) : 0;
+                    float env = 0.f;
+                    for (long long f = e_lo; f <= e_hi; ++f) {
+                        const int m = (int)(tp - f * p.hop), h2 = m >> 1;
+                        const float w = 2.f * s.wt[(h2 % L) * ROW + 2 * (h2 / L) + (m & 1)];
+                        env = __builtin_fmaf(w, w, env);
+                    }
+                    v /= env + p.env_eps;
+                    if (i >= int_lo && i < int_hi) gw[tg] = v;
+                    else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
+                } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < p.T - 1 - p.pad) {
+                    gw[tg] = v;
+                } else if (v != 0.f) {
+                    const long long tr = reflect64(tg, p.T);
+                    if (tr >= 0 && tr < p.T) unsafeAtomicAdd(gw + tr, v);
+                }
             }
         }
         __syncthreads();   // exchange / span area is rewritten by the next tile

@@ -92,6 +92,41 @@ def test_separator_cl_matches_torch_path():
         assert relf(p.grad, gref[k]) < 5e-2, k
 
 
+@pytest.mark.parametrize('channels,N,T', [(128, 3, 90), (256, 4, 173), (256, 2, 50)])
+def test_pair_launch_matches_two_launches(channels, N, T, monkeypatch):
+    """psnd_conv1d_cl_pair (conv1 -> conv2 of a ResBlock1 pair in ONE launch, the intermediate tile kept in LDS; dilations 1, 3, 5)
+    against the same chain as two psnd_conv1d_cl launches per pair: the bf16 rounding points are the same, so outputs and every
+    gradient agree to accumulation-order noise (a few bf16 flips): 3e-3 relative Frobenius; and against the fp32 torch path."""
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    dev = torch.device('cuda:0')
+    torch.manual_seed(channels + T)
+    model = build_model('conv_separator_voicebank', {'channels': channels, 'num_blocks': 2}).to(dev)
+    mag = torch.rand(N, 513, T, device=dev) * 4
+    tgt = torch.rand(N, 513, T, device=dev)
+
+    def run(pair):
+        monkeypatch.setenv('PSND_CL_PAIR', '1' if pair else '0')
+        model.zero_grad()
+        m = mag.clone().requires_grad_(True)
+        out = model(m)
+        (out - tgt).abs().mean().backward()
+        return out.detach().clone(), m.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    o1, gm1, g1 = run(True)
+    o0, gm0, g0 = run(False)
+    assert relf(o1, o0) < 3e-3, relf(o1, o0)
+    assert relf(gm1, gm0) < 1e-2, relf(gm1, gm0)
+    for k in g0:
+        assert relf(g1[k], g0[k]) < 1e-2, (k, relf(g1[k], g0[k]))
+    model.zero_grad()
+    x = model.conv_pre(torch.log1p(mag))
+    for b in model.blocks:
+        x = b(x)
+    ref = torch.sigmoid(model.conv_post(F.leaky_relu(x, 0.1))) * mag
+    assert rel(o1, ref) < 2e-2
+
+
 @pytest.mark.parametrize('env', [None, 'PSND_NO_BODY_NODE', 'PSND_NO_BLOCK_STACK', 'PSND_NO_BLOCK_NODE'])
 def test_separator_input_gradient_and_node_granularities(env, monkeypatch):
     """the separator body as one autograd node (default), as head / block-stack / tail nodes, one node per block, one node per conv:
