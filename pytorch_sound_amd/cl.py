@@ -214,6 +214,26 @@ def _run_sections(dev, nsec, sides, fn):
         main.wait_stream(sd)
 
 
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_streams(dev):
+    """side streams of the split backward (PSND_CL_BWD_SPLIT=1, off by default): the input-gradient chain of a conv stack - one
+    psnd_conv1d_cl_pair launch per residual pair - on the caller's stream, the weight gradients (needed only by the optimizer,
+    independent of each other) on PSND_CL_WGRAD_STREAMS parallel streams / graph branches.  Measured on the config-2 step (MI355X,
+    round 2): 1.22 ms with 2 side streams, 1.34 with 3, 1.26 with 4 against 1.13 ms for the paired input-/weight-gradient launches
+    on one stream - the branches overlap for only a fifth of their time (tools/overlap.py) and every kernel runs slower next to
+    another one (wgrad 20 -> 26 us, the masked pair launch 22 us): kept as an A/B switch and for the parity tests."""
+    import os
+    if os.environ.get('PSND_CL_BWD_SPLIT', '0') != '1' or not _pair_enabled() or not AUTO_SECTIONS:
+        return []
+    n = int(os.environ.get('PSND_CL_WGRAD_STREAMS', '3'))
+    pool = _WGRAD_STREAMS.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 def _pair_enabled():
     import os
     return os.environ.get('PSND_CL_PAIR', '1') != '0'
@@ -590,8 +610,12 @@ class ResBlockCL(torch.autograd.Function):
         descs, keep = [None] * n, []
         res_pending = None
         nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
+        wstreams = _wgrad_streams(dev) if shape.N * shape.Lp <= 8192 else []
+        if wstreams:
+            nsec, sides = 1, []                # split backward: whole-batch launches, the concurrency comes from the wgrad streams
         Nh = shape.N // nsec
         plan = []                              # launches, walked once per batch section (_run_sections)
+        skip = -1                              # conv already handled as the first conv of a fused input-gradient pair
         with torch.cuda.device(dev):
             # The gradient a conv receives is  g = g_raw + g_act * leaky'(own activated output).  Only the block's LAST conv gets
             # the two parts from outside and combines them on load; every earlier conv's g is formed in the EPILOGUE of the input-
@@ -599,9 +623,45 @@ class ResBlockCL(torch.autograd.Function):
             # reads ONE plain tensor in both roles - and that tensor also is the gradient handed on along the residual stream.
             g_comb = None                      # combined incoming gradient of conv i (None for the block's last conv)
             res_pending = None                 # pairs: gradient on the residual stream behind the pair being walked
+            def slabs(i, G1, G2, am, inp):
+                Cout, Cin, k, Ca, Cb, dil, pad, slope = steps[i][:8]
+                v32, g32 = saved[5 * i + 3], saved[5 * i + 4]
+                S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
+                gw = torch.empty((nsec * S, k, Cb, Ca), dtype=torch.float32, device=dev)    # slabs of section h: [h S, (h+1) S)
+                gbp = torch.empty((nsec * S, Cb), dtype=torch.float32, device=dev)
+                gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+                gv, gg = torch.empty_like(v32), torch.empty_like(g32)
+                descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
+                                       gg.data_ptr(), gb.data_ptr(), nsec * S, Cout, Cin, k, Cb, Ca)
+                keep.extend([gw, gbp, G1, G2])
+                grads[3 * i], grads[3 * i + 1] = gv, gg
+                grads[3 * i + 2] = gb[:Cout] if steps[i][9] else None
+                return ('w', G1, G2, am, slope, inp, Ca, Cb, k, -pad, dil, gw, gbp, S)
+
             for i in range(n - 1, -1, -1):
+                if i == skip:
+                    continue
                 Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias, role = steps[i]
                 inp, act, wb, v32, g32 = saved[5 * i:5 * i + 5]
+                if (wstreams and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
+                        and steps[i - 1][3] == steps[i - 1][4] == Ca and steps[i - 1][2] == k
+                        and lib().psnd_conv1d_cl_pair_supported(Ca, k, pad, -dil, steps[i - 1][6], -steps[i - 1][5])):
+                    # input gradients of conv2 and conv1 of a residual pair as ONE launch on this stream (psnd_conv1d_cl_pair with
+                    # the transposed packs, mirrored taps and the leaky' masks); their weight gradients go to the side streams
+                    inp1, wb1 = saved[5 * (i - 1)], saved[5 * (i - 1) + 2]
+                    d1, pad1 = steps[i - 1][5], steps[i - 1][6]
+                    G = g_comb
+                    g_h = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)      # gradient wrt conv1's output
+                    gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+                    plan.append(('side',) + slabs(i, G, None, None, inp))                              # ready before the pair launch
+                    plan.append(('pairb', G, wb, inp, float(steps[i - 1][7]), g_h, wb1, inp1, float(steps[i - 2][7]), G, Ca, k,
+                                 pad, -dil, pad1, -d1, gx))
+                    plan.append(('side',) + slabs(i - 1, g_h, None, None, inp1))
+                    keep.extend([g_h, gx])
+                    res_pending = G
+                    g_comb = gx
+                    skip = i - 1
+                    continue
                 if g_comb is None:
                     if g_raw is None and g_act is None:
                         raise _lib.PsndError('CL conv chain backward: no incoming gradient')
@@ -620,7 +680,7 @@ class ResBlockCL(torch.autograd.Function):
                 if i == 0 and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                     # the chain's input needs no gradient (features): weight gradient only
                     gx = None
-                    plan.append(('w', G1, G2, am, slope, inp, Ca, Cb, k, -pad, dil, gw, gbp, S))
+                    plan.append((('side',) if wstreams else ()) + ('w', G1, G2, am, slope, inp, Ca, Cb, k, -pad, dil, gw, gbp, S))
                     g_raw = g_act = None
                 else:
                     gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
@@ -651,10 +711,30 @@ class ResBlockCL(torch.autograd.Function):
                 else:                                          # gradients wrt the block's inputs (x, xa)
                     g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
 
+            used = []
+
             def run(h):
                 st = stream_ptr(dev)
                 q = lambda t: ptr(_sec(t, h, nsec))            # noqa: E731
+                main = torch.cuda.current_stream(dev)
                 for e in plan:
+                    if e[0] == 'side':                         # a weight gradient on the next side stream, behind what is enqueued so far
+                        sd = wstreams[len(used) % len(wstreams)]
+                        used.append(sd)
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        sd.wait_event(ev)
+                        _, _, G1, G2, am, slope, inp, Ca, Cb, k, off0, dil, gw, gbp, S = e
+                        with torch.cuda.stream(sd):
+                            check(lib().psnd_conv1d_cl_wgrad(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(inp), shape.N, shape.Lp, Ca, Cb, k,
+                                                             off0, dil, ptr(gw), ptr(gbp), None, stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
+                        continue
+                    if e[0] == 'pairb':
+                        _, G, wb2, m1, m1s, g_h, wb1, m2, m2s, res, C, k, off1, ds1, off2, ds2, gx = e
+                        check(lib().psnd_conv1d_cl_pair(ptr(G), ptr(wb2), None, ptr(m1), m1s, 1.0, ptr(g_h), ptr(wb1), None, ptr(m2), m2s,
+                                                        ptr(res), shape.N, shape.Lp, shape.L, shape.HP, C, k, off1, ds1, off2, ds2, 1.0,
+                                                        ptr(gx), None, st), 'psnd_conv1d_cl_pair')
+                        continue
                     if e[0] == 'w':
                         _, G1, G2, am, slope, inp, Ca, Cb, k, off0, dil, gw, gbp, S = e
                         check(lib().psnd_conv1d_cl_wgrad(q(G1), q(G2), q(am), float(slope), q(inp), Nh, shape.Lp, Ca, Cb, k, off0, dil,
@@ -668,6 +748,8 @@ class ResBlockCL(torch.autograd.Function):
                               'psnd_conv1d_cl_bwd')
 
             _run_sections(dev, nsec, sides, run)
+            for sd in set(used):
+                torch.cuda.current_stream(dev).wait_stream(sd)
             st = stream_ptr(dev)
             for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
                 chunk = descs[j0:j0 + 32]

@@ -115,6 +115,13 @@ def test_pair_launch_matches_two_launches(channels, N, T, monkeypatch):
 
     o1, gm1, g1 = run(True)
     o0, gm0, g0 = run(False)
+    # the same pair kernel as the input-gradient chain (masks, mirrored taps, transposed packs), weight gradients on side streams
+    monkeypatch.setenv('PSND_CL_BWD_SPLIT', '1')
+    o2, gm2, g2 = run(True)
+    monkeypatch.delenv('PSND_CL_BWD_SPLIT')
+    assert relf(gm2, gm0) < 1e-2, relf(gm2, gm0)
+    for k in g0:
+        assert relf(g2[k], g0[k]) < 1e-2, (k, relf(g2[k], g0[k]))
     assert relf(o1, o0) < 3e-3, relf(o1, o0)
     assert relf(gm1, gm0) < 1e-2, relf(gm1, gm0)
     for k in g0:
