@@ -310,8 +310,8 @@ def _config5_roofline(device, n_fft=4096, hop=1024, clips=32, seconds=30.0, sr=4
 
 def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
     """the kernels that take most of the step (profiles/): one ResBlock conv of the config-2 model (C -> C channels, k = 3, on
-    N x Fr frames) forward (conv_cl_kernel) and backward (conv_bwd_pair_kernel: input gradient + weight-gradient slabs),
-    launched back to back and timed with HIP events; flops = 2 N Fr C C k per GEMM, against the dense bf16 MFMA peak."""
+    N x Fr frames) forward (conv_cl_kernel; two chained convs of a residual pair: conv_pair_kernel) and backward (conv_bwd_pair_kernel:
+    input gradient + weight-gradient slabs), launched back to back and timed with HIP events; flops = 2 N Fr C C k per GEMM, against the dense bf16 MFMA peak."""
     from pytorch_sound_amd import cl
     from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
     HP = 8
@@ -339,8 +339,16 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
         check(lib().psnd_conv1d_cl_bwd(ptr(g1), None, None, 0.1, ptr(w), ptr(x), N, Lp, Fr, HP, C, C, k, dil, dil, ptr(gx), None,
                                        ptr(act), 0.1, ptr(g1), ptr(gw), ptr(gbp), st), 'psnd_conv1d_cl_bwd')
 
+    w2 = (torch.randn(k, C, C, device=device) * 0.05).to(torch.bfloat16)
+    mid = torch.empty_like(x)
+
+    def fwd_pair():
+        # conv(d = 3) -> leaky -> conv(1) -> + x of a residual pair as ONE launch (psnd_conv1d_cl_pair, csrc/psnd_conv_pair.hip)
+        check(lib().psnd_conv1d_cl_pair(ptr(x), ptr(w), ptr(bias), None, 1.0, 0.1, ptr(mid), ptr(w2), ptr(bias), None, 1.0, ptr(x), N, Lp, Fr,
+                                        HP, C, k, -3, 3, -1, 1, 0.1, ptr(out), ptr(act), st), 'psnd_conv1d_cl_pair')
+
     res = {}
-    for name, f, gemms in (('forward', fwd, 1), ('backward_pair', bwd, 2)):
+    for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2)):
         for _ in range(5):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -353,9 +361,10 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
         flops = gemms * 2.0 * N * Fr * C * C * k
         res[name] = {'launch_us': t * 1e6, 'flops_per_launch': flops, 'achieved': flops / t / 1e12, 'frac': flops / t / MFMA_BF16_PEAK}
     return {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK / 1e12, 'dtype': 'bf16 operands, fp32 accumulate',
-            'kernel': 'conv_cl_kernel / conv_bwd_pair_kernel, one 256->256 k=3 conv of the config-2 model (2.2 GFLOP on 3 MB of '
-                      'activations: a latency chain per workgroup, DESIGN.md 4.4)',
-            'achieved': res['forward']['achieved'], 'frac': res['forward']['frac'], **res}
+            'kernel': 'conv_pair_kernel (two chained 256->256 k=3 convs of a residual pair in one launch: forward_pair) / conv_cl_kernel / '
+                      'conv_bwd_pair_kernel (input + weight gradient of one conv) of the config-2 model - 2.2 GFLOP per conv on 3 MB of '
+                      'activations: latency chains per workgroup, DESIGN.md 4.4',
+            'achieved': res['forward_pair']['achieved'], 'frac': res['forward_pair']['frac'], **res}
 
 
 def _event_pair_overhead(device, n=40):

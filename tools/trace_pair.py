@@ -29,7 +29,7 @@ t = t[t[:, 0] > 0]
 ntile = t.shape[0]
 names = ['-> tile in LDS', 'conv 1 loop', 'epilogue 1 + mid out', 'conv 2 loop', 'epilogue 2']
 d_ = t[:, 1:6] - t[:, 0:5]
-print('workgroups', ntile, ' s_memtime ticks (100 MHz -> x ~21-24 core cycles)')
+print('workgroups', ntile, ' s_memtime ticks = shader cycles (wave 0 of every workgroup)')
 for i, n in enumerate(names):
     print('%-24s mean %8.1f  min %8.1f  max %8.1f' % (n, d_[:, i].mean(), d_[:, i].min(), d_[:, i].max()))
 print('epilogue 1: math + LDS writes %.1f, loads issued + barrier %.1f, mid store issue %.1f' % ((t[:, 6] - t[:, 2]).mean(), (t[:, 7] - t[:, 6]).mean(), (t[:, 3] - t[:, 7]).mean()))
