@@ -531,7 +531,7 @@ constexpr int WD = PSND_WD;
 #define PSND_WGRAD_WAVES 2
 #endif
 constexpr int kWgradLdsBytes = 2 * (1 + WKT) * 64 * RS * (int)sizeof(bf16_t);
-__device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
+__device__ __forceinline__ void conv_wgrad_body_v1(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
     const int co0 = bx * 64, ci0 = by * 64;
@@ -690,6 +690,181 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
             if (rr == 0 && co0 + 8 * cg + e < p.Cb) p.gbias[(size_t)split * p.Cb + co0 + 8 * cg + e] = v;
         }
     }
+}
+// ---- round 2: the same reduction on the gfx950 transposing LDS read ---------------------------------------------------------
+// Both MFMA operands of the weight gradient need the REDUCTION dimension (rows) along the fragment, while the tensors are row-major
+// (channels contiguous).  Version 1 above transposes while staging: lane pairs swap halves with DPP and write 4-byte words - 16
+// ds_write_b32 + 32 VALU per thread and chunk - and since a tap is a row shift, i.e. a 2-byte shift along the transposed axis, it stages
+// the activation chunk once PER TAP (3 of its 4 loads, 12 of its 16 writes); its lanes run along the rows, so every load instruction
+// touches 64 cache lines (tools/trace_wgrad.py: 2.5 k cycles per 32-row chunk, 1.0 k of it staging, 1.3 k the fetch issue + 6 MFMAs).
+// Here the chunk goes into LDS AS IT IS ([row][channel], one 16-byte ds_write per 16-byte load, eight consecutive lanes per row = one
+// full line) and `ds_read_b64_tr_b16` hands each lane 4 consecutive ROWS of its channel: two of them make the 8-deep MFMA fragment, and a
+// tap is just another row offset of the same tile (staged once, with the halo rows of its tap group).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+#ifndef PSND_WGRAD_TR
+#define PSND_WGRAD_TR 1
+#endif
+constexpr int WTP = 72;                      // LDS row pitch of the chunk tiles (bf16): 144 B
+constexpr int WXR = 64;                      // rows of the activation tile buffer: 32 + the row span of a tap group (<= 32)
+static_assert(2 * (32 + WXR) * WTP * (int)sizeof(bf16_t) <= kWgradLdsBytes, "the transposing-read tiles fit version 1's LDS");
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t *p0) {   // rows r .. r+3 and r+4 .. r+7 of this lane's channel
+    const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3))) *)(p0));
+    const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3))) *)(p0 + 4 * WTP));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
+#if !PSND_WGRAD_TR
+    conv_wgrad_body_v1(p, bx, by, bz, sT, tblk);
+#else
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
+    const int co0 = bx * 64, ci0 = by * 64;
+    const int ntg = (p.k + WKT - 1) / WKT;               // tap groups: one per workgroup (bz = split * ntg + group)
+    const int split = bz / ntg, tgrp = bz - split * ntg;
+    const long long rs = (long long)split * p.rows_per_split;
+    const long long re = min(rs + p.rows_per_split, p.R);
+    const int rr = tid >> 3, cg = tid & 7;               // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
+    const bool do_bias = (by == 0) && tgrp == 0;
+    const bool comb = p.G2 != nullptr;
+    const bool gok = co0 + 8 * cg < p.Cb, xok = ci0 + 8 * cg < p.Ca;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    PSND_WSTAMP(0);
+    constexpr unsigned OOB = 0xffffffffu;
+    const int g_bytes = (int)((size_t)p.R * p.Cb * sizeof(bf16_t));
+    const int x_bytes = p.up_u > 0 ? (int)((size_t)(p.R / p.up_Lp) * p.up_LpO * p.up_Cr * sizeof(bf16_t)) : (int)((size_t)p.R * p.Ca * sizeof(bf16_t));
+    const bool haveG1 = p.G1 != nullptr;
+    const __amdgpu_buffer_rsrc_t rG1 = make_uniform_rsrc(haveG1 ? p.G1 : p.G2, g_bytes);
+    const __amdgpu_buffer_rsrc_t rG2 = make_uniform_rsrc(comb ? p.G2 : p.G1, g_bytes);
+    const __amdgpu_buffer_rsrc_t rGM = make_uniform_rsrc(comb ? p.GM : p.G1, g_bytes);
+    const __amdgpu_buffer_rsrc_t rX = make_uniform_rsrc(p.xa, x_bytes);
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) __attribute__((always_inline)) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return __builtin_bit_cast(uint4, v);
+    };
+    const int t0 = tgrp * WKT;
+    const int nt = min(WKT, p.k - t0);
+    int lo = p.off0 + t0 * p.dstep, hi = lo;             // row offsets of this group's taps: the activation tile covers [lo, 32 + hi)
+    for (int j = 1; j < nt; ++j) {
+        const int o = p.off0 + (t0 + j) * p.dstep;
+        lo = min(lo, o), hi = max(hi, o);
+    }
+    const int xrows = 32 + hi - lo;                      // <= WXR (the launchers check the dilation)
+    f32x16 acc[WKT];
+#pragma unroll
+    for (int j = 0; j < WKT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    uint4 vg[WD], vg2[WD], vgm[WD], vx[WD][2];
+    // branch-free buffer loads (offset OOB -> zeros), see conv_cl_kernel
+    auto fetch = [&](auto sc, long long r0) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        const long long r = r0 + rr;
+        const unsigned og = (r < re && gok) ? (unsigned)(((size_t)r * p.Cb + co0 + 8 * cg) * sizeof(bf16_t)) : OOB;
+        vg[s] = ld16(rG1, haveG1 ? og : OOB);
+        vg2[s] = ld16(rG2, comb ? og : OOB);
+        vgm[s] = ld16(rGM, comb ? og : OOB);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int xi = rr + 32 * u;
+            const long long rx = r0 + lo + xi;
+            bool ok = xi < xrows && rx >= 0 && rx < p.R && xok;
+            size_t xo = (size_t)rx * p.Ca;
+            if (p.up_u > 0) {                       // uniform
+                const long long hb = ok ? up_row_base(p.up_Lp, p.up_HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, rx) : -1;
+                ok = hb >= 0;
+                xo = (size_t)hb * p.up_Cr;
+            }
+            vx[s][u] = ld16(rX, ok ? (unsigned)((xo + ci0 + 8 * cg) * sizeof(bf16_t)) : OOB);
+        }
+    };
+    auto stage = [&](auto sc, long long r0, bf16_t *sG, bf16_t *sX) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        uint4 g = vg[s];
+        if (comb) {
+            const unsigned *pv = reinterpret_cast<const unsigned *>(&vg[s]), *pg = reinterpret_cast<const unsigned *>(&vg2[s]),
+                           *pm = reinterpret_cast<const unsigned *>(&vgm[s]);
+            unsigned out[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a0 = bf2f((bf16_t)(pv[i] & 0xffff)), a1 = bf2f((bf16_t)(pv[i] >> 16));
+                const float b0 = bf2f((bf16_t)(pg[i] & 0xffff)), b1 = bf2f((bf16_t)(pg[i] >> 16));
+                const float m0 = bf2f((bf16_t)(pm[i] & 0xffff)), m1 = bf2f((bf16_t)(pm[i] >> 16));
+                out[i] = pack_bf16(a0 + b0 * (m0 > 0.f ? 1.f : p.g2_slope), a1 + b1 * (m1 > 0.f ? 1.f : p.g2_slope));
+            }
+            g = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+        if (do_bias) {
+            const unsigned *pg4 = reinterpret_cast<const unsigned *>(&g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[e] += bf2f((bf16_t)((pg4[e >> 1] >> (16 * (e & 1))) & 0xffff));
+            const long long r = r0 + rr;
+            if (p.g_out && r < re && gok) *reinterpret_cast<uint4 *>(p.g_out + (size_t)r * p.Cb + co0 + 8 * cg) = g;
+        }
+        *reinterpret_cast<uint4 *>(sG + rr * WTP + 8 * cg) = g;
+        *reinterpret_cast<uint4 *>(sX + rr * WTP + 8 * cg) = vx[s][0];
+        if (rr + 32 < xrows) *reinterpret_cast<uint4 *>(sX + (rr + 32) * WTP + 8 * cg) = vx[s][1];
+    };
+    // this lane's piece of a transposing read: row (lane & 15) >> 2 of the 4-row block, channels 16 ((lane >> 4) & 1) + 4 (lane & 3) ..
+    const int trow = 8 * kg + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    // whole ring turns: chunks past the row range load and multiply zeros (at most WD - 1 of them)
+    const int nchunk = ((int)((re - rs + 31) / 32) + WD - 1) / WD * WD;
+    static_for<0, WD>([&](auto sc) __attribute__((always_inline)) { fetch(sc, rs + 32ll * decltype(sc)::value); });
+    for (int c = 0; c < nchunk; c += WD) {
+        static_for<0, WD>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+            const int ch = c + s;
+            bf16_t *sG = sT + (ch & 1) * (32 + WXR) * WTP, *sX = sG + 32 * WTP;
+            stage(sc, rs + 32ll * ch, sG, sX);
+            if (ch == 0) PSND_WSTAMP(1);
+            __syncthreads();
+            fetch(sc, rs + 32ll * (ch + WD));
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 a = tr_frag(sG + (16 * kk + trow) * WTP + wm * 32 + tcol);
+#pragma unroll
+                for (int j = 0; j < WKT; ++j)
+                    if (j < nt) {
+                        const int o = p.off0 + (t0 + j) * p.dstep - lo;
+                        const bf16x8 b = tr_frag(sX + (16 * kk + trow + o) * WTP + wn * 32 + tcol);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                    }
+            }
+        });
+    }
+    __syncthreads();
+    PSND_WSTAMP(2);
+    // D[i = co][j = ci]: col = lane & 31 -> ci, rows -> co.  128-B runs per (co, tap): plain stores.
+    const int ci = ci0 + wn * 32 + li;
+    if (ci < p.Ca) {
+#pragma unroll
+        for (int j = 0; j < WKT; ++j)
+            if (j < nt) {
+                float *dst = p.gw + (((size_t)split * p.k + t0 + j) * p.Cb) * p.Ca + ci;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int co = co0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
+                    if (co < p.Cb) dst[(size_t)co * p.Ca] = acc[j][rg];
+                }
+            }
+    }
+    PSND_WSTAMP(3);
+#ifdef PSND_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+    PSND_WSTAMP(4);
+#endif
+    if (do_bias && p.gbias) {                // uniform per workgroup.  A channel group's rows sit in all four waves: through LDS
+        float *sb = reinterpret_cast<float *>(sT);       // [4 waves][64 channels]; the tiles are no longer read (barrier above)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+#pragma unroll
+            for (int m = 32; m >= 8; m >>= 1) v += __shfl_xor(v, m, 64);
+            if ((lane >> 3) == 0) sb[wave * 64 + 8 * cg + e] = v;
+        }
+        __syncthreads();
+        if (tid < 64 && co0 + tid < p.Cb) p.gbias[(size_t)split * p.Cb + co0 + tid] = (sb[tid] + sb[64 + tid]) + (sb[128 + tid] + sb[192 + tid]);
+    }
+#endif
 }
 __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
@@ -1067,6 +1242,8 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
                                     void *g_out, void *stream) {
     if ((!G1 && !G2) || (G2 && !GM) || !xa || !gw_part) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad: null pointer");
     if (Ca % 8 != 0 || Cb % 8 != 0 || k < 1 || k > 16 || N < 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: Ca=%d Cb=%d k=%d", Ca, Cb, k);
+    if ((k < WKT ? k - 1 : WKT - 1) * (dstep < 0 ? -dstep : dstep) > WXR - 32)
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_wgrad: dilation %d: a tap group spans more than %d rows", dstep, WXR - 32);
     if (N == 0) return PSND_OK;
     if ((size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 32)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad: operand larger than 4 GB");
     WgradParams p;
@@ -1098,6 +1275,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
                                   const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
                                   void *stream) {
     static const bool no_pair = getenv("PSND_NO_BWD_PAIR") != nullptr;
+    if (gw_part && (k < WKT ? k - 1 : WKT - 1) * (dil < 0 ? -dil : dil) > WXR - 32)
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_bwd: dilation %d: a tap group spans more than %d rows", dil, WXR - 32);
     int hm = 0;
     for (int j = 0; j < k; ++j) {
         const int o = pad - j * dil;
