@@ -118,7 +118,6 @@ def build_step(device, amp):
 def gpu_bench(args):
     from pytorch_sound_amd import distributed as pdist
     from pytorch_sound_amd import kernels as K
-    from pytorch_sound_amd import cl as cl_mod
     from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
     distributed = pdist.init_from_env('nccl')
     rank, world = pdist.rank(), pdist.world_size()
@@ -191,11 +190,7 @@ def gpu_bench(args):
         tr.prefetch_prepare = False
         tr.prefetch_copy = mode == 'prefetch_copy'
         tr._pre_stream = None
-        # a live copy stream next to the batch-section branches of the step graph can land on a shared hardware queue (cl.py
-        # AUTO_SECTIONS): the prefetch leg runs on a graph captured without sections, as Trainer._capture chooses for it
-        cl_mod.AUTO_SECTIONS = mode != 'prefetch_copy'
-        tr._graphs.clear()
-        for _ in range(tr.graph_warmup + 3):            # eager warm-up steps of the new graph, the capture, two replays
+        for _ in range(3):
             step += 1
             tr.step = step
             tr.train(step)
@@ -213,7 +208,6 @@ def gpu_bench(args):
             d = float(tdt.item())
         h2d[mode] = {'value': world * N * CLIP_SECONDS * args.steps / d, 'ms_per_step': d / args.steps * 1e3}
     tr.prefetch_prepare, tr.prefetch_copy = args.prefetch, False
-    cl_mod.AUTO_SECTIONS = True
     h2d['unit'] = 'audio-s/s'
     h2d['bytes_per_step'] = 2 * N * T * 4
     h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch_copy" = the copy of the next batch on a side stream while the '

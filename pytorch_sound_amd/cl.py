@@ -177,20 +177,21 @@ def _join_side_at_end_of_backward(dev, side):
 # overlaps another's wait / epilogue.  Inside a hipGraph capture the sections are parallel branches (ONE fork and ONE join per chain
 # and direction - the per-conv fork/join of PSND_CL_SIDE_STREAM above is what made that variant lose).
 _SECTION_STREAMS = {}
-# the default (PSND_CL_SECTIONS unset) only splits while nothing else shares the hardware queues with the step: HIP multiplexes streams
-# onto a few hardware queues, and a host->device prefetch stream that lands on the queue of a section's graph branch waits behind its
-# kernels (measured: prefetch_copy step 1.21 -> 2.9 ms in one run of three).  The Trainer switches it off when it starts a prefetch
-# stream or a gradient reducer (whose collectives are a further graph branch - not measurable on a one-GPU box).
+# Extra streams inside the step graph (batch sections when asked for, the split backward's weight-gradient streams) are only used while
+# nothing else shares the hardware queues with the step: HIP multiplexes streams onto a few hardware queues, and a host->device prefetch
+# stream that lands on the queue of such a graph branch waits behind its kernels (measured with two sections: prefetch_copy step 1.21 ->
+# 2.9 ms in one run of three).  The Trainer clears the flag when it starts a prefetch stream or a gradient reducer.
 AUTO_SECTIONS = True
 
 
 def _sections(dev, N, rows):
-    """PSND_CL_SECTIONS = n forces n sections; default: 2 for launches of at most 128 row tiles (N * Lp <= 8192 rows, the config-2
-    regime - measured 1.239 -> 1.194 ms per step), 1 for the long HiFi-GAN stages that fill the chip on their own"""
+    """PSND_CL_SECTIONS = n runs a chain as n batch sections; default 1.  Two sections took the config-2 step from 1.239 to 1.194 ms
+    while the weight-gradient role was a 40 k-cycle chain per launch; with the transposing-read weight gradient (26 k cycles) one and
+    two sections measure the same (1.014 / 1.017 ms), so the simpler graph is the default."""
     import os
     e = os.environ.get('PSND_CL_SECTIONS', 'auto')
-    n = (2 if rows <= 8192 and AUTO_SECTIONS else 1) if e == 'auto' else int(e)
-    if n <= 1 or N % n != 0 or N // n < 1:
+    n = 1 if e == 'auto' else int(e)
+    if n <= 1 or N % n != 0 or N // n < 1 or (e == 'auto' and not AUTO_SECTIONS):
         return 1, []
     pool = _SECTION_STREAMS.setdefault(dev.index, [])
     while len(pool) < n - 1:

@@ -712,6 +712,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t *p0) {   // rows r .. r+3
     const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3))) *)(p0 + 4 * WTP));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+template <bool COMB>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
 #if !PSND_WGRAD_TR
     conv_wgrad_body_v1(p, bx, by, bz, sT, tblk);
@@ -725,7 +726,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
     const long long re = min(rs + p.rows_per_split, p.R);
     const int rr = tid >> 3, cg = tid & 7;               // staging identity: row rr of the chunk, channels 8 cg .. 8 cg + 7
     const bool do_bias = (by == 0) && tgrp == 0;
-    const bool comb = p.G2 != nullptr;
+    constexpr bool comb = COMB;                          // the two extra loads per chunk of the combine are compiled out otherwise
     const bool gok = co0 + 8 * cg < p.Cb, xok = ci0 + 8 * cg < p.Ca;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     PSND_WSTAMP(0);
@@ -749,20 +750,25 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         lo = min(lo, o), hi = max(hi, o);
     }
     const int xrows = 32 + hi - lo;                      // <= WXR (the launchers check the dilation)
+    int toff[WKT];                                       // tile row offset of tap j (taps past nt: tap 0's)
+#pragma unroll
+    for (int j = 0; j < WKT; ++j) toff[j] = p.off0 + (t0 + (j < nt ? j : 0)) * p.dstep - lo;
     f32x16 acc[WKT];
 #pragma unroll
     for (int j = 0; j < WKT; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    uint4 vg[WD], vg2[WD], vgm[WD], vx[WD][2];
+    uint4 vg[WD], vg2[COMB ? WD : 1], vgm[COMB ? WD : 1], vx[WD][2];
     // branch-free buffer loads (offset OOB -> zeros), see conv_cl_kernel
     auto fetch = [&](auto sc, long long r0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         const long long r = r0 + rr;
         const unsigned og = (r < re && gok) ? (unsigned)(((size_t)r * p.Cb + co0 + 8 * cg) * sizeof(bf16_t)) : OOB;
         vg[s] = ld16(rG1, haveG1 ? og : OOB);
-        vg2[s] = ld16(rG2, comb ? og : OOB);
-        vgm[s] = ld16(rGM, comb ? og : OOB);
+        if constexpr (COMB) {
+            vg2[s] = ld16(rG2, og);
+            vgm[s] = ld16(rGM, og);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int xi = rr + 32 * u;
@@ -780,7 +786,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
     auto stage = [&](auto sc, long long r0, bf16_t *sG, bf16_t *sX) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         uint4 g = vg[s];
-        if (comb) {
+        if constexpr (COMB) {
             const unsigned *pv = reinterpret_cast<const unsigned *>(&vg[s]), *pg = reinterpret_cast<const unsigned *>(&vg2[s]),
                            *pm = reinterpret_cast<const unsigned *>(&vgm[s]);
             unsigned out[4];
@@ -814,39 +820,61 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
             constexpr int s = decltype(sc)::value;
             const int ch = c + s;
             bf16_t *sG = sT + (ch & 1) * (32 + WXR) * WTP, *sX = sG + 32 * WTP;
+            if (ch == 4) PSND_WSTAMP(5);
             stage(sc, rs + 32ll * ch, sG, sX);
             if (ch == 0) PSND_WSTAMP(1);
+            if (ch == 4) PSND_WSTAMP(6);
             __syncthreads();
+            if (ch == 4) PSND_WSTAMP(7);
             fetch(sc, rs + 32ll * (ch + WD));
+            // all sixteen transposing reads first, then the six MFMAs, in ONE basic block: taps past nt read tap 0's rows again and
+            // accumulate into registers nobody stores (a branch per tap made every MFMA wait for its own two reads: 6 x ~160 cycles)
+            bf16x8 fa[2], fb[2][WKT];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 a = tr_frag(sG + (16 * kk + trow) * WTP + wm * 32 + tcol);
+                fa[kk] = tr_frag(sG + (16 * kk + trow) * WTP + wm * 32 + tcol);
 #pragma unroll
-                for (int j = 0; j < WKT; ++j)
-                    if (j < nt) {
-                        const int o = p.off0 + (t0 + j) * p.dstep - lo;
-                        const bf16x8 b = tr_frag(sX + (16 * kk + trow + o) * WTP + wn * 32 + tcol);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-                    }
+                for (int j = 0; j < WKT; ++j) fb[kk][j] = tr_frag(sX + (16 * kk + trow + toff[j]) * WTP + wn * 32 + tcol);
             }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < WKT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][j], acc[j], 0, 0, 0);
         });
     }
     __syncthreads();
     PSND_WSTAMP(2);
-    // D[i = co][j = ci]: col = lane & 31 -> ci, rows -> co.  128-B runs per (co, tap): plain stores.
-    const int ci = ci0 + wn * 32 + li;
-    if (ci < p.Ca) {
+    // D[i = co][j = ci]: lane & 31 -> ci, registers -> co.  Through LDS (the chunk tiles are dead), so that a thread stores four consecutive
+    // ci: 12 16-byte stores per thread instead of 48 4-byte ones (the store tail is issue-bound: 3.7 k cycles of 26 k).
+    {
+        constexpr int EP = 68;                                     // fp32 row pitch of the 64 x 64 tile of one tap
+        float *sE = reinterpret_cast<float *>(sT);
+        static_assert(64 * EP * 4 <= kWgradLdsBytes, "one tap's slab tile fits the chunk buffers");
+        const bool vec = (p.Ca % 4 == 0);
 #pragma unroll
         for (int j = 0; j < WKT; ++j)
             if (j < nt) {
-                float *dst = p.gw + (((size_t)split * p.k + t0 + j) * p.Cb) * p.Ca + ci;
+                if (j > 0) __syncthreads();
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int co = co0 + wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg;
-                    if (co < p.Cb) dst[(size_t)co * p.Ca] = acc[j][rg];
+                for (int rg = 0; rg < 16; ++rg) sE[(wm * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg) * EP + wn * 32 + li] = acc[j][rg];
+                __syncthreads();
+                float *dst = p.gw + (((size_t)split * p.k + t0 + j) * p.Cb) * p.Ca;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = tid + 256 * u, row = idx >> 4, c4 = 4 * (idx & 15);
+                    const int co = co0 + row, ci = ci0 + c4;
+                    if (co >= p.Cb || ci >= p.Ca) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(sE + row * EP + c4);
+                    if (vec && ci + 3 < p.Ca) {
+                        *reinterpret_cast<f32x4 *>(dst + (size_t)co * p.Ca + ci) = v;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; q < 4 && ci + q < p.Ca; ++q) dst[(size_t)co * p.Ca + ci + q] = e[q];
+                    }
                 }
             }
     }
+    __syncthreads();                                               // the bias partial sums below re-use the same LDS
     PSND_WSTAMP(3);
 #ifdef PSND_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -868,7 +896,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
 }
 __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    conv_wgrad_body(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn, ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    if (p.G2) conv_wgrad_body<true>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn, ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+    else conv_wgrad_body<false>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem_dyn, ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // The two independent kernels of a conv's backward - weight gradient (partial slabs) and input gradient (with the on-load
@@ -881,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
     const int b = blockIdx.x;
     if (b < nw) {
         const int bx = b % wgx, r = b / wgx;
-        conv_wgrad_body(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
+        conv_wgrad_body<COMBINE>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
         conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT>(pc, c % cgx, c / cgx, smem_dyn, 0);

@@ -26,9 +26,12 @@ e.record(); torch.cuda.synchronize()
 print('wgrad: %.2f us per call (back-to-back)' % (s.elapsed_time(e) / 50 * 1e3))
 os.environ['PSND_TRACE_PTR'] = hex(trace.data_ptr())
 run(); torch.cuda.synchronize()
-tr = trace.cpu().numpy().reshape(nwg, 4, 8)[:, :, :5]
+full = trace.cpu().numpy().reshape(nwg, 4, 8)
+tr = full[:, :, :5]
 ok = (tr != 0).all(axis=(1, 2))
 tr = tr[ok]
+full = full[ok].astype(np.float64)
+print('  chunk 4: stage (incl. the wait for its loads) %.0f, barrier wait %.0f' % ((full[:, :, 6] - full[:, :, 5]).mean(), (full[:, :, 7] - full[:, :, 6]).mean()))
 names = ['entry -> chunk 0 staged', 'row loop', 'atomics issue', 'drain']
 d = np.diff(tr, axis=2).astype(np.float64)
 for i in range(4):
