@@ -1247,9 +1247,10 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
     // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
     // second partial wave of workgroups)
-    // launches of at most 4096 rows are batch sections of a config-2 sized chain running side by side with another section
-    // (cl.py _run_sections): 128 -> 1.194 ms per step, 112 -> 1.214, 96 -> 1.269, 144 .. 192 -> 1.52
-    int64_t target = R <= 4096 ? 128 : 192;
+    // round 2, transposing-read weight gradient (a 22 k-cycle chain at 16 chunks): at the config-2 size (R <= 8192) the paired launch
+    // takes 17.4 us for 128 ... 192 workgroups (the input-gradient role is its bound), so fewer, longer row ranges win through the
+    // slabs the weight-norm backward has to add up: 128 -> 0.972 ms per step, 160 -> 0.980, 192 -> 0.997, 112 -> 0.999, 96 -> 1.05
+    int64_t target = R <= 8192 ? 128 : 192;
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
