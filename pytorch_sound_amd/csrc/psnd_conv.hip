@@ -1247,10 +1247,10 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
     // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
     // second partial wave of workgroups)
-    // round 2, transposing-read weight gradient (a 22 k-cycle chain at 16 chunks): at the config-2 size (R <= 8192) the paired launch
-    // takes 17.4 us for 128 ... 192 workgroups (the input-gradient role is its bound), so fewer, longer row ranges win through the
-    // slabs the weight-norm backward has to add up: 128 -> 0.972 ms per step, 160 -> 0.980, 192 -> 0.997, 112 -> 0.999, 96 -> 1.05
-    int64_t target = R <= 8192 ? 128 : 192;
+    // round 2, transposing-read weight gradient (a 22 k-cycle chain at 16 chunks) next to 128-row input-gradient tiles in the paired
+    // launch, config-2 step: 160 -> 0.952 ms, 192 -> 0.948, 208 -> 0.953, 224 -> 0.962, 256 -> 0.965, 288 -> 1.29 (a second wave of
+    // workgroups), 128 -> 0.979, 96 -> 1.056; config-3 step 5.31 ms with 192 everywhere against 5.46 with 128 for its short stages
+    int64_t target = 192;
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
@@ -1349,7 +1349,9 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
     const char *pe = getenv("PSND_PAIR_MT");
     const int pair_mt = pe ? atoi(pe) : 0;
-    const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : conv_row_tiles(pc.R, Ca);
+    // 128-row input-gradient tiles at every size: half as many workgroups of that role share the CUs with the weight-gradient role
+    // (config-2 launch 17.4 -> 15.5 us with 192 weight-gradient workgroups; no change for the long HiFi-GAN stages, which took them anyway)
+    const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : 2;
     const int bm = 64 * mt;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
     const int nw = wgx * wgy * wgz;
