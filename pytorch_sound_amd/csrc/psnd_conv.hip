@@ -303,8 +303,11 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
                 constexpr int q = decltype(qc)::value, u = s * NCH + q, slot = u % DB;
                 static_for<0, TC>([&](auto tc) __attribute__((always_inline)) {
                     constexpr int tap = q * TC + decltype(tc)::value;
-                    if (tap < KT && tap < p.k) {                             // uniform
-                        const int off = p.off0 + tap * p.dstep + p.hm;
+                    // no run-time test of tap < p.k: a uniform branch per tap cuts the stage into basic blocks and every pair of MFMAs
+                    // then waits for its own two ds_reads (~130 cycles each time).  Taps past k multiply ZERO weight fragments
+                    // (fetch_b: offset OOB) with the last real tap's rows - nothing is added.
+                    if constexpr (tap < KT) {
+                        const int off = p.off0 + (tap < p.k ? tap : p.k - 1) * p.dstep + p.hm;
                         const bf16_t *pa = sA + (wm * 32 * MT + li + off) * RS + 8 * kg;
 #pragma unroll
                         for (int kk = 0; kk < KC / 16; ++kk) {
