@@ -276,7 +276,12 @@ struct EmitPk {
         return o;
     }
     __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+#ifdef PSND_ABLATE_BUILD
+        // A/B builds only (tools/build_variant.sh ablate -DPSND_ABLATE_BUILD, PSND_ABLATE=4: all the arithmetic, no store reaches
+        // memory).  As a RUN-TIME test in the production kernel it put an exec-mask branch in front of every one of the ~34 stores of a
+        // thread: the real split became 34 basic blocks, each waiting for its own twiddle read and square root.
         if constexpr (MAG) if (nostore && o.m > -1.f) return;
+#endif
         if constexpr (MAG) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.m), rmag, voff, soff, PSND_STORE_AUX);
         if constexpr (PHASE) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.ph), rphase, voff, soff, PSND_STORE_AUX);
         if constexpr (REIM) {
