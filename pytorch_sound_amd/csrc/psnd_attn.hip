@@ -185,18 +185,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         gemm_commit<B_NCONTIG>(tB, tid, vb[S]);
         __syncthreads();
         if (it + 2 < steps) fetch(it + 2, sc);
-#pragma unroll
-        for (int s = 0; s < GBK / 2; ++s) {
-            float a[2], b[2];
+        // fragments of k-step s + 1 are read while the four MFMAs of step s run (the compiler left every step waiting for its own reads)
+        float fa[2][2], fb[2][2];
+        auto frag = [&](int s, float (&a)[2], float (&b)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 a[t] = tA[(2 * s + kk) * GP + wm * 64 + t * 32 + li];
                 b[t] = tB[(2 * s + kk) * GP + wn * 64 + t * 32 + li];
             }
+        };
+        frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s = 0; s < GBK / 2; ++s) {
+            if (s + 1 < GBK / 2) frag(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[u], acc[t][u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][t], fb[s & 1][u], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // next step's two ds_read2 first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... under this step's four MFMAs (left alone hipcc sinks the reads
+            __builtin_amdgcn_sched_barrier(0);                      // back next to their use to save two registers)
         }
         // buffer S is written again two k-tiles from now: the barrier of the next k-tile orders these reads before that
     };
