@@ -86,6 +86,38 @@ def _to_buf(kind: str, value):
     return buf
 
 
+
+def _independent_stream(tries: int = 6):
+    """a side stream whose host->device copies really run next to the current stream's kernels.  HIP multiplexes streams onto a
+    few hardware queues; a prefetch stream that lands on the compute stream's queue makes every step wait for the NEXT batch's copy
+    (measured on MI355X: 0.96 ms per step when the queues differ, 2.0-2.9 ms when they coincide - which of the two a fresh stream gets
+    varies from run to run).  So candidates are probed: a copy enqueued behind a busy compute stream must finish before the compute does."""
+    cur = torch.cuda.current_stream()
+    dev = cur.device
+    busy = torch.empty(1 << 26, device=dev)                   # 256 MB: a fill takes ~60 us, 40 of them ~2.5 ms
+    host = torch.empty(1 << 20, dtype=torch.float32).pin_memory()
+    dst = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+    best = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        done_busy, done_copy = torch.cuda.Event(), torch.cuda.Event()
+        for _ in range(40):
+            busy.fill_(1.0)
+        done_busy.record(cur)
+        with torch.cuda.stream(cand):
+            dst.copy_(host, non_blocking=True)
+            done_copy.record(cand)
+        done_copy.synchronize()
+        overlapped = not done_busy.query()                    # the copy is through while the fills are still running
+        torch.cuda.synchronize(dev)
+        if best is None:
+            best = cand
+        if overlapped:
+            return cand
+    return best
+
+
 class Trainer:
 
     def __init__(self, model: nn.Module, optimizer: torch.optim.Optimizer,
@@ -197,7 +229,7 @@ class Trainer:
         if not ((self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available()):
             return self.prepare(*self._next_batch(self.train_dataset))
         if getattr(self, '_pre_stream', None) is None:
-            self._pre_stream = torch.cuda.Stream()
+            self._pre_stream = _independent_stream()
             self._pre = self._stage_train_batch()
         batch, event = self._pre
         if event is None:
