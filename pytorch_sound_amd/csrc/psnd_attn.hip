@@ -454,6 +454,16 @@ __device__ __forceinline__ unsigned key_bits(const unsigned char *mrow, int T, i
     const bool bad = t >= T || (mrow && mrow[t]);
     return (unsigned)__builtin_amdgcn_ballot_w64(bad && lane < 32);
 }
+// The words of ALL key tiles, once per workgroup, in LDS.  Evaluated inside the tile loop the mask byte was a dependent global load
+// per tile whose wait (vmcnt(0)) also waited for the K / V tile just requested for the NEXT iteration - the prefetch never overlapped.
+constexpr int KBITS_MAX = 512;          // tiles a table holds (T <= 16384); beyond that the loop falls back to key_bits
+__device__ __forceinline__ void fill_key_bits(unsigned *tab, const unsigned char *mrow, int T, int ntile, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < ntile && i < KBITS_MAX; i += 4) {
+        const unsigned w = key_bits(mrow, T, 32 * i, lane);
+        if (lane == 0) tab[i] = w;
+    }
+}
 // S tile: acc[i = rows of the LDS tile][j = the fragment's columns] = sum_dd tile[dd][i] * frag[dd][j]
 template <int HDP>
 __device__ __forceinline__ void mma_tile_frag(const float *tile, const float (&frag)[HDP / 2], int li, int kk, f32x16 &acc) {
@@ -478,6 +488,7 @@ __device__ __forceinline__ void mma_tile_acc(const float *tile, const f32x16 &P,
 template <int HDP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
+    __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
@@ -498,13 +509,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     float mx = -INFINITY, sum = 0.f;
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
     load_tile<HDP>(Kp, T, p.d, 32, sK[1], tid);
+    fill_key_bits(s_kb, mrow, p.T, ntile, tid);
     __syncthreads();
     f32x16 s;
     mma_tile_frag<HDP>(sK[0], qf, li, kk, s);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
-        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 sn;
         mma_tile_frag<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);       // past the last tile: zeros, never used
         float tm = -INFINITY;
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         __syncthreads();
         fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
         fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
-        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 sn;
         mma_tile_frag<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
 #pragma unroll
@@ -713,6 +725,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
 template <int HDP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
+    __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
@@ -735,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
     const int ntile = (p.T + 31) / 32;
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
     load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
+    fill_key_bits(s_kb, mrow, p.T, ntile, tid);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         float pk[HDP / 8], pv[HDP / 8];
@@ -742,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
             fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
             fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
         }
-        const unsigned bad = key_bits(mrow, p.T, 32 * it, lane);
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 s, dp;
         mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
         mma_tile_frag<HDP>(sV[it & 1], gf, li, kk, dp);
