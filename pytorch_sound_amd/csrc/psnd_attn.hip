@@ -472,6 +472,27 @@ __device__ __forceinline__ void mma_tile_frag(const float *tile, const float (&f
 #pragma unroll
     for (int s = 0; s < HDP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * s + kk) * TP + li], frag[s], acc, 0, 0, 0);
 }
+// two score-type tiles at once (S and dP of the backward kernels): acc0 = tile0^T frag0, acc1 = tile1^T frag1.  The A operands are read
+// from LDS TWO k-steps ahead of the MFMAs that use them and the order is pinned - left alone hipcc reads each operand right in front
+// of its MFMA and the pair waits ~100 cycles for it, 32 times per tile.
+template <int HDP>
+__device__ __forceinline__ void mma_tile_frag2(const float *tile0, const float (&frag0)[HDP / 2], const float *tile1, const float (&frag1)[HDP / 2],
+                                               int li, int kk, f32x16 &acc0, f32x16 &acc1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0.f, acc1[i] = 0.f;
+    constexpr int NS = HDP / 2;
+    float a0[3], a1[3];
+    a0[0] = tile0[kk * TP + li], a1[0] = tile1[kk * TP + li];
+    a0[1] = tile0[(2 + kk) * TP + li], a1[1] = tile1[(2 + kk) * TP + li];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS) a0[(s + 2) % 3] = tile0[(2 * (s + 2) + kk) * TP + li], a1[(s + 2) % 3] = tile1[(2 * (s + 2) + kk) * TP + li];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s % 3], frag0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s % 3], frag1[s], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+}
 // O[dd][j] += sum over the tile's 32 columns c of tile[dd][c] * P[c][j], P in accumulator layout (register s <-> row rho(s, kk))
 template <int HDP>
 __device__ __forceinline__ void mma_tile_acc(const float *tile, const f32x16 &P, int li, int kk, f32x16 (&O)[HDP / 32]) {
@@ -679,8 +700,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
         }
         const float *tQ = sQ[it & 1], *tG = sG[it & 1], *tS = sSt[it & 1];
         f32x16 s, dp;
-        mma_tile_frag<HDP>(tQ, kf, li, kk, s);            // rows: queries of the tile, column: this lane's key
-        mma_tile_frag<HDP>(tG, vf, li, kk, dp);
+        mma_tile_frag2<HDP>(tQ, kf, tG, vf, li, kk, s, dp);     // rows: queries of the tile, column: this lane's key
         if (it + 1 < ntile) {
             commit_tile<HDP>(sQ[(it + 1) & 1], tid, pq);
             commit_tile<HDP>(sG[(it + 1) & 1], tid, pg);
@@ -758,8 +778,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
         }
         const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 s, dp;
-        mma_tile_frag<HDP>(sK[it & 1], qf, li, kk, s);
-        mma_tile_frag<HDP>(sV[it & 1], gf, li, kk, dp);
+        mma_tile_frag2<HDP>(sK[it & 1], qf, sV[it & 1], gf, li, kk, s, dp);
         if (it + 1 < ntile) {
             commit_tile<HDP>(sK[(it + 1) & 1], tid, pk);
             commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
