@@ -71,11 +71,22 @@ def build_step(device, amp):
         from pytorch_sound_amd import kernels as K
         fe = LogMelSpectrogram(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX).to(device)
 
-        def magnitude(w):
-            return fe.stft.magnitude(w)
+        feat = {}                                                   # persistent feature buffers (Trainer.static_prepare)
 
-        def logmel_of_mag(m):
-            return K.MelLog.apply(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+        def magnitude(w):
+            n, t = w.shape
+            key = ('mag', n, t)
+            if key not in feat:
+                feat[key] = torch.empty((n, N_FFT // 2 + 1, K.frame_count(t, N_FFT, HOP)), dtype=torch.float32, device=w.device)
+            return K.stft_forward(w, N_FFT, HOP, fe.stft._plan(w.device), K.FRAMING_CENTER, 0.0, out_mag=feat[key])['mag']
+
+        def logmel_of_mag(m, static=False):
+            if not static:
+                return K.MelLog.apply(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+            key = ('mel', m.shape[0], m.shape[2])
+            if key not in feat:
+                feat[key] = torch.empty((m.shape[0], N_MEL, m.shape[2]), dtype=torch.float32, device=m.device)
+            return K.mel_forward(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db, out=feat[key])[0]
 
         l1 = K.l1_loss                                              # F.l1_loss as psnd_l1_loss_fwd / _bwd
     else:
@@ -85,19 +96,21 @@ def build_step(device, amp):
         def magnitude(w):
             return fe.stft.transform(w)[0]
 
-        def logmel_of_mag(m):
+        def logmel_of_mag(m, static=False):
             return fe.mel_of_mag(m)
 
         l1 = F.l1_loss
 
     class StepTrainer(Trainer):
+        static_prepare = gpu          # the features are written into persistent buffers: the step graph reads them in place
+
         def prepare(self, both):
             # feature extraction of the batch (no parameters, no gradient): eager, ahead of the captured graph
             with torch.no_grad():
                 n = both.shape[0] // 2
                 mag = magnitude(both)                             # mixture and reference clips: ONE STFT launch (2 x batch clips)
                 mag_mix, mag_ref = mag[:n], mag[n:]
-                mel_ref = logmel_of_mag(mag_ref)
+                mel_ref = logmel_of_mag(mag_ref, static=True)
             return mag_mix, mag_ref, mel_ref
 
         def forward(self, mag_mix, mag_ref, mel_ref, is_logging=False):

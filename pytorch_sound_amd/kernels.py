@@ -45,8 +45,9 @@ def frame_count(T, n_fft, hop, framing=FRAMING_CENTER):
 
 
 def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
-                 want_mag=True, want_phase=False, want_reim=False):
-    """wav (N,T) fp32 cuda -> dict of requested (N,K,F) tensors."""
+                 want_mag=True, want_phase=False, want_reim=False, out_mag=None):
+    """wav (N,T) fp32 cuda -> dict of requested (N,K,F) tensors.  out_mag: a caller-owned (N,K,F) fp32 tensor the magnitude is written
+    into (feature extraction into persistent buffers, Trainer.static_prepare)."""
     _need_cuda(wav, 'wav')
     if wav.dim() != 2:
         raise _lib.PsndError('wav must be (N, T), got %s' % (tuple(wav.shape),))
@@ -57,7 +58,10 @@ def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
     F = frame_count(T, n_fft, hop, framing)
     K = n_fft // 2 + 1
     mk = lambda: torch.empty((N, K, F), dtype=torch.float32, device=wav.device)  # noqa: E731
-    mag = mk() if want_mag else None
+    if out_mag is not None and (not want_mag or tuple(out_mag.shape) != (N, K, F) or out_mag.dtype != torch.float32
+                                or out_mag.device != wav.device or not out_mag.is_contiguous()):
+        raise _lib.PsndError('stft_forward: out_mag must be a contiguous fp32 (%d, %d, %d) tensor on %s' % (N, K, F, wav.device))
+    mag = (out_mag if out_mag is not None else mk()) if want_mag else None
     phase = mk() if want_phase else None
     re = mk() if want_reim else None
     im = mk() if want_reim else None
@@ -98,12 +102,16 @@ def _clamp_args(clamp_lo, clamp_hi, pre_clamp_min):
 
 
 def mel_forward(mag, mel_plan_t, M, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None,
-                clamp_lo=None, clamp_hi=None, want_lin=False):
+                clamp_lo=None, clamp_hi=None, want_lin=False, out=None):
     _need_cuda(mag, 'mag')
     mag = mag.contiguous()
     N, K, F = mag.shape
     lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
-    out = torch.empty((N, M, F), dtype=torch.float32, device=mag.device)
+    if out is not None and (tuple(out.shape) != (N, M, F) or out.dtype != torch.float32 or out.device != mag.device
+                            or not out.is_contiguous()):
+        raise _lib.PsndError('mel_forward: out must be a contiguous fp32 (%d, %d, %d) tensor on %s' % (N, M, F, mag.device))
+    if out is None:
+        out = torch.empty((N, M, F), dtype=torch.float32, device=mag.device)
     lin = torch.empty_like(out) if want_lin else None
     with torch.cuda.device(mag.device):
         check(lib().psnd_mel_fwd(ptr(mag), N, F, M, K, ptr(mel_plan_t), log_kind, float(log_offset), pre, lo, hi,

@@ -334,6 +334,9 @@ class Trainer:
     # free of host synchronisation.  Logging steps and the first `graph_warmup` steps of a signature run eagerly.
     graph_steps = False
     graph_warmup = 3
+    # (not in the reference) a prepare() that writes its outputs into persistent buffers of its own and returns those same
+    # tensors every step may say so: the captured graph then reads them where they are (no copy into graph-owned inputs per step)
+    static_prepare = False
 
     def _train_graph(self, step: int, batch) -> bool:
         if not (self.async_nan_check and self.scheduler is None
@@ -353,7 +356,8 @@ class Trainer:
             self._capture(st, batch)
             self._trim_graph_cache()
         for dst, src in zip(st['inputs'], batch):
-            dst.copy_(src, non_blocking=True)
+            if src.data_ptr() != dst.data_ptr():           # static_prepare: already there
+                dst.copy_(src, non_blocking=True)
         st['graph'].replay()
         if self._reducer is not None and st.get('ddp') in ('events', 'capture'):
             # the captured backward filled the flat buckets itself and marked where each is complete: bucket i is all-reduced
@@ -384,7 +388,8 @@ class Trainer:
     def _capture(self, st, batch):
         red = self._reducer
         mode = red.graph_mode() if red is not None and red.active else None
-        st['inputs'] = tuple(t.clone() for t in batch)
+        # static_prepare: prepare() returns the SAME buffers every step (features written in place) - they are the graph's inputs
+        st['inputs'] = tuple(batch) if self.static_prepare else tuple(t.clone() for t in batch)
         if (red is not None and red.active) or self.prefetch_copy or self.prefetch_prepare:
             from . import cl
             cl.AUTO_SECTIONS = False                   # see cl.py: no batch-section branches next to other live streams
