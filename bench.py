@@ -89,6 +89,7 @@ def build_step(device, amp):
             return K.mel_forward(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db, out=feat[key])[0]
 
         l1 = K.l1_loss                                              # F.l1_loss as psnd_l1_loss_fwd / _bwd
+        l1sum = K.l1_loss_sum
     else:
         from oracle.torch_ref import RefLogMel                      # CPU baseline leg only
         fe = RefLogMel(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX)
@@ -100,6 +101,7 @@ def build_step(device, amp):
             return fe.mel_of_mag(m)
 
         l1 = F.l1_loss
+        l1sum = None
 
     class StepTrainer(Trainer):
         static_prepare = gpu          # the features are written into persistent buffers: the step graph reads them in place
@@ -120,7 +122,10 @@ def build_step(device, amp):
                 est = est.float()
             else:
                 est = self.model(mag_mix)
-            loss = l1(est, mag_ref) + 0.5 * l1(logmel_of_mag(est), mel_ref)
+            if l1sum is not None:           # both L1 terms as one scalar node (psnd_l1_loss_sum_fwd)
+                loss = l1sum([(est, mag_ref), (logmel_of_mag(est), mel_ref)], (1.0, 0.5))
+            else:
+                loss = l1(est, mag_ref) + 0.5 * l1(logmel_of_mag(est), mel_ref)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
     torch.manual_seed(1234)

@@ -345,6 +345,12 @@ int psnd_pqmf_synthesis(const float *x, const float *filt, int64_t B, int64_t M,
 int64_t psnd_l1_loss_blocks(int64_t n);
 int psnd_l1_loss_fwd(const float *a, const float *b, int64_t n, double *part, float *out, void *stream);
 int psnd_l1_loss_bwd(const float *a, const float *b, int64_t n, const float *g, float *ga, float *gb, void *stream);
+/* a weighted sum of up to 4 mean-L1 terms as ONE scalar (a recipe's `l1(a, b) + 0.5 * l1(c, d)`): out[0] = sum_i w[i] * mean|a[i] - b[i]|;
+ * a, b, n, w: HOST arrays of `terms` entries (read during the call); part: sum_i psnd_l1_loss_blocks(n[i]) doubles of scratch.
+ * psnd_l1_loss_bwd_w: the backward of one term, ga = weight * g[0] * sign(a - b) / n. */
+int psnd_l1_loss_sum_fwd(const float *const *a, const float *const *b, const int64_t *n, const double *w, int terms, double *part,
+                         float *out, void *stream);
+int psnd_l1_loss_bwd_w(const float *a, const float *b, int64_t n, const float *g, double weight, float *ga, float *gb, void *stream);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,8 @@ SIGNATURES = {
     'psnd_l1_loss_blocks': (_I64, [_I64]),
     'psnd_l1_loss_fwd': (_INT, [_P, _P, _I64, _P, _P, _P]),
     'psnd_l1_loss_bwd': (_INT, [_P, _P, _I64, _P, _P, _P, _P]),
+    'psnd_l1_loss_sum_fwd': (_INT, [_P, _P, _P, _P, _INT, _P, _P, _P]),
+    'psnd_l1_loss_bwd_w': (_INT, [_P, _P, _I64, _P, _D, _P, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }

@@ -180,6 +180,27 @@ __global__ __launch_bounds__(256) void l1_final_kernel(const double *part, int n
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * inv_n);
 }
+// out[0] = sum_i w_i * mean_i: the partial sums of up to 4 L1 terms folded by one workgroup (a recipe's `l1(a, b) + 0.5 * l1(c, d)` without
+// the scalar multiply / add launches in between)
+struct L1Terms {
+    const double *part[4];
+    int nb[4];
+    double scale[4];            // w_i / n_i
+    int terms;
+};
+__global__ __launch_bounds__(256) void l1_final_multi_kernel(L1Terms t, float *out) {
+    double s = 0;
+    for (int k = 0; k < t.terms; ++k) {
+        double sk = 0;
+        for (int i = threadIdx.x; i < t.nb[k]; i += 256) sk += t.part[k][i];
+        s += sk * t.scale[k];
+    }
+    s = wave_sum_d(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
 // ga = g * sign(a - b) / n,  gb = -ga   (either may be NULL); g: device scalar
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float *a, const float *b, long long n, const float *g, float inv_n, float *ga,
                                                      float *gb) {
@@ -275,10 +296,36 @@ extern "C" int psnd_l1_loss_fwd(const float *a, const float *b, int64_t n, doubl
 }
 
 extern "C" int psnd_l1_loss_bwd(const float *a, const float *b, int64_t n, const float *g, float *ga, float *gb, void *stream) {
+    return psnd_l1_loss_bwd_w(a, b, n, g, 1.0, ga, gb, stream);
+}
+
+extern "C" int psnd_l1_loss_bwd_w(const float *a, const float *b, int64_t n, const float *g, double weight, float *ga, float *gb, void *stream) {
     if (!a || !b || !g || (!ga && !gb)) PSND_FAIL(PSND_E_ARG, "l1_loss_bwd: null pointer");
     if (n <= 0 || (n + 1023) / 1024 > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "l1_loss_bwd: n=%lld", (long long)n);
     hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, (long long)n, g,
-                       (float)(1.0 / (double)n), ga, gb);
+                       (float)(weight / (double)n), ga, gb);
     PSND_CHECK_LAUNCH("l1_loss_bwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_l1_loss_sum_fwd(const float *const *a, const float *const *b, const int64_t *n, const double *w, int terms, double *part,
+                                    float *out, void *stream) {
+    if (!a || !b || !n || !w || !part || !out) PSND_FAIL(PSND_E_ARG, "l1_loss_sum_fwd: null pointer");
+    if (terms < 1 || terms > 4) PSND_FAIL(PSND_E_SHAPE, "l1_loss_sum_fwd: 1 .. 4 terms, got %d", terms);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    L1Terms t;
+    t.terms = terms;
+    double *pp = part;
+    for (int k = 0; k < 4; ++k) t.part[k] = nullptr, t.nb[k] = 0, t.scale[k] = 0.0;
+    for (int k = 0; k < terms; ++k) {
+        if (!a[k] || !b[k]) PSND_FAIL(PSND_E_ARG, "l1_loss_sum_fwd: null tensor in term %d", k);
+        if (n[k] <= 0 || psnd_l1_loss_blocks(n[k]) > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "l1_loss_sum_fwd: n=%lld", (long long)n[k]);
+        const int nb = (int)psnd_l1_loss_blocks(n[k]);
+        hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, s, a[k], b[k], (long long)n[k], pp);
+        t.part[k] = pp, t.nb[k] = nb, t.scale[k] = w[k] / (double)n[k];
+        pp += nb;
+    }
+    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(256), 0, s, t, out);
+    PSND_CHECK_LAUNCH("l1_loss_sum_fwd");
     return PSND_OK;
 }

@@ -619,6 +619,61 @@ class L1Loss(torch.autograd.Function):
         return ga, gb
 
 
+class L1LossSum(torch.autograd.Function):
+    """sum_i w_i * F.l1_loss(a_i, b_i) as ONE scalar node (psnd_l1_loss_sum_fwd: one pass per term + one combine; backward one pass per
+    term with the weight folded in) - a recipe's `l1(a, b) + 0.5 * l1(c, d)` without the scalar multiply / add launches."""
+
+    @staticmethod
+    def forward(ctx, weights, *tensors):
+        import ctypes
+        k = len(weights)
+        if k < 1 or k > 4 or len(tensors) != 2 * k:
+            raise _lib.PsndError('l1_loss_sum: 1 .. 4 (input, target) pairs with one weight each')
+        ab = []
+        for i in range(k):
+            a, b = tensors[2 * i], tensors[2 * i + 1]
+            _need_cuda(a, 'input')
+            _need_cuda(b, 'target')
+            if a.shape != b.shape:
+                raise _lib.PsndError('l1_loss_sum: shapes %s and %s differ' % (tuple(a.shape), tuple(b.shape)))
+            ab += [a.contiguous(), b.contiguous()]
+        dev = ab[0].device
+        ns = [ab[2 * i].numel() for i in range(k)]
+        part = torch.empty(sum(int(lib().psnd_l1_loss_blocks(n)) for n in ns), dtype=torch.float64, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        pa = (ctypes.c_void_p * k)(*[ab[2 * i].data_ptr() for i in range(k)])
+        pb = (ctypes.c_void_p * k)(*[ab[2 * i + 1].data_ptr() for i in range(k)])
+        pn = (ctypes.c_int64 * k)(*ns)
+        pw = (ctypes.c_double * k)(*[float(w) for w in weights])
+        with torch.cuda.device(dev):
+            check(lib().psnd_l1_loss_sum_fwd(pa, pb, pn, pw, k, ptr(part), ptr(out), stream_ptr(dev)), 'psnd_l1_loss_sum_fwd')
+        ctx.weights = tuple(float(w) for w in weights)
+        ctx.save_for_backward(*ab)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ab = ctx.saved_tensors
+        g = g.contiguous().float()
+        grads = []
+        with torch.cuda.device(g.device):
+            for i, w in enumerate(ctx.weights):
+                a, b = ab[2 * i], ab[2 * i + 1]
+                ga = torch.empty_like(a) if ctx.needs_input_grad[1 + 2 * i] else None
+                gb = torch.empty_like(b) if ctx.needs_input_grad[2 + 2 * i] else None
+                if ga is not None or gb is not None:
+                    check(lib().psnd_l1_loss_bwd_w(ptr(a), ptr(b), a.numel(), ptr(g), w, ptr(ga), ptr(gb), stream_ptr(g.device)),
+                          'psnd_l1_loss_bwd_w')
+                grads += [ga, gb]
+        return (None,) + tuple(grads)
+
+
+def l1_loss_sum(pairs, weights):
+    """sum_i weights[i] * F.l1_loss(*pairs[i]) on fp32 HIP tensors, one autograd node"""
+    flat = [t for p in pairs for t in p]
+    return L1LossSum.apply(tuple(weights), *flat)
+
+
 def l1_loss(input, target):
     """drop-in for torch.nn.functional.l1_loss(input, target) (reduction 'mean') on fp32 HIP tensors"""
     return L1Loss.apply(input, target)

@@ -115,6 +115,28 @@ def test_loss_kernels_reject_bad_arguments():
         multi_stft_loss(torch.zeros(2, 4096, device=DEV), torch.zeros(2, 4096, device=DEV), [(1000, 600, 120)])   # n_fft not 2^k
 
 
+def test_l1_loss_sum_matches_torch():
+    """psnd_l1_loss_sum_fwd / psnd_l1_loss_bwd_w: w1 * l1(a, b) + w2 * l1(c, d) as one node == the same expression on F.l1_loss in
+    float64 (value 1e-6 relative, gradients 1e-6 relative; a target that needs no gradient gets none)"""
+    from pytorch_sound_amd import kernels as K
+    torch.manual_seed(5)
+    a = torch.randn(3, 513, 173, device=DEV, requires_grad=True)
+    b = torch.randn(3, 513, 173, device=DEV)
+    c = torch.randn(3, 80, 173, device=DEV, requires_grad=True)
+    d = torch.randn(3, 80, 173, device=DEV, requires_grad=True)
+    out = K.l1_loss_sum([(a, b), (c, d)], (1.0, 0.5))
+    (2.0 * out).backward()
+    a64, c64, d64 = (t.detach().double().requires_grad_(True) for t in (a, c, d))
+    ref = torch.nn.functional.l1_loss(a64, b.double()) + 0.5 * torch.nn.functional.l1_loss(c64, d64)
+    (2.0 * ref).backward()
+    assert abs(float(out) - float(ref)) <= 1e-6 * abs(float(ref))
+    for g, r in ((a.grad, a64.grad), (c.grad, c64.grad), (d.grad, d64.grad)):
+        assert torch.allclose(g.double(), r, rtol=1e-6, atol=0)
+    assert b.grad is None
+    with pytest.raises(Exception):
+        K.l1_loss_sum([(a, b)] * 5, (1.0,) * 5)
+
+
 @pytest.mark.parametrize('shape', [(32, 513, 173), (3, 7), (1, 16385), (5,)])
 def test_l1_loss_matches_torch(shape):
     """psnd_l1_loss_fwd/bwd == F.l1_loss (mean) in float64 and its autograd (sign(a - b) / n, 0 at ties)"""
