@@ -55,8 +55,11 @@ struct PairParams {
     do {                                                                                \
         if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#ifndef PSND_PAIR_RU
+#define PSND_PAIR_RU 12
+#endif
 constexpr unsigned OOB = 0x80000000u;
-constexpr int RU = 12;           // B units (one tap of one k-step: one 1 KB fragment) in flight per wave
+constexpr int RU = PSND_PAIR_RU;           // B units (one tap of one k-step: one 1 KB fragment) in flight per wave
 constexpr int HMAXP = 8;        // largest tap reach of either conv
 
 __device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(PairParams p) {
     // every address is a per-lane base plus a compile-time / scalar offset - no per-unit address arithmetic beside the MFMAs
     auto fetch_b = [&](auto slotc, __amdgpu_buffer_rsrc_t rW, int it) __attribute__((always_inline)) {
         constexpr int slot = decltype(slotc)::value, tap = slot % 3, ksl = slot / 3;
-        const int ks = 4 * it + ksl;                                   // uniform
+        const int ks = (RU / 3) * it + ksl;                                   // uniform
         rb[slot] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(ks < KSTEPS ? fwave : OOB),
                                                                                     (int)((unsigned)tap * FTAP + (unsigned)ks * 1024u), 0));
     };
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512, 1) void conv_pair_kernel(PairParams p) {
         for (int t = 0; t < 3; ++t) ab[t] = src + (rg * MB * 32 + li + hh + off0 + t * dstep) * RS + 8 * kg;
         auto afrag = [&](auto uc, int it, bf16x8 (&x)[MB]) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value, tap = u % 3, ksl = u / 3;    // u may run past the turn: k-step 4 it + ksl all the same
-            const bf16_t *pa = ab[tap] + 16 * (4 * it + ksl);
+            const bf16_t *pa = ab[tap] + 16 * ((RU / 3) * it + ksl);
 #pragma unroll
             for (int m = 0; m < MB; ++m) x[m] = *reinterpret_cast<const bf16x8 *>(pa + m * 32 * RS);
         };
