@@ -707,7 +707,8 @@ typedef short v4s_t __attribute__((ext_vector_type(4)));
 #ifndef PSND_WGRAD_TR
 #define PSND_WGRAD_TR 1
 #endif
-constexpr int WTP = 72;                      // LDS row pitch of the chunk tiles (bf16): 144 B
+constexpr int WTP = 96;                      // LDS row pitch of the chunk tiles (bf16): 192 B = 48 banks - the four rows of a transposing
+                                             // read start 16 banks apart and the two channel halves 8: conflict-free (144 B: 37 % conflict cycles)
 constexpr int WXR = 64;                      // rows of the activation tile buffer: 32 + the row span of a tap group (<= 32)
 static_assert(2 * (32 + WXR) * WTP * (int)sizeof(bf16_t) <= kWgradLdsBytes, "the transposing-read tiles fit version 1's LDS");
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t *p0) {   // rows r .. r+3 and r+4 .. r+7 of this lane's channel
