@@ -228,6 +228,20 @@ int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_
                        int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                        const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
                        void *stream);
+/* Backward of a whole residual pair (`leaky -> conv1(d) -> leaky -> conv2(1) -> + x`, hifi_gan.py:56-62) as ONE launch: the input gradients
+ * of both convs chained on chip (psnd_conv1d_cl_pair's body with the transposed packs wb2 / wb1, mirrored taps, the leaky' masks M1 = the
+ * activated conv1 output and M2 = the activated pair input, res = G the gradient on the residual stream: g_mid = gradient wrt conv1's
+ * output, gx = gradient wrt the pair's input), the weight-gradient slabs of conv2 (gradient G, input xa_a = M1; gw_a / gb_a) and the slabs
+ * of ANOTHER conv whose gradient an earlier launch produced (G_b, xa_b with taps off_b + t * dstep_b; gw_b / gb_b; all NULL: none) -
+ * in a chain walked backwards that is conv1 of the pair handled before.  G == NULL: only the `_b` weight gradient (the chain's last
+ * conv1).  Slabs: psnd_conv1d_cl_pair_bwd_splits(N, Lp, C, k) per conv, layout as psnd_conv1d_cl_wgrad.  C = 256, k = 3 and
+ * psnd_conv1d_cl_pair_bwd_supported(...) == 1, PSND_E_UNSUPPORTED otherwise. */
+int psnd_conv1d_cl_pair_bwd_supported(int C, int k, int pad2, int dil2, int pad1, int dil1);
+int psnd_conv1d_cl_pair_bwd_splits(int64_t N, int Lp, int C, int k);
+int psnd_conv1d_cl_pair_bwd(const void *G, const void *wb2, const void *M1, float m1_slope, void *g_mid, const void *wb1, const void *M2,
+                            float m2_slope, const void *res, int64_t N, int Lp, int L, int HP, int C, int k, int pad2, int dil2,
+                            int pad1, int dil1, void *gx, const void *xa_a, float *gw_a, float *gb_a, const void *G_b,
+                            const void *xa_b, int off_b, int dstep_b, float *gw_b, float *gb_b, void *stream);
 int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);

@@ -48,6 +48,10 @@ SIGNATURES = {
     'psnd_conv1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd': (_INT, [_P, _P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_cl_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _F, _P, _P, _P, _P]),
+    'psnd_conv1d_cl_pair_bwd_supported': (_INT, [_INT, _INT, _INT, _INT, _INT, _INT]),
+    'psnd_conv1d_cl_pair_bwd_splits': (_INT, [_I64, _INT, _INT, _INT]),
+    'psnd_conv1d_cl_pair_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P,
+                                       _P, _P, _INT, _INT, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd_multi': (_INT, [_P, _INT, _P]),
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),

@@ -600,6 +600,7 @@ class ResBlockCL(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_raw, g_act):
+        import os
         import struct
         import ctypes
         saved, steps, shape = ctx.saved_tensors, ctx.steps, ctx.shape
@@ -617,6 +618,9 @@ class ResBlockCL(torch.autograd.Function):
         Nh = shape.N // nsec
         plan = []                              # launches, walked once per batch section (_run_sections)
         skip = -1                              # conv already handled as the first conv of a fused input-gradient pair
+        pair_bwd = (nsec == 1 and not wstreams and _pair_enabled() and os.environ.get('PSND_CL_PAIR_BWD', '1') != '0'
+                    and shape.N * shape.Lp <= 8192)
+        lag = None                             # weight gradient of a pair's first conv, carried to the next pair launch
         with torch.cuda.device(dev):
             # The gradient a conv receives is  g = g_raw + g_act * leaky'(own activated output).  Only the block's LAST conv gets
             # the two parts from outside and combines them on load; every earlier conv's g is formed in the EPILOGUE of the input-
@@ -624,10 +628,11 @@ class ResBlockCL(torch.autograd.Function):
             # reads ONE plain tensor in both roles - and that tensor also is the gradient handed on along the residual stream.
             g_comb = None                      # combined incoming gradient of conv i (None for the block's last conv)
             res_pending = None                 # pairs: gradient on the residual stream behind the pair being walked
-            def slabs(i, G1, G2, am, inp):
+            def slabs(i, G1, G2, am, inp, S=None):
                 Cout, Cin, k, Ca, Cb, dil, pad, slope = steps[i][:8]
                 v32, g32 = saved[5 * i + 3], saved[5 * i + 4]
-                S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
+                if S is None:
+                    S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
                 gw = torch.empty((nsec * S, k, Cb, Ca), dtype=torch.float32, device=dev)    # slabs of section h: [h S, (h+1) S)
                 gbp = torch.empty((nsec * S, Cb), dtype=torch.float32, device=dev)
                 gb = torch.empty(Cb, dtype=torch.float32, device=dev)
@@ -644,6 +649,28 @@ class ResBlockCL(torch.autograd.Function):
                     continue
                 Cout, Cin, k, Ca, Cb, dil, pad, slope, has_res, has_bias, role = steps[i]
                 inp, act, wb, v32, g32 = saved[5 * i:5 * i + 5]
+                if (pair_bwd and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
+                        and steps[i - 1][3] == steps[i - 1][4] == Ca and steps[i - 1][2] == k
+                        and lib().psnd_conv1d_cl_pair_bwd_supported(Ca, k, pad, dil, steps[i - 1][6], steps[i - 1][5])):
+                    # the whole pair's backward as ONE launch (psnd_conv1d_cl_pair_bwd): input gradients of conv2 and conv1 chained on
+                    # chip, conv2's weight gradient, and the weight gradient of the conv1 of the pair handled BEFORE (its gradient is
+                    # that launch's g_h); this pair's conv1 waits for the next such launch (or the flush after the loop)
+                    inp1, wb1 = saved[5 * (i - 1)], saved[5 * (i - 1) + 2]
+                    d1, pad1 = steps[i - 1][5], steps[i - 1][6]
+                    G = g_comb
+                    g_h = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+                    gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+                    S2 = lib().psnd_conv1d_cl_pair_bwd_splits(shape.N, shape.Lp, Ca, k)
+                    wa = slabs(i, G, None, None, inp, S2)
+                    plan.append(('pb', G, wb, inp, float(steps[i - 1][7]), g_h, wb1, inp1, float(steps[i - 2][7]), Ca, k, pad, dil, pad1, d1, gx,
+                                 wa[11], wa[12], lag))
+                    wl = slabs(i - 1, g_h, None, None, inp1, S2)
+                    lag = (g_h, inp1, -pad1, d1, wl[11], wl[12], Ca, k)
+                    keep.extend([g_h, gx])
+                    res_pending = G
+                    g_comb = gx
+                    skip = i - 1
+                    continue
                 if (wstreams and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
                         and steps[i - 1][3] == steps[i - 1][4] == Ca and steps[i - 1][2] == k
                         and lib().psnd_conv1d_cl_pair_supported(Ca, k, pad, -dil, steps[i - 1][6], -steps[i - 1][5])):
@@ -712,6 +739,8 @@ class ResBlockCL(torch.autograd.Function):
                 else:                                          # gradients wrt the block's inputs (x, xa)
                     g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
 
+            if lag is not None:                # the chain's first pair: its conv1 weight gradient has no later pair launch to ride on
+                plan.append(('pbflush', lag))
             used = []
 
             def run(h):
@@ -729,6 +758,20 @@ class ResBlockCL(torch.autograd.Function):
                         with torch.cuda.stream(sd):
                             check(lib().psnd_conv1d_cl_wgrad(ptr(G1), ptr(G2), ptr(am), float(slope), ptr(inp), shape.N, shape.Lp, Ca, Cb, k,
                                                              off0, dil, ptr(gw), ptr(gbp), None, stream_ptr(dev)), 'psnd_conv1d_cl_wgrad')
+                        continue
+                    if e[0] == 'pb':
+                        _, G, wb2, m1, m1s, g_h, wb1, m2, m2s, C, k, pad2, dil2, pad1, d1, gx, gwa, gba, lg = e
+                        lb = lg if lg is not None else (None, None, 0, 0, None, None, C, k)
+                        check(lib().psnd_conv1d_cl_pair_bwd(ptr(G), ptr(wb2), ptr(m1), m1s, ptr(g_h), ptr(wb1), ptr(m2), m2s, ptr(G), shape.N,
+                                                            shape.Lp, shape.L, shape.HP, C, k, pad2, dil2, pad1, d1, ptr(gx), ptr(m1), ptr(gwa),
+                                                            ptr(gba), ptr(lb[0]), ptr(lb[1]), lb[2], lb[3], ptr(lb[4]), ptr(lb[5]), st),
+                              'psnd_conv1d_cl_pair_bwd')
+                        continue
+                    if e[0] == 'pbflush':
+                        lg = e[1]
+                        check(lib().psnd_conv1d_cl_pair_bwd(None, None, None, 1.0, None, None, None, 1.0, None, shape.N, shape.Lp, shape.L,
+                                                            shape.HP, lg[6], lg[7], 0, 1, 0, 1, None, None, None, None, ptr(lg[0]), ptr(lg[1]),
+                                                            lg[2], lg[3], ptr(lg[4]), ptr(lg[5]), st), 'psnd_conv1d_cl_pair_bwd')
                         continue
                     if e[0] == 'pairb':
                         _, G, wb2, m1, m1s, g_h, wb1, m2, m2s, res, C, k, off1, ds1, off2, ds2, gx = e

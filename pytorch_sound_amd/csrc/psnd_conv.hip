@@ -19,7 +19,9 @@
 // from L2 into the B operand registers (pack_index, conv_cl_body).  The backward of a conv is ONE launch: input-gradient
 // and weight-gradient roles share the grid (conv_bwd_pair_kernel), the weight-norm backward of a whole chain another one.
 #include "psnd_common.h"
+#include "psnd_conv_pair.h"
 #include <stdlib.h>
+#include <string.h>
 #include <atomic>
 
 namespace {
@@ -922,6 +924,25 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
 }
 
 
+// Backward of a whole residual pair as ONE launch (round 2): the input-gradient chain of both convs is the two-chained-convs body of
+// psnd_conv_pair.h (256 threads here: the weight-gradient workgroups supply the other waves of a SIMD), next to TWO weight-gradient
+// roles - the pair's second conv (its gradient is this launch's input) and a conv whose gradient an EARLIER launch produced (the first
+// conv of the pair handled before: its gradient is that launch's `mid`).
+__global__ __launch_bounds__(256, 2) void conv_pair_bwd_kernel(pairk::PairParams pp, WgradParams wa, WgradParams wb_, int nwa, int nwb, int wgx,
+                                                               int wgy) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
+    const int b = blockIdx.x;
+    if (b < nwa) {
+        const int bx = b % wgx, r = b / wgx;
+        conv_wgrad_body<false>(wa, bx, r % wgy, r / wgy, smem_dyn, 0);
+    } else if (b < nwa + nwb) {
+        const int c = b - nwa, bx = c % wgx, r = c / wgx;
+        conv_wgrad_body<false>(wb_, bx, r % wgy, r / wgy, smem_dyn, 0);
+    } else {
+        pairk::conv_pair_body<256, 1, true, 4, 6>(pp, b - nwa - nwb, smem_dyn);
+    }
+}
+
 // ---- weight prep: weight norm (dim 0) + both bf16 packs + padded bias, one block per output channel ------
 //   w = g * v / ||v|| ; wf[j][co][ci] (forward), wb[j][ci][co] (input gradient) ; pads are zero-filled by the caller
 __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const float *g, const float *bias, int Cout, int Cin, int k,
@@ -1304,6 +1325,83 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 // Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
 // taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Outside the paired instances (operands beyond the
 // 32-bit offsets) the two kernels are enqueued one after the other, same results.
+// ---- backward of a residual pair in one launch (conv_pair_bwd_kernel) -----------------------------------------------------------------
+static int pair_bwd_splits(int64_t R, int C, int k, int64_t *rps_out) {
+    const int tiles = ((C + 63) / 64) * ((C + 63) / 64) * ((k + WKT - 1) / WKT);
+    int64_t target = 128;                    // per weight-gradient role: two of them + ~200-270 pair workgroups fill the 512 slots
+    if (const char *e = getenv("PSND_PAIRBWD_BLOCKS")) target = atoi(e);
+    int64_t splits = target / tiles;
+    if (splits < 1) splits = 1;
+    int64_t rps = (R + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 64) rps = 64;
+    splits = (R + rps - 1) / rps;
+    if (rps_out) *rps_out = rps;
+    return (int)splits;
+}
+
+extern "C" int psnd_conv1d_cl_pair_bwd_supported(int C, int k, int pad2, int dil2, int pad1, int dil1) {
+    return C == 256 && psnd_conv1d_cl_pair_supported(C, k, pad2, -dil2, pad1, -dil1) && 32 - 2 * pairk::reach3(pad1, -dil1) >= 16 ? 1 : 0;
+}
+
+extern "C" int psnd_conv1d_cl_pair_bwd_splits(int64_t N, int Lp, int C, int k) {
+    if (N <= 0 || Lp <= 0 || C <= 0 || k <= 0) return 0;
+    return pair_bwd_splits(N * (int64_t)Lp, C, k, nullptr);
+}
+
+extern "C" int psnd_conv1d_cl_pair_bwd(const void *G, const void *wb2, const void *M1, float m1_slope, void *g_mid, const void *wb1, const void *M2,
+                                       float m2_slope, const void *res, int64_t N, int Lp, int L, int HP, int C, int k, int pad2, int dil2,
+                                       int pad1, int dil1, void *gx, const void *xa_a, float *gw_a, float *gb_a, const void *G_b,
+                                       const void *xa_b, int off_b, int dstep_b, float *gw_b, float *gb_b, void *stream) {
+    const bool have_pair = G != nullptr;
+    const bool have_b = G_b != nullptr;
+    if (!have_pair && !have_b) return PSND_OK;
+    if (N <= 0 || Lp <= 0 || L <= 0 || HP < 0 || Lp < L + HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair_bwd: N=%lld Lp=%d L=%d HP=%d", (long long)N, Lp, L, HP);
+    if (C != 256 || k != 3) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair_bwd: C=%d k=%d (256 channels, 3 taps)", C, k);
+    if ((size_t)N * Lp * C * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair_bwd: operand larger than 2 GB");
+    if (have_pair && (!wb2 || !wb1 || !M1 || !g_mid || !gx || !xa_a || !gw_a)) PSND_FAIL(PSND_E_ARG, "conv1d_cl_pair_bwd: null pointer");
+    if (have_pair && !psnd_conv1d_cl_pair_bwd_supported(C, k, pad2, dil2, pad1, dil1))
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair_bwd: taps (%d,%d) (%d,%d)", pad2, dil2, pad1, dil1);
+    if (have_b && (!xa_b || !gw_b)) PSND_FAIL(PSND_E_ARG, "conv1d_cl_pair_bwd: null pointer (second weight gradient)");
+    const int64_t R = N * (int64_t)Lp;
+    int64_t rps;
+    const int splits = pair_bwd_splits(R, C, k, &rps);
+    const int wgx = (C + 63) / 64, wgy = (C + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
+    auto fill = [&](WgradParams &w, const void *g, const void *xa, int off0, int dstep, float *gw, float *gb) {
+        wgrad_params_plain(w);
+        w.G1 = static_cast<const bf16_t *>(g), w.G2 = nullptr, w.GM = nullptr;
+        w.xa = static_cast<const bf16_t *>(xa), w.gw = gw, w.gbias = gb, w.g_out = nullptr;
+        w.R = R, w.Ca = C, w.Cb = C, w.k = k, w.off0 = off0, w.dstep = dstep, w.g2_slope = 1.f, w.rows_per_split = (int)rps;
+    };
+    WgradParams wa, wb_;
+    fill(wa, G, xa_a, -pad2, dil2, gw_a, gb_a);
+    fill(wb_, G_b, xa_b, off_b, dstep_b, gw_b, gb_b);
+    pairk::PairParams pp;
+    memset(&pp, 0, sizeof(pp));
+    int tiles = 0;
+    size_t lds = kWgradLdsBytes;
+    if (have_pair) {
+        pp.A = static_cast<const pairk::bf16_t *>(G), pp.W1 = static_cast<const pairk::bf16_t *>(wb2), pp.W2 = static_cast<const pairk::bf16_t *>(wb1);
+        pp.bias1 = nullptr, pp.bias2 = nullptr;
+        pp.M1 = static_cast<const pairk::bf16_t *>(M1), pp.M2 = static_cast<const pairk::bf16_t *>(M2), pp.res = static_cast<const pairk::bf16_t *>(res);
+        pp.mid_out = static_cast<pairk::bf16_t *>(g_mid), pp.out_raw = static_cast<pairk::bf16_t *>(gx), pp.out_act = nullptr;
+        pp.R = R, pp.Lp = Lp, pp.L = L, pp.HP = HP;
+        pp.off1 = pad2, pp.dstep1 = -dil2, pp.h1 = pairk::reach3(pad2, -dil2);
+        pp.off2 = pad1, pp.dstep2 = -dil1, pp.h2 = pairk::reach3(pad1, -dil1);
+        pp.m1_slope = m1_slope, pp.m2_slope = m2_slope, pp.act1_slope = 1.f, pp.act2_slope = 1.f, pp.trace = nullptr;
+        const int TS = 32 - 2 * pp.h2;
+        tiles = (int)((R + TS - 1) / TS);
+        const size_t lp = (size_t)(32 + 2 * pp.h1 + 32 + 2 * pp.h2) * (C + 8) * 2, lo = (size_t)32 * (C + 8) * 4;
+        if (lds < lp) lds = lp;
+        if (lds < lo) lds = lo;
+    }
+    const int nwa = have_pair ? wgx * wgy * wgz : 0, nwb = have_b ? wgx * wgy * wgz : 0;
+    hipLaunchKernelGGL(conv_pair_bwd_kernel, dim3((unsigned)(nwa + nwb + tiles)), dim3(256), lds, static_cast<hipStream_t>(stream), pp, wa, wb_, nwa,
+                       nwb, wgx, wgy);
+    PSND_CHECK_LAUNCH("conv1d_cl_pair_bwd");
+    return PSND_OK;
+}
+
 extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                                   int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                                   const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
