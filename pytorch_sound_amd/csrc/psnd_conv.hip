@@ -928,6 +928,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
 // psnd_conv_pair.h (256 threads here: the weight-gradient workgroups supply the other waves of a SIMD), next to TWO weight-gradient
 // roles - the pair's second conv (its gradient is this launch's input) and a conv whose gradient an EARLIER launch produced (the first
 // conv of the pair handled before: its gradient is that launch's `mid`).
+#ifndef PSND_PAIRBWD_MR
+#define PSND_PAIRBWD_MR 1
+#endif
+#ifndef PSND_PAIRBWD_RU
+#define PSND_PAIRBWD_RU 6
+#endif
 __global__ __launch_bounds__(256, 2) void conv_pair_bwd_kernel(pairk::PairParams pp, WgradParams wa, WgradParams wb_, int nwa, int nwb, int wgx,
                                                                int wgy) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_bwd_kernel(pairk::PairParams
         const int c = b - nwa, bx = c % wgx, r = c / wgx;
         conv_wgrad_body<false>(wb_, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
-        pairk::conv_pair_body<256, 1, true, 4, 6>(pp, b - nwa - nwb, smem_dyn);
+        pairk::conv_pair_body<256, PSND_PAIRBWD_MR, true, 4, PSND_PAIRBWD_RU>(pp, b - nwa - nwb, smem_dyn);
     }
 }
 
@@ -1328,7 +1334,9 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 // ---- backward of a residual pair in one launch (conv_pair_bwd_kernel) -----------------------------------------------------------------
 static int pair_bwd_splits(int64_t R, int C, int k, int64_t *rps_out) {
     const int tiles = ((C + 63) / 64) * ((C + 63) / 64) * ((k + WKT - 1) / WKT);
-    int64_t target = 128;                    // per weight-gradient role: two of them + ~200-270 pair workgroups fill the 512 slots
+    // per weight-gradient role (two of them run next to ~200-270 pair workgroups); config-2 step: 112 -> 0.816 ms, 96 -> 0.819, 128 -> 0.838,
+    // 80 -> 0.841, 144 -> 0.846, 160 -> 0.855, 64 -> 0.866, 192 -> 0.868, 48 -> 0.940
+    int64_t target = 112;
     if (const char *e = getenv("PSND_PAIRBWD_BLOCKS")) target = atoi(e);
     int64_t splits = target / tiles;
     if (splits < 1) splits = 1;
@@ -1389,9 +1397,9 @@ extern "C" int psnd_conv1d_cl_pair_bwd(const void *G, const void *wb2, const voi
         pp.off1 = pad2, pp.dstep1 = -dil2, pp.h1 = pairk::reach3(pad2, -dil2);
         pp.off2 = pad1, pp.dstep2 = -dil1, pp.h2 = pairk::reach3(pad1, -dil1);
         pp.m1_slope = m1_slope, pp.m2_slope = m2_slope, pp.act1_slope = 1.f, pp.act2_slope = 1.f, pp.trace = nullptr;
-        const int TS = 32 - 2 * pp.h2;
+        const int MRW = 32 * PSND_PAIRBWD_MR, TS = MRW - 2 * pp.h2;
         tiles = (int)((R + TS - 1) / TS);
-        const size_t lp = (size_t)(32 + 2 * pp.h1 + 32 + 2 * pp.h2) * (C + 8) * 2, lo = (size_t)32 * (C + 8) * 4;
+        const size_t lp = (size_t)(MRW + 2 * pp.h1 + MRW + 2 * pp.h2) * (C + 8) * 2, lo = (size_t)MRW * (C + 8) * 4;
         if (lds < lp) lds = lp;
         if (lds < lo) lds = lo;
     }
