@@ -359,8 +359,20 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
         check(lib().psnd_conv1d_cl_pair(ptr(x), ptr(w), ptr(bias), None, 1.0, 0.1, ptr(mid), ptr(w2), ptr(bias), None, 1.0, ptr(x), N, Lp, Fr,
                                         HP, C, k, -3, 3, -1, 1, 0.1, ptr(out), ptr(act), st), 'psnd_conv1d_cl_pair')
 
+    S2 = lib().psnd_conv1d_cl_pair_bwd_splits(N, Lp, C, k)
+    gwa, gba = torch.empty(S2, k, C, C, device=device), torch.empty(S2, C, device=device)
+    gwb, gbb = torch.empty(S2, k, C, C, device=device), torch.empty(S2, C, device=device)
+    gmid = torch.empty_like(x)
+
+    def bwd_pair2():
+        # the backward of a whole residual pair as it runs in the step (psnd_conv1d_cl_pair_bwd): both input gradients chained on chip +
+        # the weight gradients of the pair's second conv and of the previous pair's first conv: four GEMMs
+        check(lib().psnd_conv1d_cl_pair_bwd(ptr(g1), ptr(w2), ptr(act), 0.1, ptr(gmid), ptr(w), ptr(x), 0.1, ptr(g1), N, Lp, Fr, HP, C, k, 1, 1, 3, 3,
+                                            ptr(gx), ptr(act), ptr(gwa), ptr(gba), ptr(g2), ptr(x), -3, 3, ptr(gwb), ptr(gbb), st),
+              'psnd_conv1d_cl_pair_bwd')
+
     res = {}
-    for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2)):
+    for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2), ('backward_pair2', bwd_pair2, 4)):
         for _ in range(5):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -373,10 +385,11 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
         flops = gemms * 2.0 * N * Fr * C * C * k
         res[name] = {'launch_us': t * 1e6, 'flops_per_launch': flops, 'achieved': flops / t / 1e12, 'frac': flops / t / MFMA_BF16_PEAK}
     return {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK / 1e12, 'dtype': 'bf16 operands, fp32 accumulate',
-            'kernel': 'conv_pair_kernel (two chained 256->256 k=3 convs of a residual pair in one launch: forward_pair) / conv_cl_kernel / '
-                      'conv_bwd_pair_kernel (input + weight gradient of one conv) of the config-2 model - 2.2 GFLOP per conv on 3 MB of '
-                      'activations: latency chains per workgroup, DESIGN.md 4.4',
-            'achieved': res['forward_pair']['achieved'], 'frac': res['forward_pair']['frac'], **res}
+            'kernel': 'conv_pair_bwd_kernel (backward of a residual pair in one launch: both input gradients chained + two weight gradients = '
+                      'four 256->256 k=3 GEMMs: backward_pair2, 36 % of the step) / conv_pair_kernel (forward of a pair: forward_pair) / '
+                      'conv_cl_kernel / conv_bwd_pair_kernel (one conv) of the config-2 model - 2.2 GFLOP per GEMM on 3 MB of activations: '
+                      'latency chains per workgroup, DESIGN.md 4.4',
+            'achieved': res['backward_pair2']['achieved'], 'frac': res['backward_pair2']['frac'], **res}
 
 
 def _event_pair_overhead(device, n=40):
