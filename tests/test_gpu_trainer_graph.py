@@ -11,7 +11,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _run(graph, steps=12, poison_step=None):
+def _run(graph, steps=12, poison_step=None, static=False):
     from pytorch_sound_amd.trainer import Trainer, LogType
     from pytorch_sound_amd.models import build_model
     from pytorch_sound_amd.models import separator  # noqa: F401
@@ -27,10 +27,22 @@ def _run(graph, steps=12, poison_step=None):
         bad[0, 100] = float('nan')
         pool[poison_step - 1] = (bad, pool[poison_step - 1][1])
 
+    from pytorch_sound_amd import kernels as K
+    bufs = {}
+
     class T(Trainer):
+        static_prepare = static
+
         def prepare(self, noisy, clean):
             with torch.no_grad():
-                return stft.magnitude(noisy), stft.magnitude(clean)
+                if not static:
+                    return stft.magnitude(noisy), stft.magnitude(clean)
+                outs = []
+                for name, w in (('a', noisy), ('b', clean)):     # features written into persistent buffers (kernels.stft_forward out_mag=)
+                    if name not in bufs:
+                        bufs[name] = torch.empty((w.shape[0], 513, K.frame_count(w.shape[1], 1024, 256)), device=w.device)
+                    outs.append(K.stft_forward(w, 1024, 256, stft._plan(w.device), out_mag=bufs[name])['mag'])
+                return tuple(outs)
 
         def forward(self, mag_mix, mag_ref, is_logging=False):
             with torch.autocast('cuda', dtype=torch.bfloat16):
@@ -59,6 +71,16 @@ def test_graph_steps_follow_eager_steps():
     for a, b in zip(eager, graph):
         scale = float(a.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 2e-2 * scale     # bf16 model, Adam: a few ulp of bf16 after 12 steps
+
+
+def test_static_prepare_reads_the_features_in_place():
+    """Trainer.static_prepare: prepare() writes into persistent buffers (out_mag=) and returns them every step; the captured graph takes
+    them as its inputs where they are - bit-identical parameters to the run that copies fresh tensors into graph-owned inputs."""
+    a, n0, _ = _run(True)
+    b, n1, _ = _run(True, static=True)
+    assert n0 == 1 and n1 == 1
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_graph_step_skips_nan_on_device():
