@@ -369,28 +369,41 @@ __device__ __forceinline__ void post_emit_pk(v2f (&za)[L], v2f (&zb)[L], bool sp
     });
 }
 
-constexpr int kN1024Sfh = 16 * 16 * 2 + 4;   // exchange frame stride (floats): 516/4 odd -> b128 reads conflict-free,
-                                             // 8*516 = 32 (mod 64) -> the b64 writes of frames fl, fl+8 disjoint
-constexpr int kN1024TabFloats = 2 * 16 * 68 + 516;
-constexpr int kN1024WtOff = 16 * kN1024Sfh - 16 * 68;   // window table at the tail of the exchange area (one-tile mode)
-// exchange area (floats): half of the q-rows for 16 frames, or the tile's waveform span (+ 4 pad floats per 256)
-inline int n1024_area_floats(int hop) {
-    const int span = 15 * hop + 1024;
-    const int spanp = span + 4 * (span / 256 + 1);
-    return spanp > 16 * kN1024Sfh ? spanp : 16 * kN1024Sfh;
-}
+// Geometry of the span-staged kernel for C = R1 x 16 complex points (R1 = 32: n_fft = 1024, R1 = 16: n_fft = 512): a workgroup of
+// 256 threads owns FT = 512 / R1 frames; pass 1 runs in FT / 16 rounds of 16 frames x 16 lanes, pass 2 is one thread per (frame, row pair).
+template <int R1>
+struct SpanGeom {
+    static constexpr int L = 16, C = R1 * L, NFFT = 2 * C, FT = 512 / R1, NR = FT / 16, HR = R1 / 2, ROW = 2 * R1 + 4;
+    static constexpr int VKP = (2 * (C / 2 + 1) + 3) & ~3;
+    static constexpr int SFH = HR * L * 2 + 4;   // exchange frame stride (floats): SFH/4 odd -> b128 reads conflict-free,
+                                                 // 8*SFH = 32 (mod 64) -> the b64 writes of frames fl, fl+8 disjoint
+    static constexpr int TAB = 2 * L * ROW + VKP;
+    static constexpr int WT_OFF = FT * SFH - L * ROW;   // window table at the tail of the exchange area (one-tile mode)
+    static_assert((SFH / 4) % 2 == 1 && (8 * SFH) % 64 == 32, "exchange pitch");
+    // exchange area (floats): half of the q-rows for FT frames, or the tile's waveform span (+ 4 pad floats per 256)
+    static int area_floats(int hop) {
+        const int span = (FT - 1) * hop + NFFT;
+        const int spanp = span + 4 * (span / 256 + 1);
+        return spanp > FT * SFH ? spanp : FT * SFH;
+    }
+};
+constexpr int kN1024Sfh = SpanGeom<32>::SFH;
+constexpr int kN1024TabFloats = SpanGeom<32>::TAB;
+constexpr int kN1024WtOff = SpanGeom<32>::WT_OFF;
+inline int n1024_area_floats(int hop) { return SpanGeom<32>::area_floats(hop); }
 
-template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false>
+template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false, int R1 = 32>
 __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(StftFwdParams p) {
-    static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST), "fused log-mel: magnitude only, one tile per workgroup");
-    constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5;
+    static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST && R1 == 32), "fused log-mel: magnitude only, one tile per workgroup");
+    using G = SpanGeom<R1>;
+    constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1);
     constexpr int HR = R1 / 2;          // rows per exchange half
-    constexpr int SFH = kN1024Sfh;
-    constexpr int TAB = 2 * L * ROW + VKP;
+    constexpr int SFH = G::SFH;
+    constexpr int TAB = G::TAB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // One tile per workgroup (!PERSIST): the window table is only needed before the first exchange write, so
     // it sits in the tail of the exchange area that the span leaves free: 39.4 KB of LDS, 4 workgroups per CU.
-    constexpr int WT_IN_AREA = kN1024WtOff;
+    constexpr int WT_IN_AREA = G::WT_OFF;
     float *s_tw = PERSIST ? smem + L * ROW : smem;
     float *s_vk = s_tw + L * ROW;
     float *s_x = s_vk + VKP;            // exchange [frame][row][l] of (re, im), also the span buffer
@@ -403,10 +416,10 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
     PSND_STAMP(0);
 
     const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);   // pass-1 identity: half-waves hold frames fl, fl+8
-    const int f2 = t & 15;                                      // pass-2 identity
+    const int f2 = t & (FT - 1);                                // pass-2 identity: frame, row pair qq < R1 / 2
     // pairs of a wave: 4 apart (stores: one upward sweep per wave) or, for the LDS magnitude tile of the fused
     // log-mel kernel, consecutive (4 consecutive bins x 16 frames = 64 distinct banks per ds_write)
-    const int qq = FUSE_MEL ? 4 * (t >> 6) + ((t >> 4) & 3) : (t >> 6) + 4 * ((t >> 4) & 3);
+    const int qq = FUSE_MEL ? 4 * (t >> 6) + ((t >> 4) & 3) : (t >> 6) + 4 * ((t & 63) / FT);
     const bool special = (qq == 0);
     const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
     const int rowA = qq, rowB = special ? 0 : HR - qq; // row inside its half
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
         const int clip = tile / p.ntile;
         const long long f0 = (long long)(tile - clip * p.ntile) * FT;
         const bool more = PERSIST && (tile + tw.step < tw.end);
-        v2f z[R1];
+        v2f z[NR][R1];
 #ifdef PSND_TRACE
         psnd_it = (tile - tw.first) / tw.step;
 #endif
@@ -497,35 +510,38 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
         if (PERSIST && (threadIdx.x & 63) == 0 && p.trace && psnd_it == p.trace_iter + 1)   // slot 7 = next tile may start
             p.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
-        {   // taps of lane l of frame fl: samples fl*hop + 2*(l + 16 a) + {0,1}.  Affine addressing: one base
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            // taps of lane l of frame fr = fl + 16 r: samples fr*hop + 2*(l + 16 a) + {0,1}.  Affine addressing: one base
             // per group of 8 taps (the bank skew steps once per 256 samples), immediates inside the group.
-            const int sb = fl * hop + 2 * l;
+            constexpr int r = decltype(rc)::value;
+            const int sb = (fl + 16 * r) * hop + 2 * l;
             const float *tb0 = s_span + sb + skew * (sb >> 8);
             static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 const float *tb = tb0 + g * (256 + skew);
                 static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = 8 * g + decltype(ac)::value;
-                    z[a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
                 });
             });
-        }
+        });
         if (more && (p.ablate & 16)) request_span(tile + tw.step);   // A/B: prefetch a whole tile ahead
         __builtin_amdgcn_sched_barrier(0);
-        {
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
             const float *wrow = s_wt + l * ROW;
             static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-                z[2 * i] *= pk::lo(w);
-                z[2 * i + 1] *= pk::hi(w);
+                z[r][2 * i] *= pk::lo(w);
+                z[r][2 * i + 1] *= pk::hi(w);
                 // at most 4 window pieces (16 VGPRs) in flight: left alone the scheduler hoists all 16 reads
                 if constexpr (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
             });
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        pk::fft<R1>(z);
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            pk::fft<R1>(z[r]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         PSND_STAMP(3);
 
         const float *trow = s_tw + l * ROW;
@@ -537,9 +553,13 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
                 constexpr int q0 = Q0 + 2 * i, q1 = q0 + 1;
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
                 constexpr int s0_ = ct::bitrev(q0, RB), s1_ = ct::bitrev(q1, RB);
-                if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[s0_];
-                else *reinterpret_cast<v2f *>(oz + (q0 - Q0) * 2 * L) = pk::cmul(z[s0_], pk::lo(w));
-                *reinterpret_cast<v2f *>(oz + (q1 - Q0) * 2 * L) = pk::cmul(z[s1_], pk::hi(w));
+                static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+                    constexpr int r = decltype(rc)::value;
+                    float *ozr = oz + 16 * r * SFH;
+                    if constexpr (q0 == 0) *reinterpret_cast<v2f *>(ozr) = z[r][s0_];
+                    else *reinterpret_cast<v2f *>(ozr + (q0 - Q0) * 2 * L) = pk::cmul(z[r][s0_], pk::lo(w));
+                    *reinterpret_cast<v2f *>(ozr + (q1 - Q0) * 2 * L) = pk::cmul(z[r][s1_], pk::hi(w));
+                });
             });
         };
         auto read_row = [&](int row, v2f (&r)[L]) __attribute__((always_inline)) {
@@ -1131,25 +1151,36 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
     return PSND_OK;
 }
 
-int launch_n1024(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
-    size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(p.hop));
+// span-staged kernel: R1 = 32 (n_fft 1024) or 16 (n_fft 512)
+template <int R1>
+bool span_kernel_ok(int hop) {
+    using G = SpanGeom<R1>;
+    const long long span = (long long)(G::FT - 1) * hop + G::NFFT;
+    // taps are 8-byte LDS reads at frame * hop + 2 l; the tile's span (+ bank padding) must fit 8 pieces per thread and 64 KB
+    return hop % 2 == 0 && span <= 8 * 1024 && sizeof(float) * (size_t)(G::TAB + G::area_floats(hop)) <= 64 * 1024;
+}
+
+template <int R1>
+int launch_span(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
+    using G = SpanGeom<R1>;
+    size_t lds = sizeof(float) * (size_t)(G::TAB + G::area_floats(p.hop));
     int grid = p.total_tiles;
     int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
                              // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
     if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
     if (grid > cap) grid = cap;
     grid = (grid + 7) & ~7;
-    // one tile per workgroup needs hop <= 256 (5 span pieces per thread, span + window table inside the exchange area)
-    const bool persist = grid < p.total_tiles || 15 * p.hop + 1024 > 5 * 1024 ||
-                         15 * p.hop + 1024 + 4 * ((15 * p.hop + 1024) / 256 + 1) > kN1024WtOff;
-    if (!persist) lds -= sizeof(float) * 16 * 68;
+    // one tile per workgroup needs 5 span pieces per thread and span + window table inside the exchange area (n = 1024: hop <= 256)
+    const int span = (G::FT - 1) * p.hop + G::NFFT;
+    const bool persist = grid < p.total_tiles || span > 5 * 1024 || span + 4 * (span / 256 + 1) > G::WT_OFF;
+    if (!persist) lds -= sizeof(float) * G::L * G::ROW;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                          \
     do {                                                                                                                 \
-        if (15 * p.hop + 1024 <= 5 * 1024) {                                                                             \
-            if (persist) hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, true>), dim3(grid), dim3(256), lds, stream, p);  \
-            else hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, false>), dim3(grid), dim3(256), lds, stream, p);         \
+        if (span <= 5 * 1024) {                                                                                          \
+            if (persist) hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, true, false, R1>), dim3(grid), dim3(256), lds, stream, p);  \
+            else hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, false, false, R1>), dim3(grid), dim3(256), lds, stream, p);         \
         } else {                                                                                                         \
-            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8, true>), dim3(grid), dim3(256), lds, stream, p);     \
+            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8, true, false, R1>), dim3(grid), dim3(256), lds, stream, p);     \
         }                                                                                                                \
     } while (0)
     if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
@@ -1158,7 +1189,7 @@ int launch_n1024(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
     else if (mag && !phase && reim) PSND_LAUNCH(true, false, true);
     else PSND_LAUNCH(true, true, true);
 #undef PSND_LAUNCH
-    PSND_CHECK_LAUNCH("stft_fwd(n1024)");
+    PSND_CHECK_LAUNCH("stft_fwd(span)");
     return PSND_OK;
 }
 
@@ -1277,14 +1308,15 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
         switch (n_fft) {
             case 256: return launch_tuned<16, 8>(p, mag, phase, re, s);
-            case 512: return launch_tuned<16, 16>(p, mag, phase, re, s);
+            case 512:
+                // span-staged packed kernel (32 frames per workgroup, two pass-1 rounds); odd hops take the two-pass kernel
+                if (!span_kernel_ok<16>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<16, 16>(p, mag, phase, re, s);
+                return launch_span<16>(p, mag, phase, re, s);
             case 1024: {
                 // span-staged kernel: hop multiple of 4 and the tile's span (+ bank padding) must fit the
                 // exchange area; anything else takes the generic two-pass kernel
-                const long long span = 15ll * hop + 1024;
-                const bool span_ok = (hop % 4 == 0) && (sizeof(float) * (kN1024TabFloats + n1024_area_floats(hop)) <= 64 * 1024) && span <= 8 * 1024;
-                if (!span_ok || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
-                return launch_n1024(p, mag, phase, re, s);
+                if (hop % 4 != 0 || !span_kernel_ok<32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
+                return launch_span<32>(p, mag, phase, re, s);
             }
             case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
         }

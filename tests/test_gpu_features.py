@@ -62,6 +62,15 @@ CASES = [
     (1024, 256, None, 0, 1, 513),         # minimum-ish T (> pad): every frame touches an edge
     (1024, 256, None, 0, 33, 2600),       # many clips, partial last tile
 ]
+# n_fft = 512 on the span-staged kernel (32 frames per workgroup, two pass-1 rounds)
+N512_CASES = [
+    (512, 50, 240, 0, 3, 5000),           # multi_stft_loss resolution (sound.py:106-133): even hop, not a multiple of 4
+    (512, 128, None, 0, 40, 2600),        # many clips, partial last tile (F = 21 of 32)
+    (512, 200, None, 1, 2, 9000),         # span of 32 frames > 5 K samples: persistent variant, 8 span pieces
+    (512, 129, None, 0, 2, 3000),         # odd hop -> two-pass kernel
+    (512, 128, None, 0, 1, 257),          # T barely above the reflect pad
+]
+CASES += N512_CASES
 
 
 @pytest.mark.parametrize('n_fft,hop,win,framing,N,T', CASES)
@@ -74,7 +83,7 @@ def test_stft_mag_vs_oracle(n_fft, hop, win, framing, N, T):
     assert np.abs(got - ref).max() <= tol
 
 
-@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9])
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9] + N512_CASES)
 def test_stft_reim_phase_vs_oracle(n_fft, hop, win, framing, N, T):
     wav = seeded_wav(3 * n_fft + T, N, T)
     got = _stft(wav, n_fft, hop, win, framing, want_mag=True, want_phase=True, want_reim=True)
