@@ -369,11 +369,13 @@ __device__ __forceinline__ void post_emit_pk(v2f (&za)[L], v2f (&zb)[L], bool sp
     });
 }
 
-// Geometry of the span-staged kernel for C = R1 x 16 complex points (R1 = 32: n_fft = 1024, R1 = 16: n_fft = 512): a workgroup of
-// 256 threads owns FT = 512 / R1 frames; pass 1 runs in FT / 16 rounds of 16 frames x 16 lanes, pass 2 is one thread per (frame, row pair).
-template <int R1>
+// Geometry of the span-staged kernel for C = R1 x L complex points ((32, 16): n_fft = 1024, (16, 16): 512, (32, 32): 2048): a
+// workgroup of 256 threads owns FT = 512 / R1 frames; pass 1 runs in rounds of FPR = 256 / L frames x L lanes, pass 2 is one thread
+// per (frame, row pair).
+template <int R1, int L_ = 16>
 struct SpanGeom {
-    static constexpr int L = 16, C = R1 * L, NFFT = 2 * C, FT = 512 / R1, NR = FT / 16, HR = R1 / 2, ROW = 2 * R1 + 4;
+    static constexpr int L = L_, C = R1 * L, NFFT = 2 * C, FT = 512 / R1, FPR = 256 / L, NR = FT / FPR, HR = R1 / 2, ROW = 2 * R1 + 4;
+    static constexpr int TPB = 256 / (2 * L);    // taps of a lane inside one 256-sample block of the span
     static constexpr int VKP = (2 * (C / 2 + 1) + 3) & ~3;
     static constexpr int SFH = HR * L * 2 + 4;   // exchange frame stride (floats): SFH/4 odd -> b128 reads conflict-free,
                                                  // 8*SFH = 32 (mod 64) -> the b64 writes of frames fl, fl+8 disjoint
@@ -392,11 +394,11 @@ constexpr int kN1024TabFloats = SpanGeom<32>::TAB;
 constexpr int kN1024WtOff = SpanGeom<32>::WT_OFF;
 inline int n1024_area_floats(int hop) { return SpanGeom<32>::area_floats(hop); }
 
-template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false, int R1 = 32>
-__global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(StftFwdParams p) {
-    static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST && R1 == 32), "fused log-mel: magnitude only, one tile per workgroup");
-    using G = SpanGeom<R1>;
-    constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1);
+template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false, int R1 = 32, int L_ = 16>
+__global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fwd_n1024_kernel(StftFwdParams p) {
+    static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST && R1 == 32 && L_ == 16), "fused log-mel: magnitude only, one tile per workgroup");
+    using G = SpanGeom<R1, L_>;
+    constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, FPR = G::FPR, TPB = G::TPB, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1);
     constexpr int HR = R1 / 2;          // rows per exchange half
     constexpr int SFH = G::SFH;
     constexpr int TAB = G::TAB;
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
 #endif
     PSND_STAMP(0);
 
-    const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);   // pass-1 identity: half-waves hold frames fl, fl+8
+    // pass-1 identity.  L = 16: half-waves hold frames fl, fl+8; L = 32: a half-wave is the 32 lanes of one frame
+    const int l = t & (L - 1), fl = L == 16 ? ((t >> 4) & 1) * 8 + (t >> 5) : (t >> 5);
     const int f2 = t & (FT - 1);                                // pass-2 identity: frame, row pair qq < R1 / 2
     // pairs of a wave: 4 apart (stores: one upward sweep per wave) or, for the LDS magnitude tile of the fused
     // log-mel kernel, consecutive (4 consecutive bins x 16 frames = 64 distinct banks per ds_write)
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
     const int hop = p.hop;
     const int span_len = (FT - 1) * hop + NFFT;        // samples a tile touches
     // span position of sample s: s + skew * (s / 256)
-    const int skew = (hop % 256 == 0) ? 4 : 0;
+    const int skew = (L == 16 && hop % 256 == 0) ? 4 : 0;
 
     // The span of tile t+1 is REQUESTED (into SPV registers) before the stores of tile t are issued:
     // gfx9 has one in-order vmcnt for loads and stores, so a wait for loads issued AFTER the stores
@@ -511,17 +514,17 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
             p.trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
-            // taps of lane l of frame fr = fl + 16 r: samples fr*hop + 2*(l + 16 a) + {0,1}.  Affine addressing: one base
-            // per group of 8 taps (the bank skew steps once per 256 samples), immediates inside the group.
+            // taps of lane l of frame fr = fl + FPR r: samples fr*hop + 2*(l + L a) + {0,1}.  Affine addressing: one base
+            // per group of TPB taps (the bank skew steps once per 256 samples), immediates inside the group.
             constexpr int r = decltype(rc)::value;
-            const int sb = (fl + 16 * r) * hop + 2 * l;
+            const int sb = (fl + FPR * r) * hop + 2 * l;
             const float *tb0 = s_span + sb + skew * (sb >> 8);
-            static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
+            static_for<0, R1 / TPB>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 const float *tb = tb0 + g * (256 + skew);
-                static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
-                    constexpr int a = 8 * g + decltype(ac)::value;
-                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+                static_for<0, TPB>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = TPB * g + decltype(ac)::value;
+                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - TPB * g));
                 });
             });
         });
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256, PERSIST ? 3 : 4) void stft_fwd_n1024_kernel(St
                 constexpr int s0_ = ct::bitrev(q0, RB), s1_ = ct::bitrev(q1, RB);
                 static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = decltype(rc)::value;
-                    float *ozr = oz + 16 * r * SFH;
+                    float *ozr = oz + FPR * r * SFH;
                     if constexpr (q0 == 0) *reinterpret_cast<v2f *>(ozr) = z[r][s0_];
                     else *reinterpret_cast<v2f *>(ozr + (q0 - Q0) * 2 * L) = pk::cmul(z[r][s0_], pk::lo(w));
                     *reinterpret_cast<v2f *>(ozr + (q1 - Q0) * 2 * L) = pk::cmul(z[r][s1_], pk::hi(w));
@@ -1151,36 +1154,53 @@ int launch_tuned(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
     return PSND_OK;
 }
 
-// span-staged kernel: R1 = 32 (n_fft 1024) or 16 (n_fft 512)
-template <int R1>
+// span-staged kernel: (R1, L) = (32, 16) n_fft 1024, (16, 16) n_fft 512, (32, 32) n_fft 2048
+template <int R1, int L = 16>
 bool span_kernel_ok(int hop) {
-    using G = SpanGeom<R1>;
+    using G = SpanGeom<R1, L>;
     const long long span = (long long)(G::FT - 1) * hop + G::NFFT;
-    // taps are 8-byte LDS reads at frame * hop + 2 l; the tile's span (+ bank padding) must fit 8 pieces per thread and 64 KB
+    // taps are 8-byte LDS reads at frame * hop + 2 l; the tile's span (+ bank padding) must fit the span pieces of a thread and the
+    // exchange area (L = 32: one tile per workgroup, the window table rides in the tail of the area)
+    if (L == 32) return hop % 2 == 0 && span <= 10 * 1024 && span + 4 * (span / 256 + 1) <= G::WT_OFF;
     return hop % 2 == 0 && span <= 8 * 1024 && sizeof(float) * (size_t)(G::TAB + G::area_floats(hop)) <= 64 * 1024;
 }
 
-template <int R1>
+template <class K>
+int span_launch_one(K kern, int grid, size_t lds, hipStream_t stream, const StftFwdParams &p) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_fwd(span): set LDS size: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return PSND_OK;
+}
+
+template <int R1, int L = 16>
 int launch_span(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
-    using G = SpanGeom<R1>;
+    using G = SpanGeom<R1, L>;
     size_t lds = sizeof(float) * (size_t)(G::TAB + G::area_floats(p.hop));
     int grid = p.total_tiles;
     int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
                              // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
     if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
+    if (L == 32) cap = 1 << 30;
     if (grid > cap) grid = cap;
     grid = (grid + 7) & ~7;
     // one tile per workgroup needs 5 span pieces per thread and span + window table inside the exchange area (n = 1024: hop <= 256)
     const int span = (G::FT - 1) * p.hop + G::NFFT;
-    const bool persist = grid < p.total_tiles || span > 5 * 1024 || span + 4 * (span / 256 + 1) > G::WT_OFF;
+    const bool persist = L == 16 && (grid < p.total_tiles || span > 5 * 1024 || span + 4 * (span / 256 + 1) > G::WT_OFF);
     if (!persist) lds -= sizeof(float) * G::L * G::ROW;
+    int rc = PSND_OK;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                          \
     do {                                                                                                                 \
-        if (span <= 5 * 1024) {                                                                                          \
-            if (persist) hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, true, false, R1>), dim3(grid), dim3(256), lds, stream, p);  \
-            else hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 5, false, false, R1>), dim3(grid), dim3(256), lds, stream, p);         \
+        if constexpr (L == 32) {                                                                                         \
+            if (span <= 6 * 1024) rc = span_launch_one(stft_fwd_n1024_kernel<M_, P_, R_, 6, false, false, R1, L>, grid, lds, stream, p);   \
+            else rc = span_launch_one(stft_fwd_n1024_kernel<M_, P_, R_, 10, false, false, R1, L>, grid, lds, stream, p); \
+        } else if (span <= 5 * 1024) {                                                                                   \
+            if (persist) rc = span_launch_one(stft_fwd_n1024_kernel<M_, P_, R_, 5, true, false, R1, L>, grid, lds, stream, p);  \
+            else rc = span_launch_one(stft_fwd_n1024_kernel<M_, P_, R_, 5, false, false, R1, L>, grid, lds, stream, p);  \
         } else {                                                                                                         \
-            hipLaunchKernelGGL((stft_fwd_n1024_kernel<M_, P_, R_, 8, true, false, R1>), dim3(grid), dim3(256), lds, stream, p);     \
+            rc = span_launch_one(stft_fwd_n1024_kernel<M_, P_, R_, 8, true, false, R1, L>, grid, lds, stream, p);        \
         }                                                                                                                \
     } while (0)
     if (mag && !phase && !reim) PSND_LAUNCH(true, false, false);
@@ -1189,6 +1209,7 @@ int launch_span(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStre
     else if (mag && !phase && reim) PSND_LAUNCH(true, false, true);
     else PSND_LAUNCH(true, true, true);
 #undef PSND_LAUNCH
+    if (rc != PSND_OK) return rc;
     PSND_CHECK_LAUNCH("stft_fwd(span)");
     return PSND_OK;
 }
@@ -1318,7 +1339,10 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
                 if (hop % 4 != 0 || !span_kernel_ok<32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
                 return launch_span<32>(p, mag, phase, re, s);
             }
-            case 2048: return launch_tuned<32, 32>(p, mag, phase, re, s);
+            case 2048:
+                // span-staged packed kernel, 32-point second pass: 2 workgroups per CU (78.6 KB of LDS, ~200 VGPRs)
+                if (!span_kernel_ok<32, 32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 32>(p, mag, phase, re, s);
+                return launch_span<32, 32>(p, mag, phase, re, s);
         }
     }
     if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {

@@ -378,8 +378,18 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
 // LDS: tables + one FULL exchange [16 frames][32 rows][16 l] of (re, im) (65.8 KB); the forward span, the forward
 // exchange, the adjoint exchange and the overlap-add span all live in it, one after the other.
 // ---------------------------------------------------------------------------------------------
-constexpr int kB1024Sf = 32 * 16 * 2 + 4;        // exchange frame stride (floats): 1028/4 odd, 8*1028 = 32 (mod 64)
-constexpr int kB1024LdsFloats = 2 * 16 * 68 + 516 + 16 * kB1024Sf;
+// Geometry for C = R1 x 16 complex points (R1 = 32: n_fft = 1024, 16 frames per workgroup; R1 = 16: n_fft = 512, 32 frames in two
+// lane-pass rounds), as SpanGeom of psnd_stft.hip but with the FULL exchange.
+template <int R1>
+struct BwdGeom {
+    static constexpr int L = 16, C = R1 * L, NFFT = 2 * C, FT = 512 / R1, NR = FT / 16, ROW = 2 * R1 + 4;
+    static constexpr int VKP = (2 * (C / 2 + 1) + 3) & ~3;
+    static constexpr int SF = R1 * L * 2 + 4;     // exchange frame stride (floats): SF/4 odd, 8*SF = 32 (mod 64)
+    static constexpr int TAB = 2 * L * ROW + VKP;
+    static constexpr int LDS_FLOATS = TAB + FT * SF;
+    static_assert((SF / 4) % 2 == 1 && (8 * SF) % 64 == 32, "exchange pitch");
+};
+constexpr int kB1024LdsFloats = BwdGeom<32>::LDS_FLOATS;
 
 // ISTFT = true: the same kernel as the inverse transform of psnd_istft - no forward recompute, the "gradient" is the spectrum
 // mag * e^{i phase} scaled to make the adjoint the inverse real DFT, and the overlap-added signal is divided by the squared-
@@ -394,15 +404,16 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs) {
     cs = __builtin_amdgcn_cosf(f);
 }
 
-template <bool ISTFT>
+template <bool ISTFT, int R1 = 32>
 __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParams p) {
-    constexpr int R1 = 32, L = 16, C = 512, NFFT = 1024, FT = 16, ROW = 2 * R1 + 4, VKP = 516, RB = 5, LB = 4, SF = kB1024Sf;
-    constexpr int TAB = 2 * L * ROW + VKP;
+    using G = BwdGeom<R1>;
+    constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1), LB = 4, SF = G::SF;
+    constexpr int TAB = G::TAB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wt = smem, *s_tw = s_wt + L * ROW, *s_vk = s_tw + L * ROW, *s_x = s_vk + VKP;
     const int t = threadIdx.x;
     const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);     // lane identity (passes over a): half-waves hold frames fl, fl+8
-    const int f2 = t & 15, qq = (t >> 6) + 4 * ((t >> 4) & 3);    // pair identity (passes over l)
+    const int f2 = t & (FT - 1), qq = (t >> 6) + 4 * ((t & 63) / FT);    // pair identity (passes over l): frame, row pair < R1 / 2
     const bool special = (qq == 0);
     const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
     const int hop = p.hop;
@@ -471,35 +482,41 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
 
     // ---- forward pass 1 (recompute X): taps, window, radix-32, twiddle, all 32 rows to the exchange -------------------
     if constexpr (!ISTFT) {
-        v2f z[R1];
-        const int sb = fl * hop + 2 * l;
-        const float *tb0 = s_x + sb + skew * (sb >> 8);
-        static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            const float *tb = tb0 + g * (256 + skew);
-            static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
-                constexpr int a = 8 * g + decltype(ac)::value;
-                z[a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+        v2f z[NR][R1];
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            const int sb = (fl + 16 * r) * hop + 2 * l;
+            const float *tb0 = s_x + sb + skew * (sb >> 8);
+            static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                const float *tb = tb0 + g * (256 + skew);
+                static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = 8 * g + decltype(ac)::value;
+                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+                });
             });
+            const float *wrow = s_wt + l * ROW;
+            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+                z[r][2 * i] *= pk::lo(w);
+                z[r][2 * i + 1] *= pk::hi(w);
+                if constexpr (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            });
+            pk::fft<R1>(z[r]);
         });
-        const float *wrow = s_wt + l * ROW;
-        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-            z[2 * i] *= pk::lo(w);
-            z[2 * i + 1] *= pk::hi(w);
-            if constexpr (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
-        });
-        pk::fft<R1>(z);
         __syncthreads();                             // every lane holds its taps: the span area becomes the exchange
         const float *trow = s_tw + l * ROW;
-        float *oz = s_x + fl * SF + 2 * l;
-        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int q0 = 2 * decltype(ic)::value, q1 = q0 + 1;
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
-            if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[0];
-            else *reinterpret_cast<v2f *>(oz + q0 * 2 * L) = pk::cmul(z[ct::bitrev(q0, RB)], pk::lo(w));
-            *reinterpret_cast<v2f *>(oz + q1 * 2 * L) = pk::cmul(z[ct::bitrev(q1, RB)], pk::hi(w));
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            float *oz = s_x + (fl + 16 * r) * SF + 2 * l;
+            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int q0 = 2 * decltype(ic)::value, q1 = q0 + 1;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
+                if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[r][0];
+                else *reinterpret_cast<v2f *>(oz + q0 * 2 * L) = pk::cmul(z[r][ct::bitrev(q0, RB)], pk::lo(w));
+                *reinterpret_cast<v2f *>(oz + q1 * 2 * L) = pk::cmul(z[r][ct::bitrev(q1, RB)], pk::hi(w));
+            });
         });
         __syncthreads();
     }
@@ -634,32 +651,36 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
 
     // ---- lane threads: inverse radix-32 over q, window, overlap-add of the tile in LDS, one pass over the span ---------
     {
-        v2f z[R1];
-        const float *iz = s_x + fl * SF + 2 * l;
-        static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
-            constexpr int q = decltype(qc)::value;
-            z[ct::bitrev(q, RB)] = *reinterpret_cast<const v2f *>(iz + q * 2 * L);
-        });
-        pk::fft_dit<R1, 1>(z);                                        // z[l + 16 a] in slot a
-        const float *wrow = s_wt + l * ROW;
-        static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-            z[2 * i] *= pk::lo(w);
-            z[2 * i + 1] *= pk::hi(w);
+        v2f z[NR][R1];
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            const float *iz = s_x + (fl + 16 * r) * SF + 2 * l;
+            static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                z[r][ct::bitrev(q, RB)] = *reinterpret_cast<const v2f *>(iz + q * 2 * L);
+            });
+            pk::fft_dit<R1, 1>(z[r]);                                 // z[l + 16 a] in slot a
+            const float *wrow = s_wt + l * ROW;
+            static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+                z[r][2 * i] *= pk::lo(w);
+                z[r][2 * i + 1] *= pk::hi(w);
+            });
         });
         __syncthreads();                             // exchange consumed: it takes the frames' time samples Y[frame][m]
         PSND_BSTAMP(4);
         // Overlap-add WITHOUT LDS atomics: ds_add_f32 retires about one lane per 12 cycles on gfx950 (measured: the 64
         // atomics of a thread were 51 k of the workgroup's 126 k cycles and stalled the co-resident workgroup's LDS
         // traffic as well).  Every lane parks its 64 windowed samples, then each span sample gathers its <= n/hop frames.
-        {
-            float *yo = s_x + fl * SF + 2 * l;
+        static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            float *yo = s_x + (fl + 16 * r) * SF + 2 * l;
             static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                 constexpr int a = decltype(ac)::value;
-                *reinterpret_cast<v2f *>(yo + 2 * L * a) = z[a];
+                *reinterpret_cast<v2f *>(yo + 2 * L * a) = z[r][a];
             });
-        }
+        });
         __syncthreads();
         PSND_BSTAMP(5);
         const int t_start = (int)(f0 * hop - p.pad);               // clips are shorter than 2^31 samples (checked on the host)
@@ -1168,7 +1189,17 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
         switch (n_fft) {
             case 256: return launch_bwd<16, 8>(p, gmag, gre, s);
-            case 512: return launch_bwd<16, 16>(p, gmag, gre, s);
+            case 512:
+                if (gmag && !gre && hop % 2 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
+                    constexpr size_t lds = sizeof(float) * BwdGeom<16>::LDS_FLOATS;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<false, 16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e));
+                    hipLaunchKernelGGL((stft_bwd_n1024_mag_kernel<false, 16>), dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
+                    PSND_CHECK_LAUNCH("stft_bwd(n512, mag)");
+                    return PSND_OK;
+                }
+                return launch_bwd<16, 16>(p, gmag, gre, s);
             case 1024:
                 if (gmag && !gre && hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
                     constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
@@ -1237,7 +1268,17 @@ extern "C" int psnd_istft(const float *mag, const float *phase, int64_t N, int64
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
         switch (n_fft) {
             case 256: return launch_istft<16, 8>(p, s);
-            case 512: return launch_istft<16, 16>(p, s);
+            case 512:
+                if (hop % 2 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
+                    constexpr size_t lds = sizeof(float) * BwdGeom<16>::LDS_FLOATS;
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<true, 16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: set LDS size: %s", hipGetErrorString(e));
+                    hipLaunchKernelGGL((stft_bwd_n1024_mag_kernel<true, 16>), dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
+                    PSND_CHECK_LAUNCH("istft(n512)");
+                    return PSND_OK;
+                }
+                return launch_istft<16, 16>(p, s);
             case 1024:
                 if (hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
                     constexpr size_t lds = sizeof(float) * kB1024LdsFloats;

@@ -70,7 +70,15 @@ N512_CASES = [
     (512, 129, None, 0, 2, 3000),         # odd hop -> two-pass kernel
     (512, 128, None, 0, 1, 257),          # T barely above the reflect pad
 ]
-CASES += N512_CASES
+# n_fft = 2048 on the span-staged kernel (16 frames per workgroup, two pass-1 rounds of 8 frames, 32-point second pass)
+N2048_CASES = [
+    (2048, 240, 1200, 0, 3, 9000),        # multi_stft_loss resolution
+    (2048, 512, None, 0, 20, 20000),      # many clips, partial last tile, 10 span pieces per thread
+    (2048, 546, None, 1, 2, 30000),       # the largest span that fits (15 * 546 + 2048 = 10238 samples)
+    (2048, 600, None, 0, 1, 20000),       # span too long -> two-pass kernel
+    (2048, 512, None, 0, 1, 1025),        # T barely above the reflect pad
+]
+CASES += N512_CASES + N2048_CASES
 
 
 @pytest.mark.parametrize('n_fft,hop,win,framing,N,T', CASES)
@@ -83,7 +91,7 @@ def test_stft_mag_vs_oracle(n_fft, hop, win, framing, N, T):
     assert np.abs(got - ref).max() <= tol
 
 
-@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9] + N512_CASES)
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9] + N512_CASES + N2048_CASES[:3])
 def test_stft_reim_phase_vs_oracle(n_fft, hop, win, framing, N, T):
     wav = seeded_wav(3 * n_fft + T, N, T)
     got = _stft(wav, n_fft, hop, win, framing, want_mag=True, want_phase=True, want_reim=True)
@@ -311,7 +319,11 @@ BWD_CASES = [
     (1024, 256, 800, 1, 2, 4096),
     (1024, 300, None, 0, 1, 5000),
     (1024, 2000, None, 0, 1, 9000),       # hop > n_fft: span does not fit -> direct atomics path
-    (512, 128, None, 0, 2, 3000),         # two pass-1 rounds: direct atomics path
+    (512, 128, None, 0, 2, 3000),         # magnitude gradient: span kernel with two lane-pass rounds; (re, im): two-pass kernel
+    (512, 50, 240, 0, 3, 5000),           # multi_stft_loss resolution: ten frames per sample, hop not a multiple of 4
+    (512, 128, None, 0, 40, 2600),        # many clips, partial last tile
+    (512, 200, None, 1, 2, 9000),         # hop does not divide n_fft
+    (512, 129, None, 0, 2, 3000),         # odd hop -> two-pass kernel
     (256, 64, 200, 1, 3, 1500),
     (2048, 512, None, 0, 1, 6000),
     (4096, 1024, None, 0, 1, 9000),       # magnitude gradient: adjoint of the 4-frame n4096 kernel; (re, im): generic path
@@ -394,6 +406,7 @@ def test_stft_adjoint_identity_full_size():
 # inverse STFT - psnd_istft (STFT.inverse, "next" row f1) and the no-padding framing it needs
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('n_fft,hop,win,N,T', [(1024, 256, None, 2, 4096), (1024, 256, 800, 2, 2816), (512, 128, None, 3, 1024),
+                                               (512, 128, None, 2, 9000), (512, 64, 300, 2, 5000),
                                                (256, 64, 200, 2, 640), (2048, 512, None, 1, 6144), (4096, 1024, None, 1, 8192),
                                                (1024, 256, None, 5, 9000)])
 def test_istft_vs_oracle_and_roundtrip(n_fft, hop, win, N, T):

@@ -8,7 +8,7 @@ from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
 dev = torch.device('cuda:0')
 def hann(n):
     m = np.arange(n); return (0.5 - 0.5*np.cos(2*np.pi*m/n)).astype(np.float32)
-for n, h, N, T in [(4096, 1024, 4, 1323000), (4096, 1024, 32, 1323000), (2048, 512, 64, 1323000), (1024, 256, 1024, 44100), (512, 128, 1024, 44100), (512, 50, 1024, 16384), (256, 64, 1024, 44100)]:
+for n, h, N, T in [(4096, 1024, 4, 1323000), (4096, 1024, 32, 1323000), (2048, 512, 64, 1323000), (2048, 240, 1024, 16384), (1024, 256, 1024, 44100), (512, 128, 1024, 44100), (512, 50, 1024, 16384), (256, 64, 1024, 44100)]:
     wav = torch.randn(N, T, device=dev) * 0.07
     plan = K.stft_plan(n, hann(n)).to(dev)
     F = K.frame_count(T, n, h); Kb = n // 2 + 1
