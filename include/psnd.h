@@ -314,6 +314,16 @@ int psnd_stft_loss_final(const double *const *parts, const int64_t *KF, int L, i
                          void *stream);
 int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_t KF, float eps, const float *norms,
                        const float *g3, int L, float *gp, float *gt, void *stream);
+/*  psnd_stft_bwd_msl: psnd_stft_loss_bwd (gp only) FUSED into psnd_stft_bwd for one resolution - the gradient of multi_stft_loss
+ *      w.r.t. the predicted waveform in one launch: the adjoint recomputes |X| of `wav` (the prediction), forms
+ *      d loss / d |X| = k1 (|X| - t) + c_mag sign(|X| - t) / (|X| + eps) from it and the target magnitudes t_mag (N, K, F) in
+ *      registers (the magnitude gradient never exists in HBM) and continues as psnd_stft_bwd.  norms / g3 / L / eps as
+ *      psnd_stft_loss_bwd; gwav (N, T) fully overwritten.  psnd_stft_bwd_msl_supported(n_fft, hop): 1 where the span-staged
+ *      adjoint runs (n_fft 512 / 1024 / 2048, even hop up to n/2 resp. 256), else callers use the two-launch path. */
+int psnd_stft_bwd_msl_supported(int n_fft, int hop);
+int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan,
+                      float mag_eps, const float *t_mag, const float *norms, const float *g3, int L, float eps,
+                      float *gwav, void *stream);
 
 /* ---- data/dataset.py:196-250, SpeechDataLoader.pad_collate_fn on the audio column, device side --------------------
  *  flat : the batch's clips back to back (device, fp32); offs[n], lens[n] : start / length of clip n in flat (device

@@ -78,6 +78,8 @@ SIGNATURES = {
     'psnd_stft_loss_partial': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
     'psnd_stft_loss_final': (_INT, [_P, _P, _INT, _I64, _P, _P, _P]),
     'psnd_stft_loss_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P, _INT, _P, _P, _P]),
+    'psnd_stft_bwd_msl_supported': (_INT, [_INT, _INT]),
+    'psnd_stft_bwd_msl': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _INT, _F, _P, _P]),
     'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     'psnd_adam_chunk': (_I64, []),
     'psnd_adam_table_bytes': (_I64, []),

@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 121; }  // 0.1.21: + psnd_conv1d_cl_pair (two chained convs per launch)
+extern "C" int psnd_version(void) { return 122; }  // 0.1.22: + psnd_stft_bwd_msl (multi_stft_loss gradient fused into the adjoint STFT)
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 

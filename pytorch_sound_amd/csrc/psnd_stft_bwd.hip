@@ -31,6 +31,10 @@ struct StftBwdParams {
     // inverse-STFT mode (psnd_istft): gmag = magnitude, gre = phase, gwav = output (N, T = (F-1)*hop)
     int win_off;        // float offset of the raw window inside the plan
     float inv_n, env_eps;
+    // multi_stft_loss mode (psnd_stft_bwd_msl): gmag = TARGET magnitudes; the gradient of the loss w.r.t. the magnitude is formed
+    // from the recomputed |X| inside the kernel (loss_bwd_kernel of psnd_loss.hip): norms = (||t - p||, ||t||) per clip, g = upstream
+    const float *msl_norms, *msl_g;
+    float msl_invLN, msl_invLNKF, msl_eps;
 #ifdef PSND_TRACE
     long long *trace;
 #endif
@@ -380,16 +384,18 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(StftBwdParams p) {
 // ---------------------------------------------------------------------------------------------
 // Geometry for C = R1 x 16 complex points (R1 = 32: n_fft = 1024, 16 frames per workgroup; R1 = 16: n_fft = 512, 32 frames in two
 // lane-pass rounds), as SpanGeom of psnd_stft.hip but with the FULL exchange.
-template <int R1>
+// (32, 32): n_fft = 2048 - 512 threads (one lane-pass round of 16 frames x 32 lanes; the 256 pair threads are waves 0..3), the full
+// exchange of 16 frames is 131 KB: one workgroup of 8 waves per CU.
+template <int R1, int L_ = 16>
 struct BwdGeom {
-    static constexpr int L = 16, C = R1 * L, NFFT = 2 * C, FT = 512 / R1, NR = FT / 16, ROW = 2 * R1 + 4;
+    static constexpr int L = L_, NT = L == 32 ? 512 : 256;
+    static constexpr int C = R1 * L, NFFT = 2 * C, FT = 512 / R1, FPR = NT / L, NR = FT / FPR, ROW = 2 * R1 + 4, TPB = 256 / (2 * L);
     static constexpr int VKP = (2 * (C / 2 + 1) + 3) & ~3;
     static constexpr int SF = R1 * L * 2 + 4;     // exchange frame stride (floats): SF/4 odd, 8*SF = 32 (mod 64)
     static constexpr int TAB = 2 * L * ROW + VKP;
     static constexpr int LDS_FLOATS = TAB + FT * SF;
     static_assert((SF / 4) % 2 == 1 && (8 * SF) % 64 == 32, "exchange pitch");
 };
-constexpr int kB1024LdsFloats = BwdGeom<32>::LDS_FLOATS;
 
 // ISTFT = true: the same kernel as the inverse transform of psnd_istft - no forward recompute, the "gradient" is the spectrum
 // mag * e^{i phase} scaled to make the adjoint the inverse real DFT, and the overlap-added signal is divided by the squared-
@@ -404,21 +410,26 @@ __device__ __forceinline__ void fast_sincos(float x, float &sn, float &cs) {
     cs = __builtin_amdgcn_cosf(f);
 }
 
-template <bool ISTFT, int R1 = 32>
-__global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParams p) {
-    using G = BwdGeom<R1>;
-    constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1), LB = 4, SF = G::SF;
+template <bool ISTFT, int R1 = 32, int L_ = 16, bool MSL = false>
+__global__ __launch_bounds__((L_ == 32 ? 512 : 256), (L_ == 32 ? 1 : 2)) void stft_bwd_n1024_mag_kernel(StftBwdParams p) {
+    static_assert(!(ISTFT && MSL), "the fused loss gradient is a mode of the STFT adjoint");
+    using G = BwdGeom<R1, L_>;
+    constexpr int L = G::L, NT = G::NT, C = G::C, NFFT = G::NFFT, FT = G::FT, FPR = G::FPR, NR = G::NR, TPB = G::TPB, ROW = G::ROW, VKP = G::VKP;
+    constexpr int RB = ct::ilog2(R1), LB = ct::ilog2(L), SF = G::SF;
     constexpr int TAB = G::TAB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wt = smem, *s_tw = s_wt + L * ROW, *s_vk = s_tw + L * ROW, *s_x = s_vk + VKP;
     const int t = threadIdx.x;
-    const int l = t & 15, fl = ((t >> 4) & 1) * 8 + (t >> 5);     // lane identity (passes over a): half-waves hold frames fl, fl+8
-    const int f2 = t & (FT - 1), qq = (t >> 6) + 4 * ((t & 63) / FT);    // pair identity (passes over l): frame, row pair < R1 / 2
+    // lane identity (passes over a).  L = 16: half-waves hold frames fl, fl+8; L = 32: a half-wave is the 32 lanes of one frame
+    const int l = t & (L - 1), fl = L == 16 ? ((t >> 4) & 1) * 8 + (t >> 5) : (t >> 5);
+    // pair identity (passes over l): frame, row pair < R1 / 2 - the first 256 threads
+    const bool pair_thread = NT == 256 || t < 256;
+    const int f2 = t & (FT - 1), qq = ((t >> 6) & 3) + 4 * ((t & 63) / FT);
     const bool special = (qq == 0);
     const int qA = qq, qB = special ? R1 / 2 : R1 - qq;
     const int hop = p.hop;
     const int span_len = (FT - 1) * hop + NFFT;
-    const int skew = (hop % 256 == 0) ? 4 : 0;
+    const int skew = (L == 16 && hop % 256 == 0) ? 4 : 0;
 
     const int chunk = (p.total_tiles + 7) >> 3;
     const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         if constexpr (!ISTFT) {
             const long long g0 = f0 * hop - p.pad;
             const int Ti = (int)p.T;
-            for (int s4 = t * 4; s4 < span_len; s4 += 1024) {
+            for (int s4 = t * 4; s4 < span_len; s4 += 4 * NT) {
                 const long long g = g0 + s4;
                 f32x4 v;
                 if (g >= 0 && g + 3 < p.T) {
@@ -449,9 +460,24 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
                 *reinterpret_cast<f32x4 *>(s_x + s4 + skew * (s4 >> 8)) = v;
             }
         }
-        for (int i = t; i < TAB / 4; i += 256) reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(p.plan)[i];
+        for (int i = t; i < TAB / 4; i += NT) reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(p.plan)[i];
     }
-    const bool fvalid2 = (f0 + f2) < F;
+    const bool fvalid2 = pair_thread && (f0 + f2) < F;
+    // multi_stft_loss: d loss / d |X| = k1 (|X| - t) + c_mag sign(|X| - t) / (|X| + eps)   (sign of the log difference: log is monotonic)
+    float msl_k1 = 0.f, msl_cm = 0.f;
+    if constexpr (MSL) {
+        const float nd = p.msl_norms[2 * clip], nt = p.msl_norms[2 * clip + 1];
+        const float g0 = p.msl_g[0];
+        const float c_sc = (g0 + p.msl_g[1]) * p.msl_invLN;
+        msl_cm = fvalid2 ? (g0 + p.msl_g[2]) * p.msl_invLNKF : 0.f;
+        msl_k1 = fvalid2 ? c_sc / (nd * nt) : 0.f;
+    }
+    auto msl_grad = [&](float m, float tv) __attribute__((always_inline)) {
+        const float d = m - tv;
+        // sign(d) without compares (selects in the divergent self-paired rows cost 64 VGPRs): +-1 for |d| >= 2^-120, 0 at 0
+        const float sg = msl_cm * __builtin_amdgcn_fmed3f(d * 0x1p+120f, -1.f, 1.f);
+        return __builtin_fmaf(msl_k1, d, sg * __builtin_amdgcn_rcpf(m + p.msl_eps));
+    };
     const size_t goff = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)(f0 + f2);
     const float *gbase = p.gmag + goff;
     const int stepF = R1 * iF, offA = qA * iF, offB = qB * iF;
@@ -485,14 +511,14 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         v2f z[NR][R1];
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            const int sb = (fl + 16 * r) * hop + 2 * l;
+            const int sb = (fl + FPR * r) * hop + 2 * l;
             const float *tb0 = s_x + sb + skew * (sb >> 8);
-            static_for<0, R1 / 8>([&](auto gc) __attribute__((always_inline)) {
+            static_for<0, R1 / TPB>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 const float *tb = tb0 + g * (256 + skew);
-                static_for<0, 8>([&](auto ac) __attribute__((always_inline)) {
-                    constexpr int a = 8 * g + decltype(ac)::value;
-                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - 8 * g));
+                static_for<0, TPB>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = TPB * g + decltype(ac)::value;
+                    z[r][a] = *reinterpret_cast<const v2f *>(tb + 2 * L * (a - TPB * g));
                 });
             });
             const float *wrow = s_wt + l * ROW;
@@ -509,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         const float *trow = s_tw + l * ROW;
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            float *oz = s_x + (fl + 16 * r) * SF + 2 * l;
+            float *oz = s_x + (fl + FPR * r) * SF + 2 * l;
             static_for<0, R1 / 2>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int q0 = 2 * decltype(ic)::value, q1 = q0 + 1;
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
@@ -522,8 +548,8 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
     }
     PSND_BSTAMP(2);
 
-    // ---- pair threads: forward radix-16 -> X, G = gmag X / |X|, adjoint split in place, inverse radix-16, conj twiddle ----
-    {
+    // ---- pair threads: forward radix-L -> X, G = gmag X / |X|, adjoint split in place, inverse radix-L, conj twiddle ----
+    if (pair_thread) {
         v2f za[L], zb[L];
         float *rowA = s_x + f2 * SF + qA * 2 * L, *rowB = s_x + f2 * SF + qB * 2 * L;
         if constexpr (!ISTFT) {
@@ -543,6 +569,10 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
             v2f xk, xc;
             rfft_pair_pk(a, b, v, xk, xc);                           // X[k] = xk, X[C-k] = conj(xc)
             const v2f sk = pk::fma(xk, xk, eps2), sc = pk::fma(xc, xc, eps2);
+            if constexpr (MSL) {                                     // gk, gc are the TARGET magnitudes of the two bins
+                gk = msl_grad(__builtin_amdgcn_sqrtf(sk.x + sk.y), gk);
+                gc = msl_grad(__builtin_amdgcn_sqrtf(sc.x + sc.y), gc);
+            }
             const float rk = gk * __builtin_amdgcn_rsqf(sk.x + sk.y);   // 0 * inf = NaN for a zero bin, as autograd of sqrt
             const float rc = gc * __builtin_amdgcn_rsqf(sc.x + sc.y);
             const v2f ha = xk * v2f{rk, rk}, hbc = xc * v2f{rc, rc};  // G[k] and conj(G[C-k])
@@ -571,18 +601,17 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
                     pair_inv(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], pAl[pp], gBh[pp], pBh[pp]);
                     pair_inv(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], pBl[pp], gAh[pp], pAh[pp]);
                 } else {
-                    pair(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], gBh[pp]);      // bins qA + 32 pp | qB + 32 (15-pp)
-                    pair(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], gAh[pp]);      // bins qB + 32 pp | qA + 32 (15-pp)
+                    pair(za[sa], zb[sb], vk(qA + R1 * pp), gAl[pp], gBh[pp]);      // bins qA + R1 pp | qB + R1 (L-1-pp)
+                    pair(zb[sa], za[sb], vk(qB + R1 * pp), gBl[pp], gAh[pp]);      // bins qB + R1 pp | qA + R1 (L-1-pp)
+                    // keep the pairs apart: interleaved by the scheduler, the temporaries of all L / 2 evaluations are live at once
+                    // (fused loss gradient: 238 VGPRs instead of 172; L = 32: spills)
+                    if constexpr (MSL || L == 32) __builtin_amdgcn_sched_barrier(0);
                 }
             });
         } else {
-            // rows 0 and 16 are self-paired (scalar formulation of the general kernel, divergent for these 16 lanes only)
-            float ar[L], ai[L], br[L], bi[L], uAr[L], uAi[L], uBr[L], uBi[L];
-            static_for<0, L>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (ISTFT) ar[i] = ai[i] = br[i] = bi[i] = 0.f;
-                else ar[i] = za[i].x, ai[i] = za[i].y, br[i] = zb[i].x, bi[i] = zb[i].y;
-            });
+            // rows 0 and R1/2 are self-paired (divergent for these FT lanes only).  Row 0 pairs p with (L - p) % L, row R1/2 pairs p
+            // with L - 1 - p: the adjoint of a pair lands in the two slots it was read from, so both rows are rewritten IN PLACE
+            // (element p lives in slot bitrev(p)).
             // gradient (or spectrum value) of a bin; `ph` and `edge` only matter for the inverse transform
             auto gof = [&](float gm, float xr, float xi, float &gr, float &gi, float ph = 0.f, bool edge = false) __attribute__((always_inline)) {
                 if constexpr (ISTFT) {
@@ -591,47 +620,49 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
                     const float m = gm * (edge ? p.inv_n : 2.f * p.inv_n);
                     gr = m * cs, gi = m * sn;
                 } else {
-                    const float g = gm / __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, p.mag_eps)));
+                    const float m = __builtin_amdgcn_sqrtf(__builtin_fmaf(xr, xr, __builtin_fmaf(xi, xi, p.mag_eps)));
+                    if constexpr (MSL) gm = msl_grad(m, gm);
+                    const float g = gm / m;
                     gr = g * xr, gi = g * xi;
                 }
             };
-            float xkr, xki, xcr, xci, gkr, gki, gcr, gci;
+            float xkr = 0.f, xki = 0.f, xcr = 0.f, xci = 0.f, gkr, gki, gcr, gci;
             static_for<0, L / 2 + 1>([&](auto pc) __attribute__((always_inline)) {
                 constexpr int pp = decltype(pc)::value;
                 constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev((L - pp) % L, LB);
                 const v2f v = vk(R1 * pp);
-                rfft_pair(ar[sa], ai[sa], ar[sb], ai[sb], v.x, v.y, xkr, xki, xcr, xci);
+                if constexpr (!ISTFT) rfft_pair(za[sa].x, za[sa].y, za[sb].x, za[sb].y, v.x, v.y, xkr, xki, xcr, xci);
                 gof(pp < L / 2 ? gAl[pp < L / 2 ? pp : 0] : gAh[L / 2 - 1], xkr, xki, gkr, gki,
                     ISTFT ? (pp < L / 2 ? pAl[(ISTFT && pp < L / 2) ? pp : 0] : pAh[ISTFT ? L / 2 - 1 : 0]) : 0.f, pp == 0);
                 float z0r, z0i, z1r, z1i;
                 if constexpr (pp == 0) {
                     gof(gNy, xcr, xci, gcr, gci, pNy, true);
                     irfft_pair(2.f * gkr, 0.f, 2.f * gcr, 0.f, v.x, v.y, z0r, z0i, z1r, z1i);
-                    uAr[0] = z0r, uAi[0] = z0i;
+                    za[sa] = v2f{z0r, z0i};
                 } else if constexpr (2 * pp == L) {
                     irfft_pair(gkr, gki, gkr, gki, v.x, v.y, z0r, z0i, z1r, z1i);
-                    uAr[pp] = z0r, uAi[pp] = z0i;
+                    za[sa] = v2f{z0r, z0i};
                 } else {
                     gof(gAh[(pp >= 1 && pp <= L / 2) ? pp - 1 : 0], xcr, xci, gcr, gci,
                         ISTFT ? pAh[(ISTFT && pp >= 1 && pp <= L / 2) ? pp - 1 : 0] : 0.f);
                     irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
-                    uAr[pp] = z0r, uAi[pp] = z0i;
-                    uAr[L - pp] = z1r, uAi[L - pp] = z1i;
+                    za[sa] = v2f{z0r, z0i};
+                    za[sb] = v2f{z1r, z1i};
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one evaluation at a time (interleaved, the fused loss gradient needed 238 VGPRs)
             });
             static_for<0, L / 2>([&](auto pc) __attribute__((always_inline)) {
                 constexpr int pp = decltype(pc)::value;
                 constexpr int sa = ct::bitrev(pp, LB), sb = ct::bitrev(L - 1 - pp, LB);
                 const v2f v = vk(R1 / 2 + R1 * pp);
-                rfft_pair(br[sa], bi[sa], br[sb], bi[sb], v.x, v.y, xkr, xki, xcr, xci);
+                if constexpr (!ISTFT) rfft_pair(zb[sa].x, zb[sa].y, zb[sb].x, zb[sb].y, v.x, v.y, xkr, xki, xcr, xci);
                 gof(gBl[pp], xkr, xki, gkr, gki, ISTFT ? pBl[ISTFT ? pp : 0] : 0.f);
                 gof(gBh[pp], xcr, xci, gcr, gci, ISTFT ? pBh[ISTFT ? pp : 0] : 0.f);
-                irfft_pair(gkr, gki, gcr, gci, v.x, v.y, uBr[pp], uBi[pp], uBr[L - 1 - pp], uBi[L - 1 - pp]);
-            });
-            static_for<0, L>([&](auto ic) __attribute__((always_inline)) {       // natural index p -> slot bitrev(p)
-                constexpr int pq = decltype(ic)::value, sl = ct::bitrev(pq, LB);
-                za[sl] = v2f{uAr[pq], uAi[pq]};
-                zb[sl] = v2f{uBr[pq], uBi[pq]};
+                float z0r, z0i, z1r, z1i;
+                irfft_pair(gkr, gki, gcr, gci, v.x, v.y, z0r, z0i, z1r, z1i);
+                zb[sa] = v2f{z0r, z0i};
+                zb[sb] = v2f{z1r, z1i};
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
         pk::fft_dit<L, 1>(za);                                        // inverse over p: U[q][l] in slot l
@@ -654,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         v2f z[NR][R1];
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            const float *iz = s_x + (fl + 16 * r) * SF + 2 * l;
+            const float *iz = s_x + (fl + FPR * r) * SF + 2 * l;
             static_for<0, R1>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
                 z[r][ct::bitrev(q, RB)] = *reinterpret_cast<const v2f *>(iz + q * 2 * L);
@@ -675,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         // traffic as well).  Every lane parks its 64 windowed samples, then each span sample gathers its <= n/hop frames.
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
-            float *yo = s_x + (fl + 16 * r) * SF + 2 * l;
+            float *yo = s_x + (fl + FPR * r) * SF + 2 * l;
             static_for<0, R1>([&](auto ac) __attribute__((always_inline)) {
                 constexpr int a = decltype(ac)::value;
                 *reinterpret_cast<v2f *>(yo + 2 * L * a) = z[r][a];
@@ -688,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void stft_bwd_n1024_mag_kernel(StftBwdParam
         const int nfr = (int)((F - f0) < FT ? (F - f0) : FT);      // valid frames of this tile
         const unsigned hmagic = 0xffffffffu / (unsigned)hop + 1u;  // i / hop = umulhi(i, hmagic) for i < 2^32 / hop
         const int Ti = (int)p.T;
-        for (int i = t; i < span_len; i += 256) {
+        for (int i = t; i < span_len; i += NT) {
             // frames f with 0 <= i - f*hop < n
             int f_hi = (int)__umulhi((unsigned)i, hmagic);
             if (f_hi > nfr - 1) f_hi = nfr - 1;
@@ -1150,9 +1181,48 @@ int launch_istft(const StftBwdParams &p, hipStream_t stream) {
 
 using namespace psnd_stft;
 
-extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
-                             const void *plan, float mag_eps, const float *gmag, const float *gre,
-                             const float *gim, float *gwav, void *stream) {
+// span-staged adjoint (stft_bwd_n1024_mag_kernel): which (n_fft, hop) it takes, and its launch
+static bool span_bwd_ok(int n_fft, int hop) {
+    if (getenv("PSND_STFT_BWD_V1")) return false;
+    switch (n_fft) {
+        case 512: return hop % 2 == 0 && hop <= 256;
+        case 1024: return hop % 4 == 0 && hop <= 256;
+        case 2048: return hop % 2 == 0 && hop <= 1024;   // span of 16 frames must fit the exchange: always for hop <= n / 2
+    }
+    return false;
+}
+
+template <bool ISTFT, int R1, int L, bool MSL>
+static int launch_span_bwd_one(const StftBwdParams &p, hipStream_t s) {
+    using G = BwdGeom<R1, L>;
+    constexpr size_t lds = sizeof(float) * G::LDS_FLOATS;
+    auto kern = stft_bwd_n1024_mag_kernel<ISTFT, R1, L, MSL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd(span): set LDS size: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3((p.total_tiles + 7) & ~7), dim3(G::NT), lds, s, p);
+    PSND_CHECK_LAUNCH(ISTFT ? "istft(span)" : (MSL ? "stft_bwd_msl(span)" : "stft_bwd(span, mag)"));
+    return PSND_OK;
+}
+
+template <bool ISTFT, bool MSL>
+static int launch_span_bwd(int n_fft, const StftBwdParams &p, hipStream_t s) {
+    switch (n_fft) {
+        case 512: return launch_span_bwd_one<ISTFT, 16, 16, MSL>(p, s);
+        case 1024: return launch_span_bwd_one<ISTFT, 32, 16, MSL>(p, s);
+        case 2048:
+            if constexpr (!ISTFT) return launch_span_bwd_one<false, 32, 32, MSL>(p, s);
+    }
+    PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd(span): n_fft=%d", n_fft);
+}
+
+struct MslArgs {
+    const float *norms, *g3;
+    int L;
+    float eps;
+};
+
+static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan, float mag_eps,
+                         const float *gmag, const float *gre, const float *gim, float *gwav, void *stream, const MslArgs *msl) {
     if (!plan || !gwav) PSND_FAIL(PSND_E_ARG, "stft_bwd: null plan/gwav");
     if ((gre == nullptr) != (gim == nullptr)) PSND_FAIL(PSND_E_ARG, "stft_bwd: gre and gim must be given together");
     if (!gmag && !gre) PSND_FAIL(PSND_E_ARG, "stft_bwd: no gradient source");
@@ -1175,6 +1245,12 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     p.wav = wav, p.plan = static_cast<const float *>(plan), p.gmag = gmag, p.gre = gre, p.gim = gim, p.gwav = gwav;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
     p.win_off = 0, p.inv_n = 0.f, p.env_eps = 0.f;
+    p.msl_norms = p.msl_g = nullptr, p.msl_invLN = p.msl_invLNKF = p.msl_eps = 0.f;
+    if (msl) {
+        const double ln = (double)msl->L * (double)N;
+        p.msl_norms = msl->norms, p.msl_g = msl->g3, p.msl_eps = msl->eps;
+        p.msl_invLN = (float)(1.0 / ln), p.msl_invLNKF = (float)(1.0 / (ln * (double)(K * F)));
+    }
 #ifdef PSND_TRACE
     {
         const char *tp = getenv("PSND_TRACE_PTR");
@@ -1188,32 +1264,21 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: too many tiles");
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
         switch (n_fft) {
-            case 256: return launch_bwd<16, 8>(p, gmag, gre, s);
+            case 256:
+                if (msl) break;
+                return launch_bwd<16, 8>(p, gmag, gre, s);
             case 512:
-                if (gmag && !gre && hop % 2 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
-                    constexpr size_t lds = sizeof(float) * BwdGeom<16>::LDS_FLOATS;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<false, 16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e));
-                    hipLaunchKernelGGL((stft_bwd_n1024_mag_kernel<false, 16>), dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
-                    PSND_CHECK_LAUNCH("stft_bwd(n512, mag)");
-                    return PSND_OK;
-                }
-                return launch_bwd<16, 16>(p, gmag, gre, s);
             case 1024:
-                if (gmag && !gre && hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
-                    constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: set LDS size: %s", hipGetErrorString(e));
-                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel<false>, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
-                    PSND_CHECK_LAUNCH("stft_bwd(n1024, mag)");
-                    return PSND_OK;
-                }
-                return launch_bwd<32, 16>(p, gmag, gre, s);
-            case 2048: return launch_bwd<32, 32>(p, gmag, gre, s);
+            case 2048:
+                if (gmag && !gre && span_bwd_ok(n_fft, hop))
+                    return msl ? launch_span_bwd<false, true>(n_fft, p, s) : launch_span_bwd<false, false>(n_fft, p, s);
+                if (msl) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd_msl: n_fft=%d hop=%d", n_fft, hop);
+                if (n_fft == 512) return launch_bwd<16, 16>(p, gmag, gre, s);
+                if (n_fft == 1024) return launch_bwd<32, 16>(p, gmag, gre, s);
+                return launch_bwd<32, 32>(p, gmag, gre, s);
         }
     }
+    if (msl) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd_msl: n_fft=%d hop=%d", n_fft, hop);
     if (n_fft == 4096 && gmag && !gre && hop % 2 == 0 && hop <= 1364 && 4096 % hop == 0 && !getenv("PSND_STFT_GENERIC")) {
         // magnitude gradient at the config-5 size: the adjoint of stft_fwd_n4096b_kernel (4-frame tiles, two workgroups per CU)
         const int64_t ntile = (F + kB4096FT - 1) / kB4096FT;
@@ -1237,6 +1302,26 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     else hipLaunchKernelGGL((stft_bwd_generic_kernel<true, true>), grid, dim3(256), lds, s, p, n_fft);
     PSND_CHECK_LAUNCH("stft_bwd(generic)");
     return PSND_OK;
+}
+
+extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                             const void *plan, float mag_eps, const float *gmag, const float *gre,
+                             const float *gim, float *gwav, void *stream) {
+    return stft_bwd_impl(wav, N, T, n_fft, hop, framing, plan, mag_eps, gmag, gre, gim, gwav, stream, nullptr);
+}
+
+// multi_stft_loss (models/sound.py:106-133), gradient w.r.t. the PREDICTED waveform of one resolution in one launch: the adjoint STFT
+// recomputes |X| of `wav`, forms d loss / d |X| from it and the target magnitudes (what psnd_stft_loss_bwd writes to HBM as `gp`) and
+// carries on as psnd_stft_bwd.  norms / g3 / L / eps as psnd_stft_loss_bwd.
+extern "C" int psnd_stft_bwd_msl_supported(int n_fft, int hop) { return hop > 0 && span_bwd_ok(n_fft, hop) ? 1 : 0; }
+
+extern "C" int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan, float mag_eps,
+                                 const float *t_mag, const float *norms, const float *g3, int L, float eps, float *gwav, void *stream) {
+    if (!wav || !t_mag || !norms || !g3) PSND_FAIL(PSND_E_ARG, "stft_bwd_msl: null pointer");
+    if (L <= 0) PSND_FAIL(PSND_E_SHAPE, "stft_bwd_msl: L=%d", L);
+    if (!psnd_stft_bwd_msl_supported(n_fft, hop)) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd_msl: n_fft=%d hop=%d", n_fft, hop);
+    const MslArgs m{norms, g3, L, eps};
+    return stft_bwd_impl(wav, N, T, n_fft, hop, framing, plan, mag_eps, t_mag, nullptr, nullptr, gwav, stream, &m);
 }
 
 // STFT.inverse (pytorch_sound/models/transforms.py:71-101): conv_transpose1d with pinv(n/h * basis)^T * window
@@ -1269,26 +1354,10 @@ extern "C" int psnd_istft(const float *mag, const float *phase, int64_t N, int64
         switch (n_fft) {
             case 256: return launch_istft<16, 8>(p, s);
             case 512:
-                if (hop % 2 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
-                    constexpr size_t lds = sizeof(float) * BwdGeom<16>::LDS_FLOATS;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<true, 16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: set LDS size: %s", hipGetErrorString(e));
-                    hipLaunchKernelGGL((stft_bwd_n1024_mag_kernel<true, 16>), dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
-                    PSND_CHECK_LAUNCH("istft(n512)");
-                    return PSND_OK;
-                }
+                if (span_bwd_ok(512, hop)) return launch_span_bwd<true, false>(512, p, s);
                 return launch_istft<16, 16>(p, s);
             case 1024:
-                if (hop % 4 == 0 && hop <= 256 && !getenv("PSND_STFT_BWD_V1")) {
-                    constexpr size_t lds = sizeof(float) * kB1024LdsFloats;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stft_bwd_n1024_mag_kernel<true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "istft: set LDS size: %s", hipGetErrorString(e));
-                    hipLaunchKernelGGL(stft_bwd_n1024_mag_kernel<true>, dim3((p.total_tiles + 7) & ~7), dim3(256), lds, s, p);
-                    PSND_CHECK_LAUNCH("istft(n1024)");
-                    return PSND_OK;
-                }
+                if (span_bwd_ok(1024, hop)) return launch_span_bwd<true, false>(1024, p, s);
                 return launch_istft<32, 16>(p, s);
             case 2048: return launch_istft<32, 32>(p, s);
         }

@@ -474,6 +474,12 @@ class PreEmphasisFn(torch.autograd.Function):
         return gx, None
 
 
+def _msl_fused(n_fft, hop):
+    """psnd_stft_bwd_msl takes this resolution (PSND_MSL_FUSED=0: the two-launch path, for A/B runs and tests)."""
+    import os
+    return os.environ.get('PSND_MSL_FUSED', '1') != '0' and bool(lib().psnd_stft_bwd_msl_supported(int(n_fft), int(hop)))
+
+
 class MultiStftLossFn(torch.autograd.Function):
     """(loss, sc_loss, mag_loss) of sound.py:106-133 as ONE autograd node: per resolution two psnd_stft_fwd launches
     (pred, target) and one partial-sum pass, one combining launch for all resolutions; backward: per resolution one
@@ -527,6 +533,13 @@ class MultiStftLossFn(torch.autograd.Function):
             s = stream_ptr(pred.device)
             for i, (n_fft, hop) in enumerate(ctx.cfgs):
                 p, t = mags[2 * i], mags[2 * i + 1]
+                if need_p and not need_t and _msl_fused(n_fft, hop):
+                    # one launch: the adjoint STFT recomputes |X| and forms the loss gradient in registers (psnd_stft_bwd_msl)
+                    gw = torch.empty_like(pred)
+                    check(lib().psnd_stft_bwd_msl(ptr(pred), N, pred.shape[1], n_fft, hop, FRAMING_CENTER, ptr(plans[i]), 0.0, ptr(t),
+                                                  ptr(norms[i]), ptr(g), L, ctx.eps, ptr(gw), s), 'psnd_stft_bwd_msl')
+                    gpred = gw if gpred is None else gpred.add_(gw)
+                    continue
                 gp = torch.empty_like(p) if need_p else None
                 gt = torch.empty_like(t) if need_t else None
                 check(lib().psnd_stft_loss_bwd(ptr(p), ptr(t), N, ctx.kfs[i], ctx.eps, ptr(norms[i]), ptr(g), L, ptr(gp), ptr(gt), s),

@@ -325,7 +325,12 @@ BWD_CASES = [
     (512, 200, None, 1, 2, 9000),         # hop does not divide n_fft
     (512, 129, None, 0, 2, 3000),         # odd hop -> two-pass kernel
     (256, 64, 200, 1, 3, 1500),
-    (2048, 512, None, 0, 1, 6000),
+    (2048, 512, None, 0, 1, 6000),        # magnitude gradient: span kernel with 512 threads; (re, im): two-pass kernel
+    (2048, 240, 1200, 0, 3, 9000),        # multi_stft_loss resolution
+    (2048, 512, None, 0, 20, 20000),      # many clips, partial last tile
+    (2048, 1024, None, 1, 2, 30000),      # hop = n / 2
+    (2048, 600, None, 0, 1, 20000),       # hop does not divide n_fft
+    (2048, 513, None, 0, 1, 9000),        # odd hop -> two-pass kernel
     (4096, 1024, None, 0, 1, 9000),       # magnitude gradient: adjoint of the 4-frame n4096 kernel; (re, im): generic path
     (4096, 1024, None, 0, 3, 44100),      # several tiles per clip, partial last tile, plain-store interior + atomic rest
     (4096, 1024, 3000, 1, 2, 30000),      # HiFi-GAN framing, short window

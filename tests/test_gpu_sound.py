@@ -89,6 +89,38 @@ def test_multi_stft_loss_vs_oracle(N, T, eps, gtol):
     assert np.abs(target.grad.cpu().numpy() - gt).max() <= gtol * np.abs(gt).max()
 
 
+@pytest.mark.parametrize('N,T,eps,gtol', [(16, 8192, 1e-2, 2e-4), (3, 20000, 1e-2, 2e-4), (5, 8192, 1e-5, 1e-2)])
+def test_multi_stft_loss_fused_gradient(N, T, eps, gtol, monkeypatch):
+    """Training case (only the prediction needs a gradient): psnd_stft_bwd_msl forms d loss / d |X| inside the adjoint STFT.  Against
+    the f64 oracle and against the two-launch path (psnd_stft_loss_bwd + psnd_stft_bwd) on the same inputs."""
+    from pytorch_sound_amd import kernels as K
+    from pytorch_sound_amd.models.sound import multi_stft_loss, build_stft_functions
+    from pytorch_sound_amd.models.transforms import centre_pad
+    from oracle import features as fe
+    for n_fft, _, hop in PARAMS:
+        assert K.lib().psnd_stft_bwd_msl_supported(n_fft, hop) == 1
+    t = seeded_wav(900 + N, N, T)
+    p = (0.8 * t + 0.05 * seeded_wav(950 + N, N, T)).astype(np.float32)
+    target = torch.from_numpy(t).to(DEV)
+    grads = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('PSND_MSL_FUSED', fused)
+        pred = torch.from_numpy(p).to(DEV).requires_grad_(True)
+        loss, sc, mag = multi_stft_loss(pred, target, PARAMS, eps)
+        (0.5 * loss + 2.0 * sc - 0.25 * mag).backward()
+        grads[fused] = pred.grad.cpu().numpy()
+    wins = [centre_pad(f.window.numpy().astype(np.float64), f.n_fft) for f in build_stft_functions(*PARAMS)]
+    L = len(PARAMS)
+    gp = np.zeros_like(p, dtype=np.float64)
+    for (n_fft, win, hop), w in zip(PARAMS, wins):
+        pm = osnd.stft_mag_torchaudio_f64(p, n_fft, win, hop, w)
+        tm = osnd.stft_mag_torchaudio_f64(t, n_fft, win, hop, w)
+        a, _ = osnd.stft_loss_terms_bwd(pm, tm, (0.5 + 2.0) / L, (0.5 - 0.25) / L, eps)
+        gp += fe.stft_mag_bwd_f64(a, p, n_fft, hop, framing=fe.CENTER, window=w)
+    assert np.abs(grads['1'] - gp).max() <= gtol * np.abs(gp).max()
+    assert np.abs(grads['1'] - grads['0']).max() <= gtol * np.abs(gp).max()
+
+
 def test_multi_stft_loss_properties_large():
     """N = 256 clips x 16384 samples (3 resolutions: 0.5 GB of magnitudes): loss(x, x) has sc = mag = 0 exactly;
     pred = a * target gives sc = |1 - a| for every clip and mag = |log a| up to the eps inside the logs."""
