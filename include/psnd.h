@@ -320,6 +320,16 @@ int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_
  *      registers (the magnitude gradient never exists in HBM) and continues as psnd_stft_bwd.  norms / g3 / L / eps as
  *      psnd_stft_loss_bwd; gwav (N, T) fully overwritten.  psnd_stft_bwd_msl_supported(n_fft, hop): 1 where the span-staged
  *      adjoint runs (n_fft 512 / 1024 / 2048, even hop up to n/2 resp. 256), else callers use the two-launch path. */
+/*  psnd_stft_fwd_msl: psnd_stft_fwd (magnitude, centre framing) + psnd_stft_loss_partial FUSED for the prediction of one resolution:
+ *      |X| is compared with t_mag (N, K, F) in registers and only the three sums leave the kernel - part[(n*B + b)*3 + {0,1,2}],
+ *      B = psnd_stft_fwd_msl_blocks(T, n_fft, hop) entries per clip (0: this (n_fft, hop) is not covered - span-staged kernel,
+ *      n_fft 512 / 1024 / 2048, one tile per workgroup).  psnd_stft_loss_final_blocks: psnd_stft_loss_final with the entries per
+ *      clip given per resolution (blocks[L], host array; NULL = psnd_stft_loss_blocks(KF[i])). */
+int64_t psnd_stft_fwd_msl_blocks(int64_t T, int n_fft, int hop);
+int psnd_stft_fwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, const void *plan, float mag_eps,
+                      const float *t_mag, float eps, double *part, void *stream);
+int psnd_stft_loss_final_blocks(const double *const *parts, const int64_t *KF, const int64_t *blocks, int L, int64_t N,
+                                float *norms, float *out3, void *stream);
 int psnd_stft_bwd_msl_supported(int n_fft, int hop);
 int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan,
                       float mag_eps, const float *t_mag, const float *norms, const float *g3, int L, float eps,

@@ -230,8 +230,10 @@ extern "C" int psnd_stft_loss_partial(const float *p_mag, const float *t_mag, in
     return PSND_OK;
 }
 
-extern "C" int psnd_stft_loss_final(const double *const *parts, const int64_t *KF, int L, int64_t N, float *norms, float *out3,
-                                    void *stream) {
+// blocks[i] = partial-sum entries per clip of resolution i (psnd_stft_loss_blocks(KF[i]) for psnd_stft_loss_partial,
+// psnd_stft_fwd_msl_blocks for the sums the STFT kernel leaves); blocks == NULL: all from psnd_stft_loss_partial
+extern "C" int psnd_stft_loss_final_blocks(const double *const *parts, const int64_t *KF, const int64_t *blocks, int L, int64_t N,
+                                           float *norms, float *out3, void *stream) {
     if (!parts || !KF || !norms || !out3) PSND_FAIL(PSND_E_ARG, "stft_loss_final: null pointer");
     if (L <= 0 || L > MAXRES) PSND_FAIL(PSND_E_ARG, "stft_loss_final: %d resolutions (1..%d)", L, MAXRES);
     if (N <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_loss_final: N=%lld", (long long)N);
@@ -239,13 +241,20 @@ extern "C" int psnd_stft_loss_final(const double *const *parts, const int64_t *K
     a.L = L, a.N = (int)N;
     for (int i = 0; i < L; ++i) {
         if (!parts[i] || KF[i] <= 0) PSND_FAIL(PSND_E_ARG, "stft_loss_final: resolution %d: null partials / KF=%lld", i, (long long)KF[i]);
+        const int64_t B = blocks ? blocks[i] : psnd_stft_loss_blocks(KF[i]);
+        if (B <= 0 || B > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "stft_loss_final: resolution %d: %lld partial sums per clip", i, (long long)B);
         a.part[i] = parts[i];
-        a.B[i] = (int)psnd_stft_loss_blocks(KF[i]);
+        a.B[i] = (int)B;
         a.inv_kf[i] = 1.0 / (double)KF[i];
     }
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), a, norms, out3);
     PSND_CHECK_LAUNCH("stft_loss_final");
     return PSND_OK;
+}
+
+extern "C" int psnd_stft_loss_final(const double *const *parts, const int64_t *KF, int L, int64_t N, float *norms, float *out3,
+                                    void *stream) {
+    return psnd_stft_loss_final_blocks(parts, KF, nullptr, L, N, norms, out3, stream);
 }
 
 extern "C" int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_t KF, float eps, const float *norms,

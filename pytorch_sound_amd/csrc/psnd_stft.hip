@@ -46,6 +46,10 @@ struct StftFwdParams {
     float *mel_out;
     int mel_M, log_kind;
     float log_offset, pre_clamp_min, clamp_lo, clamp_hi;
+    // fused multi_stft_loss partial sums (psnd_stft_fwd_msl): |X| is compared with the target magnitudes in registers
+    const float *msl_t;
+    double *msl_part;
+    float msl_eps;
 #ifdef PSND_TRACE
     long long *trace;   // tools/trace_stft.py: 8 s_memtime stamps per wave
     int trace_iter;     // which tile iteration of a persistent workgroup is stamped
@@ -310,6 +314,37 @@ struct EmitLds {
 };
 
 
+// multi_stft_loss partial sums instead of stores (psnd_stft_fwd_msl): every bin the thread would store is compared with the target
+// magnitude at the same place: sum (t - |X|)^2, sum t^2, sum |log(t + eps) - log(|X| + eps)|  (loss_partial_kernel of psnd_loss.hip)
+struct EmitLoss {
+    __amdgpu_buffer_rsrc_t rt;
+    v2f eps2;
+    float leps;
+    bool valid;
+    mutable float s_d2 = 0.f, s_t2 = 0.f, s_l1 = 0.f;
+    __device__ __forceinline__ EmitLoss(const float *t_mag, size_t base, int bytes, float mag_eps, float log_eps, bool valid_)
+        : rt(make_uniform_rsrc(t_mag + base, bytes)), eps2(v2f{mag_eps, 0.f}), leps(log_eps), valid(valid_) {}
+    template <bool CONJ>
+    __device__ __forceinline__ OutVal make(v2f x) const {
+        OutVal o;
+        const v2f sq = pk::fma(x, x, eps2);
+        o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        return o;
+    }
+    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+        const float tv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, voff, soff, 0));
+        const float d = tv - o.m;
+        s_d2 = __builtin_fmaf(d, d, s_d2);
+        s_t2 = __builtin_fmaf(tv, tv, s_t2);
+        s_l1 += __builtin_fabsf(__logf(tv + leps) - __logf(o.m + leps));
+    }
+};
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 // real-FFT split of the two butterflies a thread holds + output (packed twin of post_emit): lower bins are
 // stored at once, their mirrors are parked (already reduced to the values to store) and written
 // afterwards in ASCENDING row order.
@@ -394,9 +429,12 @@ constexpr int kN1024TabFloats = SpanGeom<32>::TAB;
 constexpr int kN1024WtOff = SpanGeom<32>::WT_OFF;
 inline int n1024_area_floats(int hop) { return SpanGeom<32>::area_floats(hop); }
 
-template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, bool FUSE_MEL = false, int R1 = 32, int L_ = 16>
+// FUSE: 0 = outputs to memory, 1 = log-mel projection of the magnitude tile (psnd_logmel_fwd), 2 = multi_stft_loss partial sums
+template <bool MAG, bool PHASE, bool REIM, int SPV, bool PERSIST, int FUSE = 0, int R1 = 32, int L_ = 16>
 __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fwd_n1024_kernel(StftFwdParams p) {
+    constexpr bool FUSE_MEL = FUSE == 1, FUSE_LOSS = FUSE == 2;
     static_assert(!FUSE_MEL || (MAG && !PHASE && !REIM && !PERSIST && R1 == 32 && L_ == 16), "fused log-mel: magnitude only, one tile per workgroup");
+    static_assert(!FUSE_LOSS || (MAG && !PHASE && !REIM && !PERSIST), "fused loss sums: magnitude only, one tile per workgroup");
     using G = SpanGeom<R1, L_>;
     constexpr int L = G::L, C = G::C, NFFT = G::NFFT, FT = G::FT, NR = G::NR, FPR = G::FPR, TPB = G::TPB, ROW = G::ROW, VKP = G::VKP, RB = ct::ilog2(R1);
     constexpr int HR = R1 / 2;          // rows per exchange half
@@ -643,6 +681,16 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
                     }
                 }
             }
+        } else if constexpr (FUSE_LOSS) {
+            const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
+            const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
+            EmitLoss emit(p.msl_t, cbase, cbytes, p.mag_eps, p.msl_eps, (f0 + f2) < F);
+            if (emit.valid) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
+            const float w1 = wave_sum_f(emit.s_d2), w2 = wave_sum_f(emit.s_t2), w3 = wave_sum_f(emit.s_l1);
+            __syncthreads();                 // every wave has taken its second row out of the exchange
+            if ((t & 63) == 0) s_x[3 * (t >> 6)] = w1, s_x[3 * (t >> 6) + 1] = w2, s_x[3 * (t >> 6) + 2] = w3;
+            __syncthreads();
+            if (t < 3) p.msl_part[(size_t)tile * 3 + t] = (double)s_x[t] + (double)s_x[3 + t] + (double)s_x[6 + t] + (double)s_x[9 + t];
         } else {
         const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
         const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
@@ -1373,6 +1421,78 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     return PSND_OK;
 }
 
+// multi_stft_loss (models/sound.py:106-133), one resolution: STFT magnitude of the PREDICTION compared with the target magnitudes in
+// registers - part[(n * B + b) * 3 + {0,1,2}] = the three sums over tile b of clip n (B = psnd_stft_fwd_msl_blocks), as
+// psnd_stft_loss_partial writes them for its own chunking; the prediction's magnitude never exists in HBM.
+template <int R1, int L>
+static bool span_one_tile_ok(int hop) {
+    using G = SpanGeom<R1, L>;
+    const int span = (G::FT - 1) * hop + G::NFFT;
+    if (!span_kernel_ok<R1, L>(hop)) return false;
+    return L == 32 || (span <= 5 * 1024 && span + 4 * (span / 256 + 1) <= G::WT_OFF);
+}
+static bool fwd_msl_ok(int n_fft, int hop) {
+    if (hop <= 0 || getenv("PSND_STFT_V1")) return false;
+    switch (n_fft) {
+        case 512: return span_one_tile_ok<16, 16>(hop);
+        case 1024: return hop % 4 == 0 && span_one_tile_ok<32, 16>(hop);
+        case 2048: return span_one_tile_ok<32, 32>(hop);
+    }
+    return false;
+}
+extern "C" int64_t psnd_stft_fwd_msl_blocks(int64_t T, int n_fft, int hop) {
+    if (!fwd_msl_ok(n_fft, hop)) return 0;
+    const int64_t F = psnd_frame_count(T, n_fft, hop, PSND_FRAMING_CENTER);
+    const int FT = 512 / find_decomp(n_fft)->R1;
+    return F <= 0 ? 0 : (F + FT - 1) / FT;
+}
+
+template <int R1, int L>
+static int launch_span_loss(const StftFwdParams &p, hipStream_t stream) {
+    using G = SpanGeom<R1, L>;
+    const size_t lds = sizeof(float) * (size_t)(G::TAB + G::area_floats(p.hop) - G::L * G::ROW);
+    const int grid = (p.total_tiles + 7) & ~7;
+    const int span = (G::FT - 1) * p.hop + G::NFFT;
+    int rc;
+    if constexpr (L == 32) {
+        if (span <= 6 * 1024) rc = span_launch_one(stft_fwd_n1024_kernel<true, false, false, 6, false, 2, R1, L>, grid, lds, stream, p);
+        else rc = span_launch_one(stft_fwd_n1024_kernel<true, false, false, 10, false, 2, R1, L>, grid, lds, stream, p);
+    } else {
+        rc = span_launch_one(stft_fwd_n1024_kernel<true, false, false, 5, false, 2, R1, L>, grid, lds, stream, p);
+    }
+    if (rc != PSND_OK) return rc;
+    PSND_CHECK_LAUNCH("stft_fwd_msl");
+    return PSND_OK;
+}
+
+extern "C" int psnd_stft_fwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, const void *plan, float mag_eps,
+                                 const float *t_mag, float eps, double *part, void *stream) {
+    if (!wav || !plan || !t_mag || !part) PSND_FAIL(PSND_E_ARG, "stft_fwd_msl: null pointer");
+    if (N < 0) PSND_FAIL(PSND_E_ARG, "stft_fwd_msl: N=%lld", (long long)N);
+    if (!fwd_msl_ok(n_fft, hop)) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_fwd_msl: n_fft=%d hop=%d", n_fft, hop);
+    const int pad = n_fft / 2;
+    if (T <= pad) PSND_FAIL(PSND_E_SHAPE, "stft_fwd_msl: reflect padding %d needs T > pad (T=%lld)", pad, (long long)T);
+    if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "stft_fwd_msl: T=%lld exceeds 2^31 samples per clip", (long long)T);
+    const int64_t F = psnd_frame_count(T, n_fft, hop, PSND_FRAMING_CENTER);
+    if (N == 0 || F <= 0) return PSND_OK;
+    if ((int64_t)(n_fft / 2 + 1) * F >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd_msl: K*F too large");
+    StftFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.wav = wav, p.plan = static_cast<const float *>(plan);
+    p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    p.msl_t = t_mag, p.msl_part = part, p.msl_eps = eps;
+    const int FT = 512 / find_decomp(n_fft)->R1;
+    const int64_t ntile = (F + FT - 1) / FT;
+    if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd_msl: too many tiles");
+    p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (n_fft) {
+        case 512: return launch_span_loss<16, 16>(p, s);
+        case 1024: return launch_span_loss<32, 16>(p, s);
+        default: return launch_span_loss<32, 32>(p, s);
+    }
+}
+
 // Fused wav -> log-mel for LogMelSpectrogram.forward (transforms.py:229-244), Audio2Mel.forward (:351-366) and the
 // interface's MelSpectrogram (interface/hifi_gan.py:46-63): n_fft = 1024, hop <= 256 (the span-staged tile kernel).
 extern "C" int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *stft_plan,
@@ -1401,7 +1521,7 @@ extern "C" int psnd_logmel_fwd(const float *wav, int64_t N, int64_t T, int n_fft
     p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
     const size_t lds = sizeof(float) * (size_t)(kN1024TabFloats + n1024_area_floats(hop) - 16 * 68);
     const int grid = (p.total_tiles + 7) & ~7;
-    hipLaunchKernelGGL((stft_fwd_n1024_kernel<true, false, false, 5, false, true>), dim3(grid), dim3(256), lds,
+    hipLaunchKernelGGL((stft_fwd_n1024_kernel<true, false, false, 5, false, 1>), dim3(grid), dim3(256), lds,
                        static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("logmel_fwd");
     return PSND_OK;

@@ -498,25 +498,39 @@ class MultiStftLossFn(torch.autograd.Function):
         N = pred.shape[0]
         L = len(cfgs)
         dev = pred.device
-        mags, parts, kfs = [], [], []
+        mags, parts, kfs, blocks = [], [], [], []
+        # training case (only the prediction needs a gradient): the prediction's magnitudes never reach HBM - psnd_stft_fwd_msl leaves
+        # the three sums, psnd_stft_bwd_msl recomputes |X| in the backward
+        only_pred = not ctx.needs_input_grad[1]
         with torch.cuda.device(dev):
             s = stream_ptr(dev)
             for (n_fft, hop), plan in zip(cfgs, plans):
-                p = stft_forward(pred, n_fft, hop, plan)['mag']
                 t = stft_forward(target, n_fft, hop, plan)['mag']
-                KF = p.shape[1] * p.shape[2]
-                part = torch.empty((N, int(lib().psnd_stft_loss_blocks(KF)), 3), dtype=torch.float64, device=dev)
-                check(lib().psnd_stft_loss_partial(ptr(p), ptr(t), N, KF, float(eps), ptr(part), s), 'psnd_stft_loss_partial')
+                KF = t.shape[1] * t.shape[2]
+                B = int(lib().psnd_stft_fwd_msl_blocks(pred.shape[1], int(n_fft), int(hop))) if only_pred and _msl_fused(n_fft, hop) else 0
+                if B > 0:
+                    p = None
+                    part = torch.empty((N, B, 3), dtype=torch.float64, device=dev)
+                    check(lib().psnd_stft_fwd_msl(ptr(pred), N, pred.shape[1], int(n_fft), int(hop), ptr(plan), 0.0, ptr(t), float(eps),
+                                                  ptr(part), s), 'psnd_stft_fwd_msl')
+                else:
+                    p = stft_forward(pred, n_fft, hop, plan)['mag']
+                    B = int(lib().psnd_stft_loss_blocks(KF))
+                    part = torch.empty((N, B, 3), dtype=torch.float64, device=dev)
+                    check(lib().psnd_stft_loss_partial(ptr(p), ptr(t), N, KF, float(eps), ptr(part), s), 'psnd_stft_loss_partial')
                 mags.append((p, t))
                 parts.append(part)
                 kfs.append(KF)
+                blocks.append(B)
             norms = torch.empty((L, N, 2), dtype=torch.float32, device=dev)
             out = torch.empty(3, dtype=torch.float32, device=dev)
             parr = (ctypes.c_void_p * L)(*[ptr(q) for q in parts])
             karr = (ctypes.c_int64 * L)(*kfs)
-            check(lib().psnd_stft_loss_final(parr, karr, L, N, ptr(norms), ptr(out), s), 'psnd_stft_loss_final')
+            barr = (ctypes.c_int64 * L)(*blocks)
+            check(lib().psnd_stft_loss_final_blocks(parr, karr, barr, L, N, ptr(norms), ptr(out), s), 'psnd_stft_loss_final_blocks')
         ctx.cfgs, ctx.eps, ctx.kfs = cfgs, float(eps), kfs
-        ctx.save_for_backward(pred, target, norms, *[m for pt in mags for m in pt], *plans)
+        ctx.has_p = [pt[0] is not None for pt in mags]
+        ctx.save_for_backward(pred, target, norms, *[m if m is not None else norms for pt in mags for m in pt], *plans)
         return out
 
     @staticmethod
@@ -533,7 +547,7 @@ class MultiStftLossFn(torch.autograd.Function):
             s = stream_ptr(pred.device)
             for i, (n_fft, hop) in enumerate(ctx.cfgs):
                 p, t = mags[2 * i], mags[2 * i + 1]
-                if need_p and not need_t and _msl_fused(n_fft, hop):
+                if not ctx.has_p[i] or (need_p and not need_t and _msl_fused(n_fft, hop)):
                     # one launch: the adjoint STFT recomputes |X| and forms the loss gradient in registers (psnd_stft_bwd_msl)
                     gw = torch.empty_like(pred)
                     check(lib().psnd_stft_bwd_msl(ptr(pred), N, pred.shape[1], n_fft, hop, FRAMING_CENTER, ptr(plans[i]), 0.0, ptr(t),

@@ -109,6 +109,7 @@ def test_multi_stft_loss_fused_gradient(N, T, eps, gtol, monkeypatch):
         loss, sc, mag = multi_stft_loss(pred, target, PARAMS, eps)
         (0.5 * loss + 2.0 * sc - 0.25 * mag).backward()
         grads[fused] = pred.grad.cpu().numpy()
+        grads['v' + fused] = [float(loss.detach()), float(sc.detach()), float(mag.detach())]
     wins = [centre_pad(f.window.numpy().astype(np.float64), f.n_fft) for f in build_stft_functions(*PARAMS)]
     L = len(PARAMS)
     gp = np.zeros_like(p, dtype=np.float64)
@@ -119,6 +120,10 @@ def test_multi_stft_loss_fused_gradient(N, T, eps, gtol, monkeypatch):
         gp += fe.stft_mag_bwd_f64(a, p, n_fft, hop, framing=fe.CENTER, window=w)
     assert np.abs(grads['1'] - gp).max() <= gtol * np.abs(gp).max()
     assert np.abs(grads['1'] - grads['0']).max() <= gtol * np.abs(gp).max()
+    # the forward sums left by psnd_stft_fwd_msl against psnd_stft_loss_partial's, and against the oracle
+    want = osnd.multi_stft_loss(p, t, PARAMS, eps, windows=wins)
+    assert np.allclose(grads['v1'], grads['v0'], rtol=1e-5), (grads['v1'], grads['v0'])
+    assert np.allclose(grads['v1'], want, rtol=2e-5), (grads['v1'], want)
 
 
 def test_multi_stft_loss_properties_large():
