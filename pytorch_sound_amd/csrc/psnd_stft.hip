@@ -336,7 +336,9 @@ struct EmitLoss {
         const float d = tv - o.m;
         s_d2 = __builtin_fmaf(d, d, s_d2);
         s_t2 = __builtin_fmaf(tv, tv, s_t2);
-        s_l1 += __builtin_fabsf(__logf(tv + leps) - __logf(o.m + leps));
+        // log2 on the hardware unit (v_log_f32; both arguments >= eps, no denormal scaling), the sum is scaled by ln 2 at the end:
+        // __logf expands to ~14 instructions per call here and made this variant slower than the one that stores
+        s_l1 += __builtin_fabsf(__builtin_amdgcn_logf(tv + leps) - __builtin_amdgcn_logf(o.m + leps));
     }
 };
 __device__ __forceinline__ float wave_sum_f(float v) {
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
             const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
             EmitLoss emit(p.msl_t, cbase, cbytes, p.mag_eps, p.msl_eps, (f0 + f2) < F);
             if (emit.valid) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
-            const float w1 = wave_sum_f(emit.s_d2), w2 = wave_sum_f(emit.s_t2), w3 = wave_sum_f(emit.s_l1);
+            const float w1 = wave_sum_f(emit.s_d2), w2 = wave_sum_f(emit.s_t2), w3 = wave_sum_f(emit.s_l1) * 0.69314718056f;
             __syncthreads();                 // every wave has taken its second row out of the exchange
             if ((t & 63) == 0) s_x[3 * (t >> 6)] = w1, s_x[3 * (t >> 6) + 1] = w2, s_x[3 * (t >> 6) + 2] = w3;
             __syncthreads();
