@@ -318,7 +318,8 @@ int psnd_stft_loss_bwd(const float *p_mag, const float *t_mag, int64_t N, int64_
  *      w.r.t. the predicted waveform in one launch: the adjoint recomputes |X| of `wav` (the prediction), forms
  *      d loss / d |X| = k1 (|X| - t) + c_mag sign(|X| - t) / (|X| + eps) from it and the target magnitudes t_mag (N, K, F) in
  *      registers (the magnitude gradient never exists in HBM) and continues as psnd_stft_bwd.  norms / g3 / L / eps as
- *      psnd_stft_loss_bwd; gwav (N, T) fully overwritten.  psnd_stft_bwd_msl_supported(n_fft, hop): 1 where the span-staged
+ *      psnd_stft_loss_bwd; gwav (N, T) fully overwritten, or - accumulate != 0 - added to (the sum over the resolutions
+ *      without separate add launches).  psnd_stft_bwd_msl_supported(n_fft, hop): 1 where the span-staged
  *      adjoint runs (n_fft 512 / 1024 / 2048, even hop up to n/2 resp. 256), else callers use the two-launch path. */
 /*  psnd_stft_fwd_msl: psnd_stft_fwd (magnitude, centre framing) + psnd_stft_loss_partial FUSED for the prediction of one resolution:
  *      |X| is compared with t_mag (N, K, F) in registers and only the three sums leave the kernel - part[(n*B + b)*3 + {0,1,2}],
@@ -333,7 +334,7 @@ int psnd_stft_loss_final_blocks(const double *const *parts, const int64_t *KF, c
 int psnd_stft_bwd_msl_supported(int n_fft, int hop);
 int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan,
                       float mag_eps, const float *t_mag, const float *norms, const float *g3, int L, float eps,
-                      float *gwav, void *stream);
+                      int accumulate, float *gwav, void *stream);
 
 /* ---- data/dataset.py:196-250, SpeechDataLoader.pad_collate_fn on the audio column, device side --------------------
  *  flat : the batch's clips back to back (device, fp32); offs[n], lens[n] : start / length of clip n in flat (device

@@ -35,6 +35,7 @@ struct StftBwdParams {
     // from the recomputed |X| inside the kernel (loss_bwd_kernel of psnd_loss.hip): norms = (||t - p||, ||t||) per clip, g = upstream
     const float *msl_norms, *msl_g;
     float msl_invLN, msl_invLNKF, msl_eps;
+    int msl_accumulate;   // add to gwav (the other resolutions' gradient) instead of overwriting it
 #ifdef PSND_TRACE
     long long *trace;
 #endif
@@ -745,7 +746,8 @@ __global__ __launch_bounds__((L_ == 32 ? 512 : 256), (L_ == 32 ? 1 : 2)) void st
                 if (i >= int_lo && i < int_hi) gw[tg] = v;
                 else if (v != 0.f) unsafeAtomicAdd(gw + tg, v);
             } else if (i >= int_lo && i < int_hi && tg > p.pad && tg < Ti - 1 - p.pad) {
-                gw[tg] = v;
+                if (MSL && p.msl_accumulate) gw[tg] += v;          // this tile is the only writer of the sample in this launch
+                else gw[tg] = v;
             } else if (v != 0.f) {
                 int tr = tg < 0 ? -tg : tg;                        // reflect
                 tr = tr >= Ti ? 2 * (Ti - 1) - tr : tr;
@@ -1219,6 +1221,7 @@ struct MslArgs {
     const float *norms, *g3;
     int L;
     float eps;
+    int accumulate;
 };
 
 static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan, float mag_eps,
@@ -1235,8 +1238,10 @@ static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
     if (T >= ((int64_t)1 << 31) - 4 * (int64_t)n_fft) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: T too large");
     if (N == 0) return PSND_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t me = hipMemsetAsync(gwav, 0, sizeof(float) * (size_t)N * (size_t)T, s);
-    if (me != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: memset: %s", hipGetErrorString(me));
+    if (!(msl && msl->accumulate)) {
+        hipError_t me = hipMemsetAsync(gwav, 0, sizeof(float) * (size_t)N * (size_t)T, s);
+        if (me != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_bwd: memset: %s", hipGetErrorString(me));
+    }
     const int64_t F = psnd_frame_count(T, n_fft, hop, framing);
     if (F <= 0) return PSND_OK;
     const int64_t K = n_fft / 2 + 1;
@@ -1245,10 +1250,10 @@ static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
     p.wav = wav, p.plan = static_cast<const float *>(plan), p.gmag = gmag, p.gre = gre, p.gim = gim, p.gwav = gwav;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
     p.win_off = 0, p.inv_n = 0.f, p.env_eps = 0.f;
-    p.msl_norms = p.msl_g = nullptr, p.msl_invLN = p.msl_invLNKF = p.msl_eps = 0.f;
+    p.msl_norms = p.msl_g = nullptr, p.msl_invLN = p.msl_invLNKF = p.msl_eps = 0.f, p.msl_accumulate = 0;
     if (msl) {
         const double ln = (double)msl->L * (double)N;
-        p.msl_norms = msl->norms, p.msl_g = msl->g3, p.msl_eps = msl->eps;
+        p.msl_norms = msl->norms, p.msl_g = msl->g3, p.msl_eps = msl->eps, p.msl_accumulate = msl->accumulate;
         p.msl_invLN = (float)(1.0 / ln), p.msl_invLNKF = (float)(1.0 / (ln * (double)(K * F)));
     }
 #ifdef PSND_TRACE
@@ -1316,11 +1321,12 @@ extern "C" int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, 
 extern "C" int psnd_stft_bwd_msl_supported(int n_fft, int hop) { return hop > 0 && span_bwd_ok(n_fft, hop) ? 1 : 0; }
 
 extern "C" int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing, const void *plan, float mag_eps,
-                                 const float *t_mag, const float *norms, const float *g3, int L, float eps, float *gwav, void *stream) {
+                                 const float *t_mag, const float *norms, const float *g3, int L, float eps, int accumulate, float *gwav,
+                                 void *stream) {
     if (!wav || !t_mag || !norms || !g3) PSND_FAIL(PSND_E_ARG, "stft_bwd_msl: null pointer");
     if (L <= 0) PSND_FAIL(PSND_E_SHAPE, "stft_bwd_msl: L=%d", L);
     if (!psnd_stft_bwd_msl_supported(n_fft, hop)) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd_msl: n_fft=%d hop=%d", n_fft, hop);
-    const MslArgs m{norms, g3, L, eps};
+    const MslArgs m{norms, g3, L, eps, accumulate ? 1 : 0};
     return stft_bwd_impl(wav, N, T, n_fft, hop, framing, plan, mag_eps, t_mag, nullptr, nullptr, gwav, stream, &m);
 }
 

@@ -549,10 +549,12 @@ class MultiStftLossFn(torch.autograd.Function):
                 p, t = mags[2 * i], mags[2 * i + 1]
                 if not ctx.has_p[i] or (need_p and not need_t and _msl_fused(n_fft, hop)):
                     # one launch: the adjoint STFT recomputes |X| and forms the loss gradient in registers (psnd_stft_bwd_msl)
-                    gw = torch.empty_like(pred)
+                    # ... and adds it to the gradient of the resolutions before it (no memset, no add launch)
+                    acc = gpred is not None
+                    if not acc:
+                        gpred = torch.empty_like(pred)
                     check(lib().psnd_stft_bwd_msl(ptr(pred), N, pred.shape[1], n_fft, hop, FRAMING_CENTER, ptr(plans[i]), 0.0, ptr(t),
-                                                  ptr(norms[i]), ptr(g), L, ctx.eps, ptr(gw), s), 'psnd_stft_bwd_msl')
-                    gpred = gw if gpred is None else gpred.add_(gw)
+                                                  ptr(norms[i]), ptr(g), L, ctx.eps, int(acc), ptr(gpred), s), 'psnd_stft_bwd_msl')
                     continue
                 gp = torch.empty_like(p) if need_p else None
                 gt = torch.empty_like(t) if need_t else None

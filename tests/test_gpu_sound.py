@@ -89,7 +89,7 @@ def test_multi_stft_loss_vs_oracle(N, T, eps, gtol):
     assert np.abs(target.grad.cpu().numpy() - gt).max() <= gtol * np.abs(gt).max()
 
 
-@pytest.mark.parametrize('N,T,eps,gtol', [(16, 8192, 1e-2, 2e-4), (3, 20000, 1e-2, 2e-4), (5, 8192, 1e-5, 1e-2)])
+@pytest.mark.parametrize('N,T,eps,gtol', [(16, 8192, 1e-2, 2e-4), (3, 20000, 1e-2, 2e-4), (2, 3001, 1e-2, 2e-4), (5, 8192, 1e-5, 1e-2)])
 def test_multi_stft_loss_fused_gradient(N, T, eps, gtol, monkeypatch):
     """Training case (only the prediction needs a gradient): psnd_stft_bwd_msl forms d loss / d |X| inside the adjoint STFT.  Against
     the f64 oracle and against the two-launch path (psnd_stft_loss_bwd + psnd_stft_bwd) on the same inputs."""
