@@ -1021,6 +1021,41 @@ __device__ __forceinline__ void conv_finish_body(const float *gw_part, const flo
     const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
+    if constexpr (MANY) {
+        // Narrow layers over long clips (HiFi-GAN's 32- and 64-channel stages: n = Cin k of 96 ... 704, 48 ... 192 slabs): with one
+        // thread per element the slab sum was a serial chain of `splits` / 16 load batches on n of the workgroup's threads (33-83 us
+        // per launch at config 3).  The 1024 threads form NSG = 1024 / EP groups (EP = n rounded up to a power of two); group sg
+        // adds slabs sg, sg + NSG, ... (8 loads in flight), the groups' sums meet in LDS in a fixed order.
+        int EP = 64;
+        while (EP < n && EP < BD) EP <<= 1;
+        const int NSG = BD / EP, e = tid & (EP - 1), sg = tid / EP;
+        float *s_part = s_gw + pitch * k;                // [NSG][EP], behind the summed gradients
+        for (int e0 = 0; e0 < n; e0 += EP) {             // one trip unless n > 1024
+            const int ee = e0 + e;
+            const bool ok = ee < n;
+            const int j = (int)__umulhi((unsigned)ee, cmagic), c = ee - j * Cin;
+            const float *src = gw_part + ((size_t)j * Cb + co) * Ca + c;
+            float acc = 0.f;
+            for (int sp0 = sg; sp0 < splits; sp0 += 8 * NSG) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = (ok && sp0 + u * NSG < splits) ? src[(size_t)(sp0 + u * NSG) * slab] : 0.f;
+                acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+            if (NSG > 1) {
+                s_part[sg * EP + e] = acc;
+                __syncthreads();
+                if (sg == 0 && ok) {
+                    float a2 = 0.f;
+                    for (int q = 0; q < NSG; ++q) a2 += s_part[q * EP + e];
+                    s_gw[j * pitch + c] = a2;
+                }
+                __syncthreads();
+            } else if (ok) {
+                s_gw[j * pitch + c] = acc;
+            }
+        }
+    } else
     for (int e0 = tid; e0 < n; e0 += 4 * BD) {           // (j, ci) order: coalesced slab reads, 4 x 16 loads in flight
         int jj[4], cc[4];
         float gsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1030,13 +1065,13 @@ __device__ __forceinline__ void conv_finish_body(const float *gw_part, const flo
             jj[q] = (int)__umulhi((unsigned)e, cmagic);
             cc[q] = e - jj[q] * Cin;
         }
-        for (int sp0 = 0; sp0 < (MANY ? splits : 1); sp0 += 16) {
+        {
             float t[4][16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q] + (size_t)sp0 * slab;
+                const float *src = gw_part + ((size_t)jj[q] * Cb + co) * Ca + cc[q];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[q][u] = (e0 + BD * q < n && sp0 + u < splits) ? src[(size_t)u * slab] : 0.f;
+                for (int u = 0; u < 16; ++u) t[q][u] = (e0 + BD * q < n && u < splits) ? src[(size_t)u * slab] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1527,12 +1562,12 @@ extern "C" int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_pa
                                      int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream) {
     if (!gw_part || !v || !g || !gv || !gg || splits < 1) PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd: null pointer / splits");
     const size_t lds = sizeof(float) * (size_t)(Cin + 1) * k;
-    if (lds > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd: Cin*k=%d too large", Cin * k);
+    if (lds > 60 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd: Cin*k=%d too large", Cin * k);   // + 4 KB of slab-group sums
     const unsigned kmagic = (unsigned)((0x100000000ull + (unsigned)k - 1) / (unsigned)k);
     const unsigned cmagic = (unsigned)((0x100000000ull + (unsigned)Cin - 1) / (unsigned)Cin);
     const int threads = Cin * k >= 2048 ? 1024 : 256;         // big rows: 4x the loads in flight per output channel
-    if (splits > 16)
-        hipLaunchKernelGGL(conv_finish_kernel<true>, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part,
+    if (splits > 16)                                          // slab groups: 1024 threads + their partial sums (conv_finish_body)
+        hipLaunchKernelGGL(conv_finish_kernel<true>, dim3(Cout), dim3(1024), lds + 4096, static_cast<hipStream_t>(stream), gw_part,
                            gbias_part, splits, v, g, Cout, Cin, k, Cb, Ca, gv, gg, gbias, kmagic, cmagic);
     else
         hipLaunchKernelGGL(conv_finish_kernel<false>, dim3(Cout), dim3(threads), lds, static_cast<hipStream_t>(stream), gw_part,
@@ -1552,7 +1587,7 @@ extern "C" int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, 
         if (!d.gw_part || !d.v || !d.g || !d.gv || !d.gg || d.splits < 1 || d.Cout < 1 || d.Cin < 1 || d.k < 1)
             PSND_FAIL(PSND_E_ARG, "conv1d_wnorm_bwd_multi: descriptor %d: null pointer / bad sizes", i);
         const size_t l = sizeof(float) * (size_t)(d.Cin + 1) * d.k;
-        if (l > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd_multi: Cin*k=%d too large", d.Cin * d.k);
+        if (l > 60 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_wnorm_bwd_multi: Cin*k=%d too large", d.Cin * d.k);
         lds = l > lds ? l : lds;
         a.d[i] = d;
         a.kmagic[i] = (unsigned)((0x100000000ull + (unsigned)d.k - 1) / (unsigned)d.k);
@@ -1565,7 +1600,7 @@ extern "C" int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, 
     a.blk0[n] = total;
     const int threads = maxn >= 2048 ? 1024 : 256;
     if (maxsplits > 16)
-        hipLaunchKernelGGL(conv_finish_multi_kernel<true>, dim3(total), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL(conv_finish_multi_kernel<true>, dim3(total), dim3(1024), lds + 4096, static_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(conv_finish_multi_kernel<false>, dim3(total), dim3(threads), lds, static_cast<hipStream_t>(stream), a);
     PSND_CHECK_LAUNCH("conv1d_wnorm_bwd_multi");
