@@ -258,6 +258,7 @@ class FusedConvCL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, weight_v, weight_g, bias, res, shape, dil, want_raw, want_act, act_slope, prepped=None, pad=None):
+        ctx.set_materialize_grads(False)     # an unused output hands None to backward, not a zero-filled tensor
         _need(xa, torch.bfloat16)
         Cout, Cin, k = weight_v.shape
         Ca, Cb = xa.shape[2], round_up(Cout, ALIGN_C)
@@ -385,6 +386,7 @@ class ConvTransposeCL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xa, weight_v, weight_g, bias, shape, out_shape, stride, padding, act_slope):
+        ctx.set_materialize_grads(False)     # an unused output hands None to backward, not a zero-filled tensor
         _need(xa, torch.bfloat16)
         Cin, Cout, K = weight_v.shape
         if K != 2 * stride or padding > stride:
@@ -527,6 +529,7 @@ class ResBlockCL(torch.autograd.Function):
         """roles[i]:  'c1' / 'c2' the two convs of a ResBlock1 pair, 'r2' a ResBlock2 conv (conv + residual), 'head' a plain conv in
         front of the chain (input xa, raw + activated output start the residual stream; x is None), 'tail' a plain conv behind it
         (activated input, raw output only - returned as the first output, the second is None)."""
+        ctx.set_materialize_grads(False)     # an unused output hands None to backward, not a zero-filled tensor
         _need(xa, torch.bfloat16)
         dev = xa.device
         n = len(dils)
