@@ -1651,24 +1651,49 @@ __global__ __launch_bounds__(256) void convtr_prep_kernel(const float *v, const 
 
 // one block per input channel ci: s[co][jk] = sum over slabs of gw[tap][ci][phi * Cr + co] (jk = phi + tap * u), then the weight-norm
 // backward of the group v[ci] (Cout * K elements):  g_g = <s, vhat>,  g_v = (g / ||v||) (s - vhat g_g)
-__global__ __launch_bounds__(256) void convtr_finish_kernel(const float *gw_part, int splits, const float *v, const float *g, int Cin,
-                                                            int Cout, int K, int u, int Cr, int Cip, float *gv, float *gg) {
-    extern __shared__ float s_gw[];          // Cout * K
-    __shared__ float red[8];
-    const int ci = blockIdx.x, n = Cout * K, Nn = u * Cr;
+// Many slabs (the narrow upsamplers over long clips): launched with 1024 threads that form BD / EP slab groups (EP = the group's
+// elements rounded up to a power of two), as conv_finish_body<true> - one thread per element walked `splits` dependent loads.
+__global__ __launch_bounds__(1024) void convtr_finish_kernel(const float *gw_part, int splits, const float *v, const float *g, int Cin,
+                                                             int Cout, int K, int u, int Cr, int Cip, float *gv, float *gg) {
+    extern __shared__ float s_gw[];          // Cout * K, then the slab groups' partial sums [NSG][EP]
+    __shared__ float red[32];
+    const int ci = blockIdx.x, n = Cout * K, Nn = u * Cr, BD = blockDim.x, tid = threadIdx.x;
     const size_t slab = (size_t)2 * Cip * Nn;
     const float *vr = v + (size_t)ci * n;
     float ss = 0.f, dot = 0.f;
-    for (int e = threadIdx.x; e < 2 * u * Cout; e += 256) {          // (tap, phi, co) with co fastest: coalesced slab reads
+    const int E = 2 * u * Cout;
+    int EP = 64;
+    while (EP < E && EP < BD) EP <<= 1;
+    const int NSG = BD / EP, el = tid & (EP - 1), sg = tid / EP;
+    float *s_part = s_gw + n;
+    for (int e0 = 0; e0 < E; e0 += EP) {                             // (tap, phi, co) with co fastest: coalesced slab reads
+        const int e = e0 + el;
+        const bool ok = e < E;
         const int co = e % Cout, tp = e / Cout;                      // tp = tap * u + phi = jk
         const int tap = tp / u, phi = tp - tap * u;
         const float *src = gw_part + ((size_t)tap * Cip + ci) * Nn + phi * Cr + co;
         float a = 0.f;
-        for (int sp = 0; sp < splits; ++sp) a += src[(size_t)sp * slab];
-        s_gw[co * K + tp] = a;
+        for (int sp0 = sg; sp0 < splits; sp0 += 8 * NSG) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = (ok && sp0 + q * NSG < splits) ? src[(size_t)(sp0 + q * NSG) * slab] : 0.f;
+            a += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        if (NSG > 1) {
+            s_part[sg * EP + el] = a;
+            __syncthreads();
+            if (sg == 0 && ok) {
+                float a2 = 0.f;
+                for (int q = 0; q < NSG; ++q) a2 += s_part[q * EP + el];
+                s_gw[co * K + tp] = a2;
+            }
+            __syncthreads();
+        } else if (ok) {
+            s_gw[co * K + tp] = a;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = tid; i < n; i += BD) {
         const float vv = vr[i];
         ss += vv * vv;
         dot += vv * s_gw[i];
@@ -1677,14 +1702,16 @@ __global__ __launch_bounds__(256) void convtr_finish_kernel(const float *gw_part
         ss += __shfl_xor(ss, m, 64);
         dot += __shfl_xor(dot, m, 64);
     }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss, red[4 + (threadIdx.x >> 6)] = dot;
+    const int nw = BD >> 6;
+    if ((tid & 63) == 0) red[tid >> 6] = ss, red[16 + (tid >> 6)] = dot;
     __syncthreads();
-    const float sst = red[0] + red[1] + red[2] + red[3], dott = red[4] + red[5] + red[6] + red[7];
+    float sst = 0.f, dott = 0.f;
+    for (int w = 0; w < nw; ++w) sst += red[w], dott += red[16 + w];
     const float inv = 1.f / __builtin_sqrtf(sst);
     const float d = dott * inv;
     const float gs = g[ci] * inv;
-    for (int i = threadIdx.x; i < n; i += 256) gv[(size_t)ci * n + i] = gs * (s_gw[i] - vr[i] * inv * d);
-    if (threadIdx.x == 0) gg[ci] = d;
+    for (int i = tid; i < n; i += BD) gv[(size_t)ci * n + i] = gs * (s_gw[i] - vr[i] * inv * d);
+    if (tid == 0) gg[ci] = d;
 }
 
 // y = leaky_relu((a + b + c + d) / count, slope) over bf16 buffers (the mean of a stage's resblocks + the next activation,
@@ -1817,10 +1844,10 @@ extern "C" int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const f
                                        int Cr, int Cip, float *gv, float *gg, void *stream) {
     if (!gw_part || !v || !g || !gv || !gg || splits < 1) PSND_FAIL(PSND_E_ARG, "convtr1d_wnorm_bwd: null pointer / splits");
     if (K != 2 * stride) PSND_FAIL(PSND_E_SHAPE, "convtr1d_wnorm_bwd: K=%d stride=%d", K, stride);
-    const size_t lds = sizeof(float) * (size_t)Cout * K;
+    const size_t lds = sizeof(float) * ((size_t)Cout * K + 1024);     // + the slab groups' partial sums
     if (lds > 64 * 1024) PSND_FAIL(PSND_E_SHAPE, "convtr1d_wnorm_bwd: Cout*K=%d too large", Cout * K);
-    hipLaunchKernelGGL(convtr_finish_kernel, dim3(Cin), dim3(256), lds, static_cast<hipStream_t>(stream), gw_part, splits, v, g, Cin, Cout, K,
-                       stride, Cr, Cip, gv, gg);
+    hipLaunchKernelGGL(convtr_finish_kernel, dim3(Cin), dim3(splits > 16 ? 1024 : 256), lds, static_cast<hipStream_t>(stream), gw_part, splits,
+                       v, g, Cin, Cout, K, stride, Cr, Cip, gv, gg);
     PSND_CHECK_LAUNCH("convtr1d_wnorm_bwd");
     return PSND_OK;
 }
