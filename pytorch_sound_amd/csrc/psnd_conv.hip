@@ -154,18 +154,21 @@ constexpr int NA = (BM + 2 * 25) * PCS / 256 + 1;   // A pieces per thread per s
 //   KCT: input channels per pipeline stage.  Only 32 is instantiated: 64-channel stages (half the barriers, same bytes in flight)
 //   were built for the 3-tap instances in round 2 and measured no faster - config-2 step 1.242 ms against 1.236 ms, forward
 //   launch 13.8 us against 13.5 us - so the stage loop is not bound by the barrier / LDS hand-over latency per stage
-template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32>
+// WNC = waves across the output channels: 2 (tile 64 MT rows x 64 channels) or 1 (narrow layers, Cb <= 32: the four waves stack
+// along the rows, tile 128 MT rows x 32 channels - with the 2 x 2 arrangement half of the waves multiplied zero weight fragments)
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32, int WNC = 2>
 __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, const int by, bf16_t *smem_c, const size_t tblk) {
     static_assert(KCT == 32, "only 32-channel stages are validated");
+    static_assert(WNC == 1 || WNC == 2, "waves across the channels");
     constexpr int KC = KCT, PCS = KCT / 8, KS = KCT / 16;
     constexpr int RS = KC + 8;             // LDS row stride (bf16): 80 B / 144 B, odd multiples of 16 B
-    constexpr int BMt = 64 * MT, NAt = (BMt + 2 * HMX) * PCS / 256 + 1;
+    constexpr int BNt = 32 * WNC, BMt = 32 * (4 / WNC) * MT, NAt = (BMt + 2 * HMX) * PCS / 256 + 1;
     const int rowsA = BMt + 2 * p.hm;
     const int buf_elems = rowsA * RS;      // two A stage buffers; the weights never enter LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WNC == 2 ? wave >> 1 : wave, wn = WNC == 2 ? wave & 1 : 0;
     const long long r0 = (long long)bx * BMt;
-    const int n0 = by * BN;
+    const int n0 = by * BNt;
     const int li = lane & 31, kg = lane >> 5;
 
     f32x16 acc[MT];
@@ -333,7 +336,8 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     // through LDS so that every thread finishes 8 consecutive channels of one row: 16-byte loads of the mask /
     // residual operands and 16-byte stores (the first version stored 2 bytes per lane and paid a 64-bit
     // modulo per element: 8.9 k of the workgroup's 22 k cycles).
-    constexpr int OS = BN + 8;                                   // fp32 row stride: 4 rows apart = 32 banks apart
+    constexpr int OS = BNt + 8;                                  // fp32 row stride: 4 rows apart = 32 banks apart
+    constexpr int CGN = BNt / 8;                                 // 8-channel groups of a row
     float *sO = reinterpret_cast<float *>(smem_c);
     __syncthreads();                                             // every fragment read of the last stage is done
 #pragma unroll
@@ -346,8 +350,8 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     __syncthreads();
     const int l0 = (int)(r0 % p.Lp);                             // uniform
 #pragma unroll
-    for (int u = 0; u < BMt * BN / 8 / 256; ++u) {
-        const int idx = tid + 256 * u, row = idx >> 3, cg = idx & 7;
+    for (int u = 0; u < BMt * CGN / 256; ++u) {
+        const int idx = tid + 256 * u, row = idx / CGN, cg = idx % CGN;
         const long long r = r0 + row;
         const int col = n0 + 8 * cg;
         if (r >= p.R || col >= p.Cb) continue;
@@ -424,10 +428,10 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #endif
 }
 
-template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32>
+template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32, int WNC = 2>
 __global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, UPM, KCT>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, UPM, KCT, WNC>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32>
+template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2>
 __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
@@ -919,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, Wg
         conv_wgrad_body<COMBINE>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
-        conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT>(pc, c % cgx, c / cgx, smem_dyn, 0);
+        conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT, WNC>(pc, c % cgx, c / cgx, smem_dyn, 0);
     }
 }
 
@@ -1170,15 +1174,19 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     const int k = p.k, Cb = p.Cb, hm = p.hm;
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
     const int mt = conv_row_tiles(p.R, Cb);
-    const int bm = 64 * mt;
+    // narrow layers over long clips (HiFi-GAN's last stage: 32 channels x 131 k rows): 256-row tiles, the four waves along the rows
+    const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !getenv("PSND_CONV_NO_NARROW");
+    const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
-    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);   // the epilogue's fp32 tile
+    if (lds < sizeof(float) * bm * (bn + 8)) lds = sizeof(float) * bm * (bn + 8);   // the epilogue's fp32 tile
     if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "%s: LDS %zu too large", what, lds);
-    dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + BN - 1) / BN));
+    dim3 grid((unsigned)((p.R + bm - 1) / bm), (unsigned)((Cb + bn - 1) / bn));
 #define PSND_CONV_LAUNCH(KT_, D_, C_, H_, U_)                                                                         \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, U_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_, U_>;   \
+        if constexpr (!U_ && H_ == 25)                                                                                \
+            if (narrow) kern = conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, false, 32, 1>;         \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -1497,17 +1505,21 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     // 128-row input-gradient tiles at every size: half as many workgroups of that role share the CUs with the weight-gradient role
     // (config-2 launch 17.4 -> 15.5 us with 192 weight-gradient workgroups; no change for the long HiFi-GAN stages, which took them anyway)
     const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : 2;
-    const int bm = 64 * mt;
-    const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + BN - 1) / BN;
+    // narrow input gradient over long clips (Ca <= 32): 256-row tiles, the four waves along the rows (conv_cl_body, WNC = 1)
+    const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && (pc.R + 63) / 64 >= 1024 && !getenv("PSND_CONV_NO_NARROW");
+    const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
+    const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + bn - 1) / bn;
     const int nw = wgx * wgy * wgz;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);
-    if (lds < sizeof(float) * bm * (BN + 8)) lds = sizeof(float) * bm * (BN + 8);
+    if (lds < sizeof(float) * bm * (bn + 8)) lds = sizeof(float) * bm * (bn + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define PSND_PAIR_LAUNCH(KT_, D_, C_, H_)                                                                              \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
+        if constexpr (H_ == 25)                                                                                       \
+            if (narrow) kern = conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_, 32, 1>;          \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
