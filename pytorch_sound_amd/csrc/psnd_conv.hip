@@ -1175,7 +1175,8 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
     const int mt = conv_row_tiles(p.R, Cb);
     // narrow layers over long clips (HiFi-GAN's last stage: 32 channels x 131 k rows): 256-row tiles, the four waves along the rows
-    const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !getenv("PSND_CONV_NO_NARROW");
+    // (not with the combined operand: three A rings of 5 pieces per stage spill ~100 VGPRs at 256-row tiles)
+    const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !combine && !getenv("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
@@ -1185,8 +1186,8 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
 #define PSND_CONV_LAUNCH(KT_, D_, C_, H_, U_)                                                                         \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, U_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_, U_>;   \
-        if constexpr (!U_ && H_ == 25)                                                                                \
-            if (narrow) kern = conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, false, 32, 1>;         \
+        if constexpr (!U_ && H_ == 25 && !C_)                                                                         \
+            if (narrow) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 2, H_, false, 32, 1>;                 \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
@@ -1506,7 +1507,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     // (config-2 launch 17.4 -> 15.5 us with 192 weight-gradient workgroups; no change for the long HiFi-GAN stages, which took them anyway)
     const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : 2;
     // narrow input gradient over long clips (Ca <= 32): 256-row tiles, the four waves along the rows (conv_cl_body, WNC = 1)
-    const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && (pc.R + 63) / 64 >= 1024 && !getenv("PSND_CONV_NO_NARROW");
+    const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && !G2 && (pc.R + 63) / 64 >= 1024 && !getenv("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + bn - 1) / bn;
     const int nw = wgx * wgy * wgz;
@@ -1518,8 +1519,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
 #define PSND_PAIR_LAUNCH(KT_, D_, C_, H_)                                                                              \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
-        if constexpr (H_ == 25)                                                                                       \
-            if (narrow) kern = conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_, 32, 1>;          \
+        if constexpr (H_ == 25 && !C_)                                                                                \
+            if (narrow) kern = conv_bwd_pair_kernel<KT_, (D_ > 4 ? 4 : D_), 2, false, 2, H_, 32, 1>;                  \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
