@@ -428,8 +428,11 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #endif
 }
 
+#ifndef PSND_CONV_OCC
+#define PSND_CONV_OCC 2
+#endif
 template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32, int WNC = 2>
-__global__ __launch_bounds__(256, 2) void conv_cl_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, PSND_CONV_OCC) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, UPM, KCT, WNC>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
@@ -915,7 +918,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
 template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2>
-__global__ __launch_bounds__(256, 2) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
+__global__ __launch_bounds__(256, PSND_CONV_OCC) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
     if (b < nw) {
@@ -1173,11 +1176,22 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     const bool combine = p.A2 != nullptr;
     const int k = p.k, Cb = p.Cb, hm = p.hm;
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
-    const int mt = conv_row_tiles(p.R, Cb);
+    int mt = conv_row_tiles(p.R, Cb);
+    // 192-row tiles when they bring the launch from two rounds of the chip's 512 workgroup slots (2 per CU at ~200 VGPRs) down to one:
+    // HiFi-GAN at 16 x 8192 samples makes 519 / 526 tiles of 128 rows at its 64- and 128-channel stages - a second round for 7 / 14
+    // workgroups.  (PSND_CONV_MT3=0 switches it off.)
+    bool mt3 = false;
+    {
+        const char *e3 = getenv("PSND_CONV_MT3");
+        const int64_t coltiles = (Cb + BN - 1) / BN;
+        const int64_t t2 = (p.R + 127) / 128 * coltiles, t3 = (p.R + 191) / 192 * coltiles;
+        mt3 = mt == 2 && !combine && p.up_role == 0 && hm <= 25 && Cb > 32 && t2 > 512 && t2 <= 1024 && t3 <= 512 && !(e3 && atoi(e3) == 0) &&
+              !getenv("PSND_CONV_MT");
+    }
     // narrow layers over long clips (HiFi-GAN's last stage: 32 channels x 131 k rows): 256-row tiles, the four waves along the rows
     // (not with the combined operand: three A rings of 5 pieces per stage spill ~100 VGPRs at 256-row tiles)
     const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !combine && !getenv("PSND_CONV_NO_NARROW");
-    const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
+    const int bm = narrow ? 256 : (mt3 ? 192 : 64 * mt), bn = narrow ? 32 : BN;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
     if (lds < sizeof(float) * bm * (bn + 8)) lds = sizeof(float) * bm * (bn + 8);   // the epilogue's fp32 tile
@@ -1186,8 +1200,10 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
 #define PSND_CONV_LAUNCH(KT_, D_, C_, H_, U_)                                                                         \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, U_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_, U_>;   \
-        if constexpr (!U_ && H_ == 25 && !C_)                                                                         \
+        if constexpr (!U_ && H_ == 25 && !C_) {                                                                       \
             if (narrow) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 2, H_, false, 32, 1>;                 \
+            else if (mt3) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 3, H_, false, 32, 2>;               \
+        }                                                                                                             \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
