@@ -185,7 +185,9 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
     // HiFi-GAN blocks (43 / 65 KB of weights per stage buffer) ran ONE workgroup per CU.
     // (With a ROW-MAJOR pack the same idea lost, 11 -> 18 us: 64 separate 32-byte pieces per wave instruction.)
     constexpr int TC = 3, NCH = (KT + TC - 1) / TC, UNITS = D * NCH;
-    constexpr int DB = KCT == 64 ? (UNITS % 2 == 0 ? 2 : 1)          // 64-channel stages: a unit is twice the registers
+    // D = 1: the single-stage instances for 32 input channels (no A ring to turn; a shallow B ring keeps them under 168 VGPRs)
+    constexpr int DB = D == 1 ? (UNITS % 2 == 0 ? 2 : (UNITS % 3 == 0 ? 3 : 1))
+                     : KCT == 64 ? (UNITS % 2 == 0 ? 2 : 1)          // 64-channel stages: a unit is twice the registers
                      : KT <= 3 ? (COMBINE ? PSND_DB_COMBINE : PSND_DB_PLAIN) : (UNITS % 4 == 0 ? 4 : (UNITS % 3 == 0 ? 3 : 2));
     static_assert(UNITS % DB == 0, "B ring depth must divide the units of a ring turn (slots are static inside a turn)");
     uint4 ra[D][NAt], ra2[COMBINE ? D : 1][NAt], ram[COMBINE ? D : 1][NAt], rbf[DB][KS * TC];
@@ -432,7 +434,7 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
 #define PSND_CONV_OCC 2
 #endif
 template <int KT, int D, bool COMBINE, int NBUF, int MT, int HMX = 25, bool UPM = false, int KCT = 32, int WNC = 2>
-__global__ __launch_bounds__(256, PSND_CONV_OCC) void conv_cl_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_cl_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, UPM, KCT, WNC>(p, blockIdx.x, blockIdx.y, smem_dyn, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
@@ -1201,7 +1203,8 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_cl_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), C_, 2, 2, H_, U_> : conv_cl_kernel<KT_, D_, C_, 2, 1, H_, U_>;   \
         if constexpr (!U_ && H_ == 25 && !C_) {                                                                       \
-            if (narrow) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 2, H_, false, 32, 1>;                 \
+            if (narrow && p.Ca <= 32) kern = conv_cl_kernel<KT_, 1, false, 2, 2, H_, false, 32, 1>;  /* one k-stage: 3 workgroups per CU */ \
+            else if (narrow) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 2, H_, false, 32, 1>;            \
             else if (mt3) kern = conv_cl_kernel<KT_, (D_ > 4 ? 4 : D_), false, 2, 3, H_, false, 32, 2>;               \
         }                                                                                                             \
         if (lds > 64 * 1024) {                                                                                        \
