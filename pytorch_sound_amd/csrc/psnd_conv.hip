@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
 template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2>
-__global__ __launch_bounds__(256, PSND_CONV_OCC) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
+__global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
     if (b < nw) {
@@ -1539,7 +1539,8 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
         if constexpr (H_ == 25 && !C_)                                                                                \
-            if (narrow) kern = conv_bwd_pair_kernel<KT_, (D_ > 4 ? 4 : D_), 2, false, 2, H_, 32, 1>;                  \
+            if (narrow && Cb <= 32) kern = conv_bwd_pair_kernel<KT_, 1, 2, false, 2, H_, 32, 1>;   /* one k-stage: 3 workgroups per CU */ \
+            else if (narrow) kern = conv_bwd_pair_kernel<KT_, (D_ > 4 ? 4 : D_), 2, false, 2, H_, 32, 1>;             \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
