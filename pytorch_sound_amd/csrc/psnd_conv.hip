@@ -1345,6 +1345,14 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // launch, config-2 step: 160 -> 0.952 ms, 192 -> 0.948, 208 -> 0.953, 224 -> 0.962, 256 -> 0.965, 288 -> 1.29 (a second wave of
     // workgroups), 128 -> 0.979, 96 -> 1.056; config-3 step 5.31 ms with 192 everywhere against 5.46 with 128 for its short stages
     int64_t target = 192;
+    // 32 -> 32 channel layers over long clips run next to the single-stage input-gradient instance at THREE workgroups per CU (768
+    // slots, 516 short input-gradient tiles at HiFi-GAN's last stage) and the weight-gradient role is the long pole of that launch
+    // (86 chunks of 32 rows per workgroup at 192): config-3 step 4.33 (192) -> 4.24 (252), and on another box 4.13 (252), 4.14 (320),
+    // 4.10 (384), 4.08 (512), 4.10 (640)
+    if (Ca <= 32 && Cb <= 32 && (R + 63) / 64 >= 1024) {
+        target = 384;
+        if (const char *e = getenv("PSND_WGRAD_BLOCKS_NARROW")) target = atoi(e);
+    }
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
