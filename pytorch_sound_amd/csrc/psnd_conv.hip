@@ -1165,12 +1165,25 @@ extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
     return PSND_OK;
 }
 
-// 128-row workgroup tiles once 64-row tiles would make >= 1024 workgroups (two full rounds of the chip's 512 slots)
-static int conv_row_tiles(int64_t R, int Cb) {
+// Row tile of a forward / input-gradient launch: 64, 128 or (with3) 192 rows.  At ~200 VGPRs a CU holds 2 workgroups, the chip 512: the
+// launch takes ceil(tiles / 512) rounds, and a workgroup's time is a fixed part (first stage in, epilogue out: ~3.9 us) plus ~0.042 us
+// per row (fitted on HiFi-GAN's 64-channel stage: 9.3 us at 128 rows, 12 us at 192) - about 100 rows' worth.  Pick the cheapest.
+// (Before: 128 rows from 1024 tiles of 64 on - config 2's 256 -> 513 conv ran 828 workgroups of 64 rows in two rounds, HiFi-GAN's
+// 64- / 128-channel stages 519 / 526 of 128 rows.)
+static int conv_row_tiles(int64_t R, int Cb, bool with3 = false) {
     const char *fe = getenv("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
     const int force = fe ? atoi(fe) : 0;
     if (force == 1 || force == 2) return force;
-    return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;
+    if (getenv("PSND_CONV_MT_V1")) return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;   // A/B: the rule of before
+    const int64_t coltiles = (Cb + BN - 1) / BN;
+    int best = 1;
+    int64_t best_cost = 0;
+    for (int mt = 1; mt <= (with3 ? 3 : 2); ++mt) {
+        const int64_t tiles = (R + 64 * mt - 1) / (64 * mt) * coltiles;
+        const int64_t cost = (tiles + 511) / 512 * (100 + 64 * mt);
+        if (mt == 1 || cost < best_cost) best = mt, best_cost = cost;
+    }
+    return best;
 }
 
 // enqueue one conv_cl_kernel launch for a filled ConvParams (tile instance by size, tap count, operand combine, tap reach)
@@ -1178,18 +1191,12 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     const bool combine = p.A2 != nullptr;
     const int k = p.k, Cb = p.Cb, hm = p.hm;
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
-    int mt = conv_row_tiles(p.R, Cb);
-    // 192-row tiles when they bring the launch from two rounds of the chip's 512 workgroup slots (2 per CU at ~200 VGPRs) down to one:
-    // HiFi-GAN at 16 x 8192 samples makes 519 / 526 tiles of 128 rows at its 64- and 128-channel stages - a second round for 7 / 14
-    // workgroups.  (PSND_CONV_MT3=0 switches it off.)
-    bool mt3 = false;
-    {
-        const char *e3 = getenv("PSND_CONV_MT3");
-        const int64_t coltiles = (Cb + BN - 1) / BN;
-        const int64_t t2 = (p.R + 127) / 128 * coltiles, t3 = (p.R + 191) / 192 * coltiles;
-        mt3 = mt == 2 && !combine && p.up_role == 0 && hm <= 25 && Cb > 32 && t2 > 512 && t2 <= 1024 && t3 <= 512 && !(e3 && atoi(e3) == 0) &&
-              !getenv("PSND_CONV_MT");
-    }
+    // 192-row tiles exist for the plain instances (no combined operand, reach <= 25, not the transposed conv); PSND_CONV_MT3=0: off
+    const char *e3 = getenv("PSND_CONV_MT3");
+    const bool can3 = !combine && p.up_role == 0 && hm <= 25 && Cb > 32 && !(e3 && atoi(e3) == 0);
+    int mt = conv_row_tiles(p.R, Cb, can3);
+    const bool mt3 = mt == 3;
+    if (mt3) mt = 2;
     // narrow layers over long clips (HiFi-GAN's last stage: 32 channels x 131 k rows): 256-row tiles, the four waves along the rows
     // (not with the combined operand: three A rings of 5 pieces per stage spill ~100 VGPRs at 256-row tiles)
     const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !combine && !getenv("PSND_CONV_NO_NARROW");
