@@ -727,15 +727,21 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t *p0) {   // rows r .. r+3
     const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3))) *)(p0 + 4 * WTP));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-template <bool COMB>
+// NARROW (Ca, Cb <= 32: one 32 x 32 block per tap, three quarters of the 64 x 64 tile would be zeros): the four waves take four TAP
+// groups on the same staged tiles - a workgroup covers 12 taps, the rows are fetched once instead of once per tap group, and the
+// activation tile holds 32 + the span of all 12 taps (<= WXRN = 96 rows, three pieces per thread).
+constexpr int WXRN = 96;
+constexpr int kWgradNarrowLdsBytes = 2 * (32 + WXRN) * WTP * (int)sizeof(bf16_t);
+template <bool COMB, bool NARROW = false>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
 #if !PSND_WGRAD_TR
     conv_wgrad_body_v1(p, bx, by, bz, sT, tblk);
 #else
+    constexpr int XU = NARROW ? 3 : 2, XR = NARROW ? WXRN : WXR, TPW = NARROW ? 4 * WKT : WKT;   // x pieces per thread, x tile rows, taps per workgroup
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
+    const int wm = NARROW ? 0 : wave >> 1, wn = NARROW ? 0 : wave & 1, li = lane & 31, kg = lane >> 5;
     const int co0 = bx * 64, ci0 = by * 64;
-    const int ntg = (p.k + WKT - 1) / WKT;               // tap groups: one per workgroup (bz = split * ntg + group)
+    const int ntg = (p.k + TPW - 1) / TPW;               // tap groups: one per workgroup (bz = split * ntg + group)
     const int split = bz / ntg, tgrp = bz - split * ntg;
     const long long rs = (long long)split * p.rows_per_split;
     const long long re = min(rs + p.rows_per_split, p.R);
@@ -757,23 +763,24 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
         return __builtin_bit_cast(uint4, v);
     };
-    const int t0 = tgrp * WKT;
-    const int nt = min(WKT, p.k - t0);
-    int lo = p.off0 + t0 * p.dstep, hi = lo;             // row offsets of this group's taps: the activation tile covers [lo, 32 + hi)
-    for (int j = 1; j < nt; ++j) {
-        const int o = p.off0 + (t0 + j) * p.dstep;
+    const int tw0 = tgrp * TPW, ntw = min(TPW, p.k - tw0);      // the workgroup's taps
+    const int t0 = NARROW ? tw0 + wave * WKT : tw0;             // this wave's taps (NARROW: a wave past k has none)
+    const int nt = max(0, min(WKT, p.k - t0));
+    int lo = p.off0 + tw0 * p.dstep, hi = lo;            // row offsets of the workgroup's taps: the activation tile covers [lo, 32 + hi)
+    for (int j = 1; j < ntw; ++j) {
+        const int o = p.off0 + (tw0 + j) * p.dstep;
         lo = min(lo, o), hi = max(hi, o);
     }
-    const int xrows = 32 + hi - lo;                      // <= WXR (the launchers check the dilation)
-    int toff[WKT];                                       // tile row offset of tap j (taps past nt: tap 0's)
+    const int xrows = 32 + hi - lo;                      // <= XR (the launchers check the dilation)
+    int toff[WKT];                                       // tile row offset of tap j (taps past nt: the group's first tap's)
 #pragma unroll
-    for (int j = 0; j < WKT; ++j) toff[j] = p.off0 + (t0 + (j < nt ? j : 0)) * p.dstep - lo;
+    for (int j = 0; j < WKT; ++j) toff[j] = p.off0 + (j < nt ? t0 + j : (nt > 0 ? t0 : tw0)) * p.dstep - lo;
     f32x16 acc[WKT];
 #pragma unroll
     for (int j = 0; j < WKT; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    uint4 vg[WD], vg2[COMB ? WD : 1], vgm[COMB ? WD : 1], vx[WD][2];
+    uint4 vg[WD], vg2[COMB ? WD : 1], vgm[COMB ? WD : 1], vx[WD][XU];
     // branch-free buffer loads (offset OOB -> zeros), see conv_cl_kernel
     auto fetch = [&](auto sc, long long r0) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
@@ -785,7 +792,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
             vgm[s] = ld16(rGM, og);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < XU; ++u) {
             const int xi = rr + 32 * u;
             const long long rx = r0 + lo + xi;
             bool ok = xi < xrows && rx >= 0 && rx < p.R && xok;
@@ -824,6 +831,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         *reinterpret_cast<uint4 *>(sG + rr * WTP + 8 * cg) = g;
         *reinterpret_cast<uint4 *>(sX + rr * WTP + 8 * cg) = vx[s][0];
         if (rr + 32 < xrows) *reinterpret_cast<uint4 *>(sX + (rr + 32) * WTP + 8 * cg) = vx[s][1];
+        if constexpr (NARROW)
+            if (rr + 64 < xrows) *reinterpret_cast<uint4 *>(sX + (rr + 64) * WTP + 8 * cg) = vx[s][2];
     };
     // this lane's piece of a transposing read: row (lane & 15) >> 2 of the 4-row block, channels 16 ((lane >> 4) & 1) + 4 (lane & 3) ..
     const int trow = 8 * kg + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -834,7 +843,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         static_for<0, WD>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
             const int ch = c + s;
-            bf16_t *sG = sT + (ch & 1) * (32 + WXR) * WTP, *sX = sG + 32 * WTP;
+            bf16_t *sG = sT + (ch & 1) * (32 + XR) * WTP, *sX = sG + 32 * WTP;
             if (ch == 4) PSND_WSTAMP(5);
             stage(sc, rs + 32ll * ch, sG, sX);
             if (ch == 0) PSND_WSTAMP(1);
@@ -861,7 +870,35 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
     PSND_WSTAMP(2);
     // D[i = co][j = ci]: lane & 31 -> ci, registers -> co.  Through LDS (the chunk tiles are dead), so that a thread stores four consecutive
     // ci: 12 16-byte stores per thread instead of 48 4-byte ones (the store tail is issue-bound: 3.7 k cycles of 26 k).
-    {
+    if constexpr (NARROW) {
+        // every wave holds the 32 x 32 blocks of ITS taps: four blocks per pass j go through LDS, a thread stores four consecutive ci
+        constexpr int EPN = 36;
+        float *sE = reinterpret_cast<float *>(sT);
+        static_assert(4 * 32 * EPN * 4 <= kWgradNarrowLdsBytes, "four 32 x 32 blocks fit the chunk buffers");
+        const bool vec = (p.Ca % 4 == 0);
+#pragma unroll
+        for (int j = 0; j < WKT; ++j) {
+            if (j > 0) __syncthreads();
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) sE[(wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg) * EPN + li] = acc[j][rg];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = tid + 256 * u, w = idx >> 8, row = (idx >> 3) & 31, c4 = 4 * (idx & 7);
+                const int tap = tw0 + w * WKT + j;
+                const int co = co0 + row, ci = ci0 + c4;
+                if (tap >= p.k || co >= p.Cb || ci >= p.Ca) continue;
+                float *dst = p.gw + (((size_t)split * p.k + tap) * p.Cb) * p.Ca;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sE + (w * 32 + row) * EPN + c4);
+                if (vec && ci + 3 < p.Ca) {
+                    *reinterpret_cast<f32x4 *>(dst + (size_t)co * p.Ca + ci) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+                    for (int q = 0; q < 4 && ci + q < p.Ca; ++q) dst[(size_t)co * p.Ca + ci + q] = e[q];
+                }
+            }
+        }
+    } else {
         constexpr int EP = 68;                                     // fp32 row pitch of the 64 x 64 tile of one tap
         float *sE = reinterpret_cast<float *>(sT);
         static_assert(64 * EP * 4 <= kWgradLdsBytes, "one tap's slab tile fits the chunk buffers");
@@ -919,13 +956,14 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
-template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2>
+// WN: the weight-gradient role of a 32 -> 32 channel layer (conv_wgrad_body<.., NARROW>: 12 taps per workgroup, one per 3 per wave)
+template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2, bool WN = false>
 __global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
     const int b = blockIdx.x;
     if (b < nw) {
         const int bx = b % wgx, r = b / wgx;
-        conv_wgrad_body<COMBINE>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
+        conv_wgrad_body<COMBINE, WN>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
     } else {
         const int c = b - nw;
         conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT, WNC>(pc, c % cgx, c / cgx, smem_dyn, 0);
@@ -1343,7 +1381,8 @@ extern "C" int psnd_mask_head_bwd(const float *gest, const float *mag, const voi
 }
 
 static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
-    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * ((k + WKT - 1) / WKT);   // tap groups are workgroups too
+    const bool narrow_w = Ca <= 32 && Cb <= 32 && (R + 63) / 64 >= 1024;          // conv_wgrad_body<.., NARROW>: 12 taps per workgroup
+    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * (narrow_w ? (k + 4 * WKT - 1) / (4 * WKT) : (k + WKT - 1) / WKT);   // tap groups are workgroups too
     // workgroups of the weight-gradient role.  Measured on the config-2 step with the paired backward launch (256 CUs, 2
     // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
     // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
@@ -1356,8 +1395,8 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // slots, 516 short input-gradient tiles at HiFi-GAN's last stage) and the weight-gradient role is the long pole of that launch
     // (86 chunks of 32 rows per workgroup at 192): config-3 step 4.33 (192) -> 4.24 (252), and on another box 4.13 (252), 4.14 (320),
     // 4.10 (384), 4.08 (512), 4.10 (640)
-    if (Ca <= 32 && Cb <= 32 && (R + 63) / 64 >= 1024) {
-        target = 384;
+    if (narrow_w) {
+        target = 192;
         if (const char *e = getenv("PSND_WGRAD_BLOCKS_NARROW")) target = atoi(e);
     }
     if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
@@ -1534,7 +1573,6 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     int64_t rps;
     const int splits = wgrad_splits(pw.R, Ca, Cb, k, &rps);
     pw.rows_per_split = (int)rps;
-    const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + WKT - 1) / WKT);
     const char *pe = getenv("PSND_PAIR_MT");
     const int pair_mt = pe ? atoi(pe) : 0;
     // 128-row input-gradient tiles at every size: half as many workgroups of that role share the CUs with the weight-gradient role
@@ -1544,18 +1582,30 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && !G2 && (pc.R + 63) / 64 >= 1024 && !getenv("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + bn - 1) / bn;
+    // 32 -> 32 channels over long clips: the weight-gradient role spreads 12 taps over the four waves (their span must fit its tile);
+    // without the combined operand the input-gradient role is the single-stage instance at three workgroups per CU
+    const bool wn = Ca <= 32 && Cb <= 32 && (pc.R + 63) / 64 >= 1024 && hm <= 25 && gw_part &&
+                    ((k < 4 * WKT ? k : 4 * WKT) - 1) * (dil < 0 ? -dil : dil) <= WXRN - 32 && !getenv("PSND_CONV_NO_NARROW");
+    const bool narrow1 = narrow && Cb <= 32;
+    const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * (wn ? (k + 4 * WKT - 1) / (4 * WKT) : (k + WKT - 1) / WKT);
     const int nw = wgx * wgy * wgz;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);
     if (lds < sizeof(float) * bm * (bn + 8)) lds = sizeof(float) * bm * (bn + 8);
     if (lds < (size_t)kWgradLdsBytes) lds = kWgradLdsBytes;
+    if (wn && lds < (size_t)kWgradNarrowLdsBytes) lds = kWgradNarrowLdsBytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define PSND_PAIR_LAUNCH(KT_, D_, C_, H_)                                                                              \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
-        if constexpr (H_ == 25 && !C_)                                                                                \
-            if (narrow && Cb <= 32) kern = conv_bwd_pair_kernel<KT_, 1, 2, false, 2, H_, 32, 1>;   /* one k-stage: 3 workgroups per CU */ \
+        if constexpr (H_ == 25) {                                                                                     \
+            if (wn && mt == 2) kern = conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_, 32, 2, true>;   \
+        }                                                                                                             \
+        if constexpr (H_ == 25 && !C_) {                                                                              \
+            if (narrow1 && wn) kern = conv_bwd_pair_kernel<KT_, 1, 2, false, 2, H_, 32, 1, true>;   /* one k-stage: 3 workgroups per CU */ \
+            else if (narrow1) kern = conv_bwd_pair_kernel<KT_, 1, 2, false, 2, H_, 32, 1>;                            \
             else if (narrow) kern = conv_bwd_pair_kernel<KT_, (D_ > 4 ? 4 : D_), 2, false, 2, H_, 32, 1>;             \
+        }                                                                                                             \
         if (lds > 64 * 1024) {                                                                                        \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \

@@ -23,7 +23,9 @@ def relf(a, b):
 
 
 @pytest.mark.parametrize('Cin,Cout,k,dil,L,N', [(64, 64, 3, 1, 50, 2), (96, 64, 3, 5, 173, 3), (64, 40, 7, 3, 61, 2),
-                                               (513, 256, 3, 1, 173, 2), (256, 513, 3, 1, 45, 2), (32, 32, 11, 5, 200, 1)])
+                                               (513, 256, 3, 1, 173, 2), (256, 513, 3, 1, 45, 2), (32, 32, 11, 5, 200, 1),
+                                               # 32 -> 32 channels over >= 65536 rows: narrow tiles, single-stage instances, 12 taps per weight-gradient workgroup
+                                               (32, 32, 11, 5, 8192, 8), (32, 32, 7, 3, 8192, 8), (32, 32, 3, 1, 8192, 8), (32, 32, 11, 1, 8200, 8)])
 def test_fused_conv_fwd_bwd(Cin, Cout, k, dil, L, N):
     from pytorch_sound_amd import cl
     from pytorch_sound_amd.models.vocoders.hifi_gan import WNConv1d
