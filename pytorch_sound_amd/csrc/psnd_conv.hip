@@ -732,12 +732,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t *p0) {   // rows r .. r+3
 // activation tile holds 32 + the span of all 12 taps (<= WXRN = 96 rows, three pieces per thread).
 constexpr int WXRN = 96;
 constexpr int kWgradNarrowLdsBytes = 2 * (32 + WXRN) * WTP * (int)sizeof(bf16_t);
-template <bool COMB, bool NARROW = false>
+// WK: taps per (wave of a) workgroup - 3, or 4 / 6 for the 7- / 11-tap layers of the paired backward (half the tap groups: the rows
+// are staged half as often and a split count of twice the size fits the same number of workgroups)
+template <bool COMB, bool NARROW = false, int WK = WKT>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int bx, const int by, const int bz, bf16_t *sT, const size_t tblk) {
 #if !PSND_WGRAD_TR
     conv_wgrad_body_v1(p, bx, by, bz, sT, tblk);
 #else
-    constexpr int XU = NARROW ? 3 : 2, XR = NARROW ? WXRN : WXR, TPW = NARROW ? 4 * WKT : WKT;   // x pieces per thread, x tile rows, taps per workgroup
+    constexpr int XU = NARROW ? 3 : 2, XR = NARROW ? WXRN : WXR, TPW = NARROW ? 4 * WK : WK;   // x pieces per thread, x tile rows, taps per workgroup
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = NARROW ? 0 : wave >> 1, wn = NARROW ? 0 : wave & 1, li = lane & 31, kg = lane >> 5;
     const int co0 = bx * 64, ci0 = by * 64;
@@ -764,20 +766,20 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         return __builtin_bit_cast(uint4, v);
     };
     const int tw0 = tgrp * TPW, ntw = min(TPW, p.k - tw0);      // the workgroup's taps
-    const int t0 = NARROW ? tw0 + wave * WKT : tw0;             // this wave's taps (NARROW: a wave past k has none)
-    const int nt = max(0, min(WKT, p.k - t0));
+    const int t0 = NARROW ? tw0 + wave * WK : tw0;             // this wave's taps (NARROW: a wave past k has none)
+    const int nt = max(0, min(WK, p.k - t0));
     int lo = p.off0 + tw0 * p.dstep, hi = lo;            // row offsets of the workgroup's taps: the activation tile covers [lo, 32 + hi)
     for (int j = 1; j < ntw; ++j) {
         const int o = p.off0 + (tw0 + j) * p.dstep;
         lo = min(lo, o), hi = max(hi, o);
     }
     const int xrows = 32 + hi - lo;                      // <= XR (the launchers check the dilation)
-    int toff[WKT];                                       // tile row offset of tap j (taps past nt: the group's first tap's)
+    int toff[WK];                                       // tile row offset of tap j (taps past nt: the group's first tap's)
 #pragma unroll
-    for (int j = 0; j < WKT; ++j) toff[j] = p.off0 + (j < nt ? t0 + j : (nt > 0 ? t0 : tw0)) * p.dstep - lo;
-    f32x16 acc[WKT];
+    for (int j = 0; j < WK; ++j) toff[j] = p.off0 + (j < nt ? t0 + j : (nt > 0 ? t0 : tw0)) * p.dstep - lo;
+    f32x16 acc[WK];
 #pragma unroll
-    for (int j = 0; j < WKT; ++j)
+    for (int j = 0; j < WK; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
     uint4 vg[WD], vg2[COMB ? WD : 1], vgm[COMB ? WD : 1], vx[WD][XU];
@@ -853,17 +855,17 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
             fetch(sc, rs + 32ll * (ch + WD));
             // all sixteen transposing reads first, then the six MFMAs, in ONE basic block: taps past nt read tap 0's rows again and
             // accumulate into registers nobody stores (a branch per tap made every MFMA wait for its own two reads: 6 x ~160 cycles)
-            bf16x8 fa[2], fb[2][WKT];
+            bf16x8 fa[2], fb[2][WK];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 fa[kk] = tr_frag(sG + (16 * kk + trow) * WTP + wm * 32 + tcol);
 #pragma unroll
-                for (int j = 0; j < WKT; ++j) fb[kk][j] = tr_frag(sX + (16 * kk + trow + toff[j]) * WTP + wn * 32 + tcol);
+                for (int j = 0; j < WK; ++j) fb[kk][j] = tr_frag(sX + (16 * kk + trow + toff[j]) * WTP + wn * 32 + tcol);
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < WKT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < WK; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk], fb[kk][j], acc[j], 0, 0, 0);
         });
     }
     __syncthreads();
@@ -877,7 +879,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         static_assert(4 * 32 * EPN * 4 <= kWgradNarrowLdsBytes, "four 32 x 32 blocks fit the chunk buffers");
         const bool vec = (p.Ca % 4 == 0);
 #pragma unroll
-        for (int j = 0; j < WKT; ++j) {
+        for (int j = 0; j < WK; ++j) {
             if (j > 0) __syncthreads();
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) sE[(wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * kg) * EPN + li] = acc[j][rg];
@@ -885,7 +887,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = tid + 256 * u, w = idx >> 8, row = (idx >> 3) & 31, c4 = 4 * (idx & 7);
-                const int tap = tw0 + w * WKT + j;
+                const int tap = tw0 + w * WK + j;
                 const int co = co0 + row, ci = ci0 + c4;
                 if (tap >= p.k || co >= p.Cb || ci >= p.Ca) continue;
                 float *dst = p.gw + (((size_t)split * p.k + tap) * p.Cb) * p.Ca;
@@ -904,7 +906,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams &p, const int 
         static_assert(64 * EP * 4 <= kWgradLdsBytes, "one tap's slab tile fits the chunk buffers");
         const bool vec = (p.Ca % 4 == 0);
 #pragma unroll
-        for (int j = 0; j < WKT; ++j)
+        for (int j = 0; j < WK; ++j)
             if (j < nt) {
                 if (j > 0) __syncthreads();
 #pragma unroll
@@ -956,6 +958,9 @@ __global__ __launch_bounds__(256, PSND_WGRAD_WAVES) void conv_wgrad_kernel(Wgrad
 // gradient combine) - as ONE launch: each alone fills part of the chip with 10-20 us latency chains (256 + 384 workgroups
 // at the config-2 shape, 2 per CU), both read the same incoming gradient.  Workgroups [0, nw) take the weight-gradient
 // role (the longer chain goes first), the rest the input-gradient role; registers and LDS are the maximum of the two.
+// taps per weight-gradient workgroup of the paired backward instance <KT, HMX>: the 7- / 11- / 16-tap instances (reach <= 25) take
+// 4 / 6 / 6 taps per pass - two tap groups instead of three / four / six
+constexpr int pair_wk(int KT, int HMX) { return HMX != 25 ? WKT : (KT >= 9 ? 6 : (KT >= 5 ? 4 : WKT)); }
 // WN: the weight-gradient role of a 32 -> 32 channel layer (conv_wgrad_body<.., NARROW>: 12 taps per workgroup, one per 3 per wave)
 template <int KT, int D, int NBUF, bool COMBINE, int MT, int HMX = 25, int KCT = 32, int WNC = 2, bool WN = false>
 __global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_bwd_pair_kernel(ConvParams pc, WgradParams pw, int nw, int wgx, int wgy, int cgx) {
@@ -963,7 +968,7 @@ __global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_bwd_pa
     const int b = blockIdx.x;
     if (b < nw) {
         const int bx = b % wgx, r = b / wgx;
-        conv_wgrad_body<COMBINE, WN>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);
+        conv_wgrad_body<COMBINE, WN, ((WN || D == 1) ? WKT : pair_wk(KT, HMX))>(pw, bx, r % wgy, r / wgy, smem_dyn, 0);   // D == 1: the 168-VGPR instances
     } else {
         const int c = b - nw;
         conv_cl_body<KT, D, COMBINE, NBUF, MT, HMX, false, KCT, WNC>(pc, c % cgx, c / cgx, smem_dyn, 0);
@@ -1382,7 +1387,8 @@ extern "C" int psnd_mask_head_bwd(const float *gest, const float *mag, const voi
 
 static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     const bool narrow_w = Ca <= 32 && Cb <= 32 && (R + 63) / 64 >= 1024;          // conv_wgrad_body<.., NARROW>: 12 taps per workgroup
-    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * (narrow_w ? (k + 4 * WKT - 1) / (4 * WKT) : (k + WKT - 1) / WKT);   // tap groups are workgroups too
+    const int wk = narrow_w ? 4 * WKT : pair_wk(k <= 3 ? 3 : (k <= 7 ? 7 : (k <= 11 ? 11 : 16)), 25);   // taps per workgroup (paired backward)
+    const int tx = (Cb + 63) / 64, ty = (Ca + 63) / 64 * ((k + wk - 1) / wk);   // tap groups are workgroups too
     // workgroups of the weight-gradient role.  Measured on the config-2 step with the paired backward launch (256 CUs, 2
     // workgroups each, 368 input-gradient workgroups alongside): 128 -> 1.87 ms, 160 -> 1.74, 192 -> 1.73, 208 -> 1.75,
     // 256 -> 1.90, 320 -> 2.28 (more splits = shorter chains but more slabs for the weight-norm backward to add up, and a
@@ -1587,7 +1593,11 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const bool wn = Ca <= 32 && Cb <= 32 && (pc.R + 63) / 64 >= 1024 && hm <= 25 && gw_part &&
                     ((k < 4 * WKT ? k : 4 * WKT) - 1) * (dil < 0 ? -dil : dil) <= WXRN - 32 && !getenv("PSND_CONV_NO_NARROW");
     const bool narrow1 = narrow && Cb <= 32;
-    const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * (wn ? (k + 4 * WKT - 1) / (4 * WKT) : (k + WKT - 1) / WKT);
+    // taps per weight-gradient workgroup: as the instance picked below (KT by k, HMX by the reach)
+    const int wk = wn ? 4 * WKT : (narrow1 ? WKT : pair_wk(k <= 3 ? 3 : (k <= 7 ? 7 : (k <= 11 ? 11 : 16)), hm > 25 ? 40 : 25));
+    if (gw_part && !wn && ((k < wk ? k : wk) - 1) * (dil < 0 ? -dil : dil) > WXR - 32)
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_bwd: dilation %d: a group of %d taps spans more than %d rows", dil, wk, WXR - 32);
+    const int wgx = (Cb + 63) / 64, wgy = (Ca + 63) / 64, wgz = splits * ((k + wk - 1) / wk);
     const int nw = wgx * wgy * wgz;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);
