@@ -94,6 +94,12 @@ int psnd_stft_bwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, in
                   const float *gmag, const float *gre, const float *gim,
                   float *gwav, void *stream);
 
+/* ---- gradient of STFTTorchAudio.transform (transforms.py:305-311: magnitude AND a differentiable atan2 phase):
+ *      (g_mag, g_phase | mag, phase) -> (g_re, g_im), all (N,K,F) fp32 = n elements; either of g_mag / g_phase may be NULL.
+ *      The result is what psnd_stft_bwd takes as gre / gim. */
+int psnd_polar_bwd(const float *gmag, const float *gphase, const float *mag, const float *phase, int64_t n,
+                   float *gre, float *gim, void *stream);
+
 /* ---- inverse STFT: replaces STFT.inverse (transforms.py:71-101): per frame (hop/n) * window * irDFT(mag e^{i phase})
  *      (what the pinv synthesis basis computes), overlap-add, divide by the squared-window envelope + eps,
  *      scale n/hop, trim n/2 on both sides.   mag, phase : (N,K,F);  out : (N, (F-1)*hop) fp32, fully overwritten. */

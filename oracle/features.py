@@ -321,6 +321,7 @@ def istft_f64(mag, phase, n_fft, hop, win_length=None, eps=1e-9):
     for f in range(F):
         out[:, f * hop:f * hop + n_fft] += fr[:, f]
         env[f * hop:f * hop + n_fft] += w * w
-    out = out / (env + eps) * (n_fft / hop)
+    with np.errstate(divide='ignore', invalid='ignore'):     # eps = 0 (torch.istft): the envelope is zero only inside the trimmed n/2 edges
+        out = out / (env + eps) * (n_fft / hop)
     p = n_fft // 2
     return out[:, p:L - p]

@@ -72,6 +72,7 @@ SIGNATURES = {
     'psnd_mha_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _P, _P, _P]),
     'psnd_softmax_keys_fwd': (_INT, [_P, _P, _I64, _I64, _F, _P]),
     'psnd_softmax_keys_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
+    'psnd_polar_bwd': (_INT, [_P, _P, _P, _P, _I64, _P, _P, _P]),
     'psnd_preemphasis_fwd': (_INT, [_P, _I64, _I64, _F, _P, _P]),
     'psnd_preemphasis_bwd': (_INT, [_P, _I64, _I64, _F, _P, _P]),
     'psnd_stft_loss_blocks': (_I64, [_I64]),

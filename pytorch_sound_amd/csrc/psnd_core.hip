@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 122; }  // 0.1.22: + psnd_stft_bwd_msl (multi_stft_loss gradient fused into the adjoint STFT)
+extern "C" int psnd_version(void) { return 130; }  // 0.1.30: + psnd_polar_bwd, psnd_grad_sumsq (round 3)
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
@@ -96,5 +96,57 @@ extern "C" int psnd_stream_wait_event(void *stream, void *ev) {
     if (!ev) PSND_FAIL(PSND_E_ARG, "stream_wait_event: null event");
     const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0);
     if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stream_wait_event: %s", hipGetErrorString(e));
+    return PSND_OK;
+}
+
+// ---- gradient of (magnitude, phase) -> gradient of (re, im):  STFTTorchAudio.transform (transforms.py:305-311) keeps the
+// phase differentiable: with X = m e^{i phi}, d m = cos phi d re + sin phi d im, d phi = (re d im - im d re) / m^2, so
+//   g_re = g_m cos phi - g_phi sin phi / m,   g_im = g_m sin phi + g_phi cos phi / m     (m = 0: inf / NaN, as atan2's own gradient).
+// One pass; the result feeds psnd_stft_bwd(gre, gim).  Bound: HBM, 24 bytes per element.
+__global__ __launch_bounds__(256) void polar_bwd_kernel(const float *__restrict__ gmag, const float *__restrict__ gphase,
+                                                        const float *__restrict__ mag, const float *__restrict__ phase, long long n,
+                                                        float *__restrict__ gre, float *__restrict__ gim) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        float gm[4] = {0.f, 0.f, 0.f, 0.f}, gp[4] = {0.f, 0.f, 0.f, 0.f}, m[4], ph[4], o_re[4], o_im[4];
+        const int cnt = n - i >= 4 ? 4 : (int)(n - i);
+        if (cnt == 4 && (n & 3) == 0) {
+            *reinterpret_cast<float4 *>(m) = *reinterpret_cast<const float4 *>(mag + i);
+            *reinterpret_cast<float4 *>(ph) = *reinterpret_cast<const float4 *>(phase + i);
+            if (gmag) *reinterpret_cast<float4 *>(gm) = *reinterpret_cast<const float4 *>(gmag + i);
+            if (gphase) *reinterpret_cast<float4 *>(gp) = *reinterpret_cast<const float4 *>(gphase + i);
+        } else {
+            for (int j = 0; j < cnt; ++j) {
+                m[j] = mag[i + j], ph[j] = phase[i + j];
+                if (gmag) gm[j] = gmag[i + j];
+                if (gphase) gp[j] = gphase[i + j];
+            }
+        }
+        for (int j = 0; j < 4; ++j) {
+            float sn, cs;
+            sn = sinf(ph[j]), cs = cosf(ph[j]);
+            const float q = gphase ? gp[j] / m[j] : 0.f;
+            o_re[j] = gm[j] * cs - q * sn;
+            o_im[j] = gm[j] * sn + q * cs;
+        }
+        if (cnt == 4 && (n & 3) == 0) {
+            *reinterpret_cast<float4 *>(gre + i) = *reinterpret_cast<float4 *>(o_re);
+            *reinterpret_cast<float4 *>(gim + i) = *reinterpret_cast<float4 *>(o_im);
+        } else {
+            for (int j = 0; j < cnt; ++j) gre[i + j] = o_re[j], gim[i + j] = o_im[j];
+        }
+    }
+}
+extern "C" int psnd_polar_bwd(const float *gmag, const float *gphase, const float *mag, const float *phase, int64_t n, float *gre,
+                              float *gim, void *stream) {
+    if (!mag || !phase || !gre || !gim) PSND_FAIL(PSND_E_ARG, "polar_bwd: null mag/phase/gre/gim");
+    if (!gmag && !gphase) PSND_FAIL(PSND_E_ARG, "polar_bwd: neither gmag nor gphase given");
+    if (n < 0) PSND_FAIL(PSND_E_ARG, "polar_bwd: n=%lld", (long long)n);
+    if (n == 0) return PSND_OK;
+    long long blocks = (n + 1023) / 1024;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(polar_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), gmag, gphase, mag, phase,
+                       (long long)n, gre, gim);
+    PSND_CHECK_LAUNCH("polar_bwd");
     return PSND_OK;
 }

@@ -202,6 +202,34 @@ class StftReIm(torch.autograd.Function):
         return gw, None, None, None, None
 
 
+class StftPolar(torch.autograd.Function):
+    """(magnitude, phase) of STFTTorchAudio.transform (transforms.py:305-311): both outputs come out of ONE psnd_stft_fwd launch and
+    both are differentiable (the reference takes atan2 of the live tensors there).  Backward: a magnitude-only gradient takes the
+    tuned magnitude adjoint; with a phase gradient, psnd_polar_bwd turns (g_mag, g_phase) into (g_re, g_im) in one pass and the
+    (re, im) adjoint carries on."""
+
+    @staticmethod
+    def forward(ctx, wav, plan, n_fft, hop, framing):
+        o = stft_forward(wav, n_fft, hop, plan, framing, 0.0, True, True, False)
+        ctx.save_for_backward(wav, plan, o['mag'], o['phase'])
+        ctx.cfg = (n_fft, hop, framing)
+        return o['mag'], o['phase']
+
+    @staticmethod
+    def backward(ctx, gmag, gphase):
+        wav, plan, mag, phase = ctx.saved_tensors
+        n_fft, hop, framing = ctx.cfg
+        if gphase is None:
+            return stft_backward(wav, n_fft, hop, plan, framing, 0.0, gmag=gmag), None, None, None, None
+        gphase = gphase.contiguous()
+        gmag = None if gmag is None else gmag.contiguous()
+        gre, gim = torch.empty_like(mag), torch.empty_like(mag)
+        with torch.cuda.device(mag.device):
+            check(lib().psnd_polar_bwd(ptr(gmag), ptr(gphase), ptr(mag), ptr(phase), mag.numel(), ptr(gre), ptr(gim),
+                                       stream_ptr(mag.device)), 'psnd_polar_bwd')
+        return stft_backward(wav, n_fft, hop, plan, framing, 0.0, gre=gre, gim=gim), None, None, None, None
+
+
 class MelLog(torch.autograd.Function):
     """clamp(log(max(W @ mag, pre) + off), lo, hi) - transforms.py:235-243 / :364-365 /
     interface/hifi_gan.py:58-61."""
@@ -263,7 +291,10 @@ class IStft(torch.autograd.Function):
         w2 = (window * window).view(1, 1, n_fft)
         env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, F, device=g.device), w2, stride=hop).view(-1)
         p = n_fft // 2
-        gp = torch.nn.functional.pad(g.contiguous(), (p, p)) / (env + eps)
+        gp = torch.nn.functional.pad(g.contiguous(), (p, p))
+        den = env + eps
+        # eps = 0 (torch.istft's convention): the envelope vanishes only inside the trimmed n/2 edges, where the gradient is zero too
+        gp = torch.where(den > 0, gp / den, torch.zeros_like(gp))
         o = stft_forward(gp, n_fft, hop, plan, FRAMING_NONE, 0.0, False, False, True)
         s = torch.full((Kb,), 2.0 / n_fft, device=g.device)
         s[0] = s[-1] = 1.0 / n_fft

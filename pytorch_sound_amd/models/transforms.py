@@ -182,8 +182,7 @@ class LogMelSpectrogram(nn.Module):
 
 class STFTTorchAudio(nn.Module):
     """Drop-in for transforms.py:271-319 (the torch.stft wrapper that models/sound.py uses for losses).
-    forward -> (real, imag), transform -> (magnitude, phase); here the phase IS differentiable
-    (transforms.py:311), so it is formed from the kernel's (re, im) with autograd-visible ops."""
+    forward -> (real, imag), transform -> (magnitude, phase), inverse; the phase IS differentiable here (transforms.py:311)."""
 
     def __init__(self, filter_length: int = 1024, hop_length: int = 512, win_length: int = None, n_fft: int = None,
                  window: str = 'hann'):
@@ -208,12 +207,18 @@ class STFTTorchAudio(nn.Module):
         return K.StftReIm.apply(wav, self._plan(wav.device), self.n_fft, self.hop_length, K.FRAMING_CENTER)
 
     def transform(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        re, im = self.forward(wav)
-        return torch.sqrt(re ** 2 + im ** 2), torch.atan2(im, re)
+        """magnitude and (differentiable) phase out of one launch; the phase gradient goes through psnd_polar_bwd."""
+        wav = _as_2d(wav)
+        return K.StftPolar.apply(wav, self._plan(wav.device), self.n_fft, self.hop_length, K.FRAMING_CENTER)
 
     def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
-        spec = torch.complex(magnitude * torch.cos(phase), magnitude * torch.sin(phase))
-        return torch.istft(spec, self.n_fft, self.hop_length, self.win_length, self.window)
+        """torch.istft(mag e^{i phase}, n_fft, hop, win_length, window) (transforms.py:313-319): overlap-add of the windowed inverse
+        frames divided by the squared-window envelope, n_fft/2 trimmed on both sides, (F-1)*hop samples - psnd_istft with eps = 0
+        (STFT.inverse adds its 1e-9 to the envelope, torch.istft divides plainly)."""
+        w = self.window
+        win = self._plans.get(('win', w._version, w.data_ptr()), magnitude.device, lambda: torch.from_numpy(
+            centre_pad(w.detach().cpu().numpy().astype(np.float32), self.n_fft)))
+        return K.istft(magnitude, phase, self.n_fft, self.hop_length, self._plan(magnitude.device), 0.0, win)
 
 
 class _HifiGanMel(nn.Module):

@@ -91,6 +91,61 @@ def test_torch_stft_conventions(golden):
     assert np.abs(m - g['hifigan/audio2mel']).max() <= 1e-5
 
 
+MODULE_CASES = {'w1024': (1024, 256, 1024), 'w600': (1024, 256, 600), 'n512': (512, 128, 512)}
+
+
+@pytest.mark.parametrize('tag', sorted(MODULE_CASES))
+def test_torch_stft_modules_stft(golden, tag):
+    """a5 / f1 at module level: the reference's STFTTorchAudio.forward / transform (phase gradient included) / inverse."""
+    g = golden('torch_stft_modules')
+    n, h, w = MODULE_CASES[tag]
+    wav = g['wav']
+    re, im = ofe.stft_reim_f64(wav, n, h, w)
+    sc = np.abs(g[tag + '/mag']).max()
+    assert np.abs(re - g[tag + '/re']).max() <= 2e-6 * sc and np.abs(im - g[tag + '/im']).max() <= 2e-6 * sc
+    assert np.abs(np.hypot(re, im) - g[tag + '/mag']).max() <= 2e-6 * sc
+    # phase where it is well conditioned
+    strong = np.hypot(re, im) > 1e-2 * sc
+    d = np.angle(np.exp(1j * (np.arctan2(im, re) - g[tag + '/phase'])))
+    assert np.abs(d[strong]).max() <= 1e-4
+    # gradient of <g0, mag> + <g1, phase> w.r.t. the waveform: polar -> (re, im) cotangents -> adjoint STFT (all float64)
+    gm, gp = g[tag + '/g'][0].astype(np.float64), g[tag + '/g'][1].astype(np.float64)
+    m2 = re * re + im * im
+    m = np.sqrt(m2)
+    gre = gm * re / m - gp * im / m2
+    gim = gm * im / m + gp * re / m2
+    gw = ofe.stft_reim_bwd_f64(gre, gim, wav.shape[1], n, h, w)
+    ref = g[tag + '/gwav']
+    assert np.abs(gw - ref).max() <= 2e-3 * np.abs(ref).max()      # the reference's own fp32 atan2 gradient is ill-conditioned at weak bins
+    # inverse: torch.istft == overlap-add / squared-window envelope without an eps
+    inv = ofe.istft_f64(g[tag + '/mag'], g[tag + '/phase'], n, h, w, eps=0.0)
+    assert inv.shape == g[tag + '/inverse'].shape == (2, (g[tag + '/mag'].shape[2] - 1) * h)
+    assert np.abs(inv - g[tag + '/inverse']).max() <= 1e-5
+    T = min(inv.shape[1], wav.shape[1])
+    assert np.abs(inv[:, :T] - wav[:, :T]).max() <= 1e-5            # analysis -> synthesis round trip
+    ainv = ofe.istft_f64(g[tag + '/amag'], g[tag + '/aphase'], n, h, w, eps=0.0)
+    assert np.abs(ainv - g[tag + '/ainverse']).max() <= 1e-5 * max(1.0, np.abs(g[tag + '/ainverse']).max())
+
+
+def test_torch_stft_modules_mel(golden):
+    """a6 at module level: Audio2Mel (two parameter sets) and interface MelSpectrogram with is_center False / True."""
+    g = golden('torch_stft_modules')
+    wav = g['wav']
+    m = ofe.hifigan_mel_f64(wav, ofe.mel_filterbank(22050, 1024, 80, 0.0, None), log10=True)
+    assert m.shape == g['audio2mel/out'].shape and np.abs(m - g['audio2mel/out']).max() <= 2e-5
+    m = ofe.hifigan_mel_f64(wav, ofe.mel_filterbank(16000, 512, 40, 50.0, 7000.0), 512, 128, 512, log10=True)
+    assert m.shape == g['audio2mel_b/out'].shape and np.abs(m - g['audio2mel_b/out']).max() <= 2e-5
+    W = ofe.mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+    m = ofe.hifigan_mel_f64(wav, W, mag_eps=1e-9)
+    assert m.shape == g['interface/out'].shape and np.abs(m - g['interface/out']).max() <= 2e-5
+    # is_center=True: the module's own reflect pad of (n - hop) / 2 and THEN torch.stft's centre pad of n / 2
+    p = (1024 - 256) // 2
+    wp = np.pad(wav, ((0, 0), (p, p)), mode='reflect')
+    mag = ofe.stft_mag_f64(wp, 1024, 256, 1024, ofe.CENTER, eps=1e-9)
+    m = np.log(np.maximum(W.astype(np.float64) @ mag, 1e-5))
+    assert m.shape == g['interface/out_center'].shape and np.abs(m - g['interface/out_center']).max() <= 2e-5
+
+
 def test_frame_count_edges():
     assert ofe.frame_count(44100, 1024, 256, 0) == 173
     assert ofe.frame_count(8192, 1024, 256, 1) == 32

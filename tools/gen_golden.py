@@ -232,6 +232,66 @@ def gen_torch_stft():
     np.savez_compressed(os.path.join(OUT, 'torch_stft.npz'), **out)
 
 
+def gen_torch_stft_modules():
+    """a5/a6/f1 at MODULE level: the reference's STFTTorchAudio (forward / transform with its differentiable phase / inverse),
+    Audio2Mel and interface.hifi_gan.MelSpectrogram (is_center both ways), run from the imported reference.
+    Environment stubs (this tool only): torch.stft / torch.istft get the torch-1.x calling convention the reference was written
+    against (real (..., 2) views instead of complex tensors)."""
+    real_stft, real_istft = torch.stft, torch.istft
+
+    def stft_1x(*a, **k):
+        if 'return_complex' in k:
+            return real_stft(*a, **k)
+        return torch.view_as_real(real_stft(*a, return_complex=True, **k))
+
+    def istft_1x(x, *a, **k):
+        if not torch.is_complex(x):
+            x = torch.view_as_complex(x.contiguous())
+        return real_istft(x, *a, **k)
+
+    torch.stft, torch.istft = stft_1x, istft_1x
+    try:
+        from pytorch_sound.models import transforms as rt
+        from pytorch_sound.interface import hifi_gan as rh
+        out = {}
+        wav = seeded_wav(410, 2, 3000)
+        out['wav'] = wav
+        for tag, kw in (('w1024', dict(filter_length=1024, hop_length=256)),
+                        ('w600', dict(filter_length=1024, hop_length=256, win_length=600, n_fft=1024)),
+                        ('n512', dict(filter_length=512, hop_length=128))):
+            m = rt.STFTTorchAudio(**kw)
+            x = torch.from_numpy(wav).requires_grad_(True)
+            re, im = m(x)
+            mag, ph = m.transform(x)
+            g = np.random.RandomState(411).randn(2, *mag.shape).astype(np.float32)
+            (mag * torch.from_numpy(g[0]) + ph * torch.from_numpy(g[1])).sum().backward()
+            out[tag + '/re'], out[tag + '/im'] = re.detach().numpy(), im.detach().numpy()
+            out[tag + '/mag'], out[tag + '/phase'] = mag.detach().numpy(), ph.detach().numpy()
+            out[tag + '/g'] = g
+            out[tag + '/gwav'] = x.grad.numpy()
+            # inverse of the module's own analysis, and of an arbitrary (inconsistent) magnitude / phase pair
+            out[tag + '/inverse'] = m.inverse(mag.detach(), ph.detach()).numpy()
+            rs = np.random.RandomState(412)
+            amag = np.abs(rs.randn(*mag.shape)).astype(np.float32)
+            aph = rs.uniform(-np.pi, np.pi, mag.shape).astype(np.float32)
+            # real DC / Nyquist bins, as any spectrum of a real signal has
+            aph[:, 0] = 0
+            aph[:, -1] = 0
+            out[tag + '/amag'], out[tag + '/aphase'] = amag, aph
+            out[tag + '/ainverse'] = m.inverse(torch.from_numpy(amag), torch.from_numpy(aph)).numpy()
+        a2m = rt.Audio2Mel()
+        out['audio2mel/out'] = a2m(torch.from_numpy(wav).unsqueeze(1)).numpy()
+        a2m2 = rt.Audio2Mel(n_fft=512, hop_length=128, win_length=512, sampling_rate=16000, n_mel_channels=40, mel_fmin=50.0, mel_fmax=7000.0)
+        out['audio2mel_b/out'] = a2m2(torch.from_numpy(wav).unsqueeze(1)).numpy()
+        ms = rh.MelSpectrogram()
+        out['interface/out'] = ms(torch.from_numpy(wav)).numpy()
+        out['interface/out_center'] = ms(torch.from_numpy(wav), is_center=True).numpy()
+        assert int(ms.pad_size) == 384
+    finally:
+        torch.stft, torch.istft = real_stft, real_istft
+    np.savez_compressed(os.path.join(OUT, 'torch_stft_modules.npz'), **out)
+
+
 def gen_modules():
     from pytorch_sound.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding
     out = {}
@@ -608,7 +668,7 @@ def gen_lstft():
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
-    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'modules', 'hifigan', 'trainer', 'sound', 'data', 'filters', 'lstft']
+    which = sys.argv[1:] or ['stft', 'impulse', 'logmel', 'torch_stft', 'torch_stft_modules', 'modules', 'hifigan', 'trainer', 'sound', 'data', 'filters', 'lstft']
     for w in which:
         print('generating', w, flush=True)
         globals()['gen_' + w]()
