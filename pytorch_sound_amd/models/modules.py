@@ -22,16 +22,26 @@ ROUND1_PATH = False                 # A/B measurements only: round 1's path (lib
 
 
 def _hip_ok(x: torch.Tensor) -> bool:
-    """fp32 CUDA tensors take the hand-written kernels (psnd_groupnorm1_*, psnd_softmax_keys_*); CPU tensors use the
-    torch formulation that the golden tests pin (tests/test_modules_golden.py)."""
-    return x.is_cuda and x.dtype == torch.float32 and not TORCH_FORMULATION_ON_GPU
+    """A tensor that lives on the GPU ALWAYS takes the hand-written kernels (psnd_linear1x1_*, psnd_mha_*, psnd_groupnorm1_*):
+    the kernels compute in fp32 from fp32 memory, so another floating dtype is cast on the way in and the result cast back
+    (`_to_kernel_dtype`) - there is no library path for a HIP tensor.  CPU tensors use the torch formulation that the golden tests
+    pin (tests/test_modules_golden.py)."""
+    return x.is_cuda and not TORCH_FORMULATION_ON_GPU
+
+
+def _to_kernel_dtype(x: torch.Tensor) -> torch.Tensor:
+    if _hip_ok(x) and x.dtype != torch.float32:
+        if not x.is_floating_point():
+            raise TypeError('expected a floating-point activation tensor, got %s' % x.dtype)
+        return x.float()
+    return x
 
 
 def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu: bool = False) -> torch.Tensor:
     """GroupNorm(1, C)(x + residual) [-> ReLU]"""
     if _hip_ok(x):
         from pytorch_sound_amd import kernels as K
-        return K.GroupNorm1.apply(x, residual, norm.weight, norm.bias, norm.eps, relu)
+        return K.GroupNorm1.apply(x.float(), residual.float(), norm.weight.float(), norm.bias.float(), norm.eps, relu)
     y = norm(x + residual)
     return F.relu(y) if relu else y
 
@@ -51,7 +61,7 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tens
     # under torch.autocast(bfloat16) the products take bf16 operands (fp32 accumulation, fp32 activations in memory): 16x the
     # matrix rate; without autocast they are exact fp32
     bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-    return K.Linear1x1.apply(x.float(), conv.weight, conv.bias, relu, bf16)
+    return K.Linear1x1.apply(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16)
 
 
 class MultiHeadAttention(nn.Module):
@@ -80,9 +90,15 @@ class MultiHeadAttention(nn.Module):
     return_att = True
 
     def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        in_dtype = input.dtype
+        input = _to_kernel_dtype(input)
         kvq = _conv1x1(self.linear_kvq, input)
-        if _hip_ok(input) and not ROUND1_PATH and self.hidden_dim % self.heads == 0 and self.hidden_dim // self.heads <= 64:
+        if _hip_ok(input) and not ROUND1_PATH:
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
+            if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 64:
+                from pytorch_sound_amd._lib import PsndError
+                raise PsndError('MultiHeadAttention(hidden_dim=%d, heads=%d): psnd_mha_* covers head dimensions up to 64 that divide '
+                                'hidden_dim; there is no library path for a HIP tensor' % (self.hidden_dim, self.heads))
             from pytorch_sound_amd import kernels as K
             mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
             x, att = K.AttentionKVQ.apply(kvq, mask_u8, self.heads, self.return_att)
@@ -96,13 +112,16 @@ class MultiHeadAttention(nn.Module):
         x = _conv1x1(self.linear, x)
         if self.drop_out is not None:
             x = self.drop_out(x)
-        return _add_norm(self.layernorm, x, input), att
+        x = _add_norm(self.layernorm, x, input)
+        if in_dtype != x.dtype:
+            x, att = x.to(in_dtype), (None if att is None else att.to(in_dtype))
+        return x, att
 
     @staticmethod
     def scale_dot_att(k: torch.Tensor, v: torch.Tensor, q: torch.Tensor,
                       att_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         """k, v, q: (B, d, T); att_mask: (B, T) bool or None -> (B, d, T), (B, T_key, T_query)."""
-        if _hip_ok(q):
+        if _hip_ok(q):            # only reached with ROUND1_PATH (A/B measurements): softmax kernel between two library bmm
             from pytorch_sound_amd import kernels as K
             mask_u8 = None if att_mask is None else att_mask.to(torch.uint8).contiguous()
             att = K.SoftmaxKeys.apply(torch.bmm(k.transpose(1, 2), q), mask_u8, 1.0 / math.sqrt(k.size(1)))
@@ -133,10 +152,13 @@ class PointwiseFeedForward(nn.Module):
         self.drop_out = nn.Dropout(dropout_rate) if 0 < dropout_rate < 1 else None
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
+        in_dtype = input.dtype
+        input = _to_kernel_dtype(input)
         x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True))
         if self.drop_out is not None:
             x = self.drop_out(x)
-        return _add_norm(self.layernorm, x, input, relu=True)
+        x = _add_norm(self.layernorm, x, input, relu=True)
+        return x if x.dtype == in_dtype else x.to(in_dtype)
 
 
 class PositionalEncoding(nn.Module):

@@ -66,8 +66,11 @@ class PreEmphasis(torch.nn.Module):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         assert len(input.size()) == 3, 'The number of dimensions of input tensor must be 3!'
-        if input.is_cuda and input.dtype == torch.float32 and input.size(1) == 1:
-            return K.PreEmphasisFn.apply(input, self.coef)
+        if input.is_cuda:                                   # a HIP tensor always takes psnd_preemphasis_* (fp32 kernel: cast in and out)
+            if input.size(1) != 1 or not input.is_floating_point():
+                raise RuntimeError('PreEmphasis expects a floating-point (N, 1, T) tensor, got %s %s' % (input.dtype, tuple(input.shape)))
+            y = K.PreEmphasisFn.apply(input.float(), self.coef)
+            return y if y.dtype == input.dtype else y.to(input.dtype)
         input = F.pad(input, (1, 0), 'reflect')
         return F.conv1d(input, self.flipped_filter)
 

@@ -300,11 +300,12 @@ class MelToMFCC(nn.Module):
 
     def forward(self, mel_spec: torch.Tensor) -> torch.Tensor:
         assert len(mel_spec.size()) == 3
-        if mel_spec.is_cuda and mel_spec.dtype == torch.float32:
+        if mel_spec.is_cuda:
             d = self.dct_mat
             plan = self._plans.get(('dct', d._version, d.data_ptr()), mel_spec.device,
-                                   lambda: K.mel_plan(d.detach().cpu().numpy()))
-            return K.MelLog.apply(mel_spec.contiguous(), plan, self.n_mfcc, K.LOG_NONE, 0.0, None, None, None)
+                                   lambda: K.mel_plan(d.detach().float().cpu().numpy()))
+            y = K.MelLog.apply(mel_spec.float().contiguous(), plan, self.n_mfcc, K.LOG_NONE, 0.0, None, None, None)
+            return y if y.dtype == mel_spec.dtype else y.to(mel_spec.dtype)
         return torch.matmul(self.dct_mat, mel_spec)
 
 
@@ -388,18 +389,28 @@ class PQMF(torch.nn.Module):
         self.subbands, self.taps = subbands, taps
         self.pad_fn = torch.nn.ConstantPad1d(taps // 2, 0.0)
 
-    def _hip(self, x):
-        return x.is_cuda and x.dtype == torch.float32 and self.subbands <= 16 and self.taps <= 255
+    def _hip(self, x, channels):
+        """a HIP tensor always takes psnd_pqmf_* (cast to fp32 if need be); a filter bank the kernel does not cover raises"""
+        if not x.is_cuda:
+            return False
+        if self.subbands > 16 or self.taps > 255:
+            raise K.PsndError('PQMF(subbands=%d, taps=%d): psnd_pqmf_* covers up to 16 bands and 255 taps; there is no library '
+                              'path for a HIP tensor' % (self.subbands, self.taps))
+        if x.dim() != 3 or x.size(1) != channels or not x.is_floating_point():
+            raise RuntimeError('PQMF expects a floating-point (N, %d, T) tensor, got %s %s' % (channels, x.dtype, tuple(x.shape)))
+        return True
 
     def analysis(self, x):
-        if self._hip(x) and x.dim() == 3 and x.size(1) == 1:
-            return K.PqmfAnalysis.apply(x.squeeze(1), self.analysis_filter.squeeze(1), self.subbands, self.taps)
+        if self._hip(x, 1):
+            y = K.PqmfAnalysis.apply(x.squeeze(1).float(), self.analysis_filter.squeeze(1).float(), self.subbands, self.taps)
+            return y if y.dtype == x.dtype else y.to(x.dtype)
         x = torch.nn.functional.conv1d(self.pad_fn(x), self.analysis_filter)
         return torch.nn.functional.conv1d(x, self.updown_filter, stride=self.subbands)
 
     def synthesis(self, x):
-        if self._hip(x) and x.dim() == 3 and x.size(1) == self.subbands:
-            return K.PqmfSynthesis.apply(x, self.synthesis_filter.squeeze(0), self.subbands, self.taps).unsqueeze(1)
+        if self._hip(x, self.subbands):
+            y = K.PqmfSynthesis.apply(x.float(), self.synthesis_filter.squeeze(0).float(), self.subbands, self.taps).unsqueeze(1)
+            return y if y.dtype == x.dtype else y.to(x.dtype)
         x = torch.nn.functional.conv_transpose1d(x, self.updown_filter * self.subbands, stride=self.subbands)
         return torch.nn.functional.conv1d(self.pad_fn(x), self.synthesis_filter)
 

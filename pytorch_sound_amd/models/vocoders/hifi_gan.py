@@ -172,6 +172,8 @@ class Generator(nn.Module):
 
     def forward(self, x):
         if self._cl_ok(x):
+            if x.dtype != torch.float32:                 # the CL kernels read fp32 mels and write fp32 audio: cast, do not fall back
+                return self.forward_cl(x.float()).to(x.dtype)
             return self.forward_cl(x)
         x = self.conv_pre(x)
         for i, up in enumerate(self.ups):
@@ -205,10 +207,12 @@ class Generator(nn.Module):
         return list(block.convs1) + list(block.convs2) if hasattr(block, 'convs1') else list(block.convs)
 
     def _cl_ok(self, x) -> bool:
-        """False only for tensors the CL kernels cannot take at all (CPU, other dtypes); a CUDA fp32 input whose model the kernels
-        do not cover RAISES in forward_cl - no silent library path for a tensor that lives on the GPU."""
-        if not (self.use_cl and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+        """False only for CPU tensors (and for `use_cl = False`, the explicit A/B switch to the library formulation); a HIP input
+        whose model the kernels do not cover RAISES in forward_cl - no silent library path for a tensor that lives on the GPU."""
+        if not (self.use_cl and x.is_cuda):
             return False
+        if x.dim() != 3 or not x.is_floating_point():
+            raise RuntimeError('hifi_gan Generator expects a floating-point (N, 80, T) mel batch, got %s %s' % (x.dtype, tuple(x.shape)))
         for c in self._all_convs():
             c.sync_folded()
         return True
@@ -220,13 +224,18 @@ class Generator(nn.Module):
                 k = c.weight_v.shape[2]
                 if c.padding > self._CL_MAX_REACH or (c.padding > 25 and k > 7) or k > 16:
                     raise PsndError('hifi_gan: conv with k=%d, dilation %d (tap reach %d) is beyond the gfx950 conv kernels '
-                                    '(reach <= 25, or <= 40 with k <= 7)' % (k, c.dilation, c.padding))
+                                    '(reach <= 25, or <= 40 with k <= 7); use_cl = False selects the library formulation'
+                                    % (k, c.dilation, c.padding))
         if self.cl_upsample == 'polyphase':
             for u in self.ups:
-                if u.weight_v.shape[2] != 2 * u.stride or u.padding > u.stride:
+                k = u.weight_v.shape[2]
+                # k = 2 * stride with the "same" padding (k - stride) / 2: an odd stride would make the output T * stride + 1
+                # samples long (padding rounds down), which the polyphase row map does not produce
+                if k != 2 * u.stride or (k - u.stride) % 2 != 0 or 2 * u.padding != k - u.stride:
                     raise PsndError('hifi_gan: ConvTranspose1d(k=%d, stride=%d, padding=%d): the polyphase kernel needs k = 2 * '
-                                    'stride (set cl_upsample = "kernel" for the zero-spread convolution)'
-                                    % (u.weight_v.shape[2], u.stride, u.padding))
+                                    'stride, an even stride and padding = stride / 2 (set cl_upsample = "kernel" for the zero-spread '
+                                    'convolution, or use_cl = False for the library formulation)'
+                                    % (k, u.stride, u.padding))
 
     def forward_cl(self, x):
         from pytorch_sound_amd import cl

@@ -1,0 +1,135 @@
+"""A tensor that lives on the GPU never takes a library (rocBLAS / MIOpen / ATen softmax / rocFFT) path in the model-level
+modules (policy; VERDICT r02 "silent library paths"): other floating dtypes are CAST to the kernels' fp32 and the result
+cast back, geometries the kernels do not cover RAISE.  Each test also checks that the kernels really ran, by comparing the
+non-fp32 call with the fp32 call on the same (rounded) operands - equal up to the output rounding - and by running under
+`forbid_library_ops`, which makes the ATen ops the old fallbacks used raise for HIP tensors."""
+from argparse import Namespace
+from contextlib import contextmanager
+
+import pytest
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+pytestmark = pytest.mark.gpu
+
+FORBIDDEN = ('aten.bmm', 'aten.baddbmm', 'aten.mm.', 'aten.addmm', 'aten._softmax', 'aten.native_group_norm', 'aten.convolution',
+             'aten.miopen', 'aten.cudnn', 'aten._fft', 'aten.stft', 'aten.istft')
+
+
+class _Forbid(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if any(name.startswith(f) for f in FORBIDDEN):
+            flat = torch.utils._pytree.tree_leaves((args, kwargs or {}))
+            if any(isinstance(a, torch.Tensor) and a.is_cuda for a in flat):
+                raise AssertionError('library op %s reached with a HIP tensor' % name)
+        return func(*args, **(kwargs or {}))
+
+
+@contextmanager
+def forbid_library_ops():
+    with _Forbid():
+        yield
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU test run without a GPU'
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float64])
+def test_transformer_block_casts_instead_of_falling_back(dtype):
+    from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward, PositionalEncoding
+    dev = _dev()
+    torch.manual_seed(0)
+    mha, ffn, pe = MultiHeadAttention(64, 4, 0.0).to(dev), PointwiseFeedForward(64, 0.0).to(dev), PositionalEncoding(64, 256).to(dev)
+    x32 = torch.randn(3, 64, 50, device=dev).to(dtype).float()          # operands representable in `dtype`
+    mask = torch.zeros(3, 50, dtype=torch.bool, device=dev)
+    mask[1, 40:] = True
+    with forbid_library_ops():
+        y32, att32 = mha(pe(x32), mask)
+        z32 = ffn(y32)
+        y, att = mha(pe(x32).to(dtype), mask)
+        z = ffn(y32.to(dtype))
+    assert y.dtype == dtype and att.dtype == dtype and z.dtype == dtype
+    tol = {torch.bfloat16: 2e-2, torch.float16: 2e-3, torch.float64: 1e-6}[dtype]
+    assert (y.float() - y32).abs().max().item() <= tol * y32.abs().max().item() + tol
+    assert (z.float() - ffn(y32.to(dtype).float())).abs().max().item() <= tol * z32.abs().max().item() + tol
+    # with gradient
+    xg = x32.clone().to(dtype).requires_grad_(True)
+    with forbid_library_ops():
+        out, _ = mha(xg, mask)
+        ffn(out).float().sum().backward()
+    assert xg.grad is not None and xg.grad.dtype == dtype and torch.isfinite(xg.grad.float()).all()
+
+
+def test_attention_head_dimension_beyond_the_kernel_raises():
+    from pytorch_sound_amd._lib import PsndError
+    from pytorch_sound_amd.models.modules import MultiHeadAttention
+    dev = _dev()
+    x = torch.randn(2, 256, 20, device=dev)
+    with pytest.raises(PsndError):
+        MultiHeadAttention(256, 2, 0.0).to(dev)(x)                     # head dimension 128 > 64
+    y, att = MultiHeadAttention(256, 4, 0.0).to(dev)(x)                 # 64: on psnd_mha_*
+    assert tuple(y.shape) == (2, 256, 20) and tuple(att.shape) == (8, 20, 20)
+
+
+def _gen(rates, ksz):
+    from pytorch_sound_amd.models.vocoders.hifi_gan import Generator
+    torch.manual_seed(5)
+    h = Namespace(resblock='2', upsample_rates=rates, upsample_kernel_sizes=ksz, upsample_initial_channel=64,
+                  resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 2]])
+    return Generator(h).cuda()
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_generator_casts_instead_of_falling_back(dtype):
+    g = _gen([4, 2], [8, 4])
+    x = torch.randn(2, 80, 16, device='cuda').to(dtype)
+    with forbid_library_ops():
+        y = g(x)
+        y32 = g(x.float())
+    assert y.dtype == dtype and tuple(y.shape) == (2, 1, 128)
+    assert (y.float() - y32).abs().max().item() <= 1e-2                  # tanh output in [-1, 1]: one rounding of `dtype`
+
+
+def test_generator_odd_stride_raises_instead_of_a_shorter_output():
+    """ConvTranspose1d(k = 2 * stride, odd stride) gives T * stride + 1 samples in the reference; the polyphase row map
+    does not - it must refuse, with the way out in the message."""
+    from pytorch_sound_amd._lib import PsndError
+    g = _gen([3, 2], [6, 4])
+    x = torch.randn(1, 80, 8, device='cuda')
+    with pytest.raises(PsndError, match='use_cl = False'):
+        g(x)
+    g.use_cl = False                                                     # the explicit A/B switch: library formulation, reference's length
+    assert g(x).shape[-1] == (8 * 3 + 1) * 2
+    with pytest.raises(RuntimeError):
+        _gen([4, 2], [8, 4])(torch.randn(80, 16, device='cuda'))         # not (N, 80, T)
+
+
+def test_pqmf_and_preemphasis_have_no_library_path():
+    from pytorch_sound_amd._lib import PsndError
+    from pytorch_sound_amd.models.transforms import PQMF, MelToMFCC
+    from pytorch_sound_amd.models.sound import PreEmphasis
+    dev = _dev()
+    torch.manual_seed(1)
+    pq = PQMF(4, 62).to(dev)
+    x = torch.randn(2, 1, 4096, device=dev)
+    with forbid_library_ops():
+        a32 = pq.analysis(x)
+        a16 = pq.analysis(x.bfloat16())
+        s16 = pq.synthesis(a32.bfloat16())
+        s32 = pq.synthesis(a32.bfloat16().float())
+        p16 = PreEmphasis(0.97).to(dev)(x.half())
+        p32 = PreEmphasis(0.97).to(dev)(x.half().float())
+        m16 = MelToMFCC(13, 80).to(dev)(torch.randn(2, 80, 30, device=dev).bfloat16())
+    assert a16.dtype == torch.bfloat16 and s16.dtype == torch.bfloat16 and p16.dtype == torch.float16 and m16.dtype == torch.bfloat16
+    assert (a16.float() - pq.analysis(x.bfloat16().float())).abs().max().item() <= 2e-2 * a32.abs().max().item()
+    assert (s16.float() - s32).abs().max().item() <= 2e-2 * s32.abs().max().item()
+    assert (p16.float() - p32).abs().max().item() <= 2e-3 * p32.abs().max().item()
+    with pytest.raises(PsndError):
+        PQMF(32, 62).to(dev).analysis(x)                                  # 32 bands: beyond psnd_pqmf_*
+    with pytest.raises(RuntimeError):
+        pq.analysis(torch.randn(2, 2, 64, device=dev))                    # the reference's conv1d would refuse two channels too
+    with pytest.raises(RuntimeError):
+        PreEmphasis(0.97).to(dev)(torch.randn(2, 2, 64, device=dev))
