@@ -177,6 +177,9 @@ int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const
  * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
  * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */
 int psnd_conv_stats(int64_t *out4, int reset);
+/* the same for the residual-pair launches: out4 = { psnd_conv1d_cl_pair launches with 32-row tiles, with 64-row tiles,
+ * psnd_conv1d_cl_pair_bwd launches that carried a pair, weight-gradient row ranges of the last psnd_conv1d_cl_pair_bwd launch }. */
+int psnd_conv_pair_stats(int64_t *out4, int reset);
 int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *GM, float g2_slope, const void *xa, int64_t N,
                          int Lp, int Ca, int Cb, int k, int off0, int dstep, float *gw_part, float *gbias_part,
                          void *g_out, void *stream);
@@ -358,12 +361,22 @@ int psnd_pad_collate(const float *flat, const int64_t *offs, const int64_t *lens
  *      Hyper-parameters are doubles: 1 - beta and the bias corrections are formed in double, as torch does.
  *  found_inf (device, may be NULL): non-zero skips the whole update including the step count (AMP protocol);
  *  grad_scale (device, may be NULL): gradients are divided by it;  corr : 2 * n_tensors floats of device scratch (the
- *      bias corrections, formed in double by a first tiny launch that also advances the step counts). */
+ *      bias corrections, formed in double by a first tiny launch that also advances the step counts).
+ *  Trainer.clip_grad (trainer.py:184-191) folded into the same pass: clip_value > 0 clamps every (scaled) gradient element to
+ *      [-clip_value, clip_value] (`p.grad.clamp`), clip_coef (device, may be NULL) then multiplies it (`clip_grad_norm_`'s factor,
+ *      from psnd_grad_sumsq).  The gradients in memory are left as they are.
+ *  psnd_grad_sumsq: the global norm over the SAME table / work list: *sumsq (+)= sum clamp(g / grad_scale, +-clip_value)^2 in double
+ *      (partial: n_chunks doubles of device scratch, summed in index order: deterministic), coef[0] = min(1, max_norm / (norm + 1e-6))
+ *      (1 when max_norm = 0), coef[1] = norm; accumulate != 0 adds to *sumsq (second and later parameter groups). */
 int64_t psnd_adam_chunk(void);
 int64_t psnd_adam_table_bytes(void);
 int psnd_adam_step(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
-                   const float *found_inf, const float *grad_scale, float *corr, void *stream);
+                   const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
+                   void *stream);
+int psnd_grad_sumsq(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
+                    float clip_value, const float *grad_scale, int accumulate, float max_norm, double *partial, double *sumsq,
+                    float *coef, void *stream);
 
 /* ---- PQMF (models/transforms.py:492-560), polyphase --------------------------------------------------------------
  *  filt : (subbands, taps + 1) fp32 (analysis_filter / synthesis_filter of the module), taps even, P = taps / 2.

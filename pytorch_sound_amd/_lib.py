@@ -56,6 +56,7 @@ SIGNATURES = {
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
     'psnd_conv_stats': (_INT, [_P, _INT]),
+    'psnd_conv_pair_stats': (_INT, [_P, _INT]),
     'psnd_convtr1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_convtr1d_cl_fwd': (_INT, [_P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _P, _P, _P]),
     'psnd_convtr1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
@@ -87,7 +88,8 @@ SIGNATURES = {
     'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     'psnd_adam_chunk': (_I64, []),
     'psnd_adam_table_bytes': (_I64, []),
-    'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _P]),
+    'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _F, _P, _P]),
+    'psnd_grad_sumsq': (_INT, [_P, _INT, _P, _P, _I64, _F, _P, _INT, _F, _P, _P, _P, _P]),
     'psnd_mask_head_fwd': (_INT, [_P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
     'psnd_mask_head_bwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
     'psnd_pqmf_analysis': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _INT, _F, _P, _P]),

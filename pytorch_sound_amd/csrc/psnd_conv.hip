@@ -1200,6 +1200,16 @@ __global__ __launch_bounds__(1024) void conv_finish_multi_kernel(FinishArgs a) {
 // [2] paired backward launches with 64-row tiles, [3] with 128-row tiles.  Host-side counters, read by the parity tests to
 // prove that a test shape reached the instance it is meant to cover.
 static std::atomic<long long> g_conv_stats[4];
+// the residual-pair launches: [0] pair forward launches with 32-row tiles, [1] with 64-row tiles, [2] pair backward launches (chained
+// input gradients + weight-gradient roles), [3] weight-gradient row ranges (splits) of the last pair backward launch
+std::atomic<long long> g_conv_pair_stats[4];
+extern "C" int psnd_conv_pair_stats(int64_t *out4, int reset) {
+    if (out4)
+        for (int i = 0; i < 4; ++i) out4[i] = g_conv_pair_stats[i].load();
+    if (reset)
+        for (int i = 0; i < 4; ++i) g_conv_pair_stats[i].store(0);
+    return PSND_OK;
+}
 extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
     if (out4)
         for (int i = 0; i < 4; ++i) out4[i] = g_conv_stats[i].load();
@@ -1530,6 +1540,8 @@ extern "C" int psnd_conv1d_cl_pair_bwd(const void *G, const void *wb2, const voi
     hipLaunchKernelGGL(conv_pair_bwd_kernel, dim3((unsigned)(nwa + nwb + tiles)), dim3(256), lds, static_cast<hipStream_t>(stream), pp, wa, wb_, nwa,
                        nwb, wgx, wgy);
     PSND_CHECK_LAUNCH("conv1d_cl_pair_bwd");
+    if (have_pair) g_conv_pair_stats[2]++;
+    g_conv_pair_stats[3].store(splits);
     return PSND_OK;
 }
 

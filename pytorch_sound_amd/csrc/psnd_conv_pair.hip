@@ -20,6 +20,9 @@
 // fragments of a unit are read from LDS two units ahead.  The ring loop is laid out by hand (sched_group_barrier): see run_conv.
 #include "psnd_conv_pair.h"
 
+#include <atomic>
+extern std::atomic<long long> g_conv_pair_stats[4];     // psnd_conv.hip (psnd_conv_pair_stats)
+
 namespace {
 using namespace pairk;
 template <int C, int MR, bool HASM1>
@@ -83,5 +86,6 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
         else launch(conv_pair_kernel<128, 2, false>);
     }
     PSND_CHECK_LAUNCH("conv1d_cl_pair");
+    g_conv_pair_stats[MR == 1 ? 0 : 1]++;
     return PSND_OK;
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void adam_tick_kernel(const AdamTensor *tab, in
 template <bool DECOUPLED>
 __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *tab, const int *chunk_tensor, const long long *chunk_off, float lr,
                                                    float b1, float b2, float omb1, float omb2, float eps, float wd, const float *found_inf,
-                                                   const float *grad_scale, const float *corr) {
+                                                   const float *grad_scale, const float *corr, float clip_value, const float *clip_coef) {
     if (found_inf && *found_inf != 0.f) return;
     const int ti = chunk_tensor[blockIdx.x];
     const AdamTensor T = tab[ti];
@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *tab, const 
     const long long e1 = min(e0 + ACH, T.numel);
     const float step_size = lr * corr[2 * ti], inv_sqrt_bc2 = corr[2 * ti + 1];      // from adam_tick_kernel
     const float gs = grad_scale ? 1.f / *grad_scale : 1.f;
+    // Trainer.clip_grad (trainer.py:184-191) folded in: clamp to +-clip_value, then the global-norm factor of psnd_grad_sumsq
+    const float cv = clip_value > 0.f ? clip_value : __builtin_inff(), cc = clip_coef ? *clip_coef : 1.f;
     auto upd = [&](float &p, float g, float &m, float &v) __attribute__((always_inline)) {
         g *= gs;
+        g = __builtin_fminf(__builtin_fmaxf(g, -cv), cv) * cc;
         if constexpr (DECOUPLED) p -= lr * wd * p;
         else g = __builtin_fmaf(wd, p, g);
         m = __builtin_fmaf(b1, m, omb1 * g);
@@ -78,15 +81,89 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *tab, const 
     }
 }
 
+// ---- global gradient norm of Trainer.clip_grad (trainer.py:184-191: per-parameter clamp, then torch's clip_grad_norm_) over the
+// same table / work list: partial[b] = sum over chunk b of clamp(g / grad_scale, +-clip_value)^2 (double), then ONE workgroup
+// adds the partials in index order (deterministic) to *sumsq and writes coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)) (torch's
+// clip_coef_clamped), coef[1] = the norm.  HBM-bound: 4 bytes per parameter.
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const AdamTensor *tab, const int *chunk_tensor, const long long *chunk_off,
+                                                          float clip_value, const float *grad_scale, double *partial) {
+    const AdamTensor T = tab[chunk_tensor[blockIdx.x]];
+    const long long e0 = chunk_off[blockIdx.x];
+    const long long e1 = min(e0 + ACH, T.numel);
+    const float gs = grad_scale ? 1.f / *grad_scale : 1.f;
+    const float cv = clip_value > 0.f ? clip_value : __builtin_inff();
+    float acc = 0.f;
+    auto add = [&](float g) __attribute__((always_inline)) {
+        g = __builtin_fminf(__builtin_fmaxf(g * gs, -cv), cv);
+        acc = __builtin_fmaf(g, g, acc);
+    };
+    if ((((uintptr_t)T.g) & 15) == 0) {
+        for (long long e = e0 + 4 * threadIdx.x; e < e1; e += 1024) {
+            if (e + 3 < e1) {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(T.g + e);
+                add(g[0]), add(g[1]), add(g[2]), add(g[3]);
+            } else {
+                for (long long q = e; q < e1; ++q) add(T.g[q]);
+            }
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += 256) add(T.g[e]);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = (double)acc;                       // <= 8 terms per thread in float, the tree in double
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void grad_sumsq_final_kernel(const double *partial, long long n, int accumulate, float max_norm, double *sumsq,
+                                                                float *coef) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double tot = red[0] + (accumulate ? *sumsq : 0.0);
+        *sumsq = tot;
+        const float norm = (float)sqrt(tot);
+        const float c = max_norm / (norm + 1e-6f);
+        coef[0] = max_norm > 0.f ? fminf(c, 1.f) : 1.f;
+        coef[1] = norm;
+    }
+}
+
 }  // namespace
+
+extern "C" int psnd_grad_sumsq(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
+                               float clip_value, const float *grad_scale, int accumulate, float max_norm, double *partial, double *sumsq,
+                               float *coef, void *stream) {
+    if (!table || !chunk_tensor || !chunk_off || !partial || !sumsq || !coef) PSND_FAIL(PSND_E_ARG, "grad_sumsq: null pointer");
+    if (n_tensors <= 0 || n_chunks <= 0 || n_chunks > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "grad_sumsq: n_tensors=%d n_chunks=%lld", n_tensors, (long long)n_chunks);
+    if (!(clip_value >= 0.f) || !(max_norm >= 0.f)) PSND_FAIL(PSND_E_ARG, "grad_sumsq: clip_value=%g max_norm=%g", (double)clip_value, (double)max_norm);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3((unsigned)n_chunks), dim3(256), 0, s, static_cast<const AdamTensor *>(table), chunk_tensor,
+                       reinterpret_cast<const long long *>(chunk_off), clip_value, grad_scale, partial);
+    hipLaunchKernelGGL(grad_sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, (long long)n_chunks, accumulate ? 1 : 0, max_norm, sumsq, coef);
+    PSND_CHECK_LAUNCH("grad_sumsq");
+    return PSND_OK;
+}
 
 extern "C" int64_t psnd_adam_chunk(void) { return ACH; }
 extern "C" int64_t psnd_adam_table_bytes(void) { return (int64_t)sizeof(AdamTensor); }
 
 extern "C" int psnd_adam_step(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
                               double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
-                              const float *found_inf, const float *grad_scale, float *corr, void *stream) {
+                              const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
+                              void *stream) {
     if (!table || !chunk_tensor || !chunk_off || !corr) PSND_FAIL(PSND_E_ARG, "adam_step: null pointer");
+    if (!(clip_value >= 0.f)) PSND_FAIL(PSND_E_ARG, "adam_step: clip_value=%g", (double)clip_value);
     if (n_tensors < 0 || n_chunks < 0 || n_chunks > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "adam_step: n_tensors=%d n_chunks=%lld", n_tensors, (long long)n_chunks);
     if (!(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(eps >= 0.) || !(lr >= 0.) || !(weight_decay >= 0.))
         PSND_FAIL(PSND_E_ARG, "adam_step: lr=%g betas=(%g, %g) eps=%g weight_decay=%g", lr, beta1, beta2, eps, weight_decay);
@@ -96,10 +173,10 @@ extern "C" int psnd_adam_step(const void *table, int n_tensors, const int *chunk
     hipLaunchKernelGGL(adam_tick_kernel, dim3((n_tensors + 63) / 64), dim3(64), 0, s, tab, n_tensors, beta1, beta2, found_inf, corr);
     if (decoupled)
         hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)n_chunks), dim3(256), 0, s, tab, chunk_tensor, reinterpret_cast<const long long *>(chunk_off),
-                           (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, found_inf, grad_scale, corr);
+                           (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, found_inf, grad_scale, corr, clip_value, clip_coef);
     else
         hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)n_chunks), dim3(256), 0, s, tab, chunk_tensor, reinterpret_cast<const long long *>(chunk_off),
-                           (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, found_inf, grad_scale, corr);
+                           (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, found_inf, grad_scale, corr, clip_value, clip_coef);
     PSND_CHECK_LAUNCH("adam_step");
     return PSND_OK;
 }

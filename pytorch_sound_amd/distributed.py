@@ -101,11 +101,12 @@ class FlatGradReducer:
 
       'events'   an external event-record node per bucket (psnd_event_record_external).  After the replay has been enqueued the
                  host enqueues, per bucket and in fixed order, `side.wait(event_i); all_reduce(bucket_i)` on a side stream:
-                 RCCL runs bucket i while the replayed backward is still producing bucket i+1 (any backend; default)
+                 RCCL runs bucket i while the replayed backward is still producing bucket i+1 (any backend; opt-in with
+                 PSND_DDP_GRAPH=events where the HIP runtime captures external event records - never run multi-rank so far)
       'capture'  the all-reduce itself is captured into the graph on RCCL's stream (fork after the bucket, join at the end):
-                 no host involvement at all (backend nccl only; PSND_DDP_GRAPH=capture)
-      'deferred' round 1's behaviour: every collective after the replay (PSND_DDP_GRAPH=deferred; the fallback when a
-                 capture with one of the other modes fails)
+                 no host involvement at all (backend nccl only, where it is the default)
+      'deferred' round 1's behaviour: every collective after the replay (the default under gloo; the fallback ALL ranks take
+                 together when a capture with one of the other modes fails on any rank - Trainer._capture)
     """
 
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, force: bool = False):
@@ -113,6 +114,7 @@ class FlatGradReducer:
         self.active = self.world > 1 or force   # force: single-rank process group (tests the collective plumbing on one GPU)
         self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
         self._capturing = None       # graph capture in progress: its mode
+        self._stall_logged = False
         self._graph_mode = None      # mode of the graph that was replayed last (None: eager step)
         self._events = None
         self._side = None
@@ -202,17 +204,21 @@ class FlatGradReducer:
 
     # ---- graph mode --------------------------------------------------------------------------------------------------
     def graph_mode(self) -> str:
-        """events where the HIP runtime captures external event records, else the captured RCCL all-reduce (backend nccl),
-        else deferred; PSND_DDP_GRAPH overrides the preference (a mode the runtime / backend cannot do is still replaced)"""
+        """the mode a captured step uses - by default the ones that have run end to end: the captured RCCL all-reduce under backend
+        nccl, `deferred` under any other backend.  `events` (external event-record nodes; any backend) is opt-in through
+        PSND_DDP_GRAPH=events and only where the HIP runtime captures such records: the runtime bundled with this torch build refuses
+        them, so that path has never been exercised by a multi-rank run.  PSND_DDP_GRAPH=capture | deferred force those; a mode the
+        runtime / backend cannot do is replaced by the default."""
         from ._lib import lib
-        mode = os.environ.get('PSND_DDP_GRAPH', 'events')
+        nccl = dist.get_backend() == 'nccl'
+        default = 'capture' if nccl else 'deferred'
+        mode = os.environ.get('PSND_DDP_GRAPH', default)
         if mode not in ('events', 'capture', 'deferred'):
             raise ValueError('PSND_DDP_GRAPH=%s (events | capture | deferred)' % mode)
-        nccl = dist.get_backend() == 'nccl'
         if mode == 'events' and not lib().psnd_event_external_supported():
-            mode = 'capture'
+            mode = default
         if mode == 'capture' and not nccl:           # only RCCL can be captured
-            mode = 'events' if lib().psnd_event_external_supported() else 'deferred'
+            mode = 'deferred'
         return mode
 
     def capture_begin(self, flag, mode: str):
@@ -334,6 +340,17 @@ class FlatGradReducer:
                     b['flat'].mul_(1.0 / self.world)
             return
         self._graph_mode = None
+        if self._next < len(self.buckets) and not self.deferred and not self._stall_logged:
+            # eager hooks launch in bucket order: a parameter of bucket `_next` that got no gradient holds back every later bucket,
+            # whose all-reduces are then issued here, serially, after the backward - say so once instead of losing the overlap silently
+            b = self.buckets[self._next]
+            if b['pending'] > 0 and any(q['pending'] == 0 for q in self.buckets[self._next + 1:]):
+                self._stall_logged = True
+                import logging
+                logging.getLogger('pytorch_sound_amd').warning(
+                    'FlatGradReducer: %d parameter(s) of bucket %d of %d received no gradient this step; the all-reduces of the '
+                    'buckets behind it were issued after the backward (no overlap). Unused parameters are best excluded '
+                    '(requires_grad = False).', b['pending'], self._next, len(self.buckets))
         for i in range(self._next, len(self.buckets)):
             b = self.buckets[i]
             b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)

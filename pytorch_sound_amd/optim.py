@@ -15,6 +15,10 @@ from ._lib import lib, check, ptr, stream_ptr
 
 class Adam(torch.optim.Optimizer):
     _step_supports_amp_scaling = True           # honours optimizer.found_inf / optimizer.grad_scale on the device
+    # Trainer.clip_grad (trainer.py:184-191) inside the step: `optimizer.fused_clip = (grad_clip, grad_norm)` for one step() makes
+    # the kernel clamp every (scaled) gradient element and apply clip_grad_norm_'s factor - ONE extra pass over the gradients
+    # (psnd_grad_sumsq) instead of a clamp per parameter + torch's multi-launch norm; `last_grad_norm` (device scalar) = the norm
+    _supports_fused_clip = True
     _decoupled = False                          # True: AdamW (weight decay applied to the parameter, not the gradient)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
@@ -75,6 +79,9 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         found_inf = getattr(self, 'found_inf', None)
         grad_scale = getattr(self, 'grad_scale', None)
+        clip_value, max_norm = getattr(self, 'fused_clip', None) or (0.0, 0.0)
+        clip_value, max_norm = float(clip_value or 0.0), float(max_norm or 0.0)
+        work = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group['params'] if p.grad is not None]
             if not params:
@@ -82,7 +89,7 @@ class Adam(torch.optim.Optimizer):
             key = (gi, tuple(map(id, params)))
             plan = self._plans.get(key)
             if plan is None:
-                if len(self._plans) > 16:
+                if len(self._plans) > 17:
                     self._plans.clear()
                 plan = self._plans[key] = self._build_plan(params)
             device = plan['device']
@@ -103,14 +110,37 @@ class Adam(torch.optim.Optimizer):
                 stable = all(g is p.grad for g, p in zip(grads, params))
                 plan['gptrs'] = gptrs if stable else None
                 plan['grads'] = None if stable else grads
+            work.append((group, plan, len(params)))
+        coef = None
+        if max_norm > 0.0 and work:
+            device = work[0][1]['device']
+            if any(w[1]['device'] != device for w in work):
+                raise _lib.PsndError('fused gradient-norm clipping needs every parameter group on one HIP device')
+            scratch = self._plans.get('clip')
+            if scratch is None or scratch['sumsq'].device != device:
+                scratch = self._plans['clip'] = {'sumsq': torch.zeros((), dtype=torch.float64, device=device),
+                                                 'coef': torch.ones(2, dtype=torch.float32, device=device)}
+            gs = grad_scale.to(device=device, dtype=torch.float32) if grad_scale is not None else None
+            with torch.cuda.device(device):
+                for wi, (group, plan, n) in enumerate(work):
+                    if plan.get('partial') is None:
+                        plan['partial'] = torch.empty(plan['chunk_off'].numel(), dtype=torch.float64, device=device)
+                    check(lib().psnd_grad_sumsq(ptr(plan['table']), n, ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
+                                                plan['chunk_off'].numel(), clip_value, ptr(gs), int(wi > 0), max_norm,
+                                                ptr(plan['partial']), ptr(scratch['sumsq']), ptr(scratch['coef']), stream_ptr(device)),
+                          'psnd_grad_sumsq')
+            coef = scratch['coef']
+            self.last_grad_norm = coef[1]
+        for group, plan, n in work:
+            device = plan['device']
             b1, b2 = group['betas']
             fi = found_inf.to(device=device, dtype=torch.float32) if found_inf is not None else None
             gs = grad_scale.to(device=device, dtype=torch.float32) if grad_scale is not None else None
             with torch.cuda.device(device):
-                check(lib().psnd_adam_step(ptr(plan['table']), len(params), ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
+                check(lib().psnd_adam_step(ptr(plan['table']), n, ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
                                            plan['chunk_off'].numel(), float(group['lr']), float(b1), float(b2), float(group['eps']),
                                            float(group['weight_decay']), int(self._decoupled), ptr(fi), ptr(gs), ptr(plan['corr']),
-                                           stream_ptr(device)), 'psnd_adam_step')
+                                           clip_value, ptr(coef), stream_ptr(device)), 'psnd_adam_step')
         return loss
 
 

@@ -94,15 +94,15 @@ def _independent_stream(tries: int = 6):
     varies from run to run).  So candidates are probed: a copy enqueued behind a busy compute stream must finish before the compute does."""
     cur = torch.cuda.current_stream()
     dev = cur.device
-    busy = torch.empty(1 << 26, device=dev)                   # 256 MB: a fill takes ~60 us, 40 of them ~2.5 ms
-    host = torch.empty(1 << 20, dtype=torch.float32).pin_memory()
-    dst = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+    busy = torch.empty(1 << 24, device=dev)                   # 64 MB: a fill takes ~15-20 us, 120 of them ~2 ms
+    host = torch.empty(1 << 18, dtype=torch.float32).pin_memory()
+    dst = torch.empty(1 << 18, dtype=torch.float32, device=dev)
     best = None
-    for _ in range(tries):
+    for attempt in range(tries):
         cand = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)
         done_busy, done_copy = torch.cuda.Event(), torch.cuda.Event()
-        for _ in range(40):
+        for _ in range(120):
             busy.fill_(1.0)
         done_busy.record(cur)
         with torch.cuda.stream(cand):
@@ -114,8 +114,14 @@ def _independent_stream(tries: int = 6):
         if best is None:
             best = cand
         if overlapped:
+            log('prefetch stream: candidate %d of %d runs next to the compute stream' % (attempt + 1, tries))
             return cand
+    log('prefetch stream: no candidate of %d overlapped with the compute stream - copies may serialise with the step' % tries)
     return best
+
+
+def dist_backend_is_nccl() -> bool:
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'
 
 
 class Trainer:
@@ -225,11 +231,24 @@ class Trainer:
         except StopIteration as e:                       # surfaces at the step that would have used the batch
             return e, None
 
+    def setup_prefetch(self):
+        """probe for the side stream now (a 64 MB scratch buffer, ~20 ms) instead of inside the first training step - call it
+        before the model's memory peaks when the GPU is nearly full"""
+        if (self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available() and getattr(self, '_pre_stream', None) is None:
+            self._pre_stream = _independent_stream()
+
     def _take_train_batch(self):
         if not ((self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available()):
             return self.prepare(*self._next_batch(self.train_dataset))
+        if self.prefetch_prepare and self.static_prepare:
+            # prepare() of batch k+1 runs on the side stream BEFORE step k's graph replay is enqueued: with persistent feature
+            # buffers (static_prepare) it would overwrite the very tensors that replay is about to read
+            raise ValueError('Trainer.prefetch_prepare and Trainer.static_prepare are mutually exclusive: a prepare() that runs '
+                             'one step ahead must return fresh tensors (set static_prepare = False), or only the copy may run '
+                             'ahead (prefetch_copy)')
         if getattr(self, '_pre_stream', None) is None:
             self._pre_stream = _independent_stream()
+        if getattr(self, '_pre', None) is None:
             self._pre = self._stage_train_batch()
         batch, event = self._pre
         if event is None:
@@ -273,6 +292,8 @@ class Trainer:
         return self.best_valid_loss
 
     def clip_grad(self):
+        """trainer.py:184-191: clamp every gradient to +-grad_clip, then clip the global norm to grad_norm.  Called as it is by the
+        synchronous path and by user code; the device-skip path folds both into the HIP optimizer's step (`_fused_clip`)."""
         if self.grad_clip:
             for p in self.model.parameters():
                 if p.grad is not None:
@@ -399,6 +420,7 @@ class Trainer:
                 p.grad = None                          # backward then WRITES its gradients (no zero fill, no += kernels)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            ok = True
             try:
                 # thread_local: the process group's watchdog thread keeps querying events of earlier collectives while this
                 # thread captures ("operation not permitted when stream is capturing" under the default global mode)
@@ -412,17 +434,26 @@ class Trainer:
                     loss.backward()
                     if mode in ('events', 'capture'):
                         red.capture_end()
-                break
             except Exception as e:                     # noqa: BLE001 - e.g. a runtime that cannot capture the release nodes
                 if mode in (None, 'deferred'):
                     raise
-                self._log('graph capture with DDP mode %s failed (%s): falling back to deferred all-reduce' % (mode, repr(e)[:200]))
+                ok = False
+                self._log('graph capture with DDP mode %s failed (%s)' % (mode, repr(e)[:200]))
                 red._capturing = None
-                mode = 'deferred'
                 torch.cuda.synchronize()
             finally:
                 if red is not None:
                     red.deferred = False               # eager (logging) steps keep the overlapped per-bucket all-reduce
+            if mode in ('events', 'capture') and pdist.is_dist():
+                # every rank must replay the SAME collective sequence: a rank that fell back on its own would issue its all-reduces
+                # after the replay while the others have them inside the graph - agree (MIN over ranks) and fall back together
+                dev = st['flag'].device if dist_backend_is_nccl() else None
+                ok = pdist.all_reduce_scalar(1.0 if ok else 0.0, 'min', dev) > 0
+            if ok:
+                break
+            self._log('falling back to the deferred all-reduce on every rank')
+            del graph
+            mode = 'deferred'
         st['graph'] = graph
         st['ddp'] = mode
         st['grads'] = {p: p.grad for p in params}      # static tensors of the graph's memory pool
@@ -433,10 +464,14 @@ class Trainer:
         """eager tail of a step whose backward has run: NaN flag to the host (asynchronously), gradient all-reduce,
         clipping, optimizer step with on-device skip"""
         grad_scale = None
+        # K18: clamp + global-norm clipping inside the optimizer launch (psnd_grad_sumsq + psnd_adam_step) when the optimizer can and
+        # clip_grad() is the stock one; the averaging over ranks is then the kernel's grad_scale as well
+        fused_clip = ((self.grad_clip or self.grad_norm) and getattr(self.optimizer, '_supports_fused_clip', False)
+                      and type(self).clip_grad is Trainer.clip_grad)
         if self._reducer is not None and pdist.is_dist():
             # ONE collective per bucket: the flag sits behind the last bucket (set_flag), and when nothing clips the gradients the
             # division by the world size is left to the optimizer kernel (grad_scale) instead of a pass over the buckets
-            in_opt = not (self.grad_clip or self.grad_norm)
+            in_opt = fused_clip or not (self.grad_clip or self.grad_norm)
             self._reducer.finish(average=not in_opt)
             flag = (self._reducer.flag > 0).to(torch.float32).reshape(())
             if in_opt:
@@ -452,7 +487,10 @@ class Trainer:
         if not hasattr(self, '_nan_pending'):
             self._nan_pending = []
         self._nan_pending.append((step, host_flag, event))
-        self.clip_grad()
+        if fused_clip:
+            self.optimizer.fused_clip = (self.grad_clip, self.grad_norm)
+        else:
+            self.clip_grad()
         self.optimizer.found_inf = flag
         self.optimizer.grad_scale = grad_scale
         try:
@@ -460,6 +498,8 @@ class Trainer:
         finally:
             del self.optimizer.found_inf
             del self.optimizer.grad_scale
+            if fused_clip:
+                del self.optimizer.fused_clip
         self._poll_nan_log()
 
     def train(self, step: int):

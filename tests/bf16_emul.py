@@ -90,3 +90,17 @@ def generator(gen, x, upsample='library'):
         if upsample != 'library':
             h = q(h)
     return torch.tanh(q(conv(gen.conv_post, q(h))))
+
+
+def separator(model, mag):
+    """ConvSeparator.forward_cl restated (pytorch_sound_amd/models/separator.py): log1p rounded into the CL layout, conv_pre, the
+    ResBlock1 chain with its (raw, activated) tensor pair handed from block to block, conv_post stored as bf16, sigmoid(.) * mag in
+    fp32.  Rounding points as psnd_conv1d_cl / psnd_conv1d_cl_pair (the pair's intermediate is rounded to bf16 in LDS)."""
+    v = conv(model.conv_pre, q(torch.log1p(mag)))
+    x, xa = q(v), q(F.leaky_relu(v, 0.1))
+    for block in model.blocks:
+        for c1, c2 in zip(block.convs1, block.convs2):
+            ta = q(F.leaky_relu(conv(c1, xa), 0.1))
+            v = conv(c2, ta, x)
+            x, xa = q(v), q(F.leaky_relu(v, 0.1))
+    return torch.sigmoid(q(conv(model.conv_post, xa))) * mag

@@ -99,8 +99,12 @@ def test_argument_validation_of_the_wider_entry_points(L):
     assert lib.psnd_pqmf_analysis(p, p, 1, 64, 4, 61, 0, 1.0, p, None) == -2           # odd tap count
     assert lib.psnd_pqmf_analysis(p, p, 1, 64, 17, 62, 0, 1.0, p, None) == -2          # too many subbands
     assert lib.psnd_pqmf_synthesis(p, p, 0, 16, 64, 4, 62, 0, 4.0, p, None) == 0
-    assert lib.psnd_adam_step(p, 1, p, p, 1, 1e-3, 1.0, 0.999, 1e-8, 0.0, 0, None, None, p, None) == -1    # beta1 = 1
-    assert lib.psnd_adam_step(p, 0, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, p, None) == 0
+    assert lib.psnd_adam_step(p, 1, p, p, 1, 1e-3, 1.0, 0.999, 1e-8, 0.0, 0, None, None, p, 0.0, None, None) == -1    # beta1 = 1
+    assert lib.psnd_adam_step(p, 1, p, p, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, p, -1.0, None, None) == -1   # clip_value < 0
+    assert lib.psnd_grad_sumsq(p, 1, p, p, 1, 0.0, None, 0, 1.0, None, p, p, None) == -1                              # no scratch
+    assert lib.psnd_grad_sumsq(p, 1, p, p, 1, 0.0, None, 0, -1.0, p, p, p, None) == -1                                # max_norm < 0
+    assert lib.psnd_polar_bwd(None, None, p, p, 4, p, p, None) == -1                                                   # no gradient given
+    assert lib.psnd_adam_step(p, 0, p, p, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, p, 0.0, None, None) == 0
     assert lib.psnd_adam_chunk() == 2048 and lib.psnd_adam_table_bytes() == 48
     assert lib.psnd_conv1d_wnorm_bwd_multi(p, 0, None) == -1 and lib.psnd_conv1d_wnorm_bwd_multi(p, 33, None) == -1
     assert lib.psnd_mask_head_fwd(None, p, 1, 8, 8, 8, 0, 32, p, None) == -1

@@ -238,3 +238,70 @@ def test_mask_head_matches_torch_formulation(N, C, T, HP):
     assert float(gy[:, :HP].abs().max()) == 0.0 and float(gy[:, HP + T:].abs().max()) == 0.0
     if Cp > C:
         assert float(gy[:, :, C:].abs().max()) == 0.0
+
+
+def _pair_stats(reset=False):
+    import ctypes
+    from pytorch_sound_amd._lib import lib
+    out = (ctypes.c_int64 * 4)()
+    lib().psnd_conv_pair_stats(out, 1 if reset else 0)
+    return list(out)
+
+
+def test_separator_bench_shape_vs_bf16_emulation():
+    """BASELINE config 2 at the BENCH shape: registered `conv_separator_voicebank` (256 channels, 4 blocks) on 32 clips x 513 bins x
+    173 frames - the launch instances the bench runs (32-row pair-forward tiles, the pair backward with its N * L dependent
+    weight-gradient split: both asserted through psnd_conv_pair_stats) - against tests/bf16_emul.py: the same arithmetic with the
+    kernels' rounding points (bf16 operands, fp32 accumulation) in plain torch, NOT another arrangement of the same kernels.
+    Output, input gradient, every parameter gradient.  Measured: out 1.3e-4, params(all) 6.2e-4, worst single tensor 1.5e-3,
+    input gradient 8.7e-3 (one-ulp differences flip leaky' masks); vs the fp32 formulation 4e-4 / 2.3e-3 / 5.5e-3."""
+    import bf16_emul as E
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2024)
+    model = build_model('conv_separator_voicebank').to(dev)
+    N, K, T = 32, 513, 173
+    mag = torch.rand(N, K, T, device=dev) * 4
+    tgt = torch.rand(N, K, T, device=dev) * 4
+
+    def run(fn, need_gx):
+        model.zero_grad()
+        m = mag.clone().requires_grad_(need_gx)
+        out = fn(m)
+        torch.nn.functional.l1_loss(out, tgt).backward()
+        return out.detach().clone(), (m.grad.clone() if need_gx else None), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    _pair_stats(reset=True)
+    got = run(model, False)                                   # the bench's path: mask head fused (psnd_mask_head_*), no input gradient
+    st = _pair_stats()
+    # 12 residual pairs: forward launches on 32-row tiles (95 64-row tiles would not fill the chip), 12 pair backward launches,
+    # 7 weight-gradient row ranges at 32 x 213 padded rows
+    assert st[0] == 12 and st[1] == 0 and st[2] == 12, st
+    assert st[3] == 7, st
+    got_gx = run(model, True)                                 # with the input gradient (layout kernel + torch sigmoid head)
+    emul = run(lambda m: E.separator(model, m), True)
+
+    def fp32(m):
+        x = model.conv_pre(torch.log1p(m))
+        for b in model.blocks:
+            x = b(x)
+        return torch.sigmoid(model.conv_post(F.leaky_relu(x, 0.1))) * m
+    ref32 = run(fp32, True)
+
+    def compare(a, b, tol_out, tol_gx, tol_all, tol_each, tag):
+        errs = {'out': relf(a[0], b[0])}
+        if a[1] is not None:
+            errs['gx'] = relf(a[1], b[1])
+        names = sorted(a[2])
+        errs['all'] = relf(torch.cat([a[2][n].flatten() for n in names]), torch.cat([b[2][n].flatten() for n in names]))
+        each = sorted(((relf(a[2][n], b[2][n]), n) for n in names if b[2][n].norm() > 0), reverse=True)
+        print('%s: %s worst %.2e (%s)' % (tag, {k: '%.2e' % v for k, v in errs.items()}, each[0][0], each[0][1]))
+        assert errs['out'] <= tol_out and errs.get('gx', 0) <= tol_gx and errs['all'] <= tol_all, (tag, errs)
+        assert each[0][0] <= tol_each, (tag, each[:3])
+
+    compare(got, emul, 1e-3, 0, 3e-3, 1e-2, 'bench path vs bf16 emulation')
+    compare(got_gx, emul, 1e-3, 3e-2, 3e-3, 1e-2, 'with input gradient vs bf16 emulation')
+    compare(got, ref32, 5e-3, 0, 2e-2, 5e-2, 'bench path vs fp32')
+    # the fused mask head and the layout-kernel head are the same function
+    assert relf(got[0], got_gx[0]) <= 1e-6

@@ -34,24 +34,27 @@ def _batches(n):
 NAN_STEP, STEPS = 5, 9
 
 
-def _worker(rank, world, port, tmp, q, graph, hip_adam, ddp_mode='events'):
+def _worker(rank, world, port, tmp, q, graph, hip_adam, ddp_mode=None, share=True, clip=False):
     try:
-        os.environ['PSND_DDP_GRAPH'] = ddp_mode
-        _run(rank, world, port, tmp, q, graph, hip_adam)
+        if ddp_mode is None:
+            os.environ.pop('PSND_DDP_GRAPH', None)
+        else:
+            os.environ['PSND_DDP_GRAPH'] = ddp_mode
+        _run(rank, world, port, tmp, q, graph, hip_adam, share, clip)
     except Exception as e:                                                # the parent must not wait for its timeout
         q.put((rank, repr(e)))
         raise
 
 
-def _run(rank, world, port, tmp, q, graph, hip_adam):
+def _run(rank, world, port, tmp, q, graph, hip_adam, share=True, clip=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank),
-                      PSND_DIST_SHARE_GPU='1')
+                      PSND_DIST_SHARE_GPU='1' if share else '0')
     import torch.distributed as dist
     from pytorch_sound_amd import distributed as pdist, optim as poptim
     from pytorch_sound_amd.trainer import Trainer, LogType
     assert pdist.init_from_env('nccl')                                    # share mode switches to gloo itself
-    dev = torch.device('cuda:0')
+    dev = torch.device('cuda', torch.cuda.current_device())
 
     class T(Trainer):
         def forward(self, x, y, is_logging=False):
@@ -67,24 +70,30 @@ def _run(rank, world, port, tmp, q, graph, hip_adam):
     tr = T(net, opt, mine, mine[:1], max_step=STEPS, valid_max_step=1, save_interval=10 ** 6, log_interval=10 ** 6,
            save_dir=tmp, save_prefix='dp', seed=3)
     tr.graph_steps, tr.graph_warmup = graph, 1
+    if clip:
+        tr.grad_clip, tr.grad_norm = CLIP
     net.train()
     for i in range(1, STEPS + 1):
         tr.step = i
         tr.train(i)
     torch.cuda.synchronize()
-    q.put((rank, {k: v.cpu().numpy() for k, v in net.state_dict().items()}))
+    out = {k: v.cpu().numpy() for k, v in net.state_dict().items()}
+    # the mode every captured step graph REALLY ran with (a fallback must be visible to the test), and the backend
+    out['__modes__'] = np.asarray([str(v.get('ddp')) for v in getattr(tr, '_graphs', {}).values() if 'graph' in v])
+    out['__backend__'] = np.asarray(dist.get_backend())
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(400)
-@pytest.mark.parametrize('graph,hip_adam,ddp_mode', [(True, True, 'events'), (False, True, 'events'), (True, False, 'events'),
-                                                     (True, True, 'deferred')])
-def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode):
+CLIP = (0.05, 0.2)          # Trainer.grad_clip, Trainer.grad_norm of the clipping variant: both bite on this problem
+
+
+def _two_ranks(tmp_path, graph, hip_adam, ddp_mode, share, clip, expect_backend, expect_modes):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, graph, hip_adam, ddp_mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, graph, hip_adam, ddp_mode, share, clip)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=150) for _ in procs)
@@ -92,6 +101,10 @@ def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    for r in (0, 1):
+        assert str(res[r].pop('__backend__')) == expect_backend
+        modes = [str(m) for m in res[r].pop('__modes__')]
+        assert modes == expect_modes, (r, modes)                          # what ran, not what was asked for
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k                    # ranks bit-identical
     # one process, full batches, the NaN step skipped by everybody
@@ -104,9 +117,35 @@ def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode):
         x, y = data[step - 1]
         opt.zero_grad()
         torch.nn.functional.mse_loss(net(x.double()), y.double()).backward()
+        if clip:                                                          # pytorch_sound/trainer.py:184-191
+            for p in net.parameters():
+                p.grad = p.grad.clamp(-CLIP[0], CLIP[0])
+            torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP[1])
         opt.step()
     for k, v in net.state_dict().items():
         assert np.abs(v.numpy() - res[0][k]).max() <= 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize('graph,hip_adam,ddp_mode,clip', [(True, True, None, False), (False, True, None, False), (True, False, None, False),
+                                                          (True, True, 'events', False), (True, True, None, True),
+                                                          (False, False, None, True)])
+def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode, clip):
+    """two ranks share the one GPU over gloo: the default graph mode there is `deferred` - and so is `events`, which this HIP
+    runtime cannot capture (asserted: the mode recorded by the step graph, not the one asked for).  clip: Trainer.grad_clip +
+    grad_norm, folded into the HIP optimizer step (K18) or, with torch's fused Adam, the reference's per-parameter formulation -
+    the global norm is taken over the AVERAGED gradients on every rank."""
+    _two_ranks(tmp_path, graph, hip_adam, ddp_mode, True, clip, 'gloo', ['deferred'] if graph else [])
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank: this box has one GPU (the captured-RCCL '
+                    'path is covered there by the one-rank group of test_rccl_all_reduce_captured_in_the_step_graph)')
+@pytest.mark.parametrize('graph', [True, False])
+def test_two_ranks_rccl_captured_all_reduce(tmp_path, graph):
+    """the same training over RCCL on two devices: the step graph must have run in `capture` mode (all-reduce of every bucket
+    captured into the graph) on both ranks - runs wherever two GPUs are visible."""
+    _two_ranks(tmp_path, graph, True, None, False, False, 'nccl', ['capture'] if graph else [])
 
 
 # ---- graph mode: buckets are released INSIDE the replayed backward ------------------------------------------------------------

@@ -131,4 +131,93 @@ def test_rejects_what_it_cannot_do():
     p.grad = torch.ones(3)
     with pytest.raises(_lib.PsndError):
         O.Adam([p]).step()                                    # CPU parameter: no fallback
-    assert _lib.lib().psnd_adam_step(None, 1, None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, None, None) == -1
+    assert _lib.lib().psnd_adam_step(None, 1, None, None, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, None, 0.0, None, None) == -1
+
+
+@pytest.mark.parametrize('clip_value,max_norm,scale', [(0.5, 0.0, None), (0.0, 3.0, None), (0.7, 5.0, None), (0.7, 5.0, 2.0),
+                                                       (0.0, 1e9, None)])
+def test_fused_clip_matches_trainer_clip_grad(clip_value, max_norm, scale):
+    """K18: `optimizer.fused_clip = (grad_clip, grad_norm)` = Trainer.clip_grad of the reference (trainer.py:184-191: per-parameter
+    clamp, then torch.nn.utils.clip_grad_norm_) followed by the step, evaluated in float64 on the host: parameters, moments, the
+    reported norm; the gradients in memory stay untouched.  Two parameter groups (the norm is global), a grad_scale (the data-
+    parallel division by the world size) applied BEFORE the clamp, as averaging before clipping does."""
+    host = [p.double().clone().requires_grad_(True) for p in _params(0)]
+    dev = [p.to(DEV).clone().requires_grad_(True) for p in _params(0)]
+    og = O.Adam([{'params': dev[:3]}, {'params': dev[3:], 'lr': 3e-3}], lr=1e-3)
+    orf = torch.optim.Adam([{'params': host[:3]}, {'params': host[3:], 'lr': 3e-3}], lr=1e-3)
+    for s in range(3):
+        grads = _params(200 + s)
+        for p, q, g in zip(dev, host, grads):
+            p.grad = g.to(DEV).clone()
+            q.grad = g.double() / (scale or 1.0)
+        keep = [p.grad.clone() for p in dev]
+        if clip_value:
+            for q in host:
+                q.grad = q.grad.clamp(-clip_value, clip_value)
+        norm = torch.nn.utils.clip_grad_norm_(host, max_norm) if max_norm else None
+        og.fused_clip = (clip_value, max_norm)
+        if scale:
+            og.grad_scale = torch.tensor(scale, device=DEV)
+        og.step()
+        del og.fused_clip
+        if scale:
+            del og.grad_scale
+        orf.step()
+        for p, k in zip(dev, keep):
+            assert torch.equal(p.grad, k)                                   # p.grad is read, never rewritten
+        if max_norm:
+            assert abs(float(og.last_grad_norm) - float(norm)) <= 2e-6 * float(norm)
+    for p, q in zip(dev, host):
+        _close(p, q)
+        _close(og.state[p]['exp_avg'], orf.state[q]['exp_avg'])
+        _close(og.state[p]['exp_avg_sq'], orf.state[q]['exp_avg_sq'], 4e-6)
+
+
+def test_trainer_folds_clip_grad_into_the_optimizer_step(tmp_path):
+    """Trainer with grad_clip / grad_norm and the HIP optimizer: the device-skip path hands both to the optimizer (no per-parameter
+    clamp, no torch norm kernels) - equal to the same training with the reference's eager clip_grad() and to float64 on the host;
+    a Trainer subclass that overrides clip_grad() keeps being called."""
+    from pytorch_sound_amd.trainer import Trainer, LogType
+
+    class T(Trainer):
+        def forward(self, x, y, is_logging=False):
+            loss = torch.nn.functional.mse_loss(self.model(x), y)
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    calls = []
+
+    class TOverride(T):
+        def clip_grad(self):
+            calls.append(1)
+            super().clip_grad()
+
+    def net():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Conv1d(4, 16, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv1d(16, 2, 1))
+
+    g = torch.Generator().manual_seed(5)
+    data = [(torch.randn(8, 4, 32, generator=g), 3 * torch.randn(8, 2, 32, generator=g)) for _ in range(6)]
+    out = {}
+    for name, cls in (('fused', T), ('override', TOverride)):
+        m = net().to(DEV)
+        tr = cls(m, O.Adam(m.parameters(), lr=1e-2), data, data[:1], max_step=6, valid_max_step=1, save_interval=10 ** 6,
+                 log_interval=10 ** 6, save_dir=str(tmp_path), save_prefix=name, grad_clip=0.05, grad_norm=0.1, seed=1)
+        m.train()
+        for i in range(1, 7):
+            tr.step = i
+            tr.train(i)
+        torch.cuda.synchronize()
+        out[name] = {k: v.double().cpu() for k, v in m.state_dict().items()}
+    assert len(calls) == 6
+    m = net().double()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    for x, y in data:
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(m(x.double()), y.double()).backward()
+        for p in m.parameters():
+            p.grad = p.grad.clamp(-0.05, 0.05)
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 0.1)
+        opt.step()
+    for k, v in m.state_dict().items():
+        assert (out['fused'][k] - v).abs().max() <= 2e-5 * max(1.0, float(v.abs().max())), k
+        assert (out['override'][k] - v).abs().max() <= 2e-5 * max(1.0, float(v.abs().max())), k
