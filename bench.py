@@ -22,7 +22,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   h2d_inclusive    the same step with the batches in pinned HOST memory (the reference's loop includes this copy,
                    trainer.py:202): copied on a side stream one step ahead (Trainer.prefetch_prepare) and in line
   cpu_baseline     the reference's CPU path (oracle/torch_ref.py port of its dense-DFT conv1d STFT + mel,
-                   same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample.
+                   same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample;
+  cpu_baseline_torch_stft  the same step with the reference's torch.stft front end (STFTTorchAudio) instead
+  timing           ms/step of the contract region and of further identical K-step blocks (>= 100 ms timed in all): the spread
 """
 import argparse
 import json
@@ -59,8 +61,10 @@ def synth_batch(seed, n, t, device):
     return (both.to(device),)
 
 
-def build_step(device, amp):
-    """returns (trainer_cls, model, frontend modules) for the config-2 step on `device`."""
+def build_step(device, amp, static=True, cpu_frontend='port'):
+    """returns (trainer_cls, model) for the config-2 step on `device`.  static: the features go into persistent buffers that the step
+    graph reads in place (Trainer.static_prepare) - off when prepare() runs one step ahead on a side stream (--prefetch).
+    cpu_frontend (CPU baseline leg only): 'port' = the reference's dense-DFT conv1d STFT, 'torch_stft' = its torch.stft class."""
     from pytorch_sound_amd.models import build_model
     from pytorch_sound_amd.models import separator  # noqa: F401  (registers conv_separator)
     from pytorch_sound_amd.trainer import Trainer, LogType
@@ -75,14 +79,18 @@ def build_step(device, amp):
 
         def magnitude(w):
             n, t = w.shape
+            if not static:
+                return K.stft_forward(w, N_FFT, HOP, fe.stft._plan(w.device), K.FRAMING_CENTER, 0.0)['mag']
             key = ('mag', n, t)
             if key not in feat:
                 feat[key] = torch.empty((n, N_FFT // 2 + 1, K.frame_count(t, N_FFT, HOP)), dtype=torch.float32, device=w.device)
             return K.stft_forward(w, N_FFT, HOP, fe.stft._plan(w.device), K.FRAMING_CENTER, 0.0, out_mag=feat[key])['mag']
 
-        def logmel_of_mag(m, static=False):
-            if not static:
+        def logmel_of_mag(m, persistent=False):
+            if not persistent:
                 return K.MelLog.apply(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+            if not static:
+                return K.mel_forward(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)[0]
             key = ('mel', m.shape[0], m.shape[2])
             if key not in feat:
                 feat[key] = torch.empty((m.shape[0], N_MEL, m.shape[2]), dtype=torch.float32, device=m.device)
@@ -91,20 +99,20 @@ def build_step(device, amp):
         l1 = K.l1_loss                                              # F.l1_loss as psnd_l1_loss_fwd / _bwd
         l1sum = K.l1_loss_sum
     else:
-        from oracle.torch_ref import RefLogMel                      # CPU baseline leg only
-        fe = RefLogMel(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX)
+        from oracle.torch_ref import RefLogMel, RefLogMelTorch      # CPU baseline leg only
+        fe = (RefLogMelTorch if cpu_frontend == 'torch_stft' else RefLogMel)(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX)
 
         def magnitude(w):
             return fe.stft.transform(w)[0]
 
-        def logmel_of_mag(m, static=False):
+        def logmel_of_mag(m, persistent=False):
             return fe.mel_of_mag(m)
 
         l1 = F.l1_loss
         l1sum = None
 
     class StepTrainer(Trainer):
-        static_prepare = gpu          # the features are written into persistent buffers: the step graph reads them in place
+        static_prepare = gpu and static   # the features are written into persistent buffers: the step graph reads them in place
 
         def prepare(self, both):
             # feature extraction of the batch (no parameters, no gradient): eager, ahead of the captured graph
@@ -112,7 +120,7 @@ def build_step(device, amp):
                 n = both.shape[0] // 2
                 mag = magnitude(both)                             # mixture and reference clips: ONE STFT launch (2 x batch clips)
                 mag_mix, mag_ref = mag[:n], mag[n:]
-                mel_ref = logmel_of_mag(mag_ref, static=True)
+                mel_ref = logmel_of_mag(mag_ref, persistent=True)
             return mag_mix, mag_ref, mel_ref
 
         def forward(self, mag_mix, mag_ref, mel_ref, is_logging=False):
@@ -147,7 +155,7 @@ def gpu_bench(args):
     T = int(SR * CLIP_SECONDS)
     N = BATCH_PER_GPU
 
-    Trainer, model = build_step(device, amp=True)
+    Trainer, model = build_step(device, amp=True, static=not args.prefetch)
     from pytorch_sound_amd import optim as poptim
     # torch.optim.Adam semantics as one HIP launch (psnd_adam_step); --torch-adam keeps torch's fused multi-tensor kernel
     opt = (torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True) if args.torch_adam
@@ -175,6 +183,10 @@ def gpu_bench(args):
             step += 1
             tr.step = step
             tr.train(step)
+    for _ in range(args.settle):        # set-up as well: the first ~30 ms of replays run below the steady clock (timing.blocks shows it)
+        step += 1
+        tr.step = step
+        tr.train(step)
     for _ in range(args.warmup):
         step += 1
         tr.step = step
@@ -195,12 +207,34 @@ def gpu_bench(args):
         tdt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tdt.item())
+    ev_instep = K.STFT_FWD_EVENTS
+    K.STFT_FWD_EVENTS = None
+    # ---- spread: the contract region above is K steps (~17 ms at K = 20); the same K steps are repeated in further timed blocks
+    #      (each bracketed like the first) until >= 100 ms have been timed, and every block's ms/step is reported next to `value`
+    blocks = [dt / args.steps * 1e3]
+    n_blocks = int(min(64, max(4, np.ceil(0.1 / max(dt, 1e-6)))))
+    for _ in range(n_blocks):
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            step += 1
+            tr.step = step
+            tr.train(step)
+        barrier()
+        d = time.perf_counter() - tb
+        if distributed:
+            tdt = torch.tensor([d], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+            d = float(tdt.item())
+        blocks.append(d / args.steps * 1e3)
+    timing = {'blocks_ms_per_step': [round(b, 4) for b in blocks], 'block_steps': args.steps, 'blocks': len(blocks),
+              'total_timed_ms': float(sum(blocks) * args.steps), 'min': float(min(blocks)), 'median': float(np.median(blocks)),
+              'max': float(max(blocks)),
+              'note': 'block 0 is the contract region (`ms_per_step`, `value`); the further blocks repeat the same K steps'}
 
     # ---- the same step with the batches in pinned HOST memory (the reference's loop includes this copy: trainer.py:202,
     #      utils/tensor.py:15).  (a) copied + feature-extracted one step ahead on a side stream (Trainer.prefetch_prepare),
     #      (b) copied in line on the compute stream as the reference does.  Same K steps each, max over ranks.
-    ev_instep = K.STFT_FWD_EVENTS
-    K.STFT_FWD_EVENTS = None
     h2d = {}
     host_pool = [synth_batch(1234 + rank + 1000 * i, N, T, torch.device('cpu')) for i in range(args.pool)]
     for mode in ('prefetch_copy', 'inline'):
@@ -271,7 +305,7 @@ def gpu_bench(args):
         bl = 4 * NL * T + 4 * NL * Kb * Fr
         roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
                     'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic(), 'traffic_source': 'profiles/stft_pmc.json (separate rocprofv3 --pmc pass of this launch)',
+                    'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic('n1024'), 'traffic_source': _pmc_traffic('n1024', 'source'),
                     'bytes_per_launch': bl, 'launch_us': tl * 1e6, 'launches_timed': len(evs) - 3,
                     'workload': '1024 clips x 2 s, 1024/256: 181 MB in + 363 MB out = 544 MB (> the 256 MiB Infinity Cache), the '
                                 'kernel of the step on an HBM-sized working set; HIP events around every launch, measured in this run'}
@@ -288,7 +322,7 @@ def gpu_bench(args):
                        'global_batch': world * N, 'clip_seconds': CLIP_SECONDS, 'parallelism': 'dp%d' % world,
                        'model_params': sum(p.numel() for p in model.parameters())},
             'roofline': roofline, 'roofline_instep': roofline_instep, 'roofline_config5': roofline_config5,
-            'roofline_conv': roofline_conv, 'h2d_inclusive': h2d,
+            'roofline_conv': roofline_conv, 'h2d_inclusive': h2d, 'timing': timing,
         }
     return out, device
 
@@ -315,7 +349,8 @@ def _config5_roofline(device, n_fft=4096, hop=1024, clips=32, seconds=30.0, sr=4
     t = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
     b = 4 * clips * T + 4 * clips * Kb * Fr
     return {'bound': 'hbm', 'kernel': 'stft_fwd_n4096b_kernel (wav -> magnitude, 4096/1024)', 'achieved': b / t / 1e9,
-            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': None, 'bytes_per_launch': b,
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': _pmc_traffic('n4096'),
+            'traffic_source': _pmc_traffic('n4096', 'source'), 'bytes_per_launch': b,
             'launch_us': t * 1e6, 'launches_timed': len(evs) - 3,
             'workload': 'configs[4]: %d clips x %.0f s at %d Hz, n_fft %d / hop %d (%.0f MB)' % (clips, seconds, sr, n_fft, hop, b / 1e6)}
 
@@ -411,26 +446,27 @@ def _hann(n):
     return (0.5 - 0.5 * np.cos(2 * np.pi * m / n)).astype(np.float32)
 
 
-def _pmc_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/stft_pmc.json, written by
-    tools/pmc_summary.py from a separate `rocprofv3 --pmc` run), or None."""
+def _pmc_traffic(which, field='hbm_bytes_per_launch'):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md corrections) of the launch the roofline entry times,
+    from the committed PMC pass: profiles/stft_pmc.json, written by tools/pmc_to_json.py from separate `rocprofv3 --pmc` runs of
+    tools/run_stft_only.py (counters cannot be read inside an un-profiled run).  which: 'n1024' | 'n4096'."""
     p = os.path.join(ROOT, 'profiles', 'stft_pmc.json')
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get('hbm_bytes_per_launch')
-        except Exception:
-            return None
-    return None
+    try:
+        return json.load(open(p))[which].get(field)
+    except Exception:
+        return None
 
 
-def cpu_baseline(seconds):
-    """reference CPU path (port) on the host cores: same step, fp32, 4 x 2 s clips."""
+def cpu_baseline(seconds, frontend='port'):
+    """reference CPU path on the host cores: same step, fp32, 4 x 2 s clips.  frontend 'port': the reference's dense-DFT conv1d STFT
+    (STFT.transform, the class LogMelSpectrogram uses); 'torch_stft': its torch.stft wrapper (STFTTorchAudio) - BASELINE.md asks for
+    both."""
     # probe on the MI355X host (256 logical CPUs): this step scales to ~16-32 threads and collapses
     # beyond 64 (oversubscribed small convs), so the baseline uses min(32, cores) threads
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     dev = torch.device('cpu')
-    Trainer, model = build_step(dev, amp=False)
+    Trainer, model = build_step(dev, amp=False, cpu_frontend=frontend)
     Trainer.move_batches_to_gpu = False              # this leg stays on the host (Trainer would .cuda() every batch)
     Ncpu, T = 4, int(SR * CLIP_SECONDS)
     pool = [synth_batch(4321 + i, Ncpu, T, dev) for i in range(2)]
@@ -449,11 +485,23 @@ def cpu_baseline(seconds):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 200:
             break
+    # the feature path alone (wav -> magnitude -> log-mel of 2 x 4 clips, as prepare() runs it), same threads
+    both = pool[0][0]
+    tr.prepare(both)
+    m, t1 = 0, time.perf_counter()
+    while True:
+        m += 1
+        tr.prepare(both)
+        ef = time.perf_counter() - t1
+        if ef >= min(2.0, seconds / 4) or m >= 200:
+            break
+    feat = {'port': "oracle/torch_ref.py RefSTFT (the reference's dense-DFT conv1d STFT, transforms.py:53-69) + mel",
+            'torch_stft': "oracle/torch_ref.py RefSTFTTorch (the reference's torch.stft wrapper, transforms.py:297-311) + mel"}[frontend]
     return {'value': n * Ncpu * CLIP_SECONDS / el, 'unit': 'audio-s/s', 'cores': cores, 'cpu_count': os.cpu_count(), 'kind': 'port',
+            'frontend': frontend, 'features_only_audio_s_per_s': m * 2 * Ncpu * CLIP_SECONDS / ef,
             'threads_note': 'torch.set_num_threads(min(32, cpu_count)): this step scales to ~16-32 threads and collapses beyond 64',
             'sample': '%d steps of batch 4 x 2 s clips (configs[0] batch), same model/loss/Adam in fp32, '
-                      'feature path = oracle/torch_ref.py (the reference\'s dense-DFT conv1d STFT + mel); %.1f s'
-                      % (n, el)}
+                      'feature path = %s; %.1f s' % (n, feat, el)}
 
 
 def main():
@@ -462,7 +510,8 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pool', type=int, default=8, help='distinct synthetic batches resident in HBM')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--settle', type=int, default=40, help='untimed set-up steps in front of the W warm-up steps (clock ramp)')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0, help='CPU baseline budget (60 %% dense-DFT port, 40 %% torch.stft variant)')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
     ap.add_argument('--prefetch', action='store_true', help='stage the next batch (copy + feature extraction) on a side stream')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
@@ -472,7 +521,8 @@ def main():
     out, device = gpu_bench(args)
     if out is not None:
         if args.gpus == 1 and args.cpu_seconds > 0:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+            out['cpu_baseline'] = cpu_baseline(args.cpu_seconds * 0.6, 'port')
+            out['cpu_baseline_torch_stft'] = cpu_baseline(args.cpu_seconds * 0.4, 'torch_stft')
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()

@@ -7,6 +7,8 @@ established by tests/test_oracle_golden.py::test_torch_ref_* on the golden fixtu
 RefSTFT.transform          <- pytorch_sound/models/transforms.py:53-69 (reflect pad + conv1d with the
                               dense windowed-DFT basis + sqrt / atan2)
 RefLogMel.forward          <- transforms.py:231-244 (matmul, log(.+1e-6), truthiness-gated clamps)
+RefSTFTTorch.transform     <- transforms.py:297-311 (STFTTorchAudio: torch.stft(center, reflect, onesided) -> re, im -> magnitude,
+                              phase), the library-FFT variant BASELINE.md asks to be timed separately next to the dense-DFT port
 """
 import numpy as np
 import torch
@@ -49,3 +51,28 @@ class RefLogMel(torch.nn.Module):
 
     def forward(self, wav, log_offset=1e-6):
         return self.mel_of_mag(self.stft.transform(wav)[0], log_offset)
+
+
+class RefSTFTTorch(torch.nn.Module):
+    """STFTTorchAudio.forward / transform (transforms.py:297-311) on this torch: `torch.stft(..., return_complex=True)` viewed
+    as (re, im) is what the reference's torch-1.7 call returned."""
+
+    def __init__(self, filter_length=1024, hop_length=512, win_length=None):
+        super().__init__()
+        self.n_fft, self.hop_length = filter_length, hop_length
+        self.win_length = win_length if win_length else filter_length
+        self.register_buffer('window', torch.hann_window(self.win_length))
+
+    def transform(self, wav):
+        s = torch.stft(wav, self.n_fft, self.hop_length, self.win_length, self.window, True, 'reflect', False, True,
+                       return_complex=True)
+        re, im = s.real, s.imag
+        return torch.sqrt(re ** 2 + im ** 2), torch.atan2(im, re)
+
+
+class RefLogMelTorch(RefLogMel):
+    """RefLogMel with the torch.stft front end"""
+
+    def __init__(self, sample_rate, mel_size, n_fft, win_length, hop_length, min_db=None, max_db=None, mel_min=0., mel_max=None):
+        super().__init__(sample_rate, mel_size, n_fft, win_length, hop_length, min_db, max_db, mel_min, mel_max)
+        self.stft = RefSTFTTorch(win_length, hop_length)
