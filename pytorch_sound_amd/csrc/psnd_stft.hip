@@ -20,6 +20,7 @@
 //           instruction writes 64-B (128-B) runs of the (N,K,F) frame-fastest output.
 // The only LDS round trip is the transposing exchange between the passes (4 KB/frame each way).
 #include "psnd_stft_pass.h"
+#include "psnd_stft_w.h"
 #include "psnd_pk.h"
 #include <math.h>
 #include <string.h>
@@ -735,7 +736,8 @@ constexpr int k4096QP = 256 + 18;
 constexpr int k4096FP = 8 * k4096QP + 20;
 constexpr int k4096VK = 2052;                      // floats of the vk table (1025 entries, padded)
 constexpr int k4096LdsFloats = k4096FT * k4096FP * 2 + k4096VK + 512;
-constexpr int k4096PlanFloats = 4096 * 3 + 512 + k4096VK;
+constexpr int k4096PlanFloats = kW4096PlanFloats;     // the tables of the three 4096 kernels (psnd_stft_w.h)
+static_assert(kW4096TwOff == 4096 * 3 + 512 + k4096VK, "plan layout");
 
 template <bool MAG, bool PHASE, bool REIM>
 __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p) {
@@ -1305,6 +1307,7 @@ extern "C" int psnd_stft_plan_build(int n_fft, const float *window_host, void *p
                 vk[2 * k] = (float)(-sin(th));
                 vk[2 * k + 1] = (float)(-cos(th));
             }
+            psnd_stft4096w_plan_fill(pl);
         }
         return PSND_OK;
     }
@@ -1394,6 +1397,11 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
                 if (!span_kernel_ok<32, 32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 32>(p, mag, phase, re, s);
                 return launch_span<32, 32>(p, mag, phase, re, s);
         }
+    }
+    if (n_fft == 4096 && mag && !phase && !re && psnd_stft4096w_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1") &&
+        !getenv("PSND_STFT4096_V2")) {
+        // magnitude only (LogMelSpectrogram, the losses): one wave per frame, 16 frames per workgroup, 64-byte store runs (psnd_stft_w.hip)
+        return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, s);
     }
     if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {
         // 4-frame tiles, two workgroups per CU (span <= 4 pieces per thread)
