@@ -91,6 +91,63 @@ def test_stft_mag_vs_oracle(n_fft, hop, win, framing, N, T):
     assert np.abs(got - ref).max() <= tol
 
 
+# n_fft = 4096, magnitude only, on the wave-per-frame kernel (psnd_stft_w.hip: 16 frames per workgroup, 64-byte store runs).  The
+# dispatcher takes it from 2048 16-frame tiles on (config 5 at 32 clips); PSND_STFT4096_W=1 forces it at test sizes.
+N4096W_CASES = [
+    (4096, 1024, None, 0, 1, 9000),       # F = 9: one partial tile, frames 0-1 and 7-8 touch the clip edges (reflect), F % 4 != 0
+    (4096, 1024, None, 0, 3, 44100),      # F = 44 (F % 4 == 0: 16-byte stores), 3 tiles per clip, partial last tile
+    (4096, 1024, 3000, 1, 2, 30000),      # HiFi-GAN framing, short window
+    (4096, 1022, None, 0, 1, 20000),      # even hop that is not a multiple of 4
+    (4096, 512, None, 0, 2, 40000),       # hop = n / 8
+    (4096, 1900, None, 0, 2, 70000),      # the widest hop the 8-byte sample loads cover
+    (4096, 1024, None, 0, 1, 2049),       # T barely above the reflect pad: every frame touches an edge
+    (4096, 1024, None, 0, 21, 60000),     # many clips: several persistent workgroups with more than one tile
+]
+
+
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', N4096W_CASES)
+def test_stft_4096_wave_kernel_vs_oracle(n_fft, hop, win, framing, N, T, monkeypatch):
+    monkeypatch.setenv('PSND_STFT4096_W', '1')
+    wav = seeded_wav(n_fft + hop + T, N, T)
+    got = _stft(wav, n_fft, hop, win, framing, want_mag=True)['mag']
+    ref = ofe.stft_mag_f64(wav, n_fft, hop, win, framing)
+    assert got.shape == ref.shape == (N, n_fft // 2 + 1, ofe.frame_count(T, n_fft, hop, framing))
+    assert np.abs(got - ref).max() <= FFT_RTOL * np.abs(ref).max()
+    # mag_eps (interface/hifi_gan.py:55) and the 4-frame kernel agree with it as well
+    got_eps = _stft(wav, n_fft, hop, win, framing, mag_eps=1e-9, want_mag=True)['mag']
+    assert np.abs(got_eps - np.sqrt(ref * ref + 1e-9)).max() <= FFT_RTOL * np.abs(ref).max()
+    monkeypatch.delenv('PSND_STFT4096_W')
+    monkeypatch.setenv('PSND_STFT4096_V2', '1')
+    old = _stft(wav, n_fft, hop, win, framing, want_mag=True)['mag']
+    assert np.abs(got - old).max() <= 2 * FFT_RTOL * np.abs(ref).max()
+
+
+def test_stft_4096_wave_kernel_full_size(monkeypatch):
+    """config 5 at the size where the dispatcher picks the wave-per-frame kernel by itself (32 clips x 30 s: 2592 tiles): equal to the
+    4-frame kernel on the same input, Parseval per frame, every element written (NaN-filled output)."""
+    K = _k()
+    dev = _dev()
+    n_fft, hop, N, T = 4096, 1024, 32, 1323000
+    g = torch.Generator(device='cpu').manual_seed(3)
+    a = (0.0708 * torch.randn(N, T, generator=g)).to(dev)
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(dev)
+    F = K.frame_count(T, n_fft, hop)
+    out = torch.full((N, n_fft // 2 + 1, F), float('nan'), device=dev)
+    K.stft_forward(a, n_fft, hop, plan, out_mag=out)
+    assert torch.isfinite(out).all()
+    monkeypatch.setenv('PSND_STFT4096_V2', '1')
+    old = K.stft_forward(a, n_fft, hop, plan)['mag']
+    assert float((out - old).abs().max()) <= 8e-6 * float(old.max())
+    w = torch.from_numpy(ofe.analysis_window(n_fft)).to(dev).double()
+    for n in (0, 17, 31):
+        xp = torch.nn.functional.pad(a[n:n + 1].unsqueeze(1), (n_fft // 2, n_fft // 2), mode='reflect').squeeze(1).double()
+        fr = xp.unfold(-1, n_fft, hop) * w
+        rhs = n_fft * (fr * fr).sum(-1)
+        m2 = out[n:n + 1].double() ** 2
+        lhs = m2[:, 0] + m2[:, -1] + 2 * m2[:, 1:-1].sum(1)
+        assert float(((lhs - rhs).abs() / rhs.abs().clamp_min(1e-12)).max()) <= 2e-5
+
+
 @pytest.mark.parametrize('n_fft,hop,win,framing,N,T', [c for c in CASES if c[0] in (64, 256, 512, 1024, 2048)][:9] + N512_CASES + N2048_CASES[:3])
 def test_stft_reim_phase_vs_oracle(n_fft, hop, win, framing, N, T):
     wav = seeded_wav(3 * n_fft + T, N, T)
