@@ -16,8 +16,8 @@
 //   * no workgroup barrier inside the transform - the only exchanges are wave-private (a v_permlane32_swap round, one 32 x 32
 //     transpose per half-wave through an 8.4 KB LDS buffer of the wave, 32 ds_bpermute for the real-FFT partners) - so the 16
 //     waves drift apart and their load / butterfly / LDS phases overlap freely;
-//   * the magnitudes of the 16 frames meet in an LDS staging tile [16 frames][bins] (two halves of 1024 / 1025 bins, 65.8 KB,
-//     aliased onto the exchange buffers, which are idle by then) and leave as 64-byte runs: 16 rows x 64 B per store instruction;
+//   * the magnitudes of the 16 frames meet in an LDS staging tile [16 frames][2049 bins] (131 KB, aliased onto the exchange buffers,
+//     which are idle by then) and leave as 64-byte runs: 16 rows x 64 B per store instruction;
 //   * the samples of the NEXT tile are requested into the dead data registers right after the split, i.e. ahead of this tile's
 //     stores in the in-order vector-memory queue, and travel during the staging / store phases.
 //
@@ -47,11 +47,11 @@ using namespace psnd_stft;
 
 constexpr int kC = 2048, kNFFT = 4096, kK = 2049;
 constexpr int kFrames = 16;                       // frames per workgroup = waves per workgroup
-constexpr int kStgP = 1028;                       // staging pitch per frame (floats): 4 P = 16 (mod 32) keeps the flush reads conflict-free
+constexpr int kStgP = 2052;                       // staging pitch per frame (floats, 2049 bins): 4 P = 16 (mod 32) keeps the flush reads conflict-free
 constexpr int kXP = 33;                           // exchange row pitch (complex values)
 constexpr int kXaFloats = 32 * kXP * 2;           // one wave's exchange buffer (one half-wave at a time)
 constexpr int kLdsFloats = 4096 + 2048 + kFrames * kXaFloats + 260;      // window | inter-pass twiddles | exchange / staging | cL, v_c per lane
-static_assert(kFrames * kXaFloats >= kFrames * kStgP + kFrames * 1025, "staging tile + parked upper halves must fit the exchange area");
+static_assert(kFrames * kXaFloats >= kFrames * kStgP, "the staging tile [16 frames][2049 bins] must fit the exchange area");
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
 
 struct WParams {
@@ -345,8 +345,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
         float *srow = s_xa + w * kStgP;               // this wave's row of the staging tile
         // staging positions: row r sits at pi(r) = r ^ bit 5 of r (bank spread); adding multiples of 64 commutes with pi
         float *slo = srow + stg_pi(cl2);                                             // row c;            row 64 j + c at slo[64 j]
-        float *shi = srow + stg_pi(1024 - cl2) - 64 * 15;                            // row 1024 - c - 64 j at shi[64 (15 - j)]
-        float *park = s_xa + kFrames * kStgP + w * 1025 + ln;                        // [16][64 lanes] + 1 per wave, behind the staging tile
+        float *shi = srow + stg_pi(2048 - cl2) - 64 * 15;                            // row 2048 - c - 64 j at shi[64 (15 - j)]
         const int rr = ln & 15, fq = ln >> 4;                                        // flush: row within a group of 16, quad of frames
         const float *fsrc0 = s_xa + (4 * fq) * kStgP + rr, *fsrc1 = s_xa + (4 * fq) * kStgP + (rr ^ 1);
         const unsigned fdst = (unsigned)rr * (unsigned)p.F + 4u * (unsigned)fq;      // element offset of the lane inside a 16-row store
@@ -391,30 +390,16 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
         PSND_W_STAMP(6);
         if (had) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) slo[64 * j] = mlo[j];                        // row 64 j + c at pi(64 j + c) = 64 j + pi(c)
-            // the upper-half magnitudes wait in the part of the exchange area the staging tile does not cover: the registers are
-            // free for the next tile's samples
+            for (int j = 0; j < 16; ++j) slo[64 * j] = mlo[j];                        // bin 64 j + c at pi(64 j + c) = 64 j + pi(c)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) park[64 * j] = mhi[j];
-            if (special) park[1024] = mext;       // (lane 0: park + 1024 is the wave's 1025th slot)
+            for (int j = 0; j < 16; ++j) shi[64 * (15 - j)] = mhi[j];                 // bin 2048 - 64 j - c
+            if (special) srow[1024] = mext;                                          // bin 1024 (pi(1024) = 1024)
         }
         PSND_W_STAMP(7);
         __syncthreads();
         PSND_W_STAMP(8);
-        flush(1024, 0);                           // bins 0 .. 1023
+        flush(kK, 0);                             // all 2049 bins: the whole spectrum of the 16 frames fits the exchange area (131 KB)
         PSND_W_STAMP(9);
-        __syncthreads();
-        PSND_W_STAMP(10);
-        if (had) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) shi[64 * (15 - j)] = park[64 * j];           // bin 2048 - 64 j - c as row 1024 - c - 64 j
-            if (special) srow[0] = park[1024];                                       // bin 1024
-        }
-        PSND_W_STAMP(11);
-        __syncthreads();
-        PSND_W_STAMP(12);
-        flush(1025, 1024);                        // bins 1024 .. 2048
-        PSND_W_STAMP(13);
         __syncthreads();                          // staging reads done: the exchange buffers are free again
         PSND_W_STAMP(14);
         if (nkind == 2) request_edge(nx, ns0);    // (rare) needs the wave's exchange buffer

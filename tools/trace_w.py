@@ -19,12 +19,14 @@ for _ in range(3):
     check(lib().psnd_stft_fwd(ptr(wav), N, T, n, h, 0, ptr(plan), 0.0, ptr(mag), None, None, None, stream_ptr(dev)), 'stft')
 torch.cuda.synchronize()
 tr = trace.cpu().numpy().reshape(256, 16, 16)
-names = ['top', 'win+r2+swap', 'fft1+tw', 'transpose', 'fft2', 'split', 'B1', 'stage lo+park+prefetch', 'B2', 'flush lo', 'B3',
-         'stage hi', 'B4', 'flush hi', 'B5']
+names = ['top', 'win+r2+swap', 'fft1+tw', 'transpose', 'fft2', 'split', 'B1 (next loads issued)', 'stage', 'B2', 'flush', None, None, None, None, 'B3']
+use = [i for i, n in enumerate(names) if n]
 for b in (0, 9, 100):
     t = tr[b].astype(np.float64)
     t0 = t[:, 0].min()
     print('block', b, ': stamps relative to the earliest wave top, in ticks (10 ns) - mean over waves / min / max')
-    for i in range(15):
+    prev = None
+    for i in use:
         d = t[:, i] - t0
-        print('  %-26s %8.0f %8.0f %8.0f    phase mean %7.0f' % (names[i], d.mean(), d.min(), d.max(), (t[:, i] - t[:, i - 1]).mean() if i else 0))
+        print('  %-26s %8.0f %8.0f %8.0f    phase mean %7.0f' % (names[i], d.mean(), d.min(), d.max(), (t[:, i] - t[:, prev]).mean() if prev is not None else 0))
+        prev = i
