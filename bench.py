@@ -348,7 +348,9 @@ def _config5_roofline(device, n_fft=4096, hop=1024, clips=32, seconds=30.0, sr=4
     torch.cuda.synchronize()
     t = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
     b = 4 * clips * T + 4 * clips * Kb * Fr
-    return {'bound': 'hbm', 'kernel': 'stft_fwd_n4096b_kernel (wav -> magnitude, 4096/1024)', 'achieved': b / t / 1e9,
+    kern = ('stft_fwd_n4096w_kernel (one wave per frame, 16 frames per workgroup, 64-byte store runs)' if clips * ((Fr + 15) // 16) >= 2048
+            else 'stft_fwd_n4096b_kernel (4 frames per workgroup)')
+    return {'bound': 'hbm', 'kernel': kern + ': wav -> magnitude, 4096/1024', 'achieved': b / t / 1e9,
             'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': _pmc_traffic('n4096'),
             'traffic_source': _pmc_traffic('n4096', 'source'), 'bytes_per_launch': b,
             'launch_us': t * 1e6, 'launches_timed': len(evs) - 3,

@@ -182,6 +182,11 @@ _SECTION_STREAMS = {}
 # stream that lands on the queue of such a graph branch waits behind its kernels (measured with two sections: prefetch_copy step 1.21 ->
 # 2.9 ms in one run of three).  The Trainer clears the flag when it starts a prefetch stream or a gradient reducer.
 AUTO_SECTIONS = True
+# 'body': a conv chain (the separator's conv_pre + blocks + conv_post) is ONE autograd node with ONE weight-norm backward launch at its
+# end - fewest launches, but every parameter gradient then appears at the very end of the backward.  'block': one node (and one
+# weight-norm backward) per residual block - the gradients arrive block by block, which is what lets the gradient all-reduce of a
+# data-parallel run overlap the backward (Trainer switches to it when a FlatGradReducer over more than one rank is active).
+NODE_GRANULARITY = 'body'
 
 
 def _sections(dev, N, rows):
@@ -825,7 +830,8 @@ def conv_body_cl(head, blocks, tail, x0, shape, prep=None):
     x0: activated CL input of the head conv.  Returns the tail conv's raw output."""
     import os
     stack = [c for b in blocks for pair in zip(b.convs1, b.convs2) for c in pair]
-    if os.environ.get('PSND_NO_BODY_NODE') == '1' or os.environ.get('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled():
+    if (os.environ.get('PSND_NO_BODY_NODE') == '1' or os.environ.get('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled()
+            or NODE_GRANULARITY == 'block'):
         x, xa = fused_conv(x0, head, shape, None, True, True, 0.1, prep)
         x, xa = resblock1_stack_cl(blocks, x, xa, shape, prep=prep)
         return fused_conv(xa, tail, shape, None, True, False, prep=prep)[0]
@@ -862,7 +868,7 @@ def resblock1_stack_cl(blocks, x, xa, shape, last_act_slope=0.1, want_raw=True, 
 
 def _stack_enabled():
     import os
-    return os.environ.get('PSND_NO_BLOCK_STACK') != '1'        # A/B switch: one node per block instead
+    return os.environ.get('PSND_NO_BLOCK_STACK') != '1' and NODE_GRANULARITY != 'block'       # one node per block instead
 
 
 def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):

@@ -11,9 +11,10 @@ FlatGradReducer
     keeps producing the next bucket;
   * ``finish()`` (called before clip_grad / optimizer.step) waits for the outstanding collectives
     and scales by 1/world.
-Bucket size: gradients here are small (hifi_gan_v1 55.7 MB fp32, v2 3.7 MB): xGMI rings are
-per-link bound (~153 GB/s/link), so latency, not bandwidth, dominates -> few large buckets
-(default 32 MiB) rather than DDP's 25 MB chunks per layer group.
+Bucket size: gradients here are small (hifi_gan_v1 55.7 MB fp32, the config-2 separator 22 MB, v2 3.7 MB):
+xGMI rings are per-link bound (~153 GB/s/link), so latency, not bandwidth, dominates -> few large
+buckets, but more than one: by default about six per model (`auto_bucket_bytes`: whole MiB, 1..32 MiB),
+so that all but the last sixth of the reduction can run under the backward.
 """
 import collections
 import os
@@ -109,7 +110,7 @@ class FlatGradReducer:
                  together when a capture with one of the other modes fails on any rank - Trainer._capture)
     """
 
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, force: bool = False):
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = None, force: bool = False):
         self.world = world_size()
         self.active = self.world > 1 or force   # force: single-rank process group (tests the collective plumbing on one GPU)
         self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
@@ -126,6 +127,9 @@ class FlatGradReducer:
         self._bucket_of = {}
         self._handles = []
         order = list(reversed(self.params))
+        if bucket_bytes is None:
+            bucket_bytes = self.auto_bucket_bytes(sum(p.numel() * 4 for p in order))
+        self.bucket_bytes = bucket_bytes
         groups, cur, cur_bytes = [], [], 0
         for p in order:
             nbytes = p.numel() * 4
@@ -160,6 +164,16 @@ class FlatGradReducer:
         if self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    @staticmethod
+    def auto_bucket_bytes(total_bytes: int, target_buckets: int = 6) -> int:
+        """bucket size when none is given: about `target_buckets` buckets per model, whole MiB, between 1 and 32 MiB.  One 32 MiB bucket
+        holds ALL 22 MB of the config-2 separator's gradients - its all-reduce could not start before the last gradient of the
+        backward exists, i.e. no overlap at all; six buckets leave one sixth of the reduction exposed.  Below 1 MiB the per-collective
+        latency of RCCL (~20-30 us over xGMI) outweighs what the overlap returns."""
+        mib = 1 << 20
+        per = -(-total_bytes // target_buckets)
+        return int(min(32 * mib, max(mib, -(-per // mib) * mib)))
 
     # gradients must stay views of the flat buffers: zero in place instead of dropping them
     def zero_grad(self):

@@ -187,6 +187,9 @@ class Trainer:
         if pdist.is_dist() or force:                   # force: a one-rank process group still runs the whole reducer path
             pdist.broadcast_module(self._bare_model)
             self._reducer = pdist.FlatGradReducer(self._bare_model, force=force)
+            if pdist.is_dist() and self.ddp_block_granularity:
+                from pytorch_sound_amd import cl
+                cl.NODE_GRANULARITY = 'block'
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -209,6 +212,13 @@ class Trainer:
         that runs eagerly BEFORE forward() - in graph mode it stays outside the captured graph, so its kernels can
         be timed individually and it may change shapes from step to step.  Returns the inputs of forward()."""
         return inputs
+
+    # (not in the reference) data-parallel runs: one weight-norm backward per residual block instead of one per conv chain
+    # (cl.NODE_GRANULARITY = 'block'), so that the parameter gradients ARRIVE over the course of the backward and the all-reduce of
+    # the early buckets overlaps it.  Off by default: on one GPU it costs 24 % of the config-2 step (0.81 -> 1.00 ms: the chained pair
+    # backward launches are per-block then), about what hiding ~5/6 of a 22 MB all-reduce over xGMI returns (DESIGN 7); set it
+    # before constructing the Trainer when the interconnect is slower than that.
+    ddp_block_granularity = False
 
     # (not in the reference) stage the NEXT training batch - host->device copy and prepare() - on a side stream while the
     # current step computes; the step's stream waits on an event, never the host.  prepare() must then be parameter-free

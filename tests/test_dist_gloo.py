@@ -123,6 +123,28 @@ def test_flat_reducer_load_grads_and_alignment():
     red.finish()                                              # world 1: a no-op
 
 
+def test_auto_bucket_size_gives_the_backward_something_to_overlap():
+    """no bucket size given: about six buckets per model (whole MiB, 1..32 MiB) - a single 32 MiB bucket would hold all 22 MB of the
+    config-2 separator's gradients, whose all-reduce could then only start after the last gradient of the backward"""
+    from pytorch_sound_amd.distributed import FlatGradReducer
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    import pytorch_sound_amd.models.vocoders.hifi_gan  # noqa: F401
+    mib = 1 << 20
+    assert FlatGradReducer.auto_bucket_bytes(22 * mib) == 4 * mib
+    assert FlatGradReducer.auto_bucket_bytes(56 * mib) == 10 * mib
+    assert FlatGradReducer.auto_bucket_bytes(100) == mib and FlatGradReducer.auto_bucket_bytes(1 << 40) == 32 * mib
+    sep = build_model('conv_separator_voicebank')
+    red = FlatGradReducer(sep)
+    total = sum(p.numel() * 4 for p in sep.parameters())
+    assert red.bucket_bytes == FlatGradReducer.auto_bucket_bytes(total)
+    assert 5 <= len(red.buckets) <= 8, len(red.buckets)
+    # reverse registration order: the first bucket holds conv_post (the first gradients of the backward), the last conv_pre
+    first = {id(p) for p in red.buckets[0]['params']}
+    assert id(sep.conv_post.bias) in first and id(sep.conv_pre.weight_v) in {id(p) for p in red.buckets[-1]['params']}
+    red.remove()
+
+
 def _flag_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
