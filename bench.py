@@ -61,7 +61,7 @@ def synth_batch(seed, n, t, device):
     return (both.to(device),)
 
 
-def build_step(device, amp, static=True, cpu_frontend='port'):
+def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
     """returns (trainer_cls, model) for the config-2 step on `device`.  static: the features go into persistent buffers that the step
     graph reads in place (Trainer.static_prepare) - off when prepare() runs one step ahead on a side stream (--prefetch).
     cpu_frontend (CPU baseline leg only): 'port' = the reference's dense-DFT conv1d STFT, 'torch_stft' = its torch.stft class."""
@@ -124,6 +124,12 @@ def build_step(device, amp, static=True, cpu_frontend='port'):
             return mag_mix, mag_ref, mel_ref
 
         def forward(self, mag_mix, mag_ref, mel_ref, is_logging=False):
+            if gpu and fused_loss:
+                # mask head + both L1 terms as one node: 4 launches forward, 2 backward (cl.MaskHeadSpectralL1CL)
+                with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+                    loss, _ = self.model.spectral_l1_loss(mag_mix, mag_ref, mel_ref, fe._mel_plan(), N_MEL, 1.0, 0.5, 1e-6, fe.min_db,
+                                                          fe.max_db)
+                return loss, {'loss': (loss, LogType.SCALAR)}
             if amp:
                 with torch.autocast('cuda', dtype=torch.bfloat16):
                     est = self.model(mag_mix)
@@ -155,7 +161,7 @@ def gpu_bench(args):
     T = int(SR * CLIP_SECONDS)
     N = BATCH_PER_GPU
 
-    Trainer, model = build_step(device, amp=True, static=not args.prefetch)
+    Trainer, model = build_step(device, amp=True, static=not args.prefetch, fused_loss=not args.unfused_loss)
     from pytorch_sound_amd import optim as poptim
     # torch.optim.Adam semantics as one HIP launch (psnd_adam_step); --torch-adam keeps torch's fused multi-tensor kernel
     opt = (torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True) if args.torch_adam
@@ -516,6 +522,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='CPU baseline budget (60 %% dense-DFT port, 40 %% torch.stft variant)')
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
     ap.add_argument('--prefetch', action='store_true', help='stage the next batch (copy + feature extraction) on a side stream')
+    ap.add_argument('--unfused-loss', action='store_true', help='the loss as separate nodes (mask head, mel, two L1 terms) instead of the fused one')
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
     args = ap.parse_args()
     if not torch.cuda.is_available():

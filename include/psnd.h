@@ -176,6 +176,25 @@ int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const
 /* host-side launch counters of the conv kernels' tile instances: out4 = { forward / input-gradient launches with 64-row
  * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
  * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */
+/* ---- a spectral-masking recipe's loss without its intermediate tensors (round 3):
+ *      w1 * F.l1_loss(est, mag_ref) + w2 * F.l1_loss(log_mel(est), mel_ref),  est = sigmoid(from_cl(y)) * mag
+ *  psnd_mask_head_l1_fwd : psnd_mask_head_fwd + part[b] = sum |est - ref| of workgroup b (psnd_mask_head_l1_blocks doubles)
+ *  psnd_mel_l1_fwd       : psnd_mel_fwd that writes only the linear mel + part[w] = sum |log_mel - ref| of wave w (psnd_mel_l1_blocks)
+ *  psnd_l1_loss_combine  : out[0] = sum_i scale[i] * sum(parts[i]), scale = weight / numel (host arrays of <= 4 device pointers)
+ *  psnd_mel_l1_bwd       : gmag = W^T (coef * g[0] * sign(log_mel - ref) * dlog) with the sign formed on operand load (g: device scalar)
+ *  psnd_mask_head_l1_bwd : psnd_mask_head_bwd on gest (may be NULL) + coef * g[0] * sign(est - ref)                              */
+int64_t psnd_mask_head_l1_blocks(int64_t N, int64_t T, int Cp);
+int psnd_mask_head_l1_fwd(const void *y, const float *mag, const float *ref, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
+                          float *est, double *part, void *stream);
+int psnd_mask_head_l1_bwd(const float *gest, const float *mag, const void *y, const float *est, const float *ref, const float *g,
+                          float coef, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, void *gy, void *stream);
+int64_t psnd_mel_l1_blocks(int64_t N, int64_t F, int M);
+int psnd_mel_l1_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                    float pre_clamp_min, float clamp_lo, float clamp_hi, const float *ref, float *mel_lin, double *part, void *stream);
+int psnd_mel_l1_bwd(const float *ref, const float *mel_lin, const float *g, float coef, int64_t N, int64_t F, int M, int K,
+                    const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                    float *gmag, void *stream);
+int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream);
 int psnd_conv_stats(int64_t *out4, int reset);
 /* the same for the residual-pair launches: out4 = { psnd_conv1d_cl_pair launches with 32-row tiles, with 64-row tiles,
  * psnd_conv1d_cl_pair_bwd launches that carried a pair, weight-gradient row ranges of the last psnd_conv1d_cl_pair_bwd launch }. */

@@ -55,6 +55,13 @@ SIGNATURES = {
     'psnd_conv1d_wnorm_bwd_multi': (_INT, [_P, _INT, _P]),
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
+    'psnd_mask_head_l1_blocks': (_I64, [_I64, _I64, _INT]),
+    'psnd_mask_head_l1_fwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P, _P]),
+    'psnd_mask_head_l1_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _F, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
+    'psnd_mel_l1_blocks': (_I64, [_I64, _I64, _INT]),
+    'psnd_mel_l1_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P, _P]),
+    'psnd_mel_l1_bwd': (_INT, [_P, _P, _P, _F, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
+    'psnd_l1_loss_combine': (_INT, [_P, _P, _P, _INT, _P, _P]),
     'psnd_conv_stats': (_INT, [_P, _INT]),
     'psnd_conv_pair_stats': (_INT, [_P, _INT]),
     'psnd_convtr1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),

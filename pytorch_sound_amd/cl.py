@@ -125,6 +125,66 @@ class MaskHeadCL(torch.autograd.Function):
         return gy, None, None
 
 
+class MaskHeadSpectralL1CL(torch.autograd.Function):
+    """w1 * F.l1_loss(est, mag_ref) + w2 * F.l1_loss(log_mel(est), mel_ref) with est = sigmoid(from_cl(y)) * mag - a masking recipe's
+    loss as ONE autograd node over four launches forward (mask head with the first term's partial sums, mel projection with the second
+    term's, one combine) and two backward (the mel adjoint forms sign(log_mel - ref) on operand load; the mask head's backward adds
+    sign(est - ref) itself).  The separate formulation (MaskHeadCL + MelLog + l1_loss_sum) takes five launches forward and five
+    backward and materialises log_mel(est), two gradient tensors and their sum.  Returns (loss, est); est carries no gradient of its own
+    (it is there for logging / metrics)."""
+
+    @staticmethod
+    def forward(ctx, y, mag, mag_ref, mel_ref, mel_plan, shape, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, w1, w2):
+        import ctypes
+        from .kernels import _clamp_args
+        _need(y, torch.bfloat16)
+        for t in (mag, mag_ref, mel_ref):
+            _need(t, torch.float32)
+        N, C, T = mag.shape
+        if mag_ref.shape != mag.shape or tuple(mel_ref.shape) != (N, M, T):
+            raise _lib.PsndError('mask_head_spectral_l1: mag_ref %s / mel_ref %s do not match mag %s and %d mel bands'
+                                 % (tuple(mag_ref.shape), tuple(mel_ref.shape), tuple(mag.shape), M))
+        dev = y.device
+        lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+        est = torch.empty_like(mag)
+        lin = torch.empty((N, M, T), dtype=torch.float32, device=dev)
+        nb1 = int(lib().psnd_mask_head_l1_blocks(N, T, y.shape[2]))
+        nb2 = int(lib().psnd_mel_l1_blocks(N, T, M))
+        part = torch.empty(nb1 + nb2, dtype=torch.float64, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        st = stream_ptr(dev)
+        with torch.cuda.device(dev):
+            check(lib().psnd_mask_head_l1_fwd(ptr(y), ptr(mag), ptr(mag_ref), N, C, T, shape.Lp, shape.HP, y.shape[2], ptr(est),
+                                              ptr(part), st), 'psnd_mask_head_l1_fwd')
+            p2 = ctypes.c_void_p(part.data_ptr() + 8 * nb1)
+            check(lib().psnd_mel_l1_fwd(ptr(est), N, T, M, C, ptr(mel_plan), log_kind, float(log_offset), pre, lo, hi, ptr(mel_ref),
+                                        ptr(lin), p2, st), 'psnd_mel_l1_fwd')
+            parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
+            nbs = (ctypes.c_int64 * 2)(nb1, nb2)
+            sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
+            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), st), 'psnd_l1_loss_combine')
+        ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())
+        ctx.save_for_backward(y, mag, mag_ref, mel_ref, mel_plan, est, lin)
+        ctx.mark_non_differentiable(est)
+        return out, est
+
+    @staticmethod
+    def backward(ctx, g, _gest):
+        y, mag, mag_ref, mel_ref, mel_plan, est, lin = ctx.saved_tensors
+        shape, M, log_kind, log_offset, pre, lo, hi, c1, c2 = ctx.cfg
+        N, C, T = mag.shape
+        g = g.contiguous().float()
+        gest = torch.empty_like(mag)
+        gy = torch.empty_like(y)
+        st = stream_ptr(y.device)
+        with torch.cuda.device(y.device):
+            check(lib().psnd_mel_l1_bwd(ptr(mel_ref), ptr(lin), ptr(g), c2, N, T, M, C, ptr(mel_plan), log_kind, log_offset, pre, lo, hi,
+                                        ptr(gest), st), 'psnd_mel_l1_bwd')
+            check(lib().psnd_mask_head_l1_bwd(ptr(gest), ptr(mag), ptr(y), ptr(est), ptr(mag_ref), ptr(g), c1, N, C, T, shape.Lp, shape.HP,
+                                              y.shape[2], ptr(gy), st), 'psnd_mask_head_l1_bwd')
+        return (gy,) + (None,) * 13
+
+
 def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, off0, dstep, act_slope, mask_slope,
                  want_raw, want_act, a_eff_out=None):
     dev = W.device

@@ -442,9 +442,11 @@ __global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_cl_ker
 // ---- layout conversion: (N, C, T) fp32  <->  CL bf16 (N, Lp, Cp) with zero halo rows / padded channels ----
 // to_cl: optional pre-op  0: none, 1: log1p(x)
 // MASKBWD: the backward of the mask head below: out = x * mul * s * (1 - s), s = sigmoid(ycl) read at the output position
+// MASKBWD with l1_est: x (may be NULL) + coef * g[0] * sign(est - ref) is the gradient on the mask head's output (fused F.l1_loss(est, ref))
 template <bool MASKBWD>
 __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out, int N, int C, int T, int Lp, int HP, int Cp,
-                                                    int preop, const float *mul, const bf16_t *ycl) {
+                                                    int preop, const float *mul, const bf16_t *ycl, const float *l1_est = nullptr,
+                                                    const float *l1_ref = nullptr, const float *l1_g = nullptr, float l1_coef = 0.f) {
     // tile 32 (t) x 32 (c) through LDS so both sides are coalesced
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
@@ -454,9 +456,16 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
         const int c = c0 + j, t = t0 + tx;
         float v = 0.f;
         if (c < C && t >= 0 && t < T) {
-            v = x[((size_t)n * C + c) * T + t];
+            const size_t o = ((size_t)n * C + c) * T + t;
+            v = x ? x[o] : 0.f;
             if (preop == 1) v = log1pf(v);
-            if constexpr (MASKBWD) v *= mul[((size_t)n * C + c) * T + t];
+            if constexpr (MASKBWD) {
+                if (l1_est) {
+                    const float d = l1_est[o] - l1_ref[o];
+                    v += l1_coef * l1_g[0] * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+                }
+                v *= mul[o];
+            }
         }
         tile[j][tx] = v;
     }
@@ -475,9 +484,10 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
 }
 
 // from_cl: (N, Lp, Cp) bf16 -> (N, C, T) fp32.   MASK: the separator's mask head, out = sigmoid(x) * mul
+// MASK with l1_ref: also part[block] = sum |out - ref| of the block (double; fused F.l1_loss(est, ref))
 template <bool MASK>
 __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp,
-                                                      const float *mul) {
+                                                      const float *mul, const float *l1_ref = nullptr, double *l1_part = nullptr) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = blockIdx.z;
@@ -490,12 +500,25 @@ __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *ou
         tile[j][tx] = v;
     }
     __syncthreads();
+    float l1acc = 0.f;
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, t = t0 + tx;
         if (c < C && t < T) {
             const size_t o = ((size_t)n * C + c) * T + t;
-            out[o] = MASK ? tile[tx][j] * mul[o] : tile[tx][j];
+            const float v = MASK ? tile[tx][j] * mul[o] : tile[tx][j];
+            out[o] = v;
+            if (MASK && l1_ref) l1acc += fabsf(v - l1_ref[o]);
         }
+    }
+    if (MASK && l1_part) {
+        double d = (double)l1acc;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
+        __shared__ double red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            l1_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -1380,6 +1403,36 @@ extern "C" int psnd_mask_head_fwd(const void *y, const float *mag, int64_t N, in
     hipLaunchKernelGGL(from_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(y), est,
                        (int)N, C, (int)T, Lp, HP, Cp, mag);
     PSND_CHECK_LAUNCH("mask_head_fwd");
+    return PSND_OK;
+}
+
+// the same head with F.l1_loss(est, ref) folded in: forward also leaves sum |est - ref| per workgroup in part[psnd_mask_head_l1_blocks]
+// (double; fold with psnd_l1_loss_combine); backward takes the gradient on est from elsewhere (gest, may be NULL) PLUS
+// coef * g[0] * sign(est - ref) (g: device scalar = gradient of the loss value, coef = weight / numel)
+extern "C" int64_t psnd_mask_head_l1_blocks(int64_t N, int64_t T, int Cp) {
+    if (N <= 0 || T <= 0 || Cp <= 0) return 0;
+    return N * ((T + 31) / 32) * ((Cp + 31) / 32);
+}
+extern "C" int psnd_mask_head_l1_fwd(const void *y, const float *mag, const float *ref, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
+                                     float *est, double *part, void *stream) {
+    if (!y || !mag || !ref || !est || !part) PSND_FAIL(PSND_E_ARG, "mask_head_l1_fwd: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_fwd: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(from_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(y), est,
+                       (int)N, C, (int)T, Lp, HP, Cp, mag, ref, part);
+    PSND_CHECK_LAUNCH("mask_head_l1_fwd");
+    return PSND_OK;
+}
+extern "C" int psnd_mask_head_l1_bwd(const float *gest, const float *mag, const void *y, const float *est, const float *ref, const float *g,
+                                     float coef, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, void *gy, void *stream) {
+    if (!mag || !y || !est || !ref || !g || !gy) PSND_FAIL(PSND_E_ARG, "mask_head_l1_bwd: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_bwd: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(to_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), gest, static_cast<bf16_t *>(gy), (int)N, C,
+                       (int)T, Lp, HP, Cp, 0, mag, static_cast<const bf16_t *>(y), est, ref, g, coef);
+    PSND_CHECK_LAUNCH("mask_head_l1_bwd");
     return PSND_OK;
 }
 

@@ -317,6 +317,22 @@ extern "C" int psnd_l1_loss_bwd_w(const float *a, const float *b, int64_t n, con
     return PSND_OK;
 }
 
+// out[0] = sum_i scale[i] * sum(parts[i][0 .. nb[i])): folds the partial sums that fused producers leave (psnd_mask_head_l1_fwd,
+// psnd_mel_l1_fwd, psnd_l1_loss_fwd's own partials) into one loss value; scale[i] = weight_i / numel_i; 1 .. 4 terms
+extern "C" int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream) {
+    if (!parts || !nb || !scale || !out) PSND_FAIL(PSND_E_ARG, "l1_loss_combine: null pointer");
+    if (terms < 1 || terms > 4) PSND_FAIL(PSND_E_SHAPE, "l1_loss_combine: 1 .. 4 terms, got %d", terms);
+    L1Terms t;
+    t.terms = terms;
+    for (int k = 0; k < terms; ++k) {
+        if (!parts[k] || nb[k] <= 0 || nb[k] > 0x7fffffff) PSND_FAIL(PSND_E_ARG, "l1_loss_combine: term %d: null partials / nb=%lld", k, (long long)nb[k]);
+        t.part[k] = parts[k], t.nb[k] = (int)nb[k], t.scale[k] = scale[k];
+    }
+    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), t, out);
+    PSND_CHECK_LAUNCH("l1_loss_combine");
+    return PSND_OK;
+}
+
 extern "C" int psnd_l1_loss_sum_fwd(const float *const *a, const float *const *b, const int64_t *n, const double *w, int terms, double *part,
                                     float *out, void *stream) {
     if (!a || !b || !n || !w || !part || !out) PSND_FAIL(PSND_E_ARG, "l1_loss_sum_fwd: null pointer");

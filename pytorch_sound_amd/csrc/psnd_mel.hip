@@ -45,6 +45,12 @@ struct MelParams {
     int nft;            // 64-frame tiles per clip
     int log_kind;
     float log_offset, pre_clamp_min, clamp_lo, clamp_hi;
+    // fused F.l1_loss(log_mel, ref) (psnd_mel_l1_fwd / _bwd): forward adds sum |y - ref| of the wave to l1_part[wave] (double) and writes only
+    // the linear mel; backward forms the incoming gradient coef * g[0] * sign(y - ref) on operand load (in0 = ref, in1 = mel_lin)
+    const float *l1_ref;
+    double *l1_part;
+    const float *l1_g;
+    float l1_coef;
 };
 
 // derivative of the forward epilogue wrt mel (0 where any clamp is active; matches autograd of
@@ -69,6 +75,28 @@ __device__ __forceinline__ float log_grad(float mel, int kind, float off, float 
     return pass * d;
 }
 
+// gradient of  coef * sum |y - ref|  wrt the linear mel: sign(y - ref) * dy/dmel, y = the forward epilogue of mel (0 where a clamp is active)
+__device__ __forceinline__ float l1_log_grad(float mel, float ref, int kind, float off, float pre, float lo, float hi) {
+    float pass = 1.f, v = mel;
+    if (pre >= 0.f) {
+        if (v < pre) pass = 0.f;
+        v = fmaxf(v, pre);
+    }
+    v += off;
+    float y = v, d = 1.f;
+    if (kind == PSND_LOG_E) {
+        y = logf(v);
+        d = 1.f / v;
+    } else if (kind == PSND_LOG_10) {
+        y = log10f(v);
+        d = 0.43429448190325182765f / v;
+    }
+    if (y < lo || y > hi) pass = 0.f;
+    y = fminf(fmaxf(y, lo), hi);
+    const float sg = y > ref ? 1.f : (y < ref ? -1.f : 0.f);
+    return sg * pass * d;
+}
+
 template <bool BWD>
 __device__ __forceinline__ f32x4 load_b(const MelParams &p, const float *in0, const float *in1, int c, long long f,
                                         long long F) {
@@ -79,6 +107,14 @@ __device__ __forceinline__ f32x4 load_b(const MelParams &p, const float *in0, co
         v = *reinterpret_cast<const f32x4_u *>(in0 + o);
         if constexpr (BWD) {
             const f32x4 m = *reinterpret_cast<const f32x4_u *>(in1 + o);
+            if (p.l1_g) {                                                  // uniform: in0 is the L1 target
+                const float c = p.l1_coef * p.l1_g[0];
+                v.x = c * l1_log_grad(m.x, v.x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                v.y = c * l1_log_grad(m.y, v.y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                v.z = c * l1_log_grad(m.z, v.z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                v.w = c * l1_log_grad(m.w, v.w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                return v;
+            }
             v.x *= log_grad(m.x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
             v.y *= log_grad(m.y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
             v.z *= log_grad(m.z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
@@ -89,8 +125,10 @@ __device__ __forceinline__ f32x4 load_b(const MelParams &p, const float *in0, co
         for (int j = 0; j < 4; ++j)
             if (f + j < F) {
                 t[j] = in0[o + j];
-                if constexpr (BWD)
-                    t[j] *= log_grad(in1[o + j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                if constexpr (BWD) {
+                    if (p.l1_g) t[j] = p.l1_coef * p.l1_g[0] * l1_log_grad(in1[o + j], t[j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    else t[j] *= log_grad(in1[o + j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                }
             }
         v.x = t[0], v.y = t[1], v.z = t[2], v.w = t[3];
     }
@@ -139,6 +177,7 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
     }
     // D layout: col = lane&15 (-> frames f..f+3 across acc0..3), row = 4*(lane>>4) + reg
     const size_t obase = (size_t)clip * p.R * F;
+    float l1acc = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * rt + 4 * kk + r;
@@ -152,6 +191,22 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
             y.w = fminf(fmaxf(log_apply(v.w, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
         }
         const size_t o = obase + (size_t)row * F + f;
+        if constexpr (!BWD) {
+            if (p.l1_ref) {                                                // fused L1 against ref: the log-mel itself is not written
+                if (f + 3 < F) {
+                    const f32x4 rf = *reinterpret_cast<const f32x4_u *>(p.l1_ref + o);
+                    l1acc += fabsf(y.x - rf.x) + fabsf(y.y - rf.y) + fabsf(y.z - rf.z) + fabsf(y.w - rf.w);
+                    *reinterpret_cast<f32x4_u *>(p.lin + o) = v;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (f + j < F) {
+                            l1acc += fabsf(y[j] - p.l1_ref[o + j]);
+                            p.lin[o + j] = v[j];
+                        }
+                }
+                continue;
+            }
+        }
         if (f + 3 < F) {
             *reinterpret_cast<f32x4_u *>(p.out + o) = y;
             if (!BWD && p.lin) *reinterpret_cast<f32x4_u *>(p.lin + o) = v;
@@ -161,6 +216,14 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
                     p.out[o + j] = y[j];
                     if (!BWD && p.lin) p.lin[o + j] = v[j];
                 }
+        }
+    }
+    if constexpr (!BWD) {
+        if (p.l1_part) {
+            double d = (double)l1acc;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
+            if (lane == 0) p.l1_part[wid] = d;
         }
     }
 }
@@ -236,8 +299,9 @@ extern "C" int psnd_mel_plan_build(int M, int K, const float *W, void *plan_host
 
 static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, int64_t F, int M, int K,
                       const void *plan, int log_kind, float log_offset, float pre, float lo, float hi,
-                      float *out, float *lin, void *stream) {
-    if (!in0 || !plan || !out || (bwd && !in1)) PSND_FAIL(PSND_E_ARG, "mel: null pointer");
+                      float *out, float *lin, void *stream, const float *l1_ref = nullptr, double *l1_part = nullptr,
+                      const float *l1_g = nullptr, float l1_coef = 0.f) {
+    if (!in0 || !plan || (!out && !l1_ref) || (bwd && !in1)) PSND_FAIL(PSND_E_ARG, "mel: null pointer");
     if (M <= 0 || K <= 0 || N < 0 || F < 0) PSND_FAIL(PSND_E_SHAPE, "mel: M=%d K=%d N=%lld F=%lld", M, K, (long long)N, (long long)F);
     if (log_kind < PSND_LOG_NONE || log_kind > PSND_LOG_10) PSND_FAIL(PSND_E_ARG, "mel: log_kind=%d", log_kind);
     if (N == 0 || F == 0) return PSND_OK;
@@ -247,6 +311,7 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     p.F = F, p.N = (int)N;
     p.log_kind = log_kind, p.log_offset = log_offset, p.pre_clamp_min = pre, p.clamp_lo = lo, p.clamp_hi = hi;
     p.nft = (int)((F + 63) / 64);
+    p.l1_ref = l1_ref, p.l1_part = l1_part, p.l1_g = l1_g, p.l1_coef = l1_coef;
     if (!bwd) {
         p.R = M, p.Cc = K, p.RT = h.MT, p.CS = h.KS, p.band_off = 8, p.w_off = h.fw_off;
     } else {
@@ -274,4 +339,26 @@ extern "C" int psnd_mel_bwd(const float *gout, const float *mel_lin, int64_t N, 
                             float clamp_lo, float clamp_hi, float *gmag, void *stream) {
     return mel_launch(true, gout, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo,
                       clamp_hi, gmag, nullptr, stream);
+}
+
+// ---- F.l1_loss(log_mel(mag), ref) without the log-mel tensor: forward writes the linear mel (for the backward) and one partial sum of
+//      |y - ref| per wave (psnd_mel_l1_blocks of them, double; fold them with psnd_l1_loss_combine); backward forms the incoming gradient
+//      coef * g[0] * sign(y - ref) * dy/dmel while loading its operand (g: device scalar, the gradient of the loss value).
+extern "C" int64_t psnd_mel_l1_blocks(int64_t N, int64_t F, int M) {
+    if (N <= 0 || F <= 0 || M <= 0) return 0;
+    return N * ((F + 63) / 64) * ((M + 15) / 16);
+}
+extern "C" int psnd_mel_l1_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                               float pre_clamp_min, float clamp_lo, float clamp_hi, const float *ref, float *mel_lin, double *part,
+                               void *stream) {
+    if (!ref || !mel_lin || !part) PSND_FAIL(PSND_E_ARG, "mel_l1_fwd: null ref / mel_lin / part");
+    return mel_launch(false, mag, nullptr, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, nullptr, mel_lin,
+                      stream, ref, part);
+}
+extern "C" int psnd_mel_l1_bwd(const float *ref, const float *mel_lin, const float *g, float coef, int64_t N, int64_t F, int M, int K,
+                               const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                               float *gmag, void *stream) {
+    if (!g) PSND_FAIL(PSND_E_ARG, "mel_l1_bwd: null g");
+    return mel_launch(true, ref, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, gmag, nullptr,
+                      stream, nullptr, nullptr, g, coef);
 }

@@ -305,3 +305,45 @@ def test_separator_bench_shape_vs_bf16_emulation():
     compare(got, ref32, 5e-3, 0, 2e-2, 5e-2, 'bench path vs fp32')
     # the fused mask head and the layout-kernel head are the same function
     assert relf(got[0], got_gx[0]) <= 1e-6
+
+
+@pytest.mark.parametrize('N,T,channels', [(32, 173, 256), (3, 61, 64)])
+def test_fused_spectral_l1_loss_matches_separate_nodes(N, T, channels):
+    """ConvSeparator.spectral_l1_loss (cl.MaskHeadSpectralL1CL: mask head + L1(est, ref) + L1(log_mel(est), mel_ref) as one node, the
+    log-mel of the estimate and the gradient tensors never materialised) against the same loss composed from the separate nodes
+    (MaskHeadCL, MelLog, l1_loss_sum) and against plain torch on the estimate: value to 1e-6 relative, the logits' gradient to one
+    bf16 rounding, every parameter gradient to 2e-3 (the conv stack below is the same in both)."""
+    from pytorch_sound_amd import kernels as K
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    from pytorch_sound_amd.models.transforms import LogMelSpectrogram
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7 + T)
+    model = build_model('conv_separator_voicebank', {'channels': channels, 'num_blocks': 2}).to(dev)
+    fe = LogMelSpectrogram(22050, 80, 1024, 1024, 256, -50, 30, 0.0, 8000.0).to(dev)
+    mag = torch.rand(N, 513, T, device=dev) * 4
+    mag_ref = torch.rand(N, 513, T, device=dev) * 4
+    mel_ref = K.MelLog.apply(mag_ref, fe._mel_plan(), 80, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+
+    def grads():
+        return {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    model.zero_grad()
+    loss_f, est_f = model.spectral_l1_loss(mag, mag_ref, mel_ref, fe._mel_plan(), 80, 1.0, 0.5, 1e-6, fe.min_db, fe.max_db)
+    loss_f.backward()
+    gf = grads()
+
+    model.zero_grad()
+    est = model(mag)
+    mel_est = K.MelLog.apply(est, fe._mel_plan(), 80, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)
+    loss_s = K.l1_loss_sum([(est, mag_ref), (mel_est, mel_ref)], (1.0, 0.5))
+    loss_s.backward()
+    gs = grads()
+
+    assert torch.equal(est_f, est.detach())
+    ref = float(F.l1_loss(est.double(), mag_ref.double()) + 0.5 * F.l1_loss(mel_est.double(), mel_ref.double()))
+    assert abs(float(loss_f) - ref) <= 2e-6 * abs(ref), (float(loss_f), ref)
+    assert abs(float(loss_f) - float(loss_s)) <= 1e-6 * abs(ref)
+    for k in gs:
+        assert relf(gf[k], gs[k]) <= 2e-3, (k, relf(gf[k], gs[k]))
+    assert not est_f.requires_grad
