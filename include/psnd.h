@@ -293,16 +293,19 @@ int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64
  *   otherwise), batch index b = h*N + n.  mask (N,T) bytes, 1 = padding, or NULL: padded keys get no
  *   weight, padded queries are zeroed.  out (N, C, T) (heads unfolded); att (H*N, T_key, T_query) or NULL - the scores never
  *   leave the chip otherwise; stats (H*N, T, 2): per query column (max, 1/sum), kept for the backward.
- * psnd_mha_bwd: gkvq (N, 3C, T) from gout (N, C, T) and, optionally, gatt (needs att).  delta (H*N, T) scratch. */
+ *   bf16 != 0: the operands of the four score / accumulate products (K, Q, V and the probabilities) are rounded to bf16 on their
+ *   way to the matrix cores; scores, softmax statistics and accumulation stay fp32 (selected under torch.autocast(bfloat16)).
+ * psnd_mha_bwd: gkvq (N, 3C, T) from gout (N, C, T) and, optionally, gatt (needs att).  delta (H*N, T) scratch.  bf16 as above (the
+ *   probabilities are recomputed from the saved statistics: pass the forward's choice). */
 int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
                        float *y, void *stream);
 int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T);
 int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                        int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
-                 void *stream);
+                 int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
-                 const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, void *stream);
+                 const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, void *stream);
 
 /* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
  *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over

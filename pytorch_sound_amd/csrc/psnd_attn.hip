@@ -804,6 +804,395 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
     }
 }
 
+
+// =====================================================================================================================
+// The same three attention kernels with bf16 OPERANDS (fp32 scores, softmax statistics and accumulation) on
+// v_mfma_f32_32x32x16_bf16: 16 x the matrix rate of the exact-fp32 form above, which is bound by fp32 MFMA issue (~50 % of the
+// 157 TFLOP/s fp32 matrix peak at T = 1292).  Chosen by the caller (`bf16` of psnd_mha_fwd / _bwd: the module passes it under
+// torch.autocast(bfloat16), as it does for the projections).  Structure, masks, statistics and the software pipelining are those
+// of the fp32 kernels; what changes is the operand staging:
+//   * a (d x 32) tile of K / V / Q / gO lives in LDS as bf16 in the orientation(s) its products need:
+//       tT [32 t][HDP + 8]  (d contiguous)  - A operand of a SCORE product  S[t][j] = sum_dd X[dd][t] f[dd][j]: one ds_read_b128
+//       tD [HDP][36]        (t contiguous)  - A operand of an ACCUMULATE product O[dd][j] += sum_c X[dd][c] P[c][j]: two ds_read_b64
+//     (a thread converts a 2 x 2 block of fp32 values and writes packed pairs: 32-bit LDS stores in both orientations);
+//   * the probabilities / score gradients in the accumulator registers ARE the B operand of the accumulate products after a
+//     v_cvt_pk_bf16_f32 per register pair: B slot e of lane half h of the product over keys 16 s .. 16 s + 15 is accumulator
+//     register 8 s + e = row 16 s + 8 (e >> 2) + 4 h + (e & 3) - the A operand is read in that same permuted order.
+// =====================================================================================================================
+template <int HDP>
+struct BTile {
+    static constexpr int DP = HDP + 8;           // tT row pitch (bf16): 144 B at HDP = 64 - 16-byte aligned rows, conflict-free b128 reads
+    static constexpr int TPB = 36;               // tD row pitch (bf16): 72 B - 8-byte aligned, the 32 rows of a read on 64 distinct banks
+    static constexpr int TT = 32 * DP, TD = HDP * TPB;
+};
+// the thread's 2 x 2 blocks of a (HDP x 32) tile: v[u] = { X[dd][t], X[dd][t+1], X[dd+1][t], X[dd+1][t+1] }, t = t0 + 2 (tid & 15),
+// dd = 2 (tid >> 4) + 32 u; out-of-range elements read as zero (buffer loads, no branch)
+template <int HDP>
+__device__ __forceinline__ void fetch_tile_b(rsrc_t src, long long T, int d, int t0, int tid, float (&v)[HDP / 32][4]) {
+    const int t = t0 + 2 * (tid & 15);
+#pragma unroll
+    for (int u = 0; u < HDP / 32; ++u) {
+        const int dd = 2 * (tid >> 4) + 32 * u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int te = t + (e & 1), de = dd + (e >> 1);
+            v[u][e] = buf_f32(src, (te < T && de < d) ? (unsigned)(de * (int)T + te) * 4u : kOOB);
+        }
+    }
+}
+template <int HDP, bool WT, bool WD>
+__device__ __forceinline__ void commit_tile_b(unsigned short *tT, unsigned short *tD, int tid, const float (&v)[HDP / 32][4]) {
+    using B = BTile<HDP>;
+    const int tl = 2 * (tid & 15);
+#pragma unroll
+    for (int u = 0; u < HDP / 32; ++u) {
+        const int dd = 2 * (tid >> 4) + 32 * u;
+        if constexpr (WT) {
+            *reinterpret_cast<unsigned *>(tT + tl * B::DP + dd) = pack2_bf16(v[u][0], v[u][2]);
+            *reinterpret_cast<unsigned *>(tT + (tl + 1) * B::DP + dd) = pack2_bf16(v[u][1], v[u][3]);
+        }
+        if constexpr (WD) {
+            *reinterpret_cast<unsigned *>(tD + dd * B::TPB + tl) = pack2_bf16(v[u][0], v[u][1]);
+            *reinterpret_cast<unsigned *>(tD + (dd + 1) * B::TPB + tl) = pack2_bf16(v[u][2], v[u][3]);
+        }
+    }
+}
+template <int HDP, bool WT, bool WD>
+__device__ __forceinline__ void load_tile_b(rsrc_t src, long long T, int d, int t0, unsigned short *tT, unsigned short *tD, int tid) {
+    float v[HDP / 32][4];
+    fetch_tile_b<HDP>(src, T, d, t0, tid, v);
+    commit_tile_b<HDP, WT, WD>(tT, tD, tid, v);
+}
+// B-operand fragments of a (d x T) matrix for the wave's 32 columns: f[s] slot e = X[16 s + 8 kk + e][t0 + li]
+template <int HDP>
+__device__ __forceinline__ void load_frag_b(rsrc_t src, long long T, int d, int t0, int li, int kk, bf16x8_t (&f)[HDP / 16]) {
+    const int t = t0 + li;
+#pragma unroll
+    for (int s = 0; s < HDP / 16; ++s) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int dd = 16 * s + 8 * kk + e;
+            x[e] = buf_f32(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 4u : kOOB);
+        }
+        const uint4 pk = make_uint4(pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3]), pack2_bf16(x[4], x[5]), pack2_bf16(x[6], x[7]));
+        f[s] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+}
+// S tile: acc[i = rows t of the tile][j] = sum_dd X[dd][i] frag[dd][j]
+template <int HDP>
+__device__ __forceinline__ void mma_tile_frag_b(const unsigned short *tT, const bf16x8_t (&frag)[HDP / 16], int li, int kk, f32x16 &acc) {
+    using B = BTile<HDP>;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < HDP / 16; ++s) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(tT + li * B::DP + 16 * s + 8 * kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, frag[s], acc, 0, 0, 0);
+    }
+}
+// accumulator tile -> the two B operands (keys 0-15, 16-31) of an accumulate product
+__device__ __forceinline__ void pack_acc_b(const f32x16 &P, bf16x8_t (&b)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint4 pk = make_uint4(pack2_bf16(P[8 * s], P[8 * s + 1]), pack2_bf16(P[8 * s + 2], P[8 * s + 3]),
+                                    pack2_bf16(P[8 * s + 4], P[8 * s + 5]), pack2_bf16(P[8 * s + 6], P[8 * s + 7]));
+        b[s] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+}
+// O[dd][j] += sum over the tile's 32 columns c of X[dd][c] P[c][j]
+template <int HDP>
+__device__ __forceinline__ void mma_tile_acc_b(const unsigned short *tD, const bf16x8_t (&b)[2], int li, int kk, f32x16 (&O)[HDP / 32]) {
+    using B = BTile<HDP>;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt) {
+            const unsigned short *row = tD + (mt * 32 + li) * B::TPB + 16 * s + 4 * kk;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(row), hi = *reinterpret_cast<const uint2 *>(row + 8);
+            const uint4 a4 = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            O[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a4), b[s], O[mt], 0, 0, 0);
+        }
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+    using B = BTile<HDP>;
+    __shared__ __attribute__((aligned(16))) unsigned short sK[2][B::TT], sV[2][B::TD];
+    __shared__ unsigned s_kb[KBITS_MAX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    bf16x8_t qf[HDP / 16];
+    load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    const int ntile = (p.T + 31) / 32;
+    float pk[HDP / 32][4], pv[HDP / 32][4];
+    // ---- pass 1: column statistics
+    float mx = -INFINITY, sum = 0.f;
+    load_tile_b<HDP, true, false>(Kp, T, p.d, 0, sK[0], nullptr, tid);
+    load_tile_b<HDP, true, false>(Kp, T, p.d, 32, sK[1], nullptr, tid);
+    fill_key_bits(s_kb, mrow, p.T, ntile, tid);
+    __syncthreads();
+    f32x16 s;
+    mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 sn;
+        mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (bad >> rho(r, kk)) & 1u ? -INFINITY : s[r] * p.scale;
+            s[r] = v;
+            tm = fmaxf(tm, v);
+        }
+        const float m2 = fmaxf(mx, tm);
+        const float m2s = m2 > -INFINITY ? m2 : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += __expf(s[r] - m2s);
+        sum = sum * __expf(mx - m2s) + a;
+        mx = m2;
+        commit_tile_b<HDP, true, false>(sK[it & 1], nullptr, tid, pk);
+        s = sn;
+    }
+    {
+        const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
+        const float m2 = fmaxf(mx, om);
+        sum = (mx > -INFINITY ? sum * __expf(mx - m2) : 0.f) + (om > -INFINITY ? os * __expf(om - m2) : 0.f);
+        mx = m2;
+    }
+    const bool qpad = tq < p.T && mrow && mrow[tq];
+    const float inv = 1.f / sum;
+    if (tq < p.T && kk == 0) {
+        p.stats[((long long)b * T + tq) * 2] = mx;
+        p.stats[((long long)b * T + tq) * 2 + 1] = inv;
+    }
+    // ---- pass 2: probabilities and out = V P
+    f32x16 O[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O[mt][i] = 0.f;
+    const bool nancol = !(sum > 0.f);
+    const float mxs = nancol ? 0.f : mx;
+    __syncthreads();
+    load_tile_b<HDP, true, false>(Kp, T, p.d, 0, sK[0], nullptr, tid);
+    load_tile_b<HDP, true, false>(Kp, T, p.d, 32, sK[1], nullptr, tid);
+    load_tile_b<HDP, false, true>(Vp, T, p.d, 0, nullptr, sV[0], tid);
+    __syncthreads();
+    mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
+    float *attp = p.att ? p.att + (long long)b * T * T + tq : nullptr;
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+        fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 sn;
+        mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(s[r] * p.scale - mxs) * inv;
+            s[r] = ((bad >> rho(r, kk)) & 1u) || qpad ? 0.f : e;
+        }
+        if (__builtin_amdgcn_ballot_w64(nancol && !qpad) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (nancol && !qpad) ? (32 * it + rho(r, kk) < p.T ? NAN : 0.f) : s[r];
+        }
+        if (attp && tq < p.T) {
+            float *ap = attp + (long long)(32 * it + 4 * kk) * T;
+            if (32 * it + 32 <= p.T) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ap[(long long)rho(r, 0) * T] = s[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (32 * it + rho(r, kk) < p.T) ap[(long long)rho(r, 0) * T] = s[r];
+            }
+        }
+        bf16x8_t pb[2];
+        pack_acc_b(s, pb);
+        mma_tile_acc_b<HDP>(sV[it & 1], pb, li, kk, O);
+        commit_tile_b<HDP, true, false>(sK[it & 1], nullptr, tid, pk);
+        commit_tile_b<HDP, false, true>(nullptr, sV[(it + 1) & 1], tid, pv);
+        s = sn;
+    }
+    if (tq < p.T) {
+        float *op = p.out + ((long long)n * p.C + h * p.d) * T + tq;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) op[(long long)(mt * 32 + rho(r, kk)) * T] = O[mt][r];
+    }
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_bf16_kernel(AttnParams p) {
+    using B = BTile<HDP>;
+    __shared__ __attribute__((aligned(16))) unsigned short sQt[2][B::TT], sQd[2][B::TD], sGt[2][B::TT], sGd[2][B::TD];
+    __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];
+    __shared__ float sT[4][32 * TP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tk0 = blockIdx.x * 128 + wave * 32, tk = tk0 + li;
+    const bool kbad = tk >= p.T || (mrow && mrow[tk]);
+    bf16x8_t kf[HDP / 16], vf[HDP / 16];
+    load_frag_b<HDP>(Kp, T, p.d, tk0, li, kk, kf);
+    load_frag_b<HDP>(Vp, T, p.d, tk0, li, kk, vf);
+    f32x16 dK[HDP / 32], dV[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dK[mt][i] = 0.f, dV[mt][i] = 0.f;
+    const int ntile = (p.T + 31) / 32;
+    float pq[HDP / 32][4], pg[HDP / 32][4];
+    auto stage = [&](int it, int buf) __attribute__((always_inline)) {
+        if (tid < 32) {
+            const int t = 32 * it + tid;
+            f32x4_t st = {0.f, 0.f, 0.f, 1.f};
+            if (t < p.T) {
+                st[0] = p.stats[((long long)b * T + t) * 2];
+                st[1] = p.stats[((long long)b * T + t) * 2 + 1];
+                st[2] = p.delta[(long long)b * T + t];
+                st[3] = (mrow && mrow[t]) ? 1.f : 0.f;
+            }
+            *reinterpret_cast<f32x4_t *>(&sSt[buf][4 * tid]) = st;
+        }
+    };
+    stage(0, 0);
+    load_tile_b<HDP, true, true>(Qp, T, p.d, 0, sQt[0], sQd[0], tid);
+    load_tile_b<HDP, true, true>(Gp, T, p.d, 0, sGt[0], sGd[0], tid);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        if (it + 1 < ntile) {
+            stage(it + 1, (it + 1) & 1);
+            fetch_tile_b<HDP>(Qp, T, p.d, 32 * (it + 1), tid, pq);
+            fetch_tile_b<HDP>(Gp, T, p.d, 32 * (it + 1), tid, pg);
+        }
+        const float *tS = sSt[it & 1];
+        f32x16 s, dp;
+        mma_tile_frag_b<HDP>(sQt[it & 1], kf, li, kk, s);        // rows: queries of the tile, column: this lane's key
+        mma_tile_frag_b<HDP>(sGt[it & 1], vf, li, kk, dp);
+        if (it + 1 < ntile) {
+            commit_tile_b<HDP, true, true>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
+            commit_tile_b<HDP, true, true>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
+        }
+        if (p.gatt) {
+            float *tt = sT[wave];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = 2 * u + kk, k2 = tk0 + r, q2 = 32 * it + li;
+                tt[r * TP + li] = (k2 < p.T && q2 < p.T) ? p.gatt[((long long)b * T + k2) * T + q2] : 0.f;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] += tt[li * TP + rho(r, kk)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4_t st = *reinterpret_cast<const f32x4_t *>(&tS[4 * rho(r, kk)]);
+            const bool dead = kbad || st[3] > 0.f || 32 * it + rho(r, kk) >= p.T;
+            const float pr = dead ? 0.f : __expf(s[r] * p.scale - st[0]) * st[1];
+            s[r] = pr;
+            dp[r] = p.scale * pr * (dp[r] - st[2]);
+        }
+        bf16x8_t pb[2], db[2];
+        pack_acc_b(s, pb);
+        pack_acc_b(dp, db);
+        mma_tile_acc_b<HDP>(sGd[it & 1], pb, li, kk, dV);
+        mma_tile_acc_b<HDP>(sQd[it & 1], db, li, kk, dK);
+    }
+    if (tk < p.T) {
+        float *gk = p.gkvq + ((long long)n * 3 * p.C + h * p.d) * T + tk, *gv = gk + (long long)p.C * T;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) {
+                    gk[(long long)(mt * 32 + rho(r, kk)) * T] = dK[mt][r];
+                    gv[(long long)(mt * 32 + rho(r, kk)) * T] = dV[mt][r];
+                }
+    }
+}
+
+template <int HDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_bf16_kernel(AttnParams p) {
+    using B = BTile<HDP>;
+    __shared__ __attribute__((aligned(16))) unsigned short sKt[2][B::TT], sKd[2][B::TD], sVt[2][B::TT];
+    __shared__ unsigned s_kb[KBITS_MAX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
+    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    const long long T = p.T;
+    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
+    const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
+    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    bf16x8_t qf[HDP / 16], gf[HDP / 16];
+    load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    load_frag_b<HDP>(Gp, T, p.d, tq0, li, kk, gf);
+    const bool qdead = tq >= p.T || (mrow && mrow[tq]);
+    const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 0.f;
+    const float dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
+    f32x16 dQ[HDP / 32];
+#pragma unroll
+    for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dQ[mt][i] = 0.f;
+    const int ntile = (p.T + 31) / 32;
+    load_tile_b<HDP, true, true>(Kp, T, p.d, 0, sKt[0], sKd[0], tid);
+    load_tile_b<HDP, true, false>(Vp, T, p.d, 0, sVt[0], nullptr, tid);
+    fill_key_bits(s_kb, mrow, p.T, ntile, tid);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        float pk[HDP / 32][4], pv[HDP / 32][4];
+        if (it + 1 < ntile) {
+            fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
+            fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
+        }
+        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+        f32x16 s, dp;
+        mma_tile_frag_b<HDP>(sKt[it & 1], qf, li, kk, s);
+        mma_tile_frag_b<HDP>(sVt[it & 1], gf, li, kk, dp);
+        if (it + 1 < ntile) {
+            commit_tile_b<HDP, true, true>(sKt[(it + 1) & 1], sKd[(it + 1) & 1], tid, pk);
+            commit_tile_b<HDP, true, false>(sVt[(it + 1) & 1], nullptr, tid, pv);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rho(r, kk);
+            const bool dead = qdead || ((bad >> row) & 1u);
+            const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
+            float g = dp[r];
+            if (p.gatt && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            dp[r] = p.scale * pr * (g - dl);
+        }
+        bf16x8_t db[2];
+        pack_acc_b(dp, db);
+        mma_tile_acc_b<HDP>(sKd[it & 1], db, li, kk, dQ);
+    }
+    if (tq < p.T) {
+        float *gq = p.gkvq + ((long long)n * 3 * p.C + 2 * p.C + h * p.d) * T + tq;
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + rho(r, kk) < p.d) gq[(long long)(mt * 32 + rho(r, kk)) * T] = dQ[mt][r];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -901,7 +1290,7 @@ static int mha_check(const char *what, int64_t N, int H, int C, int64_t T) {
 }
 
 extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
-                            void *stream) {
+                            int bf16, void *stream) {
     if (!kvq || !out || !stats) PSND_FAIL(PSND_E_ARG, "mha_fwd: null pointer");
     int rc = mha_check("mha_fwd", N, H, C, T);
     if (rc != PSND_OK) return rc;
@@ -909,14 +1298,17 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     p.kvq = kvq, p.mask = mask, p.out = out, p.att = att, p.stats = stats;
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
-    if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (bf16) {
+        if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_bf16_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        else hipLaunchKernelGGL(attn_fwd_bf16_kernel<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    } else if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("mha_fwd");
     return PSND_OK;
 }
 
 extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
-                            const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, void *stream) {
+                            const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, void *stream) {
     if (!kvq || !out || !stats || !gout || !delta || !gkvq) PSND_FAIL(PSND_E_ARG, "mha_bwd: null pointer");
     if (gatt && !att) PSND_FAIL(PSND_E_ARG, "mha_bwd: a gradient for `att` needs the att tensor of the forward pass");
     int rc = mha_check("mha_bwd", N, H, C, T);
@@ -929,10 +1321,16 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
     p.kvq = kvq, p.mask = mask, p.stats = const_cast<float *>(stats), p.gout = gout, p.gatt = gatt, p.delta = delta, p.gkvq = gkvq;
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
-    if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, grid, dim3(256), 0, st, p);
+    if (bf16) {
+        if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_bf16_kernel<32>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_bwd_kv_bf16_kernel<64>, grid, dim3(256), 0, st, p);
+    } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
-    if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_kernel<32>, grid, dim3(256), 0, st, p);
+    if (bf16) {
+        if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_bf16_kernel<32>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_bwd_q_bf16_kernel<64>, grid, dim3(256), 0, st, p);
+    } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_kernel<32>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(q)");
     return PSND_OK;

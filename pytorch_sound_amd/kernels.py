@@ -435,10 +435,11 @@ class AttentionKVQ(torch.autograd.Function):
     """MultiHeadAttention.scale_dot_att over all heads at once (modules.py:38-48, 61-79), straight from the fused projection:
     kvq (N, 3C, T) in the reference's chunk order K | V | Q, heads folded head-major -> out (N, C, T) (heads unfolded, ready for
     the output projection) and att (H*N, T_key, T_query) when `want_att`.  psnd_mha_fwd / psnd_mha_bwd: the score tensor stays
-    on the chip; exact fp32 products.  mask_u8: (N, T), 1 = padding."""
+    on the chip; exact fp32 products, or (`bf16`, what the module passes under torch.autocast(bfloat16)) bf16 operands with fp32
+    scores / statistics / accumulation.  mask_u8: (N, T), 1 = padding."""
 
     @staticmethod
-    def forward(ctx, kvq, mask_u8, heads, want_att):
+    def forward(ctx, kvq, mask_u8, heads, want_att, bf16=False):
         _need_cuda(kvq, 'kvq')
         kvq = kvq.contiguous()
         N, C3, T = kvq.shape
@@ -449,8 +450,9 @@ class AttentionKVQ(torch.autograd.Function):
         stats = torch.empty((heads * N, T, 2), dtype=torch.float32, device=dev)
         m = None if mask_u8 is None else mask_u8.contiguous()
         with torch.cuda.device(dev):
-            check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), stream_ptr(dev)), 'psnd_mha_fwd')
-        ctx.heads = heads
+            check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), int(bool(bf16)),
+                                     stream_ptr(dev)), 'psnd_mha_fwd')
+        ctx.heads, ctx.bf16 = heads, int(bool(bf16))
         ctx.set_materialize_grads(False)             # an unused `att` must not turn into an (H*N, T, T) tensor of zeros in backward
         ctx.save_for_backward(kvq, m, out, att, stats)
         if att is None:
@@ -475,8 +477,8 @@ class AttentionKVQ(torch.autograd.Function):
         gkvq = torch.empty_like(kvq)
         with torch.cuda.device(dev):
             check(lib().psnd_mha_bwd(ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq),
-                                     stream_ptr(dev)), 'psnd_mha_bwd')
-        return gkvq, None, None, None
+                                     ctx.bf16, stream_ptr(dev)), 'psnd_mha_bwd')
+        return gkvq, None, None, None, None
 
 
 class PreEmphasisFn(torch.autograd.Function):

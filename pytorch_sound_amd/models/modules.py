@@ -101,7 +101,9 @@ class MultiHeadAttention(nn.Module):
                                 'hidden_dim; there is no library path for a HIP tensor' % (self.hidden_dim, self.heads))
             from pytorch_sound_amd import kernels as K
             mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
-            x, att = K.AttentionKVQ.apply(kvq, mask_u8, self.heads, self.return_att)
+            # under torch.autocast(bfloat16) the score / accumulate products take bf16 operands, as the projections do
+            bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            x, att = K.AttentionKVQ.apply(kvq, mask_u8, self.heads, self.return_att, bf16)
             att = att if self.return_att else None
         else:
             k, v, q = (self._fold_heads(p) for p in kvq.chunk(3, 1))

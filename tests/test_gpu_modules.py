@@ -213,8 +213,8 @@ def test_linear1x1_exact(N, Cin, Cout, T, relu, bf16):
 
 
 def test_block_under_autocast_uses_bf16_products():
-    """torch.autocast(bfloat16) around the modules: the 1x1 projections take bf16 operands (fp32 accumulation and activations),
-    the attention stays exact - outputs and gradients within bf16 tolerance (3e-2 relative Frobenius) of the fp32 run"""
+    """torch.autocast(bfloat16) around the modules: the 1x1 projections AND the attention products take bf16 operands (fp32 accumulation,
+    scores, statistics and activations) - outputs and gradients within bf16 tolerance (3e-2 relative Frobenius) of the fp32 run"""
     from pytorch_sound_amd.models.modules import MultiHeadAttention, PointwiseFeedForward
     dev = torch.device('cuda:0')
     torch.manual_seed(4)
@@ -238,3 +238,82 @@ def test_block_under_autocast_uses_bf16_products():
     for u, v in zip(a, b):           # relative Frobenius: single elements behind a sharp softmax move more than the average
         assert float((u - v).norm() / v.norm()) <= 3e-2, float((u - v).norm() / v.norm())
     assert float((a[0] - b[0]).abs().max()) > 0          # the bf16 path really ran
+
+
+def _attention_float64(kvq, mask, H, gout, gatt, round_operands):
+    """scale_dot_att over folded heads (modules.py:38-48, 61-79) in float64 torch ops with autograd; round_operands: K, Q, V and the
+    probabilities pass through bf16 before the two products - what the bf16 kernels compute, up to fp32 accumulation order."""
+    N, C3, T = kvq.shape
+    C = C3 // 3
+    d = C // H
+    x = kvq.double().requires_grad_(True)
+
+    class _R(torch.autograd.Function):          # straight-through rounding: gradients as if exact
+        @staticmethod
+        def forward(ctx, t):
+            return t.float().bfloat16().double()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    r = _R.apply if round_operands else (lambda t: t)
+    k, v, q = (t.view(N, H, d, T).transpose(0, 1).reshape(H * N, d, T) for t in x.chunk(3, 1))
+    s = torch.einsum('bdk,bdq->bkq', r(k), r(q)) / (d ** 0.5)
+    if mask is not None:
+        m = mask.bool().repeat(H, 1)
+        s = s.masked_fill(m[:, :, None], float('-inf'))
+    att = torch.softmax(s, 1)
+    if mask is not None:
+        att = att.masked_fill(m[:, None, :], 0.0)
+    out = torch.einsum('bdk,bkq->bdq', r(v), r(att))
+    out = out.view(H, N, d, T).transpose(0, 1).reshape(N, C, T)
+    loss = (out * gout.double()).sum()
+    if gatt is not None:
+        loss = loss + (att * gatt.double()).sum()
+    loss.backward()
+    return out.detach(), att.detach(), x.grad
+
+
+@pytest.mark.parametrize('N,H,C,T,masked,with_gatt', [(2, 4, 256, 173, True, False), (3, 4, 64, 50, True, True), (2, 4, 256, 1292, True, False),
+                                                     (2, 2, 96, 77, False, True), (1, 4, 128, 33, False, False), (2, 4, 256, 431, True, True)])
+def test_attention_bf16_operands(N, H, C, T, masked, with_gatt):
+    """psnd_mha_fwd / _bwd with bf16 = 1 (head dimensions 64, 16, 48, 32; ragged T; padding masks; with and without a gradient into
+    the returned attention tensor):
+      * forward against float64 with the SAME operand rounding: 2e-3 of the largest output (fp32 accumulation + the probabilities
+        that sit on a bf16 rounding boundary in fp32 but not in float64); the returned probabilities are not rounded: 2e-6 absolute
+        beyond what rounding K and Q moves them;
+      * backward against exact float64: relative Frobenius 2e-2 (bf16 operands: 2^-9 per element, random signs), the bound the
+        projections under autocast are held to;
+      * padded keys / queries get exactly zero gradient, as in the fp32 kernels."""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 1000 + T)
+    kvq = torch.randn(N, 3 * C, T, device=dev)
+    mask = None
+    if masked:
+        lens = torch.linspace(T, max(T // 3, 4), N).long()
+        mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
+    gout = torch.randn(N, C, T, device=dev)
+    gatt = 0.3 * torch.randn(H * N, T, T, device=dev) if with_gatt else None
+    x = kvq.clone().requires_grad_(True)
+    out, att = K.AttentionKVQ.apply(x, None if mask is None else mask.to(torch.uint8), H, True, True)
+    loss = (out * gout).sum()
+    if gatt is not None:
+        loss = loss + (att * gatt).sum()
+    loss.backward()
+    o_r, a_r, _ = _attention_float64(kvq, mask, H, gout, gatt, True)
+    o_x, a_x, g_x = _attention_float64(kvq, mask, H, gout, gatt, False)
+    assert float((out.double() - o_r).abs().max()) <= 2e-3 * float(o_r.abs().max())
+    assert float((att.double() - a_r).abs().max()) <= 2e-6 + 1e-4 * float(a_r.max())
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())           # noqa: E731
+    assert rel(out, o_x) <= 2e-2, rel(out, o_x)
+    assert rel(x.grad, g_x) <= 2e-2, rel(x.grad, g_x)
+    # the fp32 kernels on the same input: the bf16 path is a different computation, and close to it
+    x2 = kvq.clone().requires_grad_(True)
+    out2, att2 = K.AttentionKVQ.apply(x2, None if mask is None else mask.to(torch.uint8), H, True, False)
+    assert float((out2 - out).abs().max()) > 0 and rel(out2, o_x) <= 1e-5
+    if masked:
+        g = x.grad.view(N, 3, C, T)
+        L = int(lens[-1])
+        assert float(g[-1, :, :, L:].abs().max()) == 0

@@ -51,8 +51,8 @@ for T in (173, 431, 690, 1292):
     lens = torch.linspace(0.8 * T, T, N).long()
     mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
     res = {}
-    for name, flags in (('round 2 fp32', (False, False, True, False)), ('round 2 bf16 linears', (False, False, True, True)),
-                        ('round 2 bf16, no att', (False, False, False, True)), ('round 1', (True, False, True, False)), ('torch', (False, True, True, False))):
+    for name, flags in (('round 2 fp32', (False, False, True, False)), ('autocast bf16', (False, False, True, True)),
+                        ('autocast bf16, no att', (False, False, False, True)), ('round 1', (True, False, True, False)), ('torch', (False, True, True, False))):
         M.ROUND1_PATH, M.TORCH_FORMULATION_ON_GPU, mha.return_att, ac = flags
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=ac):
             res[name] = graph_time(x, mask)
