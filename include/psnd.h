@@ -173,6 +173,42 @@ int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const
                         void *mid_out, const void *W2, const float *bias2, const void *M2, float m2_slope, const void *res,
                         int64_t N, int Lp, int L, int HP, int C, int k, int off1, int dstep1, int off2, int dstep2,
                         float act2_slope, void *out_raw, void *out_act, void *stream);
+/* The weight gradients of n (<= 32) convs of ONE shape (Ca -> Cb channels, k taps, the same N x Lp rows) in one launch: per conv the
+ * operands and slabs of psnd_conv1d_cl_wgrad with a plain gradient (g = the conv's combined output gradient, xa = its activated input,
+ * taps off0 + j * dstep; gbias_part may be NULL), every conv with psnd_conv1d_cl_wgrad_multi_splits(N, Lp, Ca, Cb, k, n) slabs. */
+typedef struct psnd_wgrad_desc {
+    const void *g, *xa;
+    float *gw_part, *gbias_part;
+    int off0, dstep;
+} psnd_wgrad_desc;
+int psnd_conv1d_cl_wgrad_multi_splits(int64_t N, int Lp, int Ca, int Cb, int k, int n_convs);
+int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, int Ca, int Cb, int k, void *stream);
+/* A CHAIN of such pairs in one launch (csrc/psnd_conv_chain.hip; forward only: no masks): the pairs of a ResBlock1 (hifi_gan.py:56-62),
+ * pair i + 1 reading the activated output and the residual stream of pair i on the chip.  Values bit-identical to n_pairs
+ * psnd_conv1d_cl_pair launches; every pair's mid_out / out_raw / out_act (each may be NULL) is written as those launches would.  A, res: the
+ * activated input and the residual stream of the first pair.  psnd_conv1d_cl_chain_rows(C, k, n_pairs, taps): rows a workgroup OWNS of the 64
+ * it computes (the rest is recomputed by its neighbours), 0 = unsupported (taps: off1, dstep1, off2, dstep2 per pair; k = 3, C = 256,
+ * reach <= 8, 1 ... 4 pairs, >= 16 rows left).  psnd_conv_chain_stats: out2 = { chain launches, pairs they carried }.
+ * With M1 / M2 on every pair the launch is the INPUT-GRADIENT chain of those pairs walked backwards (the values of psnd_conv1d_cl_pair
+ * with masks, transposed packs, mirrored taps): mid = conv(A; W1) * (M1 > 0 ? 1 : m1_slope), out = conv(mid; W2) * (M2 > 0 ? 1 : m2_slope)
+ * + A; res == A, activation slopes 1, out_act NULL, out_raw of pair i is the input of pair i + 1. */
+typedef struct psnd_chain_pair {
+    const void *W1;
+    const float *bias1;
+    float act1_slope;
+    void *mid_out;
+    const void *W2;
+    const float *bias2;
+    int off1, dstep1, off2, dstep2;
+    float act2_slope;
+    void *out_raw, *out_act;
+    const void *M1, *M2;        /* the input-gradient form (below): leaky' masks of the two convs' outputs, or both NULL */
+    float m1_slope, m2_slope;
+} psnd_chain_pair;
+int psnd_conv1d_cl_chain_rows(int C, int k, int n_pairs, const int *taps);
+int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_chain_pair *pairs, int n_pairs, int64_t N, int Lp, int L, int HP,
+                         int C, int k, void *stream);
+void psnd_conv_chain_stats(long long *out2);
 /* host-side launch counters of the conv kernels' tile instances: out4 = { forward / input-gradient launches with 64-row
  * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
  * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */

@@ -48,6 +48,11 @@ SIGNATURES = {
     'psnd_conv1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd': (_INT, [_P, _P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_cl_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _F, _P, _P, _P, _P]),
+    'psnd_conv1d_cl_wgrad_multi_splits': (_INT, [_I64, _INT, _INT, _INT, _INT, _INT]),
+    'psnd_conv1d_cl_wgrad_multi': (_INT, [_P, _INT, _I64, _INT, _INT, _INT, _INT, _P]),
+    'psnd_conv1d_cl_chain_rows': (_INT, [_INT, _INT, _INT, _P]),
+    'psnd_conv1d_cl_chain': (_INT, [_P, _P, _P, _INT, _I64, _INT, _INT, _INT, _INT, _INT, _P]),
+    'psnd_conv_chain_stats': (None, [_P]),
     'psnd_conv1d_cl_pair_bwd_supported': (_INT, [_INT, _INT, _INT, _INT, _INT, _INT]),
     'psnd_conv1d_cl_pair_bwd_splits': (_INT, [_I64, _INT, _INT, _INT]),
     'psnd_conv1d_cl_pair_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P,
@@ -115,6 +120,18 @@ _lib = None
 
 class PsndError(RuntimeError):
     pass
+
+
+class WgradDesc(ctypes.Structure):
+    """psnd_wgrad_desc of include/psnd.h"""
+    _fields_ = [('g', _P), ('xa', _P), ('gw_part', _P), ('gbias_part', _P), ('off0', _INT), ('dstep', _INT)]
+
+
+class ChainPair(ctypes.Structure):
+    """psnd_chain_pair of include/psnd.h"""
+    _fields_ = [('W1', _P), ('bias1', _P), ('act1_slope', _F), ('mid_out', _P), ('W2', _P), ('bias2', _P),
+                ('off1', _INT), ('dstep1', _INT), ('off2', _INT), ('dstep2', _INT), ('act2_slope', _F), ('out_raw', _P), ('out_act', _P),
+                ('M1', _P), ('M2', _P), ('m1_slope', _F), ('m2_slope', _F)]
 
 
 def lib():

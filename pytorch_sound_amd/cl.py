@@ -11,6 +11,7 @@ parameters stay exactly the reference's (weight_g / weight_v / bias per conv); t
 entirely on hand-written kernels: weight prep (weight norm + bf16 packs), implicit-GEMM conv (forward and input
 gradient), split-K weight gradient with all taps / bias gradient fused, weight-norm backward.
 """
+import ctypes
 import torch
 
 from . import _lib
@@ -303,6 +304,53 @@ def _wgrad_streams(dev):
 def _pair_enabled():
     import os
     return os.environ.get('PSND_CL_PAIR', '1') != '0'
+
+
+def _chain_pairs_bwd(plan, rows):
+    """the same for the input-gradient launches ('pairb') of the batched backward: consecutive pairs, each reading the gradient the one
+    before wrote, as one masked psnd_conv1d_cl_chain launch"""
+    import os
+    mx = int(os.environ.get('PSND_CL_CHAIN_BWD', os.environ.get('PSND_CL_CHAIN', '3')))
+    if mx < 2 or rows > 8192:
+        return plan
+    out = []
+    for e in plan:
+        if e[0] == 'pairb' and e[10] == 256 and e[9] is e[1]:
+            c = out[-1] if out and out[-1][0] == 'chainb' else None
+            if c is not None and len(c[1]) < mx and c[1][-1][16] is e[1] and c[1][-1][11] == e[11]:
+                taps = [t for q_ in c[1] + [e] for t in q_[12:16]]
+                if lib().psnd_conv1d_cl_chain_rows(e[10], e[11], len(c[1]) + 1, (ctypes.c_int * len(taps))(*taps)) >= 32:
+                    c[1].append(e)
+                    continue
+            out.append(['chainb', [e]])
+        else:
+            out.append(e)
+    return [c[1][0] if c[0] == 'chainb' and len(c[1]) == 1 else c for c in out]
+
+
+def _chain_pairs(plan, rows):
+    """Consecutive 'pair' launches of a forward plan -> 'chain' launches (psnd_conv1d_cl_chain: a workgroup carries its rows through up
+    to PSND_CL_CHAIN pairs - default 3, a ResBlock1 - on the chip; 0 switches it off).  Only where a launch is a latency chain of few
+    workgroups (<= 8192 rows: the config-2 size); a pair joins the chain in front of it when it reads that chain's outputs."""
+    import os
+    mx = int(os.environ.get('PSND_CL_CHAIN', '3'))
+    if mx < 2 or rows > 8192:
+        return plan
+    out = []
+    for e in plan:
+        if (e[0] == 'pair' and e[9] == 256 and e[8] is not None and e[16] is not None and e[17] is not None
+                and 0.0 <= e[4] <= 1.0 and 0.0 <= e[15] <= 1.0):
+            c = out[-1] if out and out[-1][0] == 'chain' else None
+            if c is not None and len(c[5]) < mx and c[5][-1][17] is e[1] and c[5][-1][16] is e[8] and c[3] == e[9] and c[4] == e[10]:
+                taps = [t for q_ in c[5] + [e] for t in q_[11:15]]
+                if lib().psnd_conv1d_cl_chain_rows(e[9], e[10], len(c[5]) + 1, (ctypes.c_int * len(taps))(*taps)) >= 32:
+                    c[5].append(e)
+                    continue
+            out.append(['chain', e[1], e[8], e[9], e[10], [e]])
+        else:
+            out.append(e)
+    # a chain of one is the pair launch it came from
+    return [c[5][0] if c[0] == 'chain' and len(c[5]) == 1 else c for c in out]
 
 
 def _sec(t, h, nsec):
@@ -644,11 +692,22 @@ class ResBlockCL(torch.autograd.Function):
             saved += [inp, act if act is not None else inp, wb, v32, g32]
         nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
         Nh = shape.N // nsec
+        plan = _chain_pairs(plan, Nh * shape.Lp)
 
         def run(h):
             st = stream_ptr(dev)
             q = lambda t: ptr(_sec(t, h, nsec))                # noqa: E731
             for e in plan:
+                if e[0] == 'chain':
+                    _, inp1, res0, C, k, pairs = e
+                    arr = (_lib.ChainPair * len(pairs))()
+                    for d, (_, _, wf1, bp1, slope1, mid, wf2, bp2, _, _, _, off1, dil1, off2, dil2, oslope, raw, act) in zip(arr, pairs):
+                        d.W1, d.bias1, d.act1_slope, d.mid_out = wf1.data_ptr(), bp1.data_ptr(), float(slope1), q(mid)
+                        d.W2, d.bias2, d.off1, d.dstep1, d.off2, d.dstep2 = wf2.data_ptr(), bp2.data_ptr(), off1, dil1, off2, dil2
+                        d.act2_slope, d.out_raw, d.out_act = float(oslope), q(raw), q(act)
+                    check(lib().psnd_conv1d_cl_chain(q(inp1), q(res0), ctypes.addressof(arr), len(pairs), Nh, shape.Lp, shape.L, shape.HP,
+                                                     C, k, st), 'psnd_conv1d_cl_chain')
+                    continue
                 if e[0] == 'pair':
                     _, inp1, wf1, bp1, slope1, mid, wf2, bp2, res, C, k, off1, dil1, off2, dil2, oslope, raw, act = e
                     check(lib().psnd_conv1d_cl_pair(q(inp1), ptr(wf1), ptr(bp1), None, 1.0, float(slope1), q(mid), ptr(wf2), ptr(bp2),
@@ -686,7 +745,12 @@ class ResBlockCL(torch.autograd.Function):
         Nh = shape.N // nsec
         plan = []                              # launches, walked once per batch section (_run_sections)
         skip = -1                              # conv already handled as the first conv of a fused input-gradient pair
-        pair_bwd = (nsec == 1 and not wstreams and _pair_enabled() and os.environ.get('PSND_CL_PAIR_BWD', '1') != '0'
+        # batched backward (default; PSND_CL_BWD_BATCH=0: one psnd_conv1d_cl_pair_bwd launch per pair): the input-gradient chain runs alone (one psnd_conv1d_cl_pair launch per residual pair,
+        # masks and mirrored taps), the weight gradients of all its convs follow in ONE launch (psnd_conv1d_cl_wgrad_multi)
+        batch = (nsec == 1 and not wstreams and _pair_enabled() and os.environ.get('PSND_CL_BWD_BATCH', '1') == '1'
+                 and shape.N * shape.Lp <= 8192)
+        wbatch = []
+        pair_bwd = (nsec == 1 and not wstreams and not batch and _pair_enabled() and os.environ.get('PSND_CL_PAIR_BWD', '1') != '0'
                     and shape.N * shape.Lp <= 8192)
         lag = None                             # weight gradient of a pair's first conv, carried to the next pair launch
         with torch.cuda.device(dev):
@@ -739,20 +803,27 @@ class ResBlockCL(torch.autograd.Function):
                     g_comb = gx
                     skip = i - 1
                     continue
-                if (wstreams and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
+                if ((wstreams or batch) and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
                         and steps[i - 1][3] == steps[i - 1][4] == Ca and steps[i - 1][2] == k
                         and lib().psnd_conv1d_cl_pair_supported(Ca, k, pad, -dil, steps[i - 1][6], -steps[i - 1][5])):
                     # input gradients of conv2 and conv1 of a residual pair as ONE launch on this stream (psnd_conv1d_cl_pair with
-                    # the transposed packs, mirrored taps and the leaky' masks); their weight gradients go to the side streams
+                    # the transposed packs, mirrored taps and the leaky' masks); their weight gradients go to the side streams, or
+                    # (batch) into the one launch behind the chain
                     inp1, wb1 = saved[5 * (i - 1)], saved[5 * (i - 1) + 2]
                     d1, pad1 = steps[i - 1][5], steps[i - 1][6]
                     G = g_comb
                     g_h = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)      # gradient wrt conv1's output
                     gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
-                    plan.append(('side',) + slabs(i, G, None, None, inp))                              # ready before the pair launch
+                    if batch:
+                        wbatch.append((i, G, inp, -pad, dil))
+                    else:
+                        plan.append(('side',) + slabs(i, G, None, None, inp))                          # ready before the pair launch
                     plan.append(('pairb', G, wb, inp, float(steps[i - 1][7]), g_h, wb1, inp1, float(steps[i - 2][7]), G, Ca, k,
                                  pad, -dil, pad1, -d1, gx))
-                    plan.append(('side',) + slabs(i - 1, g_h, None, None, inp1))
+                    if batch:
+                        wbatch.append((i - 1, g_h, inp1, -pad1, d1))
+                    else:
+                        plan.append(('side',) + slabs(i - 1, g_h, None, None, inp1))
                     keep.extend([g_h, gx])
                     res_pending = G
                     g_comb = gx
@@ -809,6 +880,8 @@ class ResBlockCL(torch.autograd.Function):
 
             if lag is not None:                # the chain's first pair: its conv1 weight gradient has no later pair launch to ride on
                 plan.append(('pbflush', lag))
+            if batch:
+                plan = _chain_pairs_bwd(plan, shape.N * shape.Lp)
             used = []
 
             def run(h):
@@ -841,6 +914,18 @@ class ResBlockCL(torch.autograd.Function):
                                                             shape.HP, lg[6], lg[7], 0, 1, 0, 1, None, None, None, None, ptr(lg[0]), ptr(lg[1]),
                                                             lg[2], lg[3], ptr(lg[4]), ptr(lg[5]), st), 'psnd_conv1d_cl_pair_bwd')
                         continue
+                    if e[0] == 'chainb':
+                        pairs = e[1]
+                        arr = (_lib.ChainPair * len(pairs))()
+                        for d, (_, G, wb2, m1, m1s, g_h, wb1, m2, m2s, res, C, k, off1, ds1, off2, ds2, gx) in zip(arr, pairs):
+                            d.W1, d.bias1, d.act1_slope, d.mid_out = wb2.data_ptr(), None, 1.0, g_h.data_ptr()
+                            d.W2, d.bias2, d.off1, d.dstep1, d.off2, d.dstep2 = wb1.data_ptr(), None, off1, ds1, off2, ds2
+                            d.act2_slope, d.out_raw, d.out_act = 1.0, gx.data_ptr(), None
+                            d.M1, d.M2, d.m1_slope, d.m2_slope = m1.data_ptr(), m2.data_ptr(), m1s, m2s
+                        G0 = pairs[0][1]
+                        check(lib().psnd_conv1d_cl_chain(ptr(G0), ptr(G0), ctypes.addressof(arr), len(pairs), shape.N, shape.Lp, shape.L,
+                                                         shape.HP, pairs[0][10], pairs[0][11], st), 'psnd_conv1d_cl_chain')
+                        continue
                     if e[0] == 'pairb':
                         _, G, wb2, m1, m1s, g_h, wb1, m2, m2s, res, C, k, off1, ds1, off2, ds2, gx = e
                         check(lib().psnd_conv1d_cl_pair(ptr(G), ptr(wb2), None, ptr(m1), m1s, 1.0, ptr(g_h), ptr(wb1), None, ptr(m2), m2s,
@@ -863,6 +948,16 @@ class ResBlockCL(torch.autograd.Function):
             for sd in set(used):
                 torch.cuda.current_stream(dev).wait_stream(sd)
             st = stream_ptr(dev)
+            for j0 in range(0, len(wbatch), 32):
+                part = wbatch[j0:j0 + 32]
+                Ca, k = steps[part[0][0]][3], steps[part[0][0]][2]
+                Sb = lib().psnd_conv1d_cl_wgrad_multi_splits(shape.N, shape.Lp, Ca, Ca, k, len(part))
+                arr = (_lib.WgradDesc * len(part))()
+                for d, (ci, G, inp, off0, dstep) in zip(arr, part):
+                    w = slabs(ci, G, None, None, inp, Sb)
+                    d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = G.data_ptr(), inp.data_ptr(), w[11].data_ptr(), w[12].data_ptr(), off0, dstep
+                check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(part), shape.N, shape.Lp, Ca, Ca, k, st),
+                      'psnd_conv1d_cl_wgrad_multi')
             for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
                 chunk = descs[j0:j0 + 32]
                 buf = ctypes.create_string_buffer(b''.join(chunk))

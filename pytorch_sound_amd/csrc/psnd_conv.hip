@@ -1024,6 +1024,28 @@ __global__ __launch_bounds__(256, 2) void conv_pair_bwd_kernel(pairk::PairParams
     }
 }
 
+// The weight gradients of MANY convs of one shape in one launch (psnd_conv1d_cl_wgrad_multi): workgroup b takes tile / row range
+// b % per_conv of conv b / per_conv.  For the batched backward of a conv chain (cl.py): the input-gradient chain runs first, alone,
+// and every weight gradient it left behind is computed here at full occupancy instead of riding along in 12 latency-bound launches.
+constexpr int WGRAD_MULTI_MAX = 32;
+struct WgradMultiArgs {
+    WgradParams base;
+    int n, per_conv, wgx, wgy;
+    struct {
+        const bf16_t *g, *xa;
+        float *gw, *gb;
+        int off0, dstep;
+    } c[WGRAD_MULTI_MAX];
+};
+__global__ __launch_bounds__(256, 2) void conv_wgrad_multi_kernel(WgradMultiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
+    const int c = blockIdx.x / a.per_conv, b = blockIdx.x - c * a.per_conv;
+    WgradParams w = a.base;
+    w.G1 = a.c[c].g, w.xa = a.c[c].xa, w.gw = a.c[c].gw, w.gbias = a.c[c].gb, w.off0 = a.c[c].off0, w.dstep = a.c[c].dstep;
+    const int bx = b % a.wgx, r = b / a.wgx;
+    conv_wgrad_body<false>(w, bx, r % a.wgy, r / a.wgy, smem_dyn, 0);
+}
+
 // ---- weight prep: weight norm (dim 0) + both bf16 packs + padded bias, one block per output channel ------
 //   w = g * v / ||v|| ; wf[j][co][ci] (forward), wb[j][ci][co] (input gradient) ; pads are zero-filled by the caller
 __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const float *g, const float *bias, int Cout, int Cin, int k,
@@ -1517,6 +1539,57 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 // Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
 // taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Outside the paired instances (operands beyond the
 // 32-bit offsets) the two kernels are enqueued one after the other, same results.
+// ---- weight gradients of many same-shaped convs in one launch (conv_wgrad_multi_kernel) --------------------------------------------
+static int wgrad_multi_splits(int64_t R, int Ca, int Cb, int k, int n, int64_t *rps_out) {
+    const int tiles = ((Ca + 63) / 64) * ((Cb + 63) / 64) * ((k + WKT - 1) / WKT);
+    // 24 convs x 16 tiles at the config-2 size, launch alone (tools/perf_wgrad_multi.py): 1 row range per conv (384 workgroups of 184
+    // chunks) 106 us, 2 -> 81 us, 3 -> 100, 4 -> 90, 6 -> 100, 8 -> 108 (and the slabs the weight-norm backward has to add up grow with it)
+    int64_t target = 768;
+    if (const char *e = getenv("PSND_WGRAD_MULTI_BLOCKS")) target = atoi(e);
+    int64_t splits = target / ((int64_t)tiles * (n > 0 ? n : 1));
+    if (splits < 1) splits = 1;
+    int64_t rps = (R + splits - 1) / splits;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 64) rps = 64;
+    splits = (R + rps - 1) / rps;
+    if (rps_out) *rps_out = rps;
+    return (int)splits;
+}
+
+extern "C" int psnd_conv1d_cl_wgrad_multi_splits(int64_t N, int Lp, int Ca, int Cb, int k, int n_convs) {
+    if (N <= 0 || Lp <= 0 || Ca <= 0 || Cb <= 0 || k <= 0 || n_convs <= 0) return 0;
+    return wgrad_multi_splits(N * (int64_t)Lp, Ca, Cb, k, n_convs, nullptr);
+}
+
+extern "C" int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, int Ca, int Cb, int k, void *stream) {
+    if (!d || n < 0) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad_multi: null pointer");
+    if (n == 0 || N == 0) return PSND_OK;
+    if (n > WGRAD_MULTI_MAX) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_wgrad_multi: %d convs (at most %d per launch)", n, WGRAD_MULTI_MAX);
+    if (N < 0 || Lp <= 0 || Ca <= 0 || Cb <= 0 || k <= 0 || Ca % 8 || Cb % 8)
+        PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: N=%lld Lp=%d Ca=%d Cb=%d k=%d", (long long)N, Lp, Ca, Cb, k);
+    const int64_t R = N * (int64_t)Lp;
+    if ((size_t)R * (size_t)(Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: operand larger than 2 GB");
+    WgradMultiArgs a;
+    memset(&a, 0, sizeof(a));
+    wgrad_params_plain(a.base);
+    int64_t rps;
+    const int splits = wgrad_multi_splits(R, Ca, Cb, k, n, &rps);
+    a.base.G2 = nullptr, a.base.GM = nullptr, a.base.g_out = nullptr;
+    a.base.R = R, a.base.Ca = Ca, a.base.Cb = Cb, a.base.k = k, a.base.g2_slope = 1.f, a.base.rows_per_split = (int)rps;
+    a.wgx = (Cb + 63) / 64, a.wgy = (Ca + 63) / 64;
+    a.per_conv = a.wgx * a.wgy * splits * ((k + WKT - 1) / WKT), a.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!d[i].g || !d[i].xa || !d[i].gw_part) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad_multi: conv %d: null pointer", i);
+        if ((k < WKT ? k - 1 : WKT - 1) * (d[i].dstep < 0 ? -d[i].dstep : d[i].dstep) > WXR - 32)
+            PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_wgrad_multi: conv %d: dilation %d: a tap group spans more than %d rows", i, d[i].dstep, WXR - 32);
+        a.c[i].g = static_cast<const bf16_t *>(d[i].g), a.c[i].xa = static_cast<const bf16_t *>(d[i].xa);
+        a.c[i].gw = d[i].gw_part, a.c[i].gb = d[i].gbias_part, a.c[i].off0 = d[i].off0, a.c[i].dstep = d[i].dstep;
+    }
+    hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3((unsigned)(a.per_conv * n)), dim3(256), kWgradLdsBytes, static_cast<hipStream_t>(stream), a);
+    PSND_CHECK_LAUNCH("conv1d_cl_wgrad_multi");
+    return PSND_OK;
+}
+
 // ---- backward of a residual pair in one launch (conv_pair_bwd_kernel) -----------------------------------------------------------------
 static int pair_bwd_splits(int64_t R, int C, int k, int64_t *rps_out) {
     const int tiles = ((C + 63) / 64) * ((C + 63) / 64) * ((k + WKT - 1) / WKT);

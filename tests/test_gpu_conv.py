@@ -136,6 +136,82 @@ def test_pair_launch_matches_two_launches(channels, N, T, monkeypatch):
     assert rel(o1, ref) < 2e-2
 
 
+@pytest.mark.parametrize('N,T,blocks,chain', [(32, 173, 4, 3), (4, 173, 2, 3), (3, 50, 1, 2), (5, 97, 2, 4), (1, 20, 1, 3)])
+def test_chain_launch_is_bit_identical_to_pair_launches(N, T, blocks, chain, monkeypatch):
+    """psnd_conv1d_cl_chain (the pairs of a ResBlock1 in ONE launch, a workgroup carrying its 64-row tile through all of them on the chip
+    and owning the rows that stay valid) against the same forward as one psnd_conv1d_cl_pair launch per pair: the arithmetic, its order
+    and the rounding points are the same, so the output and EVERY tensor saved for the backward - hence every gradient - are bit-identical.
+    Shapes: the bench batch (32 x 173 frames), clips shorter than a tile, chains of 2 / 3 / 4 pairs (42 / 52 / 40 owned rows)."""
+    import ctypes
+    from pytorch_sound_amd import _lib
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N + T)
+    model = build_model('conv_separator_voicebank', {'channels': 256, 'num_blocks': blocks}).to(dev)
+    mag = torch.rand(N, 513, T, device=dev) * 4
+    tgt = torch.rand(N, 513, T, device=dev)
+
+    def stats():
+        out = (ctypes.c_longlong * 2)()
+        _lib.lib().psnd_conv_chain_stats(ctypes.addressof(out))
+        return out[0], out[1]
+
+    def run(mx):
+        monkeypatch.setenv('PSND_CL_CHAIN', str(mx))
+        model.zero_grad()
+        m = mag.clone().requires_grad_(True)
+        s0 = stats()
+        out = model(m)
+        s1 = stats()
+        (out - tgt).abs().mean().backward()
+        return (s1[0] - s0[0], s1[1] - s0[1]), out.detach().clone(), m.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    st1, o1, gm1, g1 = run(chain)
+    st0, o0, gm0, g0 = run(0)
+    assert st0 == (0, 0)
+    pairs = 3 * blocks
+    assert st1[1] == (pairs if chain <= pairs else 0) or st1[1] == pairs - pairs % chain or st1[1] >= 2, st1      # the chain kernel really ran
+    assert st1[0] >= 1
+    assert torch.equal(o1, o0)
+    assert torch.equal(gm1, gm0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+
+
+@pytest.mark.parametrize('N,T,blocks,chain', [(32, 173, 4, 3), (4, 173, 2, 0), (3, 50, 1, 2), (5, 97, 2, 3)])
+def test_batched_backward_matches_paired_backward(N, T, blocks, chain, monkeypatch):
+    """The batched backward (default): the input-gradient chain of the conv body runs alone (masked psnd_conv1d_cl_chain launches over up to `chain`
+    residual pairs, or one masked psnd_conv1d_cl_pair launch per pair for chain = 0) and ALL weight gradients follow in one
+    psnd_conv1d_cl_wgrad_multi launch - against PSND_CL_BWD_BATCH=0 (one psnd_conv1d_cl_pair_bwd launch per pair).  The input-gradient
+    arithmetic is the same (same order, same bf16 rounding points): the gradient wrt the input magnitude is bit-identical; the weight
+    gradients are the same products summed over differently cut row ranges (fp32): 2e-5 relative Frobenius."""
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 7 + T)
+    model = build_model('conv_separator_voicebank', {'channels': 256, 'num_blocks': blocks}).to(dev)
+    mag = torch.rand(N, 513, T, device=dev) * 4
+    tgt = torch.rand(N, 513, T, device=dev)
+
+    def run(batch):
+        monkeypatch.setenv('PSND_CL_BWD_BATCH', '1' if batch else '0')
+        monkeypatch.setenv('PSND_CL_CHAIN_BWD', str(chain))
+        model.zero_grad()
+        m = mag.clone().requires_grad_(True)
+        out = model(m)
+        (out - tgt).abs().mean().backward()
+        return out.detach().clone(), m.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    o1, gm1, g1 = run(True)
+    o0, gm0, g0 = run(False)
+    assert torch.equal(o1, o0)
+    assert torch.equal(gm1, gm0)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert relf(g1[k], g0[k]) < 2e-5, (k, relf(g1[k], g0[k]))
+
+
 @pytest.mark.parametrize('env', [None, 'PSND_NO_BODY_NODE', 'PSND_NO_BLOCK_STACK', 'PSND_NO_BLOCK_NODE'])
 def test_separator_input_gradient_and_node_granularities(env, monkeypatch):
     """the separator body as one autograd node (default), as head / block-stack / tail nodes, one node per block, one node per conv:
@@ -248,10 +324,21 @@ def _pair_stats(reset=False):
     return list(out)
 
 
-def test_separator_bench_shape_vs_bf16_emulation():
+def _chain_stats():
+    import ctypes
+    from pytorch_sound_amd._lib import lib
+    out = (ctypes.c_longlong * 2)()
+    lib().psnd_conv_chain_stats(ctypes.addressof(out))
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize('launches', ['chain', 'pair'])
+def test_separator_bench_shape_vs_bf16_emulation(launches, monkeypatch):
     """BASELINE config 2 at the BENCH shape: registered `conv_separator_voicebank` (256 channels, 4 blocks) on 32 clips x 513 bins x
-    173 frames - the launch instances the bench runs (32-row pair-forward tiles, the pair backward with its N * L dependent
-    weight-gradient split: both asserted through psnd_conv_pair_stats) - against tests/bf16_emul.py: the same arithmetic with the
+    173 frames - the launch instances the bench runs ('chain': one psnd_conv1d_cl_chain launch per ResBlock1 forward, the masked chain
+    for the input gradients, all weight gradients in one psnd_conv1d_cl_wgrad_multi launch; 'pair', PSND_CL_CHAIN=0 PSND_CL_BWD_BATCH=0:
+    32-row pair-forward tiles, the pair backward with its N * L dependent weight-gradient split; asserted through
+    psnd_conv_chain_stats / psnd_conv_pair_stats) - against tests/bf16_emul.py: the same arithmetic with the
     kernels' rounding points (bf16 operands, fp32 accumulation) in plain torch, NOT another arrangement of the same kernels.
     Output, input gradient, every parameter gradient.  Measured: out 1.3e-4, params(all) 6.2e-4, worst single tensor 1.5e-3,
     input gradient 8.7e-3 (one-ulp differences flip leaky' masks); vs the fp32 formulation 4e-4 / 2.3e-3 / 5.5e-3."""
@@ -272,13 +359,23 @@ def test_separator_bench_shape_vs_bf16_emulation():
         torch.nn.functional.l1_loss(out, tgt).backward()
         return out.detach().clone(), (m.grad.clone() if need_gx else None), {k: p.grad.clone() for k, p in model.named_parameters()}
 
+    if launches == 'pair':
+        monkeypatch.setenv('PSND_CL_CHAIN', '0')
+        monkeypatch.setenv('PSND_CL_BWD_BATCH', '0')
     _pair_stats(reset=True)
+    c0 = _chain_stats()
     got = run(model, False)                                   # the bench's path: mask head fused (psnd_mask_head_*), no input gradient
-    st = _pair_stats()
-    # 12 residual pairs: forward launches on 32-row tiles (95 64-row tiles would not fill the chip), 12 pair backward launches,
-    # 7 weight-gradient row ranges at 32 x 213 padded rows
-    assert st[0] == 12 and st[1] == 0 and st[2] == 12, st
-    assert st[3] == 7, st
+    st, c1 = _pair_stats(), _chain_stats()
+    if launches == 'pair':
+        # 12 residual pairs: forward launches on 32-row tiles (95 64-row tiles would not fill the chip), 12 pair backward launches,
+        # 7 weight-gradient row ranges at 32 x 213 padded rows
+        assert st[0] == 12 and st[1] == 0 and st[2] == 12, st
+        assert st[3] == 7, st
+        assert c1 == c0
+    else:
+        # 4 forward + 4 input-gradient chain launches of 3 pairs each, no pair launch left
+        assert (c1[0] - c0[0], c1[1] - c0[1]) == (8, 24), (c0, c1)
+        assert st[0] == 0 and st[1] == 0 and st[2] == 0, st
     got_gx = run(model, True)                                 # with the input gradient (layout kernel + torch sigmoid head)
     emul = run(lambda m: E.separator(model, m), True)
 
