@@ -230,6 +230,8 @@ int psnd_mel_l1_fwd(const float *mag, int64_t N, int64_t F, int M, int K, const 
 int psnd_mel_l1_bwd(const float *ref, const float *mel_lin, const float *g, float coef, int64_t N, int64_t F, int M, int K,
                     const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
                     float *gmag, void *stream);
+/* flag[0] = 1.0 if any of x[0 .. n) is NaN, else 0.0 - the device-side form of the trainer's `loss != loss` (trainer.py:205) */
+int psnd_nan_flag(const float *x, int64_t n, float *flag, void *stream);
 int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream);
 int psnd_conv_stats(int64_t *out4, int reset);
 /* the same for the residual-pair launches: out4 = { psnd_conv1d_cl_pair launches with 32-row tiles, with 64-row tiles,

@@ -138,6 +138,7 @@ class MaskHeadSpectralL1CL(torch.autograd.Function):
     def forward(ctx, y, mag, mag_ref, mel_ref, mel_plan, shape, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, w1, w2):
         import ctypes
         from .kernels import _clamp_args
+        ctx.set_materialize_grads(False)             # `est` (no gradient of its own) must not cost a zero fill of its size in backward
         _need(y, torch.bfloat16)
         for t in (mag, mag_ref, mel_ref):
             _need(t, torch.float32)
@@ -174,6 +175,8 @@ class MaskHeadSpectralL1CL(torch.autograd.Function):
         y, mag, mag_ref, mel_ref, mel_plan, est, lin = ctx.saved_tensors
         shape, M, log_kind, log_offset, pre, lo, hi, c1, c2 = ctx.cfg
         N, C, T = mag.shape
+        if g is None:
+            return (None,) * 14
         g = g.contiguous().float()
         gest = torch.empty_like(mag)
         gy = torch.empty_like(y)

@@ -317,6 +317,24 @@ extern "C" int psnd_l1_loss_bwd_w(const float *a, const float *b, int64_t n, con
     return PSND_OK;
 }
 
+// flag[0] = 1 if any of x[0 .. n) is NaN else 0 (one workgroup; n is a loss value or a handful of them): the trainer's device-side
+// "loss != loss" (trainer.py:205) as ONE launch instead of torch.isnan + a dtype cast
+namespace {
+__global__ __launch_bounds__(64) void nan_flag_kernel(const float *x, long long n, float *flag) {
+    bool bad = false;
+    for (long long i = threadIdx.x; i < n; i += 64) bad |= x[i] != x[i];
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+    if (threadIdx.x == 0) flag[0] = any ? 1.f : 0.f;
+}
+}  // namespace
+extern "C" int psnd_nan_flag(const float *x, int64_t n, float *flag, void *stream) {
+    if (!x || !flag) PSND_FAIL(PSND_E_ARG, "nan_flag: null pointer");
+    if (n < 0) PSND_FAIL(PSND_E_SHAPE, "nan_flag: n=%lld", (long long)n);
+    hipLaunchKernelGGL(nan_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), x, (long long)n, flag);
+    PSND_CHECK_LAUNCH("nan_flag");
+    return PSND_OK;
+}
+
 // out[0] = sum_i scale[i] * sum(parts[i][0 .. nb[i])): folds the partial sums that fused producers leave (psnd_mask_head_l1_fwd,
 // psnd_mel_l1_fwd, psnd_l1_loss_fwd's own partials) into one loss value; scale[i] = weight_i / numel_i; 1 .. 4 terms
 extern "C" int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream) {

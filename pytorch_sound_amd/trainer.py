@@ -339,11 +339,34 @@ class Trainer:
                 keep.append((step, host_flag, event))
         self._nan_pending = keep
 
+    @staticmethod
+    def _nan_flag(loss: torch.Tensor) -> torch.Tensor:
+        """fp32 scalar on the loss's device: 1 if the loss is NaN (`loss != loss`, trainer.py:205) - one launch (psnd_nan_flag) for an
+        fp32 loss on the GPU, torch.isnan + cast otherwise"""
+        x = loss.detach()
+        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+            from ._lib import lib, ptr, stream_ptr, check
+            flag = torch.empty((), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                check(lib().psnd_nan_flag(ptr(x), x.numel(), ptr(flag), stream_ptr(x.device)), 'psnd_nan_flag')
+            return flag
+        return torch.isnan(x).any().to(torch.float32).reshape(())
+
+    def _backward(self, loss: torch.Tensor):
+        """loss.backward() with a persistent root gradient (autograd's own ones_like is a fill launch per step)"""
+        if loss.dim() == 0 and loss.is_cuda and loss.dtype == torch.float32:
+            one = getattr(self, '_root_grad', None)
+            if one is None or one.device != loss.device:
+                one = self._root_grad = torch.ones((), dtype=torch.float32, device=loss.device)
+            loss.backward(gradient=one)
+        else:
+            loss.backward()
+
     def _train_device_skip(self, step: int, loss: torch.Tensor):
-        flag = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+        flag = self._nan_flag(loss)
         if self._reducer is not None and pdist.is_dist():
             self._reducer.set_flag(flag)               # rides along with the last gradient bucket
-        loss.backward()
+        self._backward(loss)
         self._finish_device_skip(step, flag)
 
     def _loss_is_nan(self, loss: torch.Tensor) -> bool:
@@ -425,6 +448,8 @@ class Trainer:
             from . import cl
             cl.AUTO_SECTIONS = False                   # see cl.py: no batch-section branches next to other live streams
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
+        if getattr(self, '_root_grad', None) is None or self._root_grad.device != st['inputs'][0].device:
+            self._root_grad = torch.ones((), dtype=torch.float32, device=st['inputs'][0].device)   # not inside the capture
         while True:
             for p in params:
                 p.grad = None                          # backward then WRITES its gradients (no zero fill, no += kernels)
@@ -436,12 +461,12 @@ class Trainer:
                 # thread captures ("operation not permitted when stream is capturing" under the default global mode)
                 with torch.cuda.graph(graph, capture_error_mode='thread_local' if red is not None else 'global'):
                     loss, _ = self.forward(*st['inputs'], is_logging=False)
-                    st['flag'] = torch.isnan(loss.detach()).to(torch.float32).reshape(())
+                    st['flag'] = self._nan_flag(loss)
                     if mode in ('events', 'capture'):
                         red.capture_begin(st['flag'], mode)   # the captured backward fills and releases the buckets itself
                     elif red is not None:
                         red.deferred = True            # no collective from inside the captured backward
-                    loss.backward()
+                    self._backward(loss)
                     if mode in ('events', 'capture'):
                         red.capture_end()
             except Exception as e:                     # noqa: BLE001 - e.g. a runtime that cannot capture the release nodes
@@ -490,13 +515,6 @@ class Trainer:
                 grad_scale = self._world_scale
         elif self._reducer is not None:
             self._reducer.finish()
-        host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
-        host_flag.copy_(flag, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record()
-        if not hasattr(self, '_nan_pending'):
-            self._nan_pending = []
-        self._nan_pending.append((step, host_flag, event))
         if fused_clip:
             self.optimizer.fused_clip = (self.grad_clip, self.grad_norm)
         else:
@@ -510,6 +528,14 @@ class Trainer:
             del self.optimizer.grad_scale
             if fused_clip:
                 del self.optimizer.fused_clip
+        # the flag goes to the host BEHIND the optimizer launch (which reads it on the device): the copy is off the step's critical path
+        host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
+        host_flag.copy_(flag, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        if not hasattr(self, '_nan_pending'):
+            self._nan_pending = []
+        self._nan_pending.append((step, host_flag, event))
         self._poll_nan_log()
 
     def train(self, step: int):
