@@ -97,42 +97,15 @@ __device__ __forceinline__ float l1_log_grad(float mel, float ref, int kind, flo
     return sg * pass * d;
 }
 
-template <bool BWD>
-__device__ __forceinline__ f32x4 load_b(const MelParams &p, const float *in0, const float *in1, int c, long long f,
-                                        long long F) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (c >= p.Cc) return v;
-    const size_t o = (size_t)c * F + f;
-    if (f + 3 < F) {
-        v = *reinterpret_cast<const f32x4_u *>(in0 + o);
-        if constexpr (BWD) {
-            const f32x4 m = *reinterpret_cast<const f32x4_u *>(in1 + o);
-            if (p.l1_g) {                                                  // uniform: in0 is the L1 target
-                const float c = p.l1_coef * p.l1_g[0];
-                v.x = c * l1_log_grad(m.x, v.x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                v.y = c * l1_log_grad(m.y, v.y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                v.z = c * l1_log_grad(m.z, v.z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                v.w = c * l1_log_grad(m.w, v.w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                return v;
-            }
-            v.x *= log_grad(m.x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-            v.y *= log_grad(m.y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-            v.z *= log_grad(m.z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-            v.w *= log_grad(m.w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-        }
-    } else {
-        float t[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < 4; ++j)
-            if (f + j < F) {
-                t[j] = in0[o + j];
-                if constexpr (BWD) {
-                    if (p.l1_g) t[j] = p.l1_coef * p.l1_g[0] * l1_log_grad(in1[o + j], t[j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                    else t[j] *= log_grad(in1[o + j], p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
-                }
-            }
-        v.x = t[0], v.y = t[1], v.z = t[2], v.w = t[3];
-    }
-    return v;
+// B operand of one k-step: 4 consecutive frames of reduction row c, as a BRANCH-FREE buffer load (an out-of-range row, or a lane whose
+// frames lie past the clip, reads zeros through the descriptor's range check).  A lane whose 4 frames straddle the end of the row
+// reads the first frames of the next row - harmless: MFMA output columns are independent and frames >= F are never stored.
+// (The first version tested `f + 3 < F` per lane with a scalar tail: every load sat in its own basic block, hipcc waited for each
+// one where it was issued, and a wave walked its band with ONE load in flight - 14.5 us per launch at 32 AND at 64 clips, whatever
+// the batch size MU.)
+__device__ __forceinline__ f32x4 load_b_raw(__amdgpu_buffer_rsrc_t r, int c, int Cc, long long f, long long F) {
+    const unsigned off = (c < Cc && f < F) ? (unsigned)(((size_t)c * F + f) * sizeof(float)) : 0xffffffffu;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
 
 template <bool BWD>
@@ -150,22 +123,45 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
 
     const int lo = p.plan[p.band_off + 2 * rt], hi = p.plan[p.band_off + 2 * rt + 1];
     const float *W = reinterpret_cast<const float *>(p.plan) + p.w_off + (size_t)rt * p.CS * 64 + lane;
-    const float *in0 = p.in0 + (size_t)clip * p.Cc * F;
-    const float *in1 = BWD ? p.in1 + (size_t)clip * p.Cc * F : nullptr;
+    const int in_bytes = (int)((size_t)p.Cc * F * sizeof(float));
+    const __amdgpu_buffer_rsrc_t r0 = make_uniform_rsrc(p.in0 + (size_t)clip * p.Cc * F, in_bytes);
+    const __amdgpu_buffer_rsrc_t r1 = make_uniform_rsrc(BWD ? p.in1 + (size_t)clip * p.Cc * F : p.in0, BWD ? in_bytes : 0);
+    const bool l1b = BWD && p.l1_g != nullptr;                                  // uniform: in0 is the L1 target
+    const float l1c = l1b ? p.l1_coef * p.l1_g[0] : 0.f;
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    // the band is walked in batches of MU k-steps with all 2 * MU loads of a batch in flight (the first version prefetched one
-    // step ahead: a ~100-step latency chain per wave on the widest mel tiles - 26 us per launch at 32 clips, where the grid is
-    // only 480 waves and nothing hides it)
-    constexpr int MU = 8;
+    // the band is walked in batches of MU k-steps with all loads of a batch in flight
+#ifndef PSND_MEL_MU
+#define PSND_MEL_MU 8
+#endif
+    constexpr int MU = PSND_MEL_MU;
     for (int s0 = lo; s0 < hi; s0 += MU) {
         float a[MU];
-        f32x4 b[MU];
+        f32x4 b[MU], m[BWD ? MU : 1];
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
-            const bool ok = s0 + u < hi;                               // uniform
-            a[u] = ok ? W[(size_t)(s0 + u) * 64] : 0.f;
-            b[u] = ok ? load_b<BWD>(p, in0, in1, 4 * (s0 + u) + kk, f, F) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int c = s0 + u < hi ? 4 * (s0 + u) + kk : p.Cc;       // past the band: an out-of-range row (zeros)
+            a[u] = W[(size_t)min(s0 + u, hi - 1) * 64];
+            b[u] = load_b_raw(r0, c, p.Cc, f, F);
+            if constexpr (BWD) m[u] = load_b_raw(r1, c, p.Cc, f, F);
+        }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                if (l1b) {
+                    b[u].x = l1c * l1_log_grad(m[u].x, b[u].x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].y = l1c * l1_log_grad(m[u].y, b[u].y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].z = l1c * l1_log_grad(m[u].z, b[u].z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].w = l1c * l1_log_grad(m[u].w, b[u].w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                } else {
+                    b[u].x *= log_grad(m[u].x, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].y *= log_grad(m[u].y, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].z *= log_grad(m[u].z, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                    b[u].w *= log_grad(m[u].w, p.log_kind, p.log_offset, p.pre_clamp_min, p.clamp_lo, p.clamp_hi);
+                }
+                // a row past the band / the matrix contributes nothing even where the gradient of zero is not zero
+                if (!(s0 + u < hi && 4 * (s0 + u) + kk < p.Cc)) b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
@@ -305,6 +301,8 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     if (M <= 0 || K <= 0 || N < 0 || F < 0) PSND_FAIL(PSND_E_SHAPE, "mel: M=%d K=%d N=%lld F=%lld", M, K, (long long)N, (long long)F);
     if (log_kind < PSND_LOG_NONE || log_kind > PSND_LOG_10) PSND_FAIL(PSND_E_ARG, "mel: log_kind=%d", log_kind);
     if (N == 0 || F == 0) return PSND_OK;
+    if ((size_t)(M > K ? M : K) * (size_t)F * sizeof(float) >= ((size_t)1 << 31))
+        PSND_FAIL(PSND_E_SHAPE, "mel: a clip of %lld frames exceeds the 2 GB buffer range of one clip's operand", (long long)F);
     const MelHostPlan h = mel_layout(M, K);
     MelParams p;
     p.in0 = in0, p.in1 = in1, p.plan = static_cast<const int *>(plan), p.out = out, p.lin = lin;
