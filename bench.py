@@ -414,8 +414,47 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
                                             ptr(gx), ptr(act), ptr(gwa), ptr(gba), ptr(g2), ptr(x), -3, 3, ptr(gwb), ptr(gbb), st),
               'psnd_conv1d_cl_pair_bwd')
 
+    # ---- the launches the step runs since round 3 (cl.py: _chain_pairs, batched backward): a ResBlock1 (three residual pairs, dilations
+    # 1 / 3 / 5) forward as ONE launch, its input gradients as ONE masked launch, the weight gradients of all 24 body convs as ONE launch
+    import ctypes
+    from pytorch_sound_amd import _lib
+    ws = [(torch.randn(k, C, C, device=device) * 0.05).to(torch.bfloat16) for _ in range(6)]
+    outs = [[torch.empty_like(x) for _ in range(3)] for _ in range(3)]
+
+    def chain_desc(masked):
+        arr = (_lib.ChainPair * 3)()
+        for i, (d, dd) in enumerate(zip(arr, (1, 3, 5))):
+            d.W1, d.bias1, d.act1_slope, d.mid_out = ws[2 * i].data_ptr(), None if masked else bias.data_ptr(), 1.0 if masked else 0.1, outs[i][0].data_ptr()
+            d.W2, d.bias2, d.off1, d.dstep1, d.off2, d.dstep2 = ws[2 * i + 1].data_ptr(), None if masked else bias.data_ptr(), -dd, dd, -1, 1
+            d.act2_slope, d.out_raw, d.out_act = (1.0 if masked else 0.1), outs[i][1].data_ptr(), None if masked else outs[i][2].data_ptr()
+            if masked:
+                d.M1, d.M2, d.m1_slope, d.m2_slope = act.data_ptr(), x.data_ptr(), 0.1, 0.1
+        return arr
+    arr_f, arr_b = chain_desc(False), chain_desc(True)
+
+    def fwd_chain():
+        check(lib().psnd_conv1d_cl_chain(ptr(x), ptr(g2), ctypes.addressof(arr_f), 3, N, Lp, Fr, HP, C, k, st), 'psnd_conv1d_cl_chain')
+
+    def bwd_chain():
+        check(lib().psnd_conv1d_cl_chain(ptr(g1), ptr(g1), ctypes.addressof(arr_b), 3, N, Lp, Fr, HP, C, k, st), 'psnd_conv1d_cl_chain')
+
+    NW = 24
+    Sm = lib().psnd_conv1d_cl_wgrad_multi_splits(N, Lp, C, C, k, NW)
+    gs = [torch.randn(N, Lp, C, device=device).to(torch.bfloat16) for _ in range(NW)]
+    xs = [torch.randn(N, Lp, C, device=device).to(torch.bfloat16) for _ in range(NW)]
+    gwm = [torch.empty(Sm, k, C, C, device=device) for _ in range(NW)]
+    gbm = [torch.empty(Sm, C, device=device) for _ in range(NW)]
+    wd = (_lib.WgradDesc * NW)()
+    for i, d in enumerate(wd):
+        dd = (1, 1, 3, 1, 5, 1)[i % 6]
+        d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = gs[i].data_ptr(), xs[i].data_ptr(), gwm[i].data_ptr(), gbm[i].data_ptr(), -dd, dd
+
+    def wgrad_multi():
+        check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(wd), NW, N, Lp, C, C, k, st), 'psnd_conv1d_cl_wgrad_multi')
+
     res = {}
-    for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2), ('backward_pair2', bwd_pair2, 4)):
+    for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2), ('backward_pair2', bwd_pair2, 4),
+                           ('forward_chain', fwd_chain, 6), ('input_gradient_chain', bwd_chain, 6), ('weight_gradients_24', wgrad_multi, NW)):
         for _ in range(5):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -425,14 +464,18 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / iters * 1e-3
-        flops = gemms * 2.0 * N * Fr * C * C * k
+        flops = gemms * 2.0 * N * Fr * C * C * k          # algorithmic: the rims a chain launch recomputes are not counted
         res[name] = {'launch_us': t * 1e6, 'flops_per_launch': flops, 'achieved': flops / t / 1e12, 'frac': flops / t / MFMA_BF16_PEAK}
+    # the body's 24 convs per step: 4 forward chains + 4 input-gradient chains + one weight-gradient launch = 72 GEMMs
+    t_body = 4 * res['forward_chain']['launch_us'] + 4 * res['input_gradient_chain']['launch_us'] + res['weight_gradients_24']['launch_us']
+    f_body = 72 * 2.0 * N * Fr * C * C * k
     return {'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_BF16_PEAK / 1e12, 'dtype': 'bf16 operands, fp32 accumulate',
-            'kernel': 'conv_pair_bwd_kernel (backward of a residual pair in one launch: both input gradients chained + two weight gradients = '
-                      'four 256->256 k=3 GEMMs: backward_pair2, 36 % of the step) / conv_pair_kernel (forward of a pair: forward_pair) / '
-                      'conv_cl_kernel / conv_bwd_pair_kernel (one conv) of the config-2 model - 2.2 GFLOP per GEMM on 3 MB of activations: '
-                      'latency chains per workgroup, DESIGN.md 4.4',
-            'achieved': res['backward_pair2']['achieved'], 'frac': res['backward_pair2']['frac'], **res}
+            'kernel': 'the conv body of the config-2 model as the step runs it (cl.py): conv_chain_kernel<..., false> (a ResBlock1 = three residual '
+                      'pairs forward in one launch: forward_chain), conv_chain_kernel<..., true> (their input gradients: input_gradient_chain), '
+                      'conv_wgrad_multi_kernel (the weight gradients of all 24 body convs in one launch: weight_gradients_24) - 2.2 GFLOP per '
+                      '256->256 k=3 GEMM on 3 MB of activations; achieved / frac = the 72 GEMMs of the body over 4 + 4 + 1 such launches back '
+                      'to back; the round-2 launches (forward_pair, backward_pair2, ...) are timed beside them.  DESIGN.md 4.4',
+            'achieved': f_body / (t_body * 1e-6) / 1e12, 'frac': f_body / (t_body * 1e-6) / MFMA_BF16_PEAK, 'body_us': t_body, **res}
 
 
 def _event_pair_overhead(device, n=40):

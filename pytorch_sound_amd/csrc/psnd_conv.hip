@@ -443,42 +443,71 @@ __global__ __launch_bounds__(256, (D == 1 ? 3 : PSND_CONV_OCC)) void conv_cl_ker
 // to_cl: optional pre-op  0: none, 1: log1p(x)
 // MASKBWD: the backward of the mask head below: out = x * mul * s * (1 - s), s = sigmoid(ycl) read at the output position
 // MASKBWD with l1_est: x (may be NULL) + coef * g[0] * sign(est - ref) is the gradient on the mask head's output (fused F.l1_loss(est, ref))
+// All loads are branch-free buffer loads (an element outside the tensor reads zero through the descriptor's range check) and a thread
+// issues its four elements' loads together: with `if (in range) v = x[o]` every load sat in its own basic block and a thread walked
+// its four elements as four dependent round trips (15-19 us per launch at 32 x 513 x 173 for 17 MB of traffic).
 template <bool MASKBWD>
 __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out, int N, int C, int T, int Lp, int HP, int Cp,
                                                     int preop, const float *mul, const bf16_t *ycl, const float *l1_est = nullptr,
                                                     const float *l1_ref = nullptr, const float *l1_g = nullptr, float l1_coef = 0.f) {
     // tile 32 (t) x 32 (c) through LDS so both sides are coalesced
     __shared__ float tile[32][33];
+    constexpr unsigned OOBW = 0xffffffffu;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
     const int n = blockIdx.z;
     const int t0 = blockIdx.x * 32 - HP, c0 = blockIdx.y * 32;  // rows of the CL buffer: l = t + HP
-    for (int j = ty; j < 32; j += 8) {
-        const int c = c0 + j, t = t0 + tx;
-        float v = 0.f;
-        if (c < C && t >= 0 && t < T) {
-            const size_t o = ((size_t)n * C + c) * T + t;
-            v = x ? x[o] : 0.f;
-            if (preop == 1) v = log1pf(v);
-            if constexpr (MASKBWD) {
-                if (l1_est) {
-                    const float d = l1_est[o] - l1_ref[o];
-                    v += l1_coef * l1_g[0] * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-                }
-                v *= mul[o];
-            }
+    const size_t clip = (size_t)n * C * T;
+    const int cb = (int)((size_t)C * T * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rx = make_uniform_rsrc(x ? x + clip : reinterpret_cast<const float *>(out), x ? cb : 0);
+    const bool l1 = MASKBWD && l1_est != nullptr;               // uniform
+    const __amdgpu_buffer_rsrc_t rm = make_uniform_rsrc(MASKBWD ? mul + clip : reinterpret_cast<const float *>(out), MASKBWD ? cb : 0);
+    const __amdgpu_buffer_rsrc_t re = make_uniform_rsrc(l1 ? l1_est + clip : reinterpret_cast<const float *>(out), l1 ? cb : 0);
+    const __amdgpu_buffer_rsrc_t rr = make_uniform_rsrc(l1 ? l1_ref + clip : reinterpret_cast<const float *>(out), l1 ? cb : 0);
+    const float l1c = l1 ? l1_coef * l1_g[0] : 0.f;
+    float v[4], m[4], e[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, t = t0 + tx;
+        const unsigned o = (c < C && t >= 0 && t < T) ? (unsigned)(((size_t)c * T + t) * sizeof(float)) : OOBW;
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)o, 0, 0));
+        if constexpr (MASKBWD) {
+            m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)o, 0, 0));
+            e[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, (int)o, 0, 0));
+            r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)o, 0, 0));
         }
-        tile[j][tx] = v;
+    }
+    // the sigmoid's argument at the OUTPUT positions of this thread: requested now as well
+    unsigned short yq[MASKBWD ? 4 : 1];
+    if constexpr (MASKBWD) {
+        const __amdgpu_buffer_rsrc_t ry = make_uniform_rsrc(ycl + (size_t)n * Lp * Cp, (int)((size_t)Lp * Cp * sizeof(bf16_t)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = blockIdx.x * 32 + ty + 8 * i, c = c0 + tx;
+            yq[i] = __builtin_amdgcn_raw_buffer_load_b16(ry, (l < Lp && c < Cp) ? (unsigned)(((size_t)l * Cp + c) * sizeof(bf16_t)) : OOBW, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float w = v[i];
+        if (preop == 1) w = log1pf(w);
+        if constexpr (MASKBWD) {
+            const float d = e[i] - r[i];
+            w += l1c * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            w *= m[i];
+        }
+        tile[ty + 8 * i][tx] = w;
     }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8) {
-        const int l = blockIdx.x * 32 + j, c = c0 + tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = ty + 8 * i, l = blockIdx.x * 32 + j, c = c0 + tx;
         if (l < Lp && c < Cp) {
-            float v = tile[tx][j];
+            float w = tile[tx][j];
             if constexpr (MASKBWD) {
-                const float sg = 1.f / (1.f + __expf(-bf2f(ycl[((size_t)n * Lp + l) * Cp + c])));
-                v *= sg * (1.f - sg);
+                const float sg = 1.f / (1.f + __expf(-bf2f(yq[i])));
+                w *= sg * (1.f - sg);
             }
-            out[((size_t)n * Lp + l) * Cp + c] = f2bf(v);
+            out[((size_t)n * Lp + l) * Cp + c] = f2bf(w);
         }
     }
 }
@@ -489,25 +518,48 @@ template <bool MASK>
 __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp,
                                                       const float *mul, const float *l1_ref = nullptr, double *l1_part = nullptr) {
     __shared__ float tile[32][33];
+    constexpr unsigned OOBW = 0xffffffffu;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int n = blockIdx.z;
     const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    for (int j = ty; j < 32; j += 8) {
-        const int t = t0 + j, c = c0 + tx;
-        float v = 0.f;
-        if (t < T && c < Cp) v = bf2f(x[((size_t)n * Lp + t + HP) * Cp + c]);
+    const size_t clip = (size_t)n * C * T;
+    const int cb = (int)((size_t)C * T * sizeof(float));
+    const __amdgpu_buffer_rsrc_t rx = make_uniform_rsrc(x + (size_t)n * Lp * Cp, (int)((size_t)Lp * Cp * sizeof(bf16_t)));
+    const bool l1 = MASK && l1_ref != nullptr;
+    const __amdgpu_buffer_rsrc_t rm = make_uniform_rsrc(MASK ? mul + clip : out, MASK ? cb : 0);
+    const __amdgpu_buffer_rsrc_t rr = make_uniform_rsrc(l1 ? l1_ref + clip : out, l1 ? cb : 0);
+    unsigned short xq[4];
+    float m[4], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, c = c0 + tx;
+        xq[i] = __builtin_amdgcn_raw_buffer_load_b16(rx, (t < T && c < Cp) ? (unsigned)(((size_t)(t + HP) * Cp + c) * sizeof(bf16_t)) : OOBW, 0, 0);
+    }
+    if constexpr (MASK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, t = t0 + tx;
+            const unsigned o = (c < C && t < T) ? (unsigned)(((size_t)c * T + t) * sizeof(float)) : OOBW;
+            m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)o, 0, 0));
+            r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)o, 0, 0));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = bf2f(xq[i]);
         if constexpr (MASK) v = 1.f / (1.f + __expf(-v));
-        tile[j][tx] = v;
+        tile[ty + 8 * i][tx] = v;
     }
     __syncthreads();
     float l1acc = 0.f;
-    for (int j = ty; j < 32; j += 8) {
-        const int c = c0 + j, t = t0 + tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = ty + 8 * i, c = c0 + j, t = t0 + tx;
         if (c < C && t < T) {
-            const size_t o = ((size_t)n * C + c) * T + t;
-            const float v = MASK ? tile[tx][j] * mul[o] : tile[tx][j];
+            const size_t o = clip + (size_t)c * T + t;
+            const float v = MASK ? tile[tx][j] * m[i] : tile[tx][j];
             out[o] = v;
-            if (MASK && l1_ref) l1acc += fabsf(v - l1_ref[o]);
+            if (l1) l1acc += fabsf(v - r[i]);
         }
     }
     if (MASK && l1_part) {
@@ -1394,7 +1446,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
 extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out,
                           void *stream) {
     if (!x || !out) PSND_FAIL(PSND_E_ARG, "to_cl: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "to_cl: Lp=%d T=%lld HP=%d Cp=%d C=%d", Lp, (long long)T, HP, Cp, C);
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "to_cl: Lp=%d T=%lld HP=%d Cp=%d C=%d", Lp, (long long)T, HP, Cp, C);
     if (N == 0) return PSND_OK;
     dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(to_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<bf16_t *>(out),
@@ -1405,7 +1457,7 @@ extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, i
 
 extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream) {
     if (!x || !out) PSND_FAIL(PSND_E_ARG, "from_cl: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "from_cl: bad shape");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "from_cl: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(from_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
@@ -1419,7 +1471,7 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
 extern "C" int psnd_mask_head_fwd(const void *y, const float *mag, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *est,
                                   void *stream) {
     if (!y || !mag || !est) PSND_FAIL(PSND_E_ARG, "mask_head_fwd: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_fwd: bad shape");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "mask_head_fwd: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(from_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(y), est,
@@ -1438,7 +1490,7 @@ extern "C" int64_t psnd_mask_head_l1_blocks(int64_t N, int64_t T, int Cp) {
 extern "C" int psnd_mask_head_l1_fwd(const void *y, const float *mag, const float *ref, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
                                      float *est, double *part, void *stream) {
     if (!y || !mag || !ref || !est || !part) PSND_FAIL(PSND_E_ARG, "mask_head_l1_fwd: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_fwd: bad shape");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_fwd: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(from_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(y), est,
@@ -1449,7 +1501,7 @@ extern "C" int psnd_mask_head_l1_fwd(const void *y, const float *mag, const floa
 extern "C" int psnd_mask_head_l1_bwd(const float *gest, const float *mag, const void *y, const float *est, const float *ref, const float *g,
                                      float coef, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, void *gy, void *stream) {
     if (!mag || !y || !est || !ref || !g || !gy) PSND_FAIL(PSND_E_ARG, "mask_head_l1_bwd: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_bwd: bad shape");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "mask_head_l1_bwd: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(to_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), gest, static_cast<bf16_t *>(gy), (int)N, C,
@@ -1461,7 +1513,7 @@ extern "C" int psnd_mask_head_l1_bwd(const float *gest, const float *mag, const 
 extern "C" int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64_t N, int C, int64_t T, int Lp, int HP, int Cp,
                                   void *gy, void *stream) {
     if (!gest || !mag || !y || !gy) PSND_FAIL(PSND_E_ARG, "mask_head_bwd: null pointer");
-    if (Lp < T + 2 * HP || Cp < C || N > 65535) PSND_FAIL(PSND_E_SHAPE, "mask_head_bwd: bad shape");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "mask_head_bwd: bad shape");
     if (N == 0) return PSND_OK;
     dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
     hipLaunchKernelGGL(to_cl_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), gest, static_cast<bf16_t *>(gy), (int)N, C,
