@@ -448,9 +448,10 @@ def _conv_roofline(device, N, Fr, C=256, k=3, dil=1, iters=50):
     for i, d in enumerate(wd):
         dd = (1, 1, 3, 1, 5, 1)[i % 6]
         d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = gs[i].data_ptr(), xs[i].data_ptr(), gwm[i].data_ptr(), gbm[i].data_ptr(), -dd, dd
+        d.Ca, d.Cb, d.k, d.splits = C, C, k, Sm
 
     def wgrad_multi():
-        check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(wd), NW, N, Lp, C, C, k, st), 'psnd_conv1d_cl_wgrad_multi')
+        check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(wd), NW, N, Lp, st), 'psnd_conv1d_cl_wgrad_multi')
 
     res = {}
     for name, f, gemms in (('forward', fwd, 1), ('forward_pair', fwd_pair, 2), ('backward_pair', bwd, 2), ('backward_pair2', bwd_pair2, 4),

@@ -173,16 +173,18 @@ int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const
                         void *mid_out, const void *W2, const float *bias2, const void *M2, float m2_slope, const void *res,
                         int64_t N, int Lp, int L, int HP, int C, int k, int off1, int dstep1, int off2, int dstep2,
                         float act2_slope, void *out_raw, void *out_act, void *stream);
-/* The weight gradients of n (<= 32) convs of ONE shape (Ca -> Cb channels, k taps, the same N x Lp rows) in one launch: per conv the
- * operands and slabs of psnd_conv1d_cl_wgrad with a plain gradient (g = the conv's combined output gradient, xa = its activated input,
- * taps off0 + j * dstep; gbias_part may be NULL), every conv with psnd_conv1d_cl_wgrad_multi_splits(N, Lp, Ca, Cb, k, n) slabs. */
+/* The weight gradients of n (<= 32) convs over the same N x Lp rows in one launch: per conv the operands and slabs of psnd_conv1d_cl_wgrad
+ * with a plain gradient (g = the conv's combined output gradient (N, Lp, Cb), xa = its activated input (N, Lp, Ca), taps off0 + j * dstep;
+ * gbias_part may be NULL) and `splits` row ranges = slabs.  psnd_conv1d_cl_wgrad_multi_splits(N, Lp, Ca, Cb, k, n): the number to use for n
+ * convs of that shape; convs of another shape in the same launch (a model's head / tail) take the same number. */
 typedef struct psnd_wgrad_desc {
     const void *g, *xa;
     float *gw_part, *gbias_part;
     int off0, dstep;
+    int Ca, Cb, k, splits;
 } psnd_wgrad_desc;
 int psnd_conv1d_cl_wgrad_multi_splits(int64_t N, int Lp, int Ca, int Cb, int k, int n_convs);
-int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, int Ca, int Cb, int k, void *stream);
+int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, void *stream);
 /* A CHAIN of such pairs in one launch (csrc/psnd_conv_chain.hip; forward only: no masks): the pairs of a ResBlock1 (hifi_gan.py:56-62),
  * pair i + 1 reading the activated output and the residual stream of pair i on the chip.  Values bit-identical to n_pairs
  * psnd_conv1d_cl_pair launches; every pair's mid_out / out_raw / out_act (each may be NULL) is written as those launches would.  A, res: the
@@ -289,7 +291,8 @@ int psnd_conv1d_wnorm_bwd_multi(const psnd_wnorm_desc *descs, int n, void *strea
  * partial weight-gradient slabs gw_part / gbias_part (as psnd_conv1d_cl_wgrad), both from g = G1 + G2 * leaky'(GM); g_out (may
  * be NULL) receives the combined g for the residual branch (needs G2).  gx_mask / gx_res (CL bf16, Ca channels, may be NULL):
  * epilogue of the input gradient, gx = gx * leaky'(gx_mask; gx_mask_slope) + gx_res - i.e. the NEXT conv's combined incoming gradient
- * (its own leaky-relu derivative and the residual branch) is formed here, so that conv's backward needs no combine on load. */
+ * (its own leaky-relu derivative and the residual branch) is formed here, so that conv's backward needs no combine on load.
+ * gw_part == NULL: the input gradient alone (the weight gradient is left to psnd_conv1d_cl_wgrad_multi). */
 int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM, float g2_slope, const void *wb, const void *xa,
                        int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                        const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,

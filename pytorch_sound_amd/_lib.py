@@ -49,7 +49,7 @@ SIGNATURES = {
     'psnd_conv1d_wnorm_bwd': (_INT, [_P, _P, _INT, _P, _P, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_conv1d_cl_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _F, _P, _P, _P, _P]),
     'psnd_conv1d_cl_wgrad_multi_splits': (_INT, [_I64, _INT, _INT, _INT, _INT, _INT]),
-    'psnd_conv1d_cl_wgrad_multi': (_INT, [_P, _INT, _I64, _INT, _INT, _INT, _INT, _P]),
+    'psnd_conv1d_cl_wgrad_multi': (_INT, [_P, _INT, _I64, _INT, _P]),
     'psnd_nan_flag': (_INT, [_P, _I64, _P, _P]),
     'psnd_conv1d_cl_chain_rows': (_INT, [_INT, _INT, _INT, _P]),
     'psnd_conv1d_cl_chain': (_INT, [_P, _P, _P, _INT, _I64, _INT, _INT, _INT, _INT, _INT, _P]),
@@ -125,7 +125,8 @@ class PsndError(RuntimeError):
 
 class WgradDesc(ctypes.Structure):
     """psnd_wgrad_desc of include/psnd.h"""
-    _fields_ = [('g', _P), ('xa', _P), ('gw_part', _P), ('gbias_part', _P), ('off0', _INT), ('dstep', _INT)]
+    _fields_ = [('g', _P), ('xa', _P), ('gw_part', _P), ('gbias_part', _P), ('off0', _INT), ('dstep', _INT),
+                ('Ca', _INT), ('Cb', _INT), ('k', _INT), ('splits', _INT)]
 
 
 class ChainPair(ctypes.Structure):

@@ -847,9 +847,19 @@ class ResBlockCL(torch.autograd.Function):
                 gv, gg = torch.empty_like(v32), torch.empty_like(g32)
                 g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
                 g_here = g_out if need_gout else G1          # this conv's combined gradient (= what its residual input receives)
+                # convs outside the residual pairs (a model's head / tail) keep their own launches: with them the one weight-gradient launch
+                # grows by as much as their launches took (PSND_CL_BWD_BATCH_ENDS=1: 81 -> 122 us against 23 + 7 us saved at config 2)
+                wb_ok = batch and G2 is None and not need_gout and os.environ.get('PSND_CL_BWD_BATCH_ENDS', '0') == '1'
                 if i == 0 and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                     # the chain's input needs no gradient (features): weight gradient only
                     gx = None
+                    if wb_ok:                                  # batched backward: with all the others, in the one launch behind the chain
+                        wbatch.append((i, G1, inp, -pad, dil))
+                        keep.append(G1)
+                        if i > 0:
+                            g_comb = gx
+                        g_raw = g_act = None
+                        continue
                     plan.append((('side',) if wstreams else ()) + ('w', G1, G2, am, slope, inp, Ca, Cb, k, -pad, dil, gw, gbp, S))
                     g_raw = g_act = None
                 else:
@@ -863,6 +873,20 @@ class ResBlockCL(torch.autograd.Function):
                         ep_mask, ep_res = inp, g_here
                     else:                                      # 'c2' -> its conv1, 'tail' -> the last conv of the stack
                         ep_mask, ep_res = inp, None
+                    if wb_ok:                                  # input gradient alone here; the weight gradient joins the batch
+                        plan.append(('b', G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask,
+                                     float(steps[i - 1][7] if i > 0 else 1.0), ep_res, None, None, S))
+                        wbatch.append((i, G1, inp, -pad, dil))
+                        keep += [G1]
+                        if role == 'c2':
+                            res_pending = g_here
+                        if i > 0:
+                            g_comb = gx
+                        elif role == 'head':
+                            g_raw, g_act = None, gx
+                        else:
+                            g_raw, g_act = (res_pending if role == 'c1' else g_here), gx
+                        continue
                     plan.append(('b', G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask,
                                  float(steps[i - 1][7] if i > 0 else 1.0), ep_res, gw, gbp, S))
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
@@ -944,7 +968,8 @@ class ResBlockCL(torch.autograd.Function):
                         _, G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask, ep_slope, ep_res, gw, gbp, S = e
                         check(lib().psnd_conv1d_cl_bwd(q(G1), q(G2), q(am), float(slope), ptr(wb), q(inp), Nh, shape.Lp, shape.L,
                                                        shape.HP, Ca, Cb, k, pad, dil, q(gx), q(g_out), q(ep_mask), ep_slope, q(ep_res),
-                                                       ptr(gw[h * S:(h + 1) * S]), ptr(gbp[h * S:(h + 1) * S]), st),
+                                                       None if gw is None else ptr(gw[h * S:(h + 1) * S]),
+                                                       None if gbp is None else ptr(gbp[h * S:(h + 1) * S]), st),
                               'psnd_conv1d_cl_bwd')
 
             _run_sections(dev, nsec, sides, run)
@@ -953,14 +978,16 @@ class ResBlockCL(torch.autograd.Function):
             st = stream_ptr(dev)
             for j0 in range(0, len(wbatch), 32):
                 part = wbatch[j0:j0 + 32]
-                Ca, k = steps[part[0][0]][3], steps[part[0][0]][2]
-                Sb = lib().psnd_conv1d_cl_wgrad_multi_splits(shape.N, shape.Lp, Ca, Ca, k, len(part))
+                # row ranges: what suits the most frequent shape of the launch (the body's 256 -> 256 convs); the others take the same
+                shp = [(steps[ci][3], steps[ci][4], steps[ci][2]) for ci, _, _, _, _ in part]
+                main = max(set(shp), key=shp.count)
+                Sb = lib().psnd_conv1d_cl_wgrad_multi_splits(shape.N, shape.Lp, main[0], main[1], main[2], shp.count(main))
                 arr = (_lib.WgradDesc * len(part))()
                 for d, (ci, G, inp, off0, dstep) in zip(arr, part):
                     w = slabs(ci, G, None, None, inp, Sb)
                     d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = G.data_ptr(), inp.data_ptr(), w[11].data_ptr(), w[12].data_ptr(), off0, dstep
-                check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(part), shape.N, shape.Lp, Ca, Ca, k, st),
-                      'psnd_conv1d_cl_wgrad_multi')
+                    d.Ca, d.Cb, d.k, d.splits = steps[ci][3], steps[ci][4], steps[ci][2], Sb
+                check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(part), shape.N, shape.Lp, st), 'psnd_conv1d_cl_wgrad_multi')
             for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
                 chunk = descs[j0:j0 + 32]
                 buf = ctypes.create_string_buffer(b''.join(chunk))

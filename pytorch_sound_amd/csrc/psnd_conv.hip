@@ -1082,20 +1082,25 @@ __global__ __launch_bounds__(256, 2) void conv_pair_bwd_kernel(pairk::PairParams
 constexpr int WGRAD_MULTI_MAX = 32;
 struct WgradMultiArgs {
     WgradParams base;
-    int n, per_conv, wgx, wgy;
+    int n;
+    int blk0[WGRAD_MULTI_MAX + 1];      // first workgroup of conv i
     struct {
         const bf16_t *g, *xa;
         float *gw, *gb;
-        int off0, dstep;
+        int off0, dstep, Ca, Cb, k, rps, wgx, wgy;
     } c[WGRAD_MULTI_MAX];
 };
 __global__ __launch_bounds__(256, 2) void conv_wgrad_multi_kernel(WgradMultiArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem_dyn[];
-    const int c = blockIdx.x / a.per_conv, b = blockIdx.x - c * a.per_conv;
+    int c = 0;
+    while (c + 1 < a.n && (int)blockIdx.x >= a.blk0[c + 1]) ++c;          // uniform
+    const int b = (int)blockIdx.x - a.blk0[c];
     WgradParams w = a.base;
     w.G1 = a.c[c].g, w.xa = a.c[c].xa, w.gw = a.c[c].gw, w.gbias = a.c[c].gb, w.off0 = a.c[c].off0, w.dstep = a.c[c].dstep;
-    const int bx = b % a.wgx, r = b / a.wgx;
-    conv_wgrad_body<false>(w, bx, r % a.wgy, r / a.wgy, smem_dyn, 0);
+    w.Ca = a.c[c].Ca, w.Cb = a.c[c].Cb, w.k = a.c[c].k, w.rows_per_split = a.c[c].rps;
+    const int wgx = a.c[c].wgx, wgy = a.c[c].wgy;
+    const int bx = b % wgx, r = b / wgx;
+    conv_wgrad_body<false>(w, bx, r % wgy, r / wgy, smem_dyn, 0);
 }
 
 // ---- weight prep: weight norm (dim 0) + both bf16 packs + padded bias, one block per output channel ------
@@ -1591,7 +1596,7 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
 // Backward of one conv as a single launch (conv_bwd_pair_kernel): input gradient gx = conv(g; transposed pack wb, mirrored
 // taps) and the partial weight-gradient slabs, both from g = G1 + G2 * leaky'(GM).  Outside the paired instances (operands beyond the
 // 32-bit offsets) the two kernels are enqueued one after the other, same results.
-// ---- weight gradients of many same-shaped convs in one launch (conv_wgrad_multi_kernel) --------------------------------------------
+// ---- weight gradients of many convs in one launch (conv_wgrad_multi_kernel) -----------------------------------------------------------
 static int wgrad_multi_splits(int64_t R, int Ca, int Cb, int k, int n, int64_t *rps_out) {
     const int tiles = ((Ca + 63) / 64) * ((Cb + 63) / 64) * ((k + WKT - 1) / WKT);
     // 24 convs x 16 tiles at the config-2 size, launch alone (tools/perf_wgrad_multi.py): 1 row range per conv (384 workgroups of 184
@@ -1608,36 +1613,47 @@ static int wgrad_multi_splits(int64_t R, int Ca, int Cb, int k, int n, int64_t *
     return (int)splits;
 }
 
+// row ranges for each of n_convs convs of the launch's MAIN shape (the 256 -> 256 body convs); convs of another shape in the same launch
+// (a model's head / tail) take the same number, so that every workgroup walks the same number of row chunks
 extern "C" int psnd_conv1d_cl_wgrad_multi_splits(int64_t N, int Lp, int Ca, int Cb, int k, int n_convs) {
     if (N <= 0 || Lp <= 0 || Ca <= 0 || Cb <= 0 || k <= 0 || n_convs <= 0) return 0;
     return wgrad_multi_splits(N * (int64_t)Lp, Ca, Cb, k, n_convs, nullptr);
 }
 
-extern "C" int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, int Ca, int Cb, int k, void *stream) {
+extern "C" int psnd_conv1d_cl_wgrad_multi(const psnd_wgrad_desc *d, int n, int64_t N, int Lp, void *stream) {
     if (!d || n < 0) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad_multi: null pointer");
     if (n == 0 || N == 0) return PSND_OK;
     if (n > WGRAD_MULTI_MAX) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_wgrad_multi: %d convs (at most %d per launch)", n, WGRAD_MULTI_MAX);
-    if (N < 0 || Lp <= 0 || Ca <= 0 || Cb <= 0 || k <= 0 || Ca % 8 || Cb % 8)
-        PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: N=%lld Lp=%d Ca=%d Cb=%d k=%d", (long long)N, Lp, Ca, Cb, k);
+    if (N < 0 || Lp <= 0) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: N=%lld Lp=%d", (long long)N, Lp);
     const int64_t R = N * (int64_t)Lp;
-    if ((size_t)R * (size_t)(Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: operand larger than 2 GB");
     WgradMultiArgs a;
     memset(&a, 0, sizeof(a));
     wgrad_params_plain(a.base);
-    int64_t rps;
-    const int splits = wgrad_multi_splits(R, Ca, Cb, k, n, &rps);
-    a.base.G2 = nullptr, a.base.GM = nullptr, a.base.g_out = nullptr;
-    a.base.R = R, a.base.Ca = Ca, a.base.Cb = Cb, a.base.k = k, a.base.g2_slope = 1.f, a.base.rows_per_split = (int)rps;
-    a.wgx = (Cb + 63) / 64, a.wgy = (Ca + 63) / 64;
-    a.per_conv = a.wgx * a.wgy * splits * ((k + WKT - 1) / WKT), a.n = n;
+    a.base.G2 = nullptr, a.base.GM = nullptr, a.base.g_out = nullptr, a.base.R = R, a.base.g2_slope = 1.f;
+    a.n = n;
+    int total = 0;
     for (int i = 0; i < n; ++i) {
+        const int Ca = d[i].Ca, Cb = d[i].Cb, k = d[i].k, splits = d[i].splits;
         if (!d[i].g || !d[i].xa || !d[i].gw_part) PSND_FAIL(PSND_E_ARG, "conv1d_cl_wgrad_multi: conv %d: null pointer", i);
+        if (Ca <= 0 || Cb <= 0 || k <= 0 || k > 16 || Ca % 8 || Cb % 8 || splits < 1)
+            PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: conv %d: Ca=%d Cb=%d k=%d splits=%d", i, Ca, Cb, k, splits);
+        if ((size_t)R * (size_t)(Ca > Cb ? Ca : Cb) * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: operand larger than 2 GB");
         if ((k < WKT ? k - 1 : WKT - 1) * (d[i].dstep < 0 ? -d[i].dstep : d[i].dstep) > WXR - 32)
             PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_wgrad_multi: conv %d: dilation %d: a tap group spans more than %d rows", i, d[i].dstep, WXR - 32);
+        int64_t rps = (R + splits - 1) / splits;
+        rps = (rps + 31) / 32 * 32;
+        if (rps < 64) rps = 64;
+        if ((R + rps - 1) / rps != splits)
+            PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_wgrad_multi: conv %d: %d row ranges do not cut %lld rows (ask psnd_conv1d_cl_wgrad_multi_splits)", i, splits, (long long)R);
         a.c[i].g = static_cast<const bf16_t *>(d[i].g), a.c[i].xa = static_cast<const bf16_t *>(d[i].xa);
         a.c[i].gw = d[i].gw_part, a.c[i].gb = d[i].gbias_part, a.c[i].off0 = d[i].off0, a.c[i].dstep = d[i].dstep;
+        a.c[i].Ca = Ca, a.c[i].Cb = Cb, a.c[i].k = k, a.c[i].rps = (int)rps;
+        a.c[i].wgx = (Cb + 63) / 64, a.c[i].wgy = (Ca + 63) / 64;
+        a.blk0[i] = total;
+        total += a.c[i].wgx * a.c[i].wgy * splits * ((k + WKT - 1) / WKT);
     }
-    hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3((unsigned)(a.per_conv * n)), dim3(256), kWgradLdsBytes, static_cast<hipStream_t>(stream), a);
+    a.blk0[n] = total;
+    hipLaunchKernelGGL(conv_wgrad_multi_kernel, dim3((unsigned)total), dim3(256), kWgradLdsBytes, static_cast<hipStream_t>(stream), a);
     PSND_CHECK_LAUNCH("conv1d_cl_wgrad_multi");
     return PSND_OK;
 }
@@ -1740,8 +1756,10 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
                           Ca % 32 == 0 && Cb % 32 == 0 && L > 0 && Lp >= L + 2 * HP &&
                           (size_t)N * Lp * (Ca > Cb ? Ca : Cb) * 2 < ((size_t)1 << 32) && (size_t)k * Cb * Ca * 2 < ((size_t)1 << 32);
     if (!pairable) {
-        int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
-        if (rc != PSND_OK) return rc;
+        if (gw_part) {                           // NULL: the input gradient alone (the weight gradient is computed elsewhere: psnd_conv1d_cl_wgrad_multi)
+            int rc = psnd_conv1d_cl_wgrad(G1, G2, GM, g2_slope, xa, N, Lp, Ca, Cb, k, -pad, dil, gw_part, gbias_part, nullptr, stream);
+            if (rc != PSND_OK) return rc;
+        }
         if (gx_res && gx_res == g_out) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_bwd: residual = combined gradient outside the paired launch");
         return psnd_conv1d_cl(G1, G2, GM, g2_slope, wb, nullptr, gx_res, gx_mask, N, Lp, L, HP, Cb, Ca, k, pad, -dil, 1.f, gx_mask_slope, gx,
                               nullptr, g_out, stream);

@@ -20,7 +20,8 @@ for blocks in [int(a) for a in sys.argv[1:]] or [384, 768, 1152, 1536, 2304, 307
     for i, d in enumerate(arr):
         dil = (1, 1, 3, 1, 5, 1)[i % 6]
         d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = g[i].data_ptr(), x[i].data_ptr(), gw[i].data_ptr(), gb[i].data_ptr(), -dil, dil
-    run = lambda: check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), n, N, Lp, C, C, k, stream_ptr(dev)), 'multi')
+        d.Ca, d.Cb, d.k, d.splits = C, C, k, S
+    run = lambda: check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), n, N, Lp, stream_ptr(dev)), 'multi')
     for _ in range(3): run()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
