@@ -351,11 +351,13 @@ int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, 
 /* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
  *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over
  *      (C x T) per sample (accumulated in double), per-channel affine.  x, res (may be NULL), y : (N,C,T) fp32;
- *      stats : (N,2) {mean, rstd} saved for backward; ws : (N,2) double scratch (caller owned, overwritten).
+ *      stats : (N,2) {mean, rstd} saved for backward; ws : (N,16,2) double scratch (caller owned, overwritten;
+ *      PSND_GN_WS_DOUBLES doubles per sample).
  *  psnd_groupnorm1_bwd: gx (gradient wrt x and wrt res), ggamma, gbeta (C) - all fully overwritten.
  *  psnd_softmax_keys_fwd: in place on scores (B,Tk,Tq): a = softmax over Tk of scale*s with key-padded rows at -inf,
  *      query-padded columns set to 0 (modules.py:66-76); mask (B,T) uint8, 1 = padded, or NULL.
  *  psnd_softmax_keys_bwd: gscores = scale * a * (gatt - sum_tk gatt*a). */
+#define PSND_GN_WS_DOUBLES 32
 int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
                         int64_t T, float eps, int relu, float *y, float *stats, double *ws, void *stream);
 int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma, const float *y,

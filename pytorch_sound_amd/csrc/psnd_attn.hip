@@ -364,26 +364,34 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *part, int sl
     out[i] = a;
 }
 
-// gbias[c] = sum over (z, t) of g[z][c][t] (where mask[z][c][t] > 0 when given): one workgroup per channel
-__global__ __launch_bounds__(256) void rowsum_kernel(const float *g, const float *mask, int Z, int C, long long T, float *out) {
-    const int c = blockIdx.x;
+// gbias[c] = sum over (z, t) of g[z][c][t] (where mask[z][c][t] > 0 when given): one workgroup per channel.  1024 threads = 4 clip
+// groups x 256 frame lanes, four clips per thread in flight and no branch around a load: the first version (256 threads, one load per
+// thread and iteration behind the mask test, clips walked one after the other) ran 76 us per launch at 32 x 256 x 1292 (0.55 TB/s).
+template <bool MASK>
+__global__ __launch_bounds__(1024) void rowsum_kernel(const float *g, const float *mask, int Z, int C, long long T, float *out) {
+    const int c = blockIdx.x, tid = threadIdx.x, zg = tid >> 8, tt = tid & 255;
     double acc = 0.0;
-    for (int z = 0; z < Z; ++z) {
-        const float *pg = g + ((long long)z * C + c) * T;
-        const float *pm = mask ? mask + ((long long)z * C + c) * T : nullptr;
-        for (long long t = threadIdx.x; t < T; t += 256) {
-            const float v = pg[t];
-            acc += (pm && !(pm[t] > 0.f)) ? 0.0 : (double)v;
+    for (int z0 = zg; z0 < Z; z0 += 16)
+        for (long long t = tt; t < T; t += 256) {
+            float v[4], m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int z = min(z0 + 4 * u, Z - 1);
+                const long long o = ((long long)z * C + c) * T + t;
+                v[u] = g[o];
+                m[u] = MASK ? mask[o] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (z0 + 4 * u < Z && m[u] > 0.f) ? (double)v[u] : 0.0;
         }
-    }
-    __shared__ double red[256];
-    red[threadIdx.x] = acc;
+    __shared__ double red[1024];
+    red[tid] = acc;
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    for (int s = 512; s >= 1; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = (float)red[0];
+    if (tid == 0) out[c] = (float)red[0];
 }
 
 // =====================================================================================================================
@@ -1277,7 +1285,8 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
     }
     if (gbias) {
-        hipLaunchKernelGGL(rowsum_kernel, dim3(Cout), dim3(256), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
+        if (ymask) hipLaunchKernelGGL(rowsum_kernel<true>, dim3(Cout), dim3(1024), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
+        else hipLaunchKernelGGL(rowsum_kernel<false>, dim3(Cout), dim3(1024), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
         PSND_CHECK_LAUNCH("linear1x1_bwd(bias)");
     }
     return PSND_OK;
