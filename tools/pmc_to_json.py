@@ -24,7 +24,7 @@ def summarise(d, match='stft_fwd'):
         for r in csv.DictReader(open(f)):
             if match in r['Kernel_Name']:
                 dur.append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
-                names.add(r['Kernel_Name'].split('(')[0][:80])
+                names.add((__import__('re').search(r'(\w+_kernel)', r['Kernel_Name']) or [r['Kernel_Name'][:80]])[0])
     return {k: sum(v) / len(v) for k, v in agg.items()}, dur, sorted(names)
 
 
