@@ -69,7 +69,9 @@ def main():
             return mel, valid
 
         def forward(self, mel, valid, is_logging=False):
-            y = self.model(mel, valid < 0.5)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled='--amp' in sys.argv):   # bf16 projection and attention operands
+                y = self.model(mel, valid < 0.5)
+            y = y.float()
             loss = ((y - mel).abs() * valid.unsqueeze(1)).sum() / (valid.sum() * 80.0)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
