@@ -417,6 +417,12 @@ int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop
 int psnd_pad_collate(const float *flat, const int64_t *offs, const int64_t *lens, int64_t N, int64_t Tmax, float *out,
                      float *mask, void *stream);
 
+/* ---- SpectrogramMasker.forward (models/transforms.py:409-416): wave-level mask (N, T) fp32 -> frame-level mask (N, F) fp32,
+ *  F = psnd_frame_mask_frames(T, win, hop) = (T + 2 (win / 2) - win) / hop + 1: out[n][f] = ceil(mean over frame f of the mask padded with
+ *  win / 2 ones in front and win / 2 zeros behind) - the reference's constant-weight Conv1d + ceil without a library convolution. */
+int64_t psnd_frame_mask_frames(int64_t T, int win, int hop);
+int psnd_frame_mask(const float *mask, int64_t N, int64_t T, int win, int hop, float *out, void *stream);
+
 /* ---- the optimizer step of Trainer.train (trainer.py:215-216) for Adam / AdamW: one launch over all tensors ---------
  *  table : n_tensors records {float *p; const float *g; float *m; float *v; float *step; int64 numel} (device,
  *      psnd_adam_table_bytes() each); the work list: workgroup b updates elements [chunk_off[b], chunk_off[b] +

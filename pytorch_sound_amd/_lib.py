@@ -98,6 +98,8 @@ SIGNATURES = {
     'psnd_stft_fwd_msl': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _F, _P, _F, _P, _P]),
     'psnd_stft_loss_final_blocks': (_INT, [_P, _P, _P, _INT, _I64, _P, _P, _P]),
     'psnd_stft_bwd_msl': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _INT, _F, _INT, _P, _P]),
+    'psnd_frame_mask_frames': (_I64, [_I64, _INT, _INT]),
+    'psnd_frame_mask': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _P]),
     'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     'psnd_adam_chunk': (_I64, []),
     'psnd_adam_table_bytes': (_I64, []),

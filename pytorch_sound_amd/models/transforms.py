@@ -341,6 +341,20 @@ class SpectrogramMasker(nn.Module):
         torch.nn.init.constant_(self.conv.weight, 1. / self.win_length)
 
     def forward(self, wav_mask: torch.Tensor) -> torch.Tensor:
+        if wav_mask.is_cuda:
+            # gfx950: psnd_frame_mask (span of 16 frames in LDS, window sums, exact division + ceil) - no library convolution for a
+            # HIP tensor.  The conv weight stays a parameter (state_dict parity); it is the constant 1 / win_length by construction.
+            from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check, PsndError
+            if wav_mask.dim() != 2:
+                raise RuntimeError('SpectrogramMasker: (N, T) wave-level mask expected, got %s' % (tuple(wav_mask.shape),))
+            m = wav_mask.detach().float().contiguous()
+            N, T = m.shape
+            hop = int(self.conv.stride[0])
+            F_ = int(lib().psnd_frame_mask_frames(T, self.win_length, hop))
+            out = torch.empty((N, F_), dtype=torch.float32, device=m.device)
+            with torch.cuda.device(m.device):
+                check(lib().psnd_frame_mask(ptr(m), N, T, self.win_length, hop, ptr(out), stream_ptr(m.device)), 'psnd_frame_mask')
+            return out
         with torch.no_grad():
             if self.conv.weight.device != wav_mask.device:
                 self.conv.to(wav_mask.device)

@@ -92,6 +92,23 @@ def test_spectrogram_masker_device():
     out = sm(mask)
     assert out.device.type == 'cuda' and out.shape == (3, 87)
     assert out[1].min() == 1 and out[2, 3:].max() == 0 and out[0].sum() == np.ceil((5000 + 512) / 256)
+    # against the reference's formulation (constant-weight conv + ceil) on the host, incl. windows that are not a power of two,
+    # hops that do not divide them, fractional masks, and with the library ops forbidden for HIP tensors
+    from test_gpu_no_library_paths import forbid_library_ops
+    torch.manual_seed(3)
+    for win, hop, T in ((1024, 256, 22050), (600, 120, 9000), (512, 50, 4001), (8, 4, 32), (2048, 512, 70000)):
+        sm = SpectrogramMasker(win, hop)
+        lens = torch.randint(1, T, (5,))
+        m = (torch.arange(T)[None, :] < lens[:, None]).float()
+        m[4] = 1.0
+        m[3] = torch.rand(T) * (torch.arange(T) < lens[3])          # fractional values: any positive mean rounds up to 1
+        ref = sm(m)                                                 # host: the conv formulation
+        with forbid_library_ops():
+            got = sm(m.to(DEV))
+        assert got.shape == ref.shape and got.device.type == 'cuda'
+        # (a fully valid frame is 1 + rounding in the conv formulation when 1 / win is not exact: ceil may give 2 there; the kernel's
+        # exact division gives 1)
+        assert float(got.max()) <= 1.0 and torch.equal(got.cpu(), ref.clamp(max=1.0))
 
 
 def test_logmel_torchaudio_variant_vs_oracle():
