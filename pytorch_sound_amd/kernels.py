@@ -271,6 +271,26 @@ def istft_forward(magnitude, phase, n_fft, hop, plan, eps=1e-9):
     return out
 
 
+_OLA_ENV = {}
+
+
+def _ola_envelope(window, n_fft, hop, F):
+    """sum_f window^2[t - f hop] over F frames, length (F - 1) hop + n_fft - the overlap-add envelope STFT.inverse divides by
+    (transforms.py:90-99 builds it with a conv_transpose1d of ones; here an index_add of F shifted copies, cached per window / geometry:
+    no library convolution for a HIP tensor)."""
+    key = (window.data_ptr(), window._version, str(window.device), n_fft, hop, F)
+    env = _OLA_ENV.get(key)
+    if env is None:
+        if len(_OLA_ENV) > 32:
+            _OLA_ENV.clear()
+        w2 = (window.detach().float() * window.detach().float()).reshape(-1)
+        idx = (torch.arange(F, device=window.device) * hop).unsqueeze(1) + torch.arange(n_fft, device=window.device).unsqueeze(0)
+        env = torch.zeros((F - 1) * hop + n_fft, dtype=torch.float32, device=window.device)
+        env.index_add_(0, idx.reshape(-1), w2.repeat(F))
+        _OLA_ENV[key] = env
+    return env
+
+
 class IStft(torch.autograd.Function):
     """STFT.inverse (transforms.py:71-101).  Backward: the map is linear in G = s_k * mag * e^{i phase}
     (s = 1/n for DC/Nyquist, 2/n otherwise; their imaginary parts do not reach the signal), and its adjoint is a
@@ -288,8 +308,7 @@ class IStft(torch.autograd.Function):
         magnitude, phase, window, plan = ctx.saved_tensors
         n_fft, hop, eps = ctx.cfg
         N, Kb, F = magnitude.shape
-        w2 = (window * window).view(1, 1, n_fft)
-        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, F, device=g.device), w2, stride=hop).view(-1)
+        env = _ola_envelope(window, n_fft, hop, F)
         p = n_fft // 2
         gp = torch.nn.functional.pad(g.contiguous(), (p, p))
         den = env + eps

@@ -133,3 +133,37 @@ def test_pqmf_and_preemphasis_have_no_library_path():
         pq.analysis(torch.randn(2, 2, 64, device=dev))                    # the reference's conv1d would refuse two channels too
     with pytest.raises(RuntimeError):
         PreEmphasis(0.97).to(dev)(torch.randn(2, 2, 64, device=dev))
+
+
+def test_hot_path_flows_reach_no_library_op():
+    """The flows of SURVEY 8 end to end under the dispatch-mode guard, forward AND backward: log-mel front end, STFT transform / inverse,
+    multi_stft_loss, the config-2 separator with its fused loss, a HiFi-GAN generator, the fused optimizer step, the padding-mask helper
+    - none of them may reach bmm / mm / convolution / softmax / group_norm / FFT ops with a HIP tensor."""
+    from pytorch_sound_amd import optim as poptim
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    from pytorch_sound_amd.models.sound import multi_stft_loss
+    from pytorch_sound_amd.models.transforms import LogMelSpectrogram, STFT, SpectrogramMasker
+    dev = _dev()
+    torch.manual_seed(11)
+    wav = (0.1 * torch.randn(4, 16384, device=dev)).requires_grad_(True)
+    with forbid_library_ops():
+        fe = LogMelSpectrogram(22050, 80, 1024, 1024, 256, -50.0, 30.0, 0.0, 8000.0).to(dev)
+        fe(wav).sum().backward()
+        st = STFT(1024, 256).to(dev)
+        mag, ph = st.transform(wav)
+        st.inverse(mag, ph).pow(2).sum().backward()
+        a, b, c = multi_stft_loss(wav, 0.1 * torch.randn(4, 16384, device=dev), [(1024, 600, 120), (2048, 1200, 240), (512, 240, 50)])
+        (a + b + c).backward()
+        SpectrogramMasker(1024, 256)(torch.ones(4, 16384, device=dev))
+        model = build_model('conv_separator_voicebank', {'channels': 256, 'num_blocks': 1}).to(dev)
+        opt = poptim.Adam(model.parameters(), lr=1e-4)
+        m = torch.rand(4, 513, 65, device=dev)
+        loss, _ = model.spectral_l1_loss(m, torch.rand_like(m), torch.randn(4, 80, 65, device=dev), fe._mel_plan(), 80, 1.0, 0.5, 1e-6,
+                                         fe.min_db, fe.max_db)
+        loss.backward()
+        opt.step()
+        g = _gen([4, 2], [8, 4])
+        g(torch.randn(2, 80, 16, device=dev)).abs().mean().backward()
+    assert wav.grad is not None and torch.isfinite(wav.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in g.parameters())
