@@ -208,6 +208,9 @@ typedef struct psnd_chain_pair {
     float m1_slope, m2_slope;
 } psnd_chain_pair;
 int psnd_conv1d_cl_chain_rows(int C, int k, int n_pairs, const int *taps);
+/* the rows a workgroup owns for a launch over R = N * Lp rows and its row tile (*mr_out: 1 = 32 computed rows, 2 = 64; may be NULL):
+ * 64-row tiles (32-row tiles exist for A/B runs, PSND_CHAIN_MR=1); 0 = unsupported */
+int psnd_conv1d_cl_chain_plan(int C, int k, int n_pairs, const int *taps, int64_t R, int *mr_out);
 int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_chain_pair *pairs, int n_pairs, int64_t N, int Lp, int L, int HP,
                          int C, int k, void *stream);
 void psnd_conv_chain_stats(long long *out2);

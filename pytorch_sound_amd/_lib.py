@@ -52,6 +52,7 @@ SIGNATURES = {
     'psnd_conv1d_cl_wgrad_multi': (_INT, [_P, _INT, _I64, _INT, _P]),
     'psnd_nan_flag': (_INT, [_P, _I64, _P, _P]),
     'psnd_conv1d_cl_chain_rows': (_INT, [_INT, _INT, _INT, _P]),
+    'psnd_conv1d_cl_chain_plan': (_INT, [_INT, _INT, _INT, _P, _I64, _P]),
     'psnd_conv1d_cl_chain': (_INT, [_P, _P, _P, _INT, _I64, _INT, _INT, _INT, _INT, _INT, _P]),
     'psnd_conv_chain_stats': (None, [_P]),
     'psnd_conv1d_cl_pair_bwd_supported': (_INT, [_INT, _INT, _INT, _INT, _INT, _INT]),

@@ -707,7 +707,9 @@ class ResBlockCL(torch.autograd.Function):
                     for d, (_, _, wf1, bp1, slope1, mid, wf2, bp2, _, _, _, off1, dil1, off2, dil2, oslope, raw, act) in zip(arr, pairs):
                         d.W1, d.bias1, d.act1_slope, d.mid_out = wf1.data_ptr(), bp1.data_ptr(), float(slope1), q(mid)
                         d.W2, d.bias2, d.off1, d.dstep1, d.off2, d.dstep2 = wf2.data_ptr(), bp2.data_ptr(), off1, dil1, off2, dil2
-                        d.act2_slope, d.out_raw, d.out_act = float(oslope), q(raw), q(act)
+                        # the residual stream BETWEEN the pairs of a chain never leaves the chip (nothing reads it back: the backward
+                        # needs the activated tensors only); the last pair's is the next launch's
+                        d.act2_slope, d.out_raw, d.out_act = float(oslope), (q(raw) if raw is pairs[-1][16] else None), q(act)
                     check(lib().psnd_conv1d_cl_chain(q(inp1), q(res0), ctypes.addressof(arr), len(pairs), Nh, shape.Lp, shape.L, shape.HP,
                                                      C, k, st), 'psnd_conv1d_cl_chain')
                     continue

@@ -63,6 +63,38 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
     static_assert(UNITS % RU == 0 && RU % 3 == 0, "the B ring turns whole");
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     __shared__ unsigned char s_in[MROWS];
+    // Hand-over between the convs of the chain WITHOUT a workgroup barrier (-DPSND_CHAIN_FLAGS=1; measured, OFF by default): s_flag[g] counts the epilogues
+    // the waves of group g (0: waves 0-3 = channels 0-127 of a tile, 1: waves 4-7 = channels 128-255) have finished.  A conv's loop may
+    // start on k-steps 0-7 as soon as group 0 has written the tile's first half and needs group 1 only before k-step 8.  Why: a SIMD
+    // issues its older wave first, so waves 0-3 finish every loop ~3 k cycles before waves 4-7; behind a barrier the late waves' epilogue
+    // (1.2-2 k cycles per conv) ran with the matrix pipe idle - with the flags the early waves are already multiplying the next conv's first
+    // half.  Result (tools/trace_chain.py, bit-identical outputs): 65.7 k cycles per workgroup against 64.9 k with barriers - the late
+    // waves' chain (loop + epilogue) is what a SIMD's matrix pipe and VALU can do for its two waves together (6.1 k MFMA + ~3 k VALU
+    // cycles per conv), the early waves running ahead only compete with them; with the gate INSIDE the unrolled loop 70 k.
+    __shared__ unsigned s_flag[2];
+#ifndef PSND_CHAIN_FLAGS
+#define PSND_CHAIN_FLAGS 0
+#endif
+    constexpr bool FLAGS = PSND_CHAIN_FLAGS != 0;
+#ifndef PSND_CHAIN_EPRIO
+#define PSND_CHAIN_EPRIO 2
+#endif
+    if (threadIdx.x < 2) s_flag[threadIdx.x] = 0;
+    auto wait_flag = [&](int g, unsigned need) __attribute__((always_inline)) {
+        if (!FLAGS || need == 0) return;
+        volatile unsigned *f = &s_flag[g];
+        int spins = 0;
+        while (*f < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 24)) __builtin_trap();       // a lost hand-over must fail loudly, not hang the queue
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto signal_flag = [&]() __attribute__((always_inline)) {
+        if (!FLAGS) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the LDS writes of this wave's epilogue are ordered in front of the count
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&s_flag[threadIdx.x >> 8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     bf16_t *sXa = smem, *sM = smem + BR * RS, *sXr = smem + 2 * BR * RS;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kg = lane >> 5;
     const int col0 = wave * 32 + li;
@@ -180,7 +212,8 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
     // one conv over the haloed tile `src` (tile row i <-> buffer row i + HMAXP); the unit order is that of conv_pair_body::run_conv
     // rWn: the pack of the NEXT conv - the last ring turn refills with its first units instead of out-of-range zeros, so the next loop
     // starts with a full ring and no wave spends ~700 cycles issuing twelve 1 KB loads between two loops
-    auto run_conv = [&](const bf16_t *src, int off0, int dstep, __amdgpu_buffer_rsrc_t rW, __amdgpu_buffer_rsrc_t rWn) __attribute__((always_inline)) {
+    auto run_conv = [&](const bf16_t *src, int off0, int dstep, __amdgpu_buffer_rsrc_t rW, __amdgpu_buffer_rsrc_t rWn, unsigned need) __attribute__((always_inline)) {
+        wait_flag(0, need);                                  // channels 0-127 of the source tile are written
         const bf16_t *ab[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) ab[t] = src + (li + HMAXP + off0 + t * dstep) * RS + 8 * kg;
@@ -192,21 +225,34 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
         };
         // A fragments run AD units ahead of their MFMAs in a ring of AD + 1
         bf16x8 xr[AR][MB];
-        static_for<0, AR - 1>([&](auto uc) __attribute__((always_inline)) { afrag(uc, 0, xr[decltype(uc)::value]); });
+        // the ring loop over turns [it0, it1); nothing conditional inside (a uniform test in the unrolled body splits its basic block
+        // and costs ~1.8 k cycles per conv: measured with the group-1 gate placed inside the loop)
+        auto turns = [&](int it0, int it1) __attribute__((always_inline)) {
+            static_for<0, AR - 1>([&](auto uc) __attribute__((always_inline)) { afrag(uc, it0, xr[decltype(uc)::value]); });
 #pragma unroll 1
-        for (int it = 0; it < UNITS / RU; ++it) {
-            static_for<0, RU>([&](auto uc) __attribute__((always_inline)) {
-                constexpr int u = decltype(uc)::value;
-                afrag(std::integral_constant<int, u + AR - 1>{}, it, xr[(u + AR - 1) % AR]);
-                const bf16x8 b = __builtin_bit_cast(bf16x8, rb[u]);
+            for (int it = it0; it < it1; ++it) {
+                static_for<0, RU>([&](auto uc) __attribute__((always_inline)) {
+                    constexpr int u = decltype(uc)::value;
+                    afrag(std::integral_constant<int, u + AR - 1>{}, it, xr[(u + AR - 1) % AR]);
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, rb[u]);
 #pragma unroll
-                for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[u % AR][m], b, acc[m], 0, 0, 0);
-                fetch_b(uc, it + 1 < UNITS / RU ? rW : rWn, it + 1 < UNITS / RU ? it + 1 : 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, MB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                    for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xr[u % AR][m], b, acc[m], 0, 0, 0);
+                    fetch_b(uc, it + 1 < UNITS / RU ? rW : rWn, it + 1 < UNITS / RU ? it + 1 : 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        };
+        if constexpr (FLAGS) {
+            // k-steps 0-7 (channels 0-127), then - once group 1 has written its half - k-steps 8-15.  The A prefetch of the first
+            // half's last units reads two fragments of the second half early: they are read again behind the gate.
+            turns(0, UNITS / RU / 2);
+            wait_flag(1, need);
+            turns(UNITS / RU / 2, UNITS / RU);
+        } else {
+            turns(0, UNITS / RU);
         }
     };
     // owned rows of a tile in LDS -> memory, 16 bytes per store.  Done by waves 0-3 only: a SIMD issues its OLDER wave first, so the
@@ -261,7 +307,8 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
         // ---- first conv -> mid (bf16) in LDS
         if constexpr (BWD) mask_fetch(d.M2);                 // for the second conv's epilogue
         zero_acc();
-        run_conv(sXa, d.off1, d.dstep1, rW1, rW2);
+        run_conv(sXa, d.off1, d.dstep1, rW1, rW2, 8u * pp);
+        if constexpr (FLAGS) __builtin_amdgcn_s_setprio(PSND_CHAIN_EPRIO);
         CHAIN_STAMP(2 + 4 * pp);
         // Copy-outs are issued BEHIND a conv loop, not in front of it: the vector-memory counter is in order, so a loop whose first
         // ring refill waits behind 5 stores waits for their write acknowledgements (~2 k cycles, tools/trace_chain.py).  The tiles they
@@ -296,12 +343,18 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
                 }
         }
         if (pp == 1) CHAIN_STAMP(14);
-        __syncthreads();
+        if constexpr (FLAGS) {
+            signal_flag();
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            __syncthreads();
+        }
         CHAIN_STAMP(3 + 4 * pp);
         // ---- second conv on mid; its output replaces the activated tile and the residual stream
         if constexpr (BWD) mask_fetch(dn.M1);                // for the next pair's first conv (the last pair: fetched, never read)
         zero_acc();
-        run_conv(sM, d.off2, d.dstep2, rW2, rWn);
+        run_conv(sM, d.off2, d.dstep2, rW2, rWn, 8u * pp + 4u);
+        if constexpr (FLAGS) __builtin_amdgcn_s_setprio(PSND_CHAIN_EPRIO);
         CHAIN_STAMP(4 + 4 * pp);
         if (d.mid_out) copy_out(sM, HMAXP, d.mid_out);
         if constexpr (BWD) {
@@ -335,11 +388,17 @@ __global__ __launch_bounds__(512, 1) void conv_chain_kernel(ChainParams p) {
                 }
         }
         if (pp == 1) CHAIN_STAMP(15);
-        __syncthreads();
+        if constexpr (FLAGS) {
+            signal_flag();
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            __syncthreads();
+        }
         CHAIN_STAMP(5 + 4 * pp);
         prev_raw = d.out_raw, prev_act = d.out_act;
         d = dn, b1 = b1n, b2 = b2n;
     }
+    if constexpr (FLAGS) __syncthreads();                  // every wave's last epilogue is in the tiles
     if (prev_raw) copy_out(BWD ? sXa : sXr, BWD ? HMAXP : 0, prev_raw);
     if (!BWD && prev_act) copy_out(sXa, HMAXP, prev_act);
 }
@@ -359,6 +418,25 @@ extern "C" int psnd_conv1d_cl_chain_rows(int C, int k, int n_pairs, const int *t
     return ts >= 16 ? ts : 0;
 }
 
+// Row tile of a launch over R rows: 64 computed rows per workgroup (mr = 2); PSND_CHAIN_MR=1 selects 32 (A/B runs).  Returns the owned
+// rows, 0 = unsupported.
+extern "C" int psnd_conv1d_cl_chain_plan(int C, int k, int n_pairs, const int *taps, int64_t R, int *mr_out) {
+    const int ts2 = psnd_conv1d_cl_chain_rows(C, k, n_pairs, taps);
+    if (!ts2) return 0;
+    const int ts1 = ts2 - 32;
+    // measured back to back at 32 x 173 frames: one pair on 32-row tiles 14.2 us (the pair kernel: 14.1), pairs (5, 1) 24.7 us, pairs
+    // (1, 3) on 64-row tiles 26.7 us, a whole block (1, 3, 5) on 64-row tiles 38.8 us = 12.9 us per pair - the best per pair; 32-row tiles
+    // are therefore only taken on request (a launch pays ~6 us beside its workgroups' lifetime, whatever the tile)
+    (void)R;
+    int mr = 2;
+    if (const char *e = getenv("PSND_CHAIN_MR")) {
+        const int f = atoi(e);
+        if (f == 2 || (f == 1 && ts1 >= 8)) mr = f;
+    }
+    if (mr_out) *mr_out = mr;
+    return mr == 1 ? ts1 : ts2;
+}
+
 extern "C" int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_chain_pair *pairs, int n_pairs, int64_t N, int Lp, int L, int HP,
                                     int C, int k, void *stream) {
     if (!A || !res || !pairs) PSND_FAIL(PSND_E_ARG, "conv1d_cl_chain: null pointer");
@@ -376,14 +454,15 @@ extern "C" int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_c
         if (!(pairs[i].act1_slope >= 0.f && pairs[i].act1_slope <= 1.f && pairs[i].act2_slope >= 0.f && pairs[i].act2_slope <= 1.f))
             PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_chain: activation slopes %g, %g of pair %d outside [0, 1]", pairs[i].act1_slope, pairs[i].act2_slope, i);
     }
-    const int ts = psnd_conv1d_cl_chain_rows(C, k, n_pairs, taps);
+    int mr = 2;
+    const int ts = psnd_conv1d_cl_chain_plan(C, k, n_pairs, taps, N * (int64_t)Lp, &mr);
     if (!ts) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_chain: C=%d k=%d, %d pairs: only k = 3, C = 256, reach <= %d, >= 16 rows left of 64", C, k, n_pairs, HMAXP);
     if (N == 0) return PSND_OK;
     if ((size_t)N * Lp * C * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_chain: operand larger than 2 GB");
     ChainParams p;
     p.A = static_cast<const bf16_t *>(A), p.res = static_cast<const bf16_t *>(res);
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP;
-    p.n_pairs = n_pairs, p.ts = ts, p.lo = (64 - ts) / 2;
+    p.n_pairs = n_pairs, p.ts = ts, p.lo = (32 * mr - ts) / 2;
     for (int i = 0; i < CHAIN_MAX; ++i) {
         const psnd_chain_pair &s = pairs[i < n_pairs ? i : n_pairs - 1];
         ChainPair &d = p.d[i];
@@ -399,14 +478,17 @@ extern "C" int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_c
     const int64_t tiles = (p.R + ts - 1) / ts;
     constexpr int RS = 256 + 8;
     // forward: act + mid tiles with rims and the raw tile; input-gradient form: the two tiles and two 2 KB bit tiles of the masks
-    const size_t lds = bwd ? (size_t)2 * (64 + 2 * HMAXP) * RS * 2 + 2 * 256 * 8 : (size_t)(2 * (64 + 2 * HMAXP) + 64) * RS * 2;
+    const int mrows = 32 * mr;
+    const size_t lds = bwd ? (size_t)2 * (mrows + 2 * HMAXP) * RS * 2 + 2 * 256 * 8 : (size_t)(2 * (mrows + 2 * HMAXP) + mrows) * RS * 2;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto launch = [&](auto kern) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, p);
     };
-    if (bwd) launch(conv_chain_kernel<256, 2, true>);
-    else launch(conv_chain_kernel<256, 2, false>);
+    if (bwd && mr == 2) launch(conv_chain_kernel<256, 2, true>);
+    else if (bwd) launch(conv_chain_kernel<256, 1, true>);
+    else if (mr == 2) launch(conv_chain_kernel<256, 2, false>);
+    else launch(conv_chain_kernel<256, 1, false>);
     PSND_CHECK_LAUNCH("conv1d_cl_chain");
     g_conv_chain_stats[0]++;
     g_conv_chain_stats[1] += n_pairs;

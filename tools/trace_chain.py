@@ -15,7 +15,7 @@ x[:, HP:HP + L] = torch.randn(N, L, C, device=dev).to(torch.bfloat16)
 ws = [(torch.randn(3, C, C, device=dev) / 28).to(torch.bfloat16) for _ in range(2 * npairs)]
 b = torch.zeros(C, device=dev)
 outs = [[torch.empty_like(x) for _ in range(3)] for _ in range(npairs)]
-dils = [1, 3, 5, 1][:npairs]
+dils = [int(a) for a in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1, 3, 5, 1][:npairs]
 arr = (_lib.ChainPair * npairs)()
 taps = []
 for i, d in enumerate(arr):
@@ -23,7 +23,9 @@ for i, d in enumerate(arr):
     d.W2, d.bias2, d.off1, d.dstep1, d.off2, d.dstep2 = ws[2 * i + 1].data_ptr(), b.data_ptr(), -dils[i], dils[i], -1, 1
     d.act2_slope, d.out_raw, d.out_act = 0.1, outs[i][1].data_ptr(), outs[i][2].data_ptr()
     taps += [-dils[i], dils[i], -1, 1]
-ts = lib().psnd_conv1d_cl_chain_rows(C, k, npairs, (ctypes.c_int * len(taps))(*taps))
+mr = ctypes.c_int(0)
+ts = lib().psnd_conv1d_cl_chain_plan(C, k, npairs, (ctypes.c_int * len(taps))(*taps), R, ctypes.byref(mr))
+print('row tile', 32 * mr.value, 'dilations', dils)
 ntile = (R + ts - 1) // ts
 tr = torch.zeros(ntile * 8 * 16, dtype=torch.int64, device=dev)
 def run():
