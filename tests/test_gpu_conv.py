@@ -136,7 +136,7 @@ def test_pair_launch_matches_two_launches(channels, N, T, monkeypatch):
     assert rel(o1, ref) < 2e-2
 
 
-@pytest.mark.parametrize('N,T,blocks,chain', [(32, 173, 4, 3), (4, 173, 2, 3), (3, 50, 1, 2), (5, 97, 2, 4), (1, 20, 1, 3)])
+@pytest.mark.parametrize('N,T,blocks,chain', [(32, 173, 4, 3), (4, 173, 2, 3), (3, 50, 1, 2), (5, 97, 2, 4), (1, 20, 1, 3), (6, 120, 2, -2)])
 def test_chain_launch_is_bit_identical_to_pair_launches(N, T, blocks, chain, monkeypatch):
     """psnd_conv1d_cl_chain (the pairs of a ResBlock1 in ONE launch, a workgroup carrying its 64-row tile through all of them on the chip
     and owning the rows that stay valid) against the same forward as one psnd_conv1d_cl_pair launch per pair: the arithmetic, its order
@@ -156,6 +156,10 @@ def test_chain_launch_is_bit_identical_to_pair_launches(N, T, blocks, chain, mon
         out = (ctypes.c_longlong * 2)()
         _lib.lib().psnd_conv_chain_stats(ctypes.addressof(out))
         return out[0], out[1]
+
+    if chain < 0:                                # the 32-row tile instances (A/B switch PSND_CHAIN_MR=1), forward and masked form
+        monkeypatch.setenv('PSND_CHAIN_MR', '1')
+        chain = -chain
 
     def run(mx):
         monkeypatch.setenv('PSND_CL_CHAIN', str(mx))
