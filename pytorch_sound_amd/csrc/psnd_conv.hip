@@ -1172,6 +1172,68 @@ __device__ __forceinline__ void conv_finish_body(const float *gw_part, const flo
     // different banks); i / k by multiplication with kmagic = ceil(2^32 / k) (exact for i < 2^32 / k).
     const int n = Cin * k, BD = blockDim.x, tid = threadIdx.x;
     const int pitch = Cin + 1;
+    if constexpr (!MANY) {
+        // Lean form for 4-aligned layers (Cin, Ca multiples of 4: every conv of the separator's body): 16-byte loads of the slabs, of v and
+        // 16-byte stores of g_v, one index division per four elements.  The element-wise form below spends ~480 VALU and ~600 scalar
+        // instructions per wave (magic divisions and a predicated load per slab slot and element) on 12 KB per workgroup: 48 us per launch
+        // for the 26 convs of config 2, instruction-bound (profiles/r03_wnorm_pmc.txt).
+        if ((Cin & 3) == 0 && (Ca & 3) == 0 && splits <= 16) {
+            const int cin4 = Cin >> 2, n4 = n >> 2;                      // float4s per tap row / per output channel
+            const size_t slab4 = (size_t)k * Cb * Ca;
+            const float *vrow = v + (size_t)co * n;
+            float bsum = 0.f;
+            if (tid < 64 && gbias && gb_part)
+                for (int sp = tid; sp < splits; sp += 64) bsum += gb_part[(size_t)sp * Cb + co];
+            for (int q = tid; q < n4; q += BD) {                        // (j, ci) order: coalesced slab rows
+                const int j = q / cin4, c4 = q - j * cin4;
+                const float *src = gw_part + ((size_t)j * Cb + co) * Ca + 4 * c4;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int sp = 0; sp < splits; ++sp) a += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * slab4);
+                float *dst = s_gw + j * pitch + 4 * c4;
+                dst[0] = a.x, dst[1] = a.y, dst[2] = a.z, dst[3] = a.w;
+            }
+            __syncthreads();
+            float ss4 = 0.f, dot4 = 0.f;
+            for (int q = tid; q < n4; q += BD) {                        // natural (ci, j) order
+                const f32x4 vv = *reinterpret_cast<const f32x4 *>(vrow + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e, ci = (int)__umulhi((unsigned)i, kmagic), j = i - ci * k;
+                    ss4 = __builtin_fmaf(vv[e], vv[e], ss4);
+                    dot4 = __builtin_fmaf(vv[e], s_gw[j * pitch + ci], dot4);
+                }
+            }
+            for (int m = 32; m >= 1; m >>= 1) {
+                ss4 += __shfl_xor(ss4, m, 64);
+                dot4 += __shfl_xor(dot4, m, 64);
+            }
+            const int nw4 = BD >> 6;
+            if ((tid & 63) == 0) red[tid >> 6] = ss4, red[16 + (tid >> 6)] = dot4;
+            __syncthreads();
+            float sst = 0.f, dott = 0.f;
+            for (int w = 0; w < nw4; ++w) sst += red[w], dott += red[16 + w];
+            const float inv = 1.f / __builtin_sqrtf(sst);
+            const float dd = dott * inv;
+            const float gs = g[co] * inv;
+            for (int q = tid; q < n4; q += BD) {
+                const f32x4 vv = *reinterpret_cast<const f32x4 *>(vrow + 4 * q);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e, ci = (int)__umulhi((unsigned)i, kmagic), j = i - ci * k;
+                    o[e] = gs * (s_gw[j * pitch + ci] - vv[e] * inv * dd);
+                }
+                *reinterpret_cast<f32x4 *>(gv + (size_t)co * n + 4 * q) = o;
+            }
+            if (tid == 0) gg[co] = dd;
+            if (tid < 64 && gbias && gb_part) {
+                float b = bsum;
+                for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
+                if (tid == 0) gbias[co] = b;
+            }
+            return;
+        }
+    }
     const size_t slab = (size_t)k * Cb * Ca;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f, dot = 0.f;
