@@ -278,8 +278,10 @@ def _ola_envelope(window, n_fft, hop, F):
     """sum_f window^2[t - f hop] over F frames, length (F - 1) hop + n_fft - the overlap-add envelope STFT.inverse divides by
     (transforms.py:90-99 builds it with a conv_transpose1d of ones; here an index_add of F shifted copies, cached per window / geometry:
     no library convolution for a HIP tensor)."""
-    key = (window.data_ptr(), window._version, str(window.device), n_fft, hop, F)
-    env = _OLA_ENV.get(key)
+    import weakref
+    key = (id(window), window._version, n_fft, hop, F)
+    hit = _OLA_ENV.get(key)
+    env = hit[1] if hit is not None and hit[0]() is window else None      # the id of a freed tensor may be reused: the weak reference tells
     if env is None:
         if len(_OLA_ENV) > 32:
             _OLA_ENV.clear()
@@ -287,7 +289,7 @@ def _ola_envelope(window, n_fft, hop, F):
         idx = (torch.arange(F, device=window.device) * hop).unsqueeze(1) + torch.arange(n_fft, device=window.device).unsqueeze(0)
         env = torch.zeros((F - 1) * hop + n_fft, dtype=torch.float32, device=window.device)
         env.index_add_(0, idx.reshape(-1), w2.repeat(F))
-        _OLA_ENV[key] = env
+        _OLA_ENV[key] = (weakref.ref(window), env)
     return env
 
 
