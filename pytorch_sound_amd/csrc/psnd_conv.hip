@@ -489,7 +489,13 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float w = v[i];
-        if (preop == 1) w = log1pf(w);
+        if (preop == 1) {
+            // log1p for a bf16 result: u = 1 + w rounds w away, log(u) * w / (u - 1) puts it back (the classic correction); hardware log2
+            // and reciprocal.  ~12 instructions against ~140 for log1pf - the launch was VALU-bound on it (568 VALU instructions per wave
+            // for four elements per thread, profiles/r03_step_pmc_per_kernel.txt); the error stays below 1e-6 relative, 2^-13 of a bf16 step.
+            const float u = 1.f + w;
+            w = u == 1.f ? w : __logf(u) * __fdividef(w, u - 1.f);
+        }
         if constexpr (MASKBWD) {
             const float d = e[i] - r[i];
             w += l1c * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
