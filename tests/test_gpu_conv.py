@@ -448,3 +448,66 @@ def test_fused_spectral_l1_loss_matches_separate_nodes(N, T, channels):
     for k in gs:
         assert relf(gf[k], gs[k]) <= 2e-3, (k, relf(gf[k], gs[k]))
     assert not est_f.requires_grad
+
+
+def test_wgrad_multi_mixed_shapes_vs_float64():
+    """psnd_conv1d_cl_wgrad_multi through the C ABI: convs of three shapes (256 -> 256 k = 3 with dilations, 520 -> 256 k = 3 as the separator's
+    head, 64 -> 128 k = 7) over the same rows in ONE launch - the slabs summed against the float64 product of the same bf16 operands
+    (gw[j][co][ci] = sum_r g[r][co] x[r + off0 + j dstep][ci], gbias[co] = sum_r g[r][co]): 2e-5 of the largest entry (fp32 accumulation
+    over 3.5 k rows), and against one psnd_conv1d_cl_wgrad launch per conv."""
+    import ctypes
+    from pytorch_sound_amd import _lib, cl
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    N, L, HP = 6, 173, 25
+    shape = cl.CLShape(N, L, HP)
+    Lp = shape.Lp
+    specs = [(256, 256, 3, -1, 1), (256, 256, 3, -5, 5), (520, 256, 3, -1, 1), (64, 128, 7, -9, 3), (256, 256, 3, -3, 3)]
+    S = lib().psnd_conv1d_cl_wgrad_multi_splits(N, Lp, 256, 256, 3, 3)
+    assert S >= 1
+    arr = (_lib.WgradDesc * len(specs))()
+    keep = []
+    for d, (Ca, Cb, k, off0, dstep) in zip(arr, specs):
+        g = torch.zeros(N, Lp, Cb, device=dev, dtype=torch.bfloat16)
+        x = torch.zeros(N, Lp, Ca, device=dev, dtype=torch.bfloat16)
+        g[:, HP:HP + L] = torch.randn(N, L, Cb, device=dev).to(torch.bfloat16)
+        x[:, HP:HP + L] = torch.randn(N, L, Ca, device=dev).to(torch.bfloat16)
+        gw = torch.full((S, k, Cb, Ca), 7.0, device=dev)
+        gb = torch.full((S, Cb), 7.0, device=dev)
+        d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = g.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), off0, dstep
+        d.Ca, d.Cb, d.k, d.splits = Ca, Cb, k, S
+        keep.append((g, x, gw, gb))
+    check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(specs), N, Lp, stream_ptr(dev)), 'psnd_conv1d_cl_wgrad_multi')
+    for (Ca, Cb, k, off0, dstep), (g, x, gw, gb) in zip(specs, keep):
+        G = g.double().reshape(N * Lp, Cb)
+        X = x.double().reshape(N * Lp, Ca)
+        R = N * Lp
+        ref = torch.zeros(k, Cb, Ca, dtype=torch.float64, device=dev)
+        for j in range(k):
+            o = off0 + j * dstep
+            lo, hi = max(0, -o), min(R, R - o)
+            ref[j] = G[lo:hi].t() @ X[lo + o:hi + o]
+        got = gw.double().sum(0)
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (Ca, Cb, k)
+        assert float((gb.double().sum(0) - G.sum(0)).abs().max()) <= 2e-5 * float(G.sum(0).abs().max())
+        # one launch per conv gives the same sums (its own row ranges)
+        S1 = lib().psnd_conv1d_cl_wgrad_splits(N, Lp, Ca, Cb, k)
+        gw1 = torch.empty(S1, k, Cb, Ca, device=dev)
+        gb1 = torch.empty(S1, Cb, device=dev)
+        check(lib().psnd_conv1d_cl_wgrad(ptr(g), None, None, 1.0, ptr(x), N, Lp, Ca, Cb, k, off0, dstep, ptr(gw1), ptr(gb1), None, stream_ptr(dev)),
+              'psnd_conv1d_cl_wgrad')
+        assert float((gw1.double().sum(0) - got).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # argument checks: a row-range count that does not cut the rows, too many convs
+    arr[0].splits = 1000
+    assert lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), 1, N, Lp, stream_ptr(dev)) != 0
+
+
+def test_nan_flag_kernel():
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    dev = torch.device('cuda:0')
+    for vals, want in (([1.0], 0.0), ([float('nan')], 1.0), ([float('inf')], 0.0), ([0.5] * 200 + [float('nan')] + [1.0] * 99, 1.0), ([2.0] * 300, 0.0)):
+        x = torch.tensor(vals, device=dev)
+        flag = torch.full((), 5.0, device=dev)
+        check(lib().psnd_nan_flag(ptr(x), x.numel(), ptr(flag), stream_ptr(dev)), 'psnd_nan_flag')
+        assert float(flag) == want
