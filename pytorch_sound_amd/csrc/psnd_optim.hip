@@ -46,10 +46,14 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTensor *tab, const 
     const float step_size = lr * corr[2 * ti], inv_sqrt_bc2 = corr[2 * ti + 1];      // from adam_tick_kernel
     const float gs = grad_scale ? 1.f / *grad_scale : 1.f;
     // Trainer.clip_grad (trainer.py:184-191) folded in: clamp to +-clip_value, then the global-norm factor of psnd_grad_sumsq
-    const float cv = clip_value > 0.f ? clip_value : __builtin_inff(), cc = clip_coef ? *clip_coef : 1.f;
+    // torch's clamp propagates NaN (fminf / fmaxf return the non-NaN operand): a NaN gradient must stay NaN and poison the parameter
+    // visibly, as `p.grad.clamp(...)` + clip_grad_norm_ do in the reference.  No clamp at all when clip_value == 0.
+    const bool do_clamp = clip_value > 0.f;
+    const float cv = clip_value, cc = clip_coef ? *clip_coef : 1.f;
     auto upd = [&](float &p, float g, float &m, float &v) __attribute__((always_inline)) {
         g *= gs;
-        g = __builtin_fminf(__builtin_fmaxf(g, -cv), cv) * cc;
+        if (do_clamp) g = (g != g) ? g : __builtin_fminf(__builtin_fmaxf(g, -cv), cv);
+        g *= cc;
         if constexpr (DECOUPLED) p -= lr * wd * p;
         else g = __builtin_fmaf(wd, p, g);
         m = __builtin_fmaf(b1, m, omb1 * g);
@@ -91,10 +95,12 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const AdamTensor *tab, 
     const long long e0 = chunk_off[blockIdx.x];
     const long long e1 = min(e0 + ACH, T.numel);
     const float gs = grad_scale ? 1.f / *grad_scale : 1.f;
-    const float cv = clip_value > 0.f ? clip_value : __builtin_inff();
+    const bool do_clamp = clip_value > 0.f;
+    const float cv = clip_value;
     float acc = 0.f;
     auto add = [&](float g) __attribute__((always_inline)) {
-        g = __builtin_fminf(__builtin_fmaxf(g * gs, -cv), cv);
+        g *= gs;
+        if (do_clamp) g = (g != g) ? g : __builtin_fminf(__builtin_fmaxf(g, -cv), cv);      // NaN stays NaN (torch.clamp semantics)
         acc = __builtin_fmaf(g, g, acc);
     };
     if ((((uintptr_t)T.g) & 15) == 0) {
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void grad_sumsq_final_kernel(const double *par
         *sumsq = tot;
         const float norm = (float)sqrt(tot);
         const float c = max_norm / (norm + 1e-6f);
-        coef[0] = max_norm > 0.f ? fminf(c, 1.f) : 1.f;
+        coef[0] = max_norm > 0.f ? ((c != c) ? c : fminf(c, 1.f)) : 1.f;      // a NaN norm poisons every gradient, as torch's clamp(max=1) does
         coef[1] = norm;
     }
 }

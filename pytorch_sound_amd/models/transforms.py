@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from pytorch_sound_amd import host as H
 from pytorch_sound_amd import kernels as K
 from pytorch_sound_amd.utils.mel import mel_filterbank
 
@@ -63,10 +64,12 @@ class STFT(nn.Module):
     """Drop-in for transforms.py:13-101.  ``filter_length`` is the FFT size; a shorter ``win_length``
     is zero-centre-padded.  ``square_window`` is a real buffer; ``forward_basis`` / ``inverse_basis``
     (the reference's 2 x 4.2 MB dense matrices at n=1024) are not needed by the kernels: they are
-    accepted and ignored on ``load_state_dict`` and re-created in closed form by ``state_dict`` when
-    ``emit_reference_buffers`` is set, so checkpoints travel both ways."""
+    accepted and ignored on ``load_state_dict`` and re-created in closed form by ``state_dict``, so checkpoints
+    travel both ways (a checkpoint saved here passes a strict load in the reference).  ``emit_reference_buffers``:
+    None (default) = emit for filter_length <= 1024 (2 x 4.2 MB, what the reference itself saves), skip above
+    (2 x 67 MB at 4096: set True to get them); True / False force it."""
 
-    emit_reference_buffers = False
+    emit_reference_buffers = None
 
     def __init__(self, filter_length: int = 1024, hop_length: int = 512, win_length: int = None,
                  window: str = 'hann'):
@@ -91,6 +94,8 @@ class STFT(nn.Module):
         """(N,T) -> magnitude, phase, each (N, filter_length//2+1, T//hop+1).  phase carries no
         gradient (the reference takes atan2 of ``.data``, transforms.py:69)."""
         wav = _as_2d(wav)
+        if not wav.is_cuda:                                  # host tensors: the reference's formulation in torch ops (host.py)
+            return H.stft_mag_phase(wav, self.filter_length, self.hop_length, self._host_window(), H.FRAMING_CENTER)
         mag, phase = K.StftMagPhase.apply(wav, self._plan(wav.device), self.filter_length, self.hop_length,
                                           K.FRAMING_CENTER, 0.0, True)
         return mag, phase
@@ -98,12 +103,21 @@ class STFT(nn.Module):
     def magnitude(self, wav: torch.Tensor) -> torch.Tensor:
         """transform()[0] without computing the phase nobody asked for."""
         wav = _as_2d(wav)
+        if not wav.is_cuda:
+            return H.stft_mag_phase(wav, self.filter_length, self.hop_length, self._host_window(), H.FRAMING_CENTER,
+                                    want_phase=False)[0]
         return K.StftMagPhase.apply(wav, self._plan(wav.device), self.filter_length, self.hop_length,
                                     K.FRAMING_CENTER, 0.0, False)[0]
 
+    def _host_window(self):
+        return torch.from_numpy(self._window_np)
+
     def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
-        # square_window = window ** 2 is the reference's buffer; the window itself comes from the plan's source
-        win = torch.from_numpy(self._window_np).to(magnitude.device)
+        if not magnitude.is_cuda:
+            return H.istft(magnitude, phase, self.filter_length, self.hop_length, self._host_window(), eps)
+        # square_window = window ** 2 is the reference's buffer; the window itself comes from the plan's source (cached per device:
+        # the overlap-add envelope of IStft.backward is keyed on this tensor)
+        win = self._plans.get('win', magnitude.device, lambda: torch.from_numpy(self._window_np))
         return K.istft(magnitude, phase, self.filter_length, self.hop_length, self._plan(magnitude.device), eps, win)
 
     def forward(self, wav: torch.Tensor) -> torch.Tensor:  # the reference defines no forward
@@ -117,7 +131,10 @@ class STFT(nn.Module):
 
     @staticmethod
     def _emit_reference_keys(module, state_dict, prefix, local_metadata):
-        if not module.emit_reference_buffers:
+        emit = module.emit_reference_buffers
+        if emit is None:
+            emit = module.filter_length <= 1024
+        if not emit:
             return
         fb, ib = reference_bases(module.filter_length, module.hop_length, module._window_np)
         state_dict[prefix + 'forward_basis'] = torch.from_numpy(fb)
@@ -165,6 +182,10 @@ class LogMelSpectrogram(nn.Module):
 
     def forward(self, wav: torch.Tensor, log_offset: float = 1e-6) -> torch.Tensor:
         st = self.stft
+        if not wav.is_cuda:
+            mag = st.magnitude(wav)
+            return H.mel_log(mag, self.mel_filter, H.LOG_E, float(log_offset), None,
+                             self.min_db if self.min_db else None, self.max_db if self.max_db else None)
         if (st.filter_length // 2 + 1 == self.mel_filter.shape[1]
                 and K.logmel_fused_ok(wav, st.filter_length, st.hop_length)):
             w2 = _as_2d(wav)                           # one kernel, the magnitude never leaves the chip
@@ -204,17 +225,29 @@ class STFTTorchAudio(nn.Module):
 
     def forward(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         wav = _as_2d(wav)
+        if not wav.is_cuda:
+            c = H.stft_complex(wav, self.n_fft, self.hop_length, self._host_window(), H.FRAMING_CENTER)
+            return c.real, c.imag
         return K.StftReIm.apply(wav, self._plan(wav.device), self.n_fft, self.hop_length, K.FRAMING_CENTER)
+
+    def _host_window(self):
+        w = self.window.detach().cpu().float()
+        lp = (self.n_fft - w.numel()) // 2
+        return torch.nn.functional.pad(w, (lp, self.n_fft - w.numel() - lp))
 
     def transform(self, wav: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """magnitude and (differentiable) phase out of one launch; the phase gradient goes through psnd_polar_bwd."""
         wav = _as_2d(wav)
+        if not wav.is_cuda:
+            return H.stft_mag_phase(wav, self.n_fft, self.hop_length, self._host_window(), H.FRAMING_CENTER, detach_phase=False)
         return K.StftPolar.apply(wav, self._plan(wav.device), self.n_fft, self.hop_length, K.FRAMING_CENTER)
 
     def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor) -> torch.Tensor:
         """torch.istft(mag e^{i phase}, n_fft, hop, win_length, window) (transforms.py:313-319): overlap-add of the windowed inverse
         frames divided by the squared-window envelope, n_fft/2 trimmed on both sides, (F-1)*hop samples - psnd_istft with eps = 0
         (STFT.inverse adds its 1e-9 to the envelope, torch.istft divides plainly)."""
+        if not magnitude.is_cuda:
+            return H.istft(magnitude, phase, self.n_fft, self.hop_length, self._host_window(), 0.0)
         w = self.window
         win = self._plans.get(('win', w._version, w.data_ptr()), magnitude.device, lambda: torch.from_numpy(
             centre_pad(w.detach().cpu().numpy().astype(np.float32), self.n_fft)))
@@ -243,6 +276,12 @@ class _HifiGanMel(nn.Module):
         return self._plans.get(key, mf.device, lambda: K.mel_plan(mf.detach().cpu().numpy()))
 
     def _logmel(self, wav2d, framing, mag_eps, log_kind):
+        if not wav2d.is_cuda:
+            w = getattr(self, self._window_buf).detach().cpu().float()
+            lp = (self.n_fft - w.numel()) // 2
+            w = torch.nn.functional.pad(w, (lp, self.n_fft - w.numel() - lp))
+            mag = H.stft_mag_phase(_as_2d(wav2d), self.n_fft, self.hop_length, w, framing, mag_eps, want_phase=False)[0]
+            return H.mel_log(mag, getattr(self, self._filter_buf), log_kind, 0.0, 1e-5, None, None)
         if K.logmel_fused_ok(wav2d, self.n_fft, self.hop_length):
             M = getattr(self, self._filter_buf).shape[0]
             return K.logmel_forward(wav2d, self.n_fft, self.hop_length, self._stft_plan(wav2d.device), self._mel_plan(), M,
@@ -490,6 +529,9 @@ class LogMelSpectrogramTorchAudio(nn.Module):
     def forward(self, wav: torch.Tensor, log_offset: float = 1e-6) -> torch.Tensor:
         st = self.stft
         wav = _as_2d(wav)
+        if not wav.is_cuda:
+            mag = H.stft_mag_phase(wav, st.n_fft, st.hop_length, st._host_window(), H.FRAMING_CENTER, want_phase=False)[0]
+            return H.mel_log(mag * mag, self.mel_filter, H.LOG_E, float(log_offset), None, float(self.min_db), float(self.max_db))
         mag = K.StftMagPhase.apply(wav, st._plan(wav.device), st.n_fft, st.hop_length, K.FRAMING_CENTER, 0.0, False)[0]
         mf = self.mel_filter
         plan = self._plans.get(('mel', mf._version, mf.data_ptr()), mf.device, lambda: K.mel_plan(mf.detach().cpu().numpy()))

@@ -138,6 +138,10 @@ def test_stft_4096_wave_kernel_full_size(monkeypatch):
     monkeypatch.setenv('PSND_STFT4096_V2', '1')
     old = K.stft_forward(a, n_fft, hop, plan)['mag']
     assert float((out - old).abs().max()) <= 8e-6 * float(old.max())
+    # three whole 30-s clips of the full-size launch against the float64 oracle
+    for n in (0, 17, 31):
+        ref = ofe.stft_mag_f64(a[n:n + 1].cpu().numpy(), n_fft, hop)
+        assert np.abs(out[n:n + 1].cpu().numpy() - ref).max() <= FFT_RTOL * np.abs(ref).max()
     w = torch.from_numpy(ofe.analysis_window(n_fft)).to(dev).double()
     for n in (0, 17, 31):
         xp = torch.nn.functional.pad(a[n:n + 1].unsqueeze(1), (n_fft // 2, n_fft // 2), mode='reflect').squeeze(1).double()
@@ -196,6 +200,47 @@ def test_frame_indexing_bit_exact():
             for i, p in enumerate(pos):
                 count = (idx == p).sum(axis=1).astype(np.float32)          # F
                 assert np.array_equal(got['re'][i, 0, :], count), (n_fft, framing, p)
+
+
+@pytest.mark.parametrize('variant', ['wave', 'tile4', 'reim'])
+def test_frame_indexing_bit_exact_n4096(variant, monkeypatch):
+    """the same impulse contract at n_fft = 4096 on BOTH magnitude-only kernels of config 5 (`stft_fwd_n4096w_kernel` with its
+    hand-resolved reflect loads, forced at this size, and `stft_fwd_n4096b_kernel`) and on the (re, im) instance: |DC| of frame f is
+    the number of taps of frame f that read sample p - small integers, exact in fp32 (transforms.py:55-66)."""
+    if variant == 'wave':
+        monkeypatch.setenv('PSND_STFT4096_W', '1')
+    if variant == 'tile4':
+        monkeypatch.setenv('PSND_STFT4096_V2', '1')
+    n_fft = 4096
+    for hop, T in [(1024, 20000), (512, 9000), (1024, 2049)]:
+        for framing in (0, 1):
+            F = ofe.frame_count(T, n_fft, hop, framing)
+            idx = ofe.frame_sample_index(np.arange(F)[:, None], np.arange(n_fft)[None, :], T, n_fft, hop, framing)
+            pad = ofe.pad_amount(n_fft, hop, framing)
+            pos = sorted({0, 1, hop - 1, hop, min(pad - 1, T - 1), min(pad, T - 1), min(pad + 1, T - 1), T // 2, max(T - pad - 1, 0),
+                          max(T - pad, 0), T - 2, T - 1})
+            wav = np.zeros((len(pos), T), np.float32)
+            for i, p in enumerate(pos):
+                wav[i, p] = 1.0
+            if variant == 'reim':
+                got = _stft(wav, n_fft, hop, None, framing, window=np.ones(n_fft, np.float32), want_mag=False, want_reim=True)['re']
+            else:
+                got = _stft(wav, n_fft, hop, None, framing, window=np.ones(n_fft, np.float32), want_mag=True)['mag']
+            for i, p in enumerate(pos):
+                count = (idx == p).sum(axis=1).astype(np.float32)
+                assert np.array_equal(got[i, 0, :], count), (variant, hop, T, framing, p)
+
+
+def test_config5_one_clip_vs_oracle(monkeypatch):
+    """one 30-s clip of config 5 (44.1 kHz, 4096 / 1024) against ofe.stft_mag_f64 on both 4096 magnitude kernels."""
+    wav = seeded_wav(55, 1, 1323000, 44100)
+    ref = ofe.stft_mag_f64(wav, 4096, 1024)
+    for env in ('PSND_STFT4096_W', 'PSND_STFT4096_V2'):
+        monkeypatch.setenv(env, '1')
+        got = _stft(wav, 4096, 1024, want_mag=True)['mag']
+        monkeypatch.delenv(env)
+        assert got.shape == ref.shape == (1, 2049, 1292)
+        assert np.abs(got - ref).max() <= FFT_RTOL * np.abs(ref).max()
 
 
 def test_frame_indexing_golden(golden):

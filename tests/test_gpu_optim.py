@@ -168,9 +168,39 @@ def test_fused_clip_matches_trainer_clip_grad(clip_value, max_norm, scale):
         if max_norm:
             assert abs(float(og.last_grad_norm) - float(norm)) <= 2e-6 * float(norm)
     for p, q in zip(dev, host):
-        _close(p, q)
-        _close(og.state[p]['exp_avg'], orf.state[q]['exp_avg'])
-        _close(og.state[p]['exp_avg_sq'], orf.state[q]['exp_avg_sq'], 4e-6)
+        assert _close(p, q, 4e-6)
+        assert _close(og.state[p]['exp_avg'], orf.state[q]['exp_avg'], 4e-6)
+        assert _close(og.state[p]['exp_avg_sq'], orf.state[q]['exp_avg_sq'], 8e-6)
+
+
+@pytest.mark.parametrize('clip_value,max_norm', [(0.0, 0.0), (0.5, 0.0), (0.5, 3.0), (0.0, 3.0)])
+def test_nan_gradient_propagates_like_torch_clamp(clip_value, max_norm):
+    """fminf / fmaxf return the non-NaN operand, torch.clamp + clip_grad_norm_ (trainer.py:184-191) propagate NaN.  A NaN
+    gradient element with a finite loss must poison its parameter visibly (and, through the global norm, every parameter when
+    grad_norm is on) - not turn into a maximal finite update."""
+    host = [p.double().clone().requires_grad_(True) for p in _params(0)]
+    dev = [p.to(DEV).clone().requires_grad_(True) for p in _params(0)]
+    og, orf = O.Adam(dev, lr=1e-3), torch.optim.Adam(host, lr=1e-3)
+    grads = _params(300)
+    grads[0].view(-1)[5] = float('nan')
+    for p, q, g in zip(dev, host, grads):
+        p.grad = g.to(DEV).clone()
+        q.grad = g.double()
+    if clip_value:
+        for q in host:
+            q.grad = q.grad.clamp(-clip_value, clip_value)
+    if max_norm:
+        torch.nn.utils.clip_grad_norm_(host, max_norm)
+    og.fused_clip = (clip_value, max_norm)
+    og.step()
+    orf.step()
+    for p, q in zip(dev, host):
+        a, b = p.detach().cpu(), q.detach()
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.isfinite(a[~torch.isnan(a)]).all()
+    assert torch.isnan(dev[0].detach().view(-1)[5]).item()
+    if max_norm:
+        assert torch.isnan(og.last_grad_norm).item()
 
 
 def test_trainer_folds_clip_grad_into_the_optimizer_step(tmp_path):
