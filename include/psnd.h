@@ -82,6 +82,14 @@ int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, in
                   const void *plan, float mag_eps,
                   float *mag, float *phase, float *re, float *im, void *stream);
 
+/* psnd_stft_fwd (magnitude only) with the BIN axis fastest: mag_nfk : (N,F,K) fp32 = the transpose of psnd_stft_fwd's mag over its last
+ * two axes, same values.  transforms.py:53-69 fixes (N,K,F) at the module boundary (STFT.transform returns that); every consumer INSIDE
+ * this library (psnd_mel_*, the channels-last conv stack, the spectral losses) can take either layout, and in this one a frame's spectrum
+ * is one contiguous 4K-byte run: a wave stores whole cache lines that it owns alone.  Same algorithmic bytes (4NT + 4NKF).  Tuned
+ * kernels for n_fft 1024 and 4096, the one-frame-per-workgroup kernel for every other supported size. */
+int psnd_stft_mag_nfk(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                      const void *plan, float mag_eps, float *mag_nfk, void *stream);
+
 /* ---- STFT backward (autograd through transforms.py:55-69 / torch.stft):
  *   gwav[n,t] = sum over (f,m) with frame_sample_index(f,m)==t of
  *               win[m] * sum_k ( gre[n,k,f] cos(2 pi k m/n) - gim[n,k,f] sin(2 pi k m/n) )

@@ -34,6 +34,7 @@ SIGNATURES = {
     'psnd_stft_plan_bytes': (_c.c_size_t, [_INT]),
     'psnd_stft_plan_build': (_INT, [_INT, _P, _P]),
     'psnd_stft_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
+    'psnd_stft_mag_nfk': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P]),
     'psnd_stft_bwd': (_INT, [_P, _I64, _I64, _INT, _INT, _INT, _P, _F, _P, _P, _P, _P, _P]),
     'psnd_istft': (_INT, [_P, _P, _I64, _I64, _INT, _INT, _P, _F, _P, _P]),
     'psnd_mel_plan_bytes': (_c.c_size_t, [_INT, _INT]),

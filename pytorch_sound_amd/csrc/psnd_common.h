@@ -141,6 +141,8 @@ typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t T) {
     if (i < 0) i = -i;

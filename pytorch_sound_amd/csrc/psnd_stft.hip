@@ -21,6 +21,7 @@
 // The only LDS round trip is the transposing exchange between the passes (4 KB/frame each way).
 #include "psnd_stft_pass.h"
 #include "psnd_stft_w.h"
+#include "psnd_stft_q.h"
 #include "psnd_pk.h"
 #include <math.h>
 #include <string.h>
@@ -42,6 +43,7 @@ struct StftFwdParams {
     int hop, pad, ntile, total_tiles;
     float mag_eps;
     int ablate;   // debug only (PSND_ABLATE): bit1 skip global stores
+    int nfk = 0;  // psnd_stft_mag_nfk: the output is (N, F, K), bin axis fastest (generic kernel; the tuned NFK kernels live in psnd_stft_w.hip / psnd_stft_q.hip)
     // fused wav -> log-mel (psnd_logmel_fwd): the magnitude tile stays in LDS and is projected there
     const int *mel_plan;
     float *mel_out;
@@ -1165,8 +1167,10 @@ __global__ __launch_bounds__(256) void stft_fwd_generic_kernel(StftFwdParams p, 
         }
         __syncthreads();
     }
-    const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)p.F + (size_t)f;
-    Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, (int)(((long long)(C + 1) * p.F - f) * 4), p.mag_eps, true);
+    // (N, K, F): element (k, f) of the clip at k F + f; (N, F, K): at f K + k
+    const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)p.F + (p.nfk ? (size_t)f * (size_t)(C + 1) : (size_t)f);
+    const long long kstep = p.nfk ? 1 : p.F;
+    Emit<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, p.nfk ? (C + 1) * 4 : (int)(((long long)(C + 1) * p.F - f) * 4), p.mag_eps, true);
     for (int k = t; k <= C / 2; k += 256) {
         const int kc = (C - k) % C;
         float sn, cs;
@@ -1174,8 +1178,8 @@ __global__ __launch_bounds__(256) void stft_fwd_generic_kernel(StftFwdParams p, 
         // v_k = -i W_n^k = sn - i cs ; inputs here are unscaled -> halve
         float xkr, xki, xcr, xci;
         rfft_pair(0.5f * sr[k], 0.5f * si[k], 0.5f * sr[kc], 0.5f * si[kc], sn, -cs, xkr, xki, xcr, xci);
-        emit((int)((long long)k * p.F * 4), 0, xkr, xki);
-        if (k != C - k) emit((int)((long long)(C - k) * p.F * 4), 0, xcr, xci);
+        emit((int)((long long)k * kstep * 4), 0, xkr, xki);
+        if (k != C - k) emit((int)((long long)(C - k) * kstep * 4), 0, xcr, xci);
     }
 }
 
@@ -1342,9 +1346,9 @@ extern "C" int psnd_stft_plan_build(int n_fft, const float *window_host, void *p
     return PSND_OK;
 }
 
-extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
-                             const void *plan, float mag_eps, float *mag, float *phase, float *re, float *im,
-                             void *stream) {
+static int stft_fwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                         const void *plan, float mag_eps, float *mag, float *phase, float *re, float *im,
+                         int nfk, void *stream) {
     if (!wav || !plan) PSND_FAIL(PSND_E_ARG, "stft_fwd: null wav/plan");
     if ((re == nullptr) != (im == nullptr)) PSND_FAIL(PSND_E_ARG, "stft_fwd: re and im must be given together");
     if (!mag && !phase && !re) PSND_FAIL(PSND_E_ARG, "stft_fwd: no output requested");
@@ -1362,7 +1366,7 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     StftFwdParams p;
     p.wav = wav, p.plan = static_cast<const float *>(plan);
     p.mag = mag, p.phase = phase, p.re = re, p.im = im;
-    p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps;
+    p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps, p.nfk = nfk;
     {
         const char *ab = getenv("PSND_ABLATE");
         p.ablate = ab ? atoi(ab) : 0;
@@ -1374,6 +1378,20 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
 #endif
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nfk) {
+        // bin-fastest magnitudes: a frame's spectrum is one contiguous run.  n_fft = 1024: a wave owns four frames (psnd_stft_q.hip);
+        // n_fft = 4096: one wave per frame (psnd_stft_w.hip); any other size: the one-frame-per-workgroup kernel below.
+        if (n_fft == 1024 && psnd_stft1024q_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC"))
+            return psnd_stft1024q_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, s);
+        if (n_fft == 4096 && psnd_stft4096w_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC"))
+            return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, 1, s);
+        if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_mag_nfk(generic): grid too large");
+        p.ntile = 0, p.total_tiles = 0;
+        if (const Decomp *dd = find_decomp(n_fft)) p.plan += plan_layout(n_fft, dd->R1, dd->L).win;      // the raw window inside a tuned plan
+        hipLaunchKernelGGL((stft_fwd_generic_kernel<true, false, false>), dim3((unsigned)F, (unsigned)N), dim3(256), sizeof(float) * (size_t)n_fft, s, p, n_fft);
+        PSND_CHECK_LAUNCH("stft_mag_nfk(generic)");
+        return PSND_OK;
+    }
     const Decomp *d = find_decomp(n_fft);
     if (d) {
         const int FT = 512 / d->R1;
@@ -1406,7 +1424,7 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
         // launches keep the 4-frame kernel with its two workgroups per CU.
         const int64_t tiles16 = N * ((F + 15) / 16);
         if (tiles16 >= 2048 || getenv("PSND_STFT4096_W"))
-            return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, s);
+            return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, 0, s);
     }
     if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {
         // 4-frame tiles, two workgroups per CU (span <= 4 pieces per thread)
@@ -1434,6 +1452,21 @@ extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, 
     else hipLaunchKernelGGL((stft_fwd_generic_kernel<true, true, true>), grid, dim3(256), lds, s, p, n_fft);
     PSND_CHECK_LAUNCH("stft_fwd(generic)");
     return PSND_OK;
+}
+
+extern "C" int psnd_stft_fwd(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                             const void *plan, float mag_eps, float *mag, float *phase, float *re, float *im,
+                             void *stream) {
+    return stft_fwd_impl(wav, N, T, n_fft, hop, framing, plan, mag_eps, mag, phase, re, im, 0, stream);
+}
+
+// psnd_stft_fwd (magnitude only) with the BIN axis fastest: mag_nfk (N, F, K).  Same arithmetic, same algorithmic bytes; a frame's
+// spectrum is one contiguous run, so a wave writes whole lines (no 64-byte runs at a 4 F-byte pitch shared with the neighbouring
+// workgroup).  For callers that own their consumer (the mel / channels-last kernels of this library take either layout).
+extern "C" int psnd_stft_mag_nfk(const float *wav, int64_t N, int64_t T, int n_fft, int hop, int framing,
+                                 const void *plan, float mag_eps, float *mag_nfk, void *stream) {
+    if (!mag_nfk) PSND_FAIL(PSND_E_ARG, "stft_mag_nfk: null output");
+    return stft_fwd_impl(wav, N, T, n_fft, hop, framing, plan, mag_eps, mag_nfk, nullptr, nullptr, nullptr, 1, stream);
 }
 
 // multi_stft_loss (models/sound.py:106-133), one resolution: STFT magnitude of the PREDICTION compared with the target magnitudes in

@@ -12,4 +12,4 @@ constexpr int kW4096PlanFloats = kW4096ClOff + 128;
 void psnd_stft4096w_plan_fill(float *plan);                      // host: the two tables above
 bool psnd_stft4096w_ok(long long T, long long F, int hop, int pad);
 int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long long N, long long T, long long F, int hop, int pad,
-                          float mag_eps, int ablate, hipStream_t stream);
+                          float mag_eps, int ablate, int nfk /* 1: output (N, F, K) */, hipStream_t stream);

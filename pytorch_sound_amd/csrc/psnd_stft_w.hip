@@ -113,7 +113,11 @@ __device__ __forceinline__ float bperm(int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-template <bool ALIGNED4>
+// NFK = true: the bin-fastest output (N, F, K) of psnd_stft_mag_nfk - a frame's spectrum is ONE contiguous 8196-byte run, so every
+// wave stores its own frame straight from registers (a v_permlane32_swap pairs the even / odd bins of the two half-waves: 8-byte
+// stores, 256 contiguous bytes per half-wave and instruction): no staging tile, no workgroup barrier inside the tile loop - the 16
+// waves of the workgroup share nothing but the tables.
+template <bool ALIGNED4, bool NFK = false>
 __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_win = smem;                          // [32 loads][64 lanes] of (0.5 w[2n], 0.5 w[2n+1]) in the order a lane loads its samples
@@ -338,6 +342,33 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
 #endif
         }
         PSND_W_STAMP(5);
+        if constexpr (NFK) {
+            long long ns0 = 0;
+            const float *nx = nullptr;
+            const int nkind = tile + tw.step < tw.end ? frame_kind(tile + tw.step, ns0, nx) : 0;
+            if (nkind == 1) request_interior(nx, ns0);            // ahead of this frame's stores in the in-order vector-memory queue
+            if (had && !(p.ablate & 2)) {
+                const int ln = fresh_lane();
+                const int lam_ = ln & 31, g_ = ln >> 5;
+                // frame f0 + w of the clip: K contiguous floats (wave-uniform base, range-checked by the descriptor)
+                const __amdgpu_buffer_rsrc_t ro = make_uniform_rsrc(p.mag + ((size_t)clip * (size_t)F + (size_t)(f0 + w)) * kK, kK * 4);
+                const int vlo = (64 * g_ + 2 * lam_) * 4;                      // bins 64 (j + g) + 2 lam, + 1
+                const int vhi = (2047 - 64 * 14 - 64 * g_ - 2 * lam_) * 4;     // bins 2047 - 64 (j + g) - 2 lam, + 1   (j even: + 256 (14 - j) bytes)
+                static_for<0, 8>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = 2 * decltype(jc)::value;
+                    // lanes < 32 hold c = 2 lam, lanes >= 32 c = 2 lam + 1: after the swap a lane of the lower half owns the bin PAIR of
+                    // row j, a lane of the upper half the pair of row j + 1
+                    float a0 = mlo[j], a1 = mlo[j + 1], b0 = mhi[j], b1 = mhi[j + 1];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{a0, a1}), ro, vlo, 256 * j, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{b1, b0}), ro, vhi, 256 * (14 - j), 0);
+                });
+                if (ln == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mext), ro, 1024 * 4, 0, 0);
+            }
+            if (nkind == 2) request_edge(nx, ns0);                // the exchange buffer is the wave's own at all times
+            kind = nkind;
+            continue;
+        }
         // addresses of the staging / store phases (see fresh_lane)
         const int ln = fresh_lane();
         const bool special = ln == 0;
@@ -434,7 +465,7 @@ bool psnd_stft4096w_ok(long long T, long long F, int hop, int pad) {
 }
 
 int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long long N, long long T, long long F, int hop, int pad,
-                          float mag_eps, int ablate, hipStream_t stream) {
+                          float mag_eps, int ablate, int nfk, hipStream_t stream) {
     WParams p;
     p.wav = wav, p.plan = plan, p.mag = mag, p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps, p.ablate = ablate;
     {
@@ -463,7 +494,8 @@ int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long 
         hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, p);
         return PSND_OK;
     };
-    const int rc = (F % 4 == 0) ? launch(stft_fwd_n4096w_kernel<true>) : launch(stft_fwd_n4096w_kernel<false>);
+    const int rc = nfk ? launch(stft_fwd_n4096w_kernel<false, true>)
+                       : ((F % 4 == 0) ? launch(stft_fwd_n4096w_kernel<true>) : launch(stft_fwd_n4096w_kernel<false>));
     if (rc != PSND_OK) return rc;
     PSND_CHECK_LAUNCH("stft_fwd(n4096w)");
     return PSND_OK;

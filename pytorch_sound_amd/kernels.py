@@ -17,6 +17,7 @@ _INF = float('inf')
 # bench.py sets this to a list to collect (start, end) HIP event pairs recorded on the launch stream directly
 # around every psnd_stft_fwd call (magnitude-only launches), i.e. without the Python work around it.
 STFT_FWD_EVENTS = None
+STFT_NFK_EVENTS = None          # the same for psnd_stft_mag_nfk
 
 
 def _need_cuda(t, name):
@@ -76,6 +77,35 @@ def stft_forward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0,
             e1.record()
             ev.append((e0, e1, N))
     return {'mag': mag, 'phase': phase, 're': re, 'im': im}
+
+
+def stft_mag_nfk(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0, out=None):
+    """psnd_stft_mag_nfk: wav (N,T) fp32 -> magnitude (N, F, K), bin axis fastest (`.transpose(1, 2)` is the reference's (N, K, F)
+    as a view).  For consumers inside this library that take the layout (mel kernel, channels-last conv stack); no autograd."""
+    _need_cuda(wav, 'wav')
+    if wav.dim() != 2:
+        raise _lib.PsndError('wav must be (N, T), got %s' % (tuple(wav.shape),))
+    if plan.device != wav.device:
+        raise _lib.PsndError('stft plan lives on %s but wav on %s (move the module with .to())' % (plan.device, wav.device))
+    wav = wav.detach().contiguous()
+    N, T = wav.shape
+    F = frame_count(T, n_fft, hop, framing)
+    K = n_fft // 2 + 1
+    if out is None:
+        out = torch.empty((N, F, K), dtype=torch.float32, device=wav.device)
+    elif tuple(out.shape) != (N, F, K) or out.dtype != torch.float32 or out.device != wav.device or not out.is_contiguous():
+        raise _lib.PsndError('stft_mag_nfk: out must be a contiguous fp32 (%d, %d, %d) tensor on %s' % (N, F, K, wav.device))
+    ev = STFT_NFK_EVENTS if not torch.cuda.is_current_stream_capturing() else None
+    with torch.cuda.device(wav.device):
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        check(lib().psnd_stft_mag_nfk(ptr(wav), N, T, n_fft, hop, framing, ptr(plan), float(mag_eps), ptr(out), stream_ptr(wav.device)),
+              'psnd_stft_mag_nfk')
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, N))
+    return out
 
 
 def stft_backward(wav, n_fft, hop, plan, framing=FRAMING_CENTER, mag_eps=0.0, gmag=None, gre=None, gim=None):

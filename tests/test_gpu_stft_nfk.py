@@ -1,0 +1,118 @@
+"""psnd_stft_mag_nfk: the magnitude with the BIN axis fastest, (N, F, K) - against the float64 oracle (transposed), the reference
+goldens, the impulse (bit-exact framing) contract and the (N, K, F) kernels on the same input.  Tolerance: as test_gpu_features
+(4e-6 of the largest bin: fp32 FFT round-off)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import seeded_wav
+from oracle import features as ofe
+
+pytestmark = pytest.mark.gpu
+FFT_RTOL = 4e-6
+DEV = torch.device('cuda:0')
+
+
+def _nfk(wav_np, n_fft, hop, win=None, framing=0, mag_eps=0.0, window=None):
+    from pytorch_sound_amd import kernels as K
+    w = ofe.analysis_window(n_fft, win) if window is None else np.asarray(window, np.float32)
+    plan = K.stft_plan(n_fft, w).to(DEV)
+    out = K.stft_mag_nfk(torch.from_numpy(wav_np).to(DEV), n_fft, hop, plan, framing, mag_eps)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+CASES = [
+    # n_fft = 1024: the wave-per-four-frames kernel (psnd_stft_q.hip)
+    (1024, 256, None, 0, 4, 44100),      # BASELINE config 1 / 2 clip: F = 173 (partial last quad / tile)
+    (1024, 256, None, 0, 1, 8192),       # F = 33
+    (1024, 256, 800, 0, 2, 3000),        # short window
+    (1024, 256, None, 1, 3, 8192),       # HiFi-GAN framing (config 3)
+    (1024, 256, None, 0, 1, 513),        # T barely above the pad: every frame reflects
+    (1024, 128, None, 0, 2, 5000),
+    (1024, 64, None, 0, 1, 4000),
+    (1024, 200, None, 0, 2, 6000),       # hop % 4 == 0 but not a power of two
+    (1024, 250, None, 0, 2, 6000),       # hop % 4 != 0
+    (1024, 512, None, 0, 2, 9000),       # a hop the four-frame span does not cover -> generic kernel
+    (1024, 256, None, 0, 37, 10000),     # many clips: persistent workgroups with several tiles
+    # n_fft = 4096: the wave-per-frame kernel, stores straight from registers
+    (4096, 1024, None, 0, 1, 9000),
+    (4096, 1024, None, 0, 3, 44100),
+    (4096, 1024, 3000, 1, 2, 30000),
+    (4096, 1022, None, 0, 1, 20000),
+    (4096, 512, None, 0, 2, 40000),
+    (4096, 1024, None, 0, 1, 2049),
+    (4096, 1024, None, 0, 21, 60000),
+    # the other sizes: one frame per workgroup
+    (512, 128, None, 0, 2, 3000), (2048, 512, None, 0, 2, 9000), (256, 64, 200, 1, 2, 1500), (64, 16, None, 0, 1, 300),
+]
+
+
+@pytest.mark.parametrize('n_fft,hop,win,framing,N,T', CASES)
+def test_nfk_vs_oracle(n_fft, hop, win, framing, N, T):
+    wav = seeded_wav(n_fft + hop + T, N, T)
+    got = _nfk(wav, n_fft, hop, win, framing)
+    ref = ofe.stft_mag_f64(wav, n_fft, hop, win, framing)
+    assert got.shape == (N, ofe.frame_count(T, n_fft, hop, framing), n_fft // 2 + 1)
+    assert np.abs(got.transpose(0, 2, 1) - ref).max() <= FFT_RTOL * np.abs(ref).max()
+    got_eps = _nfk(wav, n_fft, hop, win, framing, mag_eps=1e-9)
+    assert np.abs(got_eps.transpose(0, 2, 1) - np.sqrt(ref * ref + 1e-9)).max() <= FFT_RTOL * np.abs(ref).max()
+
+
+def test_nfk_every_element_written_and_nothing_else():
+    """NaN-filled output with guard rows on both sides: every element of (N, F, K) is written, nothing outside it."""
+    from pytorch_sound_amd import kernels as K
+    for n_fft, hop, N, T in [(1024, 256, 5, 44100), (4096, 1024, 3, 50000), (512, 128, 2, 3000)]:
+        wav = torch.from_numpy(seeded_wav(7, N, T)).to(DEV)
+        plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(DEV)
+        F, Kb = K.frame_count(T, n_fft, hop), n_fft // 2 + 1
+        buf = torch.full((N * F * Kb + 2 * 4096,), float('nan'), device=DEV)
+        out = buf[4096:4096 + N * F * Kb].view(N, F, Kb)
+        K.stft_mag_nfk(wav, n_fft, hop, plan, out=out)
+        assert torch.isfinite(out).all()
+        assert torch.isnan(buf[:4096]).all() and torch.isnan(buf[-4096:]).all()
+
+
+@pytest.mark.parametrize('n_fft', [1024, 4096])
+def test_nfk_frame_indexing_bit_exact(n_fft):
+    """impulse at sample p, all-ones window: |DC| of frame f = the number of taps of frame f that read p (transforms.py:55-66)."""
+    hop = n_fft // 4
+    for T in (5 * n_fft - 37, n_fft // 2 + 1):
+        for framing in (0, 1):
+            F = ofe.frame_count(T, n_fft, hop, framing)
+            idx = ofe.frame_sample_index(np.arange(F)[:, None], np.arange(n_fft)[None, :], T, n_fft, hop, framing)
+            pad = ofe.pad_amount(n_fft, hop, framing)
+            pos = sorted({0, 1, min(hop - 1, T - 1), min(hop, T - 1), min(pad - 1, T - 1), min(pad, T - 1), min(pad + 1, T - 1), T // 2,
+                          max(T - pad - 1, 0), max(T - pad, 0), T - 2, T - 1})
+            wav = np.zeros((len(pos), T), np.float32)
+            for i, p in enumerate(pos):
+                wav[i, p] = 1.0
+            got = _nfk(wav, n_fft, hop, None, framing, window=np.ones(n_fft, np.float32))
+            for i, p in enumerate(pos):
+                assert np.array_equal(got[i, :, 0], (idx == p).sum(axis=1).astype(np.float32)), (n_fft, T, framing, p)
+
+
+def test_nfk_golden_reference(golden):
+    """the reference's own STFT.transform magnitudes (tests/golden/stft.npz), transposed"""
+    g = golden('stft')
+    for name in ('n1024_h256', 'n1024_h256_w800', 'n512_h128', 'n256_h64_w200', 'n2048_h512', 'n4096_h1024'):
+        n, h, w = (int(v) for v in g[name + '/params'])
+        got = _nfk(g[name + '/wav'], n, h, w)
+        gm = g[name + '/mag']
+        assert np.abs(got.transpose(0, 2, 1) - gm).max() <= 6e-6 * gm.max()
+
+
+@pytest.mark.parametrize('n_fft,hop,N,T,sr', [(1024, 256, 64, 44100, 22050), (4096, 1024, 32, 1323000, 44100)])
+def test_nfk_full_size_equals_nkf(n_fft, hop, N, T, sr):
+    """BASELINE full sizes (config 2: 2 x 32 clips x 2 s; config 5: 32 x 30 s): equal to psnd_stft_fwd on the same input (which the
+    oracle / Parseval tests of test_gpu_features pin), whole clips against the float64 oracle."""
+    from pytorch_sound_amd import kernels as K
+    g = torch.Generator(device='cpu').manual_seed(11)
+    a = (0.0708 * torch.randn(N, T, generator=g)).to(DEV)
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(DEV)
+    nkf = K.stft_forward(a, n_fft, hop, plan)['mag']
+    nfk = K.stft_mag_nfk(a, n_fft, hop, plan)
+    assert float((nfk.transpose(1, 2) - nkf).abs().max()) <= 8e-6 * float(nkf.max())
+    for n in (0, N - 1):
+        ref = ofe.stft_mag_f64(a[n:n + 1].cpu().numpy(), n_fft, hop)
+        assert np.abs(nfk[n:n + 1].cpu().numpy().transpose(0, 2, 1) - ref).max() <= FFT_RTOL * np.abs(ref).max()
