@@ -1,3 +1,332 @@
+// psnd_stft_q.hip - n_fft = 1024 forward STFT, magnitude output in the BIN-FASTEST layout (N, F, K) of psnd_stft_mag_nfk:
+// ONE WAVE OWNS FOUR CONSECUTIVE FRAMES from its samples to its stores.
+//
+// Replaces STFT.transform (pytorch_sound/models/transforms.py:53-69) where the consumer is a kernel of this library (mel projection,
+// channels-last conv stack, spectral losses), which take either layout.
+//
+// Why another n = 1024 kernel.  stft_fwd_n1024_kernel (psnd_stft.hip) writes the reference's frame-fastest (N, K, F): its pass 2 spreads
+// the bin rows of a 16-frame tile over the four waves of a workgroup so that a store instruction covers 16 frames x 4 bins = 64-byte
+// runs - which needs the exchange between the passes to cross waves, i.e. five workgroup barriers per tile, 39 KB of LDS per 4 waves and
+// one tile per workgroup (prologue latency exposed: profiles/r03_stft1024_phase_table.txt - a quarter of a workgroup's life is the load
+// prologue, a quarter the half exchange with its barriers).  With the bin axis fastest a frame's spectrum is ONE contiguous 2052-byte
+// run, so the lanes that hold a frame's bins can store it alone, whatever wave they are in:
+//
+//   * wave = 4 frames x 16 lanes in BOTH passes: pass 1 lane (frame, l) holds z[l + 16 a], a < 32 (window, radix-32 in registers,
+//     inter-pass twiddle), pass 2 lane (frame, qq) holds the rows qq and 32 - qq (two radix-16, real-FFT split: post_emit_pk of the
+//     span-staged kernel) - the exchange between the passes never leaves the wave: a 9.2 KB LDS buffer of its own, two half rounds,
+//     LDS operations of one wave execute in order => NO workgroup barrier anywhere in the tile loop;
+//   * the wave's span of samples (3 hop + 1024 = 7 KB) is fetched with 16-byte loads into registers one quad AHEAD (requested before
+//     the current quad's stores in the in-order vector-memory queue) and staged through the same LDS buffer;
+//   * 16 waves = one persistent 1024-thread workgroup per CU share nothing but the tables (10.8 KB, loaded once per workgroup instead
+//     of once per tile); they drift apart, so loads, butterflies, LDS rounds and stores of different waves overlap freely;
+//   * stores: 16 lanes x 4 bytes = 64 contiguous bytes per frame and instruction, 4 frames per instruction; a wave's 34 store
+//     instructions fill one contiguous 8.2 KB region that no other wave touches.
+//
+// Bound: HBM, 4 hop + 4 K = 3076 B per frame at hop 256 (DESIGN.md 4.1d for the measured fraction).
+#include "psnd_pk.h"
+#include "psnd_stft_pass.h"
+#include "psnd_stft_emit.h"
 #include "psnd_stft_q.h"
-bool psnd_stft1024q_ok(long long, long long, int, int) { return false; }
-int psnd_stft1024q_launch(const float *, const float *, float *, long long, long long, long long, int, int, float, int, hipStream_t) { return PSND_E_UNSUPPORTED; }
+#include <stdlib.h>
+
+#ifndef PSND_Q_STORE_AUX
+#define PSND_Q_STORE_AUX 2    // cache-policy bits of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt: whole lines written once, never
+                              // re-read by this kernel - measured 148 against 162 us (same box, 1024 clips x 2 s); 17 / 18 / 19: 166 / 159 / 161
+#endif
+#ifdef PSND_Q_NOSB            // A/B builds (tools/r04/variant_q.sh): no scheduling fences between the phases
+#define Q_SB()
+#else
+#define Q_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+namespace {
+using namespace psnd_stft;
+
+constexpr int kR1 = 32, kL = 16, kC = 512, kNFFT = 1024, kK = 513;
+constexpr int kWaves = 16;                         // waves per workgroup: 4 per SIMD at <= 128 VGPRs, one workgroup per CU
+constexpr int kRow = 2 * kR1 + 4;                  // pitch of the window / twiddle tables (plan layout, psnd_stft_plan.h)
+constexpr int kVkp = (2 * (kC / 2 + 1) + 3) & ~3;
+constexpr int kTab = 2 * kL * kRow + kVkp;         // floats of tables in LDS: wt[16][68] | tw[16][68] | vk[257](re, im)
+constexpr int kRP = 2 * kL + 4;                    // exchange row pitch (floats): 16 complex + 4; row * 9 mod 16 distinct -> b128 reads conflict-free
+constexpr int kXF = 16 * kRP;                      // one frame's half exchange (16 rows); 576 = 0 (mod 64): the 4 frames of a lane group differ in rows only
+constexpr int kXW = 4 * kXF;                       // a wave's buffer: 2304 floats = 9216 B (also its span of samples)
+constexpr int kLdsFloats = kTab + kWaves * kXW;
+static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
+constexpr int kStoresPerQuad = 10;                 // store instructions a wave issues per quad (behind the next span's transfer): 9 x 16 bytes per lane + 1 tail
+constexpr int kSPVMax = 9;                         // 16-byte span pieces per lane: 64 x 9 x 4 = 2304 samples (hop 256: 7)
+
+struct QParams {
+    const float *wav;
+    const float *plan;
+    float *mag;
+    long long T, F;
+    int hop, pad, nq, total_groups;                // nq = quads per clip; a group = 16 consecutive quads (one per wave)
+    long long total_quads;
+    float mag_eps;
+    int ablate;                                    // debug (PSND_ABLATE): 2 = no global stores
+};
+
+// magnitude writer for post_emit_pk: the wave-uniform descriptor covers the quad's frames, voff = frame * 4 K + bin * 4
+struct EmitNfk {
+    __amdgpu_buffer_rsrc_t r;
+    v2f eps2;
+    template <bool CONJ>
+    __device__ __forceinline__ OutVal make(v2f x) const {
+        OutVal o;
+        const v2f sq = pk::fma(x, x, eps2);
+        o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        return o;
+    }
+    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.m), r, voff, soff, 0);
+    }
+};
+
+// magnitude writer into the wave's LDS buffer: the quad's four spectra as they will lie in memory (frame * K + bin), post_emit_pk's
+// byte offsets are used as they are
+struct EmitStage {
+    float *buf;
+    v2f eps2;
+    template <bool CONJ>
+    __device__ __forceinline__ OutVal make(v2f x) const {
+        OutVal o;
+        const v2f sq = pk::fma(x, x, eps2);
+        o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
+        return o;
+    }
+    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(buf) + voff + soff) = o.m;
+    }
+};
+
+// HOP256: hop == 256 (settings.py:13, every BASELINE config at this size) - the span is stored with a skew of 32 floats per 256
+// samples, so that the two frames of a 32-lane group (256 samples apart = the same 32 of 64 banks) read disjoint banks; the tap
+// offsets stay compile-time immediates.  Other hops: plain span (partial two-way conflicts on the tap reads).
+template <bool HOP256>
+__global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_wt = smem, *s_tw = smem + kL * kRow, *s_vk = smem + 2 * kL * kRow;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    float *xw = smem + kTab + w * kXW;             // this wave's buffer: span of samples, then the exchange halves
+    // lane = (frame of the quad fi = lane >> 4, l = lane & 15): pass 1 lane l of the frame, pass 2 row pair qq = l.
+    // Per-lane addresses are NOT kept across the loop: every phase derives its own from a lane id laundered through an empty asm (hipcc
+    // would hoist ~15 address registers out of the loop, past the 128 there are - and a scratch reload issued behind a global store
+    // waits for that store's acknowledgement: one in-order vmcnt, psnd_stft_w.hip).
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(ln));
+        return ln;
+    };
+    const int hop = p.hop;
+    const TileWalk tw = tile_walk(p.total_groups);
+
+    // ---- the wave's quad of a group: clip, first frame, frames that exist -------------------------------------------------------
+    auto quad_of = [&](int group, int &clip, int &f0, int &nval) __attribute__((always_inline)) {
+        const unsigned q = (unsigned)group * kWaves + w;            // (< 2^31: checked at launch)
+        if (q >= (unsigned)p.total_quads) {
+            nval = 0, clip = 0, f0 = 0;
+            return;
+        }
+        clip = (int)(q / (unsigned)p.nq);
+        f0 = (int)(q - (unsigned)clip * (unsigned)p.nq) * 4;
+        const long long left = p.F - f0;
+        nval = left < 4 ? (int)left : 4;
+    };
+    constexpr int kSPV = HOP256 ? 7 : kSPVMax;
+    constexpr int kPiece = 256 + (HOP256 ? 32 : 0);              // LDS floats between two 256-sample pieces of the span
+    typedef __attribute__((address_space(3))) char *lds_ptr;
+    const unsigned xw_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_ptr)xw));        // LDS byte address of the buffer (SGPR)
+    // The quad's span of samples goes STRAIGHT into the wave's LDS buffer (buffer_load_dwordx4 ... lds: 1 KiB = 256 samples per
+    // instruction, lane-linear - exactly the span's layout, the skew of HOP256 falls between two instructions): no staging registers,
+    // no commit pass.  Range-checked by the descriptor (lanes past the span deliver zeros).  The instructions are written out: as a
+    // builtin hipcc answers the next LDS read with vmcnt(0), i.e. it waits for the 33 STORES issued behind the transfer as well (one
+    // in-order counter for loads and stores); here the wait at the top of the next quad is counted - vmcnt(kStoresPerQuad).
+    // Clip edges (reflect indexing; the first and the last one or two quads of a clip): element by element in a rolled loop.
+    auto request_span = [&](int clip, int f0, int nval) __attribute__((always_inline)) {
+        const float *x_ = p.wav + (size_t)clip * p.T;
+        const int span_len = (nval - 1) * hop + kNFFT;
+        const long long g0 = (long long)f0 * hop - p.pad;
+        if (p.ablate & 4) return;                                // A/B: no sample loads
+        if (g0 >= 0 && g0 + span_len <= p.T) {                   // wave-uniform
+            const unsigned long long a = reinterpret_cast<unsigned long long>(x_ + g0);
+            u32x4 rs;
+            rs.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+            rs.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+            rs.z = __builtin_amdgcn_readfirstlane((unsigned)(span_len * 4));
+            rs.w = 0x00020000u;
+            const int voff = fresh_lane() * 16;
+#pragma unroll
+            for (int j = 0; j < kSPV; ++j) {
+                const unsigned dst = xw_lds + 4u * kPiece * j;
+                const int soff = 1024 * j;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"(dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
+            }
+        } else {
+            const int Ti = (int)p.T, gb = (int)g0;
+#pragma unroll 1
+            for (int s = fresh_lane(); s < span_len; s += 64) xw[s + (HOP256 ? 32 * (s >> 8) : 0)] = x_[reflect_idx32(gb + s, Ti)];
+        }
+    };
+
+    int clip = 0, f0 = 0, nval = 0;
+    if (tw.first < tw.end) {
+        quad_of(tw.first, clip, f0, nval);
+        if (nval > 0) request_span(clip, f0, nval);             // HBM first, then the tables (L2)
+    }
+    for (int i = t; i < kTab / 4; i += 1024) reinterpret_cast<f32x4 *>(smem)[i] = reinterpret_cast<const f32x4 *>(p.plan)[i];
+    __syncthreads();                                            // the only workgroup barrier: tables visible
+
+    for (int group = tw.first; group < tw.end; group += tw.step) {
+        int nclip = 0, nf0 = 0, nnval = 0;
+        if (group + tw.step < tw.end) quad_of(group + tw.step, nclip, nf0, nnval);
+        if (nval > 0) {                                         // wave-uniform
+            // the span transfer was issued in front of the previous quad's stores: wait for IT, not for them
+            if (group != tw.first && !(p.ablate & 2)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStoresPerQuad) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- pass 1: taps, window, radix-32, inter-pass twiddle ---------------------------------------------------------------
+            v2f z[kR1];
+            {
+                const int ln = fresh_lane(), fi = ln >> 4, l = ln & 15;
+                const int sb = fi * hop + 2 * l;
+                const float *tb = xw + sb + (HOP256 ? 32 * fi : 0);
+                static_for<0, kR1>([&](auto ac) __attribute__((always_inline)) {
+                    constexpr int a = decltype(ac)::value;
+                    // sample 2 (l + 16 a) of the frame; HOP256: 32 a + 2 l < 256 (a % 8 + 1), so the block of the skew is fi + a / 8
+                    z[a] = *reinterpret_cast<const v2f *>(tb + 32 * a + (HOP256 ? 32 * (a / 8) : 0));
+                });
+            }
+            Q_SB();
+            {
+                const float *wrow = s_wt + (fresh_lane() & 15) * kRow;
+                static_for<0, kR1 / 2>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
+                    z[2 * i] *= pk::lo(wv);
+                    z[2 * i + 1] *= pk::hi(wv);
+                    if constexpr (i % 4 == 3) Q_SB();
+                });
+            }
+            Q_SB();
+            pk::fft<kR1>(z);
+            Q_SB();
+
+            // ---- exchange inside the wave, two half rounds (rows 0..15, then 16..31) ------------------------------------------------
+            const int ln2 = fresh_lane(), fi = ln2 >> 4, l = ln2 & 15;
+            const float *trow = s_tw + l * kRow;
+            float *oz = xw + fi * kXF + 2 * l;
+            const bool special2 = l == 0;
+            const int rowB = special2 ? 0 : 16 - l;             // row inside the second half (rows 16 .. 31)
+            auto write_half = [&](auto hc) __attribute__((always_inline)) {
+                constexpr int Q0 = decltype(hc)::value;
+                static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int q0 = Q0 + 2 * decltype(ic)::value, q1 = q0 + 1;
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
+                    constexpr int s0_ = ct::bitrev(q0, 5), s1_ = ct::bitrev(q1, 5);
+                    if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[s0_];
+                    else *reinterpret_cast<v2f *>(oz + (q0 - Q0) * kRP) = pk::cmul(z[s0_], pk::lo(wv));
+                    *reinterpret_cast<v2f *>(oz + (q1 - Q0) * kRP) = pk::cmul(z[s1_], pk::hi(wv));
+                });
+            };
+            auto read_row = [&](int row, v2f (&r)[kL]) __attribute__((always_inline)) {
+                const float *pr = xw + fi * kXF + row * kRP;
+                static_for<0, kL / 2>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
+                    r[2 * i] = pk::lo(v);
+                    r[2 * i + 1] = pk::hi(v);
+                });
+            };
+            v2f za[kL], zb[kL];
+            // (the taps above were read out of the same buffer: one wave's LDS operations execute in order)
+            write_half(std::integral_constant<int, 0>{});
+            read_row(l, za);
+            write_half(std::integral_constant<int, 16>{});
+            Q_SB();
+            pk::fft<kL>(za);
+            read_row(rowB, zb);
+            Q_SB();
+            pk::fft<kL>(zb);                                    // (waits for zb: the buffer has been read out)
+            Q_SB();
+            // ---- real-FFT split + magnitude into the wave's buffer: the quad's region of the output, byte for byte (4 x 2052 B) -----------
+            {
+                const int ln3 = fresh_lane(), qq = ln3 & 15;
+                const bool special = qq == 0;
+                EmitStage emit{xw, v2f{p.mag_eps, 0.f}};
+                post_emit_pk<kR1, kL>(za, zb, special, qq, special ? kR1 / 2 : kR1 - qq, s_vk, emit, 1, (ln3 >> 4) * (kK * 4));
+            }
+            Q_SB();
+            // ---- out again as 16 bytes per lane: a store instruction writes 1 KiB of contiguous memory ---------------------------------
+            constexpr int kPieces = (4 * kK * 4 + 1023) / 1024;              // 9: 8 full instructions + the last 16 bytes
+            f32x4 o[kPieces];
+            const int lnf = fresh_lane();
+            const int bytes = nval * (kK * 4);
+            {
+                const char *src = reinterpret_cast<const char *>(xw) + lnf * 16;
+                static_for<0, kPieces>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (j < kPieces - 1) o[j] = *reinterpret_cast<const f32x4 *>(src + 1024 * j);
+                    else o[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(xw) + 8192);     // (every lane: the last piece)
+                });
+            }
+            const int full = bytes & ~15;                                    // bytes covered by whole 16-byte pieces
+            const int toff = full + 4 * lnf;                                 // the 1 - 3 dwords behind them (odd frame counts: 2052 = 16 * 128 + 4)
+            const float tv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xw) + (toff < bytes ? toff : 0));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the buffer has been read out
+            Q_SB();
+            // the next quad's span: into the (free) buffer, AHEAD of this quad's stores in the in-order vector-memory queue
+            if (nnval > 0) request_span(nclip, nf0, nnval);
+            Q_SB();
+            if (!(p.ablate & 2)) {
+                // every store is ISSUED whatever the quad (the wait above counts them): what lies past the quad's bytes is dropped by
+                // the descriptor's range check (frames past F of a clip's last quad)
+                const __amdgpu_buffer_rsrc_t ro = make_uniform_rsrc(p.mag + ((size_t)clip * (size_t)p.F + (size_t)f0) * kK, bytes);
+                static_for<0, kPieces>([&](auto jc) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+                    int off = j < kPieces - 1 ? lnf * 16 + 1024 * j : 8192 + (lnf == 0 ? 0 : (1 << 30));
+                    off = off + 16 <= full ? off : (1 << 30);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[j]), ro, off, 0, PSND_Q_STORE_AUX);
+                });
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), ro, toff < bytes ? toff : (1 << 30), 0, 0);
+            }
+        }
+        clip = nclip, f0 = nf0, nval = nnval;
+    }
+}
+
+}  // namespace
+
+bool psnd_stft1024q_ok(long long T, long long F, int hop, int pad) {
+    (void)T;
+    (void)pad;
+    // even hop (8-byte tap reads), the four-frame span inside the wave's buffer, 32-bit offsets
+    return hop >= 2 && hop % 2 == 0 && 3 * hop + kNFFT + (hop == 256 ? 32 * 7 : 0) <= kXW && 3 * hop + kNFFT <= 64 * 4 * kSPVMax && F > 0 &&
+           (long long)kK * F < (1ll << 31);
+}
+
+int psnd_stft1024q_launch(const float *wav, const float *plan, float *mag_nfk, long long N, long long T, long long F, int hop, int pad,
+                          float mag_eps, int ablate, hipStream_t stream) {
+    QParams p;
+    p.wav = wav, p.plan = plan, p.mag = mag_nfk, p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps, p.ablate = ablate;
+    const long long nq = (F + 3) / 4;
+    p.nq = (int)nq;
+    p.total_quads = nq * N;
+    const long long groups = (p.total_quads + kWaves - 1) / kWaves;
+    if (p.total_quads + kWaves >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "stft_mag_nfk(n1024q): too many quads");
+    if (groups >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "stft_mag_nfk(n1024q): too many quads");
+    p.total_groups = (int)groups;
+    int grid = p.total_groups < 256 ? p.total_groups : 256;            // one persistent workgroup per CU
+    grid = (grid + 7) & ~7;
+    constexpr size_t lds = sizeof(float) * kLdsFloats;
+    auto launch = [&](auto kern) -> int {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "stft_mag_nfk(n1024q): set LDS size: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, stream, p);
+        return PSND_OK;
+    };
+    const int rc = hop == 256 ? launch(stft_fwd_n1024q_kernel<true>) : launch(stft_fwd_n1024q_kernel<false>);
+    if (rc != PSND_OK) return rc;
+    PSND_CHECK_LAUNCH("stft_mag_nfk(n1024q)");
+    return PSND_OK;
+}

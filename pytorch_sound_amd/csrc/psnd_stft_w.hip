@@ -38,6 +38,9 @@
 #include "psnd_stft_w.h"
 #include <stdlib.h>
 
+#ifndef PSND_W_NFK_AUX
+#define PSND_W_NFK_AUX 2     // cache-policy bits of the (N, F, K) stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt: 188 against 205 us (config 5, same box)
+#endif
 #ifndef PSND_W_SKIP
 #define PSND_W_SKIP 0        // register-pressure bisection only: bit k leaves stage k of the transform out
 #endif
@@ -360,8 +363,8 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
                     // row j, a lane of the upper half the pair of row j + 1
                     float a0 = mlo[j], a1 = mlo[j + 1], b0 = mhi[j], b1 = mhi[j + 1];
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{a0, a1}), ro, vlo, 256 * j, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{b1, b0}), ro, vhi, 256 * (14 - j), 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{a0, a1}), ro, vlo, 256 * j, PSND_W_NFK_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2f{b1, b0}), ro, vhi, 256 * (14 - j), PSND_W_NFK_AUX);
                 });
                 if (ln == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mext), ro, 1024 * 4, 0, 0);
             }
