@@ -225,6 +225,30 @@ void psnd_conv_chain_stats(long long *out2);
 /* host-side launch counters of the conv kernels' tile instances: out4 = { forward / input-gradient launches with 64-row
  * workgroup tiles, with 128-row tiles, paired backward launches with 64-row tiles, with 128-row tiles } (out4 may be NULL);
  * reset != 0 clears them.  Test instrumentation: lets a parity test assert that its shape ran the instance it covers. */
+/* ---- the same passes with the magnitude side BIN-FASTEST, (N, F, K) (psnd_stft_mag_nfk): (N, F, K) is the channels-last order (frame t
+ *      of clip n = row n*Lp + HP + t, bin c = channel c), so the layout changes around the conv stack become plain streams, no transposes.
+ *  psnd_to_cl_nfk            : x_nfk (N,F,K) fp32 -> CL bf16 (N,Lp,Cp), preop 1 = log1p; halo rows / padded channels written as zeros
+ *  psnd_mask_head_l1_fwd_nfk : est_nfk = sigmoid(y) * mag_nfk; ref_nfk + part (both or neither): part[b] = sum |est - ref| of workgroup b
+ *                              (psnd_mask_head_l1_blocks_nfk doubles)
+ *  psnd_mask_head_l1_bwd_nfk : gy (CL) = (gest_nfk (may be NULL) + coef * g[0] * sign(est - ref)) * mag * s (1 - s)
+ *  psnd_mel_fwd_nfk / psnd_mel_l1_fwd_nfk : psnd_mel_fwd / psnd_mel_l1_fwd reading mag_nfk (N,F,K); outputs stay (N,M,F)
+ *  psnd_mel_bwd_nfk / psnd_mel_l1_bwd_nfk : psnd_mel_bwd / psnd_mel_l1_bwd writing gmag_nfk (N,F,K)
+ *  Cp % 8 == 0, Cp >= round_up(K, 8); N*F*K*4 < 2^32 bytes. */
+int psnd_to_cl_nfk(const float *x_nfk, int64_t N, int K, int64_t F, int Lp, int HP, int Cp, int preop, void *out, void *stream);
+int64_t psnd_mask_head_l1_blocks_nfk(int64_t N, int64_t F, int K);
+int psnd_mask_head_l1_fwd_nfk(const void *y, const float *mag_nfk, const float *ref_nfk, int64_t N, int K, int64_t F, int Lp, int HP, int Cp,
+                              float *est_nfk, double *part, void *stream);
+int psnd_mask_head_l1_bwd_nfk(const float *gest_nfk, const float *mag_nfk, const void *y, const float *est_nfk, const float *ref_nfk,
+                              const float *g, float coef, int64_t N, int K, int64_t F, int Lp, int HP, int Cp, void *gy, void *stream);
+int psnd_mel_fwd_nfk(const float *mag_nfk, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                     float pre_clamp_min, float clamp_lo, float clamp_hi, float *out, float *mel_lin, void *stream);
+int psnd_mel_bwd_nfk(const float *gout, const float *mel_lin, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind,
+                     float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi, float *gmag_nfk, void *stream);
+int psnd_mel_l1_fwd_nfk(const float *mag_nfk, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                        float pre_clamp_min, float clamp_lo, float clamp_hi, const float *ref, float *mel_lin, double *part, void *stream);
+int psnd_mel_l1_bwd_nfk(const float *ref, const float *mel_lin, const float *g, float coef, int64_t N, int64_t F, int M, int K,
+                        const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                        float *gmag_nfk, void *stream);
 /* ---- a spectral-masking recipe's loss without its intermediate tensors (round 3):
  *      w1 * F.l1_loss(est, mag_ref) + w2 * F.l1_loss(log_mel(est), mel_ref),  est = sigmoid(from_cl(y)) * mag
  *  psnd_mask_head_l1_fwd : psnd_mask_head_fwd + part[b] = sum |est - ref| of workgroup b (psnd_mask_head_l1_blocks doubles)

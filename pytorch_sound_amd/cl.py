@@ -189,6 +189,82 @@ class MaskHeadSpectralL1CL(torch.autograd.Function):
         return (gy,) + (None,) * 13
 
 
+def to_cl_nfk(x_nfk, shape, preop=0):
+    """(N, F, K) fp32 (bin-fastest: kernels.stft_mag_nfk) -> CL bf16, optionally through log1p - a plain stream, (N, F, K) being the
+    channels-last order already (psnd_to_cl_nfk).  No gradient: the features are inputs."""
+    _need(x_nfk, torch.float32)
+    if x_nfk.requires_grad and torch.is_grad_enabled():
+        raise _lib.PsndError('to_cl_nfk carries no gradient (feature tensors are inputs); use ToCL on an (N, K, F) tensor')
+    N, F, K = x_nfk.shape
+    if F != shape.L or N != shape.N:
+        raise _lib.PsndError('to_cl_nfk: tensor %s does not match the CL geometry (N=%d, L=%d)' % (tuple(x_nfk.shape), shape.N, shape.L))
+    Cp = round_up(K, ALIGN_C)
+    out = torch.empty((N, shape.Lp, Cp), dtype=torch.bfloat16, device=x_nfk.device)
+    with torch.cuda.device(x_nfk.device):
+        check(lib().psnd_to_cl_nfk(ptr(x_nfk), N, K, F, shape.Lp, shape.HP, Cp, int(preop), ptr(out), stream_ptr(x_nfk.device)),
+              'psnd_to_cl_nfk')
+    return out
+
+
+class MaskHeadSpectralL1NFK(torch.autograd.Function):
+    """MaskHeadSpectralL1CL with every spectrogram-sized tensor BIN-FASTEST, (N, F, K): mag / mag_ref / est are (N, F, K) (mel_ref stays
+    (N, M, F)).  The mask head and its backward are plain streams over the channels-last rows (no 32 x 32 transposes through LDS), the mel
+    kernels read / write whole 16-byte pieces of a frame's spectrum.  Same value, same gradient."""
+
+    @staticmethod
+    def forward(ctx, y, mag, mag_ref, mel_ref, mel_plan, shape, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, w1, w2):
+        from .kernels import _clamp_args
+        ctx.set_materialize_grads(False)
+        _need(y, torch.bfloat16)
+        for t in (mag, mag_ref, mel_ref):
+            _need(t, torch.float32)
+        N, F, K = mag.shape
+        if mag_ref.shape != mag.shape or tuple(mel_ref.shape) != (N, M, F):
+            raise _lib.PsndError('mask_head_spectral_l1 (nfk): mag_ref %s / mel_ref %s do not match mag %s and %d mel bands'
+                                 % (tuple(mag_ref.shape), tuple(mel_ref.shape), tuple(mag.shape), M))
+        dev = y.device
+        lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+        est = torch.empty_like(mag)
+        lin = torch.empty((N, M, F), dtype=torch.float32, device=dev)
+        nb1 = int(lib().psnd_mask_head_l1_blocks_nfk(N, F, K))
+        nb2 = int(lib().psnd_mel_l1_blocks(N, F, M))
+        part = torch.empty(nb1 + nb2, dtype=torch.float64, device=dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        st = stream_ptr(dev)
+        with torch.cuda.device(dev):
+            check(lib().psnd_mask_head_l1_fwd_nfk(ptr(y), ptr(mag), ptr(mag_ref), N, K, F, shape.Lp, shape.HP, y.shape[2], ptr(est),
+                                                  ptr(part), st), 'psnd_mask_head_l1_fwd_nfk')
+            p2 = ctypes.c_void_p(part.data_ptr() + 8 * nb1)
+            check(lib().psnd_mel_l1_fwd_nfk(ptr(est), N, F, M, K, ptr(mel_plan), log_kind, float(log_offset), pre, lo, hi, ptr(mel_ref),
+                                            ptr(lin), p2, st), 'psnd_mel_l1_fwd_nfk')
+            parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
+            nbs = (ctypes.c_int64 * 2)(nb1, nb2)
+            sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
+            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), st), 'psnd_l1_loss_combine')
+        ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())
+        ctx.save_for_backward(y, mag, mag_ref, mel_ref, mel_plan, est, lin)
+        ctx.mark_non_differentiable(est)
+        return out, est
+
+    @staticmethod
+    def backward(ctx, g, _gest):
+        y, mag, mag_ref, mel_ref, mel_plan, est, lin = ctx.saved_tensors
+        shape, M, log_kind, log_offset, pre, lo, hi, c1, c2 = ctx.cfg
+        N, F, K = mag.shape
+        if g is None:
+            return (None,) * 14
+        g = g.contiguous().float()
+        gest = torch.empty_like(mag)
+        gy = torch.empty_like(y)
+        st = stream_ptr(y.device)
+        with torch.cuda.device(y.device):
+            check(lib().psnd_mel_l1_bwd_nfk(ptr(mel_ref), ptr(lin), ptr(g), c2, N, F, M, K, ptr(mel_plan), log_kind, log_offset, pre, lo, hi,
+                                            ptr(gest), st), 'psnd_mel_l1_bwd_nfk')
+            check(lib().psnd_mask_head_l1_bwd_nfk(ptr(gest), ptr(mag), ptr(y), ptr(est), ptr(mag_ref), ptr(g), c1, N, K, F, shape.Lp,
+                                                  shape.HP, y.shape[2], ptr(gy), st), 'psnd_mask_head_l1_bwd_nfk')
+        return (gy,) + (None,) * 13
+
+
 def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, off0, dstep, act_slope, mask_slope,
                  want_raw, want_act, a_eff_out=None):
     dev = W.device

@@ -51,6 +51,7 @@ struct MelParams {
     double *l1_part;
     const float *l1_g;
     float l1_coef;
+    int wn_off, CS16;   // NFK forward: float offset of the 16-bin-group weights, groups per row tile
 };
 
 // derivative of the forward epilogue wrt mel (0 where any clamp is active; matches autograd of
@@ -108,7 +109,12 @@ __device__ __forceinline__ f32x4 load_b_raw(__amdgpu_buffer_rsrc_t r, int c, int
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
 }
 
-template <bool BWD>
+// NFK: the magnitude side of the product is bin-fastest, (N, F, K) (psnd_stft_mag_nfk) - forward: the INPUT, backward: the OUTPUT.
+//   forward   a lane loads 16 B = 4 consecutive BINS 16 S + 4 kk .. + 3 of ONE frame (f + g for accumulator g); component j feeds the MFMA
+//             whose A operand holds W[.][16 S + 4 kk + j] (a second weight table in 16-bin groups, plan[wn_off ..)): the same 16 MFMAs
+//             per 16 bins and 4 loads of 16 B as the frame-fastest walk.  The last group of a row (K = 513: one bin) takes element loads.
+//   backward  a lane owns 4 consecutive bins of a frame per accumulator: one 16-byte store each.
+template <bool BWD, bool NFK = false>
 __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
     const int lane = threadIdx.x & 63;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -135,6 +141,46 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
 #define PSND_MEL_MU 8
 #endif
     constexpr int MU = PSND_MEL_MU;
+    if constexpr (!BWD && NFK) {
+        const int K = p.Cc;
+        const f32x4 *Wn = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.plan) + p.wn_off) + (size_t)rt * p.CS16 * 64 + lane;
+        const int lo16 = lo >> 2, hi16 = (hi + 3) >> 2;
+        constexpr unsigned OOB = 0xffffffffu;
+        // byte offset of bin 4 kk of frame f + g inside the clip, or out of range for a frame past the clip
+        unsigned fb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fb[g] = (f + g < F) ? (unsigned)((((size_t)(f + g)) * K + 4 * kk) * sizeof(float)) : OOB;
+        for (int S0 = lo16; S0 < hi16; S0 += 2) {
+            f32x4 a[2], b[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int S = S0 + u;
+                const bool in = S < hi16;
+                a[u] = in ? Wn[(size_t)S * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (16 * S + 16 <= K || !in) {                                  // (uniform) whole group inside the row
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        b[u][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, (int)((in && fb[g] != OOB) ? fb[g] + 64u * (unsigned)S : OOB), 0, 0));
+                } else {                                                        // the row ends inside the group: element by element
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            b[u][g][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                r0, (int)((fb[g] != OOB && 16 * S + 4 * kk + j < K) ? fb[g] + 64u * (unsigned)S + 4u * j : OOB), 0, 0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][0][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][1][j], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][2][j], acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u][3][j], acc3, 0, 0, 0);
+                }
+        }
+    } else
     for (int s0 = lo; s0 < hi; s0 += MU) {
         float a[MU];
         f32x4 b[MU], m[BWD ? MU : 1];
@@ -174,6 +220,23 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
     // D layout: col = lane&15 (-> frames f..f+3 across acc0..3), row = 4*(lane>>4) + reg
     const size_t obase = (size_t)clip * p.R * F;
     float l1acc = 0.f;
+    if constexpr (BWD && NFK) {
+        // D: row = bin 16 rt + 4 kk + reg, column = frame f + j of accumulator j -> (N, F, K): 4 consecutive bins of one frame per store
+        const int bin0 = 16 * rt + 4 * kk;
+        const f32x4 accs[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (f + j >= F || bin0 >= p.R) continue;
+            float *dst = p.out + obase + (size_t)(f + j) * p.R + bin0;
+            if (bin0 + 3 < p.R) {
+                *reinterpret_cast<f32x4_u *>(dst) = accs[j];
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (bin0 + r < p.R) dst[r] = accs[j][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 16 * rt + 4 * kk + r;
@@ -225,7 +288,7 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
 }
 
 struct MelHostPlan {
-    int M, K, MT, KS, KT, MS, hdr, fw_off, bw_off;
+    int M, K, MT, KS, KT, MS, hdr, fw_off, bw_off, wn_off, KS16;
     size_t total_bytes;
 };
 MelHostPlan mel_layout(int M, int K) {
@@ -236,7 +299,10 @@ MelHostPlan mel_layout(int M, int K) {
     h.hdr = hdr_ints(h.MT, h.KT);
     h.fw_off = h.hdr;
     h.bw_off = h.fw_off + h.MT * h.KS * 64;
-    h.total_bytes = sizeof(float) * ((size_t)h.bw_off + (size_t)h.KT * h.MS * 64);
+    // forward weights once more, in 16-bin groups for the bin-fastest operand: Wn[((t*KS16 + S)*64 + lane)*4 + j] = W[16 t + (lane&15)][16 S + 4 (lane>>4) + j]
+    h.KS16 = (K + 15) / 16;
+    h.wn_off = h.bw_off + h.KT * h.MS * 64;
+    h.total_bytes = sizeof(float) * ((size_t)h.wn_off + (size_t)h.MT * h.KS16 * 256);
     return h;
 }
 
@@ -290,13 +356,18 @@ extern "C" int psnd_mel_plan_build(int M, int K, const float *W, void *plan_host
         if (hi <= lo) lo = hi = 0;
         hdr[8 + 2 * h.MT + 2 * t] = lo, hdr[8 + 2 * h.MT + 2 * t + 1] = hi;
     }
+    for (int t = 0; t < h.MT; ++t)
+        for (int S = 0; S < h.KS16; ++S)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j)
+                    fl[h.wn_off + (((size_t)t * h.KS16 + S) * 64 + lane) * 4 + j] = w(16 * t + (lane & 15), 16 * S + 4 * (lane >> 4) + j);
     return PSND_OK;
 }
 
 static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, int64_t F, int M, int K,
                       const void *plan, int log_kind, float log_offset, float pre, float lo, float hi,
                       float *out, float *lin, void *stream, const float *l1_ref = nullptr, double *l1_part = nullptr,
-                      const float *l1_g = nullptr, float l1_coef = 0.f) {
+                      const float *l1_g = nullptr, float l1_coef = 0.f, bool nfk = false) {
     if (!in0 || !plan || (!out && !l1_ref) || (bwd && !in1)) PSND_FAIL(PSND_E_ARG, "mel: null pointer");
     if (M <= 0 || K <= 0 || N < 0 || F < 0) PSND_FAIL(PSND_E_SHAPE, "mel: M=%d K=%d N=%lld F=%lld", M, K, (long long)N, (long long)F);
     if (log_kind < PSND_LOG_NONE || log_kind > PSND_LOG_10) PSND_FAIL(PSND_E_ARG, "mel: log_kind=%d", log_kind);
@@ -310,6 +381,7 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     p.log_kind = log_kind, p.log_offset = log_offset, p.pre_clamp_min = pre, p.clamp_lo = lo, p.clamp_hi = hi;
     p.nft = (int)((F + 63) / 64);
     p.l1_ref = l1_ref, p.l1_part = l1_part, p.l1_g = l1_g, p.l1_coef = l1_coef;
+    p.wn_off = h.wn_off, p.CS16 = h.KS16;
     if (!bwd) {
         p.R = M, p.Cc = K, p.RT = h.MT, p.CS = h.KS, p.band_off = 8, p.w_off = h.fw_off;
     } else {
@@ -319,7 +391,10 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     const long long blocks = (waves + 3) / 4;
     if (blocks >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "mel: grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!bwd) hipLaunchKernelGGL(mel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (nfk) {
+        if (!bwd) hipLaunchKernelGGL((mel_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mel_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (!bwd) hipLaunchKernelGGL(mel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(mel_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     PSND_CHECK_LAUNCH(bwd ? "mel_bwd" : "mel_fwd");
     return PSND_OK;
@@ -359,4 +434,31 @@ extern "C" int psnd_mel_l1_bwd(const float *ref, const float *mel_lin, const flo
     if (!g) PSND_FAIL(PSND_E_ARG, "mel_l1_bwd: null g");
     return mel_launch(true, ref, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, gmag, nullptr,
                       stream, nullptr, nullptr, g, coef);
+}
+
+// ---- the same four with the magnitude side bin-fastest, (N, F, K) (psnd_stft_mag_nfk): forward INPUT mag_nfk, backward OUTPUT gmag_nfk; the
+//      mel side stays (N, M, F) as transforms.py:235 returns it.
+extern "C" int psnd_mel_fwd_nfk(const float *mag_nfk, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                                float pre_clamp_min, float clamp_lo, float clamp_hi, float *out, float *mel_lin, void *stream) {
+    return mel_launch(false, mag_nfk, nullptr, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, out, mel_lin, stream,
+                      nullptr, nullptr, nullptr, 0.f, true);
+}
+extern "C" int psnd_mel_bwd_nfk(const float *gout, const float *mel_lin, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind,
+                                float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi, float *gmag_nfk, void *stream) {
+    return mel_launch(true, gout, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, gmag_nfk, nullptr, stream,
+                      nullptr, nullptr, nullptr, 0.f, true);
+}
+extern "C" int psnd_mel_l1_fwd_nfk(const float *mag_nfk, int64_t N, int64_t F, int M, int K, const void *mel_plan, int log_kind, float log_offset,
+                                   float pre_clamp_min, float clamp_lo, float clamp_hi, const float *ref, float *mel_lin, double *part,
+                                   void *stream) {
+    if (!ref || !mel_lin || !part) PSND_FAIL(PSND_E_ARG, "mel_l1_fwd_nfk: null ref / mel_lin / part");
+    return mel_launch(false, mag_nfk, nullptr, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, nullptr, mel_lin,
+                      stream, ref, part, nullptr, 0.f, true);
+}
+extern "C" int psnd_mel_l1_bwd_nfk(const float *ref, const float *mel_lin, const float *g, float coef, int64_t N, int64_t F, int M, int K,
+                                   const void *mel_plan, int log_kind, float log_offset, float pre_clamp_min, float clamp_lo, float clamp_hi,
+                                   float *gmag_nfk, void *stream) {
+    if (!g) PSND_FAIL(PSND_E_ARG, "mel_l1_bwd_nfk: null g");
+    return mel_launch(true, ref, mel_lin, N, F, M, K, mel_plan, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, gmag_nfk, nullptr,
+                      stream, nullptr, nullptr, g, coef, true);
 }

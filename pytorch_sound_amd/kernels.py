@@ -149,6 +149,57 @@ def mel_forward(mag, mel_plan_t, M, log_kind=LOG_E, log_offset=0.0, pre_clamp_mi
     return out, lin
 
 
+def mel_forward_nfk(mag_nfk, mel_plan_t, M, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None, clamp_lo=None, clamp_hi=None,
+                    want_lin=False, out=None):
+    """psnd_mel_fwd_nfk: the mel projection of a BIN-FASTEST magnitude (N, F, K) (stft_mag_nfk); the result is (N, M, F) as mel_forward's"""
+    _need_cuda(mag_nfk, 'mag_nfk')
+    mag_nfk = mag_nfk.contiguous()
+    N, F, K = mag_nfk.shape
+    lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+    if out is not None and (tuple(out.shape) != (N, M, F) or out.dtype != torch.float32 or out.device != mag_nfk.device
+                            or not out.is_contiguous()):
+        raise _lib.PsndError('mel_forward_nfk: out must be a contiguous fp32 (%d, %d, %d) tensor on %s' % (N, M, F, mag_nfk.device))
+    if out is None:
+        out = torch.empty((N, M, F), dtype=torch.float32, device=mag_nfk.device)
+    lin = torch.empty_like(out) if want_lin else None
+    with torch.cuda.device(mag_nfk.device):
+        check(lib().psnd_mel_fwd_nfk(ptr(mag_nfk), N, F, M, K, ptr(mel_plan_t), log_kind, float(log_offset), pre, lo, hi,
+                                     ptr(out), ptr(lin), stream_ptr(mag_nfk.device)), 'psnd_mel_fwd_nfk')
+    return out, lin
+
+
+def mel_backward_nfk(gout, mel_lin, mel_plan_t, K, log_kind=LOG_E, log_offset=0.0, pre_clamp_min=None, clamp_lo=None, clamp_hi=None):
+    """psnd_mel_bwd_nfk: gradient of mel_forward_nfk w.r.t. the magnitude, (N, F, K)"""
+    _need_cuda(gout, 'gout')
+    gout = gout.contiguous()
+    N, M, F = gout.shape
+    lo, hi, pre = _clamp_args(clamp_lo, clamp_hi, pre_clamp_min)
+    gmag = torch.empty((N, F, K), dtype=torch.float32, device=gout.device)
+    with torch.cuda.device(gout.device):
+        check(lib().psnd_mel_bwd_nfk(ptr(gout), ptr(mel_lin), N, F, M, K, ptr(mel_plan_t), log_kind, float(log_offset), pre, lo, hi,
+                                     ptr(gmag), stream_ptr(gout.device)), 'psnd_mel_bwd_nfk')
+    return gmag
+
+
+class MelLogNfk(torch.autograd.Function):
+    """MelLog for a bin-fastest magnitude: (N, F, K) -> (N, M, F)"""
+
+    @staticmethod
+    def forward(ctx, mag_nfk, plan, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi):
+        need_grad = ctx.needs_input_grad[0]
+        out, lin = mel_forward_nfk(mag_nfk, plan, M, log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi, want_lin=need_grad)
+        if need_grad:
+            ctx.save_for_backward(lin, plan)
+        ctx.cfg = (mag_nfk.shape[2], log_kind, log_offset, pre_clamp_min, clamp_lo, clamp_hi)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lin, plan = ctx.saved_tensors
+        K, log_kind, log_offset, pre, lo, hi = ctx.cfg
+        return mel_backward_nfk(gout, lin, plan, K, log_kind, log_offset, pre, lo, hi), None, None, None, None, None, None, None
+
+
 def logmel_fused_ok(wav, n_fft, hop):
     """the fused wav -> log-mel kernel covers the span-staged tile size and needs no gradient (forward only)"""
     return (n_fft == 1024 and 0 < hop <= 256 and hop % 4 == 0 and wav.is_cuda

@@ -34,26 +34,35 @@ class ConvSeparator(nn.Module):
         return mask * mag
 
 
-    def logits_cl(self, mag: torch.Tensor):
-        """the mask logits in the CL layout (bf16) and that layout's geometry: everything of forward_cl but the head"""
+    def logits_cl(self, mag: torch.Tensor, layout: str = 'nkf'):
+        """the mask logits in the CL layout (bf16) and that layout's geometry: everything of forward_cl but the head.  layout 'nfk': `mag`
+        is bin-fastest, (N, F, K) (kernels.stft_mag_nfk) - the channels-last order itself, so the way in is a plain stream"""
         from pytorch_sound_amd import cl
-        N, C, T = mag.shape
+        if layout == 'nfk':
+            N, T, C = mag.shape
+        else:
+            N, C, T = mag.shape
         halo = max(c.padding for b in self.blocks for c in list(b.convs1) + list(b.convs2))
         shape = cl.CLShape(N, T, max(halo, self.conv_pre.padding, self.conv_post.padding))
         convs = [self.conv_pre] + [c for b in self.blocks for c in list(b.convs1) + list(b.convs2)] + [self.conv_post]
         prep = cl.prep_all(self, convs)
-        x0 = cl.ToCL.apply(mag.float(), shape, 1)
+        x0 = cl.to_cl_nfk(mag.float(), shape, 1) if layout == 'nfk' else cl.ToCL.apply(mag.float(), shape, 1)
         return cl.conv_body_cl(self.conv_pre, list(self.blocks), self.conv_post, x0, shape, prep), shape
 
     def spectral_l1_loss(self, mag: torch.Tensor, mag_ref: torch.Tensor, mel_ref: torch.Tensor, mel_plan: torch.Tensor, n_mels: int,
-                         w_mag: float = 1.0, w_mel: float = 0.5, log_offset: float = 1e-6, clamp_lo=None, clamp_hi=None):
+                         w_mag: float = 1.0, w_mel: float = 0.5, log_offset: float = 1e-6, clamp_lo=None, clamp_hi=None, layout: str = 'nkf'):
         """w_mag * l1(est, mag_ref) + w_mel * l1(log_mel(est), mel_ref) for est = forward(mag), as one fused node on a HIP tensor
         (cl.MaskHeadSpectralL1CL: the log-mel of the estimate and the two gradient tensors never exist); returns (loss, est).
         mel_plan: kernels.mel_plan of the mel filter; the log-mel is ln(mel + log_offset) clamped to [clamp_lo, clamp_hi] as
-        LogMelSpectrogram does."""
+        LogMelSpectrogram does.  layout 'nfk': mag / mag_ref (and the returned est) are bin-fastest (N, F, K) tensors (kernels.stft_mag_nfk;
+        `.transpose(1, 2)` is the reference's layout as a view); mel_ref stays (N, M, F)."""
         from pytorch_sound_amd import cl, kernels as K
         if not mag.is_cuda:
             raise RuntimeError('spectral_l1_loss is the fused HIP formulation; on the host compose the loss from forward()')
+        if layout == 'nfk':
+            y, shape = self.logits_cl(mag, 'nfk')
+            return cl.MaskHeadSpectralL1NFK.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
+                                                  mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
         y, shape = self.logits_cl(mag)
         return cl.MaskHeadSpectralL1CL.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
                                              mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
