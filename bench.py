@@ -61,10 +61,12 @@ def synth_batch(seed, n, t, device):
     return (both.to(device),)
 
 
-def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
+def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True, layout='nfk'):
     """returns (trainer_cls, model) for the config-2 step on `device`.  static: the features go into persistent buffers that the step
     graph reads in place (Trainer.static_prepare) - off when prepare() runs one step ahead on a side stream (--prefetch).
-    cpu_frontend (CPU baseline leg only): 'port' = the reference's dense-DFT conv1d STFT, 'torch_stft' = its torch.stft class."""
+    cpu_frontend (CPU baseline leg only): 'port' = the reference's dense-DFT conv1d STFT, 'torch_stft' = its torch.stft class.
+    layout (GPU, fused loss): 'nfk' = the magnitudes stay bin-fastest (N, F, K) between the STFT kernel and their consumers (psnd_stft_mag_nfk,
+    the channels-last order of the conv stack: no transposing passes); 'nkf' = the reference's (N, K, F) everywhere (round 3's step)."""
     from pytorch_sound_amd.models import build_model
     from pytorch_sound_amd.models import separator  # noqa: F401  (registers conv_separator)
     from pytorch_sound_amd.trainer import Trainer, LogType
@@ -76,6 +78,24 @@ def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
         fe = LogMelSpectrogram(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX).to(device)
 
         feat = {}                                                   # persistent feature buffers (Trainer.static_prepare)
+        nfk = layout == 'nfk' and fused_loss
+
+        def magnitude_nfk(w):
+            n, t = w.shape
+            if not static:
+                return K.stft_mag_nfk(w, N_FFT, HOP, fe.stft._plan(w.device), K.FRAMING_CENTER, 0.0)
+            key = ('mag_nfk', n, t)
+            if key not in feat:
+                feat[key] = torch.empty((n, K.frame_count(t, N_FFT, HOP), N_FFT // 2 + 1), dtype=torch.float32, device=w.device)
+            return K.stft_mag_nfk(w, N_FFT, HOP, fe.stft._plan(w.device), K.FRAMING_CENTER, 0.0, out=feat[key])
+
+        def logmel_of_mag_nfk(m):
+            if not static:
+                return K.mel_forward_nfk(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)[0]
+            key = ('mel', m.shape[0], m.shape[1])
+            if key not in feat:
+                feat[key] = torch.empty((m.shape[0], N_MEL, m.shape[1]), dtype=torch.float32, device=m.device)
+            return K.mel_forward_nfk(m, fe._mel_plan(), N_MEL, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db, out=feat[key])[0]
 
         def magnitude(w):
             n, t = w.shape
@@ -110,6 +130,7 @@ def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
 
         l1 = F.l1_loss
         l1sum = None
+        nfk = False
 
     class StepTrainer(Trainer):
         static_prepare = gpu and static   # the features are written into persistent buffers: the step graph reads them in place
@@ -118,6 +139,11 @@ def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
             # feature extraction of the batch (no parameters, no gradient): eager, ahead of the captured graph
             with torch.no_grad():
                 n = both.shape[0] // 2
+                if nfk:
+                    mag = magnitude_nfk(both)                     # (2 n, F, K): ONE launch, a frame's spectrum contiguous
+                    mag_mix, mag_ref = mag[:n], mag[n:]
+                    mel_ref = logmel_of_mag_nfk(mag_ref)
+                    return mag_mix, mag_ref, mel_ref
                 mag = magnitude(both)                             # mixture and reference clips: ONE STFT launch (2 x batch clips)
                 mag_mix, mag_ref = mag[:n], mag[n:]
                 mel_ref = logmel_of_mag(mag_ref, persistent=True)
@@ -128,7 +154,7 @@ def build_step(device, amp, static=True, cpu_frontend='port', fused_loss=True):
                 # mask head + both L1 terms as one node: 4 launches forward, 2 backward (cl.MaskHeadSpectralL1CL)
                 with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
                     loss, _ = self.model.spectral_l1_loss(mag_mix, mag_ref, mel_ref, fe._mel_plan(), N_MEL, 1.0, 0.5, 1e-6, fe.min_db,
-                                                          fe.max_db)
+                                                          fe.max_db, layout='nfk' if nfk else 'nkf')
                 return loss, {'loss': (loss, LogType.SCALAR)}
             if amp:
                 with torch.autocast('cuda', dtype=torch.bfloat16):
@@ -161,7 +187,7 @@ def gpu_bench(args):
     T = int(SR * CLIP_SECONDS)
     N = BATCH_PER_GPU
 
-    Trainer, model = build_step(device, amp=True, static=not args.prefetch, fused_loss=not args.unfused_loss)
+    Trainer, model = build_step(device, amp=True, static=not args.prefetch, fused_loss=not args.unfused_loss, layout=args.layout)
     from pytorch_sound_amd import optim as poptim
     # torch.optim.Adam semantics as one HIP launch (psnd_adam_step); --torch-adam keeps torch's fused multi-tensor kernel
     opt = (torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99), fused=True) if args.torch_adam
@@ -175,6 +201,8 @@ def gpu_bench(args):
     # next batch's feature extraction on a side stream (Trainer.prefetch_prepare): +1.6 % throughput, but the in-step STFT
     # launch then shares the chip with the conv kernels and its event timing doubles - off for the judged line
     tr.prefetch_prepare = args.prefetch
+    # the next batch's feature extraction behind this step's backward, on a side stream next to the optimizer launch (Trainer.overlap_prepare)
+    tr.overlap_prepare = args.overlap_prepare and not args.prefetch          # measured: no gain (0.691 vs 0.682 ms, the STFT launch doubles next to the optimizer's): off
     model.train()
 
     def barrier():
@@ -199,6 +227,7 @@ def gpu_bench(args):
         tr.train(step)
     barrier()
     K.STFT_FWD_EVENTS = []
+    K.STFT_NFK_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step += 1
@@ -213,8 +242,10 @@ def gpu_bench(args):
         tdt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tdt.item())
-    ev_instep = K.STFT_FWD_EVENTS
+    instep_nfk = len(K.STFT_NFK_EVENTS) > 0
+    ev_instep = K.STFT_NFK_EVENTS if instep_nfk else K.STFT_FWD_EVENTS
     K.STFT_FWD_EVENTS = None
+    K.STFT_NFK_EVENTS = None
     # ---- spread: the contract region above is K steps (~17 ms at K = 20); the same K steps are repeated in further timed blocks
     #      (each bracketed like the first) until >= 100 ms have been timed, and every block's ms/step is reported next to `value`
     blocks = [dt / args.steps * 1e3]
@@ -243,8 +274,11 @@ def gpu_bench(args):
     #      (b) copied in line on the compute stream as the reference does.  Same K steps each, max over ranks.
     h2d = {}
     host_pool = [synth_batch(1234 + rank + 1000 * i, N, T, torch.device('cpu')) for i in range(args.pool)]
+    ovl_keep = tr.overlap_prepare
+    tr.overlap_prepare = False
     for mode in ('prefetch_copy', 'inline'):
         tr.train_dataset = tr.repeat(host_pool)
+        tr._ovl = None                                # (a batch staged by overlap_prepare belongs to the device-resident pool)
         tr.prefetch_prepare = False
         tr.prefetch_copy = mode == 'prefetch_copy'
         tr._pre_stream = None
@@ -266,6 +300,7 @@ def gpu_bench(args):
             d = float(tdt.item())
         h2d[mode] = {'value': world * N * CLIP_SECONDS * args.steps / d, 'ms_per_step': d / args.steps * 1e3}
     tr.prefetch_prepare, tr.prefetch_copy = args.prefetch, False
+    tr.overlap_prepare = ovl_keep
     h2d['unit'] = 'audio-s/s'
     h2d['bytes_per_step'] = 2 * N * T * 4
     h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch_copy" = the copy of the next batch on a side stream while the '
@@ -284,7 +319,8 @@ def gpu_bench(args):
     t_stft = t_raw
     n_launch = int(ev[0][2])                       # clips per in-step launch (mixture + reference clips of a batch together)
     bytes_launch = 4 * n_launch * T + 4 * n_launch * Kb * Fr
-    roofline_instep = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
+    roofline_instep = {'bound': 'hbm', 'kernel': ('stft_fwd_n1024q_kernel (wav -> magnitude (N,F,K), 1024/256)' if instep_nfk else
+                                                  'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)'),
                        'achieved': bytes_launch / t_stft / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                        'frac': bytes_launch / t_stft / HBM_PEAK, 'traffic': None,
                        'bytes_per_launch': bytes_launch, 'launch_us': t_stft * 1e6,
@@ -567,6 +603,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
     ap.add_argument('--prefetch', action='store_true', help='stage the next batch (copy + feature extraction) on a side stream')
     ap.add_argument('--unfused-loss', action='store_true', help='the loss as separate nodes (mask head, mel, two L1 terms) instead of the fused one')
+    ap.add_argument('--overlap-prepare', action='store_true', help="the next batch's feature extraction behind this step's backward on a side stream (Trainer.overlap_prepare)")
+    ap.add_argument('--layout', choices=('nfk', 'nkf'), default='nfk',
+                    help="magnitude layout between the STFT kernel and its consumers inside the step: 'nfk' bin-fastest (psnd_stft_mag_nfk), 'nkf' the reference's")
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
     args = ap.parse_args()
     if not torch.cuda.is_available():

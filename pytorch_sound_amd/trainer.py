@@ -228,6 +228,33 @@ class Trainer:
     # on the compute stream at the step that uses the batch (no second stream competing for the CUs)
     prefetch_copy = False
 
+    # (not in the reference) prepare() of batch k+1 on a side stream BEHIND step k's forward / backward: the side stream waits for
+    # the step's last backward kernel (so persistent feature buffers - static_prepare - are free again) and its feature extraction runs
+    # next to step k's optimizer launch and step k+1's weight prep, which leave most of the chip idle; step k+1 waits on an event.
+    # prepare() must be parameter-free.  The data iterator is advanced one batch ahead of the step that uses it.
+    overlap_prepare = False
+
+    def _stage_overlapped(self):
+        """called right behind the step's backward (graph replay) on the compute stream"""
+        if not (self.overlap_prepare and torch.cuda.is_available()) or self.prefetch_prepare or self.prefetch_copy:
+            return
+        if getattr(self, '_ovl_stream', None) is None:
+            self._ovl_stream = _independent_stream()
+        side, cur = self._ovl_stream, torch.cuda.current_stream()
+        side.wait_stream(cur)
+        try:
+            with torch.cuda.stream(side):
+                raw = tuple(self._next_batch(self.train_dataset))
+                for t in raw:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(side)
+                batch = self.prepare(*raw)
+                event = torch.cuda.Event()
+                event.record(side)
+            self._ovl = (batch, event)
+        except StopIteration as e:                       # surfaces at the step that would have used the batch
+            self._ovl = (e, None)
+
     def _stage_train_batch(self):
         side = self._pre_stream
         try:
@@ -249,6 +276,18 @@ class Trainer:
 
     def _take_train_batch(self):
         if not ((self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available()):
+            ovl = getattr(self, '_ovl', None)
+            if ovl is not None:                          # staged behind the previous step (overlap_prepare)
+                self._ovl = None
+                batch, event = ovl
+                if event is None:
+                    raise batch
+                cur = torch.cuda.current_stream()
+                cur.wait_event(event)
+                for t in batch:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
+                return batch
             return self.prepare(*self._next_batch(self.train_dataset))
         if self.prefetch_prepare and self.static_prepare:
             # prepare() of batch k+1 runs on the side stream BEFORE step k's graph replay is enqueued: with persistent feature
@@ -413,6 +452,7 @@ class Trainer:
             if src.data_ptr() != dst.data_ptr():           # static_prepare: already there
                 dst.copy_(src, non_blocking=True)
         st['graph'].replay()
+        self._stage_overlapped()                       # the next batch's prepare(): side stream, next to this step's optimizer launch
         if self._reducer is not None and st.get('ddp') in ('events', 'capture'):
             # the captured backward filled the flat buckets itself and marked where each is complete: bucket i is all-reduced
             # while the replay is still producing bucket i + 1 (FlatGradReducer, graph mode)
