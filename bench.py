@@ -177,6 +177,13 @@ def gpu_bench(args):
     from pytorch_sound_amd import distributed as pdist
     from pytorch_sound_amd import kernels as K
     from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    if args.force_ddp and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        # one-rank RCCL process group: the whole data-parallel step (flat buckets, captured all-reduce, hand-over from inside the
+        # backward) on one GPU - what the reducer costs without a second device (the sum over one rank is the identity)
+        os.environ.update(PSND_DDP_FORCE='1', MASTER_ADDR='127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group('nccl', rank=0, world_size=1)
     distributed = pdist.init_from_env('nccl')
     rank, world = pdist.rank(), pdist.world_size()
     if world != args.gpus:
@@ -198,6 +205,11 @@ def gpu_bench(args):
     tr = Trainer(model, opt, pool, pool, max_step=huge, valid_max_step=1, save_interval=huge, log_interval=huge,
                  save_dir=save_dir, save_prefix='bench', seed=1234)
     tr.graph_steps = not args.no_graph          # forward + backward replayed as one hipGraph (Trainer.graph_steps)
+    if tr._reducer is not None and args.no_handover:
+        tr._reducer.sink_enabled = False
+    if args.handover_side:
+        from pytorch_sound_amd import cl as _cl
+        _cl.HANDOVER_SIDE_STREAM = True
     # next batch's feature extraction on a side stream (Trainer.prefetch_prepare): +1.6 % throughput, but the in-step STFT
     # launch then shares the chip with the conv kernels and its event timing doubles - off for the judged line
     tr.prefetch_prepare = args.prefetch
@@ -603,6 +615,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='enqueue every kernel of the step eagerly (no hipGraph replay)')
     ap.add_argument('--prefetch', action='store_true', help='stage the next batch (copy + feature extraction) on a side stream')
     ap.add_argument('--unfused-loss', action='store_true', help='the loss as separate nodes (mask head, mel, two L1 terms) instead of the fused one')
+    ap.add_argument('--force-ddp', action='store_true', help='single GPU with a one-rank RCCL group: the data-parallel reducer path on one device')
+    ap.add_argument('--handover-side', action='store_true', help='(with a reducer) the hand-over chunks on a side stream next to the following input-gradient launch')
+    ap.add_argument('--no-handover', action='store_true', help='(with a reducer) gradients reach the buckets through autograd hooks only (round 3)')
     ap.add_argument('--overlap-prepare', action='store_true', help="the next batch's feature extraction behind this step's backward on a side stream (Trainer.overlap_prepare)")
     ap.add_argument('--layout', choices=('nfk', 'nkf'), default='nfk',
                     help="magnitude layout between the STFT kernel and its consumers inside the step: 'nfk' bin-fastest (psnd_stft_mag_nfk), 'nkf' the reference's")

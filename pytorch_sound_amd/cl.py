@@ -328,6 +328,24 @@ AUTO_SECTIONS = True
 # data-parallel run overlap the backward (Trainer switches to it when a FlatGradReducer over more than one rank is active).
 NODE_GRANULARITY = 'body'
 
+# Data-parallel gradient hand-over from INSIDE a conv-chain node's backward (distributed.FlatGradReducer registers itself here while a
+# data-parallel step runs): with a sink, the weight gradients of a chain are produced in CHUNKS - behind every input-gradient launch
+# of the chain (one per ResBlock1) the weight gradients of the convs that launch completed, their weight-norm backward, and the
+# hand-over of those parameters - so the all-reduce of the late blocks' buckets runs under the backward of the early blocks.  The
+# weight-norm backward writes (g_v, g_g, g_bias) straight into the reducer's flat buckets (`dest`), no copy.
+#   sink.dest(param, numel) -> fp32 tensor of `numel` elements to write the gradient into, or None (not this parameter / already
+#                              delivered this step: the node then returns the gradient and autograd accumulates it)
+#   sink.deliver(params)    -> these parameters' gradients are in place (enqueued on the current stream)
+GRAD_SINK = None
+# chunks of the hand-over (weight gradients + weight-norm backward of a block) on a side stream / graph branch next to the following
+# block's input-gradient launch, which holds a workgroup on 141 of the 256 CUs only
+HANDOVER_SIDE_STREAM = False
+# the hand-over points: the body's input-gradient launches (one per ResBlock1: 4 at config 2) are cut into this many chunks; every
+# chunk costs an extra weight-gradient / weight-norm-backward launch pair and evicts the next input-gradient launch's operands from the
+# L2 (38 -> 50 us for that launch), so not every block gets one: 3 chunks release 4 of the config-2 model's 6 buckets early
+HANDOVER_CHUNKS = 3
+_HANDOVER_STREAMS = {}
+
 
 def _sections(dev, N, rows):
     """PSND_CL_SECTIONS = n runs a chain as n batch sections; default 1.  Two sections took the config-2 step from 1.239 to 1.194 ms
@@ -803,6 +821,7 @@ class ResBlockCL(torch.autograd.Function):
         with torch.cuda.device(dev):
             _run_sections(dev, nsec, sides, run)
         ctx.steps, ctx.shape = steps, shape
+        ctx.param_refs = params                    # the Parameter objects (GRAD_SINK looks its buckets up by them)
         ctx.save_for_backward(*saved)
         return cur_x, cur_xa
 
@@ -819,6 +838,24 @@ class ResBlockCL(torch.autograd.Function):
         grads = [None] * (3 * n)
         descs, keep = [None] * n, []
         res_pending = None
+        sink = GRAD_SINK if (GRAD_SINK is not None and GRAD_SINK.sink_active()) else None
+        prefs = getattr(ctx, 'param_refs', None)
+        early = {}                             # conv index -> parameters whose gradient goes straight into the sink's buffers
+
+        def grad_out(i, v32, g32, Cb):
+            """(g_v, g_g, g_bias[Cb]) of conv i: the sink's flat-bucket slots when there is one, else fresh tensors"""
+            gv = gg = gb = None
+            if sink is not None and prefs is not None:
+                pv, pg, pb = prefs[3 * i:3 * i + 3]
+                gv, gg = sink.dest(pv, pv.numel()), sink.dest(pg, pg.numel())
+                gb = sink.dest(pb, Cb) if pb is not None else None
+                early[i] = [(0, pv) if gv is not None else None, (1, pg) if gg is not None else None,
+                            (2, pb) if gb is not None else None]
+            gv = torch.empty_like(v32) if gv is None else gv.view_as(v32)
+            gg = torch.empty_like(g32) if gg is None else gg.view_as(g32)
+            gb = torch.empty(Cb, dtype=torch.float32, device=dev) if gb is None else gb
+            return gv, gg, gb
+
         nsec, sides = _sections(dev, shape.N, shape.N * shape.Lp)
         wstreams = _wgrad_streams(dev) if shape.N * shape.Lp <= 8192 else []
         if wstreams:
@@ -831,6 +868,8 @@ class ResBlockCL(torch.autograd.Function):
         batch = (nsec == 1 and not wstreams and _pair_enabled() and os.environ.get('PSND_CL_BWD_BATCH', '1') == '1'
                  and shape.N * shape.Lp <= 8192)
         wbatch = []
+        own_launch = []                        # (plan entry, conv): convs whose weight-gradient slabs are written by that entry itself
+        flush_after = {}                       # id(input-gradient tensor a pair launch writes) -> len(wbatch) once that launch has run
         pair_bwd = (nsec == 1 and not wstreams and not batch and _pair_enabled() and os.environ.get('PSND_CL_PAIR_BWD', '1') != '0'
                     and shape.N * shape.Lp <= 8192)
         lag = None                             # weight gradient of a pair's first conv, carried to the next pair launch
@@ -848,8 +887,7 @@ class ResBlockCL(torch.autograd.Function):
                     S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
                 gw = torch.empty((nsec * S, k, Cb, Ca), dtype=torch.float32, device=dev)    # slabs of section h: [h S, (h+1) S)
                 gbp = torch.empty((nsec * S, Cb), dtype=torch.float32, device=dev)
-                gb = torch.empty(Cb, dtype=torch.float32, device=dev)
-                gv, gg = torch.empty_like(v32), torch.empty_like(g32)
+                gv, gg, gb = grad_out(i, v32, g32, Cb)
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
                                        gg.data_ptr(), gb.data_ptr(), nsec * S, Cout, Cin, k, Cb, Ca)
                 keep.extend([gw, gbp, G1, G2])
@@ -903,6 +941,7 @@ class ResBlockCL(torch.autograd.Function):
                                  pad, -dil, pad1, -d1, gx))
                     if batch:
                         wbatch.append((i - 1, g_h, inp1, -pad1, d1))
+                        flush_after[id(gx)] = len(wbatch)
                     else:
                         plan.append(('side',) + slabs(i - 1, g_h, None, None, inp1))
                     keep.extend([g_h, gx])
@@ -921,8 +960,7 @@ class ResBlockCL(torch.autograd.Function):
                 S = lib().psnd_conv1d_cl_wgrad_splits(Nh, shape.Lp, Ca, Cb, k)
                 gw = torch.empty((nsec * S, k, Cb, Ca), dtype=torch.float32, device=dev)    # slabs of section h: [h S, (h+1) S)
                 gbp = torch.empty((nsec * S, Cb), dtype=torch.float32, device=dev)
-                gb = torch.empty(Cb, dtype=torch.float32, device=dev)
-                gv, gg = torch.empty_like(v32), torch.empty_like(g32)
+                gv, gg, gb = None, None, None                  # (taken below, once it is known that this conv keeps its own launch)
                 g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
                 g_here = g_out if need_gout else G1          # this conv's combined gradient (= what its residual input receives)
                 # convs outside the residual pairs (a model's head / tail) keep their own launches: with them the one weight-gradient launch
@@ -967,8 +1005,10 @@ class ResBlockCL(torch.autograd.Function):
                         continue
                     plan.append(('b', G1, G2, am, slope, wb, inp, Ca, Cb, k, pad, dil, gx, g_out, ep_mask,
                                  float(steps[i - 1][7] if i > 0 else 1.0), ep_res, gw, gbp, S))
+                gv, gg, gb = grad_out(i, v32, g32, Cb)
                 descs[i] = struct.pack('<7Q6i', gw.data_ptr(), gbp.data_ptr(), v32.data_ptr(), g32.data_ptr(), gv.data_ptr(),
                                        gg.data_ptr(), gb.data_ptr(), nsec * S, Cout, Cin, k, Cb, Ca)
+                own_launch.append((plan[-1], i))               # its slabs exist once that plan entry has run
                 keep += [gw, gbp, G1, G2, g_out]
                 grads[3 * i], grads[3 * i + 1] = gv, gg
                 grads[3 * i + 2] = gb[:Cout] if has_bias else None
@@ -989,11 +1029,11 @@ class ResBlockCL(torch.autograd.Function):
                 plan = _chain_pairs_bwd(plan, shape.N * shape.Lp)
             used = []
 
-            def run(h):
+            def run(h, entries=None):
                 st = stream_ptr(dev)
                 q = lambda t: ptr(_sec(t, h, nsec))            # noqa: E731
                 main = torch.cuda.current_stream(dev)
-                for e in plan:
+                for e in (plan if entries is None else entries):
                     if e[0] == 'side':                         # a weight gradient on the next side stream, behind what is enqueued so far
                         sd = wstreams[len(used) % len(wstreams)]
                         used.append(sd)
@@ -1050,26 +1090,103 @@ class ResBlockCL(torch.autograd.Function):
                                                        None if gbp is None else ptr(gbp[h * S:(h + 1) * S]), st),
                               'psnd_conv1d_cl_bwd')
 
-            _run_sections(dev, nsec, sides, run)
-            for sd in set(used):
-                torch.cuda.current_stream(dev).wait_stream(sd)
             st = stream_ptr(dev)
-            for j0 in range(0, len(wbatch), 32):
-                part = wbatch[j0:j0 + 32]
-                # row ranges: what suits the most frequent shape of the launch (the body's 256 -> 256 convs); the others take the same
-                shp = [(steps[ci][3], steps[ci][4], steps[ci][2]) for ci, _, _, _, _ in part]
-                main = max(set(shp), key=shp.count)
-                Sb = lib().psnd_conv1d_cl_wgrad_multi_splits(shape.N, shape.Lp, main[0], main[1], main[2], shp.count(main))
-                arr = (_lib.WgradDesc * len(part))()
-                for d, (ci, G, inp, off0, dstep) in zip(arr, part):
-                    w = slabs(ci, G, None, None, inp, Sb)
-                    d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = G.data_ptr(), inp.data_ptr(), w[11].data_ptr(), w[12].data_ptr(), off0, dstep
-                    d.Ca, d.Cb, d.k, d.splits = steps[ci][3], steps[ci][4], steps[ci][2], Sb
-                check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(part), shape.N, shape.Lp, st), 'psnd_conv1d_cl_wgrad_multi')
-            for j0 in range(0, n, 32):                       # PSND_WNORM_MAX descriptors per launch
-                chunk = descs[j0:j0 + 32]
-                buf = ctypes.create_string_buffer(b''.join(chunk))
-                check(lib().psnd_conv1d_wnorm_bwd_multi(buf, len(chunk), st), 'psnd_conv1d_wnorm_bwd_multi')
+            handed = set()
+
+            def wgrad_batch(part):
+                """the weight gradients of these convs (wbatch entries) as psnd_conv1d_cl_wgrad_multi launches of <= 32"""
+                for j0 in range(0, len(part), 32):
+                    sub = part[j0:j0 + 32]
+                    # row ranges: what suits the most frequent shape of the launch (the body's 256 -> 256 convs); the others take the same
+                    shp = [(steps[ci][3], steps[ci][4], steps[ci][2]) for ci, _, _, _, _ in sub]
+                    main_shape = max(set(shp), key=shp.count)
+                    # (a chunk of the hand-over: row ranges as if it were at least half of all the convs - the weight-norm backward
+                    #  has to add every range's slab up)
+                    cnt = max(shp.count(main_shape), len(wbatch) // 2) if len(part) < len(wbatch) else shp.count(main_shape)
+                    Sb = lib().psnd_conv1d_cl_wgrad_multi_splits(shape.N, shape.Lp, main_shape[0], main_shape[1], main_shape[2], cnt)
+                    arr = (_lib.WgradDesc * len(sub))()
+                    for d, (ci, G, inp, off0, dstep) in zip(arr, sub):
+                        w = slabs(ci, G, None, None, inp, Sb)
+                        d.g, d.xa, d.gw_part, d.gbias_part, d.off0, d.dstep = G.data_ptr(), inp.data_ptr(), w[11].data_ptr(), w[12].data_ptr(), off0, dstep
+                        d.Ca, d.Cb, d.k, d.splits = steps[ci][3], steps[ci][4], steps[ci][2], Sb
+                    check(lib().psnd_conv1d_cl_wgrad_multi(ctypes.addressof(arr), len(sub), shape.N, shape.Lp, st), 'psnd_conv1d_cl_wgrad_multi')
+
+            def finish(convs):
+                """weight-norm backward of these convs (their slabs are complete on this stream), then the hand-over of what went straight
+                into the sink's buffers"""
+                ds = [descs[ci] for ci in convs]
+                for j0 in range(0, len(ds), 32):                 # PSND_WNORM_MAX descriptors per launch
+                    chunk = ds[j0:j0 + 32]
+                    buf = ctypes.create_string_buffer(b''.join(chunk))
+                    check(lib().psnd_conv1d_wnorm_bwd_multi(buf, len(chunk), st), 'psnd_conv1d_wnorm_bwd_multi')
+                out = []
+                for ci in convs:
+                    for ent in early.get(ci, ()):
+                        if ent is not None:
+                            grads[3 * ci + ent[0]] = None        # in place already: nothing for autograd to accumulate
+                            out.append(ent[1])
+                    handed.add(ci)
+                if out:
+                    sink.deliver(out)
+
+            if sink is not None and batch and nsec == 1 and not wstreams:
+                # chunked: behind every input-gradient launch the weight gradients of the convs it completed, their weight-norm
+                # backward and their hand-over - the reducer's buckets fill (and leave) block by block, last block first
+                done_w = 0
+                main_s = torch.cuda.current_stream(dev)
+                side_s = None
+                if HANDOVER_SIDE_STREAM:
+                    side_s = _HANDOVER_STREAMS.get(dev.index)
+                    if side_s is None:
+                        side_s = _HANDOVER_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+
+                def chunk(part, ready):
+                    nonlocal st
+                    if side_s is not None:
+                        side_s.wait_stream(main_s)
+                        with torch.cuda.stream(side_s):
+                            st = stream_ptr(dev)
+                            if part:
+                                wgrad_batch(part)
+                            finish(ready)
+                        st = stream_ptr(dev)
+                    else:
+                        if part:
+                            wgrad_batch(part)
+                        finish(ready)
+
+                launches = [e for e in plan if (e[1][-1] if e[0] == 'chainb' else e)[0] == 'pairb']
+                L, C = len(launches), max(1, int(HANDOVER_CHUNKS))
+                cut = {id(launches[min(L - 1, max(0, round((j + 1) * L / C) - 1))]) for j in range(C - 1)} if L else set()
+                ready = []
+                for e in plan:
+                    run(0, [e])
+                    ready += [ci for pe, ci in own_launch if pe is e]
+                    last = e[1][-1] if e[0] == 'chainb' else e
+                    upto = flush_after.get(id(last[16])) if (last[0] == 'pairb' and id(e) in cut) else None
+                    if upto is None:
+                        continue                                  # no hand-over point behind this launch (own-launch convs wait for the next)
+                    part = []
+                    if upto is not None and upto > done_w:
+                        part = wbatch[done_w:upto]
+                        ready += [ci for ci, _, _, _, _ in part]
+                        done_w = upto
+                    if ready:
+                        chunk(part, ready)
+                        ready = []
+                part = wbatch[done_w:]
+                rest = [ci for ci in range(n) if ci not in handed and descs[ci] is not None and ci not in [c for c, _, _, _, _ in part]]
+                rest = [ci for ci in rest if ci not in ready]
+                if part or rest or ready:
+                    chunk(part, ready + rest + [ci for ci, _, _, _, _ in part])
+                if side_s is not None:
+                    main_s.wait_stream(side_s)
+            else:
+                _run_sections(dev, nsec, sides, run)
+                for sd in set(used):
+                    torch.cuda.current_stream(dev).wait_stream(sd)
+                wgrad_batch(wbatch)
+                finish([ci for ci in range(n) if descs[ci] is not None])
         return (g_raw, g_act, None, None, None, None, None, None) + tuple(grads)
 
 

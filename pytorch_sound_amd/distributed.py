@@ -125,18 +125,37 @@ class FlatGradReducer:
         self._next = 0               # first bucket whose all-reduce has not been issued in this step
         self.launch_log = collections.deque(maxlen=4096)   # bucket indices in the order their collectives were issued (tests)
         self._bucket_of = {}
+        self._slot = {}              # parameter -> (bucket, offset in floats); a slot is 64-float aligned
+        self._deliver_seq = 0        # deliver() calls so far; _in_deliver: the running one's number (0: none) - handover_log (tests, profiles)
+        self._in_deliver = 0
+        self.handover_log = collections.deque(maxlen=4096)   # (bucket, number of the deliver() call that released it, or 0 = a hook / finish())
+        self._sunk = set()           # parameters whose gradient was written straight into its slot this step (sink protocol)
+        self.sink_enabled = True     # cl.GRAD_SINK protocol: conv-chain nodes write into the buckets and hand parameters over mid-backward
         self._handles = []
         order = list(reversed(self.params))
         if bucket_bytes is None:
             bucket_bytes = self.auto_bucket_bytes(sum(p.numel() * 4 for p in order))
         self.bucket_bytes = bucket_bytes
-        groups, cur, cur_bytes = [], [], 0
+        # the parameters of one leaf module (a conv's weight_v / weight_g / bias) stay in ONE bucket: their gradients appear together, and
+        # a bucket that holds the bias of the NEXT conv as well would wait for that conv's block (measured at config 2: bucket 3 of 6
+        # waited for the first block because two 1 KB tensors of it had slipped in behind five convs of the second)
+        owner = {}
+        for m in module.modules():
+            for q in m.parameters(recurse=False):
+                owner.setdefault(q, m)
+        units = []
         for p in order:
-            nbytes = p.numel() * 4
-            if cur and (cur_bytes + nbytes > bucket_bytes or p.device != cur[0].device):
+            if units and owner.get(p) is not None and owner.get(units[-1][-1]) is owner.get(p) and p.device == units[-1][-1].device:
+                units[-1].append(p)
+            else:
+                units.append([p])
+        groups, cur, cur_bytes = [], [], 0
+        for u in units:
+            nbytes = sum(q.numel() for q in u) * 4
+            if cur and (cur_bytes + nbytes > bucket_bytes or u[0].device != cur[0].device):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
-            cur.append(p)
+            cur.extend(u)
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
@@ -159,11 +178,14 @@ class FlatGradReducer:
                 p.grad = flat[o:o + p.numel()].view_as(p)
             b = {'flat': flat, 'params': g, 'offs': offs, 'pending': len(g), 'work': None}
             self.buckets.append(b)
-            for p in g:
+            for p, o in zip(g, offs):
                 self._bucket_of[p] = b
+                self._slot[p] = (b, o)
         if self.active:
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            from . import cl
+            cl.GRAD_SINK = self      # conv-chain nodes hand their weight gradients over from inside their backward (cl.py)
 
     @staticmethod
     def auto_bucket_bytes(total_bytes: int, target_buckets: int = 6) -> int:
@@ -175,9 +197,49 @@ class FlatGradReducer:
         per = -(-total_bytes // target_buckets)
         return int(min(32 * mib, max(mib, -(-per // mib) * mib)))
 
+    # ---- cl.GRAD_SINK protocol: gradients produced INSIDE a node's backward ------------------------------------------------------
+    def sink_active(self) -> bool:
+        """true while a backward runs whose gradients belong in the buckets: an eager data-parallel step, or a capture in mode
+        'capture' / 'events' (the deferred mode keeps the graph's own gradient tensors: load_grads copies them)"""
+        if not (self.active and self.sink_enabled):
+            return False
+        if self._capturing is not None:
+            return self._capturing in ('capture', 'events')
+        return not self.deferred
+
+    def dest(self, p, numel: int):
+        """the slot of parameter `p` as a flat fp32 tensor of `numel` elements (>= p.numel(): a padded bias), to be OVERWRITTEN with its
+        gradient - or None: not a parameter of this reducer, no backward of ours running, or already written this step (a shared
+        parameter: the node then returns the gradient and autograd accumulates it as usual)"""
+        if p is None or not self.sink_active():
+            return None
+        slot = self._slot.get(p)
+        if slot is None or p in self._sunk:
+            return None
+        b, off = slot
+        if numel > (p.numel() + 63) // 64 * 64:
+            return None
+        self._sunk.add(p)
+        return b['flat'][off:off + numel]
+
+    def deliver(self, params):
+        """the gradients of these parameters have been written into their slots (enqueued on the current stream): count them as
+        arrived - a bucket that is complete leaves now, while the backward goes on"""
+        self._deliver_seq += 1
+        self._in_deliver = self._deliver_seq
+        try:
+            for p in params:
+                b, off = self._slot[p]
+                if p.grad is None or p.grad.data_ptr() != b['flat'].data_ptr() + off * 4:
+                    p.grad = b['flat'][off:off + p.numel()].view_as(p)
+                self._on_grad(p)
+        finally:
+            self._in_deliver = 0
+
     # gradients must stay views of the flat buffers: zero in place instead of dropping them
     def zero_grad(self):
         self._next = 0
+        self._sunk.clear()
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
@@ -240,6 +302,7 @@ class FlatGradReducer:
         behind the last bucket now (a captured copy), ahead of every bucket's release point."""
         self._capturing = mode
         self._next = 0
+        self._sunk.clear()
         self._cap_works = []
         self._arrived = 0
         self.emit_log = []           # (bucket, gradients that had arrived when its release point was captured) - tests
@@ -260,7 +323,8 @@ class FlatGradReducer:
         """captured: gradients of bucket i (static tensors of the graph's pool) -> its flat buffer, then the release point"""
         b = self.buckets[i]
         views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
-        have = [(v, p.grad) for v, p in zip(views, b['params']) if p.grad is not None]
+        # (a gradient that a node wrote straight into its slot - cl.GRAD_SINK - is there already)
+        have = [(v, p.grad) for v, p in zip(views, b['params']) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         for v, p in zip(views, b['params']):
             if p.grad is None:
                 v.zero_()            # a parameter the captured backward never reached
@@ -274,6 +338,7 @@ class FlatGradReducer:
             check(lib().psnd_event_record_external(self._events[i], torch.cuda.current_stream(b['flat'].device).cuda_stream),
                   'psnd_event_record_external')
         self.launch_log.append(i)
+        self.handover_log.append((i, self._in_deliver))
         self.emit_log.append((i, self._arrived))
 
     def capture_end(self):
@@ -285,6 +350,7 @@ class FlatGradReducer:
             w.wait()
         self._cap_works = []
         mode, self._capturing = self._capturing, None
+        self._sunk.clear()
         self._next = 0
         for b in self.buckets:
             b['pending'] = len(b['params'])
@@ -339,6 +405,7 @@ class FlatGradReducer:
             nb = self.buckets[self._next]
             nb['work'] = dist.all_reduce(nb['flat'], op=dist.ReduceOp.SUM, async_op=True)
             self.launch_log.append(self._next)
+            self.handover_log.append((self._next, self._in_deliver))
             self._next += 1
 
     def finish(self, average: bool = True):
@@ -376,8 +443,12 @@ class FlatGradReducer:
             b['work'] = None
             b['pending'] = len(b['params'])
         self._next = 0
+        self._sunk.clear()
 
     def remove(self):
+        from . import cl
+        if cl.GRAD_SINK is self:
+            cl.GRAD_SINK = None
         for h in self._handles:
             h.remove()
         self._handles = []

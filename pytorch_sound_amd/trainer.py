@@ -543,7 +543,7 @@ class Trainer:
         # clip_grad() is the stock one; the averaging over ranks is then the kernel's grad_scale as well
         fused_clip = ((self.grad_clip or self.grad_norm) and getattr(self.optimizer, '_supports_fused_clip', False)
                       and type(self).clip_grad is Trainer.clip_grad)
-        if self._reducer is not None and pdist.is_dist():
+        if self._reducer is not None and (pdist.is_dist() or self._reducer.active):      # (active without is_dist: a forced one-rank group)
             # ONE collective per bucket: the flag sits behind the last bucket (set_flag), and when nothing clips the gradients the
             # division by the world size is left to the optimizer kernel (grad_scale) instead of a pass over the buckets
             in_opt = fused_clip or not (self.grad_clip or self.grad_norm)
