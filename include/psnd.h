@@ -503,6 +503,14 @@ int psnd_pqmf_synthesis(const float *x, const float *filt, int64_t B, int64_t M,
  *      per 16384-element chunk, summed in a fixed order by a second tiny launch: bit-reproducible).
  *  psnd_l1_loss_bwd: ga = g[0] * sign(a - b) / n, gb = -ga (either NULL); g = device pointer to the upstream gradient. */
 int64_t psnd_l1_loss_blocks(int64_t n);
+/* masked L1 of padded batches (data/dataset.py:196-250 pads the clips of a batch to its longest): a, b (N,C,T) fp32, frame_weight (N,T)
+ * fp32 (1 = the frame holds signal): out[0] = sum |a - b| w / (C sum w); part: 2 * psnd_masked_l1_blocks(N*C*T) doubles of scratch;
+ * inv_den[0] = 1 / (C sum w) is kept for the backward: ga = g[0] * sign(a - b) * w * inv_den, gb = -ga (either NULL). */
+int64_t psnd_masked_l1_blocks(int64_t n);
+int psnd_masked_l1_fwd(const float *a, const float *b, const float *frame_weight, int64_t N, int C, int64_t T, double *part, float *out,
+                       float *inv_den, void *stream);
+int psnd_masked_l1_bwd(const float *a, const float *b, const float *frame_weight, int64_t N, int C, int64_t T, const float *g,
+                       const float *inv_den, float *ga, float *gb, void *stream);
 int psnd_l1_loss_fwd(const float *a, const float *b, int64_t n, double *part, float *out, void *stream);
 int psnd_l1_loss_bwd(const float *a, const float *b, int64_t n, const float *g, float *ga, float *gb, void *stream);
 /* a weighted sum of up to 4 mean-L1 terms as ONE scalar (a recipe's `l1(a, b) + 0.5 * l1(c, d)`): out[0] = sum_i w[i] * mean|a[i] - b[i]|;

@@ -64,6 +64,9 @@ SIGNATURES = {
     'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
     'psnd_mask_head_l1_blocks': (_I64, [_I64, _I64, _INT]),
+    'psnd_masked_l1_blocks': (_I64, [_I64]),
+    'psnd_masked_l1_fwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _P, _P, _P, _P]),
+    'psnd_masked_l1_bwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _P, _P, _P, _P, _P]),
     'psnd_to_cl_nfk': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_mask_head_l1_blocks_nfk': (_I64, [_I64, _I64, _INT]),
     'psnd_mask_head_l1_fwd_nfk': (_INT, [_P, _P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P, _P]),

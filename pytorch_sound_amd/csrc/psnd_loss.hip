@@ -330,6 +330,83 @@ extern "C" int psnd_l1_loss_bwd_w(const float *a, const float *b, int64_t n, con
     return PSND_OK;
 }
 
+// ---- masked L1 over (N, C, T) tensors with a per-frame weight m (N, T) - the padded-batch recipes' loss (variable-length clips,
+//      data/dataset.py:196-250 pads to the batch maximum): out = sum_{n,c,t} |a - b| m[n,t] / (C sum m).  Forward: one partial pair
+//      (sum |a - b| m, sum m of the block's frames for c = 0) per workgroup, one combine; backward ga = g sign(a - b) m / (C sum m).
+namespace {
+constexpr int ML1CH = 4096;      // elements per workgroup
+__global__ __launch_bounds__(256) void masked_l1_partial_kernel(const float *a, const float *b, const float *m, long long CT, int T, long long n,
+                                                                 double *part) {
+    const long long e0 = (long long)blockIdx.x * ML1CH;
+    float acc = 0.f, macc = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e0 + ML1CH && e < n; e += 256) {
+        const long long clip = e / CT, r = e - clip * CT;
+        const int t = (int)(r % T);
+        const float w = m[clip * T + t];
+        acc += __builtin_fabsf(a[e] - b[e]) * w;
+        if (r < T) macc += w;                                  // every frame's weight once (channel 0)
+    }
+    double d = (double)acc, dm = (double)macc;
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) d += __shfl_xor(d, k, 64), dm += __shfl_xor(dm, k, 64);
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d, red[4 + (threadIdx.x >> 6)] = dm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * (size_t)blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        part[2 * (size_t)blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+__global__ __launch_bounds__(256) void masked_l1_final_kernel(const double *part, int nb, int C, float *out, float *inv_den) {
+    double s = 0.0, sm = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[2 * i], sm += part[2 * i + 1];
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k, 64), sm += __shfl_xor(sm, k, 64);
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s, red[4 + (threadIdx.x >> 6)] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double den = (red[4] + red[5] + red[6] + red[7]) * (double)C;
+        out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / den);
+        inv_den[0] = (float)(1.0 / den);
+    }
+}
+__global__ __launch_bounds__(256) void masked_l1_bwd_kernel(const float *a, const float *b, const float *m, long long CT, int T, long long n,
+                                                             const float *g, const float *inv_den, float *ga, float *gb) {
+    const float sc = g[0] * inv_den[0];
+    for (long long e = (long long)blockIdx.x * 1024 + threadIdx.x; e < (long long)(blockIdx.x + 1) * 1024 && e < n; e += 256) {
+        const long long clip = e / CT, r = e - clip * CT;
+        const float d = a[e] - b[e];
+        const float v = sc * m[clip * T + (int)(r % T)] * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        if (ga) ga[e] = v;
+        if (gb) gb[e] = -v;
+    }
+}
+}  // namespace
+extern "C" int64_t psnd_masked_l1_blocks(int64_t n) { return n <= 0 ? 0 : (n + ML1CH - 1) / ML1CH; }
+extern "C" int psnd_masked_l1_fwd(const float *a, const float *b, const float *frame_weight, int64_t N, int C, int64_t T, double *part,
+                                  float *out, float *inv_den, void *stream) {
+    if (!a || !b || !frame_weight || !part || !out || !inv_den) PSND_FAIL(PSND_E_ARG, "masked_l1_fwd: null pointer");
+    const int64_t n = N * C * T;
+    if (N <= 0 || C <= 0 || T <= 0 || T > 0x7fffffff || psnd_masked_l1_blocks(n) > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "masked_l1_fwd: N=%lld C=%d T=%lld", (long long)N, C, (long long)T);
+    const int nb = (int)psnd_masked_l1_blocks(n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(masked_l1_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, frame_weight, (long long)C * T, (int)T, (long long)n, part);
+    hipLaunchKernelGGL(masked_l1_final_kernel, dim3(1), dim3(256), 0, s, part, nb, C, out, inv_den);
+    PSND_CHECK_LAUNCH("masked_l1_fwd");
+    return PSND_OK;
+}
+extern "C" int psnd_masked_l1_bwd(const float *a, const float *b, const float *frame_weight, int64_t N, int C, int64_t T, const float *g,
+                                  const float *inv_den, float *ga, float *gb, void *stream) {
+    if (!a || !b || !frame_weight || !g || !inv_den || (!ga && !gb)) PSND_FAIL(PSND_E_ARG, "masked_l1_bwd: null pointer");
+    const int64_t n = N * C * T;
+    if (N <= 0 || C <= 0 || T <= 0 || T > 0x7fffffff || (n + 1023) / 1024 > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "masked_l1_bwd: N=%lld C=%d T=%lld", (long long)N, C, (long long)T);
+    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, frame_weight,
+                       (long long)C * T, (int)T, (long long)n, g, inv_den, ga, gb);
+    PSND_CHECK_LAUNCH("masked_l1_bwd");
+    return PSND_OK;
+}
+
 // flag[0] = 1 if any of x[0 .. n) is NaN else 0 (one workgroup; n is a loss value or a handful of them): the trainer's device-side
 // "loss != loss" (trainer.py:205) as ONE launch instead of torch.isnan + a dtype cast
 namespace {

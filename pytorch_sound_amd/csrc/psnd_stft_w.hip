@@ -41,6 +41,9 @@
 #ifndef PSND_W_NFK_AUX
 #define PSND_W_NFK_AUX 2     // cache-policy bits of the (N, F, K) stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt: 188 against 205 us (config 5, same box)
 #endif
+#ifndef PSND_W_NFK_SYNC
+#define PSND_W_NFK_SYNC 0
+#endif
 #ifndef PSND_W_SKIP
 #define PSND_W_SKIP 0        // register-pressure bisection only: bit k leaves stage k of the transform out
 #endif
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
             }
             if (nkind == 2) request_edge(nx, ns0);                // the exchange buffer is the wave's own at all times
             kind = nkind;
+#if PSND_W_NFK_SYNC
+            // the 16 waves of a workgroup read overlapping samples (hop = n / 4: every sample belongs to 4 frames): started together, the
+            // later readers find them in the L2; drifting apart they go back to HBM (FETCH_SIZE 1.57 x the algorithmic reads without this)
+            __syncthreads();
+#endif
             continue;
         }
         // addresses of the staging / store phases (see fresh_lane)

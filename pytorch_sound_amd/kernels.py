@@ -832,6 +832,47 @@ class L1LossSum(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class MaskedL1(torch.autograd.Function):
+    """sum |a - b| w / (C sum w) over (N, C, T) tensors with a per-frame weight w (N, T): the loss of a padded-batch recipe (clips of
+    different lengths padded to the batch maximum, data/dataset.py:196-250) - psnd_masked_l1_fwd / _bwd instead of abs / mul / two sums /
+    div and their autograd twins"""
+
+    @staticmethod
+    def forward(ctx, a, b, w):
+        _need_cuda(a, 'input')
+        _need_cuda(b, 'target')
+        _need_cuda(w, 'frame weight')
+        a, b, w = a.contiguous(), b.contiguous(), w.contiguous()
+        N, C, T = a.shape
+        if b.shape != a.shape or tuple(w.shape) != (N, T):
+            raise _lib.PsndError('masked_l1_loss: input %s, target %s, frame weight %s' % (tuple(a.shape), tuple(b.shape), tuple(w.shape)))
+        part = torch.empty(2 * int(lib().psnd_masked_l1_blocks(a.numel())), dtype=torch.float64, device=a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        inv = torch.empty(1, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib().psnd_masked_l1_fwd(ptr(a), ptr(b), ptr(w), N, C, T, ptr(part), ptr(out), ptr(inv), stream_ptr(a.device)), 'psnd_masked_l1_fwd')
+        ctx.save_for_backward(a, b, w, inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w, inv = ctx.saved_tensors
+        N, C, T = a.shape
+        g = g.contiguous().float()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if ga is None and gb is None:
+            return None, None, None
+        with torch.cuda.device(a.device):
+            check(lib().psnd_masked_l1_bwd(ptr(a), ptr(b), ptr(w), N, C, T, ptr(g), ptr(inv), ptr(ga), ptr(gb), stream_ptr(a.device)), 'psnd_masked_l1_bwd')
+        return ga, gb, None
+
+
+def masked_l1_loss(input, target, frame_weight):
+    """sum |input - target| * frame_weight[:, None, :] / (C * frame_weight.sum()) on fp32 HIP tensors (N, C, T) / (N, T)"""
+    return MaskedL1.apply(input, target, frame_weight)
+
+
 def l1_loss_sum(pairs, weights):
     """sum_i weights[i] * F.l1_loss(*pairs[i]) on fp32 HIP tensors, one autograd node"""
     flat = [t for p in pairs for t in p]

@@ -17,16 +17,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-TORCH_FORMULATION_ON_GPU = False    # tests only: evaluate the torch formulation on a CUDA tensor (the fp32 yardstick of a parity test)
-ROUND1_PATH = False                 # A/B measurements only: round 1's path (library bmm / GEMMs around the softmax + GroupNorm kernels)
-
-
 def _hip_ok(x: torch.Tensor) -> bool:
     """A tensor that lives on the GPU ALWAYS takes the hand-written kernels (psnd_linear1x1_*, psnd_mha_*, psnd_groupnorm1_*):
     the kernels compute in fp32 from fp32 memory, so another floating dtype is cast on the way in and the result cast back
-    (`_to_kernel_dtype`) - there is no library path for a HIP tensor.  CPU tensors use the torch formulation that the golden tests
-    pin (tests/test_modules_golden.py)."""
-    return x.is_cuda and not TORCH_FORMULATION_ON_GPU
+    (`_to_kernel_dtype`) - there is no library path for a HIP tensor and no switch in this module that opens one (a parity test that
+    wants the torch formulation evaluated on the GPU as its fp32 yardstick patches this function).  CPU tensors use the torch
+    formulation that the golden tests pin (tests/test_modules_golden.py)."""
+    return x.is_cuda
 
 
 def _to_kernel_dtype(x: torch.Tensor) -> torch.Tensor:
@@ -50,12 +47,8 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tens
     """the 1x1 Conv1d projections of modules.py:21-22, 93-95 as what they are - one GEMM over (C_in, N*T), on the exact-fp32
     matrix-core kernel (psnd_linear1x1_*, bias and the following ReLU fused).  CPU tensors (and the tests' fp32 yardstick) keep
     the torch formulation."""
-    if not _hip_ok(x) or ROUND1_PATH:
-        if not x.is_cuda:
-            y = conv(x)
-        else:
-            y = torch.bmm(conv.weight.squeeze(-1).unsqueeze(0).expand(x.shape[0], -1, -1), x)
-            y = y if conv.bias is None else y + conv.bias.view(1, -1, 1)
+    if not _hip_ok(x):
+        y = conv(x)
         return F.relu(y) if relu else y
     from pytorch_sound_amd import kernels as K
     # under torch.autocast(bfloat16) the products take bf16 operands (fp32 accumulation, fp32 activations in memory): 16x the
@@ -93,7 +86,7 @@ class MultiHeadAttention(nn.Module):
         in_dtype = input.dtype
         input = _to_kernel_dtype(input)
         kvq = _conv1x1(self.linear_kvq, input)
-        if _hip_ok(input) and not ROUND1_PATH:
+        if _hip_ok(input):
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
             if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 64:
                 from pytorch_sound_amd._lib import PsndError
@@ -123,11 +116,20 @@ class MultiHeadAttention(nn.Module):
     def scale_dot_att(k: torch.Tensor, v: torch.Tensor, q: torch.Tensor,
                       att_mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
         """k, v, q: (B, d, T); att_mask: (B, T) bool or None -> (B, d, T), (B, T_key, T_query)."""
-        if _hip_ok(q):            # only reached with ROUND1_PATH (A/B measurements): softmax kernel between two library bmm
+        if _hip_ok(q):
+            # a public static method in the reference (modules.py:61-79): called directly on HIP tensors it runs on psnd_mha_* as well -
+            # one "head" per batch entry (the heads are folded into the batch here already), scores on the chip, no library bmm
             from pytorch_sound_amd import kernels as K
+            from pytorch_sound_amd._lib import PsndError
+            if not (k.shape == v.shape == q.shape) or k.dim() != 3 or k.size(1) > 64:
+                raise PsndError('scale_dot_att on HIP tensors: (B, d, T) operands of one shape with d <= 64 (psnd_mha_*), got %s / %s / %s; '
+                                'there is no library path for a HIP tensor' % (tuple(k.shape), tuple(v.shape), tuple(q.shape)))
+            dt = q.dtype
+            kvq = torch.cat([k.float(), v.float(), q.float()], dim=1)
             mask_u8 = None if att_mask is None else att_mask.to(torch.uint8).contiguous()
-            att = K.SoftmaxKeys.apply(torch.bmm(k.transpose(1, 2), q), mask_u8, 1.0 / math.sqrt(k.size(1)))
-            return torch.bmm(v, att), att
+            bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            x, att = K.AttentionKVQ.apply(kvq, mask_u8, 1, True, bf16)
+            return (x, att) if dt == torch.float32 else (x.to(dt), att.to(dt))
         scores = torch.bmm(k.transpose(1, 2), q) / math.sqrt(k.size(1))
         if att_mask is not None:
             scores = scores.masked_fill(att_mask.unsqueeze(2), -float('inf'))     # padded keys

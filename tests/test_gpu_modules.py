@@ -143,14 +143,15 @@ def test_config4_block_vs_float64(T, N):
         # yardstick: the SAME formulation in plain fp32 torch ops (library GEMMs, torch softmax / group_norm) against float64 -
         # what fp32 arithmetic itself costs at this size (the softmax backward cancels: att * (g - sum att g))
         import pytorch_sound_amd.models.modules as M
-        M.TORCH_FORMULATION_ON_GPU = True
+        keep_hip_ok = M._hip_ok
+        M._hip_ok = lambda t: False                   # the torch formulation evaluated on the GPU: this test's fp32 yardstick
         try:
             for m in (mha, ffn):
                 m.zero_grad()
             y32, att32, gx32, gp32 = run((pe, mha, ffn), torch.float32, att_in_loss)
             y32, att32, gx32, gp32 = y32.clone(), att32.clone(), gx32.clone(), {k: v.clone() for k, v in gp32.items()}
         finally:
-            M.TORCH_FORMULATION_ON_GPU = False
+            M._hip_ok = keep_hip_ok
         err = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())   # noqa: E731
         ok = lambda a, a32, b, rt: err(a, b) <= max(rt, 2.0 * err(a32, b))        # noqa: E731
         print('T=%d att_in_loss=%s: y %.1e (torch fp32 %.1e)  gx %.1e (%.1e)  worst param grad %.1e (%.1e)' % (
@@ -317,3 +318,26 @@ def test_attention_bf16_operands(N, H, C, T, masked, with_gatt):
         g = x.grad.view(N, 3, C, T)
         L = int(lens[-1])
         assert float(g[-1, :, :, L:].abs().max()) == 0
+
+
+def test_scale_dot_att_static_method_on_hip_tensors():
+    """MultiHeadAttention.scale_dot_att is a public static method in the reference (modules.py:61-79): called directly on HIP tensors it
+    runs on psnd_mha_* too (one head per batch entry) - no library bmm / softmax (dispatch-mode check) - and equals the torch
+    formulation in float64, masks included; an uncovered head dimension raises."""
+    from pytorch_sound_amd.models.modules import MultiHeadAttention
+    from pytorch_sound_amd._lib import PsndError
+    from test_gpu_no_library_paths import forbid_library_ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(4)
+    B, d, T = 6, 48, 77
+    k, v, q = (torch.randn(B, d, T, device=dev) for _ in range(3))
+    lens = torch.randint(T // 2, T + 1, (B,))
+    mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
+    for m in (None, mask):
+        with forbid_library_ops():
+            x, att = MultiHeadAttention.scale_dot_att(k, v, q, m)
+        xr, attr = MultiHeadAttention.scale_dot_att(k.double().cpu(), v.double().cpu(), q.double().cpu(), None if m is None else m.cpu())
+        assert float((x.double().cpu() - xr).abs().max()) <= 2e-5 * float(xr.abs().max())
+        assert float((att.double().cpu() - attr).abs().max()) <= 1e-5
+    with pytest.raises(PsndError):
+        MultiHeadAttention.scale_dot_att(torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), None)

@@ -192,3 +192,26 @@ def test_l1_loss_matches_torch(shape):
     assert torch.allclose(a.grad.double(), a64.grad, rtol=1e-6, atol=0) and torch.allclose(b.grad.double(), b64.grad, rtol=1e-6, atol=0)
     with pytest.raises(Exception):
         K.l1_loss(a, torch.zeros(2, device=DEV))
+
+
+def test_masked_l1_loss_matches_torch_f64():
+    """kernels.masked_l1_loss (psnd_masked_l1_fwd / _bwd) against the padded-batch recipe's formulation in float64: value to 1e-6, both
+    gradients to 1e-6 of their largest entry; an all-ones weight equals F.l1_loss"""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    for N, C, T in [(32, 80, 1292), (3, 5, 7), (1, 1, 4097)]:
+        a = torch.randn(N, C, T, device=dev, requires_grad=True)
+        b = torch.randn(N, C, T, device=dev, requires_grad=True)
+        lens = torch.randint(1, T + 1, (N,))
+        w = (torch.arange(T)[None, :] < lens[:, None]).float().to(dev)
+        loss = K.masked_l1_loss(a, b, w)
+        (loss * 1.7).backward()
+        a64, b64 = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+        ref = ((a64 - b64).abs() * w.double().unsqueeze(1)).sum() / (w.double().sum() * C)
+        (ref * 1.7).backward()
+        assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+        assert float((a.grad.double() - a64.grad).abs().max()) <= 1e-6 * float(a64.grad.abs().max())
+        assert float((b.grad.double() - b64.grad).abs().max()) <= 1e-6 * float(b64.grad.abs().max())
+        ones = torch.ones(N, T, device=dev)
+        assert abs(float(K.masked_l1_loss(a.detach(), b.detach(), ones)) - float(torch.nn.functional.l1_loss(a64, b64))) <= 1e-6

@@ -71,8 +71,8 @@ def main():
         def forward(self, mel, valid, is_logging=False):
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled='--amp' in sys.argv):   # bf16 projection and attention operands
                 y = self.model(mel, valid < 0.5)
-            y = y.float()
-            loss = ((y - mel).abs() * valid.unsqueeze(1)).sum() / (valid.sum() * 80.0)
+            from pytorch_sound_amd import kernels as K
+            loss = K.masked_l1_loss(y.float(), mel, valid)             # psnd_masked_l1_* instead of abs / mul / sum / sum / div
             return loss, {'loss': (loss, LogType.SCALAR)}
 
     def batches():

@@ -51,10 +51,12 @@ for T in (173, 431, 690, 1292):
     lens = torch.linspace(0.8 * T, T, N).long()
     mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
     res = {}
-    for name, flags in (('round 2 fp32', (False, False, True, False)), ('autocast bf16', (False, False, True, True)),
-                        ('autocast bf16, no att', (False, False, False, True)), ('round 1', (True, False, True, False)), ('torch', (False, True, True, False))):
-        M.ROUND1_PATH, M.TORCH_FORMULATION_ON_GPU, mha.return_att, ac = flags
+    keep = M._hip_ok
+    for name, (torch_path, ret_att, ac) in (('kernels fp32', (False, True, False)), ('autocast bf16', (False, True, True)),
+                                             ('autocast bf16, no att', (False, False, True)), ('torch', (True, True, False))):
+        M._hip_ok = (lambda t: False) if torch_path else keep        # (the product module has no switch: the torch yardstick is a patch)
+        mha.return_att = ret_att
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=ac):
             res[name] = graph_time(x, mask)
-    M.ROUND1_PATH, M.TORCH_FORMULATION_ON_GPU, mha.return_att = False, False, True
+    M._hip_ok, mha.return_att = keep, True
     print('T=%4d frames (att %4.0f MB): ' % (T, H * N * T * T * 4 / 1e6) + ' | '.join('%s %.2f ms' % kv for kv in res.items()), flush=True)

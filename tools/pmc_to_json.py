@@ -10,7 +10,10 @@ import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORK = {'n1024': ('stft_fwd_n1024_kernel<mag>', '1024 clips x 2 s, 1024/256', 4 * 1024 * 44100 + 4 * 1024 * 513 * 173),
-        'n4096': ('stft_fwd 4096/1024 <mag>', '32 clips x 30 s at 44.1 kHz, 4096/1024', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292)}
+        'n4096': ('stft_fwd 4096/1024 <mag>', '32 clips x 30 s at 44.1 kHz, 4096/1024', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292),
+        # psnd_stft_mag_nfk: the same transforms writing (N, F, K) (tools/pmc_stft.sh ... RUNNER=tools/r04/run_nfk_only.py)
+        'nfk1024': ('stft_fwd_n1024q_kernel', '1024 clips x 2 s, 1024/256, output (N, F, K)', 4 * 1024 * 44100 + 4 * 1024 * 513 * 173),
+        'nfk4096': ('stft_fwd_n4096w_kernel<NFK>', '32 clips x 30 s at 44.1 kHz, 4096/1024, output (N, F, K)', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292)}
 
 
 def summarise(d, match='stft_fwd'):
