@@ -376,7 +376,7 @@ def gpu_bench(args):
         roofline_mel = _mel_roofline(device)
         roofline_conv = _conv_roofline(device, N, Fr)
         legs = {}
-        if not args.no_legs:
+        if not args.no_legs and world == 1:      # single-GPU legs: each builds a Trainer of its own (a collective set-up under a process group)
             legs['config3_step'] = _config3_leg(device)
             legs['config4_step'] = _config4_leg(device)
         audio_s = world * N * CLIP_SECONDS * args.steps
@@ -795,6 +795,9 @@ def main():
                     help="magnitude layout between the STFT kernel and its consumers inside the step: 'nfk' bin-fastest (psnd_stft_mag_nfk), 'nkf' the reference's")
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
     args = ap.parse_args()
+    if os.environ.get('PSND_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit if the run is still alive after S seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['PSND_BENCH_WATCHDOG']), exit=True)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')
     out, device = gpu_bench(args)
