@@ -307,11 +307,15 @@ int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const float *v, co
 int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c, const void *d, int count, float slope, void *out, int64_t n,
                          void *stream);
 int psnd_cl_mean_act_bwd(const void *g, const void *y, int count, float slope, void *gin, int64_t n, void *stream);
-/* psnd_conv1d_prep for n convs in ONE launch.  descs_dev: device array of n records
+/* psnd_conv1d_prep for n convs in ONE launch (one workgroup per 8 output channels: every store a 16-byte piece of the packs).
+ * descs_dev: device array of n records
  *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cout, Cin, k, Cb, Ca, blk0; }   (72 bytes, blk0 = sum of
- *   the Cout of the records before it), total_blocks = sum of all Cout.  The pad regions of wf / wb / bp are not written
- *   (zero them once when allocating). */
-int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
+ *   ceil(Cout / 8) of the records before it), total_blocks = that sum over all records, max_row = the largest Cin * k
+ *   (<= 10240: the 8 rows of a workgroup live in LDS; larger layers take psnd_conv1d_prep).  Same packs, bit for bit, as
+ *   psnd_conv1d_prep.  which: 1 = forward pack + bias, 2 = backward pack, 3 = both (the backward pack can be written when the backward
+ *   starts: lines written by 16-byte stores are read fastest while they are fresh).  The pad regions of wf / wb / bp beyond the 8-channel
+ *   groups are not written (zero them once). */
+int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, int max_row, int which, void *stream);
 /* psnd_conv1d_wnorm_bwd for up to PSND_WNORM_MAX convs (the six of a ResBlock1, the 26 of the separator body) in one launch; descs is a HOST array,
  * passed to the kernel by value (nothing is uploaded, the launch can be captured in a hipGraph). */
 #define PSND_WNORM_MAX 32

@@ -61,7 +61,7 @@ SIGNATURES = {
     'psnd_conv1d_cl_pair_bwd': (_INT, [_P, _P, _P, _F, _P, _P, _P, _F, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P,
                                        _P, _P, _INT, _INT, _P, _P, _P]),
     'psnd_conv1d_wnorm_bwd_multi': (_INT, [_P, _INT, _P]),
-    'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
+    'psnd_conv1d_prep_multi': (_INT, [_P, _INT, _INT, _INT, _INT, _P]),
     'psnd_conv1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),
     'psnd_mask_head_l1_blocks': (_I64, [_I64, _I64, _INT]),
     'psnd_masked_l1_blocks': (_I64, [_I64]),

@@ -684,10 +684,29 @@ class MeanActCL(torch.autograd.Function):
         return (None,) + (gin,) * ctx.n
 
 
-def prep_all(owner, convs):
+class PrepPacks(dict):
+    """{id(conv): (wf, wb, bp)} of prep_all().  `deferred`: set when the backward packs have NOT been written yet - the first backward
+    node that needs one calls write_backward_packs() (once per forward)."""
+    deferred = None
+
+    def write_backward_packs(self):
+        cache = self.deferred
+        if cache is None or cache['wb_done']:
+            return
+        cache['wb_done'] = True
+        with torch.cuda.device(cache['dev']):
+            check(lib().psnd_conv1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], cache['max_row'], 2, stream_ptr(cache['dev'])),
+                  'psnd_conv1d_prep_multi')
+
+
+def prep_all(owner, convs, defer_backward_packs=False):
     """weight norm + both bf16 packs + padded bias of every conv in `convs` (WNConv1d modules) in ONE launch
     (psnd_conv1d_prep_multi).  The pack buffers and the device descriptor table are cached on `owner` and rebuilt only
-    when a parameter moved; returns {id(conv): (wf, wb, bp)} for fused_conv(..., prepped=...)."""
+    when a parameter moved; returns {id(conv): (wf, wb, bp)} for fused_conv(..., prepped=...).
+    defer_backward_packs: only the forward packs + biases now; the [j][ci][co] packs of the input-gradient kernels are written by a second
+    launch when the backward starts (PrepPacks.write_backward_packs, called by ResBlockCL.backward).  Measured on the config-2 step: packs
+    written with 16-byte stores are read at full speed while fresh (the forward chains right behind the launch) but ~25 % slower 300 us
+    later (input-gradient chains 38 -> 47 us each) - the per-channel kernel's 2-byte stores did not show that, at 35 us per launch."""
     import struct
     import os
     if os.environ.get('PSND_NO_PREP_ALL') == '1':      # A/B switch: one prep launch per conv
@@ -697,7 +716,7 @@ def prep_all(owner, convs):
     cache = getattr(owner, '_cl_prep_cache', None)
     if cache is None or cache['key'] != key:
         dev = convs[0].weight_v.device
-        packs, recs, blk0 = {}, [], 0
+        packs, recs, blk0, max_row = PrepPacks(), [], 0, 0
         for c in convs:
             Cout, Cin, k = c.weight_v.shape
             Ca, Cb = round_up(Cin, ALIGN_C), round_up(Cout, ALIGN_C)
@@ -708,16 +727,21 @@ def prep_all(owner, convs):
             recs.append(struct.pack('<6Q6i', c.weight_v.data_ptr(), c.weight_g.data_ptr(),
                                     0 if c.bias is None else c.bias.data_ptr(), wf.data_ptr(), wb.data_ptr(), bp.data_ptr(),
                                     Cout, Cin, k, Cb, Ca, blk0))
-            blk0 += Cout
+            blk0 += (Cout + 7) // 8                   # one workgroup per 8 output channels
+            max_row = max(max_row, Cin * k)
         table = torch.frombuffer(bytearray(b''.join(recs)), dtype=torch.uint8).to(dev)
-        cache = {'key': key, 'packs': packs, 'table': table, 'n': len(convs), 'blocks': blk0, 'dev': dev}
+        cache = {'key': key, 'packs': packs, 'table': table, 'n': len(convs), 'blocks': blk0, 'max_row': max_row, 'dev': dev,
+                 'wb_done': True}
         owner._cl_prep_cache = cache
     for c in convs:
         if not (c.weight_v.is_contiguous() and c.weight_g.is_contiguous() and c.weight_v.dtype == torch.float32):
             raise _lib.PsndError('prep_all: fp32 contiguous weight_v / weight_g expected')
+    defer = bool(defer_backward_packs) and torch.is_grad_enabled() and os.environ.get('PSND_PREP_NO_DEFER') != '1'
     with torch.cuda.device(cache['dev']):
-        check(lib().psnd_conv1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], stream_ptr(cache['dev'])),
-              'psnd_conv1d_prep_multi')
+        check(lib().psnd_conv1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], cache['max_row'], 1 if defer else 3,
+                                           stream_ptr(cache['dev'])), 'psnd_conv1d_prep_multi')
+    cache['wb_done'] = not defer
+    cache['packs'].deferred = cache if defer else None
     return cache['packs']
 
 
@@ -743,6 +767,7 @@ class ResBlockCL(torch.autograd.Function):
         _need(xa, torch.bfloat16)
         dev = xa.device
         n = len(dils)
+        ctx.pack_owner = getattr(packs, 'owner', None)       # PrepPacks with deferred backward packs (prep_all)
         steps, saved, plan = [], [], []
         cur_x, cur_xa, pending = x, xa, None
         for i in range(n):
@@ -833,6 +858,8 @@ class ResBlockCL(torch.autograd.Function):
         saved, steps, shape = ctx.saved_tensors, ctx.steps, ctx.shape
         dev = saved[0].device
         n = len(steps)
+        if ctx.pack_owner is not None:
+            ctx.pack_owner.write_backward_packs()          # the [j][ci][co] packs: written now, read while fresh
         g_raw = None if g_raw is None else g_raw.contiguous()
         g_act = None if g_act is None else g_act.contiguous()
         grads = [None] * (3 * n)
@@ -1194,9 +1221,15 @@ def _block_node(convs, x, xa, shape, pairs, last_act_slope, want_raw, prep):
     params = []
     for c in convs:
         params += [c.weight_v, c.weight_g, c.bias]
-    packs = None if prep is None else [prep[id(c)] for c in convs]
+    packs = None if prep is None else _PackList(prep[id(c)] for c in convs)
+    if packs is not None:
+        packs.owner = prep if isinstance(prep, PrepPacks) else None
     roles = pairs if isinstance(pairs, tuple) else (('c1', 'c2') * (len(convs) // 2) if pairs else ('r2',) * len(convs))
     return ResBlockCL.apply(x, xa, shape, roles, tuple(c.dilation for c in convs), last_act_slope, want_raw, packs, *params)
+
+
+class _PackList(list):
+    owner = None                               # the PrepPacks the entries come from (deferred backward packs)
 
 
 def _use_block_node(convs, x):
@@ -1212,6 +1245,8 @@ def conv_body_cl(head, blocks, tail, x0, shape, prep=None):
     stack = [c for b in blocks for pair in zip(b.convs1, b.convs2) for c in pair]
     if (os.environ.get('PSND_NO_BODY_NODE') == '1' or os.environ.get('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled()
             or NODE_GRANULARITY == 'block'):
+        if isinstance(prep, PrepPacks):
+            prep.write_backward_packs()                    # per-conv nodes keep their backward pack from the forward
         x, xa = fused_conv(x0, head, shape, None, True, True, 0.1, prep)
         x, xa = resblock1_stack_cl(blocks, x, xa, shape, prep=prep)
         return fused_conv(xa, tail, shape, None, True, False, prep=prep)[0]

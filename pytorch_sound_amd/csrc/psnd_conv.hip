@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const fl
     const int co = blockIdx.x, n = Cin * k;
     const float *vr = v + (size_t)co * n;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) ss += vr[i] * vr[i];
+    for (int i = threadIdx.x; i < n; i += 256) ss = __builtin_fmaf(vr[i], vr[i], ss);
     for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
@@ -1131,16 +1131,23 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *v, const fl
     if (threadIdx.x == 0) bp[co] = bias ? bias[co] : 0.f;
 }
 
-// the same for MANY convs in one launch (one descriptor per conv, one block per output channel): a model's 26 prep
-// launches of ~5 us each were launch latency, not work.  Pads of wf / wb / bp are never written: zero them once.
+// the same for MANY convs in one launch (one descriptor per conv): a model's 26 prep launches of ~5 us each were launch latency, not
+// work.  Round 4: one workgroup per EIGHT output channels instead of one per channel.  The per-channel kernel wrote every bf16 of both
+// packs on its own (2-byte stores, 64 different lines per store instruction: 11 M line requests for the 5.5 M weights of the separator,
+// 35 us, 74 % of the wave time waiting); with eight rows in LDS every store is a whole 16-byte piece of the fragment order - the forward
+// pack [j][co][ci] takes 8 consecutive ci of one row (8 rows x 16 B = 128 contiguous bytes per lane octet), the backward pack [j][ci][co]
+// the 8 rows of one (ci, j) (consecutive ci = consecutive pieces: 512-byte runs).  The row norms keep the per-channel kernel's summation
+// order (256 strided partial sums, xor tree, four wave sums added in order), so the packs are bit-identical to psnd_conv1d_prep's.
+// Pads of wf / wb / bp beyond the 8-channel groups are never written: zero them once.
 struct PrepDesc {                 // 72 bytes, mirrored by pytorch_sound_amd/cl.py (struct format '<6Q6i')
     const float *v, *g, *bias;
     bf16_t *wf, *wb;
     float *bp;
-    int Cout, Cin, k, Cb, Ca, blk0;
+    int Cout, Cin, k, Cb, Ca, blk0;          // blk0: sum of ceil(Cout / 8) of the records before this one
 };
-__global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *descs, int n) {
-    __shared__ float red[4];
+constexpr int PREP_ROWS = 8;
+__global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *descs, int n, int which) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t s_prep[];          // [8 rows][nn] scaled weights, natural (ci, j) order
     int lo = 0, hi = n - 1;                                  // last descriptor with blk0 <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1148,22 +1155,95 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepDesc *de
         else hi = mid - 1;
     }
     const PrepDesc d = descs[lo];
-    const int co = blockIdx.x - d.blk0, nn = d.Cin * d.k;
-    if (co >= d.Cout) return;
-    const float *vr = d.v + (size_t)co * nn;
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < nn; i += 256) ss += vr[i] * vr[i];
-    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    const float scale = d.g[co] / __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
-    for (int i = threadIdx.x; i < nn; i += 256) {
-        const int ci = i / d.k, j = i - ci * d.k;
-        const bf16_t w = f2bf(vr[i] * scale);
-        d.wf[pack_index(d.k, j, co, ci, d.Cb, d.Ca)] = w;
-        d.wb[pack_index(d.k, j, ci, co, d.Ca, d.Cb)] = w;
+    const int co0 = (blockIdx.x - d.blk0) * PREP_ROWS, nn = d.Cin * d.k;
+    if (co0 >= d.Cout) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // ---- norms: wave w owns rows 2 w and 2 w + 1; lane l carries the partial sums of the per-channel kernel's threads l + 64 q ------------
+    constexpr int NR = 32;                                   // row values a lane keeps in registers: rows up to 64 * NR = 2048 weights
+    if (nn <= 64 * NR) {
+        // both rows' values are requested at once and stay in registers: one load latency per workgroup instead of four
+        float x[2][NR];
+        const float *vr0 = d.v + (size_t)(co0 + 2 * w) * nn;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bool live = co0 + 2 * w + rr < d.Cout;     // (wave-uniform)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int i = 64 * q + lane;
+                x[rr][q] = (live && i < nn) ? vr0[(size_t)rr * nn + i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * w + rr, co = co0 + r;
+            bf16_t *srow = s_prep + (size_t)r * nn;
+            float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NR; ++q) ss[q & 3] = __builtin_fmaf(x[rr][q], x[rr][q], ss[q & 3]);     // fused, as the per-channel kernel's loop compiles
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                for (int m = 32; m >= 1; m >>= 1) ss[q] += __shfl_xor(ss[q], m, 64);
+            const float scale = co < d.Cout ? d.g[co] / __builtin_sqrtf(ss[0] + ss[1] + ss[2] + ss[3]) : 0.f;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int i = 64 * q + lane;
+                if (i < nn) srow[i] = f2bf(x[rr][q] * scale);
+            }
+            if (lane == 0 && (which & 1) && co < d.Cout) d.bp[co] = d.bias ? d.bias[co] : 0.f;
+        }
+    } else {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * w + rr, co = co0 + r;
+        bf16_t *srow = s_prep + (size_t)r * nn;
+        if (co >= d.Cout) {                                  // (wave-uniform) rows past the conv: zeros
+            for (int i = lane; i < nn; i += 64) srow[i] = 0;
+            continue;
+        }
+        const float *vr = d.v + (size_t)co * nn;
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < nn; i0 += 256) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 64 * q + lane;
+                const float x = i < nn ? vr[i] : 0.f;
+                ss[q] = __builtin_fmaf(x, x, ss[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int m = 32; m >= 1; m >>= 1) ss[q] += __shfl_xor(ss[q], m, 64);
+        const float scale = d.g[co] / __builtin_sqrtf(ss[0] + ss[1] + ss[2] + ss[3]);
+        for (int i = lane; i < nn; i += 64) srow[i] = f2bf(vr[i] * scale);        // (second read: L1 / L2)
+        if (lane == 0 && (which & 1)) d.bp[co] = d.bias ? d.bias[co] : 0.f;
     }
-    if (threadIdx.x == 0) d.bp[co] = d.bias ? d.bias[co] : 0.f;
+    }
+    __syncthreads();
+    const int k = d.k, Ca8 = d.Ca >> 3;
+    // ---- forward pack: piece (j, row r, ci octet o) = wf[pack_index(j, co0 + r, 8 o)] .. + 8 ------------------------------------------------
+    if (which & 1)
+    for (int q = tid; q < k * Ca8 * PREP_ROWS; q += 256) {
+        const int r = q & (PREP_ROWS - 1), rest = q >> 3;
+        const int o = rest % Ca8, j = rest / Ca8;
+        const bf16_t *srow = s_prep + (size_t)r * nn + j;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 8 * o + e;
+            v[e] = ci < d.Cin ? (short)srow[ci * k] : (short)0;
+        }
+        *reinterpret_cast<bf16x8 *>(d.wf + pack_index(k, j, co0 + r, 8 * o, d.Cb, d.Ca)) = v;
+    }
+    // ---- backward pack: piece (j, ci) = wb[pack_index(j, ci, co0)] .. + 8: the eight rows of one (ci, j) ------------------------------------
+    if (which & 2)
+    for (int q = tid; q < k * d.Cin; q += 256) {
+        const int ci = q % d.Cin, j = q / d.Cin;
+        const bf16_t *sp = s_prep + ci * k + j;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (short)sp[(size_t)e * nn];
+        *reinterpret_cast<bf16x8 *>(d.wb + pack_index(k, j, ci, co0, d.Ca, d.Cb)) = v;
+    }
 }
 
 // ---- weight-norm backward: from gw[j][co][ci] (fp32) to g_v (Cout,Cin,k) and g_g (Cout) ------------------
@@ -1934,10 +2014,16 @@ extern "C" int psnd_conv1d_prep(const float *v, const float *g, const float *bia
     return PSND_OK;
 }
 
-extern "C" int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream) {
-    if (!descs_dev || n <= 0 || total_blocks <= 0) PSND_FAIL(PSND_E_ARG, "conv1d_prep_multi: bad arguments");
-    hipLaunchKernelGGL(conv_prep_multi_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const PrepDesc *>(descs_dev), n);
+extern "C" int psnd_conv1d_prep_multi(const void *descs_dev, int n, int total_blocks, int max_row, int which, void *stream) {
+    if (!descs_dev || n <= 0 || total_blocks <= 0 || max_row <= 0 || which < 1 || which > 3) PSND_FAIL(PSND_E_ARG, "conv1d_prep_multi: bad arguments");
+    const size_t lds = (size_t)PREP_ROWS * (size_t)max_row * sizeof(bf16_t);
+    if (lds > 160 * 1024) PSND_FAIL(PSND_E_SHAPE, "conv1d_prep_multi: Cin * k = %d too large for the 8-row tile (use psnd_conv1d_prep)", max_row);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_prep_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "conv1d_prep_multi: set LDS size: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(conv_prep_multi_kernel, dim3(total_blocks), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const PrepDesc *>(descs_dev), n, which);
     PSND_CHECK_LAUNCH("conv1d_prep_multi");
     return PSND_OK;
 }

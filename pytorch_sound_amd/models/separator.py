@@ -45,7 +45,7 @@ class ConvSeparator(nn.Module):
         halo = max(c.padding for b in self.blocks for c in list(b.convs1) + list(b.convs2))
         shape = cl.CLShape(N, T, max(halo, self.conv_pre.padding, self.conv_post.padding))
         convs = [self.conv_pre] + [c for b in self.blocks for c in list(b.convs1) + list(b.convs2)] + [self.conv_post]
-        prep = cl.prep_all(self, convs)
+        prep = cl.prep_all(self, convs, defer_backward_packs=True)                 # backward packs: written when the backward starts
         x0 = cl.to_cl_nfk(mag.float(), shape, 1) if layout == 'nfk' else cl.ToCL.apply(mag.float(), shape, 1)
         return cl.conv_body_cl(self.conv_pre, list(self.blocks), self.conv_post, x0, shape, prep), shape
 
@@ -75,7 +75,7 @@ class ConvSeparator(nn.Module):
         halo = max(c.padding for b in self.blocks for c in list(b.convs1) + list(b.convs2))
         shape = cl.CLShape(N, T, max(halo, self.conv_pre.padding, self.conv_post.padding))
         convs = [self.conv_pre] + [c for b in self.blocks for c in list(b.convs1) + list(b.convs2)] + [self.conv_post]
-        prep = cl.prep_all(self, convs)                                            # all weight-norm packs: one launch
+        prep = cl.prep_all(self, convs, defer_backward_packs=True)                 # all weight-norm packs: one launch (+ one when the backward starts)
         x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
         y = cl.conv_body_cl(self.conv_pre, list(self.blocks), self.conv_post, x0, shape, prep)     # 26 convs: one autograd node
         if mag.dtype == torch.float32 and not mag.requires_grad:

@@ -511,3 +511,48 @@ def test_nan_flag_kernel():
         flag = torch.full((), 5.0, device=dev)
         check(lib().psnd_nan_flag(ptr(x), x.numel(), ptr(flag), stream_ptr(dev)), 'psnd_nan_flag')
         assert float(flag) == want
+
+
+def test_prep_all_packs_bit_identical_to_single_prep():
+    """psnd_conv1d_prep_multi (round 4: one workgroup per 8 output channels, 16-byte pieces) writes the packs psnd_conv1d_prep writes,
+    bit for bit - weight norm (hifi_gan.py:32-69 `weight_norm(Conv1d(...))`), forward [j][co][ci] and backward [j][ci][co] fragment
+    order, padded bias - for channel counts that are / are not multiples of 8 and 32, long rows, one output channel."""
+    from pytorch_sound_amd import cl
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    from pytorch_sound_amd.models.vocoders.hifi_gan import WNConv1d
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    shapes = [(513, 256, 3), (256, 256, 3), (256, 513, 3), (80, 512, 7), (32, 1, 7), (64, 40, 7), (96, 64, 11), (33, 9, 5), (512, 256, 16)]
+    convs = []
+    for Cin, Cout, k in shapes:
+        c = WNConv1d(Cin, Cout, k, 1, (k - 1) // 2, init_std=0.05).to(dev)
+        with torch.no_grad():
+            c.weight_g.mul_(1.0 + 0.3 * torch.rand_like(c.weight_g))
+            if c.bias is not None:
+                c.bias.normal_()
+        convs.append(c)
+    owner = torch.nn.Module()
+    packs = cl.prep_all(owner, convs)
+    assert packs is not None
+    for c in convs:
+        Cout, Cin, k = c.weight_v.shape
+        Ca, Cb = cl.round_up(Cin, cl.ALIGN_C), cl.round_up(Cout, cl.ALIGN_C)
+        wf = torch.zeros((k, Cb, Ca), dtype=torch.bfloat16, device=dev)
+        wb = torch.zeros((k, Ca, Cb), dtype=torch.bfloat16, device=dev)
+        bp = torch.zeros(Cb, dtype=torch.float32, device=dev)
+        check(lib().psnd_conv1d_prep(ptr(c.weight_v), ptr(c.weight_g), ptr(c.bias), Cout, Cin, k, Cb, Ca, ptr(wf), ptr(wb), ptr(bp),
+                                     stream_ptr(dev)), 'psnd_conv1d_prep')
+        mf, mb, mp = packs[id(c)]
+        assert torch.equal(mf.view(torch.int16), wf.view(torch.int16)), (Cin, Cout, k)
+        assert torch.equal(mb.view(torch.int16), wb.view(torch.int16)), (Cin, Cout, k)
+        assert torch.equal(mp, bp)
+        # and the values: w = g v / ||v|| in float64, rounded to bf16 once
+        v = c.weight_v.detach().double()
+        w = (c.weight_g.detach().double().view(-1, 1, 1) * v / v.flatten(1).norm(dim=1).view(-1, 1, 1)).float()
+        # un-pack the forward pack through the kernel's own index map: compare a few hundred random elements
+        g = torch.Generator().manual_seed(1)
+        for _ in range(200):
+            co, ci, j = int(torch.randint(Cout, (1,), generator=g)), int(torch.randint(Cin, (1,), generator=g)), int(torch.randint(k, (1,), generator=g))
+            idx = ((((j * (Cb >> 5) + (co >> 5)) * (Ca >> 4) + (ci >> 4)) * 64 + (((ci & 15) >> 3) << 5) + (co & 31)) * 8 + (ci & 7))
+            got = float(mf.flatten()[idx])
+            assert abs(got - float(w[co, ci, j])) <= 2 ** -8 * abs(float(w[co, ci, j])) + 1e-30
