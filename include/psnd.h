@@ -253,7 +253,8 @@ int psnd_mel_l1_bwd_nfk(const float *ref, const float *mel_lin, const float *g, 
  *      w1 * F.l1_loss(est, mag_ref) + w2 * F.l1_loss(log_mel(est), mel_ref),  est = sigmoid(from_cl(y)) * mag
  *  psnd_mask_head_l1_fwd : psnd_mask_head_fwd + part[b] = sum |est - ref| of workgroup b (psnd_mask_head_l1_blocks doubles)
  *  psnd_mel_l1_fwd       : psnd_mel_fwd that writes only the linear mel + part[w] = sum |log_mel - ref| of wave w (psnd_mel_l1_blocks)
- *  psnd_l1_loss_combine  : out[0] = sum_i scale[i] * sum(parts[i]), scale = weight / numel (host arrays of <= 4 device pointers)
+ *  psnd_l1_loss_combine  : out[0] = sum_i scale[i] * sum(parts[i]), scale = weight / numel (host arrays of <= 4 device pointers);
+ *                          nan_flag (may be NULL): nan_flag[0] = 1 if that loss is NaN, else 0 (the trainer's `loss != loss`, trainer.py:205)
  *  psnd_mel_l1_bwd       : gmag = W^T (coef * g[0] * sign(log_mel - ref) * dlog) with the sign formed on operand load (g: device scalar)
  *  psnd_mask_head_l1_bwd : psnd_mask_head_bwd on gest (may be NULL) + coef * g[0] * sign(est - ref)                              */
 int64_t psnd_mask_head_l1_blocks(int64_t N, int64_t T, int Cp);
@@ -269,7 +270,7 @@ int psnd_mel_l1_bwd(const float *ref, const float *mel_lin, const float *g, floa
                     float *gmag, void *stream);
 /* flag[0] = 1.0 if any of x[0 .. n) is NaN, else 0.0 - the device-side form of the trainer's `loss != loss` (trainer.py:205) */
 int psnd_nan_flag(const float *x, int64_t n, float *flag, void *stream);
-int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream);
+int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, float *nan_flag, void *stream);
 int psnd_conv_stats(int64_t *out4, int reset);
 /* the same for the residual-pair launches: out4 = { psnd_conv1d_cl_pair launches with 32-row tiles, with 64-row tiles,
  * psnd_conv1d_cl_pair_bwd launches that carried a pair, weight-gradient row ranges of the last psnd_conv1d_cl_pair_bwd launch }. */

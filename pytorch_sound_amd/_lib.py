@@ -80,7 +80,7 @@ SIGNATURES = {
     'psnd_mel_l1_blocks': (_I64, [_I64, _I64, _INT]),
     'psnd_mel_l1_fwd': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P, _P, _P]),
     'psnd_mel_l1_bwd': (_INT, [_P, _P, _P, _F, _I64, _I64, _INT, _INT, _P, _INT, _F, _F, _F, _F, _P, _P]),
-    'psnd_l1_loss_combine': (_INT, [_P, _P, _P, _INT, _P, _P]),
+    'psnd_l1_loss_combine': (_INT, [_P, _P, _P, _INT, _P, _P, _P]),
     'psnd_conv_stats': (_INT, [_P, _INT]),
     'psnd_conv_pair_stats': (_INT, [_P, _INT]),
     'psnd_convtr1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),

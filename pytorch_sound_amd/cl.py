@@ -126,6 +126,11 @@ class MaskHeadCL(torch.autograd.Function):
         return gy, None, None
 
 
+# the NaN flag (`loss != loss`, trainer.py:205) of the fused loss nodes below: written by the launch that forms the loss; the caller that receives
+# the loss tensor attaches it as `loss.psnd_nan_flag`, which Trainer._nan_flag takes instead of a launch of its own
+LAST_LOSS_NAN_FLAG = [None]
+
+
 class MaskHeadSpectralL1CL(torch.autograd.Function):
     """w1 * F.l1_loss(est, mag_ref) + w2 * F.l1_loss(log_mel(est), mel_ref) with est = sigmoid(from_cl(y)) * mag - a masking recipe's
     loss as ONE autograd node over four launches forward (mask head with the first term's partial sums, mel projection with the second
@@ -164,7 +169,9 @@ class MaskHeadSpectralL1CL(torch.autograd.Function):
             parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
             nbs = (ctypes.c_int64 * 2)(nb1, nb2)
             sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
-            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), st), 'psnd_l1_loss_combine')
+            nan_flag = torch.empty((), dtype=torch.float32, device=dev)
+            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), ptr(nan_flag), st), 'psnd_l1_loss_combine')
+        LAST_LOSS_NAN_FLAG[0] = nan_flag
         ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())
         ctx.save_for_backward(y, mag, mag_ref, mel_ref, mel_plan, est, lin)
         ctx.mark_non_differentiable(est)
@@ -240,7 +247,9 @@ class MaskHeadSpectralL1NFK(torch.autograd.Function):
             parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
             nbs = (ctypes.c_int64 * 2)(nb1, nb2)
             sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
-            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), st), 'psnd_l1_loss_combine')
+            nan_flag = torch.empty((), dtype=torch.float32, device=dev)
+            check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), ptr(nan_flag), st), 'psnd_l1_loss_combine')
+        LAST_LOSS_NAN_FLAG[0] = nan_flag
         ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())
         ctx.save_for_backward(y, mag, mag_ref, mel_ref, mel_plan, est, lin)
         ctx.mark_non_differentiable(est)

@@ -190,7 +190,7 @@ struct L1Terms {
 };
 // one workgroup of 1024 threads, four partials per thread in flight (256 threads walking 3264 + 480 partials one load at a time were
 // fifteen dependent L2 round trips: 6.4 us for a kernel that adds 30 KB)
-__global__ __launch_bounds__(1024) void l1_final_multi_kernel(L1Terms t, float *out) {
+__global__ __launch_bounds__(1024) void l1_final_multi_kernel(L1Terms t, float *out, float *nan_flag) {
     double s = 0;
     for (int k = 0; k < t.terms; ++k) {
         double sk = 0;
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(1024) void l1_final_multi_kernel(L1Terms t, float *
         double a = 0;
         for (int w = 0; w < 16; ++w) a += red[w];
         out[0] = (float)a;
+        if (nan_flag) nan_flag[0] = a != a ? 1.f : 0.f;       // Trainer's `loss != loss` (trainer.py:205), formed where the loss is
     }
 }
 // ga = g * sign(a - b) / n,  gb = -ga   (either may be NULL); g: device scalar
@@ -427,7 +428,7 @@ extern "C" int psnd_nan_flag(const float *x, int64_t n, float *flag, void *strea
 
 // out[0] = sum_i scale[i] * sum(parts[i][0 .. nb[i])): folds the partial sums that fused producers leave (psnd_mask_head_l1_fwd,
 // psnd_mel_l1_fwd, psnd_l1_loss_fwd's own partials) into one loss value; scale[i] = weight_i / numel_i; 1 .. 4 terms
-extern "C" int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, void *stream) {
+extern "C" int psnd_l1_loss_combine(const double *const *parts, const int64_t *nb, const double *scale, int terms, float *out, float *nan_flag, void *stream) {
     if (!parts || !nb || !scale || !out) PSND_FAIL(PSND_E_ARG, "l1_loss_combine: null pointer");
     if (terms < 1 || terms > 4) PSND_FAIL(PSND_E_SHAPE, "l1_loss_combine: 1 .. 4 terms, got %d", terms);
     L1Terms t;
@@ -436,7 +437,7 @@ extern "C" int psnd_l1_loss_combine(const double *const *parts, const int64_t *n
         if (!parts[k] || nb[k] <= 0 || nb[k] > 0x7fffffff) PSND_FAIL(PSND_E_ARG, "l1_loss_combine: term %d: null partials / nb=%lld", k, (long long)nb[k]);
         t.part[k] = parts[k], t.nb[k] = (int)nb[k], t.scale[k] = scale[k];
     }
-    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, out);
+    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), t, out, nan_flag);
     PSND_CHECK_LAUNCH("l1_loss_combine");
     return PSND_OK;
 }
@@ -458,7 +459,7 @@ extern "C" int psnd_l1_loss_sum_fwd(const float *const *a, const float *const *b
         t.part[k] = pp, t.nb[k] = nb, t.scale[k] = w[k] / (double)n[k];
         pp += nb;
     }
-    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(1024), 0, s, t, out);
+    hipLaunchKernelGGL(l1_final_multi_kernel, dim3(1), dim3(1024), 0, s, t, out, static_cast<float *>(nullptr));
     PSND_CHECK_LAUNCH("l1_loss_sum_fwd");
     return PSND_OK;
 }

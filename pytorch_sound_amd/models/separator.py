@@ -61,11 +61,15 @@ class ConvSeparator(nn.Module):
             raise RuntimeError('spectral_l1_loss is the fused HIP formulation; on the host compose the loss from forward()')
         if layout == 'nfk':
             y, shape = self.logits_cl(mag, 'nfk')
-            return cl.MaskHeadSpectralL1NFK.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
-                                                  mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
+            loss, est = cl.MaskHeadSpectralL1NFK.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
+                                                       mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
+            loss.psnd_nan_flag = cl.LAST_LOSS_NAN_FLAG[0]          # isnan(loss), written by the launch that formed the loss
+            return loss, est
         y, shape = self.logits_cl(mag)
-        return cl.MaskHeadSpectralL1CL.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
-                                             mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
+        loss, est = cl.MaskHeadSpectralL1CL.apply(y, mag.float().contiguous(), mag_ref.float().contiguous(), mel_ref.float().contiguous(),
+                                                  mel_plan, shape, n_mels, K.LOG_E, log_offset, None, clamp_lo, clamp_hi, w_mag, w_mel)
+        loss.psnd_nan_flag = cl.LAST_LOSS_NAN_FLAG[0]
+        return loss, est
 
     def forward_cl(self, mag: torch.Tensor) -> torch.Tensor:
         """the same function on the gfx950 implicit-GEMM conv kernel (channels-last bf16, fp32 accumulate):

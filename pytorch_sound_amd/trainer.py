@@ -382,6 +382,9 @@ class Trainer:
     def _nan_flag(loss: torch.Tensor) -> torch.Tensor:
         """fp32 scalar on the loss's device: 1 if the loss is NaN (`loss != loss`, trainer.py:205) - one launch (psnd_nan_flag) for an
         fp32 loss on the GPU, torch.isnan + cast otherwise"""
+        ready = getattr(loss, 'psnd_nan_flag', None)       # a fused loss node formed the flag in the launch that formed the loss
+        if ready is not None and ready.device == loss.device and ready.dtype == torch.float32 and ready.dim() == 0:
+            return ready
         x = loss.detach()
         if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
             from ._lib import lib, ptr, stream_ptr, check
