@@ -313,6 +313,7 @@ def gpu_bench(args):
         h2d[mode] = {'value': world * N * CLIP_SECONDS * args.steps / d, 'ms_per_step': d / args.steps * 1e3}
     tr.prefetch_prepare, tr.prefetch_copy = args.prefetch, False
     tr.overlap_prepare = ovl_keep
+    h2d['default'] = 'prefetch_copy (Trainer.prefetch_copy = None: on when the batches arrive in pinned host memory)'
     h2d['unit'] = 'audio-s/s'
     h2d['bytes_per_step'] = 2 * N * T * 4
     h2d['note'] = ('batches in pinned host memory, %d steps: "prefetch_copy" = the copy of the next batch on a side stream while the '

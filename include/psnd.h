@@ -44,6 +44,9 @@ extern "C" {
 
 int psnd_version(void);
 const char *psnd_last_error(void);
+/* the PSND_* A/B switches of the dispatchers are read from the environment once per call site; a process that changes its
+ * environment afterwards (parity tests flipping kernel instances) calls this to have them looked up again */
+void psnd_env_refresh(void);
 
 /* ---- stream events: release points inside a captured step graph (data-parallel training) ------------------------
  * psnd_event_record_external on a CAPTURING stream adds an external event-record node (hipEventRecordExternal): after the

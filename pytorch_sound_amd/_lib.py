@@ -24,6 +24,7 @@ _D = _c.c_double
 SIGNATURES = {
     'psnd_version': (_INT, []),
     'psnd_last_error': (_c.c_char_p, []),
+    'psnd_env_refresh': (None, []),
     'psnd_event_create': (_P, []),
     'psnd_event_destroy': (_INT, [_P]),
     'psnd_event_record_external': (_INT, [_P, _P]),

@@ -25,6 +25,36 @@ void psnd_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------
+// A/B switches (host).  The PSND_* environment switches of the dispatchers (kernel-instance choices for parity tests and same-box
+// A/B timings) are looked up ONCE per call site and kept; a launch costs one atomic load per switch, not a getenv().  A process that
+// changes its environment afterwards calls psnd_env_refresh() (tests/conftest.py does, around monkeypatch.setenv).
+// ---------------------------------------------------------------------------------------
+#include <atomic>
+#include <stdlib.h>
+extern std::atomic<int> g_psnd_env_gen;
+struct PsndEnvSlot {
+    std::atomic<int> gen{-1};
+    const char *val = nullptr;
+};
+inline const char *psnd_env_lookup(PsndEnvSlot &c, const char *name) {
+    const int g = g_psnd_env_gen.load(std::memory_order_acquire);
+    if (c.gen.load(std::memory_order_acquire) != g) {
+        c.val = getenv(name);
+        c.gen.store(g, std::memory_order_release);
+    }
+    return c.val;
+}
+#define PSND_ENV(name_) ([]() -> const char * { static PsndEnvSlot slot_; return psnd_env_lookup(slot_, name_); }())
+// integer switch clamped to [lo, hi]; `dflt` when unset or unparsable
+inline int psnd_env_int(const char *v, int dflt, int lo, int hi) {
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    const long x = strtol(v, &end, 10);
+    if (end == v) return dflt;
+    return x < lo ? lo : (x > hi ? hi : (int)x);
+}
+
+// ---------------------------------------------------------------------------------------
 // compile-time loops
 // ---------------------------------------------------------------------------------------
 template <int B, int E, class F>

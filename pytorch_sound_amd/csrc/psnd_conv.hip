@@ -1474,10 +1474,10 @@ extern "C" int psnd_conv_stats(int64_t *out4, int reset) {
 // (Before: 128 rows from 1024 tiles of 64 on - config 2's 256 -> 513 conv ran 828 workgroups of 64 rows in two rounds, HiFi-GAN's
 // 64- / 128-channel stages 519 / 526 of 128 rows.)
 static int conv_row_tiles(int64_t R, int Cb, bool with3 = false) {
-    const char *fe = getenv("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
+    const char *fe = PSND_ENV("PSND_CONV_MT");              // read per call: the parity tests flip it inside one process
     const int force = fe ? atoi(fe) : 0;
     if (force == 1 || force == 2) return force;
-    if (getenv("PSND_CONV_MT_V1")) return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;   // A/B: the rule of before
+    if (PSND_ENV("PSND_CONV_MT_V1")) return ((R + 63) / 64) * ((Cb + BN - 1) / BN) >= 1024 ? 2 : 1;   // A/B: the rule of before
     const int64_t coltiles = (Cb + BN - 1) / BN;
     int best = 1;
     int64_t best_cost = 0;
@@ -1495,14 +1495,14 @@ static int conv_launch(ConvParams &p, hipStream_t st, const char *what) {
     const int k = p.k, Cb = p.Cb, hm = p.hm;
     if (hm > 40 || (hm > 25 && k > 7)) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: tap reach %d beyond the staged A tile (25; 40 for k <= 7)", what, hm);
     // 192-row tiles exist for the plain instances (no combined operand, reach <= 25, not the transposed conv); PSND_CONV_MT3=0: off
-    const char *e3 = getenv("PSND_CONV_MT3");
+    const char *e3 = PSND_ENV("PSND_CONV_MT3");
     const bool can3 = !combine && p.up_role == 0 && hm <= 25 && Cb > 32 && !(e3 && atoi(e3) == 0);
     int mt = conv_row_tiles(p.R, Cb, can3);
     const bool mt3 = mt == 3;
     if (mt3) mt = 2;
     // narrow layers over long clips (HiFi-GAN's last stage: 32 channels x 131 k rows): 256-row tiles, the four waves along the rows
     // (not with the combined operand: three A rings of 5 pieces per stage spill ~100 VGPRs at 256-row tiles)
-    const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !combine && !getenv("PSND_CONV_NO_NARROW");
+    const bool narrow = Cb <= 32 && mt == 2 && p.up_role == 0 && hm <= 25 && !combine && !PSND_ENV("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : (mt3 ? 192 : 64 * mt), bn = narrow ? 32 : BN;
     const int kct = 32;
     size_t lds = 2 * sizeof(bf16_t) * (kct + 8) * (size_t)(bm + 2 * hm);             // two A stage buffers (the weights never enter LDS)
@@ -1589,7 +1589,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
     p.act_slope = act_slope, p.mask_slope = mask_slope;
 #ifdef PSND_TRACE
     {
-        const char *tp = getenv("PSND_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
@@ -1693,9 +1693,9 @@ static int wgrad_splits(int64_t R, int Ca, int Cb, int k, int64_t *rps_out) {
     // 4.10 (384), 4.08 (512), 4.10 (640)
     if (narrow_w) {
         target = 192;
-        if (const char *e = getenv("PSND_WGRAD_BLOCKS_NARROW")) target = atoi(e);
+        if (const char *e = PSND_ENV("PSND_WGRAD_BLOCKS_NARROW")) target = psnd_env_int(e, target, 1, 65535);
     }
-    if (const char *e = getenv("PSND_WGRAD_BLOCKS")) target = atoi(e);
+    if (const char *e = PSND_ENV("PSND_WGRAD_BLOCKS")) target = psnd_env_int(e, target, 1, 65535);
     int64_t splits = target / ((int64_t)tx * ty);
     if (splits < 1) splits = 1;
     int64_t rps = (R + splits - 1) / splits;
@@ -1731,7 +1731,7 @@ extern "C" int psnd_conv1d_cl_wgrad(const void *G1, const void *G2, const void *
     p.rows_per_split = (int)rps;
 #ifdef PSND_TRACE
     {
-        const char *tp = getenv("PSND_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
@@ -1750,7 +1750,7 @@ static int wgrad_multi_splits(int64_t R, int Ca, int Cb, int k, int n, int64_t *
     // 24 convs x 16 tiles at the config-2 size, launch alone (tools/perf_wgrad_multi.py): 1 row range per conv (384 workgroups of 184
     // chunks) 106 us, 2 -> 81 us, 3 -> 100, 4 -> 90, 6 -> 100, 8 -> 108 (and the slabs the weight-norm backward has to add up grow with it)
     int64_t target = 768;
-    if (const char *e = getenv("PSND_WGRAD_MULTI_BLOCKS")) target = atoi(e);
+    if (const char *e = PSND_ENV("PSND_WGRAD_MULTI_BLOCKS")) target = psnd_env_int(e, target, 1, 65535);
     int64_t splits = target / ((int64_t)tiles * (n > 0 ? n : 1));
     if (splits < 1) splits = 1;
     int64_t rps = (R + splits - 1) / splits;
@@ -1812,7 +1812,7 @@ static int pair_bwd_splits(int64_t R, int C, int k, int64_t *rps_out) {
     // per weight-gradient role (two of them run next to ~200-270 pair workgroups); config-2 step: 112 -> 0.816 ms, 96 -> 0.819, 128 -> 0.838,
     // 80 -> 0.841, 144 -> 0.846, 160 -> 0.855, 64 -> 0.866, 192 -> 0.868, 48 -> 0.940
     int64_t target = 112;
-    if (const char *e = getenv("PSND_PAIRBWD_BLOCKS")) target = atoi(e);
+    if (const char *e = PSND_ENV("PSND_PAIRBWD_BLOCKS")) target = psnd_env_int(e, target, 1, 65535);
     int64_t splits = target / tiles;
     if (splits < 1) splits = 1;
     int64_t rps = (R + splits - 1) / splits;
@@ -1891,7 +1891,7 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
                                   int64_t N, int Lp, int L, int HP, int Ca, int Cb, int k, int pad, int dil, void *gx, void *g_out,
                                   const void *gx_mask, float gx_mask_slope, const void *gx_res, float *gw_part, float *gbias_part,
                                   void *stream) {
-    static const bool no_pair = getenv("PSND_NO_BWD_PAIR") != nullptr;
+    static const bool no_pair = PSND_ENV("PSND_NO_BWD_PAIR") != nullptr;
     if (gw_part && (k < WKT ? k - 1 : WKT - 1) * (dil < 0 ? -dil : dil) > WXR - 32)
         PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_bwd: dilation %d: a tap group spans more than %d rows", dil, WXR - 32);
     int hm = 0;
@@ -1935,19 +1935,19 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     int64_t rps;
     const int splits = wgrad_splits(pw.R, Ca, Cb, k, &rps);
     pw.rows_per_split = (int)rps;
-    const char *pe = getenv("PSND_PAIR_MT");
+    const char *pe = PSND_ENV("PSND_PAIR_MT");
     const int pair_mt = pe ? atoi(pe) : 0;
     // 128-row input-gradient tiles at every size: half as many workgroups of that role share the CUs with the weight-gradient role
     // (config-2 launch 17.4 -> 15.5 us with 192 weight-gradient workgroups; no change for the long HiFi-GAN stages, which took them anyway)
     const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : 2;
     // narrow input gradient over long clips (Ca <= 32): 256-row tiles, the four waves along the rows (conv_cl_body, WNC = 1)
-    const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && !G2 && (pc.R + 63) / 64 >= 1024 && !getenv("PSND_CONV_NO_NARROW");
+    const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && !G2 && (pc.R + 63) / 64 >= 1024 && !PSND_ENV("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
     const int cgx = (int)((pc.R + bm - 1) / bm), cgy = (Ca + bn - 1) / bn;
     // 32 -> 32 channels over long clips: the weight-gradient role spreads 12 taps over the four waves (their span must fit its tile);
     // without the combined operand the input-gradient role is the single-stage instance at three workgroups per CU
     const bool wn = Ca <= 32 && Cb <= 32 && (pc.R + 63) / 64 >= 1024 && hm <= 25 && gw_part &&
-                    ((k < 4 * WKT ? k : 4 * WKT) - 1) * (dil < 0 ? -dil : dil) <= WXRN - 32 && !getenv("PSND_CONV_NO_NARROW");
+                    ((k < 4 * WKT ? k : 4 * WKT) - 1) * (dil < 0 ? -dil : dil) <= WXRN - 32 && !PSND_ENV("PSND_CONV_NO_NARROW");
     const bool narrow1 = narrow && Cb <= 32;
     // taps per weight-gradient workgroup: as the instance picked below (KT by k, HMX by the reach)
     const int wk = wn ? 4 * WKT : (narrow1 ? WKT : pair_wk(k <= 3 ? 3 : (k <= 7 ? 7 : (k <= 11 ? 11 : 16)), hm > 25 ? 40 : 25));

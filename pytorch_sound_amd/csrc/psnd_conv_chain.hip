@@ -429,7 +429,7 @@ extern "C" int psnd_conv1d_cl_chain_plan(int C, int k, int n_pairs, const int *t
     // are therefore only taken on request (a launch pays ~6 us beside its workgroups' lifetime, whatever the tile)
     (void)R;
     int mr = 2;
-    if (const char *e = getenv("PSND_CHAIN_MR")) {
+    if (const char *e = PSND_ENV("PSND_CHAIN_MR")) {
         const int f = atoi(e);
         if (f == 2 || (f == 1 && ts1 >= 8)) mr = f;
     }
@@ -471,10 +471,13 @@ extern "C" int psnd_conv1d_cl_chain(const void *A, const void *res, const psnd_c
         d.off1 = s.off1, d.dstep1 = s.dstep1, d.off2 = s.off2, d.dstep2 = s.dstep2, d.act1_slope = s.act1_slope, d.act2_slope = s.act2_slope;
         d.M1 = static_cast<const bf16_t *>(s.M1), d.M2 = static_cast<const bf16_t *>(s.M2), d.m1_slope = s.m1_slope, d.m2_slope = s.m2_slope;
     }
+    p.trace = nullptr;
+#ifdef PSND_TRACE      // tools/trace_chain.py builds: a device pointer the kernel writes s_memtime stamps to - never in the product build
     {
-        const char *tp = getenv("PSND_PAIR_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_PAIR_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
+#endif
     const int64_t tiles = (p.R + ts - 1) / ts;
     constexpr int RS = 256 + 8;
     // forward: act + mid tiles with rims and the raw tile; input-gradient form: the two tiles and two 2 KB bit tiles of the masks

@@ -56,14 +56,17 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP;
     p.off1 = off1, p.dstep1 = dstep1, p.h1 = reach3(off1, dstep1), p.off2 = off2, p.dstep2 = dstep2, p.h2 = reach3(off2, dstep2);
     p.m1_slope = m1_slope, p.m2_slope = m2_slope, p.act1_slope = act1_slope, p.act2_slope = act2_slope;
+    p.trace = nullptr;
+#ifdef PSND_TRACE      // tools/trace_pair.py builds only
     {
-        const char *tp = getenv("PSND_PAIR_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_PAIR_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
+#endif
     // 64-row tiles when they fill the chip; at the config-2 size (95 of them) 32-row tiles: twice the CUs share the stores
     int MR = 2;
     if (C == 256 && (p.R + (64 - 2 * p.h2) - 1) / (64 - 2 * p.h2) < 256 && 32 - 2 * p.h2 >= 16) MR = 1;
-    if (const char *e = getenv("PSND_PAIR_MR")) MR = (atoi(e) == 1 && C == 256 && 32 - 2 * p.h2 >= 8) ? 1 : 2;
+    if (const char *e = PSND_ENV("PSND_PAIR_MR")) MR = (atoi(e) == 1 && C == 256 && 32 - 2 * p.h2 >= 8) ? 1 : 2;
     const int MROWS = 32 * MR, TS = MROWS - 2 * p.h2;
     const int64_t tiles = (p.R + TS - 1) / TS;
     const int RS = C + 8;

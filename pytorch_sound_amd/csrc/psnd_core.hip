@@ -14,6 +14,9 @@ extern "C" int psnd_version(void) { return 131; }  // 0.1.31: psnd_mha_fwd / _bw
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
+std::atomic<int> g_psnd_env_gen{0};
+extern "C" void psnd_env_refresh(void) { g_psnd_env_gen.fetch_add(1, std::memory_order_acq_rel); }
+
 static inline int64_t pad_of(int n_fft, int hop, int framing) {
     if (framing == PSND_FRAMING_NONE) return 0;
     return framing == PSND_FRAMING_CENTER ? n_fft / 2 : (n_fft - hop) / 2;

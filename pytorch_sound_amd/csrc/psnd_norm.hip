@@ -430,7 +430,7 @@ extern "C" int psnd_softmax_keys_fwd(float *scores, const uint8_t *mask, int64_t
     if (!scores) PSND_FAIL(PSND_E_ARG, "softmax_keys_fwd: null pointer");
     if (B < 0 || T <= 0 || B > 65535) PSND_FAIL(PSND_E_SHAPE, "softmax_keys_fwd: B=%lld T=%lld", (long long)B, (long long)T);
     if (B == 0) return PSND_OK;
-    const bool v4 = T % 4 == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0 && getenv("PSND_SOFTMAX_SCALAR") == nullptr;
+    const bool v4 = T % 4 == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0 && PSND_ENV("PSND_SOFTMAX_SCALAR") == nullptr;
     hipLaunchKernelGGL(v4 ? softmax_keys_fwd4_kernel : softmax_keys_fwd_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), scores, mask, (long long)T, scale);
     PSND_CHECK_LAUNCH("softmax_keys_fwd");
@@ -443,7 +443,7 @@ extern "C" int psnd_softmax_keys_bwd(const float *att, const float *gatt, int64_
     if (B < 0 || T <= 0 || B > 65535) PSND_FAIL(PSND_E_SHAPE, "softmax_keys_bwd: bad shape");
     if (B == 0) return PSND_OK;
     const bool v4 = T % 4 == 0 && ((reinterpret_cast<uintptr_t>(att) | reinterpret_cast<uintptr_t>(gatt) | reinterpret_cast<uintptr_t>(gscores)) & 15) == 0 &&
-                    getenv("PSND_SOFTMAX_SCALAR") == nullptr;
+                    PSND_ENV("PSND_SOFTMAX_SCALAR") == nullptr;
     hipLaunchKernelGGL(v4 ? softmax_keys_bwd4_kernel : softmax_keys_bwd_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0,
                        static_cast<hipStream_t>(stream), att, gatt, (long long)T, scale, gscores);
     PSND_CHECK_LAUNCH("softmax_keys_bwd");

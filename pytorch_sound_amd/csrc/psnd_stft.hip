@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p
 int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * k4096LdsFloats;
     int grid = p.total_tiles < 256 ? p.total_tiles : 256;      // one persistent workgroup per CU
-    if (const char *e = getenv("PSND_STFT4096_GRID")) grid = atoi(e);
+    if (const char *e = PSND_ENV("PSND_STFT4096_GRID")) grid = psnd_env_int(e, grid, 1, 65535);
     grid = (grid + 7) & ~7;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                     \
     do {                                                                                                            \
@@ -1045,7 +1045,7 @@ int launch_n4096(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStr
 int launch_n4096b(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * k4096bLdsFloats;
     int grid = p.total_tiles < 512 ? p.total_tiles : 512;      // two persistent workgroups per CU
-    if (const char *e = getenv("PSND_STFT4096_GRID")) grid = atoi(e);
+    if (const char *e = PSND_ENV("PSND_STFT4096_GRID")) grid = psnd_env_int(e, grid, 1, 65535);
     grid = (grid + 7) & ~7;
 #define PSND_LAUNCH(M_, P_, R_)                                                                                     \
     do {                                                                                                            \
@@ -1175,7 +1175,7 @@ int launch_span(const StftFwdParams &p, bool mag, bool phase, bool reim, hipStre
     int grid = p.total_tiles;
     int cap = 1 << 20;       // one tile per workgroup up to 1M tiles: in-order dispatch keeps neighbouring tiles
                              // concurrent (204 us vs 221 us persistent at 1024 x 2 s clips)
-    if (const char *e = getenv("PSND_STFT_GRIDCAP")) cap = atoi(e);
+    if (const char *e = PSND_ENV("PSND_STFT_GRIDCAP")) cap = psnd_env_int(e, cap, 8, 1 << 20);
     if (L == 32) cap = 1 << 30;
     if (grid > cap) grid = cap;
     grid = (grid + 7) & ~7;
@@ -1305,12 +1305,12 @@ static int stft_fwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
     p.mag = mag, p.phase = phase, p.re = re, p.im = im;
     p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps, p.nfk = nfk;
     {
-        const char *ab = getenv("PSND_ABLATE");
+        const char *ab = PSND_ENV("PSND_ABLATE");
         p.ablate = ab ? atoi(ab) : 0;
 #ifdef PSND_TRACE
-        const char *tp = getenv("PSND_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
-        const char *ti = getenv("PSND_TRACE_ITER");
+        const char *ti = PSND_ENV("PSND_TRACE_ITER");
         p.trace_iter = ti ? atoi(ti) : 0;
 #endif
     }
@@ -1318,9 +1318,9 @@ static int stft_fwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
     if (nfk) {
         // bin-fastest magnitudes: a frame's spectrum is one contiguous run.  n_fft = 1024: a wave owns four frames (psnd_stft_q.hip);
         // n_fft = 4096: one wave per frame (psnd_stft_w.hip); any other size: the one-frame-per-workgroup kernel below.
-        if (n_fft == 1024 && psnd_stft1024q_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC"))
+        if (n_fft == 1024 && psnd_stft1024q_ok(T, F, hop, pad) && !PSND_ENV("PSND_STFT_GENERIC"))
             return psnd_stft1024q_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, s);
-        if (n_fft == 4096 && psnd_stft4096w_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC"))
+        if (n_fft == 4096 && psnd_stft4096w_ok(T, F, hop, pad) && !PSND_ENV("PSND_STFT_GENERIC"))
             return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, 1, s);
         if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_mag_nfk(generic): grid too large");
         p.ntile = 0, p.total_tiles = 0;
@@ -1339,38 +1339,38 @@ static int stft_fwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
             case 256: return launch_tuned<16, 8>(p, mag, phase, re, s);
             case 512:
                 // span-staged packed kernel (32 frames per workgroup, two pass-1 rounds); odd hops take the two-pass kernel
-                if (!span_kernel_ok<16>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<16, 16>(p, mag, phase, re, s);
+                if (!span_kernel_ok<16>(hop) || PSND_ENV("PSND_STFT_V1")) return launch_tuned<16, 16>(p, mag, phase, re, s);
                 return launch_span<16>(p, mag, phase, re, s);
             case 1024: {
                 // span-staged kernel: hop multiple of 4 and the tile's span (+ bank padding) must fit the
                 // exchange area; anything else takes the generic two-pass kernel
-                if (hop % 4 != 0 || !span_kernel_ok<32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
+                if (hop % 4 != 0 || !span_kernel_ok<32>(hop) || PSND_ENV("PSND_STFT_V1")) return launch_tuned<32, 16>(p, mag, phase, re, s);
                 return launch_span<32>(p, mag, phase, re, s);
             }
             case 2048:
                 // span-staged packed kernel, 32-point second pass: 2 workgroups per CU (78.6 KB of LDS, ~200 VGPRs)
-                if (!span_kernel_ok<32, 32>(hop) || getenv("PSND_STFT_V1")) return launch_tuned<32, 32>(p, mag, phase, re, s);
+                if (!span_kernel_ok<32, 32>(hop) || PSND_ENV("PSND_STFT_V1")) return launch_tuned<32, 32>(p, mag, phase, re, s);
                 return launch_span<32, 32>(p, mag, phase, re, s);
         }
     }
-    if (n_fft == 4096 && mag && !phase && !re && psnd_stft4096w_ok(T, F, hop, pad) && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1") &&
-        !getenv("PSND_STFT4096_V2")) {
+    if (n_fft == 4096 && mag && !phase && !re && psnd_stft4096w_ok(T, F, hop, pad) && !PSND_ENV("PSND_STFT_GENERIC") && !PSND_ENV("PSND_STFT4096_V1") &&
+        !PSND_ENV("PSND_STFT4096_V2")) {
         // magnitude only (LogMelSpectrogram, the losses): one wave per frame, 16 frames per workgroup, 64-byte store runs
         // (psnd_stft_w.hip).  One workgroup per CU: it pays from ~8 tiles per CU on (32 clips x 30 s: 229 us against 245 us for the
         // 4-frame kernel below, write traffic 1.27 x instead of 1.94 x the magnitudes; 16 clips: 119 us against 94 us) - smaller
         // launches keep the 4-frame kernel with its two workgroups per CU.
         const int64_t tiles16 = N * ((F + 15) / 16);
-        if (tiles16 >= 2048 || getenv("PSND_STFT4096_W"))
+        if (tiles16 >= 2048 || PSND_ENV("PSND_STFT4096_W"))
             return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, 0, s);
     }
-    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !getenv("PSND_STFT_GENERIC") && !getenv("PSND_STFT4096_V1")) {
+    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1364 && !PSND_ENV("PSND_STFT_GENERIC") && !PSND_ENV("PSND_STFT4096_V1")) {
         // 4-frame tiles, two workgroups per CU (span <= 4 pieces per thread)
         const int64_t ntile = (F + k4096bFT - 1) / k4096bFT;
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: too many tiles");
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
         return launch_n4096b(p, mag, phase, re, s);
     }
-    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1792 && !getenv("PSND_STFT_GENERIC")) {   // span <= 8 pieces per thread
+    if (n_fft == 4096 && hop % 2 == 0 && hop <= 1792 && !PSND_ENV("PSND_STFT_GENERIC")) {   // span <= 8 pieces per thread
         const int64_t ntile = (F + k4096FT - 1) / k4096FT;
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_fwd: too many tiles");
         p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
@@ -1417,7 +1417,7 @@ static bool span_one_tile_ok(int hop) {
     return L == 32 || (span <= 5 * 1024 && span + 4 * (span / 256 + 1) <= G::WT_OFF);
 }
 static bool fwd_msl_ok(int n_fft, int hop) {
-    if (hop <= 0 || getenv("PSND_STFT_V1")) return false;
+    if (hop <= 0 || PSND_ENV("PSND_STFT_V1")) return false;
     switch (n_fft) {
         case 512: return span_one_tile_ok<16, 16>(hop);
         case 1024: return hop % 4 == 0 && span_one_tile_ok<32, 16>(hop);

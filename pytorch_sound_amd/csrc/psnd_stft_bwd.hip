@@ -1185,7 +1185,7 @@ using namespace psnd_stft;
 
 // span-staged adjoint (stft_bwd_n1024_mag_kernel): which (n_fft, hop) it takes, and its launch
 static bool span_bwd_ok(int n_fft, int hop) {
-    if (getenv("PSND_STFT_BWD_V1")) return false;
+    if (PSND_ENV("PSND_STFT_BWD_V1")) return false;
     switch (n_fft) {
         case 512: return hop % 2 == 0 && hop <= 256;
         case 1024: return hop % 4 == 0 && hop <= 256;
@@ -1258,7 +1258,7 @@ static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
     }
 #ifdef PSND_TRACE
     {
-        const char *tp = getenv("PSND_TRACE_PTR");
+        const char *tp = PSND_ENV("PSND_TRACE_PTR");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
@@ -1284,7 +1284,7 @@ static int stft_bwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
         }
     }
     if (msl) PSND_FAIL(PSND_E_UNSUPPORTED, "stft_bwd_msl: n_fft=%d hop=%d", n_fft, hop);
-    if (n_fft == 4096 && gmag && !gre && hop % 2 == 0 && hop <= 1364 && 4096 % hop == 0 && !getenv("PSND_STFT_GENERIC")) {
+    if (n_fft == 4096 && gmag && !gre && hop % 2 == 0 && hop <= 1364 && 4096 % hop == 0 && !PSND_ENV("PSND_STFT_GENERIC")) {
         // magnitude gradient at the config-5 size: the adjoint of stft_fwd_n4096b_kernel (4-frame tiles, two workgroups per CU)
         const int64_t ntile = (F + kB4096FT - 1) / kB4096FT;
         if (ntile * N >= (int64_t)1 << 31) PSND_FAIL(PSND_E_SHAPE, "stft_bwd: too many tiles");

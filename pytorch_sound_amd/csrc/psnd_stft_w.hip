@@ -480,14 +480,14 @@ int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long 
     WParams p;
     p.wav = wav, p.plan = plan, p.mag = mag, p.T = T, p.F = F, p.hop = hop, p.pad = pad, p.mag_eps = mag_eps, p.ablate = ablate;
     {
-        const char *e = getenv("PSND_STFT4096_STAGGER");
-        p.stagger = e ? atoi(e) : 0;
+        const char *e = PSND_ENV("PSND_STFT4096_STAGGER");
+        p.stagger = psnd_env_int(e, 0, 0, 64);
     }
 #ifdef PSND_W_DEBUG
     {
-        const char *e = getenv("PSND_W_DBG_PTR");
+        const char *e = PSND_ENV("PSND_W_DBG_PTR");
         p.dbg = e ? reinterpret_cast<float *>(strtoull(e, nullptr, 0)) : nullptr;
-        const char *tp = getenv("PSND_W_TRACE_PTR"), *ti = getenv("PSND_W_TRACE_ITER");
+        const char *tp = PSND_ENV("PSND_W_TRACE_PTR"), *ti = PSND_ENV("PSND_W_TRACE_ITER");
         p.trace = tp ? reinterpret_cast<long long *>(strtoull(tp, nullptr, 0)) : nullptr;
         p.trace_iter = ti ? atoi(ti) : 3;
     }
@@ -496,7 +496,7 @@ int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long 
     if (ntile * N >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "stft_fwd(n4096w): too many tiles");
     p.ntile = (int)ntile, p.total_tiles = (int)(ntile * N);
     int grid = p.total_tiles < 256 ? p.total_tiles : 256;                            // one persistent workgroup per CU
-    if (const char *e = getenv("PSND_STFT4096_GRID")) grid = atoi(e);
+    if (const char *e = PSND_ENV("PSND_STFT4096_GRID")) grid = psnd_env_int(e, grid, 1, 65535);
     grid = (grid + 7) & ~7;
     constexpr size_t lds = sizeof(float) * kLdsFloats;
     auto launch = [&](auto kern) -> int {

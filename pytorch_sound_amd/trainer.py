@@ -226,7 +226,22 @@ class Trainer:
     prefetch_prepare = False
     # (not in the reference) only the host->device COPY of the next batch runs one step ahead on a side stream; prepare() stays
     # on the compute stream at the step that uses the batch (no second stream competing for the CUs)
-    prefetch_copy = False
+    # None (default) = decided at the first training batch: on when the data set hands over PINNED host tensors (the case the copy can
+    # overlap at all), off otherwise (device-resident or pageable batches: the reference's in-line `.cuda()`, trainer.py:202)
+    prefetch_copy = None
+
+    def _decide_prefetch_copy(self):
+        """first training batch with prefetch_copy = None: look at what the data set hands over, use this batch in line"""
+        raw = next(self.train_dataset)
+        items = raw if isinstance(raw, (tuple, list)) else (raw,)
+        gpu = torch.cuda.is_available() and self.move_batches_to_gpu
+        pinned = gpu and any(isinstance(t, torch.Tensor) and not t.is_cuda and t.is_pinned() for t in items)
+        self.prefetch_copy = bool(pinned) and not self.prefetch_prepare
+        if self.prefetch_copy:
+            self._log('batches arrive in pinned host memory: the next batch is copied on a side stream while a step computes '
+                      '(Trainer.prefetch_copy; set it to False for the in-line copy)')
+        batch = to_device(raw) if gpu else items
+        return self.prepare(*batch)
 
     # (not in the reference) prepare() of batch k+1 on a side stream BEHIND step k's forward / backward: the side stream waits for
     # the step's last backward kernel (so persistent feature buffers - static_prepare - are free again) and its feature extraction runs
@@ -275,6 +290,8 @@ class Trainer:
             self._pre_stream = _independent_stream()
 
     def _take_train_batch(self):
+        if self.prefetch_copy is None and getattr(self, '_ovl', None) is None:
+            return self._decide_prefetch_copy()
         if not ((self.prefetch_prepare or self.prefetch_copy) and torch.cuda.is_available()):
             ovl = getattr(self, '_ovl', None)
             if ovl is not None:                          # staged behind the previous step (overlap_prepare)
@@ -538,6 +555,18 @@ class Trainer:
         self._log('captured the training step as a hipGraph for inputs %s' % (
             ', '.join('x'.join(map(str, t.shape)) for t in batch)))
 
+    def _optimizer_covers_model(self) -> bool:
+        """the fused clip takes its global norm over the OPTIMIZER's parameters; Trainer.clip_grad (trainer.py:184-191) over every model
+        parameter that requires a gradient.  The two agree only when the sets agree - otherwise the stock clip_grad() runs.
+        (With the fused clip `p.grad` itself stays unclipped - and un-averaged under DDP; read `optimizer.last_grad_norm`.)"""
+        key = (id(self.optimizer), sum(len(g['params']) for g in self.optimizer.param_groups))
+        cached = getattr(self, '_opt_cover', None)
+        if cached is None or cached[0] != key:
+            model = {id(p) for p in self._bare_model.parameters() if p.requires_grad}
+            opt = {id(p) for g in self.optimizer.param_groups for p in g['params']}
+            cached = self._opt_cover = (key, model == opt)
+        return cached[1]
+
     def _finish_device_skip(self, step: int, flag: torch.Tensor):
         """eager tail of a step whose backward has run: NaN flag to the host (asynchronously), gradient all-reduce,
         clipping, optimizer step with on-device skip"""
@@ -545,7 +574,7 @@ class Trainer:
         # K18: clamp + global-norm clipping inside the optimizer launch (psnd_grad_sumsq + psnd_adam_step) when the optimizer can and
         # clip_grad() is the stock one; the averaging over ranks is then the kernel's grad_scale as well
         fused_clip = ((self.grad_clip or self.grad_norm) and getattr(self.optimizer, '_supports_fused_clip', False)
-                      and type(self).clip_grad is Trainer.clip_grad)
+                      and type(self).clip_grad is Trainer.clip_grad and self._optimizer_covers_model())
         if self._reducer is not None and (pdist.is_dist() or self._reducer.active):      # (active without is_dist: a forced one-rank group)
             # ONE collective per bucket: the flag sits behind the last bucket (set_flag), and when nothing clips the gradients the
             # division by the world size is left to the optimizer kernel (grad_scale) instead of a pass over the buckets

@@ -42,3 +42,37 @@ def seeded_wav(seed, N, T, sr=22050):
     t = np.arange(T) / sr
     w = 0.0708 * g.randn(N, T) + 0.1 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 3000 * t + 0.3)
     return np.clip(w, -1, 1).astype(np.float32)
+
+
+def _refresh_switches():
+    """libpsnd_hip.so looks its PSND_* A/B switches up once per call site (psnd_env_refresh, include/psnd.h): tests that flip them inside one
+    process have them read again.  No-op when the library is not built / loadable."""
+    try:
+        from pytorch_sound_amd._lib import lib
+        lib().psnd_env_refresh()
+    except Exception:      # noqa: BLE001 - CPU-only collection without the library
+        pass
+
+
+@pytest.fixture(autouse=True)
+def _fresh_switches():
+    _refresh_switches()
+    yield
+    _refresh_switches()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch, with the library's cached switches refreshed after every environment change"""
+    set_, del_ = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(*a, **k):
+        set_(*a, **k)
+        _refresh_switches()
+
+    def delenv(*a, **k):
+        del_(*a, **k)
+        _refresh_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    return monkeypatch
