@@ -488,6 +488,13 @@ int psnd_adam_step(const void *table, int n_tensors, const int *chunk_tensor, co
                    double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
                    const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
                    void *stream);
+/* psnd_adam_step + a host-visible record of the step's skip flag: flag_log = a pinned, device-mapped int ring of {flag, seq} pairs (or NULL);
+ * the launch writes flag_log[2 slot] = (found_inf != 0) and then, behind a system-scope fence, flag_log[2 slot + 1] = log_seq.  The host
+ * polls the sequence number: no device-to-host copy, no event (Trainer's NaN log line, trainer.py:205-207). */
+int psnd_adam_step_logged(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
+                          double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
+                          const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
+                          int *flag_log, int log_slot, int log_seq, void *stream);
 int psnd_grad_sumsq(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
                     float clip_value, const float *grad_scale, int accumulate, float max_norm, double *partial, double *sumsq,
                     float *coef, void *stream);

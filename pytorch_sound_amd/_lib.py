@@ -118,6 +118,7 @@ SIGNATURES = {
     'psnd_adam_chunk': (_I64, []),
     'psnd_adam_table_bytes': (_I64, []),
     'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _F, _P, _P]),
+    'psnd_adam_step_logged': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _F, _P, _P, _INT, _INT, _P]),
     'psnd_grad_sumsq': (_INT, [_P, _INT, _P, _P, _I64, _F, _P, _INT, _F, _P, _P, _P, _P]),
     'psnd_mask_head_fwd': (_INT, [_P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
     'psnd_mask_head_bwd': (_INT, [_P, _P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),

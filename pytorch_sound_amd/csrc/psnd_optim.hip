@@ -23,8 +23,18 @@ constexpr int ACH = 2048;   // elements per workgroup (256 threads x 2 float4)
 
 // step += 1 and the two bias-correction factors of every tensor, in double like torch's kernels (1 - b^step cancels badly
 // in float for the first steps): corr[2 i] = 1 / (1 - b1^step), corr[2 i + 1] = 1 / sqrt(1 - b2^step)
-__global__ __launch_bounds__(64) void adam_tick_kernel(const AdamTensor *tab, int n, double b1, double b2, const float *found_inf, float *corr) {
+// flag_log (may be null): a host-visible (pinned, device-mapped) int ring {flag, seq} per slot.  The first thread leaves the step's skip flag
+// there and, behind a system-scope fence, the sequence number the host waits for - the trainer learns about a skipped (NaN) step without
+// a device-to-host copy and an event behind every optimizer launch (4 us of blit kernel + ~10 us of idle queue per config-2 step).
+__global__ __launch_bounds__(64) void adam_tick_kernel(const AdamTensor *tab, int n, double b1, double b2, const float *found_inf, float *corr,
+                                                        int *flag_log, int log_slot, int log_seq) {
     const int i = blockIdx.x * 64 + threadIdx.x;
+    if (flag_log && i == 0) {
+        volatile int *slot = flag_log + 2 * log_slot;
+        slot[0] = (found_inf && *found_inf != 0.f) ? 1 : 0;
+        __threadfence_system();
+        slot[1] = log_seq;
+    }
     if (i >= n) return;
     if (found_inf && *found_inf != 0.f) return;
     const float step = *tab[i].step + 1.f;
@@ -168,6 +178,15 @@ extern "C" int psnd_adam_step(const void *table, int n_tensors, const int *chunk
                               double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
                               const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
                               void *stream) {
+    return psnd_adam_step_logged(table, n_tensors, chunk_tensor, chunk_off, n_chunks, lr, beta1, beta2, eps, weight_decay, decoupled, found_inf,
+                                 grad_scale, corr, clip_value, clip_coef, nullptr, 0, 0, stream);
+}
+
+extern "C" int psnd_adam_step_logged(const void *table, int n_tensors, const int *chunk_tensor, const int64_t *chunk_off, int64_t n_chunks,
+                                     double lr, double beta1, double beta2, double eps, double weight_decay, int decoupled,
+                                     const float *found_inf, const float *grad_scale, float *corr, float clip_value, const float *clip_coef,
+                                     int *flag_log, int log_slot, int log_seq, void *stream) {
+    if (flag_log && log_slot < 0) PSND_FAIL(PSND_E_ARG, "adam_step: log_slot=%d", log_slot);
     if (!table || !chunk_tensor || !chunk_off || !corr) PSND_FAIL(PSND_E_ARG, "adam_step: null pointer");
     if (!(clip_value >= 0.f)) PSND_FAIL(PSND_E_ARG, "adam_step: clip_value=%g", (double)clip_value);
     if (n_tensors < 0 || n_chunks < 0 || n_chunks > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "adam_step: n_tensors=%d n_chunks=%lld", n_tensors, (long long)n_chunks);
@@ -176,7 +195,7 @@ extern "C" int psnd_adam_step(const void *table, int n_tensors, const int *chunk
     if (n_tensors == 0 || n_chunks == 0) return PSND_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const AdamTensor *tab = static_cast<const AdamTensor *>(table);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3((n_tensors + 63) / 64), dim3(64), 0, s, tab, n_tensors, beta1, beta2, found_inf, corr);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3((n_tensors + 63) / 64), dim3(64), 0, s, tab, n_tensors, beta1, beta2, found_inf, corr, flag_log, log_slot, log_seq);
     if (decoupled)
         hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)n_chunks), dim3(256), 0, s, tab, chunk_tensor, reinterpret_cast<const long long *>(chunk_off),
                            (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, found_inf, grad_scale, corr, clip_value, clip_coef);

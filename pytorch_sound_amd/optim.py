@@ -19,6 +19,9 @@ class Adam(torch.optim.Optimizer):
     # the kernel clamp every (scaled) gradient element and apply clip_grad_norm_'s factor - ONE extra pass over the gradients
     # (psnd_grad_sumsq) instead of a clamp per parameter + torch's multi-launch norm; `last_grad_norm` (device scalar) = the norm
     _supports_fused_clip = True
+    # `optimizer.flag_log = (pinned int32 ring tensor (R, 2), slot, seq)` for one step(): the launch leaves found_inf and the sequence number
+    # in host-visible memory (psnd_adam_step_logged) - the trainer's NaN log needs no device-to-host copy
+    _supports_flag_log = True
     _decoupled = False                          # True: AdamW (weight decay applied to the parameter, not the gradient)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
@@ -131,16 +134,19 @@ class Adam(torch.optim.Optimizer):
                           'psnd_grad_sumsq')
             coef = scratch['coef']
             self.last_grad_norm = coef[1]
-        for group, plan, n in work:
+        flag_log = getattr(self, 'flag_log', None)
+        self.flag_logged = flag_log is not None and len(work) > 0           # (no launch, no record: the caller falls back to a copy)
+        for wi, (group, plan, n) in enumerate(work):
             device = plan['device']
             b1, b2 = group['betas']
+            log_ptr, log_slot, log_seq = (ptr(flag_log[0]), int(flag_log[1]), int(flag_log[2])) if (flag_log is not None and wi == 0) else (None, 0, 0)
             fi = found_inf.to(device=device, dtype=torch.float32) if found_inf is not None else None
             gs = grad_scale.to(device=device, dtype=torch.float32) if grad_scale is not None else None
             with torch.cuda.device(device):
-                check(lib().psnd_adam_step(ptr(plan['table']), n, ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
-                                           plan['chunk_off'].numel(), float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                           float(group['weight_decay']), int(self._decoupled), ptr(fi), ptr(gs), ptr(plan['corr']),
-                                           clip_value, ptr(coef), stream_ptr(device)), 'psnd_adam_step')
+                check(lib().psnd_adam_step_logged(ptr(plan['table']), n, ptr(plan['chunk_tensor']), ptr(plan['chunk_off']),
+                                                  plan['chunk_off'].numel(), float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                                  float(group['weight_decay']), int(self._decoupled), ptr(fi), ptr(gs), ptr(plan['corr']),
+                                                  clip_value, ptr(coef), log_ptr, log_slot, log_seq, stream_ptr(device)), 'psnd_adam_step')
         return loss
 
 

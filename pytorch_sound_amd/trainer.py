@@ -380,19 +380,42 @@ class Trainer:
         return (self.async_nan_check and loss.is_cuda and self.scheduler is None
                 and getattr(self.optimizer, '_step_supports_amp_scaling', False))
 
+    # The skip flag reaches the host without a device-to-host copy when the optimizer can leave it in host-visible memory itself
+    # (pytorch_sound_amd.optim: psnd_adam_step_logged writes {flag, seq} into a pinned ring): a blit kernel + an event behind every
+    # optimizer launch were ~14 us of a 0.67 ms config-2 step.  Other optimizers: a pinned scalar, an asynchronous copy and an event.
+    _NAN_RING = 256
+
+    def _nan_ring(self):
+        ring = getattr(self, '_nan_ring_buf', None)
+        if ring is None:
+            ring = self._nan_ring_buf = torch.zeros((self._NAN_RING, 2), dtype=torch.int32).pin_memory()
+            self._nan_seq = 0
+        return ring
+
     def _poll_nan_log(self, block: bool = False):
         pending = getattr(self, '_nan_pending', None)
         if not pending:
             return
+        if block and torch.cuda.is_available():
+            torch.cuda.synchronize()
         keep = []
-        for step, host_flag, event in pending:
+        for entry in pending:
+            step, host_flag, event = entry
+            if isinstance(event, int):                 # ring slot: host_flag = the slot, event = the sequence number to wait for
+                ring = self._nan_ring_buf
+                if int(ring[host_flag, 1]) == event:
+                    if int(ring[host_flag, 0]) != 0:
+                        self._log('{} cur step NAN is occured'.format(step))
+                else:
+                    keep.append(entry)
+                continue
             if block:
                 event.synchronize()
             if event.query():
                 if float(host_flag.item()) > 0:
                     self._log('{} cur step NAN is occured'.format(step))
             else:
-                keep.append((step, host_flag, event))
+                keep.append(entry)
         self._nan_pending = keep
 
     @staticmethod
@@ -591,6 +614,16 @@ class Trainer:
             self.optimizer.fused_clip = (self.grad_clip, self.grad_norm)
         else:
             self.clip_grad()
+        if not hasattr(self, '_nan_pending'):
+            self._nan_pending = []
+        use_ring = bool(getattr(self.optimizer, '_supports_flag_log', False)) and flag.is_cuda
+        if use_ring:
+            ring = self._nan_ring()
+            if len(self._nan_pending) >= self._NAN_RING - 2:   # the host is a whole ring ahead of the device: let it catch up
+                self._poll_nan_log(block=True)
+            self._nan_seq += 1
+            slot, seq = self._nan_seq % self._NAN_RING, self._nan_seq
+            self.optimizer.flag_log = (ring, slot, seq)
         self.optimizer.found_inf = flag
         self.optimizer.grad_scale = grad_scale
         try:
@@ -600,14 +633,17 @@ class Trainer:
             del self.optimizer.grad_scale
             if fused_clip:
                 del self.optimizer.fused_clip
-        # the flag goes to the host BEHIND the optimizer launch (which reads it on the device): the copy is off the step's critical path
-        host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
-        host_flag.copy_(flag, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record()
-        if not hasattr(self, '_nan_pending'):
-            self._nan_pending = []
-        self._nan_pending.append((step, host_flag, event))
+            if use_ring:
+                del self.optimizer.flag_log
+        if use_ring and getattr(self.optimizer, 'flag_logged', False):
+            self._nan_pending.append((step, slot, seq))    # written by the optimizer launch itself
+        else:
+            # the flag goes to the host BEHIND the optimizer launch (which reads it on the device): the copy is off the step's critical path
+            host_flag = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host_flag.copy_(flag, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            self._nan_pending.append((step, host_flag, event))
         self._poll_nan_log()
 
     def train(self, step: int):
