@@ -311,6 +311,10 @@ int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const float *v, co
 int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c, const void *d, int count, float slope, void *out, int64_t n,
                          void *stream);
 int psnd_cl_mean_act_bwd(const void *g, const void *y, int count, float slope, void *gin, int64_t n, void *stream);
+/* out_a = a[0] + .. + a[na-1], out_b = b[0] + .. + b[nb-1] over bf16 buffers of n elements (n % 8 == 0; fp32 accumulation, one rounding), both in ONE
+ * launch: the gradients arriving at an upsampler's raw / activated outputs from the resblocks of its stage (hifi_gan.py:122-131).  a, b: HOST
+ * arrays of na, nb (0..4) device pointers. */
+int psnd_cl_sum2(const void *const *a, int na, void *out_a, const void *const *b, int nb, void *out_b, int64_t n, void *stream);
 /* psnd_conv1d_prep for n convs in ONE launch (one workgroup per 8 output channels: every store a 16-byte piece of the packs).
  * descs_dev: device array of n records
  *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cout, Cin, k, Cb, Ca, blk0; }   (72 bytes, blk0 = sum of

@@ -661,6 +661,47 @@ class ConvTransposeCL(torch.autograd.Function):
         return gx, gv, gg, g_bias, None, None, None, None, None
 
 
+class FanOutCL(torch.autograd.Function):
+    """(x_raw, x_act) of an upsampler -> `count` aliases of each, one pair per resblock of the stage (hifi_gan.py:122-131: every resblock
+    reads x; their outputs are averaged).  Forward is free (aliases); backward adds the gradients that come back - up to `count` per output -
+    in ONE launch (psnd_cl_sum2, fp32 accumulation, one rounding) instead of autograd's 2 x (count - 1) library adds."""
+
+    @staticmethod
+    def forward(ctx, x_raw, x_act, count):
+        ctx.set_materialize_grads(False)
+        ctx.count = count
+        ctx.meta = (x_raw.shape, x_raw.device)
+        outs = []
+        for _ in range(count):
+            outs += [x_raw.detach(), x_act.detach()]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        g_raw = [g.contiguous() for g in gs[0::2] if g is not None]
+        g_act = [g.contiguous() for g in gs[1::2] if g is not None]
+        shape, dev = ctx.meta
+
+        def single(lst):
+            return lst[0] if len(lst) == 1 else None
+
+        if len(g_raw) <= 1 and len(g_act) <= 1:
+            return single(g_raw), single(g_act), None
+        out_r = single(g_raw) if len(g_raw) <= 1 else torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        out_a = single(g_act) if len(g_act) <= 1 else torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        for g in g_raw + g_act:
+            _need(g, torch.bfloat16)
+        ra = g_raw if len(g_raw) > 1 else []
+        aa = g_act if len(g_act) > 1 else []
+        pa = (ctypes.c_void_p * max(1, len(ra)))(*[g.data_ptr() for g in ra])
+        pb = (ctypes.c_void_p * max(1, len(aa)))(*[g.data_ptr() for g in aa])
+        n = (ra or aa)[0].numel()
+        with torch.cuda.device(dev):
+            check(lib().psnd_cl_sum2(pa, len(ra), ptr(out_r) if ra else None, pb, len(aa), ptr(out_a) if aa else None, n, stream_ptr(dev)),
+                  'psnd_cl_sum2')
+        return out_r, out_a, None
+
+
 class MeanActCL(torch.autograd.Function):
     """leaky_relu(mean of the stage's resblock outputs, slope) on CL buffers in one pass each way (hifi_gan.py:122-131:
     xs / num_kernels, then the leaky_relu in front of the next upsampler / of conv_post)"""

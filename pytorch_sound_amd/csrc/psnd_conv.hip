@@ -2207,6 +2207,31 @@ __global__ __launch_bounds__(256) void cl_mean_act_kernel(const bf16_t *a, const
     }
     reinterpret_cast<uint4 *>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
+// out_g = sum of up to four bf16 buffers (fp32 accumulation, one rounding), for TWO groups in one launch (blockIdx.y): the gradients that
+// arrive at an upsampler's two outputs from the resblocks of its stage (hifi_gan.py:122-131: every resblock reads x and adds to xs) -
+// autograd's accumulation was 2 x (count - 1) library add launches per stage
+struct SumGroup {
+    const bf16_t *src[4];
+    bf16_t *out;
+    int count;
+};
+__global__ __launch_bounds__(256) void cl_sum2_kernel(SumGroup ga, SumGroup gb, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const SumGroup &g = blockIdx.y == 0 ? ga : gb;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.count; ++s) {
+        const uint4 q = reinterpret_cast<const uint4 *>(g.src[s])[i];
+        const unsigned *pq = reinterpret_cast<const unsigned *>(&q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[2 * e] += bf2f((bf16_t)(pq[e] & 0xffff)), acc[2 * e + 1] += bf2f((bf16_t)(pq[e] >> 16));
+    }
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf16(acc[2 * e], acc[2 * e + 1]);
+    reinterpret_cast<uint4 *>(g.out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ __launch_bounds__(256) void cl_mean_act_bwd_kernel(const bf16_t *g, const bf16_t *y, int count, float slope, bf16_t *gin, size_t n8) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
@@ -2332,6 +2357,28 @@ extern "C" int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c,
                        static_cast<const bf16_t *>(a), static_cast<const bf16_t *>(b), static_cast<const bf16_t *>(c), static_cast<const bf16_t *>(d),
                        count, slope, static_cast<bf16_t *>(out), n8);
     PSND_CHECK_LAUNCH("cl_mean_act_fwd");
+    return PSND_OK;
+}
+
+extern "C" int psnd_cl_sum2(const void *const *a, int na, void *out_a, const void *const *b, int nb, void *out_b, int64_t n, void *stream) {
+    if (na < 0 || na > 4 || nb < 0 || nb > 4 || (na == 0 && nb == 0)) PSND_FAIL(PSND_E_ARG, "cl_sum2: %d / %d sources (0..4 each, not both 0)", na, nb);
+    if ((na > 0 && (!a || !out_a)) || (nb > 0 && (!b || !out_b))) PSND_FAIL(PSND_E_ARG, "cl_sum2: null pointer");
+    if (n % 8 != 0 || n < 0) PSND_FAIL(PSND_E_SHAPE, "cl_sum2: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return PSND_OK;
+    SumGroup ga = {}, gb = {};
+    for (int i = 0; i < na; ++i) {
+        if (!a[i]) PSND_FAIL(PSND_E_ARG, "cl_sum2: null source");
+        ga.src[i] = static_cast<const bf16_t *>(a[i]);
+    }
+    for (int i = 0; i < nb; ++i) {
+        if (!b[i]) PSND_FAIL(PSND_E_ARG, "cl_sum2: null source");
+        gb.src[i] = static_cast<const bf16_t *>(b[i]);
+    }
+    ga.out = static_cast<bf16_t *>(out_a), ga.count = na, gb.out = static_cast<bf16_t *>(out_b), gb.count = nb;
+    if (na == 0) ga = gb, gb.count = 0;               // one group only: it is group 0
+    const size_t n8 = (size_t)n / 8;
+    hipLaunchKernelGGL(cl_sum2_kernel, dim3((unsigned)((n8 + 255) / 256), gb.count > 0 ? 2 : 1), dim3(256), 0, static_cast<hipStream_t>(stream), ga, gb, n8);
+    PSND_CHECK_LAUNCH("cl_sum2");
     return PSND_OK;
 }
 

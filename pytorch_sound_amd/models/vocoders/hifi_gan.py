@@ -262,9 +262,12 @@ class Generator(nn.Module):
             shape, T = out_shape, out_shape.L
             stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
             rs = []
-            for block in stage:
+            # every resblock of the stage reads (x_raw, x_act): aliases whose gradients come back summed by ONE launch (cl.FanOutCL)
+            fan = cl.FanOutCL.apply(x_raw, x_act, len(stage)) if (len(stage) > 1 and torch.is_grad_enabled() and x_raw.requires_grad) \
+                else (x_raw, x_act) * len(stage)
+            for bi, block in enumerate(stage):
                 fn = cl.resblock1_cl if hasattr(block, 'convs1') else cl.resblock2_cl
-                rs.append(fn(block, x_raw, x_act, shape, prep=prep)[0])
+                rs.append(fn(block, fan[2 * bi], fan[2 * bi + 1], shape, prep=prep)[0])
             xa = cl.MeanActCL.apply(0.01 if last else LRELU_SLOPE, *rs)      # last: F.leaky_relu's default slope, as the reference
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return torch.tanh(cl.FromCL.apply(y, 1, T, shape))

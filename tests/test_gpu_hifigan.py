@@ -131,3 +131,28 @@ def test_folded_generator_decodes_on_the_cl_kernels(arch):
     assert got.shape == want.shape
     err = float((got - want).norm() / want.norm())
     assert err < (4e-2 if on_cl else 1e-4), err
+
+
+def test_fanout_sums_stage_gradients_in_one_launch():
+    """cl.FanOutCL: the aliases an upsampler's outputs are handed to the resblocks of its stage as (hifi_gan.py:122-131) are the same
+    memory, and the gradients that come back are added by psnd_cl_sum2 (fp32 accumulation, one bf16 rounding) - compared with the
+    float64 sum; a single contribution passes through untouched."""
+    from pytorch_sound_amd import cl
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    xr = torch.randn(2, 40, 64, device=dev).to(torch.bfloat16).requires_grad_(True)
+    xa = torch.randn(2, 40, 64, device=dev).to(torch.bfloat16).requires_grad_(True)
+    outs = cl.FanOutCL.apply(xr, xa, 3)
+    assert len(outs) == 6 and all(o.data_ptr() in (xr.data_ptr(), xa.data_ptr()) for o in outs)
+    gs = [torch.randn(2, 40, 64, device=dev).to(torch.bfloat16) for _ in range(6)]
+    loss = sum((o.float() * g.float()).sum() for o, g in zip(outs, gs))
+    loss.backward()
+    want_r = (gs[0].double() + gs[2].double() + gs[4].double())
+    want_a = (gs[1].double() + gs[3].double() + gs[5].double())
+    assert float((xr.grad.double() - want_r).abs().max()) <= 2 ** -8 * float(want_r.abs().max())
+    assert float((xa.grad.double() - want_a).abs().max()) <= 2 ** -8 * float(want_a.abs().max())
+    # one contribution only (the other outputs unused): handed through as it is
+    xr.grad = xa.grad = None
+    outs = cl.FanOutCL.apply(xr, xa, 3)
+    (outs[2].float() * gs[0].float()).sum().backward()
+    assert torch.equal(xr.grad, gs[0]) and xa.grad is None

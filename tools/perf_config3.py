@@ -18,6 +18,7 @@ from pytorch_sound_amd.interface.hifi_gan import MelSpectrogram  # noqa: E402
 from pytorch_sound_amd.models.sound import multi_stft_loss  # noqa: E402
 from pytorch_sound_amd.trainer import Trainer, LogType  # noqa: E402
 from pytorch_sound_amd import optim as poptim  # noqa: E402
+from pytorch_sound_amd import kernels as K  # noqa: E402
 
 dev = torch.device('cuda:0')
 N, T, SR = 16, 8192, 22050
@@ -48,7 +49,7 @@ def make(hip):
 
         def forward(self, wav, m, is_logging=False):
             y = self.model(m).squeeze(1)
-            loss = F.l1_loss(feat(y), m)
+            loss = (K.l1_loss if hip else F.l1_loss)(feat(y), m)
             if MSL:
                 loss = loss + multi_stft_loss(y, wav, PARAMS)[0]
             return loss, {'loss': (loss, LogType.SCALAR)}
