@@ -620,8 +620,8 @@ class ConvTransposeCL(torch.autograd.Function):
         wf = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
         wb = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
         bp = torch.empty(stride * Cr, dtype=torch.float32, device=dev)
-        raw = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
-        act = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
+        both = torch.zeros((2, shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)     # (one fill for the two outputs' halo rows)
+        raw, act = both[0], both[1]
         with torch.cuda.device(dev):
             st = stream_ptr(dev)
             check(lib().psnd_convtr1d_prep(ptr(v32), ptr(g32), ptr(b32), Cin, Cout, K, stride, Cr, Cip, ptr(wf), ptr(wb), ptr(bp), st),
