@@ -37,7 +37,27 @@ struct GemmParams {
     long long sCslab;
     int flatT;                   // > 0 (n-contiguous B only): the columns of all Z batches form ONE axis of Z * flatT columns,
                                  // column j = (z = j / flatT, t = j % flatT) - no partly filled column tile per batch (T = 173: 68 % -> 98 %)
+    // Tile order (round 4).  The launch is ONE-dimensional; workgroup L is tile gemm_tile(L).  Tiles that read the same operand bytes - the
+    // M tiles over one column tile of B (projections: B is the 42-169 MB activation tensor, read once PER M TILE before: 8 x at 256 -> 1024),
+    // all the tiles of one batch chunk in weight-gradient mode - are numbered consecutively AND land on one XCD (workgroup L runs on XCD
+    // L % 8): the first of them brings the bytes into that XCD's L2, the others hit.  tiles_x / tiles_y / tiles_z: the logical grid.
+    int tiles_x, tiles_y, tiles_z;
 };
+
+// logical tile (x, y, z) of workgroup L; false = padding workgroup (the numbering is padded to whole groups of 8 outer tiles)
+__device__ __forceinline__ bool gemm_tile(const GemmParams &p, int &bx, int &by, int &bz) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    if (p.zchunk > 0) {                          // weight gradient: inner = the tiles of one batch chunk, outer = the chunks
+        const int inner = p.tiles_x * p.tiles_y, o = (j / inner) * 8 + xcd, i = j % inner;
+        if (o >= p.tiles_z) return false;
+        bx = i % p.tiles_x, by = i / p.tiles_x, bz = o;
+    } else {                                     // inner = the M tiles over one (column tile, batch), outer = those
+        const int inner = p.tiles_y, o = (j / inner) * 8 + xcd, i = j % inner;
+        if (o >= p.tiles_x * p.tiles_z) return false;
+        bx = o % p.tiles_x, bz = o / p.tiles_x, by = i;
+    }
+    return true;
+}
 
 constexpr int GBM = 128, GBN = 128, GBK = 16, GP = 132;   // LDS pitch of both tiles ([k][m] and [k][n], m / n fastest)
 
@@ -117,8 +137,8 @@ __device__ __forceinline__ void gemm_commit(float *tile, int tid, const f32x4_t 
 }
 
 // epilogue shared by both GEMM kernels: bias, relu, store (flat mode: column -> (batch, t))
-__device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0) {
-    float *C = p.C + (p.zchunk > 0 ? blockIdx.z * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
+__device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0, int bz) {
+    float *C = p.C + (p.zchunk > 0 ? bz * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
     const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -151,8 +171,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float sA[2][GBK * GP], sB[2][GBK * GP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    const int z0 = p.zchunk > 0 ? blockIdx.z * p.zchunk : blockIdx.z;
+    int tbx, tby, tbz;
+    if (!gemm_tile(p, tbx, tby, tbz)) return;
+    const int m0 = tby * GBM, n0 = tbx * GBN;
+    const int z0 = p.zchunk > 0 ? tbz * p.zchunk : tbz;
     const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    gemm_store(p, acc, m0, n0, wm, wn, li, kk, z0);
+    gemm_store(p, acc, m0, n0, wm, wn, li, kk, z0, tbz);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -289,8 +311,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM * HP], sB[2][GBN * HP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    const int z0 = p.zchunk > 0 ? blockIdx.z * p.zchunk : blockIdx.z;
+    int tbx, tby, tbz;
+    if (!gemm_tile(p, tbx, tby, tbz)) return;
+    const int m0 = tby * GBM, n0 = tbx * GBN;
+    const int z0 = p.zchunk > 0 ? tbz * p.zchunk : tbz;
     const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -352,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0);
+    gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
 }
 
 // out[i] = sum over slabs of part[s][i]
@@ -1206,12 +1230,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_bf16_kernel(AttnParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hipStream_t st, const char *what, bool bf16 = false) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || gz <= 0) return PSND_OK;
-    dim3 grid((p.N + GBN - 1) / GBN, (p.M + GBM - 1) / GBM, gz);
+    long long tx = (p.N + GBN - 1) / GBN, ty = (p.M + GBM - 1) / GBM, tz = gz;
     if (p.flatT > 0) {           // one column axis over all batches
         if (!b_ncontig || p.zchunk > 0 || p.sAz != 0) PSND_FAIL(PSND_E_ARG, "%s: flat columns need a shared A and an n-contiguous B", what);
-        grid.x = (unsigned)(((long long)p.Z * p.flatT + GBN - 1) / GBN), grid.z = 1;
+        tx = ((long long)p.Z * p.flatT + GBN - 1) / GBN, tz = 1;
     }
-    if (grid.y > 65535 || grid.z > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: grid too large", what);
+    // one-dimensional launch in the tile order of gemm_tile(): outer tiles padded to a multiple of 8 (one per XCD)
+    const long long inner = p.zchunk > 0 ? tx * ty : ty, outer = p.zchunk > 0 ? tz : tx * tz;
+    const long long total = (outer + 7) / 8 * 8 * inner;
+    if (total > 0x7fffffff || tx > 0x7fffffff || ty > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: grid too large", what);
+    p.tiles_x = (int)tx, p.tiles_y = (int)ty, p.tiles_z = (int)tz;
+    const dim3 grid((unsigned)total);
     if (bf16) {
         if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p);
         else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p);
