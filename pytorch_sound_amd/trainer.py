@@ -603,8 +603,11 @@ class Trainer:
             # division by the world size is left to the optimizer kernel (grad_scale) instead of a pass over the buckets
             in_opt = fused_clip or not (self.grad_clip or self.grad_norm)
             self._reducer.finish(average=not in_opt)
-            rf = self._reducer.flag                    # sum of the ranks' 0 / 1 flags: non-zero = skip, which is all the optimizer kernel tests
-            flag = rf.reshape(()) if rf.dtype == torch.float32 else (rf > 0).to(torch.float32).reshape(())
+            # the sum of the ranks' 0 / 1 flags (divided by the world size when the buckets are averaged): psnd_adam_step skips on any
+            # non-zero value and takes it as it is; torch's fused optimizers test `found_inf == 1`, so they get it normalised (two launches)
+            rf = self._reducer.flag
+            raw_ok = rf.dtype == torch.float32 and getattr(self.optimizer, '_supports_flag_log', False)
+            flag = rf.reshape(()) if raw_ok else (rf > 0).to(torch.float32).reshape(())
             if in_opt:
                 if getattr(self, '_world_scale', None) is None or self._world_scale.device != flag.device:
                     self._world_scale = torch.full((), float(pdist.world_size()), dtype=torch.float32, device=flag.device)
