@@ -306,8 +306,11 @@ __device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, cons
     }
 }
 
-template <bool A_MCONTIG, bool B_NCONTIG>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+// MASKED: a relu mask travels with an operand (input / weight gradient behind a ReLU).  Without one the two mask stages (64 registers) do not
+// exist: 3 workgroups per CU instead of 2 - the kernel is a latency chain per workgroup (8 k-steps behind barriers, operands two steps
+// ahead), so residency is what hides it, and 646 workgroups (256 -> 256 at 32 x 1292) fit the chip in ONE round instead of 1.26.
+template <bool A_MCONTIG, bool B_NCONTIG, bool MASKED>
+__global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM * HP], sB[2][GBN * HP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
@@ -338,22 +341,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             rowB = rb;
         }
     }
-    const bool ma = p.amask != nullptr, mb = p.bmask != nullptr;
-    float fa[2][2][8], fb[2][2][8], fam[2][2][8], fbm[2][2][8];
+    const bool ma = MASKED && p.amask != nullptr, mb = MASKED && p.bmask != nullptr;
+    float fa[2][2][8], fb[2][2][8], fam[MASKED ? 2 : 1][2][8], fbm[MASKED ? 2 : 1][2][8];
     auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         const int zi = it / nk, k0 = (it - zi * nk) * HBK;
         const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
         hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fa[S]);
         hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fb[S]);
-        if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fam[S]);
-        if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fbm[S]);
+        if constexpr (MASKED) {
+            if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fam[S]);
+            if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fbm[S]);
+        }
     };
     auto body = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         unsigned short *tA = sA[S], *tB = sB[S];
-        hgemm_commit<A_MCONTIG>(tA, tid, fa[S], fam[S], ma);
-        hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[S], mb);
+        hgemm_commit<A_MCONTIG>(tA, tid, fa[S], fam[MASKED ? S : 0], ma);
+        hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[MASKED ? S : 0], mb);
         __syncthreads();
         if (it + 2 < steps) fetch(it + 2, sc);
 #pragma unroll
@@ -1242,10 +1247,16 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
     p.tiles_x = (int)tx, p.tiles_y = (int)ty, p.tiles_z = (int)tz;
     const dim3 grid((unsigned)total);
     if (bf16) {
-        if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p);
-        else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p);
-        else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, p);
+        const bool masked = p.amask || p.bmask;
+        if (masked) {
+            if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, true>), grid, dim3(256), 0, st, p);
+            else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, true>), grid, dim3(256), 0, st, p);
+            else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, true>), grid, dim3(256), 0, st, p);
+        } else if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false>), grid, dim3(256), 0, st, p);
+        else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, false>), grid, dim3(256), 0, st, p);
+        else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false>), grid, dim3(256), 0, st, p);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e2));
         return PSND_OK;
