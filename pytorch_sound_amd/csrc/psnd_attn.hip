@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *out, const
 // backward, key side.  One wave = 32 keys (its K and V fragments stay in registers), loop over query tiles:
 //   S'[tq][tk], dP'[tq][tk] (+ gatt) -> p', dS' = scale p' (dP' - delta) -> dV += gO p', dK += Q dS'.   grid (ceil(T / 128), H * N)
 template <int HDP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
     __shared__ float sQ[2][HDP * TP], sG[2][HDP * TP];
     __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];           // per query of the tile: max, 1 / sum, delta, query padded
     __shared__ float sT[4][32 * TP];                                     // per wave: a gatt tile, transposed through LDS
@@ -953,7 +953,7 @@ __device__ __forceinline__ void mma_tile_acc_b(const unsigned short *tD, const b
 }
 
 template <int HDP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][B::TT], sV[2][B::TD];
     __shared__ unsigned s_kb[KBITS_MAX];
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
 }
 
 template <int HDP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_bf16_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sQt[2][B::TT], sQd[2][B::TD], sGt[2][B::TT], sGd[2][B::TD];
     __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];
