@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(AttnParams p) {
     }
 }
 
-template <int HDP>
+// GATT: a gradient arrives for the returned attention tensor too (modules.py:60 returns `att`; training recipes rarely differentiate it).
+// The plain instances do not carry that path: 232 / 158 instead of 256 (13 spilled) / 190 registers - the query kernel runs three waves per SIMD.
+template <int HDP, bool GATT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sQt[2][B::TT], sQd[2][B::TD], sGt[2][B::TT], sGd[2][B::TD];
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
             commit_tile_b<HDP, true, true>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
             commit_tile_b<HDP, true, true>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
         }
-        if (p.gatt) {
+        if constexpr (GATT) {
             float *tt = sT[wave];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -1164,8 +1166,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     }
 }
 
-template <int HDP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_q_bf16_kernel(AttnParams p) {
+template <int HDP, bool GATT>
+__global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sKt[2][B::TT], sKd[2][B::TD], sVt[2][B::TT];
     __shared__ unsigned s_kb[KBITS_MAX];
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_bf16_kernel(AttnParams p) {
             const bool dead = qdead || ((bad >> row) & 1u);
             const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
             float g = dp[r];
-            if (p.gatt && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            if (GATT && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
             dp[r] = p.scale * pr * (g - dl);
         }
         bf16x8_t db[2];
@@ -1371,14 +1373,20 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
     if (bf16) {
-        if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_bf16_kernel<32>, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(attn_bwd_kv_bf16_kernel<64>, grid, dim3(256), 0, st, p);
+        if (p.gatt) {
+            if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
+        } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
     } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
     if (bf16) {
-        if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_bf16_kernel<32>, grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(attn_bwd_q_bf16_kernel<64>, grid, dim3(256), 0, st, p);
+        if (p.gatt) {
+            if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
+        } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
     } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_kernel<32>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(q)");
