@@ -543,8 +543,8 @@ __device__ __forceinline__ void mma_tile_acc(const float *tile, const f32x16 &P,
 
 // forward.  One wave = 32 query columns; pass 1: column statistics (max, sum) over all keys; pass 2: probabilities (written to
 // `att` when asked for) and out = V P.  grid (ceil(T / 128), H * N)
-template <int HDP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+template <int HDP, bool ATT>
+__global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_kernel(AttnParams p) {
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
     __syncthreads();
     mma_tile_frag<HDP>(sK[0], qf, li, kk, s);
-    float *attp = p.att ? p.att + (long long)b * T * T + tq : nullptr;
+    float *attp = ATT ? p.att + (long long)b * T * T + tq : nullptr;      // ATT: the (H N, T, T) tensor is written (its own instances)
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *out, const
 
 // backward, key side.  One wave = 32 keys (its K and V fragments stay in registers), loop over query tiles:
 //   S'[tq][tk], dP'[tq][tk] (+ gatt) -> p', dS' = scale p' (dP' - delta) -> dV += gO p', dK += Q dS'.   grid (ceil(T / 128), H * N)
-template <int HDP>
+template <int HDP, bool GATT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
     __shared__ float sQ[2][HDP * TP], sG[2][HDP * TP];
     __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];           // per query of the tile: max, 1 / sum, delta, query padded
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
             commit_tile<HDP>(sQ[(it + 1) & 1], tid, pq);
             commit_tile<HDP>(sG[(it + 1) & 1], tid, pg);
         }
-        if (p.gatt) {                                // gatt[tk][tq] is query-contiguous: through LDS, read transposed
+        if constexpr (GATT) {                                // gatt[tk][tq] is query-contiguous: through LDS, read transposed
             float *tt = sT[wave];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -779,8 +779,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
 
 // backward, query side.  One wave = 32 queries (Q and gO fragments in registers), loop over key tiles:
 //   S, dP (+ gatt) -> p, dS = scale p (dP - delta) -> dQ += K dS.    grid (ceil(T / 128), H * N)
-template <int HDP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
+template <int HDP, bool GATT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {      // (three waves per SIMD: 24 spilled registers)
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {
             const bool dead = qdead || ((bad >> row) & 1u);
             const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
             float g = dp[r];
-            if (p.gatt && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            if (GATT && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
             dp[r] = p.scale * pr * (g - dl);
         }
         mma_tile_acc<HDP>(sK[it & 1], dp, li, kk, dQ);
@@ -952,8 +952,8 @@ __device__ __forceinline__ void mma_tile_acc_b(const unsigned short *tD, const b
         }
 }
 
-template <int HDP>
-__global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(AttnParams p) {
+template <int HDP, bool ATT>
+__global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][B::TT], sV[2][B::TD];
     __shared__ unsigned s_kb[KBITS_MAX];
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_bf16_kernel(AttnParams p) {
     load_tile_b<HDP, false, true>(Vp, T, p.d, 0, nullptr, sV[0], tid);
     __syncthreads();
     mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
-    float *attp = p.att ? p.att + (long long)b * T * T + tq : nullptr;
+    float *attp = ATT ? p.att + (long long)b * T * T + tq : nullptr;      // ATT: the (H N, T, T) tensor is written (its own instances)
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
@@ -1350,10 +1350,16 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
     if (bf16) {
-        if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_bf16_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-        else hipLaunchKernelGGL(attn_fwd_bf16_kernel<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    } else if (p.d <= 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        if (att) {
+            if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        } else if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    } else if (att) {
+        if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    } else if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     PSND_CHECK_LAUNCH("mha_fwd");
     return PSND_OK;
 }
@@ -1378,8 +1384,11 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
             else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
         } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
-    } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_bwd_kv_kernel<64>, grid, dim3(256), 0, st, p);
+    } else if (p.gatt) {
+        if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_kernel<32, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), grid, dim3(256), 0, st, p);
+    } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_kernel<32, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_kv_kernel<64, false>), grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
     if (bf16) {
         if (p.gatt) {
@@ -1387,8 +1396,11 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
             else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
         } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
-    } else if (p.d <= 32) hipLaunchKernelGGL(attn_bwd_q_kernel<32>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_bwd_q_kernel<64>, grid, dim3(256), 0, st, p);
+    } else if (p.gatt) {
+        if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_kernel<32, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), grid, dim3(256), 0, st, p);
+    } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_kernel<32, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_q_kernel<64, false>), grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(q)");
     return PSND_OK;
 }
