@@ -405,6 +405,9 @@ int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, 
  *      query-padded columns set to 0 (modules.py:66-76); mask (B,T) uint8, 1 = padded, or NULL.
  *  psnd_softmax_keys_bwd: gscores = scale * a * (gatt - sum_tk gatt*a). */
 #define PSND_GN_WS_DOUBLES 32
+/* PositionalEncoding.forward (modules.py:119-145): y = x * scale + pe[:, :T] in one pass; x, y (N,C,T) fp32, pe (C, pe_len) rows (the module's
+ * buffer (1, C, max_len)), pe_len >= T.  pe == NULL: y = x * scale (the backward: gx = g * scale). */
+int psnd_posenc(const float *x, const float *pe, float scale, int64_t N, int C, int64_t T, int64_t pe_len, float *y, void *stream);
 int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
                         int64_t T, float eps, int relu, float *y, float *stats, double *ws, void *stream);
 int psnd_groupnorm1_bwd(const float *gy, const float *x, const float *res, const float *gamma, const float *y,

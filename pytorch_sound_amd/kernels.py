@@ -533,6 +533,33 @@ class Linear1x1(torch.autograd.Function):
         return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None
 
 
+class PosEnc(torch.autograd.Function):
+    """PositionalEncoding.forward (modules.py:143-145): x * sqrt(C) + pe[..., :T] as one pass (psnd_posenc); backward g * sqrt(C)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, scale):
+        _need_cuda(x, 'input')
+        x = x.contiguous()
+        N, C, T = x.shape
+        pe2 = pe.reshape(pe.shape[-2], pe.shape[-1])
+        if pe2.shape[0] != C or pe2.shape[1] < T or not pe2.is_contiguous() or pe2.dtype != torch.float32 or pe2.device != x.device:
+            raise PsndError('PosEnc: table %s does not cover a (%d, %d, %d) input' % (tuple(pe.shape), N, C, T))
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_posenc(ptr(x), ptr(pe2), float(scale), N, C, T, pe2.shape[1], ptr(y), stream_ptr(x.device)), 'psnd_posenc')
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, C, T = g.shape
+        gx = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            check(lib().psnd_posenc(ptr(g), None, ctx.scale, N, C, T, T, ptr(gx), stream_ptr(g.device)), 'psnd_posenc')
+        return gx, None, None
+
+
 class AttentionKVQ(torch.autograd.Function):
     """MultiHeadAttention.scale_dot_att over all heads at once (modules.py:38-48, 61-79), straight from the fused projection:
     kvq (N, 3C, T) in the reference's chunk order K | V | Q, heads folded head-major -> out (N, C, T) (heads unfolded, ready for

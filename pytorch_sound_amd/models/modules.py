@@ -185,4 +185,11 @@ class PositionalEncoding(nn.Module):
         return table
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _hip_ok(x) and x.dim() == 3 and x.dtype == torch.float32 and x.size(-1) <= self.pe.size(-1) and self.pe.device == x.device:
+            from pytorch_sound_amd import kernels as K
+            # the buffer is the reference's transposed view (1, C, max_len) of a (max_len, C) table: the kernel reads (C, max_len) rows
+            key = (self.pe.data_ptr(), self.pe._version, self.pe.device)
+            if getattr(self, '_pe_rows_key', None) != key:
+                self._pe_rows, self._pe_rows_key = self.pe[0].contiguous(), key
+            return K.PosEnc.apply(x, self._pe_rows, self.dim ** 0.5)    # one pass instead of a scalar multiply + a broadcast add
         return x * (self.dim ** 0.5) + self.pe[..., :x.size(-1)]

@@ -341,3 +341,20 @@ def test_scale_dot_att_static_method_on_hip_tensors():
         assert float((att.double().cpu() - attr).abs().max()) <= 1e-5
     with pytest.raises(PsndError):
         MultiHeadAttention.scale_dot_att(torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), None)
+
+
+def test_positional_encoding_kernel_matches_the_torch_formulation():
+    """PositionalEncoding on a HIP tensor (psnd_posenc, modules.py:143-145) against x * sqrt(C) + pe[..., :T] in torch, bit for bit, and
+    its gradient g * sqrt(C)"""
+    from pytorch_sound_amd.models import modules as M
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    for N, C, T in ((3, 16, 10), (2, 256, 173), (1, 30, 1000)):
+        pe = M.PositionalEncoding(C, 1200).to(dev)
+        x = torch.randn(N, C, T, device=dev, requires_grad=True)
+        y = pe(x)
+        ref = x.detach() * (C ** 0.5) + pe.pe[..., :T]
+        assert torch.equal(y.detach(), ref)
+        g = torch.randn_like(ref)
+        y.backward(g)
+        assert torch.equal(x.grad, g * (C ** 0.5))
