@@ -33,8 +33,10 @@ struct GemmParams {
     int M, N, K, Z;
     long long sAm, sAk, sAz, sBk, sBn, sBz, sCm, sCz;
     int relu;
-    int zchunk;                  // > 0: weight-gradient mode - a workgroup sums over zchunk batches (and all of K) into slab blockIdx.z
+    int zchunk;                  // > 0: weight-gradient mode - a workgroup sums over zchunk batches into its slab (tile z = chunk * ksplit + part)
     long long sCslab;
+    int ksplit, kpart;           // weight-gradient mode: the K axis (frames of a clip) in ksplit parts of kpart (a multiple of 32) each - small weight
+                                 // matrices over few clips otherwise give fewer workgroups than CUs (256 x 256 over 32 clips: 128)
     int flatT;                   // > 0 (n-contiguous B only): the columns of all Z batches form ONE axis of Z * flatT columns,
                                  // column j = (z = j / flatT, t = j % flatT) - no partly filled column tile per batch (T = 173: 68 % -> 98 %)
     // Tile order (round 4).  The launch is ONE-dimensional; workgroup L is tile gemm_tile(L).  Tiles that read the same operand bytes - the
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     int tbx, tby, tbz;
     if (!gemm_tile(p, tbx, tby, tbz)) return;
     const int m0 = tby * GBM, n0 = tbx * GBN;
-    const int z0 = p.zchunk > 0 ? tbz * p.zchunk : tbz;
+    const int zc = p.zchunk > 0 ? tbz / p.ksplit : tbz, kbeg = p.zchunk > 0 ? (tbz - zc * p.ksplit) * p.kpart : 0;
+    const int kend = p.zchunk > 0 ? min(p.K, kbeg + p.kpart) : p.K;
+    const int z0 = p.zchunk > 0 ? zc * p.zchunk : tbz;
     const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int nk = (p.K + GBK - 1) / GBK;
+    const int nk = kend > kbeg ? (kend - kbeg + GBK - 1) / GBK : 0;
     const int steps = (z1 - z0) * nk;
     const MinorSpan msA = minor_span(m0 + 4 * (tid & 31), p.M, 0, 0);
     const MinorSpan msB = minor_span(n0 + 4 * (tid & 31), p.flatT > 0 ? p.Z * p.flatT : p.N, p.flatT, p.sBz);
@@ -191,12 +195,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
     f32x4_t va[2][2], vb[2][2], vam[2][2], vbm[2][2];
     auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
-        const int zi = it / nk, k0 = (it - zi * nk) * GBK;
+        const int zi = it / nk, k0 = kbeg + (it - zi * nk) * GBK;
         const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
-        gemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, msA, va[S]);
-        gemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, msB, vb[S]);
-        if (ma) gemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, msA, vam[S]);
-        if (mb) gemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, msB, vbm[S]);
+        gemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, msA, va[S]);
+        gemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, msB, vb[S]);
+        if (ma) gemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, msA, vam[S]);
+        if (mb) gemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, msB, vbm[S]);
     };
     auto body = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
@@ -317,7 +321,9 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
     int tbx, tby, tbz;
     if (!gemm_tile(p, tbx, tby, tbz)) return;
     const int m0 = tby * GBM, n0 = tbx * GBN;
-    const int z0 = p.zchunk > 0 ? tbz * p.zchunk : tbz;
+    const int zc = p.zchunk > 0 ? tbz / p.ksplit : tbz, kbeg = p.zchunk > 0 ? (tbz - zc * p.ksplit) * p.kpart : 0;
+    const int kend = p.zchunk > 0 ? min(p.K, kbeg + p.kpart) : p.K;
+    const int z0 = p.zchunk > 0 ? zc * p.zchunk : tbz;
     const int z1 = p.zchunk > 0 ? min(z0 + p.zchunk, p.Z) : z0 + 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    const int nk = (p.K + HBK - 1) / HBK;
+    const int nk = kend > kbeg ? (kend - kbeg + HBK - 1) / HBK : 0;
     const int steps = (z1 - z0) * nk;
     long long rowA = -1, rowB = -1;
     {
@@ -345,13 +351,13 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
     float fa[2][2][8], fb[2][2][8], fam[MASKED ? 2 : 1][2][8], fbm[MASKED ? 2 : 1][2][8];
     auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
-        const int zi = it / nk, k0 = (it - zi * nk) * HBK;
+        const int zi = it / nk, k0 = kbeg + (it - zi * nk) * HBK;
         const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
-        hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fa[S]);
-        hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fb[S]);
+        hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowA, fa[S]);
+        hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowB, fb[S]);
         if constexpr (MASKED) {
-            if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, p.K, m0, k0, tid, rowA, fam[S]);
-            if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, p.K, n0, k0, tid, rowB, fbm[S]);
+            if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowA, fam[S]);
+            if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowB, fbm[S]);
         }
     };
     auto body = [&](int it, auto sc) __attribute__((always_inline)) {
@@ -384,13 +390,26 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
     gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
 }
 
-// out[i] = sum over slabs of part[s][i]
+// out[i] = sum over slabs of part[s][i].  64 elements x 4 slab groups per workgroup, four loads in flight per thread: one thread walking
+// 128-160 slabs one dependent load at a time took 29 us per launch for a 256 x 256 matrix.  Fixed summation order (deterministic).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float *part, int slabs, long long n, float *out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.f;
-    for (int s = 0; s < slabs; ++s) a += part[(long long)s * n + i];
-    out[i] = a;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        int s = g;
+        for (; s + 12 < slabs; s += 16) {
+            a0 += part[(long long)s * n + i];
+            a1 += part[(long long)(s + 4) * n + i];
+            a2 += part[(long long)(s + 8) * n + i];
+            a3 += part[(long long)(s + 12) * n + i];
+        }
+        for (; s < slabs; s += 4) a0 += part[(long long)s * n + i];
+    }
+    red[g][e] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // gbias[c] = sum over (z, t) of g[z][c][t] (where mask[z][c][t] > 0 when given): one workgroup per channel.  1024 threads = 4 clip
@@ -1285,14 +1304,32 @@ extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *b
     return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
+// weight-gradient launch of psnd_linear1x1_bwd: batch chunks x K parts (frames of a clip) so that there are ~3 workgroups per CU
+static void wgrad_split(int64_t N, int Cin, int Cout, int64_t T, int64_t *zslabs, int *ksplit, int *kpart) {
+    const int64_t tiles = (int64_t)((Cout + GBM - 1) / GBM) * ((Cin + GBN - 1) / GBN);
+    int64_t want = 768 / (tiles > 0 ? tiles : 1);
+    if (want < 1) want = 1;
+    int64_t zs = want > N ? N : want;
+    const int64_t chunk = (N + zs - 1) / zs;
+    zs = (N + chunk - 1) / chunk;
+    int64_t ks = 1;
+    if (zs == N && want > N) {                   // one clip per chunk already: cut the frames of a clip, parts of >= 256 frames
+        ks = (want + N - 1) / N;
+        const int64_t cap = T / 256 > 1 ? T / 256 : 1;
+        if (ks > cap) ks = cap;
+        if (PSND_ENV("PSND_LINEAR_NO_KSPLIT")) ks = 1;
+    }
+    int64_t kp = ((T + ks - 1) / ks + 31) / 32 * 32;
+    ks = (T + kp - 1) / kp;
+    *zslabs = zs, *ksplit = (int)ks, *kpart = (int)kp;
+}
+
 extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T) {
     if (N <= 0) return 0;
-    const int64_t tiles = (int64_t)((Cout + GBM - 1) / GBM) * ((Cin + GBN - 1) / GBN);
-    int64_t want = 512 / (tiles > 0 ? tiles : 1);          // enough workgroups for two per CU
-    if (want < 1) want = 1;
-    if (want > N) want = N;
-    const int64_t chunk = (N + want - 1) / want;
-    return (N + chunk - 1) / chunk;
+    int64_t zs;
+    int ks, kp;
+    wgrad_split(N, Cin, Cout, T, &zs, &ks, &kp);
+    return zs * ks;
 }
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
@@ -1314,16 +1351,19 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         if (rc != PSND_OK) return rc;
     }
     if (gw) {
-        const int64_t slabs = psnd_linear1x1_wgrad_slabs(N, Cin, Cout, T);
+        int64_t zslabs;
+        int ks, kp;
+        wgrad_split(N, Cin, Cout, T, &zslabs, &ks, &kp);
+        const int64_t slabs = zslabs * ks;
         GemmParams p = {};
         p.A = gy, p.B = x, p.C = gw_part, p.bias = nullptr, p.amask = ymask, p.bmask = nullptr;
         p.M = Cout, p.N = Cin, p.K = (int)T, p.Z = (int)N;
         p.sAm = T, p.sAk = 1, p.sAz = (long long)Cout * T, p.sBk = 1, p.sBn = T, p.sBz = (long long)Cin * T, p.sCm = Cin, p.sCz = 0;
-        p.zchunk = (int)((N + slabs - 1) / slabs), p.sCslab = (long long)Cout * Cin;
+        p.zchunk = (int)((N + zslabs - 1) / zslabs), p.sCslab = (long long)Cout * Cin, p.ksplit = ks, p.kpart = kp;
         rc = gemm_launch(p, false, false, (int)slabs, st, "linear1x1_bwd(weight)", bf16 != 0);
         if (rc != PSND_OK) return rc;
         const long long n = (long long)Cout * Cin;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, gw_part, (int)slabs, n, gw);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, gw_part, (int)slabs, n, gw);
         PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
     }
     if (gbias) {
