@@ -358,3 +358,39 @@ def test_positional_encoding_kernel_matches_the_torch_formulation():
         g = torch.randn_like(ref)
         y.backward(g)
         assert torch.equal(x.grad, g * (C ** 0.5))
+
+
+@pytest.mark.parametrize('N,H,C,T,masked', [(2, 4, 256, 173, True), (3, 4, 64, 50, True), (2, 4, 256, 1292, True), (2, 2, 96, 77, False),
+                                            (1, 4, 128, 33, False)])
+def test_attention_bf16_single_pass_forward(N, H, C, T, masked):
+    """psnd_mha_fwd, bf16 operands, WITHOUT the returned attention tensor: the one-pass form (running column maximum, rescaled
+    accumulator - attn_fwd_bf16_kernel<HDP, false>) against float64 with rounded operands (4e-3 of the largest output), against the two-pass instance (want_att = True), and its gradients (the backward recomputes the
+    probabilities from the statistics this pass writes) against exact float64; padded queries are exactly zero."""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 100 + T)
+    kvq = torch.randn(N, 3 * C, T, device=dev)
+    mask = None
+    if masked:
+        lens = torch.linspace(T, max(T // 3, 4), N).long()
+        mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
+    m8 = None if mask is None else mask.to(torch.uint8)
+    gout = torch.randn(N, C, T, device=dev)
+    x = kvq.clone().requires_grad_(True)
+    out, att = K.AttentionKVQ.apply(x, m8, H, False, True)
+    assert att is None or att.numel() == 0
+    (out * gout).sum().backward()
+    o_r, _, _ = _attention_float64(kvq, mask, H, gout, None, True)
+    o_x, _, g_x = _attention_float64(kvq, mask, H, gout, None, False)
+    # 4e-3 of the largest output: the one-pass form rounds exp(s - running maximum) to bf16 (2^-9 each, random signs over the keys), the
+    # emulation rounds the final probabilities - the same size of error, not the same values
+    assert float((out.double() - o_r).abs().max()) <= 4e-3 * float(o_r.abs().max())
+    x2 = kvq.clone().requires_grad_(True)
+    out2, _ = K.AttentionKVQ.apply(x2, m8, H, True, True)
+    assert float((out - out2).abs().max()) <= 4e-3 * float(o_r.abs().max())
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())           # noqa: E731
+    assert rel(out, o_x) <= 2e-2 and rel(x.grad, g_x) <= 2e-2, (rel(out, o_x), rel(x.grad, g_x))
+    if masked:
+        L = int(lens[-1])
+        assert float(out[-1, :, L:].abs().max()) == 0
+        assert float(x.grad.view(N, 3, C, T)[-1, :, :, L:].abs().max()) == 0
