@@ -582,6 +582,75 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_kernel(AttnParams p
     //   iteration it: barrier | request K(it+2), V(it+1) | S(it+1) from sK[(it+1)&1]  ||  softmax of S(it) | O += V(it) P from
     //   sV[it&1] | commit K(it+2) -> sK[it&1] (K(it) was consumed in iteration it-1), V(it+1) -> sV[(it+1)&1]
     float pk[HDP / 8], pv[HDP / 8];
+    if constexpr (!ATT) {
+        // ONE pass when the probabilities are not returned (round 4; see attn_fwd_bf16_kernel): running column maximum, rescaled accumulator
+        float mx = -INFINITY, sum = 0.f;
+        f32x16 O[HDP / 32];
+#pragma unroll
+        for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) O[mt][i] = 0.f;
+        load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);
+        load_tile<HDP>(Kp, T, p.d, 32, sK[1], tid);
+        load_tile<HDP>(Vp, T, p.d, 0, sV[0], tid);
+        fill_key_bits(s_kb, mrow, p.T, ntile, tid);
+        __syncthreads();
+        f32x16 s;
+        mma_tile_frag<HDP>(sK[0], qf, li, kk, s);
+        for (int it = 0; it < ntile; ++it) {
+            __syncthreads();
+            fetch_tile<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+            fetch_tile<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
+            const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+            f32x16 sn;
+            mma_tile_frag<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
+            float tm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = (bad >> rho(r, kk)) & 1u ? -INFINITY : s[r] * p.scale;
+                s[r] = v;
+                tm = fmaxf(tm, v);
+            }
+            tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+            const float m2 = fmaxf(mx, tm);
+            const float m2s = m2 > -INFINITY ? m2 : 0.f;
+            const float alpha = __expf(mx - m2s);
+            float asum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(s[r] - m2s);
+                s[r] = e;
+                asum += e;
+            }
+            sum = sum * alpha + asum;
+            mx = m2;
+#pragma unroll
+            for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[mt][i] *= alpha;
+            mma_tile_acc<HDP>(sV[it & 1], s, li, kk, O);
+            commit_tile<HDP>(sK[it & 1], tid, pk);
+            commit_tile<HDP>(sV[(it + 1) & 1], tid, pv);
+            s = sn;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const bool qpad = tq < p.T && mrow && mrow[tq];
+        const float inv = 1.f / sum;
+        const bool nancol = !(sum > 0.f);
+        if (tq < p.T && kk == 0) {
+            p.stats[((long long)b * T + tq) * 2] = mx;
+            p.stats[((long long)b * T + tq) * 2 + 1] = inv;
+        }
+        if (tq < p.T) {
+            float *op = p.out + ((long long)n * p.C + h * p.d) * T + tq;
+#pragma unroll
+            for (int mt = 0; mt < HDP / 32; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mt * 32 + rho(r, kk) < p.d) op[(long long)(mt * 32 + rho(r, kk)) * T] = qpad ? 0.f : (nancol ? NAN : O[mt][r] * inv);
+        }
+        return;
+    }
     // ---- pass 1
     float mx = -INFINITY, sum = 0.f;
     load_tile<HDP>(Kp, T, p.d, 0, sK[0], tid);

@@ -394,3 +394,29 @@ def test_attention_bf16_single_pass_forward(N, H, C, T, masked):
         L = int(lens[-1])
         assert float(out[-1, :, L:].abs().max()) == 0
         assert float(x.grad.view(N, 3, C, T)[-1, :, :, L:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('N,H,C,T,masked', [(2, 4, 256, 173, True), (3, 4, 64, 50, True), (2, 2, 96, 77, False), (1, 4, 256, 700, True)])
+def test_attention_fp32_single_pass_forward(N, H, C, T, masked):
+    """psnd_mha_fwd with exact fp32 products and no returned attention tensor (attn_fwd_kernel<HDP, false>, the one-pass form) against
+    float64 and against the two-pass instance; gradients against float64."""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N * 10 + T)
+    kvq = torch.randn(N, 3 * C, T, device=dev)
+    mask = None
+    if masked:
+        lens = torch.linspace(T, max(T // 3, 4), N).long()
+        mask = (torch.arange(T)[None, :] >= lens[:, None]).to(dev)
+    m8 = None if mask is None else mask.to(torch.uint8)
+    gout = torch.randn(N, C, T, device=dev)
+    x = kvq.clone().requires_grad_(True)
+    out, _ = K.AttentionKVQ.apply(x, m8, H, False, False)
+    (out * gout).sum().backward()
+    o_x, _, g_x = _attention_float64(kvq, mask, H, gout, None, False)
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())           # noqa: E731
+    assert rel(out, o_x) <= 1e-5 and rel(x.grad, g_x) <= 1e-4, (rel(out, o_x), rel(x.grad, g_x))
+    out2, _ = K.AttentionKVQ.apply(kvq.clone(), m8, H, True, False)
+    assert float((out - out2).abs().max()) <= 1e-5 * float(o_x.abs().max())
+    if masked and int(lens[-1]) < T:
+        assert float(out[-1, :, int(lens[-1]):].abs().max()) == 0
