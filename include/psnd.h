@@ -298,6 +298,10 @@ int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout
  *  psnd_convtr1d_wnorm_bwd: slabs -> g_v (Cin, Cout, K), g_g (Cin). */
 int psnd_convtr1d_prep(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int stride, int Cr, int Cip,
                        void *wf, void *wb, float *bias_rep, void *stream);
+/* psnd_convtr1d_prep for n transposed convs in ONE launch.  descs_dev: device array of n records
+ *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cin, Cout, K, u, Cr, Cip, blk0, pad; }   (80 bytes; blk0 = sum of the Cin of the
+ *   records before it), total_blocks = the sum of all Cin.  Same packs as psnd_convtr1d_prep; the pads of wf / wb are not written (zero once). */
+int psnd_convtr1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream);
 int psnd_convtr1d_cl_fwd(const void *xa, const void *wf, const float *bias_rep, int64_t N, int Lp, int L, int HP, int Cip, int Cr,
                          int stride, int padding, int LpO, int HPO, float act_slope, void *out_raw, void *out_act, void *stream);
 int psnd_convtr1d_cl_wgrad_splits(int64_t N, int Lp, int Cip, int Cr, int stride);

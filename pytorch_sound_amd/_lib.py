@@ -84,6 +84,7 @@ SIGNATURES = {
     'psnd_l1_loss_combine': (_INT, [_P, _P, _P, _INT, _P, _P, _P]),
     'psnd_conv_stats': (_INT, [_P, _INT]),
     'psnd_conv_pair_stats': (_INT, [_P, _INT]),
+    'psnd_convtr1d_prep_multi': (_INT, [_P, _INT, _INT, _P]),
     'psnd_convtr1d_prep': (_INT, [_P, _P, _P, _INT, _INT, _INT, _INT, _INT, _INT, _P, _P, _P, _P]),
     'psnd_convtr1d_cl_fwd': (_INT, [_P, _P, _P, _I64, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _INT, _F, _P, _P, _P]),
     'psnd_convtr1d_cl_wgrad_splits': (_INT, [_I64, _INT, _INT, _INT, _INT]),

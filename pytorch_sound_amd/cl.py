@@ -604,7 +604,7 @@ class ConvTransposeCL(torch.autograd.Function):
     multiplied.  weight_v: (Cin, Cout, K), weight_g: (Cin, 1, 1) - weight norm over dim 0, as torch's for nn.ConvTranspose1d."""
 
     @staticmethod
-    def forward(ctx, xa, weight_v, weight_g, bias, shape, out_shape, stride, padding, act_slope):
+    def forward(ctx, xa, weight_v, weight_g, bias, shape, out_shape, stride, padding, act_slope, prepped=None):
         ctx.set_materialize_grads(False)     # an unused output hands None to backward, not a zero-filled tensor
         _need(xa, torch.bfloat16)
         Cin, Cout, K = weight_v.shape
@@ -617,15 +617,19 @@ class ConvTransposeCL(torch.autograd.Function):
         dev = xa.device
         v32, g32 = weight_v.detach().contiguous(), weight_g.detach().contiguous()
         b32 = None if bias is None else bias.detach().contiguous()
-        wf = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
-        wb = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
-        bp = torch.empty(stride * Cr, dtype=torch.float32, device=dev)
+        if prepped is not None:                      # packs made by prep_all_convtr() for all upsamplers in one launch
+            wf, wb, bp = prepped
+        else:
+            wf = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+            wb = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+            bp = torch.empty(stride * Cr, dtype=torch.float32, device=dev)
         both = torch.zeros((2, shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)     # (one fill for the two outputs' halo rows)
         raw, act = both[0], both[1]
         with torch.cuda.device(dev):
             st = stream_ptr(dev)
-            check(lib().psnd_convtr1d_prep(ptr(v32), ptr(g32), ptr(b32), Cin, Cout, K, stride, Cr, Cip, ptr(wf), ptr(wb), ptr(bp), st),
-                  'psnd_convtr1d_prep')
+            if prepped is None:
+                check(lib().psnd_convtr1d_prep(ptr(v32), ptr(g32), ptr(b32), Cin, Cout, K, stride, Cr, Cip, ptr(wf), ptr(wb), ptr(bp), st),
+                      'psnd_convtr1d_prep')
             check(lib().psnd_convtr1d_cl_fwd(ptr(xa), ptr(wf), ptr(bp), shape.N, shape.Lp, shape.L, shape.HP, Cip, Cr, stride, padding,
                                              out_shape.Lp, out_shape.HP, float(act_slope), ptr(raw), ptr(act), st), 'psnd_convtr1d_cl_fwd')
         ctx.geo = (shape, out_shape, stride, padding, float(act_slope), Cin, Cout, K, Cip, Cr)
@@ -658,7 +662,40 @@ class ConvTransposeCL(torch.autograd.Function):
         g_bias = None
         if ctx.has_bias:       # column sums of the combined gradient (halo rows are zero)
             g_bias = torch.sum((g_eff if g_eff is not None else g_raw).view(-1, Cr), 0, dtype=torch.float32)[:Cout]
-        return gx, gv, gg, g_bias, None, None, None, None, None
+        return gx, gv, gg, g_bias, None, None, None, None, None, None
+
+
+def prep_all_convtr(owner, ups):
+    """weight norm (over dim 0) + both bf16 packs + replicated bias of every transposed conv in `ups` (WNConvTranspose1d modules with
+    k = 2 * stride) in ONE launch (psnd_convtr1d_prep_multi); buffers and the descriptor table cached on `owner`.
+    Returns {id(up): (wf, wb, bp)} for ConvTransposeCL.apply(..., prepped)."""
+    import struct
+    key = tuple((u.weight_v.data_ptr(), u.weight_g.data_ptr(), 0 if u.bias is None else u.bias.data_ptr(), tuple(u.weight_v.shape), u.stride)
+                for u in ups)
+    cache = getattr(owner, '_cl_prep_convtr_cache', None)
+    if cache is None or cache['key'] != key:
+        dev = ups[0].weight_v.device
+        packs, recs, blk0 = {}, [], 0
+        for u in ups:
+            Cin, Cout, K = u.weight_v.shape
+            Cip, Cr = round_up(Cin, ALIGN_C), round_up(Cout, ALIGN_C)
+            wf = torch.zeros(2 * u.stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+            wb = torch.zeros(2 * u.stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
+            bp = torch.zeros(u.stride * Cr, dtype=torch.float32, device=dev)
+            packs[id(u)] = (wf, wb, bp)
+            recs.append(struct.pack('<6Q8i', u.weight_v.data_ptr(), u.weight_g.data_ptr(), 0 if u.bias is None else u.bias.data_ptr(),
+                                    wf.data_ptr(), wb.data_ptr(), bp.data_ptr(), Cin, Cout, K, u.stride, Cr, Cip, blk0, 0))
+            blk0 += Cin
+        table = torch.frombuffer(bytearray(b''.join(recs)), dtype=torch.uint8).to(dev)
+        cache = {'key': key, 'packs': packs, 'table': table, 'n': len(ups), 'blocks': blk0, 'dev': dev}
+        owner._cl_prep_convtr_cache = cache
+    for u in ups:
+        if not (u.weight_v.is_contiguous() and u.weight_g.is_contiguous() and u.weight_v.dtype == torch.float32):
+            raise _lib.PsndError('prep_all_convtr: fp32 contiguous weight_v / weight_g expected')
+    with torch.cuda.device(cache['dev']):
+        check(lib().psnd_convtr1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], stream_ptr(cache['dev'])),
+              'psnd_convtr1d_prep_multi')
+    return cache['packs']
 
 
 class FanOutCL(torch.autograd.Function):

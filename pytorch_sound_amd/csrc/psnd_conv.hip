@@ -2260,6 +2260,57 @@ static int convtr_check(const char *what, int64_t N, int Lp, int L, int HP, int 
     return PSND_OK;
 }
 
+// psnd_convtr1d_prep for MANY transposed convs in one launch (the four upsamplers of a HiFi-GAN generator: four ~10 us launches were launch
+// latency).  One workgroup per input channel of every layer; the pads of wf / wb are never written (zero them once).
+namespace {
+struct ConvtrPrepDesc {           // 80 bytes, mirrored by pytorch_sound_amd/cl.py ('<6Q8i')
+    const float *v, *g, *bias;
+    bf16_t *wf, *wb;
+    float *bp;
+    int Cin, Cout, K, u, Cr, Cip, blk0, pad_;
+};
+__global__ __launch_bounds__(256) void convtr_prep_multi_kernel(const ConvtrPrepDesc *descs, int n) {
+    __shared__ float red[4];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk0 <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ConvtrPrepDesc d = descs[lo];
+    const int ci = blockIdx.x - d.blk0, nn = d.Cout * d.K;
+    if (ci >= d.Cin) return;
+    const float *vr = d.v + (size_t)ci * nn;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < nn; i += 256) ss = __builtin_fmaf(vr[i], vr[i], ss);
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float scale = d.g[ci] / __builtin_sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const int Nn = d.u * d.Cr;
+    for (int i = threadIdx.x; i < nn; i += 256) {
+        const int co = i / d.K, jk = i - co * d.K;
+        const int tap = jk / d.u, phi = jk - tap * d.u;
+        const bf16_t w = f2bf(vr[i] * scale);
+        d.wf[pack_index(2, tap, phi * d.Cr + co, ci, Nn, d.Cip)] = w;
+        d.wb[pack_index(2, tap, ci, phi * d.Cr + co, d.Cip, Nn)] = w;
+    }
+    if (ci == 0)
+        for (int i = threadIdx.x; i < Nn; i += 256) {
+            const int co = i % d.Cr;
+            d.bp[i] = (d.bias && co < d.Cout) ? d.bias[co] : 0.f;
+        }
+}
+}  // namespace
+
+extern "C" int psnd_convtr1d_prep_multi(const void *descs_dev, int n, int total_blocks, void *stream) {
+    if (!descs_dev || n <= 0 || total_blocks <= 0) PSND_FAIL(PSND_E_ARG, "convtr1d_prep_multi: bad arguments");
+    hipLaunchKernelGGL(convtr_prep_multi_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const ConvtrPrepDesc *>(descs_dev), n);
+    PSND_CHECK_LAUNCH("convtr1d_prep_multi");
+    return PSND_OK;
+}
+
 extern "C" int psnd_convtr1d_prep(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int stride, int Cr, int Cip,
                                   void *wf, void *wb, float *bias_rep, void *stream) {
     if (!v || !g || !wf || !wb || !bias_rep) PSND_FAIL(PSND_E_ARG, "convtr1d_prep: null pointer");

@@ -246,6 +246,7 @@ class Generator(nn.Module):
         nst = len(self.ups)
         convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
         prep = cl.prep_all(self, convs)                            # all weight-norm packs of the Conv1d layers: one launch
+        prep_up = cl.prep_all_convtr(self, list(self.ups))         # ... and of the upsamplers: one more
         # halo of a stage's buffers = the widest tap reach of the convs that read them
         halo = [max(self.conv_pre.padding, 1)]
         for i in range(nst):
@@ -258,7 +259,7 @@ class Generator(nn.Module):
             last = i + 1 == nst
             out_shape = cl.CLShape(N, T * up.stride, halo[i + 1])
             x_raw, x_act = cl.ConvTransposeCL.apply(xa, up.weight_v, up.weight_g, up.bias, shape, out_shape, up.stride, up.padding,
-                                                    LRELU_SLOPE)
+                                                    LRELU_SLOPE, prep_up[id(up)])
             shape, T = out_shape, out_shape.L
             stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
             rs = []
