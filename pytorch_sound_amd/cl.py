@@ -129,6 +129,16 @@ class MaskHeadCL(torch.autograd.Function):
 # the NaN flag (`loss != loss`, trainer.py:205) of the fused loss nodes below: written by the launch that forms the loss; the caller that receives
 # the loss tensor attaches it as `loss.psnd_nan_flag`, which Trainer._nan_flag takes instead of a launch of its own
 LAST_LOSS_NAN_FLAG = [None]
+# where that flag should be written when somebody has a place for it: a data-parallel reducer registers the spare slot behind its last gradient
+# bucket (distributed.FlatGradReducer: the flag rides along with the gradients) - FlatGradReducer.set_flag then has nothing to copy
+NAN_FLAG_DEST = [None]
+
+
+def _nan_flag_tensor(dev):
+    dest = NAN_FLAG_DEST[0]
+    if dest is not None and dest.device == dev and dest.dtype == torch.float32 and dest.numel() == 1:
+        return dest.view(())
+    return torch.empty((), dtype=torch.float32, device=dev)
 
 
 class MaskHeadSpectralL1CL(torch.autograd.Function):
@@ -169,7 +179,7 @@ class MaskHeadSpectralL1CL(torch.autograd.Function):
             parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
             nbs = (ctypes.c_int64 * 2)(nb1, nb2)
             sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
-            nan_flag = torch.empty((), dtype=torch.float32, device=dev)
+            nan_flag = _nan_flag_tensor(dev)
             check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), ptr(nan_flag), st), 'psnd_l1_loss_combine')
         LAST_LOSS_NAN_FLAG[0] = nan_flag
         ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())
@@ -247,7 +257,7 @@ class MaskHeadSpectralL1NFK(torch.autograd.Function):
             parts = (ctypes.c_void_p * 2)(part.data_ptr(), part.data_ptr() + 8 * nb1)
             nbs = (ctypes.c_int64 * 2)(nb1, nb2)
             sc = (ctypes.c_double * 2)(float(w1) / mag.numel(), float(w2) / mel_ref.numel())
-            nan_flag = torch.empty((), dtype=torch.float32, device=dev)
+            nan_flag = _nan_flag_tensor(dev)
             check(lib().psnd_l1_loss_combine(parts, nbs, sc, 2, ptr(out), ptr(nan_flag), st), 'psnd_l1_loss_combine')
         LAST_LOSS_NAN_FLAG[0] = nan_flag
         ctx.cfg = (shape, M, log_kind, float(log_offset), pre, lo, hi, float(w1) / mag.numel(), float(w2) / mel_ref.numel())

@@ -186,6 +186,7 @@ class FlatGradReducer:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
             from . import cl
             cl.GRAD_SINK = self      # conv-chain nodes hand their weight gradients over from inside their backward (cl.py)
+            cl.NAN_FLAG_DEST[0] = self._flag     # a fused loss node writes the step's NaN flag straight into the spare slot (set_flag: no copy)
 
     @staticmethod
     def auto_bucket_bytes(total_bytes: int, target_buckets: int = 6) -> int:
@@ -271,6 +272,8 @@ class FlatGradReducer:
 
     def set_flag(self, flag):
         """place this rank's NaN flag (0 / 1) in the spare slot BEFORE the last bucket is reduced"""
+        if flag.data_ptr() == self._flag.data_ptr() and flag.dtype == self._flag.dtype:
+            return                                   # written in place by the launch that formed the loss (cl.NAN_FLAG_DEST)
         self._flag.copy_(flag.detach().reshape(1).to(self._flag.dtype))
 
     @property
@@ -449,6 +452,8 @@ class FlatGradReducer:
         from . import cl
         if cl.GRAD_SINK is self:
             cl.GRAD_SINK = None
+        if cl.NAN_FLAG_DEST[0] is not None and cl.NAN_FLAG_DEST[0].data_ptr() == self._flag.data_ptr():
+            cl.NAN_FLAG_DEST[0] = None
         for h in self._handles:
             h.remove()
         self._handles = []
