@@ -107,7 +107,7 @@ def test_unsupported_geometry_fails_loudly():
         g(torch.randn(1, 80, 8, device='cuda'))
 
 
-@pytest.mark.parametrize('arch', ['hifi_gan_v2', 'hifi_gan_v3'])
+@pytest.mark.parametrize('arch', ['hifi_gan_v1', 'hifi_gan_v2', 'hifi_gan_v3'])
 def test_folded_generator_decodes_on_the_cl_kernels(arch):
     """InterfaceHifiGAN's decoder (interface/hifi_gan.py:66-117): weight norm removed, torch.no_grad - still on the gfx950 conv
     kernels ((v, g) = (w, ||w||)), equal to the fp32 torch path within the bf16 tolerance; state dict = weight / bias only."""
@@ -130,7 +130,8 @@ def test_folded_generator_decodes_on_the_cl_kernels(arch):
         got = gen(mel.to('cuda:0')).cpu()
     assert got.shape == want.shape
     err = float((got - want).norm() / want.norm())
-    assert err < (4e-2 if on_cl else 1e-4), err
+    # measured over seeds and the three architectures: 0.4e-3 .. 2.2e-3 relative L2 (bf16 activations between ~20 convs, fp32 accumulation)
+    assert err < (5e-3 if on_cl else 1e-4), err
 
 
 def test_fanout_sums_stage_gradients_in_one_launch():
