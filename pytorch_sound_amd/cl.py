@@ -397,6 +397,17 @@ def _run_sections(dev, nsec, sides, fn):
         main.wait_stream(sd)
 
 
+_BRANCH_STREAMS = {}
+
+
+def branch_streams(dev, n):
+    """n side streams for independent branches of a model graph (the resblocks of a HiFi-GAN stage)"""
+    pool = _BRANCH_STREAMS.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 _WGRAD_STREAMS = {}
 
 

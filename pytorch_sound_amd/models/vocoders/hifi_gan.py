@@ -13,6 +13,7 @@ pinned by tests/golden/hifigan.npz:
 """
 from argparse import Namespace
 
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -194,6 +195,7 @@ class Generator(nn.Module):
     #      between two layout kernels) or 'kernel' (a convolution over zero-spread rows).
     use_cl = True
     cl_upsample = 'polyphase'
+    cl_branches = os.environ.get('PSND_HIFIGAN_BRANCHES', '1') == '1'      # a stage's resblocks on parallel streams (0: one stream, the A/B of tools/r04/ab_branches.sh)
     _CL_MAX_REACH = 40          # tap reach (k-1)/2*dilation the conv kernel's A-tile ring is sized for (25; 40 for k <= 7)
 
     def _all_convs(self):
@@ -266,9 +268,26 @@ class Generator(nn.Module):
             # every resblock of the stage reads (x_raw, x_act): aliases whose gradients come back summed by ONE launch (cl.FanOutCL)
             fan = cl.FanOutCL.apply(x_raw, x_act, len(stage)) if (len(stage) > 1 and torch.is_grad_enabled() and x_raw.requires_grad) \
                 else (x_raw, x_act) * len(stage)
-            for bi, block in enumerate(stage):
+            def run_block(bi):
+                block = stage[bi]
                 fn = cl.resblock1_cl if hasattr(block, 'convs1') else cl.resblock2_cl
-                rs.append(fn(block, fan[2 * bi], fan[2 * bi + 1], shape, prep=prep)[0])
+                return fn(block, fan[2 * bi], fan[2 * bi + 1], shape, prep=prep)[0]
+            if self.cl_branches and len(stage) > 1 and cl.AUTO_SECTIONS and os.environ.get('PSND_CL_SECTIONS', 'auto') in ('auto', '1'):
+                # the resblocks of a stage are independent: one stream each (inside the step graph: parallel branches, ONE fork and
+                # join per stage and direction - autograd runs a node's backward on the stream of its forward)
+                main = torch.cuda.current_stream(x.device)
+                sides = cl.branch_streams(x.device, len(stage) - 1)
+                for sd in sides:
+                    sd.wait_stream(main)
+                rs = [None] * len(stage)
+                for bi, sd in enumerate(sides, 1):
+                    with torch.cuda.stream(sd):
+                        rs[bi] = run_block(bi)
+                rs[0] = run_block(0)
+                for sd in sides:
+                    main.wait_stream(sd)
+            else:
+                rs = [run_block(bi) for bi in range(len(stage))]
             xa = cl.MeanActCL.apply(0.01 if last else LRELU_SLOPE, *rs)      # last: F.leaky_relu's default slope, as the reference
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
