@@ -295,6 +295,8 @@ int psnd_conv1d_prep(const float *v, const float *g, const float *bias, int Cout
  *  psnd_convtr1d_cl_bwd: g = g_raw + g_act * leaky'(act) (either part may be NULL) -> gx (N, Lp, Cip), g_eff (N, LpO, Cr; the
  *                       combined gradient, required when g_act is given: its column sums are the bias gradient) and the
  *                       weight-gradient slabs gw_part fp32 [S][2][Cip][stride * Cr], S = psnd_convtr1d_cl_wgrad_splits(...).
+ *                       gw_part == NULL: the input-gradient launch alone; gx == NULL: the weight-gradient launch alone (g_eff as
+ *                       the first call wrote it) - the two roles of one backward on two streams.
  *  psnd_convtr1d_wnorm_bwd: slabs -> g_v (Cin, Cout, K), g_g (Cin). */
 int psnd_convtr1d_prep(const float *v, const float *g, const float *bias, int Cin, int Cout, int K, int stride, int Cr, int Cip,
                        void *wf, void *wb, float *bias_rep, void *stream);

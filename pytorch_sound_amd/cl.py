@@ -12,6 +12,7 @@ entirely on hand-written kernels: weight prep (weight norm + bf16 packs), implic
 gradient), split-K weight gradient with all taps / bias gradient fused, weight-norm backward.
 """
 import ctypes
+import os
 import torch
 
 from . import _lib
@@ -397,7 +398,10 @@ def _run_sections(dev, nsec, sides, fn):
         main.wait_stream(sd)
 
 
+# the parameter-side launches of a transposed conv's backward on a side stream / graph branch (ConvTransposeCL.backward)
+BRANCH_PARAM_GRADS = os.environ.get('PSND_BRANCH_PARAM_GRADS', '1') == '1'
 _BRANCH_STREAMS = {}
+_PARAM_STREAM = {}
 
 
 def branch_streams(dev, n):
@@ -655,6 +659,7 @@ class ConvTransposeCL(torch.autograd.Function):
                                              out_shape.Lp, out_shape.HP, float(act_slope), ptr(raw), ptr(act), st), 'psnd_convtr1d_cl_fwd')
         ctx.geo = (shape, out_shape, stride, padding, float(act_slope), Cin, Cout, K, Cip, Cr)
         ctx.has_bias = bias is not None
+        ctx.params = (weight_v, weight_g, bias)
         ctx.save_for_backward(xa, v32, g32, wb, act)
         return raw, act
 
@@ -673,16 +678,43 @@ class ConvTransposeCL(torch.autograd.Function):
         g_eff = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev) if g_act is not None else None
         gw = torch.empty((S, 2, Cip, stride * Cr), dtype=torch.float32, device=dev)
         gv, gg = torch.empty_like(v32), torch.empty_like(g32)
-        with torch.cuda.device(dev):
-            st = stream_ptr(dev)
+        # Parameter-side branch (weight gradient, weight-norm backward, bias gradient: needed only by the optimizer) on a side stream -
+        # inside the step graph a parallel branch next to the stage's resblock backward that follows, joined once at the end of the
+        # backward pass.  Only when these gradients are WRITTEN (no .grad yet: autograd then takes the tensors without a launch) and
+        # nothing else shares the hardware queues with the step (AUTO_SECTIONS).
+        side = None
+        if BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None and all(q is None or q.grad is None for q in ctx.params):
+            side = _PARAM_STREAM.get(dev.index)
+            if side is None:
+                side = _PARAM_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+
+        def param_side(st):
             check(lib().psnd_convtr1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None), slope, ptr(wb), ptr(xa),
                                              shape.N, shape.Lp, shape.L, shape.HP, Cip, Cr, stride, padding, out_shape.Lp, out_shape.HP,
-                                             ptr(gx), ptr(g_eff), ptr(gw), st), 'psnd_convtr1d_cl_bwd')
+                                             None, ptr(g_eff), ptr(gw), st), 'psnd_convtr1d_cl_bwd')
             check(lib().psnd_convtr1d_wnorm_bwd(ptr(gw), S, ptr(v32), ptr(g32), Cin, Cout, K, stride, Cr, Cip, ptr(gv), ptr(gg), st),
                   'psnd_convtr1d_wnorm_bwd')
-        g_bias = None
-        if ctx.has_bias:       # column sums of the combined gradient (halo rows are zero)
-            g_bias = torch.sum((g_eff if g_eff is not None else g_raw).view(-1, Cr), 0, dtype=torch.float32)[:Cout]
+            if ctx.has_bias:   # column sums of the combined gradient (halo rows are zero)
+                return torch.sum((g_eff if g_eff is not None else g_raw).view(-1, Cr), 0, dtype=torch.float32)[:Cout]
+            return None
+
+        with torch.cuda.device(dev):
+            check(lib().psnd_convtr1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(act if g_act is not None else None), slope, ptr(wb), ptr(xa),
+                                             shape.N, shape.Lp, shape.L, shape.HP, Cip, Cr, stride, padding, out_shape.Lp, out_shape.HP,
+                                             ptr(gx), ptr(g_eff), None, stream_ptr(dev)), 'psnd_convtr1d_cl_bwd')
+            if side is None:
+                g_bias = param_side(stream_ptr(dev))
+            else:
+                side.wait_stream(main)                       # the combined gradient is complete on the main stream
+                with torch.cuda.stream(side):
+                    gw = torch.empty_like(gw)
+                    gv, gg = torch.empty_like(gv), torch.empty_like(gg)
+                    g_bias = param_side(stream_ptr(dev))
+                for t in (g_raw, g_act, g_eff, act, xa, v32, g32, wb):     # allocated on the main stream, still read by the side stream
+                    if t is not None:
+                        t.record_stream(side)
+                _join_side_at_end_of_backward(dev, side)
         return gx, gv, gg, g_bias, None, None, None, None, None, None
 
 

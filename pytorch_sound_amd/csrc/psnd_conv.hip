@@ -2353,7 +2353,9 @@ extern "C" int psnd_convtr1d_cl_wgrad_splits(int64_t N, int Lp, int Cip, int Cr,
 extern "C" int psnd_convtr1d_cl_bwd(const void *g_raw, const void *g_act, const void *act, float act_slope, const void *wb, const void *xa,
                                     int64_t N, int Lp, int L, int HP, int Cip, int Cr, int stride, int padding, int LpO, int HPO, void *gx,
                                     void *g_eff, float *gw_part, void *stream) {
-    if ((!g_raw && !g_act) || (g_act && !act) || !wb || !xa || !gx || !gw_part) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_bwd: null pointer");
+    // gx == NULL: the weight-gradient launch alone (g_eff already holds the combined gradient); gw_part == NULL: the input-gradient launch alone
+    // - the two roles of one backward enqueued on two streams by two calls
+    if ((!g_raw && !g_act) || (g_act && !act) || !wb || !xa || (!gx && !gw_part)) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_bwd: null pointer");
     if (g_act && !g_eff) PSND_FAIL(PSND_E_ARG, "convtr1d_cl_bwd: g_eff (the combined gradient, N x LpO x Cr) is needed when g_act is given");
     int rc = convtr_check("convtr1d_cl_bwd", N, Lp, L, HP, Cip, Cr, stride, padding, LpO, HPO);
     if (rc != PSND_OK) return rc;
@@ -2368,8 +2370,11 @@ extern "C" int psnd_convtr1d_cl_bwd(const void *g_raw, const void *g_act, const 
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP, p.Ca = stride * Cr, p.Cb = Cip, p.k = 2, p.off0 = 0, p.dstep = 1, p.hm = 1;
     p.act_slope = 1.f, p.mask_slope = 1.f;
     p.up_role = 2, p.up_u = stride, p.up_p = padding, p.up_LpO = LpO, p.up_HPO = HPO, p.up_LO = L * stride, p.up_Cr = Cr;
-    rc = conv_launch(p, st, "convtr1d_cl_bwd(data)");
-    if (rc != PSND_OK) return rc;
+    if (gx) {
+        rc = conv_launch(p, st, "convtr1d_cl_bwd(data)");
+        if (rc != PSND_OK) return rc;
+    }
+    if (!gw_part) return PSND_OK;
     // weight gradient, operands swapped: gw[tap][ci][phi, co] = sum_l xa[l][ci] * G[l + tap][phi, co]
     WgradParams w;
     wgrad_params_plain(w);
