@@ -1352,6 +1352,10 @@ class ResBlockCL(torch.autograd.Function):
                 _run_sections(dev, nsec, sides, run)
                 for sd in set(used):
                     torch.cuda.current_stream(dev).wait_stream(sd)
+                # (measured, not kept: these two on the parameter stream as ConvTransposeCL.backward does - config-3 step 3.04 -> 3.10-3.15 ms,
+                #  config-2 step 0.666 -> 0.669 ms: the resblocks' weight-norm backward launches queue up behind each other on that stream.
+                #  Likewise at the config-2 size: the input layout change next to the weight prep + the backward packs next to the loss
+                #  node's backward, 0.655-0.660 -> 0.668-0.679 ms and one 3.3 ms block in 18 - tools/r04/ab_c2.sh)
                 wgrad_batch(wbatch)
                 finish([ci for ci in range(n) if descs[ci] is not None])
         return (g_raw, g_act, None, None, None, None, None, None) + tuple(grads)
