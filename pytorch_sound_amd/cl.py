@@ -404,6 +404,15 @@ _BRANCH_STREAMS = {}
 _PARAM_STREAM = {}
 
 
+def param_stream(dev):
+    """the stream of the parameter-side launches (BRANCH_PARAM_GRADS)"""
+    s = _PARAM_STREAM.get(dev.index)
+    if s is None:
+        s = _PARAM_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
+
 def branch_streams(dev, n):
     """n side streams for independent branches of a model graph (the resblocks of a HiFi-GAN stage)"""
     pool = _BRANCH_STREAMS.setdefault(dev.index, [])
@@ -684,9 +693,7 @@ class ConvTransposeCL(torch.autograd.Function):
         # nothing else shares the hardware queues with the step (AUTO_SECTIONS).
         side = None
         if BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None and all(q is None or q.grad is None for q in ctx.params):
-            side = _PARAM_STREAM.get(dev.index)
-            if side is None:
-                side = _PARAM_STREAM[dev.index] = torch.cuda.Stream(device=dev)
+            side = param_stream(dev)
         main = torch.cuda.current_stream(dev)
 
         def param_side(st):

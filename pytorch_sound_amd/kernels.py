@@ -509,6 +509,7 @@ class Linear1x1(torch.autograd.Function):
             check(lib().psnd_linear1x1_fwd(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), int(bool(bf16)), ptr(y), stream_ptr(x.device)),
                   'psnd_linear1x1_fwd')
         ctx.relu, ctx.has_bias, ctx.wshape, ctx.bf16 = bool(relu), bias is not None, tuple(w.shape), bool(bf16)
+        ctx.params = (w, bias)
         ctx.save_for_backward(x, w2, y if relu else None)
         return y
 
@@ -527,9 +528,31 @@ class Linear1x1(torch.autograd.Function):
         if need_w:
             slabs = int(lib().psnd_linear1x1_wgrad_slabs(N, Cin, Cout, T))
             part = torch.empty((slabs, Cout, Cin), dtype=torch.float32, device=dev)
+        # The parameter side (weight-gradient GEMM, slab sum, bias row sum: needed only by the optimizer) on the parameter stream - inside
+        # the step graph a branch next to the input-gradient chain that goes on, joined at the end of the backward pass (cl.py,
+        # BRANCH_PARAM_GRADS).  Only when these gradients are WRITTEN (leaf parameters without a .grad: autograd takes the tensors without
+        # a launch) and nothing else shares the hardware queues with the step.
+        from . import cl
+        side = None
+        if (need_x and (need_w or need_b) and cl.BRANCH_PARAM_GRADS and cl.AUTO_SECTIONS and cl.GRAD_SINK is None
+                and all(q is None or (q.is_leaf and q.grad is None) for q in ctx.params)):
+            side = cl.param_stream(dev)
         with torch.cuda.device(dev):
-            check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), ptr(gw), ptr(part), ptr(gb),
-                                           stream_ptr(dev)), 'psnd_linear1x1_bwd')
+            if side is None:
+                check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), ptr(gw), ptr(part), ptr(gb),
+                                               stream_ptr(dev)), 'psnd_linear1x1_bwd')
+            else:
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)                          # gy is complete on the main stream
+                check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), None, None, None,
+                                               stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                with torch.cuda.stream(side):
+                    check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), None, ptr(gw), ptr(part),
+                                                   ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                for t in (gy, y, x, w2, gw, part, gb):          # main-stream blocks the side stream reads / writes
+                    if t is not None:
+                        t.record_stream(side)
+                cl._join_side_at_end_of_backward(dev, side)
         return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None
 
 
