@@ -400,6 +400,10 @@ int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, 
                  int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
                  const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, void *stream);
+/* psnd_mha_bwd in parts (bit mask): 1 = delta, 2 = key / value gradients, 4 = query gradients (7 = psnd_mha_bwd).  The two gradient
+ * kernels need `delta` only and write disjoint rows of gkvq: a caller may enqueue them on two streams behind the delta launch. */
+int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
+                       const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, int parts, void *stream);
 
 /* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
  *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over

@@ -101,6 +101,7 @@ SIGNATURES = {
     'psnd_linear1x1_bwd': (_INT, [_P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _P, _P, _P, _P, _P]),
     'psnd_mha_fwd': (_INT, [_P, _P, _I64, _INT, _INT, _I64, _P, _P, _P, _INT, _P]),
     'psnd_mha_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _P, _P, _INT, _P]),
+    'psnd_mha_bwd_parts': (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _P, _P, _INT, _INT, _P]),
     'psnd_softmax_keys_fwd': (_INT, [_P, _P, _I64, _I64, _F, _P]),
     'psnd_softmax_keys_bwd': (_INT, [_P, _P, _I64, _I64, _F, _P, _P]),
     'psnd_polar_bwd': (_INT, [_P, _P, _P, _P, _I64, _P, _P, _P]),

@@ -1547,21 +1547,28 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     return PSND_OK;
 }
 
-extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
-                            const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, void *stream) {
+// parts: 1 = delta (the per-query-column dot products both gradient kernels read), 2 = key / value gradients, 4 = query gradients; the two
+// gradient kernels write disjoint rows of gkvq and need only `delta`, so a caller may enqueue them on two streams
+extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats,
+                                  const float *gout, const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16,
+                                  int parts, void *stream) {
     if (!kvq || !out || !stats || !gout || !delta || !gkvq) PSND_FAIL(PSND_E_ARG, "mha_bwd: null pointer");
+    if (parts < 1 || parts > 7) PSND_FAIL(PSND_E_ARG, "mha_bwd: parts=%d", parts);
     if (gatt && !att) PSND_FAIL(PSND_E_ARG, "mha_bwd: a gradient for `att` needs the att tensor of the forward pass");
     int rc = mha_check("mha_bwd", N, H, C, T);
     if (rc != PSND_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st, out, gout, att, gatt, (int)N, H, C,
-                       C / H, (long long)T, delta);
-    PSND_CHECK_LAUNCH("mha_bwd(delta)");
+    if (parts & 1) {
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st, out, gout, att, gatt, (int)N, H, C,
+                           C / H, (long long)T, delta);
+        PSND_CHECK_LAUNCH("mha_bwd(delta)");
+    }
     AttnParams p = {};
     p.kvq = kvq, p.mask = mask, p.stats = const_cast<float *>(stats), p.gout = gout, p.gatt = gatt, p.delta = delta, p.gkvq = gkvq;
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
-    if (bf16) {
+    if (!(parts & 2)) {
+    } else if (bf16) {
         if (p.gatt) {
             if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
@@ -1573,7 +1580,8 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
     } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_kernel<32, false>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_bwd_kv_kernel<64, false>), grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
-    if (bf16) {
+    if (!(parts & 4)) {
+    } else if (bf16) {
         if (p.gatt) {
             if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
@@ -1586,4 +1594,9 @@ extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const f
     else hipLaunchKernelGGL((attn_bwd_q_kernel<64, false>), grid, dim3(256), 0, st, p);
     PSND_CHECK_LAUNCH("mha_bwd(q)");
     return PSND_OK;
+}
+
+extern "C" int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,
+                            const float *gatt, int64_t N, int H, int C, int64_t T, float *delta, float *gkvq, int bf16, void *stream) {
+    return psnd_mha_bwd_parts(kvq, mask, out, att, stats, gout, gatt, N, H, C, T, delta, gkvq, bf16, 7, stream);
 }

@@ -5,6 +5,7 @@ by libpsnd_hip.so.  No function in this module has a CPU or eager fallback - a C
 or a missing library raises.
 """
 import math
+import os
 import numpy as np
 import torch
 
@@ -583,6 +584,11 @@ class PosEnc(torch.autograd.Function):
         return gx, None, None
 
 
+# measured, off: the two attention gradient kernels on two streams - config-4 block 2.24 -> 2.36 ms (both kernels fill the chip at 2-3 waves
+# per SIMD: next to each other each runs slower than the overlap returns; tools/r04/ab_c4.sh)
+ATTN_BWD_TWO_STREAMS = os.environ.get('PSND_ATTN_BWD_TWO_STREAMS', '0') == '1'
+
+
 class AttentionKVQ(torch.autograd.Function):
     """MultiHeadAttention.scale_dot_att over all heads at once (modules.py:38-48, 61-79), straight from the fused projection:
     kvq (N, 3C, T) in the reference's chunk order K | V | Q, heads folded head-major -> out (N, C, T) (heads unfolded, ready for
@@ -627,9 +633,21 @@ class AttentionKVQ(torch.autograd.Function):
             gatt = gatt.contiguous()
         delta = torch.empty((H * N, T), dtype=torch.float32, device=dev)
         gkvq = torch.empty_like(kvq)
+        from . import cl
+        args = (ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq), ctx.bf16)
         with torch.cuda.device(dev):
-            check(lib().psnd_mha_bwd(ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq),
-                                     ctx.bf16, stream_ptr(dev)), 'psnd_mha_bwd')
+            if ATTN_BWD_TWO_STREAMS and cl.AUTO_SECTIONS and cl.GRAD_SINK is None:
+                # the key / value and the query gradient kernels need `delta` only and write disjoint rows of gkvq: two streams (inside
+                # the step graph: two branches) behind the delta launch, joined before the projection's backward reads gkvq
+                main, side = torch.cuda.current_stream(dev), cl.branch_streams(dev, 1)[0]
+                check(lib().psnd_mha_bwd_parts(*args, 1, stream_ptr(dev)), 'psnd_mha_bwd')
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    check(lib().psnd_mha_bwd_parts(*args, 4, stream_ptr(dev)), 'psnd_mha_bwd')
+                check(lib().psnd_mha_bwd_parts(*args, 2, stream_ptr(dev)), 'psnd_mha_bwd')
+                main.wait_stream(side)
+            else:
+                check(lib().psnd_mha_bwd(*args, stream_ptr(dev)), 'psnd_mha_bwd')
         return gkvq, None, None, None, None
 
 
