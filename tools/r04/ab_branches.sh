@@ -7,3 +7,4 @@ for v in 1 0 1 0; do
   PSND_BRANCH_PARAM_GRADS=$v python bench.py --steps 40 --warmup 10 --cpu-seconds 0 --no-legs 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed "s/^/config2 param_side=$v /"
 done
 timeout 500 python -m pytest tests/test_gpu_config3.py tests/test_gpu_hifigan.py tests/test_gpu_conv.py tests/test_gpu_trainer_graph.py -x -q 2>&1 | tail -3
+# measured: side branches on high-priority streams (torch.cuda.Stream(priority=-1)): config-3 step 3.02-3.09 -> 5.93-5.97 ms; not kept
