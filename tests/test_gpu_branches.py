@@ -1,0 +1,124 @@
+"""Round 4: independent parts of a step on parallel streams (graph branches).  The branches must not change a single bit: the same
+launches on the same data, only their order in time differs.
+  * the resblocks of a HiFi-GAN stage on cl.branch_streams (Generator.cl_branches),
+  * the parameter-side backward of the transposed convs / the 1x1 projections on cl.param_stream (cl.BRANCH_PARAM_GRADS),
+  * psnd_convtr1d_cl_bwd with either role alone, psnd_mha_bwd_parts against psnd_mha_bwd."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(seed=5):
+    from pytorch_sound_amd.models.vocoders.hifi_gan import Generator
+    torch.manual_seed(seed)
+    h = Namespace(resblock='1', upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=64,
+                  resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
+    g = Generator(h).cuda()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith('weight_v'):
+                p.mul_(10.0 if p.abs().max() < 0.1 else 1.0)
+    return g
+
+
+def _run(g, x, w):
+    g.zero_grad(set_to_none=True)
+    xc = x.clone().requires_grad_(True)
+    out = g(xc)
+    (out * w).sum().backward()
+    torch.cuda.synchronize()
+    return out.detach().clone(), xc.grad.clone(), {n: p.grad.clone() for n, p in g.named_parameters()}
+
+
+def test_generator_branches_are_bit_identical_to_one_stream(monkeypatch):
+    from pytorch_sound_amd import cl
+    g = _gen()
+    x = torch.randn(3, 80, 24, device='cuda')
+    w = torch.randn(3, 1, 24 * 8, device='cuda')
+    monkeypatch.setattr(g, 'cl_branches', False, raising=False)
+    monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', False)
+    o0, gx0, gp0 = _run(g, x, w)
+    monkeypatch.setattr(g, 'cl_branches', True, raising=False)
+    monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', True)
+    for _ in range(3):                                     # several passes: a missing join shows up as a changing result
+        o1, gx1, gp1 = _run(g, x, w)
+        assert torch.equal(o0, o1) and torch.equal(gx0, gx1)
+        for n in gp0:
+            assert torch.equal(gp0[n], gp1[n]), n
+
+
+def test_generator_branches_inside_a_captured_step(monkeypatch):
+    """forward + backward captured as one hipGraph with the branches on: replays reproduce the eager one-stream gradients"""
+    from pytorch_sound_amd import cl
+    g = _gen(7)
+    x = torch.randn(2, 80, 16, device='cuda')
+    w = torch.randn(2, 1, 16 * 8, device='cuda')
+    monkeypatch.setattr(g, 'cl_branches', False, raising=False)
+    monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', False)
+    o0, _, gp0 = _run(g, x, w)
+    monkeypatch.setattr(g, 'cl_branches', True, raising=False)
+    monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', True)
+    _run(g, x, w)                                          # warm-up: stream pools, pack caches
+    g.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = g(x)
+        (out * w).sum().backward()
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, o0)
+        for n, p in g.named_parameters():
+            assert torch.equal(p.grad, gp0[n]), n
+
+
+def test_linear1x1_parameter_branch_is_bit_identical(monkeypatch):
+    from pytorch_sound_amd import cl, kernels as K
+    torch.manual_seed(0)
+    lin = torch.nn.Conv1d(96, 160, 1).cuda()
+    x = torch.randn(4, 96, 300, device='cuda')
+    res = []
+    for flag in (False, True, True):
+        monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', flag)
+        lin.zero_grad(set_to_none=True)
+        xc = x.clone().requires_grad_(True)
+        y = K.Linear1x1.apply(xc, lin.weight, lin.bias, True, False)
+        (y * y).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach().clone(), xc.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert torch.equal(a, b)
+    # with a .grad already there autograd ACCUMULATES with a launch on the caller's stream: the branch must not be taken
+    monkeypatch.setattr(cl, 'BRANCH_PARAM_GRADS', True)
+    xc = x.clone().requires_grad_(True)
+    y = K.Linear1x1.apply(xc, lin.weight, lin.bias, True, False)
+    (y * y).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(lin.weight.grad, 2 * res[0][2], rtol=1e-6, atol=0) and torch.allclose(lin.bias.grad, 2 * res[0][3], rtol=1e-6, atol=0)
+
+
+def test_mha_bwd_parts_equal_the_whole(monkeypatch):
+    from pytorch_sound_amd._lib import lib, check, ptr, stream_ptr
+    torch.manual_seed(1)
+    N, H, C, T = 3, 4, 128, 200
+    dev = torch.device('cuda', 0)
+    kvq = torch.randn(N, 3 * C, T, device=dev)
+    out = torch.empty(N, C, T, device=dev)
+    stats = torch.empty(H * N, T, 2, device=dev)
+    gout = torch.randn(N, C, T, device=dev)
+    for bf16 in (0, 1):
+        check(lib().psnd_mha_fwd(ptr(kvq), None, N, H, C, T, ptr(out), None, ptr(stats), bf16, stream_ptr(dev)), 'fwd')
+        d0, g0 = torch.empty(H * N, T, device=dev), torch.full_like(kvq, float('nan'))
+        check(lib().psnd_mha_bwd(ptr(kvq), None, ptr(out), None, ptr(stats), ptr(gout), None, N, H, C, T, ptr(d0), ptr(g0), bf16, stream_ptr(dev)), 'bwd')
+        d1, g1 = torch.empty(H * N, T, device=dev), torch.full_like(kvq, float('nan'))
+        for part in (1, 4, 2):
+            check(lib().psnd_mha_bwd_parts(ptr(kvq), None, ptr(out), None, ptr(stats), ptr(gout), None, N, H, C, T, ptr(d1), ptr(g1), bf16, part,
+                                           stream_ptr(dev)), 'bwd parts')
+        torch.cuda.synchronize()
+        assert torch.equal(d0, d1) and torch.equal(g0, g1) and not torch.isnan(g1).any()
+    assert lib().psnd_mha_bwd_parts(ptr(kvq), None, ptr(out), None, ptr(stats), ptr(gout), None, N, H, C, T, ptr(d1), ptr(g1), 0, 8, stream_ptr(dev)) != 0
