@@ -358,7 +358,7 @@ _OLA_ENV = {}
 
 def _ola_envelope(window, n_fft, hop, F):
     """sum_f window^2[t - f hop] over F frames, length (F - 1) hop + n_fft - the overlap-add envelope STFT.inverse divides by
-    (transforms.py:90-99 builds it with a conv_transpose1d of ones; here an index_add of F shifted copies, cached per window / geometry:
+    (transforms.py:90-99 builds it with a conv_transpose1d of ones; here ceil(n_fft / hop) shifted block adds, cached per window / geometry:
     no library convolution for a HIP tensor)."""
     import weakref
     key = (id(window), window._version, n_fft, hop, F)
@@ -367,10 +367,15 @@ def _ola_envelope(window, n_fft, hop, F):
     if env is None:
         if len(_OLA_ENV) > 32:
             _OLA_ENV.clear()
+        # deterministic: the window squared cut into R = ceil(n_fft / hop) pieces of `hop` samples; piece r of every frame lands on the hop
+        # blocks r .. r + F - 1, added piece by piece in a fixed order (an index_add_ of F shifted copies adds with float atomics)
         w2 = (window.detach().float() * window.detach().float()).reshape(-1)
-        idx = (torch.arange(F, device=window.device) * hop).unsqueeze(1) + torch.arange(n_fft, device=window.device).unsqueeze(0)
-        env = torch.zeros((F - 1) * hop + n_fft, dtype=torch.float32, device=window.device)
-        env.index_add_(0, idx.reshape(-1), w2.repeat(F))
+        R = (n_fft + hop - 1) // hop
+        w2 = torch.nn.functional.pad(w2, (0, R * hop - n_fft)).view(R, hop)
+        blocks = torch.zeros((F - 1 + R, hop), dtype=torch.float32, device=window.device)
+        for r in range(R):
+            blocks[r:r + F] += w2[r]
+        env = blocks.reshape(-1)[:(F - 1) * hop + n_fft].contiguous()
         _OLA_ENV[key] = (weakref.ref(window), env)
     return env
 
