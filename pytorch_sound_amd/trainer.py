@@ -527,9 +527,11 @@ class Trainer:
         mode = red.graph_mode() if red is not None and red.active else None
         # static_prepare: prepare() returns the SAME buffers every step (features written in place) - they are the graph's inputs
         st['inputs'] = tuple(batch) if self.static_prepare else tuple(t.clone() for t in batch)
-        if (red is not None and red.active) or self.prefetch_copy or self.prefetch_prepare:
-            from . import cl
-            cl.AUTO_SECTIONS = False                   # see cl.py: no batch-section branches next to other live streams
+        from . import cl
+        # see cl.py: no extra graph branches (batch sections, resblock / parameter-side branches) next to other live streams; decided per
+        # capture - a Trainer without such streams captured later in the same process gets its branches back
+        cl.AUTO_SECTIONS = not ((red is not None and red.active) or bool(self.prefetch_copy) or bool(self.prefetch_prepare)
+                                or getattr(self, '_pre_stream', None) is not None)
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
         if getattr(self, '_root_grad', None) is None or self._root_grad.device != st['inputs'][0].device:
             self._root_grad = torch.ones((), dtype=torch.float32, device=st['inputs'][0].device)   # not inside the capture
