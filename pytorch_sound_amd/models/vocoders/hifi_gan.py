@@ -247,8 +247,11 @@ class Generator(nn.Module):
         N, _, T = x.shape
         nst = len(self.ups)
         convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
+        branches = (self.cl_branches and cl.AUTO_SECTIONS and x.is_cuda and os.environ.get('PSND_CL_SECTIONS', 'auto') in ('auto', '1'))
+        main = torch.cuda.current_stream(x.device)
         prep = cl.prep_all(self, convs)                            # all weight-norm packs of the Conv1d layers: one launch
-        prep_up = cl.prep_all_convtr(self, list(self.ups))         # ... and of the upsamplers: one more
+        prep_up = cl.prep_all_convtr(self, list(self.ups))         # ... and of the upsamplers: one more (next to the first on the parameter
+        #                                                            stream: measured, no difference - 2.97-3.07 against 3.00-3.09 ms)
         # halo of a stage's buffers = the widest tap reach of the convs that read them
         halo = [max(self.conv_pre.padding, 1)]
         for i in range(nst):
@@ -272,10 +275,9 @@ class Generator(nn.Module):
                 block = stage[bi]
                 fn = cl.resblock1_cl if hasattr(block, 'convs1') else cl.resblock2_cl
                 return fn(block, fan[2 * bi], fan[2 * bi + 1], shape, prep=prep)[0]
-            if self.cl_branches and len(stage) > 1 and cl.AUTO_SECTIONS and os.environ.get('PSND_CL_SECTIONS', 'auto') in ('auto', '1'):
+            if branches and len(stage) > 1:
                 # the resblocks of a stage are independent: one stream each (inside the step graph: parallel branches, ONE fork and
                 # join per stage and direction - autograd runs a node's backward on the stream of its forward)
-                main = torch.cuda.current_stream(x.device)
                 sides = cl.branch_streams(x.device, len(stage) - 1)
                 for sd in sides:
                     sd.wait_stream(main)
