@@ -392,6 +392,14 @@ __global__ __launch_bounds__(256) void softmax_keys_bwd4_kernel(const float *a, 
     }
 }
 
+// zero the statistics slots and the two parameter-gradient rows of one backward in ONE launch (three memset launches otherwise: ~5 us each
+// on the step's critical path)
+__global__ __launch_bounds__(256) void gn_zero_kernel(double *ws, long long nws, float *a, float *b, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nws) ws[i] = 0.0;
+    if (i < C) a[i] = 0.f, b[i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
@@ -415,10 +423,8 @@ extern "C" int psnd_groupnorm1_bwd(const float *gy, const float *x, const float 
     if (N < 0 || C <= 0 || T <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "groupnorm1_bwd: bad shape");
     if (N == 0) return PSND_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)N, s);
-    if (e == hipSuccess) e = hipMemsetAsync(ggamma, 0, sizeof(float) * (size_t)C, s);
-    if (e == hipSuccess) e = hipMemsetAsync(gbeta, 0, sizeof(float) * (size_t)C, s);
-    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "groupnorm1_bwd: memset: %s", hipGetErrorString(e));
+    const long long nws = 2ll * GN_SLOTS * (long long)N, nz = nws > C ? nws : C;
+    hipLaunchKernelGGL(gn_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, ws, nws, ggamma, gbeta, C);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws,
                        ggamma, gbeta);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws, gx);
