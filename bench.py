@@ -450,7 +450,8 @@ def _config3_leg(device, steps=40, warm=10):
     return {'ms_per_step': ms, 'value': N * T / SR / (ms * 1e-3), 'unit': 'audio-s/s', 'steps': steps, 'warmup': warm, 'n_gpus': 1,
             'dtype': 'bf16 conv operands, fp32 accumulate / features / optimizer',
             'workload': 'configs[2] on one GPU: hifi_gan_v1 (13.9 M parameters), 16 x 8192-sample segments at 22.05 kHz (F = 32), '
-                        'mel 1024/256/80 (HiFi-GAN framing), L1(mel(G(mel x)), mel x), Adam, hipGraph replay',
+                        'mel 1024/256/80 (HiFi-GAN framing), L1(mel(G(mel x)), mel x), Adam, hipGraph replay; the resblocks of a stage and the upsamplers\' '
+                        'parameter-side backward as parallel graph branches (DESIGN 4.4)',
             'model_params': sum(p.numel() for p in gen.parameters())}
 
 
@@ -504,7 +505,7 @@ def _config4_leg(device, steps=30, warm=6, T=1292):
             'dtype': 'bf16 operands under autocast, fp32 scores / statistics / accumulation',
             'workload': 'configs[3] block on one GPU: 80-mel -> 1x1 -> PositionalEncoding -> MultiHeadAttention(256, 4) -> '
                         'PointwiseFeedForward -> 1x1, batch 32 x %d frames (15-s bucket, lengths 0.8-1.0 of it, padding mask), masked L1, '
-                        'Adam, hipGraph replay' % T,
+                        'Adam, hipGraph replay; the 1x1 projections\' parameter-side backward as a parallel graph branch (DESIGN 4.4)' % T,
             'model_params': sum(p.numel() for p in net.parameters())}
 
 
