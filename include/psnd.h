@@ -367,6 +367,10 @@ int psnd_conv1d_cl_pair_bwd(const void *G, const void *wb2, const void *M1, floa
 int psnd_conv1d_wnorm_bwd(const float *gw_part, const float *gbias_part, int splits, const float *v, const float *g,
                           int Cout, int Cin, int k, int Cb, int Ca, float *gv, float *gg, float *gbias, void *stream);
 int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out, void *stream);
+/* out = tanh(from_cl(x)) - the generator's output non-linearity (vocoders/hifi_gan.py:134-135) inside the layout change - and its backward
+ * gx = to_cl(g * (1 - out_fwd^2)) (halo rows / padded channels written as zeros). */
+int psnd_from_cl_tanh(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
+int psnd_to_cl_tanh_bwd(const float *g, const float *out_fwd, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, void *gx, void *stream);
 int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream);
 /* mask head of a spectrogram-masking model: est (N,C,T) fp32 = sigmoid(from_cl(y)) * mag in one pass; backward
  * gy (CL bf16) = to_cl(gest * mag * s (1 - s)), s = sigmoid(y) recomputed (halo rows / padded channels written as zeros). */

@@ -135,6 +135,8 @@ SIGNATURES = {
     'psnd_l1_loss_bwd_w': (_INT, [_P, _P, _I64, _P, _D, _P, _P, _P]),
     'psnd_to_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _P, _P]),
     'psnd_from_cl': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
+    'psnd_from_cl_tanh': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
+    'psnd_to_cl_tanh_bwd': (_INT, [_P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _P, _P]),
 }
 
 _lib = None

@@ -97,6 +97,34 @@ class FromCL(torch.autograd.Function):
         return out, None, None, None
 
 
+class FromCLTanh(torch.autograd.Function):
+    """tanh(from_cl(buf)): the generator's output non-linearity (hifi_gan.py:134-135) inside the layout change (psnd_from_cl_tanh); backward
+    to_cl(g * (1 - out^2)) in one pass (psnd_to_cl_tanh_bwd) - no library tanh / tanh_backward launches on a HIP tensor"""
+
+    @staticmethod
+    def forward(ctx, buf, C, T, shape):
+        buf = buf.contiguous()
+        _need(buf, torch.bfloat16)
+        N, Lp, Cp = buf.shape
+        out = torch.empty((N, C, T), dtype=torch.float32, device=buf.device)
+        with torch.cuda.device(buf.device):
+            check(lib().psnd_from_cl_tanh(ptr(buf), N, C, T, Lp, shape.HP, Cp, ptr(out), stream_ptr(buf.device)), 'psnd_from_cl_tanh')
+        ctx.shape, ctx.Cp = shape, Cp
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        N, C, T = g.shape
+        gx = torch.empty((N, ctx.shape.Lp, ctx.Cp), dtype=torch.bfloat16, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib().psnd_to_cl_tanh_bwd(ptr(g), ptr(out), N, C, T, ctx.shape.Lp, ctx.shape.HP, ctx.Cp, ptr(gx), stream_ptr(g.device)),
+                  'psnd_to_cl_tanh_bwd')
+        return gx, None, None, None
+
+
 class MaskHeadCL(torch.autograd.Function):
     """est = sigmoid(from_cl(y)) * mag  - the head of a spectrogram-masking model (one pass instead of layout change + sigmoid +
     multiply; backward one pass instead of three).  mag: (N, C, T) fp32, treated as a constant (no gradient)."""

@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
     const int cb = (int)((size_t)C * T * sizeof(float));
     const __amdgpu_buffer_rsrc_t rx = make_uniform_rsrc(x ? x + clip : reinterpret_cast<const float *>(out), x ? cb : 0);
     const bool l1 = MASKBWD && l1_est != nullptr;               // uniform
-    const __amdgpu_buffer_rsrc_t rm = make_uniform_rsrc(MASKBWD ? mul + clip : reinterpret_cast<const float *>(out), MASKBWD ? cb : 0);
+    const bool tanhb = !MASKBWD && preop == 2;                  // uniform: x * (1 - mul^2), the backward of out = tanh(from_cl(.)) with mul = out
+    const __amdgpu_buffer_rsrc_t rm = make_uniform_rsrc((MASKBWD || tanhb) ? mul + clip : reinterpret_cast<const float *>(out), (MASKBWD || tanhb) ? cb : 0);
     const __amdgpu_buffer_rsrc_t re = make_uniform_rsrc(l1 ? l1_est + clip : reinterpret_cast<const float *>(out), l1 ? cb : 0);
     const __amdgpu_buffer_rsrc_t rr = make_uniform_rsrc(l1 ? l1_ref + clip : reinterpret_cast<const float *>(out), l1 ? cb : 0);
     const float l1c = l1 ? l1_coef * l1_g[0] : 0.f;
@@ -470,8 +471,8 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
         const int c = c0 + ty + 8 * i, t = t0 + tx;
         const unsigned o = (c < C && t >= 0 && t < T) ? (unsigned)(((size_t)c * T + t) * sizeof(float)) : OOBW;
         v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)o, 0, 0));
+        m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)o, 0, 0));      // (zero-sized descriptor when unused)
         if constexpr (MASKBWD) {
-            m[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)o, 0, 0));
             e[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(re, (int)o, 0, 0));
             r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)o, 0, 0));
         }
@@ -500,6 +501,8 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
             const float d = e[i] - r[i];
             w += l1c * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
             w *= m[i];
+        } else if (tanhb) {
+            w *= 1.f - m[i] * m[i];
         }
         tile[ty + 8 * i][tx] = w;
     }
@@ -522,7 +525,8 @@ __global__ __launch_bounds__(256) void to_cl_kernel(const float *x, bf16_t *out,
 // MASK with l1_ref: also part[block] = sum |out - ref| of the block (double; fused F.l1_loss(est, ref))
 template <bool MASK>
 __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *out, int N, int C, int T, int Lp, int HP, int Cp,
-                                                      const float *mul, const float *l1_ref = nullptr, double *l1_part = nullptr) {
+                                                      const float *mul, const float *l1_ref = nullptr, double *l1_part = nullptr, int post = 0) {
+    // post == 1 (plain instance): out = tanh(x) - the generator's output non-linearity (hifi_gan.py:134) in the layout change
     __shared__ float tile[32][33];
     constexpr unsigned OOBW = 0xffffffffu;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(256) void from_cl_kernel(const bf16_t *x, float *ou
     for (int i = 0; i < 4; ++i) {
         float v = bf2f(xq[i]);
         if constexpr (MASK) v = 1.f / (1.f + __expf(-v));
+        else if (post == 1) v = tanhf(v);
         tile[ty + 8 * i][tx] = v;
     }
     __syncthreads();
@@ -1599,6 +1604,7 @@ extern "C" int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, flo
 extern "C" int psnd_to_cl(const float *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, int preop, void *out,
                           void *stream) {
     if (!x || !out) PSND_FAIL(PSND_E_ARG, "to_cl: null pointer");
+    if (preop != 0 && preop != 1) PSND_FAIL(PSND_E_ARG, "to_cl: preop=%d (0: none, 1: log1p)", preop);
     if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "to_cl: Lp=%d T=%lld HP=%d Cp=%d C=%d", Lp, (long long)T, HP, Cp, C);
     if (N == 0) return PSND_OK;
     dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
@@ -1616,6 +1622,29 @@ extern "C" int psnd_from_cl(const void *x, int64_t N, int C, int64_t T, int Lp, 
     hipLaunchKernelGGL(from_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
                        (int)N, C, (int)T, Lp, HP, Cp, nullptr);
     PSND_CHECK_LAUNCH("from_cl");
+    return PSND_OK;
+}
+
+// out = tanh(from_cl(x)) in one pass (the generator's last two operations, hifi_gan.py:134-135) and its backward gx = to_cl(g * (1 - out^2))
+extern "C" int psnd_from_cl_tanh(const void *x, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, float *out, void *stream) {
+    if (!x || !out) PSND_FAIL(PSND_E_ARG, "from_cl_tanh: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "from_cl_tanh: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((unsigned)((T + 31) / 32), (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(from_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t *>(x), out,
+                       (int)N, C, (int)T, Lp, HP, Cp, nullptr, nullptr, nullptr, 1);
+    PSND_CHECK_LAUNCH("from_cl_tanh");
+    return PSND_OK;
+}
+
+extern "C" int psnd_to_cl_tanh_bwd(const float *g, const float *out_fwd, int64_t N, int C, int64_t T, int Lp, int HP, int Cp, void *gx, void *stream) {
+    if (!g || !out_fwd || !gx) PSND_FAIL(PSND_E_ARG, "to_cl_tanh_bwd: null pointer");
+    if (Lp < T + 2 * HP || Cp < C || N > 65535 || (size_t)C * (size_t)T * 4 >= ((size_t)1 << 31) || (size_t)Lp * Cp * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "to_cl_tanh_bwd: bad shape");
+    if (N == 0) return PSND_OK;
+    dim3 grid((Lp + 31) / 32, (Cp + 31) / 32, (unsigned)N);
+    hipLaunchKernelGGL(to_cl_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g, static_cast<bf16_t *>(gx),
+                       (int)N, C, (int)T, Lp, HP, Cp, 2, out_fwd, nullptr);
+    PSND_CHECK_LAUNCH("to_cl_tanh_bwd");
     return PSND_OK;
 }
 

@@ -292,7 +292,7 @@ class Generator(nn.Module):
                 rs = [run_block(bi) for bi in range(len(stage))]
             xa = cl.MeanActCL.apply(0.01 if last else LRELU_SLOPE, *rs)      # last: F.leaky_relu's default slope, as the reference
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
-        return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
+        return cl.FromCLTanh.apply(y, 1, T, shape)
 
     def _forward_cl_ab(self, x):
         """round 1's upsampling variants, kept for A/B measurements (cl_upsample = 'library' | 'kernel')"""
@@ -335,7 +335,7 @@ class Generator(nn.Module):
         if not kernel_ups:
             xa = cl.ToCL.apply(h, shape, 0)
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
-        return torch.tanh(cl.FromCL.apply(y, 1, T, shape))
+        return cl.FromCLTanh.apply(y, 1, T, shape)
 
     def remove_weight_norm(self):
         for up in self.ups:

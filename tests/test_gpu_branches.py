@@ -122,3 +122,27 @@ def test_mha_bwd_parts_equal_the_whole(monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(d0, d1) and torch.equal(g0, g1) and not torch.isnan(g1).any()
     assert lib().psnd_mha_bwd_parts(ptr(kvq), None, ptr(out), None, ptr(stats), ptr(gout), None, N, H, C, T, ptr(d1), ptr(g1), 0, 8, stream_ptr(dev)) != 0
+
+
+def test_from_cl_tanh_and_its_backward():
+    """psnd_from_cl_tanh / psnd_to_cl_tanh_bwd against tanh(from_cl) / to_cl(g * (1 - y^2)) formed by torch on the same buffers"""
+    from pytorch_sound_amd import cl
+    torch.manual_seed(3)
+    N, C, T, HP = 5, 1, 301, 3
+    shape = cl.CLShape(N, T, HP)
+    buf = torch.zeros(N, shape.Lp, 32, dtype=torch.bfloat16, device='cuda')
+    buf[:, HP:HP + T, :C] = (2.0 * torch.randn(N, T, C, device='cuda')).to(torch.bfloat16)
+    b1 = buf.clone().requires_grad_(True)
+    y = cl.FromCLTanh.apply(b1, C, T, shape)
+    ref = torch.tanh(cl.from_cl_raw(buf, C, T, shape))
+    assert float((y.detach() - ref).abs().max()) <= 2e-7                  # the same tanhf, up to the compiler's contraction
+    g = torch.randn_like(y)
+    y.backward(g)
+    gref = torch.zeros_like(buf, dtype=torch.float32)
+    gref[:, HP:HP + T, :C] = (g * (1 - y.detach() * y.detach())).transpose(1, 2)
+    assert torch.equal(b1.grad, gref.to(torch.bfloat16))
+    # psnd_to_cl keeps refusing pre-operations it does not know (2 is the internal tanh-backward mode and needs its operand)
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr
+    x = torch.randn(N, C, T, device='cuda')
+    out = torch.empty_like(buf)
+    assert lib().psnd_to_cl(ptr(x), N, C, T, shape.Lp, HP, 32, 2, ptr(out), stream_ptr(x.device)) != 0
