@@ -167,3 +167,46 @@ def test_hot_path_flows_reach_no_library_op():
         g(torch.randn(2, 80, 16, device=dev)).abs().mean().backward()
     assert wav.grad is not None and torch.isfinite(wav.grad).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in g.parameters())
+
+
+def test_config3_training_step_reaches_no_library_math():
+    """the WHOLE config-3 training step (mel -> hifi_gan_v1-shaped generator -> mel of the output -> L1 -> backward ->
+    fused Adam) under the guard, with the step's former library launches added to the list: tanh / tanh_backward (now inside the output
+    layout change), leaky_relu, tensor adds / means on the bf16 CL buffers, abs / sign of the L1.  What remains library work in this step
+    is memory initialisation (zero fills of halo rows / slabs) and the four bias-gradient column sums of the upsamplers (off the
+    critical path, on the parameter branch)."""
+    from pytorch_sound_amd import kernels as K, optim as poptim
+    from pytorch_sound_amd.interface.hifi_gan import MelSpectrogram
+    from pytorch_sound_amd.models.vocoders.hifi_gan import Generator
+    dev = _dev()
+    torch.manual_seed(2)
+    h = Namespace(resblock='1', upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=64,
+                  resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
+    gen = Generator(h).to(dev).train()
+    mel = MelSpectrogram().to(dev)
+    opt = poptim.Adam(gen.parameters(), lr=2e-4, betas=(0.8, 0.99))
+    wav = (0.07 * torch.randn(2, 8192, device=dev)).clamp(-1, 1)
+    extra = ('aten.tanh', 'aten.leaky_relu', 'aten.abs', 'aten.sign', 'aten.sgn', 'aten.mean', 'aten.l1_loss', 'aten.add.Tensor', 'aten.add_.Tensor',
+             'aten.mul.Tensor', 'aten.div.Tensor')
+
+    class _ForbidMore(_Forbid):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if any(name.startswith(f) for f in extra):
+                flat = torch.utils._pytree.tree_leaves((args, kwargs or {}))
+                if any(isinstance(a, torch.Tensor) and a.is_cuda and a.numel() > 4096 for a in flat):       # (scalars / tiny host-side bookkeeping aside)
+                    raise AssertionError('library op %s reached with a HIP tensor of %s' % (name, [tuple(a.shape) for a in flat if isinstance(a, torch.Tensor)]))
+            return super().__torch_dispatch__(func, types, args, kwargs)
+
+    losses = []
+    with _ForbidMore():
+        for _ in range(2):
+            with torch.no_grad():
+                m = mel(wav)
+            y = gen(m).squeeze(1)
+            loss = K.l1_loss(mel(y), m)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert all(l == l and l > 0 for l in losses)
