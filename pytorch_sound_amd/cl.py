@@ -347,13 +347,21 @@ def _side_stream(dev):
 
 
 def _join_side_at_end_of_backward(dev, side):
-    if _JOIN_PENDING.get(dev.index):
-        return
-    _JOIN_PENDING[dev.index] = True
+    """the stream this is called on (the running node's stream = the stream of its forward, in the flows of this library the stream
+    `backward()` was called on) waits for `side` when the running backward pass ends.
+    The target is taken HERE, not in the callback: autograd runs its final callbacks on whichever thread finishes the pass - possibly
+    the device's worker thread, whose current stream is the default stream, not the caller's (inside a capture that would pull the
+    legacy stream into the capture instead of joining the branch)."""
+    target = torch.cuda.current_stream(dev)
+    pending = _JOIN_PENDING.setdefault(dev.index, [])
+    if not any(t == target and sd == side for t, sd in pending):
+        pending.append((target, side))
+    # (a callback per call, not per pass: the first one to run joins everything registered so far, the others find nothing - a pass that
+    #  died half-way cannot leave a stale "already queued" mark behind)
 
     def join():
-        _JOIN_PENDING[dev.index] = False
-        torch.cuda.current_stream(dev).wait_stream(side)
+        for t, sd in _JOIN_PENDING.pop(dev.index, []):
+            t.wait_stream(sd)
 
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
@@ -720,7 +728,8 @@ class ConvTransposeCL(torch.autograd.Function):
         # backward pass.  Only when these gradients are WRITTEN (no .grad yet: autograd then takes the tensors without a launch) and
         # nothing else shares the hardware queues with the step (AUTO_SECTIONS).
         side = None
-        if BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None and all(q is None or q.grad is None for q in ctx.params):
+        if (BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None
+                and all(q is None or (q.is_leaf and q.grad is None) for q in ctx.params)):
             side = param_stream(dev)
         main = torch.cuda.current_stream(dev)
 
