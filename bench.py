@@ -378,8 +378,10 @@ def gpu_bench(args):
         roofline_conv = _conv_roofline(device, N, Fr)
         legs = {}
         if not args.no_legs and world == 1:      # single-GPU legs: each builds a Trainer of its own (a collective set-up under a process group)
-            legs['config3_step'] = _config3_leg(device)
-            legs['config4_step'] = _config4_leg(device)
+            # each leg in a child process under a time limit: a leg that dies or hangs (extra graph branches, a Trainer of its own) costs its
+            # own entry, not the line
+            legs['config3_step'] = _leg_subprocess('config3')
+            legs['config4_step'] = _leg_subprocess('config4')
         audio_s = world * N * CLIP_SECONDS * args.steps
         out = {
             'metric': 'audio-sec/s STFT+mel+fwd/bwd', 'value': audio_s / dt, 'unit': 'audio-s/s',
@@ -396,6 +398,20 @@ def gpu_bench(args):
         out.update(legs)
     return out, device
 
+
+
+def _leg_subprocess(name, limit=180.0):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--leg', name], capture_output=True, text=True, timeout=limit)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': 'leg %s: exit code %d: %s' % (name, r.returncode, (r.stderr or '')[-300:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {'error': 'leg %s: no result within %.0f s (killed)' % (name, limit)}
+    except Exception as e:                                    # noqa: BLE001
+        return {'error': 'leg %s: %r' % (name, e)}
 
 
 def _time_steps(tr, steps, warm):
@@ -797,7 +813,14 @@ def main():
     ap.add_argument('--layout', choices=('nfk', 'nkf'), default='nfk',
                     help="magnitude layout between the STFT kernel and its consumers inside the step: 'nfk' bin-fastest (psnd_stft_mag_nfk), 'nkf' the reference's")
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
+    ap.add_argument('--leg', choices=('config3', 'config4'), help='one bounded single-GPU leg alone, its JSON on stdout (the main run starts each leg this way, in a child process)')
     args = ap.parse_args()
+    if args.leg:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: no GPU visible')
+        torch.cuda.set_device(0)
+        print(json.dumps({'config3': _config3_leg, 'config4': _config4_leg}[args.leg](torch.device('cuda', 0))), flush=True)
+        return
     if os.environ.get('PSND_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit if the run is still alive after S seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['PSND_BENCH_WATCHDOG']), exit=True)
