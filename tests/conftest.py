@@ -19,11 +19,11 @@ def pytest_collection_modifyitems(config, items):
     run did not ask for them; under `-m gpu` a missing device or library is a hard failure."""
     import torch
     if config.pluginmanager.hasplugin('timeout'):
-        # a GPU test that hangs (a missing stream join, a wedged queue) ends the run with the stacks of all threads after 10 minutes instead
+        # a GPU test that hangs (a missing stream join, a wedged queue) ends the run with the stacks of all threads after 4 minutes (the slowest test takes 26 s) instead
         # of sitting there until the caller's own limit; 'thread': a blocked hipStreamSynchronize does not return to a signal handler
         for it in items:
             if 'gpu' in it.keywords and it.get_closest_marker('timeout') is None:
-                it.add_marker(pytest.mark.timeout(600, method='thread'))
+                it.add_marker(pytest.mark.timeout(240, method='thread'))
     if torch.cuda.is_available():
         return
     asked = 'gpu' in (config.getoption('-m') or '') and 'not gpu' not in (config.getoption('-m') or '')
