@@ -1320,6 +1320,10 @@ static int stft_fwd_impl(const float *wav, int64_t N, int64_t T, int n_fft, int 
         // n_fft = 4096: one wave per frame (psnd_stft_w.hip); any other size: the one-frame-per-workgroup kernel below.
         if (n_fft == 1024 && psnd_stft1024q_ok(T, F, hop, pad) && !PSND_ENV("PSND_STFT_GENERIC"))
             return psnd_stft1024q_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, s);
+        // n_fft = 4096 at hop 1024 (config 5): the same transform fed from a workgroup-shared LDS sample ring (psnd_stft_r.hip)
+        if (n_fft == 4096 && psnd_stft4096r_ok(T, F, hop, pad) && (reinterpret_cast<uintptr_t>(wav) & 15) == 0 && !PSND_ENV("PSND_STFT_GENERIC") &&
+            !PSND_ENV("PSND_STFT4096_NORING"))
+            return psnd_stft4096r_launch(wav, static_cast<const float *>(plan), mag, N, T, F, pad, mag_eps, p.ablate, s);
         if (n_fft == 4096 && psnd_stft4096w_ok(T, F, hop, pad) && !PSND_ENV("PSND_STFT_GENERIC"))
             return psnd_stft4096w_launch(wav, static_cast<const float *>(plan), mag, N, T, F, hop, pad, mag_eps, p.ablate, 1, s);
         if (F > 0x7fffffff || N > 65535) PSND_FAIL(PSND_E_SHAPE, "stft_mag_nfk(generic): grid too large");

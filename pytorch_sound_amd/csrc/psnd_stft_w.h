@@ -13,3 +13,8 @@ void psnd_stft4096w_plan_fill(float *plan);                      // host: the tw
 bool psnd_stft4096w_ok(long long T, long long F, int hop, int pad);
 int psnd_stft4096w_launch(const float *wav, const float *plan, float *mag, long long N, long long T, long long F, int hop, int pad,
                           float mag_eps, int ablate, int nfk /* 1: output (N, F, K) */, hipStream_t stream);
+
+// psnd_stft_r.hip - hop = 1024, (N, F, K): the same transform fed from a workgroup-shared LDS sample ring (LDS-DMA, every sample fetched once)
+bool psnd_stft4096r_ok(long long T, long long F, int hop, int pad);
+int psnd_stft4096r_launch(const float *wav, const float *plan, float *mag_nfk, long long N, long long T, long long F, int pad, float mag_eps,
+                          int ablate, hipStream_t stream);
