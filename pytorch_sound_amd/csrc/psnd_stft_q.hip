@@ -66,6 +66,11 @@ struct QParams {
     int ablate;                                    // debug (PSND_ABLATE): 2 = no global stores
 };
 
+template <int OFF>
+__device__ __forceinline__ void lds_rd64(v2f &dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
 // magnitude writer for post_emit_pk: the wave-uniform descriptor covers the quad's frames, voff = frame * 4 K + bin * 4
 struct EmitNfk {
     __amdgpu_buffer_rsrc_t r;
@@ -191,11 +196,18 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 const int ln = fresh_lane(), fi = ln >> 4, l = ln & 15;
                 const int sb = fi * hop + 2 * l;
                 const float *tb = xw + sb + (HOP256 ? 32 * fi : 0);
+                // explicit ds_read_b64: hipcc pairs neighbouring taps into ds_read2_b64, which the LDS serves at half the rate of two
+                // ds_read_b64 (MI355X_MICROARCH.md, LDS table; round 5: psnd_stft_r.hip)
+                const unsigned ta = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tb));
                 static_for<0, kR1>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = decltype(ac)::value;
                     // sample 2 (l + 16 a) of the frame; HOP256: 32 a + 2 l < 256 (a % 8 + 1), so the block of the skew is fi + a / 8
-                    z[a] = *reinterpret_cast<const v2f *>(tb + 32 * a + (HOP256 ? 32 * (a / 8) : 0));
+                    lds_rd64<4 * (32 * a + (HOP256 ? 32 * (a / 8) : 0))>(z[a], ta);
                 });
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]),
+                             "+v"(z[8]), "+v"(z[9]), "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15]));
+                asm volatile("" : "+v"(z[16]), "+v"(z[17]), "+v"(z[18]), "+v"(z[19]), "+v"(z[20]), "+v"(z[21]), "+v"(z[22]), "+v"(z[23]),
+                             "+v"(z[24]), "+v"(z[25]), "+v"(z[26]), "+v"(z[27]), "+v"(z[28]), "+v"(z[29]), "+v"(z[30]), "+v"(z[31]));
             }
             Q_SB();
             {

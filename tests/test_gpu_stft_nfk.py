@@ -116,3 +116,46 @@ def test_nfk_full_size_equals_nkf(n_fft, hop, N, T, sr):
     for n in (0, N - 1):
         ref = ofe.stft_mag_f64(a[n:n + 1].cpu().numpy(), n_fft, hop)
         assert np.abs(nfk[n:n + 1].cpu().numpy().transpose(0, 2, 1) - ref).max() <= FFT_RTOL * np.abs(ref).max()
+
+
+# ---- round 5: the LDS sample-ring kernel of config 5 (psnd_stft_r.hip: hop 1024, T % 4 == 0) ----------------------------------------------
+RING_SHAPES = [
+    # (N, T, framing): single frames, segments cut at clip boundaries (many short clips per workgroup), clips shorter than the pad (every
+    # chunk a reflect gather), one long clip split over many workgroups, HiFi-GAN framing, config-5 clips
+    (1, 4096, 0), (1, 2052, 0), (7, 2052, 0), (3, 44100, 0), (2, 30000, 1), (21, 60000, 0), (300, 8192, 0), (1000, 4100, 0),
+    (5, 4096 * 40, 1), (1, 1323000, 0), (3, 1323000, 0),
+]
+
+
+@pytest.mark.parametrize('N,T,framing', RING_SHAPES)
+def test_ring_kernel_is_bit_identical_to_the_register_load_kernel(N, T, framing, monkeypatch):
+    """stft_fwd_n4096r_kernel (samples through the workgroup's LDS ring) and stft_fwd_n4096w_kernel<NFK> (every wave loads its frame) run the
+    same arithmetic on the same values: equal bit for bit - and the latter is pinned to the oracle / goldens / impulse contract above."""
+    from pytorch_sound_amd import kernels as K
+    g = torch.Generator(device='cpu').manual_seed(N * 31 + T)
+    x = (0.0708 * torch.randn(N, T, generator=g)).to(DEV)
+    plan = K.stft_plan(4096, ofe.analysis_window(4096)).to(DEV)
+    ring = K.stft_mag_nfk(x, 4096, 1024, plan, framing)
+    monkeypatch.setenv('PSND_STFT4096_NORING', '1')
+    regs = K.stft_mag_nfk(x, 4096, 1024, plan, framing)
+    monkeypatch.delenv('PSND_STFT4096_NORING')
+    assert torch.isfinite(ring).all()
+    assert torch.equal(ring, regs)
+    ref = ofe.stft_mag_f64(x[:1].cpu().numpy(), 4096, 1024, None, framing)
+    assert np.abs(ring[:1].cpu().numpy().transpose(0, 2, 1) - ref).max() <= FFT_RTOL * np.abs(ref).max()
+
+
+def test_ring_kernel_repeats_exactly():
+    """the ring's hand-offs (loader wave -> frame waves, slot re-use, the transpose buffers' locks) are timing dependent; the result is not:
+    30 launches on changing inputs, each equal to the first launch on the same input; poisoned output in between."""
+    from pytorch_sound_amd import kernels as K
+    plan = K.stft_plan(4096, ofe.analysis_window(4096)).to(DEV)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    xs = [(0.0708 * torch.randn(n, t, generator=g)).to(DEV) for n, t in ((32, 330752), (9, 1323000), (130, 40000))]
+    first = [K.stft_mag_nfk(x, 4096, 1024, plan).clone() for x in xs]
+    outs = [torch.empty_like(f) for f in first]
+    for rep in range(10):
+        for x, f, o in zip(xs, first, outs):
+            o.fill_(float('nan'))
+            K.stft_mag_nfk(x, 4096, 1024, plan, out=o)
+            assert torch.equal(o, f), rep
