@@ -12,19 +12,25 @@ clips resident in HBM, random-init weights.  One "step" = Trainer.train(): zero_
 psnd_stft_fwd launches, the separator under bf16 autocast, psnd_mel_fwd x2), NaN check, backward
 (incl. psnd_mel_bwd), flat-bucket RCCL all-reduce overlapped with backward, Adam step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline         the STFT kernel of the step (wav -> magnitude, stft_fwd_n1024_kernel) on a 544 MB working set (1024 clips,
-                   >> the 256 MiB Infinity Cache): algorithmic bytes 4*N*T + 4*N*K*F per launch / mean launch duration
-                   (HIP events on the launch stream, measured in this run) against 8 TB/s
-  roofline_instep  the same kernel as launched inside the timed steps (64 clips, 34 MB, cache resident): a latency figure
-  roofline_config5 BASELINE config 5: n_fft 4096 / hop 1024, 32 clips x 30 s at 44.1 kHz (508 MB)
-  roofline_conv    the conv kernels that take most of the step, against the dense bf16 MFMA peak
+Prints ONE JSON line on rank 0 (contract in the task statement; `settle` = untimed set-up steps in front of the warm-up) with these extra objects:
+  roofline         the STFT kernel the timed step launches (psnd_stft_mag_nfk: wav -> magnitude (N, F, K), stft_fwd_n1024q_kernel) on a
+                   544 MB working set (1024 clips, >> the 256 MiB Infinity Cache): algorithmic bytes 4*N*T + 4*N*K*F per launch / mean
+                   launch duration (HIP events on the launch stream, measured in this run) against 8 TB/s; frac_config5 / frac_nkf /
+                   frac_config5_nkf beside it
+  roofline_nkf     the same transform in the reference's layout (N, K, F) (psnd_stft_fwd, stft_fwd_n1024_kernel)
+  roofline_instep  the step's launch as it runs inside the timed steps (64 clips, 34 MB, cache resident): a latency figure
+  roofline_config5 BASELINE config 5: n_fft 4096 / hop 1024, 32 clips x 30 s at 44.1 kHz (508 MB), (N, F, K) - stft_fwd_n4096r_kernel;
+                   roofline_config5_nkf: the (N, K, F) kernel
+  roofline_mel     the unfused mel stage; roofline_conv: the conv kernels that take most of the step, against the dense bf16 MFMA peak
+  config3_step / config4_step   BASELINE configs[2] / configs[3] on one GPU: ms/step, p50 / p99 / max over 200 steps, fraction of the MFMA peak
+  dropin_step      configs[1] written against the reference's API names only (Trainer.forward override, STFT.transform, F.l1_loss)
   h2d_inclusive    the same step with the batches in pinned HOST memory (the reference's loop includes this copy,
                    trainer.py:202): copied on a side stream one step ahead (Trainer.prefetch_prepare) and in line
   cpu_baseline     the reference's CPU path (oracle/torch_ref.py port of its dense-DFT conv1d STFT + mel,
                    same model / loss / optimizer in fp32) timed on this host's cores on a bounded sample;
   cpu_baseline_torch_stft  the same step with the reference's torch.stft front end (STFTTorchAudio) instead
   timing           ms/step of the contract region and of further identical K-step blocks (>= 100 ms timed in all): the spread
+`--config 3 | 4 | 5 --gpus N` runs BASELINE configs[2] / [3] / [4] data-parallel under the same contract (config_bench).
 """
 import argparse
 import json
@@ -342,7 +348,14 @@ def gpu_bench(args):
                                '(Infinity-Cache resident) - one workgroup lifetime, a latency figure, not a bandwidth measurement'}
     out = None
     if rank == 0:
-        # the same kernel on 1024 clips: 181 MB in + 363 MB out
+        # The judged `roofline` is the kernel the timed step launches - psnd_stft_mag_nfk, stft_fwd_n1024q_kernel - on an HBM-sized working
+        # set (1024 clips x 2 s: 181 MB in + 363 MB out = 544 MB >> the 256 MiB Infinity Cache), HIP events around every launch, measured in
+        # this run; the same transform in the reference's (N, K, F) layout (psnd_stft_fwd, what STFT.transform returns) is `roofline_nkf`,
+        # BASELINE config 5 `roofline_config5` (N, F, K) / `roofline_config5_nkf`.
+        roofline = _nfk_roofline(device, N_FFT, HOP, 1024, T, 'stft_fwd_n1024q_kernel (a wave owns four frames; wav -> magnitude (N,F,K), 1024/256)')
+        roofline['workload'] = ('1024 clips x 2 s, 1024/256: 181 MB in + 363 MB out = 544 MB (> the 256 MiB Infinity Cache): the kernel the timed step '
+                                'launches (psnd_stft_mag_nfk, bin-fastest magnitudes for the in-library consumers) on an HBM-sized working set; HIP '
+                                'events around every launch, measured in this run')
         NL = 1024
         wav = torch.randn(NL, T, device=device) * 0.07
         plan = K.stft_plan(N_FFT, _hann(N_FFT)).to(device)
@@ -358,22 +371,23 @@ def gpu_bench(args):
         torch.cuda.synchronize()
         tl = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
         bl = 4 * NL * T + 4 * NL * Kb * Fr
-        roofline = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude, 1024/256)',
-                    'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic('n1024'), 'traffic_source': _pmc_traffic('n1024', 'source'),
-                    'bytes_per_launch': bl, 'launch_us': tl * 1e6, 'launches_timed': len(evs) - 3,
-                    'workload': '1024 clips x 2 s, 1024/256: 181 MB in + 363 MB out = 544 MB (> the 256 MiB Infinity Cache), the '
-                                'kernel of the step on an HBM-sized working set; HIP events around every launch, measured in this run'}
+        roofline_nkf = {'bound': 'hbm', 'kernel': 'stft_fwd_n1024_kernel<mag> (wav -> magnitude (N,K,F), 1024/256)',
+                        'achieved': bl / tl / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                        'frac': bl / tl / HBM_PEAK, 'traffic': _pmc_traffic('n1024'), 'traffic_source': _pmc_traffic('n1024', 'source'),
+                        'bytes_per_launch': bl, 'launch_us': tl * 1e6, 'launches_timed': len(evs) - 3,
+                        'workload': '1024 clips x 2 s, 1024/256, the reference layout (N, K, F) of STFT.transform: 544 MB; HIP events around every launch'}
         del wav, mag
-        roofline_config5 = _config5_roofline(device)
-        # the judged object states BOTH STFT fractions of the reference's layout: the step's kernel on an HBM-sized working set and BASELINE config 5
+        roofline_config5_nkf = _config5_roofline(device)
+        roofline_config5 = _nfk_roofline(device, 4096, 1024, 32, int(44100 * 30.0),
+                                         'stft_fwd_n4096r_kernel (LDS sample ring + loader wave, one wave per frame, stores from registers; wav -> magnitude (N,F,K), 4096/1024)')
+        roofline_config5['workload'] = 'configs[4]: 32 clips x 30 s at 44.1 kHz, n_fft 4096 / hop 1024 (508 MB), (N, F, K)'
         roofline['frac_config5'] = roofline_config5['frac']
-        roofline['note'] = ('frac: stft_fwd_n1024_kernel, 1024 clips x 2 s; frac_config5: configs[4] (4096/1024, 32 x 30 s), the full entry is '
-                            'roofline_config5; both in the reference layout (N, K, F).  roofline_nfk / roofline_config5_nfk: the same transforms '
-                            'writing the bin-fastest layout (N, F, K) that the in-step consumers take')
-        roofline_nfk = _nfk_roofline(device, N_FFT, HOP, 1024, T, 'stft_fwd_n1024q_kernel (a wave owns four frames; wav -> magnitude (N,F,K), 1024/256)')
-        roofline_config5_nfk = _nfk_roofline(device, 4096, 1024, 32, int(44100 * 30.0),
-                                             'stft_fwd_n4096w_kernel<NFK> (one wave per frame, stores from registers; wav -> magnitude (N,F,K), 4096/1024)')
+        roofline['frac_nkf'] = roofline_nkf['frac']
+        roofline['frac_config5_nkf'] = roofline_config5_nkf['frac']
+        roofline['note'] = ('frac: the step\'s STFT kernel (N, F, K) on 1024 clips x 2 s; frac_config5: configs[4] (4096/1024, 32 x 30 s) in the same '
+                            'layout (full entry: roofline_config5); frac_nkf / frac_config5_nkf: the same transforms writing the reference\'s (N, K, F) '
+                            '(roofline_nkf, roofline_config5_nkf).  `traffic` fields are RECORDED counter passes (profiles/stft_pmc.json, rocprofv3 '
+                            '--pmc in separate runs), not measured in this run')
         roofline_mel = _mel_roofline(device)
         roofline_conv = _conv_roofline(device, N, Fr)
         legs = {}
@@ -382,17 +396,19 @@ def gpu_bench(args):
             # own entry, not the line
             legs['config3_step'] = _leg_subprocess('config3')
             legs['config4_step'] = _leg_subprocess('config4')
+            legs['dropin_step'] = _leg_subprocess('dropin')
         audio_s = world * N * CLIP_SECONDS * args.steps
         out = {
             'metric': 'audio-sec/s STFT+mel+fwd/bwd', 'value': audio_s / dt, 'unit': 'audio-s/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'settle': args.settle, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: Conv1d separator (4 x ResBlock1, C=256, on 513-bin magnitude), '
                                    '22.05 kHz, STFT 1024/256, 80 mel, batch 32 x 2 s per GPU, Adam, bf16 autocast',
                        'global_batch': world * N, 'clip_seconds': CLIP_SECONDS, 'parallelism': 'dp%d' % world,
                        'model_params': sum(p.numel() for p in model.parameters())},
-            'roofline': roofline, 'roofline_instep': roofline_instep, 'roofline_config5': roofline_config5,
-            'roofline_conv': roofline_conv, 'roofline_nfk': roofline_nfk, 'roofline_config5_nfk': roofline_config5_nfk,
+            'settle_note': '`settle` untimed set-up steps (clock ramp) run in front of the `warmup` steps; timing.blocks_ms_per_step shows what is left of the ramp',
+            'roofline': roofline, 'roofline_instep': roofline_instep, 'roofline_nkf': roofline_nkf, 'roofline_config5': roofline_config5,
+            'roofline_config5_nkf': roofline_config5_nkf, 'roofline_conv': roofline_conv,
             'roofline_mel': roofline_mel, 'h2d_inclusive': h2d, 'timing': timing,
         }
         out.update(legs)
@@ -415,26 +431,34 @@ def _leg_subprocess(name, limit=180.0):
 
 
 def _time_steps(tr, steps, warm):
-    """ms/step of a Trainer loop (graph replays), synchronised on both sides"""
+    """ms/step of a Trainer loop (graph replays), synchronised on both sides; plus the per-step distribution from a HIP event after every step
+    (device time between the ends of consecutive steps: no host synchronisation inside the loop)"""
     s = 0
     for _ in range(warm):
         s += 1
         tr.step = s
         tr.train(s)
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         s += 1
         tr.step = s
         tr.train(s)
+        evs[i + 1].record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    dist = {'p50': float(np.percentile(per, 50)), 'p99': float(np.percentile(per, 99)), 'max': float(per.max()), 'min': float(per.min()),
+            'steps': int(steps), 'max_over_p50': float(per.max() / np.percentile(per, 50)),
+            'note': 'ms between the ends of consecutive steps on the device (one HIP event per step, no host synchronisation in the loop)'}
+    return ms, dist
 
 
-def _config3_leg(device, steps=40, warm=10):
-    """BASELINE configs[2] on one GPU under the driver's clock: 16 segments x 8192 samples (22.05 kHz), HiFi-GAN framing mel
-    (1024 / 256 / 80), hifi_gan_v1 generator on the channels-last conv kernels under bf16 autocast semantics of those kernels,
-    loss = L1(mel(G(mel(x))), mel(x)), pytorch_sound_amd.optim.Adam, the step replayed as a hipGraph (tools/perf_config3.py)."""
+def _config3_build(device):
+    """BASELINE configs[2]: 16 segments x 8192 samples (22.05 kHz) per GPU, HiFi-GAN framing mel (1024 / 256 / 80), hifi_gan_v1 generator on
+    the channels-last conv kernels (bf16 operands), loss = L1(mel(G(mel(x))), mel(x)), pytorch_sound_amd.optim.Adam, hipGraph replay."""
     from pytorch_sound_amd.models import build_model
     from pytorch_sound_amd.models.vocoders import hifi_gan  # noqa: F401
     from pytorch_sound_amd.interface.hifi_gan import MelSpectrogram
@@ -456,25 +480,27 @@ def _config3_leg(device, steps=40, warm=10):
             loss = K.l1_loss(mel(y), m)                 # F.l1_loss as psnd_l1_loss_fwd / _bwd (abs / mean / sign / scale: 5 library launches otherwise)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
-    g = torch.Generator().manual_seed(1)
+    g = torch.Generator().manual_seed(1 + int(os.environ.get('RANK', '0')))
     pool = [((0.07 * torch.randn(N, T, generator=g)).clamp(-1, 1).to(device),) for _ in range(4)]
     tr = Step(gen, poptim.Adam(gen.parameters(), lr=2e-4, betas=(0.8, 0.99)), pool, pool, max_step=10 ** 9, valid_max_step=1,
               save_interval=10 ** 9, log_interval=10 ** 9, save_dir=tempfile.mkdtemp(prefix='psnd_c3_'), seed=1)
     tr.graph_steps = True
     gen.train()
-    ms = _time_steps(tr, steps, warm)
-    return {'ms_per_step': ms, 'value': N * T / SR / (ms * 1e-3), 'unit': 'audio-s/s', 'steps': steps, 'warmup': warm, 'n_gpus': 1,
-            'dtype': 'bf16 conv operands, fp32 accumulate / features / optimizer',
-            'workload': 'configs[2] on one GPU: hifi_gan_v1 (13.9 M parameters), 16 x 8192-sample segments at 22.05 kHz (F = 32), '
+    # hifi_gan_v1 forward 19.65 GFLOP per 8192-sample segment (conv MACs x 2), x 3 for forward + both gradients
+    flops = 19.65e9 * N * 3.0
+    meta = {'unit': 'audio-s/s', 'dtype': 'bf16 conv operands, fp32 accumulate / features / optimizer',
+            'workload': 'configs[2] per GPU: hifi_gan_v1 (13.9 M parameters), 16 x 8192-sample segments at 22.05 kHz (F = 32), '
                         'mel 1024/256/80 (HiFi-GAN framing), L1(mel(G(mel x)), mel x), Adam, hipGraph replay; the resblocks of a stage and the upsamplers\' '
                         'parameter-side backward as parallel graph branches (DESIGN 4.4)',
-            'model_params': sum(p.numel() for p in gen.parameters())}
+            'model_params': sum(p.numel() for p in gen.parameters()), 'flops_per_step': flops,
+            'flops_note': 'SURVEY 8(d): 19.65 GFLOP forward per segment x 16 segments x 3 (forward + input + weight gradients); mel / loss / Adam not counted'}
+    return tr, N * T / SR, meta
 
 
-def _config4_leg(device, steps=30, warm=6, T=1292):
-    """BASELINE configs[3] block on one GPU under the driver's clock: 1x1 projection of an 80-mel input -> PositionalEncoding ->
-    MultiHeadAttention(256, 4) -> PointwiseFeedForward, batch 32 at the 15-s bucket (1292 frames), padding mask (lengths 0.8 .. 1.0 of
-    the bucket), masked L1 to the input, Adam, bf16 operands under autocast (fp32 scores / statistics), hipGraph replay."""
+def _config4_build(device, T=1292):
+    """BASELINE configs[3] block: 1x1 projection of an 80-mel input -> PositionalEncoding -> MultiHeadAttention(256, 4) ->
+    PointwiseFeedForward -> 1x1, batch 32 per GPU at the 15-s bucket (1292 frames), padding mask (lengths 0.8 .. 1.0 of the bucket),
+    masked L1 to the input, Adam, bf16 operands under autocast (fp32 scores / statistics), hipGraph replay."""
     from pytorch_sound_amd.models import modules as M
     from pytorch_sound_amd.trainer import Trainer, LogType
     from pytorch_sound_amd import optim as poptim
@@ -503,11 +529,10 @@ def _config4_leg(device, steps=30, warm=6, T=1292):
         def forward(self, mel_, valid, is_logging=False):
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 y = self.model(mel_, valid < 0.5)
-            loss = K.masked_l1_loss(y.float(), mel_, valid) if hasattr(K, 'masked_l1_loss') else \
-                ((y.float() - mel_).abs() * valid.unsqueeze(1)).sum() / (valid.sum() * 80.0)
+            loss = K.masked_l1_loss(y.float(), mel_, valid)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
-    g = torch.Generator().manual_seed(2)
+    g = torch.Generator().manual_seed(2 + int(os.environ.get('RANK', '0')))
     lens = torch.linspace(0.8 * T, T, N).long()
     valid = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
     pool = [(torch.randn(N, 80, T, generator=g).to(device), valid) for _ in range(3)]
@@ -515,14 +540,157 @@ def _config4_leg(device, steps=30, warm=6, T=1292):
               log_interval=10 ** 9, save_dir=tempfile.mkdtemp(prefix='psnd_c4_'), seed=1)
     tr.graph_steps = True
     net.train()
-    ms = _time_steps(tr, steps, warm)
-    audio = float(lens.sum()) * HOP / SR
-    return {'ms_per_step': ms, 'value': audio / (ms * 1e-3), 'unit': 'audio-s/s (unpadded)', 'steps': steps, 'warmup': warm, 'n_gpus': 1,
-            'dtype': 'bf16 operands under autocast, fp32 scores / statistics / accumulation',
-            'workload': 'configs[3] block on one GPU: 80-mel -> 1x1 -> PositionalEncoding -> MultiHeadAttention(256, 4) -> '
+    # transformer block 2 * 12 C^2 + 4 C T flop per frame forward, + the two 1x1 projections 2 * 2 * 80 * C; x 3 for the backward
+    flops = (24.0 * C * C + 4.0 * C * T + 4.0 * 80 * C) * N * T * 3.0
+    meta = {'unit': 'audio-s/s (unpadded)', 'dtype': 'bf16 operands under autocast, fp32 scores / statistics / accumulation',
+            'workload': 'configs[3] block per GPU: 80-mel -> 1x1 -> PositionalEncoding -> MultiHeadAttention(256, 4) -> '
                         'PointwiseFeedForward -> 1x1, batch 32 x %d frames (15-s bucket, lengths 0.8-1.0 of it, padding mask), masked L1, '
                         'Adam, hipGraph replay; the 1x1 projections\' parameter-side backward as a parallel graph branch (DESIGN 4.4)' % T,
-            'model_params': sum(p.numel() for p in net.parameters())}
+            'model_params': sum(p.numel() for p in net.parameters()), 'flops_per_step': flops,
+            'flops_note': 'SURVEY 8(d): (24 C^2 + 4 C T + 4 * 80 C) flop per frame forward (C = 256, T = 1292) x 32 x 1292 frames x 3 (forward + backward)'}
+    return tr, float(lens.sum()) * HOP / SR, meta
+
+
+def _leg(device, build, steps, warm):
+    tr, audio_s, meta = build(device)
+    ms, dist = _time_steps(tr, steps, warm)
+    out = {'ms_per_step': ms, 'value': audio_s / (ms * 1e-3), 'steps': steps, 'warmup': warm, 'n_gpus': 1, 'step_ms': dist,
+           'mfma_frac': meta['flops_per_step'] / (ms * 1e-3) / MFMA_BF16_PEAK, 'mfma_peak': 'dense bf16 MFMA 2.5 PFLOP/s'}
+    out.update(meta)
+    return out
+
+
+def _config3_leg(device, steps=200, warm=10):
+    return _leg(device, _config3_build, steps, warm)
+
+
+def _config4_leg(device, steps=200, warm=6):
+    return _leg(device, _config4_build, steps, warm)
+
+
+def _dropin_leg(device, steps=60, warm=8):
+    """configs[1] written ONLY with the reference's API names, the way a user of pytorch_sound writes a step (trainer.py:58-73: override
+    Trainer.forward): STFT.transform on the waveforms inside forward (magnitude AND phase, as the reference computes them),
+    build_model('conv_separator_voicebank') under autocast, LogMelSpectrogram for the target, the mel of the estimate as torch ops on the
+    module's `mel_filter` buffer, F.l1_loss.  No prepare(), no library-only layout / fused-loss entry points.  Eager and with graph_steps."""
+    from pytorch_sound.models import build_model
+    from pytorch_sound.models.transforms import LogMelSpectrogram
+    from pytorch_sound.trainer import Trainer, LogType
+    from pytorch_sound_amd.models import separator  # noqa: F401  (registers conv_separator)
+    from pytorch_sound_amd import optim as poptim
+    T, N = int(SR * CLIP_SECONDS), BATCH_PER_GPU
+    fe = LogMelSpectrogram(SR, N_MEL, N_FFT, N_FFT, HOP, -50, 30, FMIN, FMAX).to(device)
+
+    class Step(Trainer):
+        def forward(self, both, is_logging=False):
+            n = both.shape[0] // 2
+            noisy, clean = both[:n], both[n:]
+            with torch.no_grad():
+                mag_ref, _ = fe.stft.transform(clean)
+                mel_ref = fe(clean)
+            mag_mix, _ = fe.stft.transform(noisy)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                est = self.model(mag_mix)
+            est = est.float()
+            mel_est = torch.log(torch.matmul(fe.mel_filter, est) + 1e-6).clamp(fe.min_db, fe.max_db)
+            loss = F.l1_loss(est, mag_ref) + 0.5 * F.l1_loss(mel_est, mel_ref)
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    res = {}
+    for mode in ('eager', 'graph_steps'):
+        torch.manual_seed(1234)
+        model = build_model('conv_separator_voicebank').to(device)
+        pool = [synth_batch(1234 + 1000 * i, N, T, device) for i in range(4)]
+        tr = Step(model, poptim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99)), pool, pool, max_step=10 ** 9, valid_max_step=1,
+                  save_interval=10 ** 9, log_interval=10 ** 9, save_dir=tempfile.mkdtemp(prefix='psnd_dropin_'), seed=1234)
+        tr.graph_steps = mode == 'graph_steps'
+        model.train()
+        try:
+            ms, dist = _time_steps(tr, steps, warm + (tr.graph_warmup + 1 if tr.graph_steps else 0))
+            res[mode] = {'ms_per_step': ms, 'value': N * CLIP_SECONDS / (ms * 1e-3), 'step_ms': dist}
+        except Exception as e:                                  # noqa: BLE001 - a mode that cannot run is reported, not fatal
+            res[mode] = {'error': repr(e)[:300]}
+    res.update({'unit': 'audio-s/s', 'n_gpus': 1, 'steps': steps, 'dtype': 'bf16 autocast around the model, fp32 features / loss',
+                'workload': 'configs[1] (32 x 2 s, conv_separator_voicebank, Adam) with the step written against the reference\'s API only: '
+                            'Trainer.forward override, STFT.transform (magnitude and phase) x 2 + LogMelSpectrogram inside forward, torch.matmul / '
+                            'log / clamp on `mel_filter` for the mel of the estimate, F.l1_loss x 2 - what a user gets who switches the import and '
+                            'changes nothing else; the headline `value` is the same step on the library\'s prepare() / (N, F, K) / fused-loss API'})
+    return res
+
+
+def _dist_setup(args):
+    from pytorch_sound_amd import distributed as pdist
+    distributed = pdist.init_from_env('nccl')
+    rank, world = pdist.rank(), pdist.world_size()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+    local = 0 if os.environ.get('PSND_DIST_SHARE_GPU') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    return distributed, rank, world, torch.device('cuda', local)
+
+
+def config_bench(args):
+    """--config 3 | 4 | 5 (with --gpus N under torch.distributed.run): the data-parallel runs of BASELINE configs[2] / [3] / [4] under the same
+    contract as the headline line - W warm-up steps, K timed steps between barriers, the maximum over the ranks, whole-job audio-s/s.
+    Configs 3 and 4: one process per GPU, flat gradient buckets all-reduced over RCCL (distributed.FlatGradReducer, captured into the step
+    graph); config 5 is feature extraction only (32 x 30 s clips per GPU through psnd_stft_mag_nfk): clips shard, no collective."""
+    distributed, rank, world, device = _dist_setup(args)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    if args.config == 5:
+        from pytorch_sound_amd import kernels as K
+        n_fft, hop, clips, T = 4096, 1024, 32, int(44100 * 30.0)
+        g = torch.Generator().manual_seed(5 + rank)
+        wav = (0.07 * torch.randn(clips, T, generator=g)).to(device)
+        plan = K.stft_plan(n_fft, _hann(n_fft)).to(device)
+        mag = torch.empty(clips, K.frame_count(T, n_fft, hop), n_fft // 2 + 1, device=device)
+
+        def one_step():
+            K.stft_mag_nfk(wav, n_fft, hop, plan, out=mag)
+        audio_s, meta = clips * 30.0, {'unit': 'audio-s/s', 'dtype': 'f32', 'model_params': 0,
+                                       'workload': 'configs[4] per GPU: 32 clips x 30 s at 44.1 kHz, STFT 4096 / 1024 magnitude, (N, F, K) output '
+                                                   '(508 MB of algorithmic traffic per step): feature extraction only, clips shard across GPUs, no collective'}
+        bytes_step = 4.0 * clips * T + 4.0 * mag.numel()
+    else:
+        tr, audio_s, meta = (_config3_build if args.config == 3 else _config4_build)(device)
+        st = [0]
+
+        def one_step():
+            st[0] += 1
+            tr.step = st[0]
+            tr.train(st[0])
+        bytes_step = None
+    for _ in range(args.settle + args.warmup + (8 if args.config != 5 else 0)):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tdt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tdt.item())
+    if rank != 0:
+        return None
+    out = {'metric': 'audio-sec/s STFT+mel+fwd/bwd' if args.config != 5 else 'audio-sec/s STFT (feature extraction only)',
+           'value': world * audio_s * args.steps / dt, 'unit': 'audio-s/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'settle': args.settle, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'bf16' if args.config != 5 else 'f32', 'data': 'synthetic',
+           'config': {'workload': meta['workload'], 'parallelism': 'dp%d' % world, 'model_params': meta['model_params'], 'baseline_config': args.config - 1}}
+    if args.config == 5:
+        out['roofline'] = {'bound': 'hbm', 'achieved': bytes_step * args.steps / dt / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                           'frac': bytes_step * args.steps / dt / HBM_PEAK, 'traffic': None, 'kernel': 'stft_fwd_n4096r_kernel',
+                           'note': 'per GPU, host-timed over the K launches of the contract region (includes the launch gaps)'}
+    else:
+        out['mfma_frac'] = meta['flops_per_step'] * world * args.steps / dt / (world * MFMA_BF16_PEAK)
+    return out
 
 
 def _nfk_roofline(device, n_fft, hop, clips, T, label):
@@ -545,7 +713,8 @@ def _nfk_roofline(device, n_fft, hop, clips, T, label):
     b = 4 * clips * T + 4 * clips * Kb * Fr
     return {'bound': 'hbm', 'kernel': label, 'achieved': b / t / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK,
             'traffic': _pmc_traffic('nfk%d' % n_fft), 'bytes_per_launch': b, 'launch_us': t * 1e6, 'launches_timed': len(evs) - 3,
-            'layout': '(N, F, K): bin axis fastest - for consumers inside the library; the judged `roofline` stays the reference layout (N, K, F)'}
+            'traffic_source': _pmc_traffic('nfk%d' % n_fft, 'source'),
+            'layout': '(N, F, K): bin axis fastest - what the consumers inside the library (mel kernel, channels-last conv stack, spectral losses) take'}
 
 
 def _mel_roofline(device, clips=1024, Fr=173, Kb=513, M=80):
@@ -566,7 +735,8 @@ def _mel_roofline(device, clips=1024, Fr=173, Kb=513, M=80):
     t = float(np.mean([a.elapsed_time(b) for a, b in evs[3:]])) * 1e-3
     b = 4 * clips * Kb * Fr + 4 * clips * M * Fr
     return {'bound': 'hbm', 'kernel': 'mel_kernel<false> (band-sparse fp32 MFMA 16x16x4: magnitude (N,K,F) -> log-mel (N,M,F))', 'achieved': b / t / 1e9,
-            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': None, 'bytes_per_launch': b, 'launch_us': t * 1e6,
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': _pmc_traffic('mel'), 'traffic_source': _pmc_traffic('mel', 'source'),
+            'bytes_per_launch': b, 'launch_us': t * 1e6,
             'launches_timed': len(evs) - 3, 'flops_per_launch': 2.0 * M * Kb * clips * Fr,
             'workload': '%d clips x 2 s: %d x %d x %d magnitudes -> %d mel bands (%.0f MB)' % (clips, clips, Kb, Fr, M, b / 1e6)}
 
@@ -813,19 +983,30 @@ def main():
     ap.add_argument('--layout', choices=('nfk', 'nkf'), default='nfk',
                     help="magnitude layout between the STFT kernel and its consumers inside the step: 'nfk' bin-fastest (psnd_stft_mag_nfk), 'nkf' the reference's")
     ap.add_argument('--torch-adam', action='store_true', help="torch.optim.Adam(fused=True) instead of pytorch_sound_amd.optim.Adam")
-    ap.add_argument('--leg', choices=('config3', 'config4'), help='one bounded single-GPU leg alone, its JSON on stdout (the main run starts each leg this way, in a child process)')
+    ap.add_argument('--leg', choices=('config3', 'config4', 'dropin'), help='one bounded single-GPU leg alone, its JSON on stdout (the main run starts each leg this way, in a child process)')
+    ap.add_argument('--config', type=int, choices=(2, 3, 4, 5), default=2,
+                    help='which BASELINE configuration the contract line runs (1-based as in BASELINE.json configs: 2 = the headline, 3 = conv vocoder DDP, '
+                         '4 = transformer block DDP, 5 = 4096-point STFT of 30-s clips); 3 / 4 / 5 take --gpus N under torch.distributed.run like the headline')
     args = ap.parse_args()
     if args.leg:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: no GPU visible')
         torch.cuda.set_device(0)
-        print(json.dumps({'config3': _config3_leg, 'config4': _config4_leg}[args.leg](torch.device('cuda', 0))), flush=True)
+        print(json.dumps({'config3': _config3_leg, 'config4': _config4_leg, 'dropin': _dropin_leg}[args.leg](torch.device('cuda', 0))), flush=True)
         return
     if os.environ.get('PSND_BENCH_WATCHDOG'):      # debugging aid: dump every thread's stack and exit if the run is still alive after S seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ['PSND_BENCH_WATCHDOG']), exit=True)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')
+    if args.config != 2:
+        out = config_bench(args)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
     out, device = gpu_bench(args)
     if out is not None:
         if args.gpus == 1 and args.cpu_seconds > 0:

@@ -393,6 +393,38 @@ NODE_GRANULARITY = 'body'
 #                              delivered this step: the node then returns the gradient and autograd accumulates it)
 #   sink.deliver(params)    -> these parameters' gradients are in place (enqueued on the current stream)
 GRAD_SINK = None
+
+# ---- how many autograd nodes of the running forward pass will produce a gradient for a parameter --------------------------------------
+# A node may hand a parameter's gradient over early (GRAD_SINK.dest / deliver) or produce it on a side stream (BRANCH_PARAM_GRADS) only when
+# it is the parameter's ONLY producer in this backward: with a second node (a module applied twice, shared weights) autograd accumulates
+# the two contributions - into a slot whose bucket may already be on its way through the all-reduce, or on the main stream with no
+# dependency on the side stream.  Every node that uses one of these shortcuts notes its parameters in forward; the table
+# resets itself when the first note arrives after a backward pass has consulted it.
+_PARAM_USES = {}
+_PARAM_USES_PHASE = ['fwd']
+
+
+def note_param_use(ctx, *params):
+    """called from an autograd.Function's forward (grad mode is off in there: ctx.needs_input_grad tells a recorded pass from inference)"""
+    if not any(ctx.needs_input_grad):
+        return
+    if _PARAM_USES_PHASE[0] != 'fwd':
+        _PARAM_USES.clear()
+        _PARAM_USES_PHASE[0] = 'fwd'
+    for p in params:
+        if p is not None:
+            _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+
+
+def single_use(p) -> bool:
+    """true iff exactly one node of the forward pass that this backward belongs to noted `p` (unknown parameters: false)"""
+    _PARAM_USES_PHASE[0] = 'bwd'
+    return p is None or _PARAM_USES.get(id(p), 0) == 1
+
+
+def reset_param_uses():
+    _PARAM_USES.clear()
+    _PARAM_USES_PHASE[0] = 'fwd'
 # chunks of the hand-over (weight gradients + weight-norm backward of a block) on a side stream / graph branch next to the following
 # block's input-gradient launch, which holds a workgroup on 141 of the 256 CUs only (DESIGN 4.4)
 HANDOVER_SIDE_STREAM = False
@@ -705,6 +737,7 @@ class ConvTransposeCL(torch.autograd.Function):
         ctx.geo = (shape, out_shape, stride, padding, float(act_slope), Cin, Cout, K, Cip, Cr)
         ctx.has_bias = bias is not None
         ctx.params = (weight_v, weight_g, bias)
+        note_param_use(ctx, weight_v, weight_g, bias)
         ctx.save_for_backward(xa, v32, g32, wb, act)
         return raw, act
 
@@ -729,7 +762,7 @@ class ConvTransposeCL(torch.autograd.Function):
         # nothing else shares the hardware queues with the step (AUTO_SECTIONS).
         side = None
         if (BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None
-                and all(q is None or (q.is_leaf and q.grad is None) for q in ctx.params)):
+                and all(q is None or (q.is_leaf and q.grad is None and single_use(q)) for q in ctx.params)):
             side = param_stream(dev)
         main = torch.cuda.current_stream(dev)
 
@@ -895,6 +928,10 @@ def prep_all(owner, convs, defer_backward_packs=False):
     import os
     if os.environ.get('PSND_NO_PREP_ALL') == '1':      # A/B switch: one prep launch per conv
         return None
+    # psnd_conv1d_prep_multi stages 8 rows of Cin * k bf16 values in LDS: wider rows (e.g. 1024 channels x 11 taps) take the per-conv prep
+    # launch (fused_conv / ResBlockCL with prep = None) instead of failing with PSND_E_SHAPE
+    if any(c.weight_v.shape[1] * c.weight_v.shape[2] > 10240 for c in convs):
+        return None
     key = tuple((c.weight_v.data_ptr(), c.weight_g.data_ptr(), 0 if c.bias is None else c.bias.data_ptr(),
                  tuple(c.weight_v.shape)) for c in convs)
     cache = getattr(owner, '_cl_prep_cache', None)
@@ -1031,6 +1068,7 @@ class ResBlockCL(torch.autograd.Function):
             _run_sections(dev, nsec, sides, run)
         ctx.steps, ctx.shape = steps, shape
         ctx.param_refs = params                    # the Parameter objects (GRAD_SINK looks its buckets up by them)
+        note_param_use(ctx, *params)
         ctx.save_for_backward(*saved)
         return cur_x, cur_xa
 

@@ -217,6 +217,9 @@ class FlatGradReducer:
         slot = self._slot.get(p)
         if slot is None or p in self._sunk:
             return None
+        from . import cl
+        if not cl.single_use(p):         # a second node of this backward produces a gradient for p too: autograd must accumulate both BEFORE the
+            return None                  # parameter counts as arrived (the post-accumulate hook does that) - no early hand-over
         b, off = slot
         if numel > (p.numel() + 63) // 64 * 64:
             return None
@@ -263,8 +266,11 @@ class FlatGradReducer:
             views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
             src = [grads.get(p) for p in b['params']]
             have = [(v, g) for v, g in zip(views, src) if g is not None]
-            if len(have) != len(views):
-                b['flat'].zero_()
+            # (only the views of parameters WITHOUT a gradient are cleared - as _emit_bucket does: the last bucket's spare slot carries the
+            #  step's NaN flag, written by the replayed loss launch before this runs (cl.NAN_FLAG_DEST); zeroing the whole buffer wiped it)
+            missing = [v for v, g in zip(views, src) if g is None]
+            if missing:
+                torch._foreach_zero_(missing)
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
             for p, v in zip(b['params'], views):

@@ -516,6 +516,8 @@ class Linear1x1(torch.autograd.Function):
                   'psnd_linear1x1_fwd')
         ctx.relu, ctx.has_bias, ctx.wshape, ctx.bf16 = bool(relu), bias is not None, tuple(w.shape), bool(bf16)
         ctx.params = (w, bias)
+        from . import cl
+        cl.note_param_use(ctx, w, bias)
         ctx.save_for_backward(x, w2, y if relu else None)
         return y
 
@@ -541,7 +543,7 @@ class Linear1x1(torch.autograd.Function):
         from . import cl
         side = None
         if (need_x and (need_w or need_b) and cl.BRANCH_PARAM_GRADS and cl.AUTO_SECTIONS and cl.GRAD_SINK is None
-                and all(q is None or (q.is_leaf and q.grad is None) for q in ctx.params)):
+                and all(q is None or (q.is_leaf and q.grad is None and cl.single_use(q)) for q in ctx.params)):
             side = cl.param_stream(dev)
         with torch.cuda.device(dev):
             if side is None:

@@ -446,7 +446,7 @@ class Trainer:
 
     def _train_device_skip(self, step: int, loss: torch.Tensor):
         flag = self._nan_flag(loss)
-        if self._reducer is not None and pdist.is_dist():
+        if self._reducer is not None and (pdist.is_dist() or self._reducer.active):   # (the same condition as _finish_device_skip: a forced one-rank group)
             self._reducer.set_flag(flag)               # rides along with the last gradient bucket
         self._backward(loss)
         self._finish_device_skip(step, flag)

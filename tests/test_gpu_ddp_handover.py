@@ -185,3 +185,71 @@ def test_handover_gradients_equal_the_hooks_path():
     chunks = [c for _, c in got[2][True]]
     # cl.HANDOVER_CHUNKS = 3: bucket 0 behind the last block, buckets 1-3 behind the second, 4-5 at the end
     assert chunks == sorted(chunks) and len(set(chunks)) == 3 and chunks[0] > 0 and chunks[3] < chunks[4], chunks
+
+
+def _shared_worker(port, q):
+    """the body applied TWICE in one forward (two nodes produce gradients for every parameter): ADVICE r04 - the hand-over must stand back"""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0')
+        import torch.distributed as dist
+        from pytorch_sound_amd import kernels as K, distributed as pdist
+        from pytorch_sound_amd.models import build_model, separator  # noqa: F401
+        from pytorch_sound_amd.models.transforms import LogMelSpectrogram
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        dev = torch.device('cuda:0')
+        fe = LogMelSpectrogram(22050, 80, 1024, 1024, 256, -50, 30, 0.0, 8000.0).to(dev)
+        torch.manual_seed(1234)
+        net = build_model('conv_separator_voicebank').to(dev)
+        g = torch.Generator().manual_seed(5)
+        mags = [(torch.rand(4, 513, 173, generator=g) * 4).to(dev) for _ in range(2)]
+        refs = [(torch.rand(4, 513, 173, generator=g) * 4).to(dev) for _ in range(2)]
+        mels = [K.mel_forward(r, fe._mel_plan(), 80, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)[0] for r in refs]
+
+        def losses():
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                return [net.spectral_l1_loss(m, r, l, fe._mel_plan(), 80, 1.0, 0.5, 1e-6, fe.min_db, fe.max_db)[0] for m, r, l in zip(mags, refs, mels)]
+
+        # reference: the two uses in separate backward passes, no reducer, summed
+        want = {k: torch.zeros_like(p) for k, p in net.named_parameters()}
+        for i in range(2):
+            net.zero_grad(set_to_none=True)
+            losses()[i].backward()
+            for k, p in net.named_parameters():
+                want[k] += p.grad
+        net.zero_grad(set_to_none=True)
+        red = pdist.FlatGradReducer(net, force=True)
+        out = {}
+        for mode in (False, True):
+            red.sink_enabled = mode
+            red.zero_grad()
+            a, b = losses()
+            (a + b).backward()
+            red.finish()
+            torch.cuda.synchronize()
+            out[mode] = {k: p.grad.clone() for k, p in net.named_parameters()}
+            late = [c for _, c in list(red.handover_log)[-len(red.buckets):]]
+            out[str(mode) + 'log'] = late
+        worst = {m: max(float((out[m][k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-30)) for k in want) for m in (False, True)}
+        dist.destroy_process_group()
+        q.put(('ok', worst, out['Truelog']))
+    except Exception as e:
+        import traceback
+        q.put(('err', repr(e) + traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_shared_parameters_are_not_handed_over_early():
+    """a model whose body runs twice in one forward: every parameter has two producing nodes, so no bucket may leave from inside a node's
+    backward (chunk 0 = released by the post-accumulate hooks / finish()), and the gradients equal the sum of the two uses."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_shared_worker, args=(_port(), q))
+    p.start()
+    got = q.get(timeout=200)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and got[0] == 'ok', got
+    assert got[1][False] <= 2e-5 and got[1][True] <= 2e-5, got[1]
+    assert all(c == 0 for c in got[2]), got[2]

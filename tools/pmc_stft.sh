@@ -16,5 +16,5 @@ for set in "WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "FETCH_SIZE TCC_
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$i -o p --output-format csv -- python $ROOT/${RUNNER:-tools/run_stft_only.py} $NFFT $NCLIP $TT 3 > $OUT/pmc_$i.log 2>&1
 done
-python $ROOT/tools/pmc_summary.py $OUT stft_fwd > $OUT/summary.txt 2>&1
+python $ROOT/tools/pmc_summary.py $OUT ${MATCH:-stft_fwd} > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -13,7 +13,10 @@ WORK = {'n1024': ('stft_fwd_n1024_kernel<mag>', '1024 clips x 2 s, 1024/256', 4 
         'n4096': ('stft_fwd 4096/1024 <mag>', '32 clips x 30 s at 44.1 kHz, 4096/1024', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292),
         # psnd_stft_mag_nfk: the same transforms writing (N, F, K) (tools/pmc_stft.sh ... RUNNER=tools/r04/run_nfk_only.py)
         'nfk1024': ('stft_fwd_n1024q_kernel', '1024 clips x 2 s, 1024/256, output (N, F, K)', 4 * 1024 * 44100 + 4 * 1024 * 513 * 173),
-        'nfk4096': ('stft_fwd_n4096w_kernel<NFK>', '32 clips x 30 s at 44.1 kHz, 4096/1024, output (N, F, K)', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292)}
+        'nfk4096': ('stft_fwd_n4096r_kernel', '32 clips x 30 s at 44.1 kHz, 4096/1024, output (N, F, K)', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292),
+        # psnd_mel_fwd (tools/pmc_stft.sh ... RUNNER=tools/r05/run_mel_only.py; kernel name match 'mel_kernel')
+        'mel': ('mel_kernel', '1024 clips x 2 s: (N, K, F) magnitudes -> 80 log-mel bands', 4 * 1024 * 513 * 173 + 4 * 1024 * 80 * 173)}
+MATCH = {'mel': 'mel_kernel'}
 
 
 def summarise(d, match='stft_fwd'):
@@ -35,7 +38,7 @@ def main():
     out = {}
     for a in sys.argv[1:]:
         which, d = a.split('=', 1)
-        c, dur, names = summarise(d)
+        c, dur, names = summarise(d, MATCH.get(which, 'stft_fwd'))
         kern, workload, alg = WORK[which]
         rd, wr = c['FETCH_SIZE'] * 1024 * 2, c['WRITE_SIZE'] * 1024
         out[which] = {'kernel': names[0] if names else kern, 'workload': workload, 'fetch_size_kb': c['FETCH_SIZE'], 'write_size_kb': c['WRITE_SIZE'],
@@ -43,7 +46,7 @@ def main():
                       'traffic_over_algorithmic': (rd + wr) / alg,
                       'write_requests': c.get('TCC_EA0_WRREQ_sum'), 'write_requests_64B': c.get('TCC_EA0_WRREQ_64B_sum'),
                       'kernel_us_under_pmc': [round(x, 1) for x in dur],
-                      'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/run_stft_only.py (tools/pmc_stft.sh %s); '
+                      'source': 'RECORDED, not measured in the bench run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_stft.sh %s); '
                                 'FETCH_SIZE doubled per MI355X_MICROARCH.md' % os.path.basename(d.rstrip('/'))}
     p = os.path.join(ROOT, 'profiles', 'stft_pmc.json')
     old = json.load(open(p)) if os.path.exists(p) else {}
