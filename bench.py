@@ -620,6 +620,12 @@ def _dropin_leg(device, steps=60, warm=8):
 
 def _dist_setup(args):
     from pytorch_sound_amd import distributed as pdist
+    if args.force_ddp and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        # one-rank RCCL process group: the whole data-parallel step (flat buckets, captured all-reduce) on one GPU
+        os.environ.update(PSND_DDP_FORCE='1', MASTER_ADDR='127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29519')
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group('nccl', rank=0, world_size=1)
     distributed = pdist.init_from_env('nccl')
     rank, world = pdist.rank(), pdist.world_size()
     if world != args.gpus:
@@ -679,7 +685,10 @@ def config_bench(args):
         dt = float(tdt.item())
     if rank != 0:
         return None
+    red = getattr(tr, '_reducer', None) if args.config != 5 else None
     out = {'metric': 'audio-sec/s STFT+mel+fwd/bwd' if args.config != 5 else 'audio-sec/s STFT (feature extraction only)',
+           'reducer': None if red is None else {'active': bool(red.active), 'buckets': len(red.buckets),
+                                                'graph_modes': [v.get('ddp') for v in getattr(tr, '_graphs', {}).values() if 'graph' in v]},
            'value': world * audio_s * args.steps / dt, 'unit': 'audio-s/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
            'settle': args.settle, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'bf16' if args.config != 5 else 'f32', 'data': 'synthetic',

@@ -761,9 +761,11 @@ class ConvTransposeCL(torch.autograd.Function):
         # backward pass.  Only when these gradients are WRITTEN (no .grad yet: autograd then takes the tensors without a launch) and
         # nothing else shares the hardware queues with the step (AUTO_SECTIONS).
         side = None
-        if (BRANCH_PARAM_GRADS and AUTO_SECTIONS and GRAD_SINK is None
+        if (BRANCH_PARAM_GRADS and AUTO_SECTIONS
                 and all(q is None or (q.is_leaf and q.grad is None and single_use(q)) for q in ctx.params)):
             side = param_stream(dev)
+            if GRAD_SINK is not None:          # a reducer's bucket waits for the stream that WRITES these gradients (round 5)
+                GRAD_SINK.note_producer(ctx.params, side)
         main = torch.cuda.current_stream(dev)
 
         def param_side(st):

@@ -130,6 +130,15 @@ class FlatGradReducer:
         self._in_deliver = 0
         self.handover_log = collections.deque(maxlen=4096)   # (bucket, number of the deliver() call that released it, or 0 = a hook / finish())
         self._sunk = set()           # parameters whose gradient was written straight into its slot this step (sink protocol)
+        # Streams.  A backward pass may produce gradients on several streams (inside a captured step: graph branches - the resblocks of a
+        # HiFi-GAN stage, the parameter-side branch of a transposed conv / a 1x1 projection): every arrival leaves an event on the stream
+        # that PRODUCES the gradient, and the stream a bucket is released from waits for the events of the bucket's other streams first
+        # (round 5: graph branches and the reducer in one step).
+        self._release = None         # the stream buckets are released from (_release_on)
+        self._release_used = False
+        self._bucket_events = {}     # bucket index -> {stream id: (stream, event)}
+        self._producer = {}          # parameter -> stream its gradient is being written on, when that is not the node's stream (note_producer)
+        self._event_pool = []
         self.sink_enabled = True     # cl.GRAD_SINK protocol: conv-chain nodes write into the buckets and hand parameters over mid-backward
         self._handles = []
         order = list(reversed(self.params))
@@ -226,6 +235,42 @@ class FlatGradReducer:
         self._sunk.add(p)
         return b['flat'][off:off + numel]
 
+    def note_producer(self, params, stream):
+        """the gradients of these parameters are being written on `stream` (a side stream / graph branch), not on the stream the node
+        that returns them runs on: the bucket's release waits for THAT stream"""
+        for p in params:
+            if p is not None and p in self._slot:
+                self._producer[p] = stream
+
+    def _arrival(self, p):
+        """an event behind the gradient of p on the stream that produces it"""
+        b = self._bucket_of[p]
+        if not b['flat'].is_cuda:                     # host tensors (gloo): no streams
+            return
+        st = self._producer.pop(p, None)
+        if st is None:
+            st = torch.cuda.current_stream(b['flat'].device)
+        evs = self._bucket_events.setdefault(id(b), {})
+        ent = evs.get(st.cuda_stream)
+        if ent is None:
+            ev = self._event_pool.pop() if (self._event_pool and self._capturing is None) else torch.cuda.Event()
+            ent = evs[st.cuda_stream] = (st, ev)
+        ent[1].record(st)
+
+    def _join_streams(self, b):
+        """the current stream waits for the gradients of bucket b that other streams produced"""
+        cur = torch.cuda.current_stream(b['flat'].device)
+        for key, (st, ev) in self._bucket_events.get(id(b), {}).items():
+            if key != cur.cuda_stream:
+                cur.wait_event(ev)
+
+    def _reset_streams(self):
+        if self._capturing is None:
+            for evs in self._bucket_events.values():
+                self._event_pool.extend(ev for _, ev in evs.values())
+        self._bucket_events = {}
+        self._producer.clear()
+
     def deliver(self, params):
         """the gradients of these parameters have been written into their slots (enqueued on the current stream): count them as
         arrived - a bucket that is complete leaves now, while the backward goes on"""
@@ -244,6 +289,7 @@ class FlatGradReducer:
     def zero_grad(self):
         self._next = 0
         self._sunk.clear()
+        self._reset_streams()
         for b in self.buckets:
             b['flat'].zero_()
             b['pending'] = len(b['params'])
@@ -260,6 +306,7 @@ class FlatGradReducer:
         an unused parameter); copy them into the buckets (one multi-tensor copy per bucket) and make the buckets'
         views the parameters' .grad again, ready for finish()."""
         self._next = 0
+        self._reset_streams()                         # (events of an earlier eager step say nothing about the copies below)
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
@@ -312,6 +359,7 @@ class FlatGradReducer:
         self._capturing = mode
         self._next = 0
         self._sunk.clear()
+        self._reset_streams()
         self._cap_works = []
         self._arrived = 0
         self.emit_log = []           # (bucket, gradients that had arrived when its release point was captured) - tests
@@ -328,24 +376,57 @@ class FlatGradReducer:
                     raise RuntimeError('psnd_event_create failed')
                 self._events.append(ev)
 
+    def _release_on(self, b):
+        """the stream a bucket is released from: the reducer's RELEASE stream, behind the events of every stream that produced one of the
+        bucket's gradients.  Neither the backward's main stream nor a branch waits for the others at a release, and the collective is
+        never issued from a graph branch (capturing RCCL's all-reduce from a resblock branch of the HiFi-GAN step ended the process in
+        hipStreamEndCapture).  PSND_DDP_RELEASE=current: round 4's behaviour, released from whatever stream the last hook ran on."""
+        dev = b['flat'].device
+        if not b['flat'].is_cuda:
+            import contextlib
+            return contextlib.nullcontext()
+        if os.environ.get('PSND_DDP_RELEASE', 'stream') != 'stream':
+            self._join_streams(b)
+            return torch.cuda.current_stream(dev)
+        if self._release is None:
+            self._release = torch.cuda.Stream(device=dev)
+        rel = self._release
+        # the releasing stream itself (where the last gradient arrived, or - nothing having arrived through a hook: load_grads / capture_end /
+        # finish on an untouched bucket - where the gradients were copied in), then every other stream that produced one
+        rel.wait_stream(torch.cuda.current_stream(dev))
+        for st, ev in self._bucket_events.get(id(b), {}).values():
+            rel.wait_event(ev)
+        self._release_used = True
+        return rel
+
+    def _join_release(self, dev):
+        """the current stream waits for what was enqueued on the release stream (the end of a backward pass / a capture)"""
+        if self._release is not None and self._release_used and dev.type == 'cuda':
+            torch.cuda.current_stream(dev).wait_stream(self._release)
+            self._release_used = False
+
     def _emit_bucket(self, i):
         """captured: gradients of bucket i (static tensors of the graph's pool) -> its flat buffer, then the release point"""
         b = self.buckets[i]
-        views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
-        # (a gradient that a node wrote straight into its slot - cl.GRAD_SINK - is there already)
-        have = [(v, p.grad) for v, p in zip(views, b['params']) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
-        for v, p in zip(views, b['params']):
-            if p.grad is None:
-                v.zero_()            # a parameter the captured backward never reached
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        mode = self._capturing
-        if mode == 'capture':
-            self._cap_works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
-        elif mode == 'events':
-            from ._lib import lib, check
-            check(lib().psnd_event_record_external(self._events[i], torch.cuda.current_stream(b['flat'].device).cuda_stream),
-                  'psnd_event_record_external')
+        rel = self._release_on(b)
+        with (torch.cuda.stream(rel) if b['flat'].is_cuda else rel):
+            views = [b['flat'][off:off + p.numel()].view_as(p) for p, off in zip(b['params'], b['offs'])]
+            # (a gradient that a node wrote straight into its slot - cl.GRAD_SINK - is there already)
+            have = [(v, p.grad) for v, p in zip(views, b['params']) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+            for v, p in zip(views, b['params']):
+                if p.grad is None:
+                    v.zero_()            # a parameter the captured backward never reached
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                if b['flat'].is_cuda:
+                    for _, g in have:
+                        g.record_stream(rel)
+            mode = self._capturing
+            if mode == 'capture':
+                self._cap_works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
+            elif mode == 'events':
+                from ._lib import lib, check
+                check(lib().psnd_event_record_external(self._events[i], rel.cuda_stream), 'psnd_event_record_external')   # (events mode: HIP tensors only)
         self.launch_log.append(i)
         self.handover_log.append((i, self._in_deliver))
         self.emit_log.append((i, self._arrived))
@@ -358,6 +439,7 @@ class FlatGradReducer:
         for w in self._cap_works:
             w.wait()
         self._cap_works = []
+        self._join_release(self.buckets[0]['flat'].device)
         mode, self._capturing = self._capturing, None
         self._sunk.clear()
         self._next = 0
@@ -395,6 +477,7 @@ class FlatGradReducer:
     def _on_grad(self, p):
         if self._capturing is not None:
             b = self._bucket_of[p]
+            self._arrival(p)
             b['pending'] -= 1
             self._arrived += 1
             if self._capturing != 'deferred':
@@ -405,6 +488,7 @@ class FlatGradReducer:
         if self.deferred:            # backward is being captured / replayed as a hipGraph: no collective from inside it
             return
         b = self._bucket_of[p]
+        self._arrival(p)
         b['pending'] -= 1
         # collectives are issued in FIXED bucket order on every rank: a completed bucket launches from the hook only when all
         # earlier buckets have launched (a parameter without a gradient on one rank only - a data-dependent branch - would
@@ -412,7 +496,8 @@ class FlatGradReducer:
         # out, in order, in finish()
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             nb = self.buckets[self._next]
-            nb['work'] = dist.all_reduce(nb['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            with (torch.cuda.stream(self._release_on(nb)) if nb['flat'].is_cuda else self._release_on(nb)):
+                nb['work'] = dist.all_reduce(nb['flat'], op=dist.ReduceOp.SUM, async_op=True)
             self.launch_log.append(self._next)
             self.handover_log.append((self._next, self._in_deliver))
             self._next += 1
@@ -443,8 +528,10 @@ class FlatGradReducer:
                     '(requires_grad = False).', b['pending'], self._next, len(self.buckets))
         for i in range(self._next, len(self.buckets)):
             b = self.buckets[i]
-            b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            with (torch.cuda.stream(self._release_on(b)) if b['flat'].is_cuda else self._release_on(b)):
+                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
             self.launch_log.append(i)
+        self._join_release(self.buckets[0]['flat'].device)
         for b in self.buckets:
             b['work'].wait()
             if average:

@@ -542,9 +542,11 @@ class Linear1x1(torch.autograd.Function):
         # a launch) and nothing else shares the hardware queues with the step.
         from . import cl
         side = None
-        if (need_x and (need_w or need_b) and cl.BRANCH_PARAM_GRADS and cl.AUTO_SECTIONS and cl.GRAD_SINK is None
+        if (need_x and (need_w or need_b) and cl.BRANCH_PARAM_GRADS and cl.AUTO_SECTIONS
                 and all(q is None or (q.is_leaf and q.grad is None and cl.single_use(q)) for q in ctx.params)):
             side = cl.param_stream(dev)
+            if cl.GRAD_SINK is not None:       # a reducer's bucket waits for the stream that WRITES these gradients (round 5)
+                cl.GRAD_SINK.note_producer(ctx.params, side)
         with torch.cuda.device(dev):
             if side is None:
                 check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), ptr(gw), ptr(part), ptr(gb),
@@ -643,7 +645,7 @@ class AttentionKVQ(torch.autograd.Function):
         from . import cl
         args = (ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq), ctx.bf16)
         with torch.cuda.device(dev):
-            if ATTN_BWD_TWO_STREAMS and cl.AUTO_SECTIONS and cl.GRAD_SINK is None:
+            if ATTN_BWD_TWO_STREAMS and cl.AUTO_SECTIONS:
                 # the key / value and the query gradient kernels need `delta` only and write disjoint rows of gkvq: two streams (inside
                 # the step graph: two branches) behind the delta launch, joined before the projection's backward reads gkvq
                 main, side = torch.cuda.current_stream(dev), cl.branch_streams(dev, 1)[0]

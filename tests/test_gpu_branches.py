@@ -146,3 +146,13 @@ def test_from_cl_tanh_and_its_backward():
     x = torch.randn(N, C, T, device='cuda')
     out = torch.empty_like(buf)
     assert lib().psnd_to_cl(ptr(x), N, C, T, shape.Lp, HP, 32, 2, ptr(out), stream_ptr(x.device)) != 0
+
+
+def test_a_gradient_reducer_keeps_the_branches_off_by_default(monkeypatch):
+    """Trainer._capture: graph branches next to an active FlatGradReducer are opt-in (PSND_DDP_BRANCHES=1; round 5 measured 3.27 ms against
+    4.1 ms for the config-3 step on a one-rank RCCL group, but the replayed gradients were not reproducible next to the in-backward
+    hand-over - tools/r05/dbg_branch_reducer.py).  The switch the capture derives must say so."""
+    import inspect
+    from pytorch_sound_amd import trainer
+    src = inspect.getsource(trainer.Trainer._capture)
+    assert "os.environ.get('PSND_DDP_BRANCHES', '0') != '1'" in src
