@@ -691,9 +691,11 @@ def conv_transpose_cl(xa, up, shape, act_slope=0.1):
     xa: activated CL input (N, Lp, Cin_p).  Returns (raw, leaky_relu(raw, act_slope), CLShape of the output)."""
     s, k, p = up.stride, up.weight_v.shape[2] if hasattr(up, 'weight_v') else up.weight.shape[2], up.padding
     N, T, HP = shape.N, shape.L, shape.HP
-    out_shape = CLShape(N, T * s, HP)
+    if k - 1 - p < 0 or max(k - 1 - p, p) > HP:
+        raise _lib.PsndError('conv_transpose_cl: k = %d, padding = %d needs a halo of %d rows (have %d)' % (k, p, max(k - 1 - p, p), HP))
+    out_shape = CLShape(N, (T - 1) * s - 2 * p + k, HP)       # nn.ConvTranspose1d's output length (T * s for k - 2 p = s)
     xu = torch.zeros((N, out_shape.Lp, xa.shape[2]), dtype=xa.dtype, device=xa.device)
-    xu[:, HP:HP + T * s:s, :] = xa[:, HP:HP + T, :]
+    xu[:, HP:HP + (T - 1) * s + 1:s, :] = xa[:, HP:HP + T, :]
     w_c = up.effective_weight().permute(1, 0, 2).flip(2).contiguous()            # (Cout, Cin, k) of the equivalent conv
     g = w_c.flatten(1).norm(dim=1).view(-1, 1, 1)
     raw, act = FusedConvCL.apply(xu, w_c, g, up.bias, None, out_shape, 1, True, True, act_slope, None, k - 1 - p)

@@ -191,8 +191,9 @@ class Generator(nn.Module):
     #      conv_pre, every ResBlock conv and conv_post with leaky-relu / bias / residual / weight norm fused, the ConvTranspose1d
     #      upsamplers in polyphase form (cl.ConvTransposeCL: k = 2 * stride, no zero multiplied), the mean over a stage's
     #      resblocks + the next activation in one pass (cl.MeanActCL).  fp32 in / fp32 out, fp32 accumulation, bf16 between convs;
-    #      the activations never leave the CL layout.  A/B switches: cl_upsample = 'library' (round 1: library ConvTranspose1d
-    #      between two layout kernels) or 'kernel' (a convolution over zero-spread rows).
+    #      the activations never leave the CL layout.  Upsamplers the polyphase kernel does not cover (odd stride, k != 2 * stride) run
+    #      as a convolution over zero-spread rows on the same conv kernels (cl.conv_transpose_cl) - chosen automatically (round 5);
+    #      cl_upsample = 'kernel' forces that form (parity tests).
     use_cl = True
     cl_upsample = 'polyphase'
     cl_branches = os.environ.get('PSND_HIFIGAN_BRANCHES', '1') == '1'      # a stage's resblocks on parallel streams (0: one stream, the A/B of tools/r04/ab_branches.sh)
@@ -228,22 +229,26 @@ class Generator(nn.Module):
                     raise PsndError('hifi_gan: conv with k=%d, dilation %d (tap reach %d) is beyond the gfx950 conv kernels '
                                     '(reach <= 25, or <= 40 with k <= 7); use_cl = False selects the library formulation'
                                     % (k, c.dilation, c.padding))
-        if self.cl_upsample == 'polyphase':
-            for u in self.ups:
-                k = u.weight_v.shape[2]
-                # k = 2 * stride with the "same" padding (k - stride) / 2: an odd stride would make the output T * stride + 1
-                # samples long (padding rounds down), which the polyphase row map does not produce
-                if k != 2 * u.stride or (k - u.stride) % 2 != 0 or 2 * u.padding != k - u.stride:
-                    raise PsndError('hifi_gan: ConvTranspose1d(k=%d, stride=%d, padding=%d): the polyphase kernel needs k = 2 * '
-                                    'stride, an even stride and padding = stride / 2 (set cl_upsample = "kernel" for the zero-spread '
-                                    'convolution, or use_cl = False for the library formulation)'
-                                    % (k, u.stride, u.padding))
+        for u in self.ups:
+            k = u.weight_v.shape[2]
+            if k - 1 - u.padding < 0 or getattr(u, 'output_padding', 0) not in (0, (0,)):
+                raise PsndError('hifi_gan: ConvTranspose1d(k=%d, stride=%d, padding=%d, output_padding=%s) is beyond the gfx950 kernels; '
+                                'use_cl = False selects the library formulation' % (k, u.stride, u.padding, getattr(u, 'output_padding', 0)))
+
+    def _polyphase_ok(self):
+        """the polyphase kernel (psnd_convtr1d_*) needs k = 2 * stride, an even stride and padding = stride / 2 (an odd stride makes the
+        reference's output T * stride + 1 samples long - padding rounds down - which its row map does not produce)"""
+        for u in self.ups:
+            k = u.weight_v.shape[2]
+            if k != 2 * u.stride or (k - u.stride) % 2 != 0 or 2 * u.padding != k - u.stride:
+                return False
+        return True
 
     def forward_cl(self, x):
         from pytorch_sound_amd import cl
         self._check_cl()
-        if self.cl_upsample != 'polyphase':
-            return self._forward_cl_ab(x)
+        if self.cl_upsample != 'polyphase' or not self._polyphase_ok():
+            return self._forward_cl_zero_spread(x)
         N, _, T = x.shape
         nst = len(self.ups)
         convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
@@ -294,46 +299,29 @@ class Generator(nn.Module):
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return cl.FromCLTanh.apply(y, 1, T, shape)
 
-    def _forward_cl_ab(self, x):
-        """round 1's upsampling variants, kept for A/B measurements (cl_upsample = 'library' | 'kernel')"""
+    def _forward_cl_zero_spread(self, x):
+        """every ConvTranspose1d as a convolution over zero-spread rows on the CL conv kernels (cl.conv_transpose_cl: any kernel size,
+        stride and padding; (T - 1) * stride - 2 * padding + k output samples as hifi_gan.py:107-110 gives) - the form for upsamplers the
+        polyphase kernel does not cover; s - 1 of every s products are zeros"""
         from pytorch_sound_amd import cl
         N, _, T = x.shape
         halo = max([self.conv_pre.padding, self.conv_post.padding] + [
             c.padding for b in self.resblocks for c in self._block_convs(b)] + [
-            u.weight_v.shape[2] - 1 - u.padding for u in self.ups])
+            max(u.weight_v.shape[2] - 1 - u.padding, u.padding) for u in self.ups])
         shape = cl.CLShape(N, T, halo)
         convs = [self.conv_pre, self.conv_post] + [c for b in self.resblocks for c in self._block_convs(b)]
         prep = cl.prep_all(self, convs)
         _, xa = cl.fused_conv(cl.ToCL.apply(x, shape, 0), self.conv_pre, shape, None, False, True, LRELU_SLOPE, prep)
-        kernel_ups = self.cl_upsample == 'kernel'
-        h = None                                                   # library mode: (N, C, T) fp32 between the stages
         for i, up in enumerate(self.ups):
             last = i + 1 == len(self.ups)
-            if kernel_ups:
-                x_raw, x_act, shape = cl.conv_transpose_cl(xa, up, shape, LRELU_SLOPE)
-                T = shape.L
-            else:
-                if h is None:
-                    h = cl.FromCL.apply(xa, up.weight_v.shape[0], T, shape)      # leaky_relu(conv_pre(x), 0.1)
-                h = up(h)
-                T = h.shape[2]
-                shape = cl.CLShape(N, T, halo)
-                x_raw = cl.ToCL.apply(h, shape, 0)
-                x_act = cl.ToCL.apply(F.leaky_relu(h, LRELU_SLOPE), shape, 0)
+            x_raw, x_act, shape = cl.conv_transpose_cl(xa, up, shape, LRELU_SLOPE)
+            T = shape.L
             stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
-            acc = None
+            rs = []
             for block in stage:
-                if hasattr(block, 'convs1'):
-                    r, _ = cl.resblock1_cl(block, x_raw, x_act, shape, prep=prep)
-                else:
-                    r, _ = cl.resblock2_cl(block, x_raw, x_act, shape, prep=prep)
-                r = r.float() if kernel_ups else cl.FromCL.apply(r, up.weight_v.shape[1], T, shape)
-                acc = r if acc is None else acc + r
-            h = F.leaky_relu(acc / self.num_kernels, 0.01 if last else LRELU_SLOPE)   # last: default slope, as the reference
-            if kernel_ups:
-                xa = h.to(torch.bfloat16)                          # CL layout, halo rows stay zero
-        if not kernel_ups:
-            xa = cl.ToCL.apply(h, shape, 0)
+                fn = cl.resblock1_cl if hasattr(block, 'convs1') else cl.resblock2_cl
+                rs.append(fn(block, x_raw, x_act, shape, prep=prep)[0])
+            xa = cl.MeanActCL.apply(0.01 if last else LRELU_SLOPE, *rs)      # last: F.leaky_relu's default slope, as the reference
         y, _ = cl.fused_conv(xa, self.conv_post, shape, None, True, False, prep=prep)
         return cl.FromCLTanh.apply(y, 1, T, shape)
 

@@ -67,7 +67,7 @@ def _compare(got, want, tol_out, tol_gx, tol_all, tol_each, tag):
     assert each[0][0] <= tol_each, (tag, each[:3])
 
 
-@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'kernel'])
 def test_hifi_gan_v1_config3_shape(upsample):
     """registered hifi_gan_v1, 16 clips x 32 frames -> 16 x 8192 samples (the config-3 training shape), forward + backward"""
     from pytorch_sound_amd.models import build_model
@@ -92,7 +92,7 @@ def test_hifi_gan_v1_config3_shape(upsample):
     assert st[1] > 0 and st[3] > 0 and st[0] > 0, st
     g.use_cl = False
     ref32 = _run(g, g, x, w)
-    emul = _run(g, lambda t: E.generator(g, t, 'library' if upsample == 'library' else 'kernel'), x, w)
+    emul = _run(g, lambda t: E.generator(g, t, 'kernel'), x, w)
     g.use_cl = True
     _compare(got, ref32, 4e-2, 8e-2, 8e-2, 1.0, 'v1 vs fp32')          # single tensors vs fp32: see the emulation bound below
     # measured: out 7e-4, all parameter gradients together 1.2e-3; the input gradient and single bias gradients 2.4e-2 .. 3.5e-2 -
@@ -101,7 +101,7 @@ def test_hifi_gan_v1_config3_shape(upsample):
 
 
 @pytest.mark.parametrize('name', ['tiny1', 'tiny2'])
-@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'kernel'])
 def test_reference_golden_on_gpu(golden, name, upsample):
     """the imported reference's outputs and gradients (fp32, CPU) against the CL kernels on the GPU"""
     from pytorch_sound_amd.models.vocoders import hifi_gan
@@ -118,7 +118,7 @@ def test_reference_golden_on_gpu(golden, name, upsample):
             {n: torch.from_numpy(gd['%s/g/%s' % (name, n)]).cuda() for n, _ in g.named_parameters()})
     # fp32 reference vs bf16 kernels: accumulated rounding of the whole stack
     _compare(got, want, 4e-2, 1.5e-1, 1e-1, 0.5, name + ' vs reference golden')
-    emul = _run(g, lambda t: E.generator(g, t, 'library' if upsample == 'library' else 'kernel'), x, w)
+    emul = _run(g, lambda t: E.generator(g, t, 'kernel'), x, w)
     _compare(got, emul, 1e-3, 2e-2, 2e-2, 3e-2, name + ' vs bf16 emulation')      # measured: output bit-exact, gradients 5e-3 .. 9e-3
     _compare(emul, want, 4e-2, 1.5e-1, 1e-1, 0.5, name + ' emulation vs reference golden')   # the emulation itself is the reference's function
 

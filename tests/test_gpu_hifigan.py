@@ -31,7 +31,7 @@ def _make(resblock, rates, ksz, c0, rk, rd):
     ('1', [4, 2], [8, 4], 64, [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
     ('2', [4, 4], [8, 8], 64, [3, 5], [[1, 2], [2, 6]]),
 ])
-@pytest.mark.parametrize('upsample', ['polyphase', 'library', 'kernel'])
+@pytest.mark.parametrize('upsample', ['polyphase', 'kernel'])
 def test_generator_cl_matches_torch_path(cfg, upsample):
     g = _make(*cfg)
     g.cl_upsample = upsample

