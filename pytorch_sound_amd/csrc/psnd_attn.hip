@@ -1517,8 +1517,16 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
     return PSND_OK;
 }
 
+// head dimension padded to 32 / 64 / 128 (round 5: 128 - MultiHeadAttention(256, 2), modules.py:24-27 takes any hidden_dim / num_head)
+#define PSND_ATTN_LAUNCH(kern_, flag_, st_)                                                                          \
+    do {                                                                                                            \
+        if (p.d <= 32) hipLaunchKernelGGL((kern_<32, flag_>), grid, dim3(256), 0, st_, p);                          \
+        else if (p.d <= 64) hipLaunchKernelGGL((kern_<64, flag_>), grid, dim3(256), 0, st_, p);                     \
+        else hipLaunchKernelGGL((kern_<128, flag_>), grid, dim3(256), 0, st_, p);                                   \
+    } while (0)
+
 static int mha_check(const char *what, int64_t N, int H, int C, int64_t T) {
-    if (N <= 0 || H <= 0 || C % H != 0 || C / H > 64) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: hidden_dim %d / heads %d: head dimensions up to 64 only", what, C, H);
+    if (N <= 0 || H <= 0 || C % H != 0 || C / H > 128) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: hidden_dim %d / heads %d: head dimensions up to 128 only", what, C, H);
     if (T <= 0 || T >= ((int64_t)1 << 24) || (int64_t)H * N > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: T=%lld, H*N=%lld", what, (long long)T, (long long)(H * N));
     return PSND_OK;
 }
@@ -1534,15 +1542,11 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
     if (bf16) {
         if (att) {
-            if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-            else hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-        } else if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+            PSND_ATTN_LAUNCH(attn_fwd_bf16_kernel, true, static_cast<hipStream_t>(stream));
+        } else PSND_ATTN_LAUNCH(attn_fwd_bf16_kernel, false, static_cast<hipStream_t>(stream));
     } else if (att) {
-        if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-        else hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    } else if (p.d <= 32) hipLaunchKernelGGL((attn_fwd_kernel<32, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+        PSND_ATTN_LAUNCH(attn_fwd_kernel, true, static_cast<hipStream_t>(stream));
+    } else PSND_ATTN_LAUNCH(attn_fwd_kernel, false, static_cast<hipStream_t>(stream));
     PSND_CHECK_LAUNCH("mha_fwd");
     return PSND_OK;
 }
@@ -1570,28 +1574,20 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     if (!(parts & 2)) {
     } else if (bf16) {
         if (p.gatt) {
-            if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
-        } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
+            PSND_ATTN_LAUNCH(attn_bwd_kv_bf16_kernel, true, st);
+        } else PSND_ATTN_LAUNCH(attn_bwd_kv_bf16_kernel, false, st);
     } else if (p.gatt) {
-        if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_kernel<32, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_bwd_kv_kernel<64, true>), grid, dim3(256), 0, st, p);
-    } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_kv_kernel<32, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_kv_kernel<64, false>), grid, dim3(256), 0, st, p);
+        PSND_ATTN_LAUNCH(attn_bwd_kv_kernel, true, st);
+    } else PSND_ATTN_LAUNCH(attn_bwd_kv_kernel, false, st);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
     if (!(parts & 4)) {
     } else if (bf16) {
         if (p.gatt) {
-            if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, true>), grid, dim3(256), 0, st, p);
-        } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<32, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<64, false>), grid, dim3(256), 0, st, p);
+            PSND_ATTN_LAUNCH(attn_bwd_q_bf16_kernel, true, st);
+        } else PSND_ATTN_LAUNCH(attn_bwd_q_bf16_kernel, false, st);
     } else if (p.gatt) {
-        if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_kernel<32, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((attn_bwd_q_kernel<64, true>), grid, dim3(256), 0, st, p);
-    } else if (p.d <= 32) hipLaunchKernelGGL((attn_bwd_q_kernel<32, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_q_kernel<64, false>), grid, dim3(256), 0, st, p);
+        PSND_ATTN_LAUNCH(attn_bwd_q_kernel, true, st);
+    } else PSND_ATTN_LAUNCH(attn_bwd_q_kernel, false, st);
     PSND_CHECK_LAUNCH("mha_bwd(q)");
     return PSND_OK;
 }

@@ -88,9 +88,9 @@ class MultiHeadAttention(nn.Module):
         kvq = _conv1x1(self.linear_kvq, input)
         if _hip_ok(input):
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
-            if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 64:
+            if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 128:
                 from pytorch_sound_amd._lib import PsndError
-                raise PsndError('MultiHeadAttention(hidden_dim=%d, heads=%d): psnd_mha_* covers head dimensions up to 64 that divide '
+                raise PsndError('MultiHeadAttention(hidden_dim=%d, heads=%d): psnd_mha_* covers head dimensions up to 128 that divide '
                                 'hidden_dim; there is no library path for a HIP tensor' % (self.hidden_dim, self.heads))
             from pytorch_sound_amd import kernels as K
             mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
@@ -121,8 +121,8 @@ class MultiHeadAttention(nn.Module):
             # one "head" per batch entry (the heads are folded into the batch here already), scores on the chip, no library bmm
             from pytorch_sound_amd import kernels as K
             from pytorch_sound_amd._lib import PsndError
-            if not (k.shape == v.shape == q.shape) or k.dim() != 3 or k.size(1) > 64:
-                raise PsndError('scale_dot_att on HIP tensors: (B, d, T) operands of one shape with d <= 64 (psnd_mha_*), got %s / %s / %s; '
+            if not (k.shape == v.shape == q.shape) or k.dim() != 3 or k.size(1) > 128:
+                raise PsndError('scale_dot_att on HIP tensors: (B, d, T) operands of one shape with d <= 128 (psnd_mha_*), got %s / %s / %s; '
                                 'there is no library path for a HIP tensor' % (tuple(k.shape), tuple(v.shape), tuple(q.shape)))
             dt = q.dtype
             kvq = torch.cat([k.float(), v.float(), q.float()], dim=1)
