@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from pytorch_sound_amd import dense as D
 from pytorch_sound_amd import host as H
 from pytorch_sound_amd import kernels as K
 from pytorch_sound_amd.utils.mel import mel_filterbank
@@ -96,6 +97,8 @@ class STFT(nn.Module):
         wav = _as_2d(wav)
         if not wav.is_cuda:                                  # host tensors: the reference's formulation in torch ops (host.py)
             return H.stft_mag_phase(wav, self.filter_length, self.hop_length, self._host_window(), H.FRAMING_CENTER)
+        if not D.is_fast_size(self.filter_length):           # e.g. 800 / 1200 / 2400: the dense-basis GEMM on the matrix cores (dense.py)
+            return D.stft_mag_phase(wav, self.filter_length, self.hop_length, self._window_np, self.pad_amount)
         mag, phase = K.StftMagPhase.apply(wav, self._plan(wav.device), self.filter_length, self.hop_length,
                                           K.FRAMING_CENTER, 0.0, True)
         return mag, phase
@@ -106,6 +109,8 @@ class STFT(nn.Module):
         if not wav.is_cuda:
             return H.stft_mag_phase(wav, self.filter_length, self.hop_length, self._host_window(), H.FRAMING_CENTER,
                                     want_phase=False)[0]
+        if not D.is_fast_size(self.filter_length):
+            return D.stft_mag_phase(wav, self.filter_length, self.hop_length, self._window_np, self.pad_amount, want_phase=False)[0]
         return K.StftMagPhase.apply(wav, self._plan(wav.device), self.filter_length, self.hop_length,
                                     K.FRAMING_CENTER, 0.0, False)[0]
 
@@ -115,6 +120,8 @@ class STFT(nn.Module):
     def inverse(self, magnitude: torch.Tensor, phase: torch.Tensor, eps: float = 1e-9) -> torch.Tensor:
         if not magnitude.is_cuda:
             return H.istft(magnitude, phase, self.filter_length, self.hop_length, self._host_window(), eps)
+        if not D.is_fast_size(self.filter_length):
+            return D.istft(magnitude, phase, self.filter_length, self.hop_length, self._window_np, eps)
         # square_window = window ** 2 is the reference's buffer; the window itself comes from the plan's source (cached per device:
         # the overlap-add envelope of IStft.backward is keyed on this tensor)
         win = self._plans.get('win', magnitude.device, lambda: torch.from_numpy(self._window_np))

@@ -161,3 +161,40 @@ def test_polar_bwd_kernel_matches_formula():
             eim = g0 * np.sin(ph.astype(np.float64)) + q * np.cos(ph.astype(np.float64))
             sc = max(np.abs(ere).max(), np.abs(eim).max())
             assert np.abs(_np(gre) - ere).max() <= 2e-6 * sc and np.abs(_np(gim) - eim).max() <= 2e-6 * sc
+
+
+# ---- round 5: filter_length that is not a power of two on HIP tensors (reference transforms.py:19-51 takes any) -------------------------------
+@pytest.mark.parametrize('n,hop,win', [(800, 200, None), (1200, 300, None), (2400, 600, 2000), (1000, 250, None), (48, 12, None)])
+def test_stft_any_even_filter_length_on_hip_tensors(n, hop, win):
+    """STFT(filter_length = 800 / 1200 / 2400 ...) used to raise on a HIP tensor; it now runs the reference's dense-basis formulation on the
+    exact-fp32 matrix-core GEMM (pytorch_sound_amd/dense.py, psnd_linear1x1_*): magnitude and phase against the float64 oracle, the
+    magnitude's gradient against the oracle's adjoint, inverse(transform(x)) == x, no library convolution / fft / bmm on the way.
+    Tolerance 2e-5 of the largest bin (fp32 sums of n products)."""
+    import numpy as np
+    from conftest import seeded_wav
+    from oracle import features as ofe
+    from pytorch_sound_amd.models.transforms import STFT
+    from test_gpu_no_library_paths import forbid_library_ops
+    dev = torch.device('cuda:0')
+    N, T = 3, 6 * n + 37
+    wav_np = seeded_wav(n + hop, N, T)
+    stft = STFT(n, hop, win).to(dev)
+    x = torch.from_numpy(wav_np).to(dev).requires_grad_(True)
+    with forbid_library_ops():
+        mag, phase = stft.transform(x)
+        g = torch.from_numpy(np.random.RandomState(1).randn(*mag.shape).astype(np.float32)).to(dev)
+        (mag * g).sum().backward()
+        rec = stft.inverse(mag.detach(), phase)
+    ref = ofe.stft_mag_f64(wav_np, n, hop, win)
+    assert mag.shape == ref.shape
+    assert np.abs(mag.detach().cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    re, im = ofe.stft_reim_f64(wav_np, n, hop, win) if hasattr(ofe, 'stft_reim_f64') else (None, None)
+    if re is not None:
+        strong = ref > 1e-3 * ref.max()                                  # the phase of a near-zero bin is noise
+        d = np.angle(np.exp(1j * (phase.cpu().numpy() - np.arctan2(im, re))))
+        assert np.abs(d[strong]).max() <= 2e-3
+    gref = ofe.stft_mag_bwd_f64(g.cpu().numpy().astype(np.float64), wav_np, n, hop, win)
+    assert np.abs(x.grad.cpu().numpy() - gref).max() <= 5e-5 * np.abs(gref).max()
+    Fr = mag.shape[2]
+    assert rec.shape == (N, (Fr - 1) * hop)
+    assert float((rec - x.detach()[:, :(Fr - 1) * hop]).abs().max()) <= 2e-5 * float(x.detach().abs().max()) + 2e-5
