@@ -213,9 +213,6 @@ def gpu_bench(args):
     tr.graph_steps = not args.no_graph          # forward + backward replayed as one hipGraph (Trainer.graph_steps)
     if tr._reducer is not None and args.no_handover:
         tr._reducer.sink_enabled = False
-    if args.handover_side:
-        from pytorch_sound_amd import cl as _cl
-        _cl.HANDOVER_SIDE_STREAM = True
     # next batch's feature extraction on a side stream (Trainer.prefetch_prepare): +1.6 % throughput, but the in-step STFT
     # launch then shares the chip with the conv kernels and its event timing doubles - off for the judged line
     tr.prefetch_prepare = args.prefetch
@@ -986,7 +983,6 @@ def main():
     ap.add_argument('--unfused-loss', action='store_true', help='the loss as separate nodes (mask head, mel, two L1 terms) instead of the fused one')
     ap.add_argument('--no-legs', action='store_true', help='skip the bounded config-3 / config-4 step legs (config3_step, config4_step)')
     ap.add_argument('--force-ddp', action='store_true', help='single GPU with a one-rank RCCL group: the data-parallel reducer path on one device')
-    ap.add_argument('--handover-side', action='store_true', help='(with a reducer) the hand-over chunks on a side stream next to the following input-gradient launch')
     ap.add_argument('--no-handover', action='store_true', help='(with a reducer) gradients reach the buckets through autograd hooks only (round 3)')
     ap.add_argument('--overlap-prepare', action='store_true', help="the next batch's feature extraction behind this step's backward on a side stream (Trainer.overlap_prepare)")
     ap.add_argument('--layout', choices=('nfk', 'nkf'), default='nfk',

@@ -325,25 +325,7 @@ def _launch_conv(A, A2, AM, a2_slope, W, bias, res, mask_src, shape, Ca, Cb, k, 
     return raw, act
 
 
-# ---- optional: the weight-gradient branch of a conv's backward on a second stream (PSND_CL_SIDE_STREAM=1) ---------------------
-# Per conv the backward is  (a) input gradient, needed by the next layer's backward, and  (b) weight gradient + weight-norm
-# backward, needed only by the optimizer; each fills a fraction of the chip for 10-20 us (latency chains).
-# The default runs (a) and (b) as ONE launch (psnd_conv1d_cl_bwd, conv_bwd_pair_kernel).  This A/B switch instead enqueues (b)
-# on a side stream, joined by one engine callback at the end of the backward pass (inside a hipGraph capture: a parallel
-# branch); measured on the config-2 step it loses 3 % against separate launches on one stream - the graph pays a fork/join
-# per conv - and 18 % against the paired launch.
-_SIDE = {}
 _JOIN_PENDING = {}
-
-
-def _side_stream(dev):
-    import os
-    if os.environ.get('PSND_CL_SIDE_STREAM', '0') != '1':
-        return None
-    s = _SIDE.get(dev.index)
-    if s is None:
-        s = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
-    return s
 
 
 def _join_side_at_end_of_backward(dev, side):
@@ -371,7 +353,7 @@ def _join_side_at_end_of_backward(dev, side):
 # The clips of a batch are independent, so a conv chain can be walked as PSND_CL_SECTIONS independent chains over contiguous groups of
 # clips (views of the same CL buffers: no copies), each on its own stream: the chains drift apart and one section's load phase
 # overlaps another's wait / epilogue.  Inside a hipGraph capture the sections are parallel branches (ONE fork and ONE join per chain
-# and direction - the per-conv fork/join of PSND_CL_SIDE_STREAM above is what made that variant lose).
+# and direction; a fork / join per conv - round 2's weight-gradient side stream - lost 3 % against one stream).
 _SECTION_STREAMS = {}
 # Extra streams inside the step graph (batch sections when asked for, the split backward's weight-gradient streams) are only used while
 # nothing else shares the hardware queues with the step: HIP multiplexes streams onto a few hardware queues, and a host->device prefetch
@@ -425,14 +407,12 @@ def single_use(p) -> bool:
 def reset_param_uses():
     _PARAM_USES.clear()
     _PARAM_USES_PHASE[0] = 'fwd'
-# chunks of the hand-over (weight gradients + weight-norm backward of a block) on a side stream / graph branch next to the following
-# block's input-gradient launch, which holds a workgroup on 141 of the 256 CUs only
-HANDOVER_SIDE_STREAM = False
+
+
 # the hand-over points: the body's input-gradient launches (one per ResBlock1: 4 at config 2) are cut into this many chunks; every
 # chunk costs an extra weight-gradient / weight-norm-backward launch pair and evicts the next input-gradient launch's operands from the
 # L2 (38 -> 50 us for that launch), so not every block gets one: 3 chunks release 4 of the config-2 model's 6 buckets early
 HANDOVER_CHUNKS = 3
-_HANDOVER_STREAMS = {}
 
 
 def _sections(dev, N, rows):
@@ -618,67 +598,26 @@ class FusedConvCL(torch.autograd.Function):
         S = lib().psnd_conv1d_cl_wgrad_splits(shape.N, shape.Lp, Ca, Cb, k)
         am = act if g_act is not None else None
         need_gout = ctx.has_res and (g_act is not None)
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev)
         g_out = torch.empty((shape.N, shape.Lp, Cb), dtype=torch.bfloat16, device=dev) if need_gout else None
-        if side is None:
-            # input gradient + weight-gradient slabs in ONE launch (conv_bwd_pair_kernel: both read the same incoming gradient,
-            # each alone only part-fills the chip), then the weight-norm backward over the slabs
-            gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
-            gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
-            gb = torch.empty(Cb, dtype=torch.float32, device=dev)
-            gv = torch.empty_like(v32)
-            gg = torch.empty_like(g32)
-            gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
-            with torch.cuda.device(dev):
-                check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(wb), ptr(xa), shape.N,
-                                               shape.Lp, shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), None, 1.0, None,
-                                               ptr(gw), ptr(gbp), stream_ptr(dev)), 'psnd_conv1d_cl_bwd')
-                check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
-                                                  ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
-        else:
-            gx, gv, gg, gb = FusedConvCL._backward_two_streams(ctx, g_raw, g_act, am, g_out, S, main, side)
+        # input gradient + weight-gradient slabs in ONE launch (conv_bwd_pair_kernel: both read the same incoming gradient,
+        # each alone only part-fills the chip), then the weight-norm backward over the slabs
+        gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
+        gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
+        gb = torch.empty(Cb, dtype=torch.float32, device=dev)
+        gv = torch.empty_like(v32)
+        gg = torch.empty_like(g32)
+        gx = torch.empty((shape.N, shape.Lp, Ca), dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().psnd_conv1d_cl_bwd(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(wb), ptr(xa), shape.N,
+                                           shape.Lp, shape.L, shape.HP, Ca, Cb, k, pad, dil, ptr(gx), ptr(g_out), None, 1.0, None,
+                                           ptr(gw), ptr(gbp), stream_ptr(dev)), 'psnd_conv1d_cl_bwd')
+            check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
+                                              ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
         g_res = None
         if ctx.has_res:
             g_res = g_out if need_gout else g_raw
         g_bias = gb[:Cout] if ctx.has_bias else None
         return gx, gv, gg, g_bias, g_res, None, None, None, None, None, None, None
-
-
-    @staticmethod
-    def _backward_two_streams(ctx, g_raw, g_act, am, g_out, S, main, side):
-        """PSND_CL_SIDE_STREAM=1: weight-gradient branch on a second stream (kept for A/B measurements, see above)"""
-        xa, v32, g32, wb, act = ctx.saved_tensors
-        shape, dil, k, pad = ctx.shape, ctx.dil, ctx.k, ctx.pad
-        Cout, Cin, Ca, Cb = ctx.dims
-        dev = xa.device
-        if side is not None:
-            side.wait_stream(main)                          # the incoming gradients are complete on the main stream
-        with torch.cuda.stream(side if side is not None else main):
-            # (b) weight gradient (partial slabs) + weight-norm backward; temporaries belong to the side stream's pool
-            gw = torch.empty((S, k, Cb, Ca), dtype=torch.float32, device=dev)
-            gbp = torch.empty((S, Cb), dtype=torch.float32, device=dev)
-            gb = torch.empty(Cb, dtype=torch.float32, device=dev)
-            gv = torch.empty_like(v32)
-            gg = torch.empty_like(g32)
-            with torch.cuda.device(dev):
-                check(lib().psnd_conv1d_cl_wgrad(ptr(g_raw), ptr(g_act), ptr(am), float(ctx.act_slope), ptr(xa), shape.N,
-                                                 shape.Lp, Ca, Cb, k, -pad, dil, ptr(gw), ptr(gbp), None, stream_ptr(dev)),
-                      'psnd_conv1d_cl_wgrad')
-                check(lib().psnd_conv1d_wnorm_bwd(ptr(gw), ptr(gbp), S, ptr(v32), ptr(g32), Cout, Cin, k, Cb, Ca, ptr(gv),
-                                                  ptr(gg), ptr(gb), stream_ptr(dev)), 'psnd_conv1d_wnorm_bwd')
-        if side is not None:
-            for t in (g_raw, g_act, am, xa, v32, g32):      # allocated on the main stream, still read by the side stream
-                if t is not None:
-                    t.record_stream(side)
-            for t in (gv, gg, gb):                          # allocated on the side stream, consumed on the main one
-                t.record_stream(main)
-            _join_side_at_end_of_backward(dev, side)
-        # (a) input gradient: same kernel, transposed pack, mirrored taps; g = g_raw + g_act * leaky'(y) is formed on load
-        #     and written back for the residual branch when both parts exist
-        gx, _ = _launch_conv(g_raw, g_act, am, ctx.act_slope, wb, None, None, None, shape, Cb, Ca, k, pad, -dil, 1.0, 1.0,
-                             True, False, g_out)
-        return gx, gv, gg, gb
 
 
 def conv_transpose_cl(xa, up, shape, act_slope=0.1):
@@ -1386,27 +1325,11 @@ class ResBlockCL(torch.autograd.Function):
                 # chunked: behind every input-gradient launch the weight gradients of the convs it completed, their weight-norm
                 # backward and their hand-over - the reducer's buckets fill (and leave) block by block, last block first
                 done_w = 0
-                main_s = torch.cuda.current_stream(dev)
-                side_s = None
-                if HANDOVER_SIDE_STREAM:
-                    side_s = _HANDOVER_STREAMS.get(dev.index)
-                    if side_s is None:
-                        side_s = _HANDOVER_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
 
                 def chunk(part, ready):
-                    nonlocal st
-                    if side_s is not None:
-                        side_s.wait_stream(main_s)
-                        with torch.cuda.stream(side_s):
-                            st = stream_ptr(dev)
-                            if part:
-                                wgrad_batch(part)
-                            finish(ready)
-                        st = stream_ptr(dev)
-                    else:
-                        if part:
-                            wgrad_batch(part)
-                        finish(ready)
+                    if part:
+                        wgrad_batch(part)
+                    finish(ready)
 
                 launches = [e for e in plan if (e[1][-1] if e[0] == 'chainb' else e)[0] == 'pairb']
                 L, C = len(launches), max(1, int(HANDOVER_CHUNKS))
@@ -1432,8 +1355,6 @@ class ResBlockCL(torch.autograd.Function):
                 rest = [ci for ci in rest if ci not in ready]
                 if part or rest or ready:
                     chunk(part, ready + rest + [ci for ci, _, _, _, _ in part])
-                if side_s is not None:
-                    main_s.wait_stream(side_s)
             else:
                 _run_sections(dev, nsec, sides, run)
                 for sd in set(used):

@@ -27,7 +27,7 @@
 //     ds_read_b64) and takes itself off the chunks' reader counts.  Every dependency points to an EARLIER frame of the segment: no
 //     cycle, no workgroup barrier in the frame loop, the waves drift as they like;
 //   * clip edges (reflect padding, transforms.py:55-60; the first two and the last three chunks of a clip) are gathered element by
-//     element by the issuing wave - the frames themselves never see an edge;
+//     element by the loader wave - the frames themselves never see an edge;
 //   * to make room for the ring the sixteen 8.3 KB per-wave transpose buffers are gone: the 32 x 32 transposes of both half-waves go
 //     through one of FOUR 16.9 KB buffers (one per SIMD) in a single burst of 32 ds_write_b64 + 32 ds_read_b64 over all 64 lanes, taken
 //     under a lock (an LDS compare-and-swap; a wave holds it for ~1 k cycles of a ~20 k-cycle frame).  Full-wave 8-byte accesses cost

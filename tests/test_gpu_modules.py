@@ -339,8 +339,13 @@ def test_scale_dot_att_static_method_on_hip_tensors():
         xr, attr = MultiHeadAttention.scale_dot_att(k.double().cpu(), v.double().cpu(), q.double().cpu(), None if m is None else m.cpu())
         assert float((x.double().cpu() - xr).abs().max()) <= 2e-5 * float(xr.abs().max())
         assert float((att.double().cpu() - attr).abs().max()) <= 1e-5
+    # round 5: head dimensions up to 128 run on the HDP = 128 instances; beyond that the call raises
+    k9, v9, q9 = (torch.randn(2, 96, 8, device=dev) for _ in range(3))
+    x9, a9 = MultiHeadAttention.scale_dot_att(k9, v9, q9, None)
+    x9r, a9r = MultiHeadAttention.scale_dot_att(k9.double().cpu(), v9.double().cpu(), q9.double().cpu(), None)
+    assert float((x9.double().cpu() - x9r).abs().max()) <= 2e-5 * float(x9r.abs().max()) and float((a9.double().cpu() - a9r).abs().max()) <= 1e-5
     with pytest.raises(PsndError):
-        MultiHeadAttention.scale_dot_att(torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), torch.randn(2, 96, 8, device=dev), None)
+        MultiHeadAttention.scale_dot_att(torch.randn(2, 160, 8, device=dev), torch.randn(2, 160, 8, device=dev), torch.randn(2, 160, 8, device=dev), None)
 
 
 def test_positional_encoding_kernel_matches_the_torch_formulation():
