@@ -715,8 +715,15 @@ class ConvTransposeCL(torch.autograd.Function):
                                              None, ptr(g_eff), ptr(gw), st), 'psnd_convtr1d_cl_bwd')
             check(lib().psnd_convtr1d_wnorm_bwd(ptr(gw), S, ptr(v32), ptr(g32), Cin, Cout, K, stride, Cr, Cip, ptr(gv), ptr(gg), st),
                   'psnd_convtr1d_wnorm_bwd')
-            if ctx.has_bias:   # column sums of the combined gradient (halo rows are zero)
-                return torch.sum((g_eff if g_eff is not None else g_raw).view(-1, Cr), 0, dtype=torch.float32)[:Cout]
+            if ctx.has_bias:   # column sums of the combined gradient (halo rows are zero): psnd_cl_colsum, fp32, fixed order
+                gsrc = (g_eff if g_eff is not None else g_raw).view(-1, Cr)
+                if Cr > 256:   # (wider than the kernel's column groups: not a HiFi-GAN upsampler)
+                    return torch.sum(gsrc, 0, dtype=torch.float32)[:Cout]
+                rows = gsrc.shape[0]
+                part = torch.empty(lib().psnd_cl_colsum_splits(rows, Cr) * Cr, dtype=torch.float32, device=dev)
+                gb_full = torch.empty(Cr, dtype=torch.float32, device=dev)
+                check(lib().psnd_cl_colsum(ptr(gsrc), rows, Cr, ptr(part), ptr(gb_full), st), 'psnd_cl_colsum')
+                return gb_full[:Cout]
             return None
 
         with torch.cuda.device(dev):

@@ -2432,6 +2432,65 @@ extern "C" int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const f
     return PSND_OK;
 }
 
+
+// ---- column sums of a channels-last bf16 matrix: out[c] = sum over rows of g[r][c] in fp32 - the bias gradient of a transposed conv
+//      (hifi_gan.py:107-110: d/d bias = the sum of the output gradient over clips and positions; halo rows are zero).  Two stages, fixed
+//      summation order: a workgroup sums the rows of its split (a thread owns 8 consecutive columns, 16-byte loads), the partial rows
+//      [splits][C] are added by the second launch.  Replaces torch.sum(g.view(-1, C), 0) - 21 us per upsampler at config 3 for ~3 us of
+//      traffic (a library reduction over 32 .. 256 narrow columns).
+static __global__ __launch_bounds__(256) void cl_colsum_partial_kernel(const bf16_t *g, long long rows, int C, int splits, float *part) {
+    __shared__ float red[256 * 8];
+    const int cols8 = C >> 3;                           // column groups of 8
+    const int rpp = 256 / cols8;                        // rows per pass (cols8 <= 256: checked at launch)
+    const int tid = threadIdx.x, cg = tid % cols8, rr = tid / cols8;
+    const long long r0 = rows * blockIdx.x / splits, r1 = rows * (blockIdx.x + 1) / splits;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rr < rpp) {
+        for (long long r = r0 + rr; r < r1; r += rpp) {
+            const u32x4 q = *reinterpret_cast<const u32x4 *>(g + (size_t)r * C + 8 * cg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += __builtin_bit_cast(float, q[j] << 16);
+                acc[2 * j + 1] += __builtin_bit_cast(float, q[j] & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[j];
+    __syncthreads();
+    if (tid < C) {                                      // column tid: the rpp partial sums of its group, in order
+        const int cgc = tid >> 3, j = tid & 7;
+        float sum = 0.f;
+        for (int k = 0; k < rpp; ++k) sum += red[(k * cols8 + cgc) * 8 + j];
+        part[(size_t)blockIdx.x * C + tid] = sum;
+    }
+}
+static __global__ __launch_bounds__(256) void cl_colsum_final_kernel(const float *part, int C, int splits, float *out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float sum = 0.f;
+    for (int s = 0; s < splits; ++s) sum += part[(size_t)s * C + c];
+    out[c] = sum;
+}
+
+extern "C" int psnd_cl_colsum_splits(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 1;
+    const long long want = (rows * (long long)C * 2 + (1 << 15) - 1) >> 15;      // ~32 KB of the matrix per workgroup
+    return (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+}
+
+extern "C" int psnd_cl_colsum(const void *g, int64_t rows, int C, float *part, float *out, void *stream) {
+    if (!g || !part || !out) PSND_FAIL(PSND_E_ARG, "cl_colsum: null pointer");
+    if (C % 8 != 0 || C < 8 || C > 256 || rows <= 0) PSND_FAIL(PSND_E_SHAPE, "cl_colsum: rows=%lld, C=%d (C % 8 == 0, 8 <= C <= 256)", (long long)rows, C);
+    const int splits = psnd_cl_colsum_splits(rows, C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cl_colsum_partial_kernel, dim3(splits), dim3(256), 0, st, static_cast<const bf16_t *>(g), (long long)rows, C, splits, part);
+    PSND_CHECK_LAUNCH("cl_colsum(partial)");
+    hipLaunchKernelGGL(cl_colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, C, splits, out);
+    PSND_CHECK_LAUNCH("cl_colsum(final)");
+    return PSND_OK;
+}
+
 extern "C" int psnd_cl_mean_act_fwd(const void *a, const void *b, const void *c, const void *d, int count, float slope, void *out, int64_t n,
                                     void *stream) {
     if (!a || !out || count < 1 || count > 4 || (count > 1 && !b) || (count > 2 && !c) || (count > 3 && !d)) PSND_FAIL(PSND_E_ARG, "cl_mean_act_fwd: arguments");
