@@ -130,6 +130,7 @@ class FlatGradReducer:
         self._in_deliver = 0
         self.handover_log = collections.deque(maxlen=4096)   # (bucket, number of the deliver() call that released it, or 0 = a hook / finish())
         self._sunk = set()           # parameters whose gradient was written straight into its slot this step (sink protocol)
+        self._delivered = set()      # ... and that a node has handed over (deliver): a later hook call for them is not an arrival
         # Streams.  A backward pass may produce gradients on several streams (inside a captured step: graph branches - the resblocks of a
         # HiFi-GAN stage, the parameter-side branch of a transposed conv / a 1x1 projection): every arrival leaves an event on the stream
         # that PRODUCES the gradient, and the stream a bucket is released from waits for the events of the bucket's other streams first
@@ -289,6 +290,7 @@ class FlatGradReducer:
     def zero_grad(self):
         self._next = 0
         self._sunk.clear()
+        self._delivered.clear()
         self._reset_streams()
         for b in self.buckets:
             b['flat'].zero_()
@@ -359,10 +361,12 @@ class FlatGradReducer:
         self._capturing = mode
         self._next = 0
         self._sunk.clear()
+        self._delivered.clear()
         self._reset_streams()
         self._cap_works = []
         self._arrived = 0
         self.emit_log = []           # (bucket, gradients that had arrived when its release point was captured) - tests
+        self.zeroed_log = []         # (bucket, its pending count, shape) of parameters zero-filled at a release point: no gradient had arrived
         for b in self.buckets:
             b['pending'] = len(b['params'])
             b['work'] = None
@@ -416,6 +420,7 @@ class FlatGradReducer:
             for v, p in zip(views, b['params']):
                 if p.grad is None:
                     v.zero_()            # a parameter the captured backward never reached
+                    self.zeroed_log.append((i, b['pending'], tuple(p.shape)))
             if have:
                 torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
                 if b['flat'].is_cuda:
@@ -442,6 +447,7 @@ class FlatGradReducer:
         self._join_release(self.buckets[0]['flat'].device)
         mode, self._capturing = self._capturing, None
         self._sunk.clear()
+        self._delivered.clear()
         self._next = 0
         for b in self.buckets:
             b['pending'] = len(b['params'])
@@ -475,6 +481,16 @@ class FlatGradReducer:
         self._next = len(self.buckets)
 
     def _on_grad(self, p):
+        # A parameter that a node handed over itself (deliver) arrives ONCE: autograd still runs the parameter's AccumulateGrad node with an
+        # undefined gradient when the node returns None for it, and the engine calls the post-accumulate hooks of that node all the same -
+        # counted a second time, a bucket's `pending` reached zero while other parameters' gradients were still to come: the bucket was
+        # released (copied / zero-filled / all-reduced) early, and what arrived afterwards landed in the flat buffer behind the
+        # collective - invisible on one rank and one stream, wrong gradients on several ranks, zeros next to graph branches (round 5,
+        # tools/r05/dbg_branch_reducer.py: every resblock parameter of the HiFi-GAN generator arrived twice).
+        if self._in_deliver == 0 and p in self._delivered:
+            return
+        if self._in_deliver != 0:
+            self._delivered.add(p)
         if self._capturing is not None:
             b = self._bucket_of[p]
             self._arrival(p)
@@ -540,6 +556,7 @@ class FlatGradReducer:
             b['pending'] = len(b['params'])
         self._next = 0
         self._sunk.clear()
+        self._delivered.clear()
 
     def remove(self):
         from . import cl

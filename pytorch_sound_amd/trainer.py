@@ -530,13 +530,13 @@ class Trainer:
         from . import cl
         # see cl.py: no extra graph branches (batch sections, resblock / parameter-side branches) next to other live streams; decided per
         # capture - a Trainer without such streams captured later in the same process gets its branches back
-        # Round 5: the reducer releases its buckets from a stream of its own behind the events of every stream that produced one of their
-        # gradients (distributed.FlatGradReducer._release_on), so the captured all-reduce no longer has to be issued from a graph branch
-        # (that ended the process in hipStreamEndCapture) - with PSND_DDP_BRANCHES=1 the config-3 step on a one-rank RCCL group runs at
-        # 3.23-3.30 ms instead of 4.1-4.4.  It stays OPT-IN: next to the in-backward hand-over (cl.GRAD_SINK) the replayed gradients of the
-        # last stage's resblocks came back as zeros in some runs (tools/r05/dbg_branch_reducer.py, profiles/NOTEBOOK.md) - a missing edge
-        # in the captured graph that round 5 did not find.
-        red_blocks = red is not None and red.active and os.environ.get('PSND_DDP_BRANCHES', '0') != '1'
+        # Round 5: graph branches and a gradient reducer in one captured step.  The reducer releases every bucket from a stream of its own
+        # behind the events of all streams that produced its gradients (distributed.FlatGradReducer._release_on: a captured RCCL all-reduce
+        # issued from a graph branch ended the process in hipStreamEndCapture), and a parameter handed over from inside a node arrives once
+        # (the engine calls the post-accumulate hooks of its AccumulateGrad node although the node returned None for it; counted twice,
+        # buckets left before their last gradients - zeros next to branches, an all-reduce ahead of its data on several ranks).
+        # PSND_DDP_BRANCHES=0: round 4's behaviour (no branches next to a reducer) for A/B runs.
+        red_blocks = red is not None and red.active and os.environ.get('PSND_DDP_BRANCHES', '1') != '1'
         cl.AUTO_SECTIONS = not (red_blocks or bool(self.prefetch_copy) or bool(self.prefetch_prepare)
                                 or getattr(self, '_pre_stream', None) is not None)
         params = [p for p in self._bare_model.parameters() if p.requires_grad]

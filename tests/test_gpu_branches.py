@@ -148,11 +148,83 @@ def test_from_cl_tanh_and_its_backward():
     assert lib().psnd_to_cl(ptr(x), N, C, T, shape.Lp, HP, 32, 2, ptr(out), stream_ptr(x.device)) != 0
 
 
-def test_a_gradient_reducer_keeps_the_branches_off_by_default(monkeypatch):
-    """Trainer._capture: graph branches next to an active FlatGradReducer are opt-in (PSND_DDP_BRANCHES=1; round 5 measured 3.27 ms against
-    4.1 ms for the config-3 step on a one-rank RCCL group, but the replayed gradients were not reproducible next to the in-backward
-    hand-over - tools/r05/dbg_branch_reducer.py).  The switch the capture derives must say so."""
-    import inspect
-    from pytorch_sound_amd import trainer
-    src = inspect.getsource(trainer.Trainer._capture)
-    assert "os.environ.get('PSND_DDP_BRANCHES', '0') != '1'" in src
+def _reducer_worker(port, q):
+    """a Trainer on a one-rank RCCL group (PSND_DDP_FORCE): captured steps of a small HiFi-GAN generator with the graph branches next to the
+    gradient reducer (round 5) against the same steps with the branches switched off - gradients after one eager + one replayed step and
+    parameters after 4 steps, bit for bit; no parameter zero-filled at a release point; every parameter arrived exactly once"""
+    import faulthandler
+    import os
+    import sys
+    import tempfile
+    faulthandler.dump_traceback_later(150, exit=True)        # a hang in here must not outlive the test's timeout
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0', PSND_DDP_FORCE='1')
+        import torch.distributed as dist
+        from pytorch_sound_amd import cl, kernels as K, optim as poptim
+        from pytorch_sound_amd.trainer import Trainer, LogType
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        out = {}
+        for branches in (False, True):
+            os.environ['PSND_DDP_BRANCHES'] = '1' if branches else '0'
+            for nstep in (2, 4):
+                g = _gen(11)
+                g.cl_branches = branches
+                cl.BRANCH_PARAM_GRADS = branches
+
+                class Step(Trainer):
+                    def forward(self, x, y, is_logging=False):
+                        loss = K.l1_loss(self.model(x), y)
+                        return loss, {'loss': (loss, LogType.SCALAR)}
+
+                gen = torch.Generator().manual_seed(3)
+                data = [(torch.randn(2, 80, 16, generator=gen).cuda(), torch.randn(2, 1, 128, generator=gen).cuda()) for _ in range(4)]
+                tr = Step(g, poptim.Adam(g.parameters(), lr=1e-3), data, data[:1], max_step=4, valid_max_step=1, save_interval=10 ** 6,
+                          log_interval=10 ** 6, save_dir=tempfile.mkdtemp(prefix='psnd_br_'), save_prefix='b%d%d' % (branches, nstep), seed=1)
+                assert tr._reducer is not None and tr._reducer.active
+                tr.graph_steps, tr.graph_warmup = True, 1
+                g.train()
+                for i in range(1, nstep + 1):
+                    tr.step = i
+                    tr.train(i)
+                torch.cuda.synchronize()
+                modes = [v.get('ddp') for v in getattr(tr, '_graphs', {}).values() if 'graph' in v]
+                red = tr._reducer
+                out[(branches, nstep)] = ({k: p.grad.detach().float().cpu().numpy().copy() for k, p in g.named_parameters()} if nstep == 2 else
+                                          {k: v.detach().float().cpu().numpy() for k, v in g.state_dict().items()},
+                                          modes, bool(cl.AUTO_SECTIONS), list(red.zeroed_log), list(red.emit_log), [len(b['params']) for b in red.buckets])
+                red.remove()
+        dist.destroy_process_group()
+        q.put(('ok', out))
+    except Exception as e:                  # noqa: BLE001
+        import traceback
+        q.put(('err', repr(e) + traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_branches_next_to_a_gradient_reducer_are_bit_identical():
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_reducer_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=200)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and got[0] == 'ok', got
+    for nstep in (2, 4):
+        (w0, m0, s0, z0, e0, n0), (w1, m1, s1, z1, e1, n1) = got[1][(False, nstep)], got[1][(True, nstep)]
+        assert m0 == ['capture'] and m1 == ['capture'], (m0, m1)       # the all-reduce captured into the step graph both times
+        assert s1 is True and s0 is False                               # the branches really were on next to the reducer / off
+        assert z0 == [] and z1 == [], (z0[:3], z1[:3])                  # no used parameter was zero-filled at a release point ...
+        need = list(np.cumsum(n1))
+        assert all(a == n for (_, a), n in zip(e1, need)), (e1, need)   # ... every bucket left with exactly its parameters arrived, once each
+        for k in w0:
+            assert np.array_equal(w0[k], w1[k]), (nstep, k)

@@ -28,6 +28,8 @@ for name, (ddpb, resb, parb) in {'off': (0, 0, 0), 'sections_only': (1, 0, 0), '
         tr.step = i; tr.train(i)
     torch.cuda.synchronize()
     res[name] = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in g.named_parameters()}
+    red = tr._reducer
+    print(name, 'emit_log', red.emit_log, 'sizes', [len(b['params']) for b in red.buckets], 'zeroed', getattr(red, 'zeroed_log', None), flush=True)
     tr._reducer.remove()
 for name in res:
     bad = {k: float(np.abs(res[name][k] - res['off'][k]).max() / max(np.abs(res['off'][k]).max(), 1e-30)) for k in res['off'] if not np.array_equal(res[name][k], res['off'][k])}
