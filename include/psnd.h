@@ -323,9 +323,10 @@ int psnd_cl_mean_act_bwd(const void *g, const void *y, int count, float slope, v
 int psnd_cl_sum2(const void *const *a, int na, void *out_a, const void *const *b, int nb, void *out_b, int64_t n, void *stream);
 /* out[c] = sum over the rows of a channels-last bf16 matrix g (rows, C) in fp32, C % 8 == 0, 8 <= C <= 256: the bias gradient of a transposed
  * conv (reference hifi_gan.py:107-110; replaces a library column reduction).  part: fp32 scratch of psnd_cl_colsum_splits(rows, C) * C
- * elements; two launches, fixed summation order. */
+ * elements; two launches, fixed summation order.  Lp > 0: g is rows / Lp clip buffers of Lp rows and only the rows [lo, hi) of each are
+ * summed (the others are never read: they may be unwritten); Lp = 0: every row. */
 int psnd_cl_colsum_splits(int64_t rows, int C);
-int psnd_cl_colsum(const void *g, int64_t rows, int C, float *part, float *out, void *stream);
+int psnd_cl_colsum(const void *g, int64_t rows, int C, int Lp, int lo, int hi, float *part, float *out, void *stream);
 /* psnd_conv1d_prep for n convs in ONE launch (one workgroup per 8 output channels: every store a 16-byte piece of the packs).
  * descs_dev: device array of n records
  *   { const float *v, *g, *bias; void *wf, *wb; float *bp; int Cout, Cin, k, Cb, Ca, blk0; }   (72 bytes, blk0 = sum of

@@ -641,6 +641,14 @@ def conv_transpose_cl(xa, up, shape, act_slope=0.1):
     return raw, act, out_shape
 
 
+def _up_covers(shape, out_shape, u, p):
+    """true iff the polyphase forward kernel writes EVERY row of the high-resolution buffer: low row l writes the high rows
+    HPO - p + (l - HP) u .. + u - 1 that exist (conv_cl_body, up_role 1), so the first low row must reach row 0 and the last one the end"""
+    first = out_shape.HP - p - shape.HP * u
+    last = out_shape.HP - p + (shape.Lp - 1 - shape.HP) * u + u - 1
+    return first <= 0 and last >= out_shape.Lp - 1
+
+
 class ConvTransposeCL(torch.autograd.Function):
     """ConvTranspose1d(k = 2 * stride, padding p) of hifi_gan.py:109 / 118-121 in polyphase form on the CL kernels
     (psnd_convtr1d_*): raw = y, act = leaky_relu(y, act_slope); the activations never leave the CL layout and no zero is
@@ -666,7 +674,10 @@ class ConvTransposeCL(torch.autograd.Function):
             wf = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
             wb = torch.empty(2 * stride * Cr * Cip, dtype=torch.bfloat16, device=dev)
             bp = torch.empty(stride * Cr, dtype=torch.float32, device=dev)
-        both = torch.zeros((2, shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)     # (one fill for the two outputs' halo rows)
+        # the kernel writes every high-resolution row some low-resolution row maps to (zeros outside the clip); when those reach both ends
+        # of the buffer - every HiFi-GAN upsampler: the same halo on both sides of the stride - nothing has to be zeroed first
+        alloc = torch.empty if _up_covers(shape, out_shape, stride, padding) else torch.zeros
+        both = alloc((2, shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
         raw, act = both[0], both[1]
         with torch.cuda.device(dev):
             st = stream_ptr(dev)
@@ -693,8 +704,12 @@ class ConvTransposeCL(torch.autograd.Function):
             raise _lib.PsndError('ConvTransposeCL backward: no incoming gradient')
         S = lib().psnd_convtr1d_cl_wgrad_splits(shape.N, shape.Lp, Cip, Cr, stride)
         gx = torch.empty((shape.N, shape.Lp, Cip), dtype=torch.bfloat16, device=dev)
-        # zeroed: rows no low-resolution row maps to are never written, and the bias gradient sums every row
-        g_eff = torch.zeros((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev) if g_act is not None else None
+        # the combined gradient: written for every group of `stride` rows that lies inside the buffer (all the weight gradient reads); when
+        # those include every clip row the bias gradient sums the clip rows only and nothing has to be zeroed first
+        clip_rows = out_shape.HP >= stride
+        g_eff = None
+        if g_act is not None:
+            g_eff = (torch.empty if clip_rows else torch.zeros)((shape.N, out_shape.Lp, Cr), dtype=torch.bfloat16, device=dev)
         gw = torch.empty((S, 2, Cip, stride * Cr), dtype=torch.float32, device=dev)
         gv, gg = torch.empty_like(v32), torch.empty_like(g32)
         # Parameter-side branch (weight gradient, weight-norm backward, bias gradient: needed only by the optimizer) on a side stream -
@@ -722,7 +737,8 @@ class ConvTransposeCL(torch.autograd.Function):
                 rows = gsrc.shape[0]
                 part = torch.empty(lib().psnd_cl_colsum_splits(rows, Cr) * Cr, dtype=torch.float32, device=dev)
                 gb_full = torch.empty(Cr, dtype=torch.float32, device=dev)
-                check(lib().psnd_cl_colsum(ptr(gsrc), rows, Cr, ptr(part), ptr(gb_full), st), 'psnd_cl_colsum')
+                win = (out_shape.Lp, out_shape.HP, out_shape.HP + out_shape.L) if (g_eff is not None and clip_rows) else (0, 0, 0)
+                check(lib().psnd_cl_colsum(ptr(gsrc), rows, Cr, win[0], win[1], win[2], ptr(part), ptr(gb_full), st), 'psnd_cl_colsum')
                 return gb_full[:Cout]
             return None
 

@@ -362,11 +362,14 @@ __device__ __forceinline__ void conv_cl_body(const ConvParams &p, const int bx, 
         float v[8];
         bool inside = l >= p.HP && l < p.HP + p.L;
         if (UPM && p.up_role == 1) {           // forward of the transposed conv: column block phi of low row l = high row t
-            const long long hb = up_row_base(p.Lp, p.HP, p.up_u, p.up_p, p.up_LpO, p.up_HPO, r);
-            if (hb < 0) continue;
-            const int t = (l - p.HP) * p.up_u + col / p.up_Cr - p.up_p;
+            // every high row that SOME low row maps to is written (zeros outside the clip), also those of a group of u rows that lies
+            // only partly inside the buffer: the caller need not zero the output first as long as the low rows reach both ends
+            const int phi = col / p.up_Cr;
+            const int hr = p.up_HPO - p.up_p + (l - p.HP) * p.up_u + phi;      // row inside the clip's high-resolution buffer
+            if (hr < 0 || hr >= p.up_LpO) continue;
+            const int t = hr - p.up_HPO;
             inside = t >= 0 && t < p.up_LO;
-            o = (size_t)hb * p.up_Cr + col;
+            o = ((size_t)(r / p.Lp) * p.up_LpO + hr) * p.up_Cr + (col - phi * p.up_Cr);
         }
         if (inside) {
             const f32x4 a0 = *reinterpret_cast<const f32x4 *>(sO + row * OS + 8 * cg);
@@ -1278,8 +1281,25 @@ __device__ __forceinline__ void conv_finish_body(const float *gw_part, const flo
             for (int q = tid; q < n4; q += BD) {                        // (j, ci) order: coalesced slab rows
                 const int j = q / cin4, c4 = q - j * cin4;
                 const float *src = gw_part + ((size_t)j * Cb + co) * Ca + 4 * c4;
+                // the slabs are added in order, but their loads are all in flight together (one load per trip of a `for (sp < splits)`
+                // loop waited for the one before: 6-8 dependent L2 round trips per thread, 35 us per launch at config 2, 91-139 us for the
+                // 256-channel 11-tap chains of config 3).  Slots past `splits` re-read the last slab and add zero.
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int sp = 0; sp < splits; ++sp) a += *reinterpret_cast<const f32x4 *>(src + (size_t)sp * slab4);
+                auto add_slabs = [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int NS = decltype(nc)::value;
+                    f32x4 t[NS];
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) t[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)(u < splits ? u : splits - 1) * slab4);
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) {
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        a += u < splits ? t[u] : z;
+                    }
+                };
+                if (splits <= 2) add_slabs(std::integral_constant<int, 2>{});             // (uniform)
+                else if (splits <= 4) add_slabs(std::integral_constant<int, 4>{});
+                else if (splits <= 8) add_slabs(std::integral_constant<int, 8>{});
+                else add_slabs(std::integral_constant<int, 16>{});
                 float *dst = s_gw + j * pitch + 4 * c4;
                 dst[0] = a.x, dst[1] = a.y, dst[2] = a.z, dst[3] = a.w;
             }
@@ -2438,7 +2458,8 @@ extern "C" int psnd_convtr1d_wnorm_bwd(const float *gw_part, int splits, const f
 //      summation order: a workgroup sums the rows of its split (a thread owns 8 consecutive columns, 16-byte loads), the partial rows
 //      [splits][C] are added by the second launch.  Replaces torch.sum(g.view(-1, C), 0) - 21 us per upsampler at config 3 for ~3 us of
 //      traffic (a library reduction over 32 .. 256 narrow columns).
-static __global__ __launch_bounds__(256) void cl_colsum_partial_kernel(const bf16_t *g, long long rows, int C, int splits, float *part) {
+static __global__ __launch_bounds__(256) void cl_colsum_partial_kernel(const bf16_t *g, long long rows, int C, int splits, float *part, int Lp, int lo,
+                                                                        int hi) {
     __shared__ float red[256 * 8];
     const int cols8 = C >> 3;                           // column groups of 8
     const int rpp = 256 / cols8;                        // rows per pass (cols8 <= 256: checked at launch)
@@ -2446,7 +2467,14 @@ static __global__ __launch_bounds__(256) void cl_colsum_partial_kernel(const bf1
     const long long r0 = rows * blockIdx.x / splits, r1 = rows * (blockIdx.x + 1) / splits;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (rr < rpp) {
+        int l = Lp > 0 ? (int)((r0 + rr) % Lp) : 0;    // Lp > 0: only the rows [lo, hi) of every Lp-row clip buffer count (the rest may be unwritten)
         for (long long r = r0 + rr; r < r1; r += rpp) {
+            const bool in = Lp <= 0 || (l >= lo && l < hi);
+            if (Lp > 0) {
+                l += rpp;
+                while (l >= Lp) l -= Lp;
+            }
+            if (!in) continue;
             const u32x4 q = *reinterpret_cast<const u32x4 *>(g + (size_t)r * C + 8 * cg);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2498,12 +2526,14 @@ extern "C" int psnd_cl_colsum_splits(int64_t rows, int C) {
     return (int)(want < 1 ? 1 : (want > 128 ? 128 : want));
 }
 
-extern "C" int psnd_cl_colsum(const void *g, int64_t rows, int C, float *part, float *out, void *stream) {
+extern "C" int psnd_cl_colsum(const void *g, int64_t rows, int C, int Lp, int lo, int hi, float *part, float *out, void *stream) {
     if (!g || !part || !out) PSND_FAIL(PSND_E_ARG, "cl_colsum: null pointer");
     if (C % 8 != 0 || C < 8 || C > 256 || rows <= 0) PSND_FAIL(PSND_E_SHAPE, "cl_colsum: rows=%lld, C=%d (C % 8 == 0, 8 <= C <= 256)", (long long)rows, C);
+    if (Lp < 0 || (Lp > 0 && (lo < 0 || hi > Lp || lo > hi || rows % Lp != 0)))
+        PSND_FAIL(PSND_E_SHAPE, "cl_colsum: rows=%lld in buffers of Lp=%d rows, window [%d, %d)", (long long)rows, Lp, lo, hi);
     const int splits = psnd_cl_colsum_splits(rows, C);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(cl_colsum_partial_kernel, dim3(splits), dim3(256), 0, st, static_cast<const bf16_t *>(g), (long long)rows, C, splits, part);
+    hipLaunchKernelGGL(cl_colsum_partial_kernel, dim3(splits), dim3(256), 0, st, static_cast<const bf16_t *>(g), (long long)rows, C, splits, part, Lp, lo, hi);
     PSND_CHECK_LAUNCH("cl_colsum(partial)");
     hipLaunchKernelGGL(cl_colsum_final_kernel, dim3(1), dim3(1024), 0, st, part, C, splits, out);
     PSND_CHECK_LAUNCH("cl_colsum(final)");

@@ -251,7 +251,14 @@ def test_polyphase_conv_transpose_exact_on_rounded_operands(Cin, Cout, u, L, N):
     gya = torch.randn(N, Cout, L * u, device=dev)
     shape, out_shape = cl.CLShape(N, L, 3), cl.CLShape(N, L * u, 11)
     xc = x.clone().requires_grad_(True)
+    # the output buffers and the combined gradient are NOT zeroed first (round 5): the kernels write every row that is read.  Freed blocks
+    # of exactly their sizes, full of NaN, are what the allocator hands out next.
+    Cr = cl.round_up(Cout, cl.ALIGN_C)
+    junk = [torch.full(shp, float('nan'), dtype=torch.bfloat16, device=dev)
+            for shp in ((2, N, out_shape.Lp, Cr), (N, out_shape.Lp, Cr)) for _ in range(4)]
+    del junk
     raw, act = cl.ConvTransposeCL.apply(cl.ToCL.apply(xc, shape, 0), up.weight_v, up.weight_g, up.bias, shape, out_shape, u, pad, 0.1)
+    assert bool(torch.isfinite(raw.float()).all()) and bool(torch.isfinite(act.float()).all())
     y2 = cl.FromCL.apply(raw, Cout, L * u, out_shape)
     ya2 = cl.FromCL.apply(act, Cout, L * u, out_shape)
     ((y2 * gy).sum() + (ya2 * gya).sum()).backward()
