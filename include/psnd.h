@@ -493,6 +493,10 @@ int psnd_pad_collate(const float *flat, const int64_t *offs, const int64_t *lens
 int64_t psnd_frame_mask_frames(int64_t T, int win, int hop);
 int psnd_frame_mask(const float *mask, int64_t N, int64_t T, int win, int hop, float *out, void *stream);
 
+/* bf16 communication image of a flat fp32 gradient bucket (pytorch_sound_amd/distributed.py, FlatGradReducer(comm_dtype=bfloat16); the reference
+ * has no distributed code): dst[i] = bf16(src[i] * scale), round to nearest even / dst[i] = float(src[i]) * scale.  n % 8 == 0. */
+int psnd_grad_pack_bf16(const float *src, void *dst, int64_t n, float scale, void *stream);
+int psnd_grad_unpack_bf16(const void *src, float *dst, int64_t n, float scale, void *stream);
 /* ---- the optimizer step of Trainer.train (trainer.py:215-216) for Adam / AdamW: one launch over all tensors ---------
  *  table : n_tensors records {float *p; const float *g; float *m; float *v; float *step; int64 numel} (device,
  *      psnd_adam_table_bytes() each); the work list: workgroup b updates elements [chunk_off[b], chunk_off[b] +

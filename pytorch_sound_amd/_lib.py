@@ -93,6 +93,8 @@ SIGNATURES = {
     'psnd_cl_mean_act_fwd': (_INT, [_P, _P, _P, _P, _INT, _F, _P, _I64, _P]),
     'psnd_cl_mean_act_bwd': (_INT, [_P, _P, _INT, _F, _P, _I64, _P]),
     'psnd_cl_sum2': (_INT, [_P, _INT, _P, _P, _INT, _P, _I64, _P]),
+    'psnd_grad_pack_bf16': (_INT, [_P, _P, _I64, _F, _P]),
+    'psnd_grad_unpack_bf16': (_INT, [_P, _P, _I64, _F, _P]),
     'psnd_cl_colsum_splits': (_INT, [_I64, _INT]),
     'psnd_cl_colsum': (_INT, [_P, _I64, _INT, _INT, _INT, _INT, _P, _P, _P]),
     'psnd_posenc': (_INT, [_P, _P, _F, _I64, _INT, _I64, _I64, _P, _P]),

@@ -205,3 +205,59 @@ extern "C" int psnd_adam_step_logged(const void *table, int n_tensors, const int
     PSND_CHECK_LAUNCH("adam_step");
     return PSND_OK;
 }
+
+// ---- bf16 communication buffers of the data-parallel gradient all-reduce (distributed.FlatGradReducer, comm_dtype = bf16) ---------------
+// The reducer's flat buckets stay fp32 (the gradients the backward kernels write and the optimizer reads); what crosses xGMI is a bf16
+// image of a bucket: pack (fp32 -> bf16, round to nearest even) -> all-reduce -> unpack (bf16 -> fp32, exact).  Half the bytes per link;
+// n is a multiple of 8 (bucket slots are 64-float aligned).
+namespace {
+typedef __bf16 hwbf16x2_o __attribute__((ext_vector_type(2)));
+typedef float f32x2_o __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void grad_pack_bf16_kernel(const float *src, unsigned *dst, long long n8, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src + 8 * i), b = *reinterpret_cast<const f32x4 *>(src + 8 * i + 4);
+    const float v[8] = {a.x * scale, a.y * scale, a.z * scale, a.w * scale, b.x * scale, b.y * scale, b.z * scale, b.w * scale};
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f32x2_o t = {v[2 * e], v[2 * e + 1]};
+        w[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, hwbf16x2_o));
+    }
+    *reinterpret_cast<uint4 *>(dst + 4 * i) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ __launch_bounds__(256) void grad_unpack_bf16_kernel(const unsigned *src, float *dst, long long n8, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 q = *reinterpret_cast<const uint4 *>(src + 4 * i);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __builtin_bit_cast(float, w[e] << 16) * scale;
+        v[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u) * scale;
+    }
+    const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4 *>(dst + 8 * i) = a;
+    *reinterpret_cast<f32x4 *>(dst + 8 * i + 4) = b;
+}
+}  // namespace
+
+extern "C" int psnd_grad_pack_bf16(const float *src, void *dst, int64_t n, float scale, void *stream) {
+    if (!src || !dst) PSND_FAIL(PSND_E_ARG, "grad_pack_bf16: null pointer");
+    if (n < 0 || n % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "grad_pack_bf16: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return PSND_OK;
+    hipLaunchKernelGGL(grad_pack_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       static_cast<unsigned *>(dst), (long long)(n / 8), scale);
+    PSND_CHECK_LAUNCH("grad_pack_bf16");
+    return PSND_OK;
+}
+extern "C" int psnd_grad_unpack_bf16(const void *src, float *dst, int64_t n, float scale, void *stream) {
+    if (!src || !dst) PSND_FAIL(PSND_E_ARG, "grad_unpack_bf16: null pointer");
+    if (n < 0 || n % 8 != 0) PSND_FAIL(PSND_E_SHAPE, "grad_unpack_bf16: n=%lld must be a multiple of 8", (long long)n);
+    if (n == 0) return PSND_OK;
+    hipLaunchKernelGGL(grad_unpack_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned *>(src), dst, (long long)(n / 8), scale);
+    PSND_CHECK_LAUNCH("grad_unpack_bf16");
+    return PSND_OK;
+}

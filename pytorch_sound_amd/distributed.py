@@ -110,7 +110,17 @@ class FlatGradReducer:
                  together when a capture with one of the other modes fails on any rank - Trainer._capture)
     """
 
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = None, force: bool = False):
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = None, force: bool = False, comm_dtype=None):
+        """comm_dtype: None = the fp32 buckets themselves cross the wire; torch.bfloat16 (or PSND_DDP_COMM=bf16) = a bf16 image of each
+        bucket does (pack -> all-reduce -> unpack on the release stream): half the bytes per xGMI link, the buckets, the kernels that
+        write them and the optimizer that reads them stay fp32.  What the ranks add up is then the bf16 ROUNDING of each rank's
+        gradient (8 mantissa bits; RCCL / gloo accumulate the ring steps in bf16 as well) - the usual gradient-compression trade,
+        identical on every rank (same collective, same result), not bit-compatible with the fp32 wire."""
+        if comm_dtype is None and os.environ.get('PSND_DDP_COMM', '').lower() in ('bf16', 'bfloat16'):
+            comm_dtype = torch.bfloat16
+        if comm_dtype not in (None, torch.float32, torch.bfloat16):
+            raise TypeError('FlatGradReducer: comm_dtype %s (None / torch.float32 / torch.bfloat16)' % (comm_dtype,))
+        self.comm_dtype = torch.bfloat16 if comm_dtype is torch.bfloat16 else None
         self.world = world_size()
         self.active = self.world > 1 or force   # force: single-rank process group (tests the collective plumbing on one GPU)
         self.deferred = False        # True: no per-bucket all-reduce from the backward hooks, finish() reduces everything
@@ -197,6 +207,32 @@ class FlatGradReducer:
             from . import cl
             cl.GRAD_SINK = self      # conv-chain nodes hand their weight gradients over from inside their backward (cl.py)
             cl.NAN_FLAG_DEST[0] = self._flag     # a fused loss node writes the step's NaN flag straight into the spare slot (set_flag: no copy)
+
+    class _Done:
+        """the collective has been enqueued in stream order already (bf16 wire): nothing to wait for"""
+        def wait(self):
+            return True
+
+    def _reduce(self, b):
+        """SUM over the ranks of bucket b, enqueued on the CURRENT stream (the release stream); returns a work object"""
+        flat = b['flat']
+        if self.comm_dtype is None:
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        c = b.get('comm')
+        if c is None:
+            c = b['comm'] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        if flat.is_cuda:
+            from ._lib import lib, check, ptr, stream_ptr
+            with torch.cuda.device(flat.device):
+                st = stream_ptr(flat.device)
+                check(lib().psnd_grad_pack_bf16(ptr(flat), ptr(c), flat.numel(), 1.0, st), 'psnd_grad_pack_bf16')
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)         # stream-ordered: this stream waits for RCCL's, the host does not
+                check(lib().psnd_grad_unpack_bf16(ptr(c), ptr(flat), flat.numel(), 1.0, st), 'psnd_grad_unpack_bf16')
+        else:                                                    # the gloo tests on CPU tensors
+            c.copy_(flat)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            flat.copy_(c)
+        return FlatGradReducer._Done()
 
     @staticmethod
     def auto_bucket_bytes(total_bytes: int, target_buckets: int = 6) -> int:
@@ -428,7 +464,7 @@ class FlatGradReducer:
                         g.record_stream(rel)
             mode = self._capturing
             if mode == 'capture':
-                self._cap_works.append(dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True))
+                self._cap_works.append(self._reduce(b))
             elif mode == 'events':
                 from ._lib import lib, check
                 check(lib().psnd_event_record_external(self._events[i], rel.cuda_stream), 'psnd_event_record_external')   # (events mode: HIP tensors only)
@@ -476,7 +512,7 @@ class FlatGradReducer:
                     m = torch.cuda.Event(enable_timing=True)
                     m.record(self._side)
                     self.release_marks.append(m)
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+                b['work'] = self._reduce(b)
                 self.launch_log.append(i)
         self._next = len(self.buckets)
 
@@ -513,7 +549,7 @@ class FlatGradReducer:
         while self._next < len(self.buckets) and self.buckets[self._next]['pending'] == 0:
             nb = self.buckets[self._next]
             with (torch.cuda.stream(self._release_on(nb)) if nb['flat'].is_cuda else self._release_on(nb)):
-                nb['work'] = dist.all_reduce(nb['flat'], op=dist.ReduceOp.SUM, async_op=True)
+                nb['work'] = self._reduce(nb)
             self.launch_log.append(self._next)
             self.handover_log.append((self._next, self._in_deliver))
             self._next += 1
@@ -545,7 +581,7 @@ class FlatGradReducer:
         for i in range(self._next, len(self.buckets)):
             b = self.buckets[i]
             with (torch.cuda.stream(self._release_on(b)) if b['flat'].is_cuda else self._release_on(b)):
-                b['work'] = dist.all_reduce(b['flat'], op=dist.ReduceOp.SUM, async_op=True)
+                b['work'] = self._reduce(b)
             self.launch_log.append(i)
         self._join_release(self.buckets[0]['flat'].device)
         for b in self.buckets:

@@ -186,7 +186,7 @@ class Trainer:
         force = os.environ.get('PSND_DDP_FORCE') == '1' and torch.distributed.is_available() and torch.distributed.is_initialized()
         if pdist.is_dist() or force:                   # force: a one-rank process group still runs the whole reducer path
             pdist.broadcast_module(self._bare_model)
-            self._reducer = pdist.FlatGradReducer(self._bare_model, force=force)
+            self._reducer = pdist.FlatGradReducer(self._bare_model, force=force, comm_dtype=self.ddp_comm_dtype)
             if pdist.is_dist() and self.ddp_block_granularity:
                 from pytorch_sound_amd import cl
                 cl.NODE_GRANULARITY = 'block'
@@ -219,6 +219,9 @@ class Trainer:
     # backward launches are per-block then), about what hiding ~5/6 of a 22 MB all-reduce over xGMI returns; set it
     # before constructing the Trainer when the interconnect is slower than that.
     ddp_block_granularity = False
+    # (not in the reference) data-parallel runs: what crosses the wire per gradient bucket - None: the fp32 bucket; torch.bfloat16: a bf16
+    # image of it (FlatGradReducer(comm_dtype=...): half the bytes per xGMI link, bf16-rounded contributions).  PSND_DDP_COMM=bf16 does the same.
+    ddp_comm_dtype = None
 
     # (not in the reference) stage the NEXT training batch - host->device copy and prepare() - on a side stream while the
     # current step computes; the step's stream waits on an event, never the host.  prepare() must then be parameter-free

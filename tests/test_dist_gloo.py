@@ -30,7 +30,7 @@ def _batches(n):
     return [(torch.randn(4, 4, 16, generator=g), torch.randn(4, 2, 16, generator=g)) for _ in range(n)]
 
 
-def _worker(rank, world, port, tmp, q, deferred):
+def _worker(rank, world, port, tmp, q, deferred, comm=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK=str(rank))
     torch.cuda.is_available = lambda: False
@@ -54,8 +54,11 @@ def _worker(rank, world, port, tmp, q, deferred):
     data = _batches(6)
     mine = [(x[rank * 2:rank * 2 + 2], y[rank * 2:rank * 2 + 2]) for x, y in data]     # shard each batch
     opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    if comm == 'bf16':
+        T.ddp_comm_dtype = torch.bfloat16
     tr = T(net, opt, mine, mine[:2], max_step=4, valid_max_step=2, save_interval=2, log_interval=1,
            save_dir=tmp, save_prefix='dp', seed=3)
+    assert tr._reducer.comm_dtype is (torch.bfloat16 if comm == 'bf16' else None)
     tr._reducer.deferred = deferred        # graph mode: no collective from the backward hooks, one reduction in finish()
     tr.run()
     q.put((rank, {k: v.numpy() for k, v in net.state_dict().items()}, float(tr.best_valid_loss)))
@@ -100,6 +103,44 @@ def test_two_rank_gloo_training(tmp_path, deferred):
     # rank 0 alone wrote checkpoints
     ck = sorted(os.listdir(tmp_path / 'models' / 'dp' / 'Sequential'))
     assert ck == ['step_000002.chkpt', 'step_000004.chkpt']
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('deferred', [False, True])
+def test_two_rank_gloo_training_bf16_wire(tmp_path, deferred):
+    """FlatGradReducer(comm_dtype=bfloat16): a bf16 image of every bucket crosses the wire.  The ranks stay BIT-identical (same collective,
+    same result everywhere), the NaN step is still skipped by both, and the weights follow the fp32 run to bf16 rounding of the gradients."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, deferred, 'bf16')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, sd, best = q.get(timeout=240)
+        res[r] = (sd, best)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    assert res[0][1] == res[1][1]
+    net = _net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    data = _batches(6)
+    for step in range(1, 5):
+        x, y = data[(step - 1) % 6]
+        if step == 2:
+            continue
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(x), y).backward()
+        opt.step()
+    worst = 0.0
+    for k, v in net.state_dict().items():
+        worst = max(worst, float(np.abs(v.numpy() - res[0][0][k]).max()))
+    # three SGD steps of lr 0.1 on gradients of magnitude <= ~1, each rounded to 8 mantissa bits twice (per rank, and the sum)
+    assert 0.0 < worst <= 3 * 0.1 * 2.0 ** -7, worst
 
 
 def test_flat_reducer_load_grads_and_alignment():

@@ -253,3 +253,62 @@ def test_shared_parameters_are_not_handed_over_early():
     assert p.exitcode == 0 and got[0] == 'ok', got
     assert got[1][False] <= 2e-5 and got[1][True] <= 2e-5, got[1]
     assert all(c == 0 for c in got[2]), got[2]
+
+
+def _bf16_wire_worker(port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0')
+        import torch.distributed as dist
+        from pytorch_sound_amd import kernels as K, distributed as pdist
+        from pytorch_sound_amd.models import build_model, separator  # noqa: F401
+        from pytorch_sound_amd.models.transforms import LogMelSpectrogram
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        dev = torch.device('cuda:0')
+        fe = LogMelSpectrogram(22050, 80, 1024, 1024, 256, -50, 30, 0.0, 8000.0).to(dev)
+        torch.manual_seed(1234)
+        net = build_model('conv_separator_voicebank').to(dev)
+        g = torch.Generator().manual_seed(5)
+        mag = (torch.rand(8, 513, 173, generator=g) * 4).to(dev)
+        ref = (torch.rand(8, 513, 173, generator=g) * 4).to(dev)
+        mel_ref = K.mel_forward(ref, fe._mel_plan(), 80, K.LOG_E, 1e-6, None, fe.min_db, fe.max_db)[0]
+        out = {}
+        for wire in (None, torch.bfloat16):
+            red = pdist.FlatGradReducer(net, force=True, comm_dtype=wire)
+            assert red.comm_dtype is wire
+            for rep in range(2):
+                red.zero_grad()
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    loss, _ = net.spectral_l1_loss(mag, ref, mel_ref, fe._mel_plan(), 80, 1.0, 0.5, 1e-6, fe.min_db, fe.max_db)
+                loss.backward()
+                red.finish()
+                torch.cuda.synchronize()
+            out[wire] = {k: p.grad.clone() for k, p in net.named_parameters()}
+            red.remove()
+            for p in net.parameters():
+                p.grad = None
+        # one rank: the sum over the ranks is the rank's own contribution, so the bf16 wire returns exactly bf16(fp32 gradient)
+        bad = [k for k in out[None] if not torch.equal(out[torch.bfloat16][k], out[None][k].to(torch.bfloat16).float())]
+        nz = sum(int((out[torch.bfloat16][k] != out[None][k]).sum()) for k in out[None])
+        dist.destroy_process_group()
+        q.put(('ok', bad, nz))
+    except Exception as e:
+        import traceback
+        q.put(('err', repr(e) + traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_bf16_wire_returns_the_rounded_gradients():
+    """FlatGradReducer(comm_dtype=bfloat16) over a one-rank RCCL group: psnd_grad_pack_bf16 -> all-reduce -> psnd_grad_unpack_bf16 on the
+    release stream; every gradient the optimizer sees is the bf16 rounding (nearest even) of the fp32-wire gradient, bit for bit"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_bf16_wire_worker, args=(_port(), q))
+    p.start()
+    got = q.get(timeout=200)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and got[0] == 'ok', got
+    assert got[1] == [], got[1][:5]
+    assert got[2] > 1000            # (and it did round something)
