@@ -1139,6 +1139,7 @@ class ResBlockCL(torch.autograd.Function):
                     continue
                 if ((wstreams or batch) and role == 'c2' and i >= 2 and steps[i - 1][10] == 'c1' and g_comb is not None and Ca == Cb
                         and steps[i - 1][3] == steps[i - 1][4] == Ca and steps[i - 1][2] == k
+                        and k == 3 and Ca in (128, 256)          # (the masked form of the pair kernel: the 3-tap instances only)
                         and lib().psnd_conv1d_cl_pair_supported(Ca, k, pad, -dil, steps[i - 1][6], -steps[i - 1][5])):
                     # input gradients of conv2 and conv1 of a residual pair as ONE launch on this stream (psnd_conv1d_cl_pair with
                     # the transposed packs, mirrored taps and the leaky' masks); their weight gradients go to the side streams, or

@@ -1873,7 +1873,7 @@ static int pair_bwd_splits(int64_t R, int C, int k, int64_t *rps_out) {
 }
 
 extern "C" int psnd_conv1d_cl_pair_bwd_supported(int C, int k, int pad2, int dil2, int pad1, int dil1) {
-    return C == 256 && psnd_conv1d_cl_pair_supported(C, k, pad2, -dil2, pad1, -dil1) && 32 - 2 * pairk::reach3(pad1, -dil1) >= 16 ? 1 : 0;
+    return C == 256 && k == 3 && psnd_conv1d_cl_pair_supported(C, k, pad2, -dil2, pad1, -dil1) && 32 - 2 * pairk::reach3(pad1, -dil1) >= 16 ? 1 : 0;
 }
 
 extern "C" int psnd_conv1d_cl_pair_bwd_splits(int64_t N, int Lp, int C, int k) {

@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 struct PairParams {
     const bf16_t *A;            // (R, C) input of the first conv
-    const bf16_t *W1, *W2;      // [3][C][C] fragment-ordered packs
+    const bf16_t *W1, *W2;      // [k][C][C] fragment-ordered packs
     const float *bias1, *bias2; // C or null
     const bf16_t *M1, *M2;      // (R, C) or null: v *= (M > 0 ? 1 : slope)
     const bf16_t *res;          // (R, C) or null, added to the second conv's output
@@ -28,7 +28,7 @@ struct PairParams {
     bf16_t *out_raw, *out_act;  // (R, C), either may be null
     long long R;
     int Lp, L, HP;
-    int off1, dstep1, h1;       // taps of the first conv: rows off1 + t * dstep1, reach h1
+    int off1, dstep1, h1;       // taps of the first conv: rows off1 + t * dstep1 (t < KT, the kernel's tap count), reach h1
     int off2, dstep2, h2;
     float m1_slope, m2_slope, act1_slope, act2_slope;
     long long *trace;          // PSND_PAIR_TRACE_PTR (tools/trace_pair.py): 8 s_memtime stamps per workgroup, or null
@@ -43,7 +43,8 @@ struct PairParams {
 #endif
 constexpr unsigned OOB = 0x80000000u;
 constexpr int RU8 = PSND_PAIR_RU;          // B units (one tap of one k-step) in flight per wave, 8-wave workgroups
-constexpr int HMAXP = 8;        // largest tap reach of either conv
+constexpr int HMAXP = 8;        // largest tap reach of either conv of the 3-tap instances (dilation <= 8)
+constexpr int HMAXW = 25;       // ... of the 7- / 11-tap instances (hifi_gan_v1 / v2: k = 11, dilation 5)
 
 __device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
@@ -58,16 +59,17 @@ __device__ __forceinline__ uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
 //           that supply the other waves of a SIMD; two column blocks per wave at C = 256.
 // MR: 32-row blocks of `mid` per workgroup (1: launches that would otherwise leave most CUs without a workgroup - the per-CU store
 // path, ~12 B/clk, and the load issue slots are what a workgroup waits for, so more CUs is what helps; 2: every B fragment feeds
-// two MFMAs).  RU: ring depth in units (a multiple of 3 that divides 3 C / 16).
-template <int C, int MR, bool HASM1, int NW, int RU>
+// two MFMAs).  RU: ring depth in units (a multiple of KT that divides KT C / 16).  KT: taps of both convs (3; round 5: 7 and 11, the
+// other two resblock kernels of a HiFi-GAN stage), HMX: the largest tap reach the tile bookkeeping is sized for.
+template <int C, int MR, bool HASM1, int NW, int RU, int KT = 3, int HMX = HMAXP>
 __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int tile, bf16_t *smem) {
     constexpr int NT = 64 * NW;
-    constexpr int RS = C + 8, PCS = C / 8, KSTEPS = C / 16, UNITS = 3 * KSTEPS;
+    constexpr int RS = C + 8, PCS = C / 8, KSTEPS = C / 16, UNITS = KT * KSTEPS;
     constexpr int MROWS = 32 * MR, CGT = C / 32, NBW = CGT > NW ? CGT / NW : 1, CG = CGT / NBW, RG = NW / CG, MB = MR / RG;
     static_assert(CG * RG == NW && MB * RG == MR && MB >= 1 && NBW * CG == CGT, "NW waves tile MROWS rows x C columns");
-    constexpr int NAU = ((MROWS + 2 * HMAXP) * PCS + NT - 1) / NT;
-    static_assert(UNITS % RU == 0 && RU % 3 == 0, "the B ring turns whole");
-    __shared__ unsigned char s_in1[MROWS + 2 * HMAXP], s_in2[MROWS];      // row inside its clip (mid rows / output rows)
+    constexpr int NAU = ((MROWS + 2 * HMX) * PCS + NT - 1) / NT;
+    static_assert(UNITS % RU == 0 && RU % KT == 0, "the B ring turns whole");   // (RU % 3 != 0: see the end of a turn in run_conv)
+    __shared__ unsigned char s_in1[MROWS + 2 * HMX], s_in2[MROWS];      // row inside its clip (mid rows / output rows)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kg = lane >> 5;
     const int cg = wave % CG, rg = wave / CG;
     const int col0 = cg * NBW * 32 + li;                             // this lane's first output channel (both convs); + 32 nb
@@ -75,7 +77,7 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
     const long long r0 = (long long)tile * TS, m0 = r0 - p.h2, a0 = m0 - p.h1;
     const int rowsA = MROWS + 2 * p.h1, rowsM = MROWS + 2 * p.h2;
     bf16_t *sA = smem, *sM = smem + rowsA * RS;
-    const unsigned t_bytes = (unsigned)((size_t)p.R * C * sizeof(bf16_t)), w_bytes = (unsigned)(3u * C * C * sizeof(bf16_t));
+    const unsigned t_bytes = (unsigned)((size_t)p.R * C * sizeof(bf16_t)), w_bytes = (unsigned)((unsigned)KT * C * C * sizeof(bf16_t));
     const __amdgpu_buffer_rsrc_t rA = make_uniform_rsrc(p.A, (int)t_bytes);
     const __amdgpu_buffer_rsrc_t rW1 = make_uniform_rsrc(p.W1, (int)w_bytes), rW2 = make_uniform_rsrc(p.W2, (int)w_bytes);
     PAIR_STAMP(0);
@@ -92,11 +94,12 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
     uint4 rb[RU][NBW];
     const unsigned fwave = (unsigned)(cg * NBW) * (unsigned)KSTEPS * 1024u + (unsigned)lane * 16u;
     constexpr unsigned FTAP = (unsigned)(C / 32) * (unsigned)KSTEPS * 1024u;
-    // unit u = (k-step u / 3, tap u % 3); the ring is 12 units = 4 k-steps long, so slot s always holds tap s % 3 of k-step 4 it + s / 3:
+    // unit u = (k-step u / KT, tap u % KT); the ring is RU units = RU / KT k-steps long (12 units = 4 k-steps at 3 taps), so slot s always
+    // holds tap s % KT of k-step (RU / KT) it + s / KT:
     // every address is a per-lane base plus a compile-time / scalar offset - no per-unit address arithmetic beside the MFMAs
     auto fetch_b = [&](auto slotc, __amdgpu_buffer_rsrc_t rW, int it) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slotc)::value, tap = slot % 3, ksl = slot / 3;
-        const int ks = (RU / 3) * it + ksl;                                   // uniform
+        constexpr int slot = decltype(slotc)::value, tap = slot % KT, ksl = slot / KT;
+        const int ks = (RU / KT) * it + ksl;                                  // uniform
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
             rb[slot][nb] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, (int)(ks < KSTEPS ? fwave : OOB),
@@ -120,15 +123,28 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
                     mk[m][nb][q] = __builtin_amdgcn_raw_buffer_load_b16(rM, (r >= 0 && r < p.R) ? (unsigned)(((size_t)r * C + col0 + 32 * nb) * 2) : OOB, 0, 0);
                 }
     }
-    if (tid < rowsM) {
-        const long long r = m0 + tid;
-        const int l = (int)(((r % p.Lp) + p.Lp) % p.Lp);
-        s_in1[tid] = (r >= 0 && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
-    } else if (tid >= 128 && tid < 128 + MROWS) {
-        const int i = tid - 128;
-        const long long r = r0 + i;
-        const int l = (int)(r % p.Lp);
-        s_in2[i] = (i < TS && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
+    if constexpr (MROWS + 2 * HMX <= 128 && 128 + MROWS <= NT) {     // (the 3-tap instances: one row per thread, two thread ranges)
+        if (tid < rowsM) {
+            const long long r = m0 + tid;
+            const int l = (int)(((r % p.Lp) + p.Lp) % p.Lp);
+            s_in1[tid] = (r >= 0 && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
+        } else if (tid >= 128 && tid < 128 + MROWS) {
+            const int i = tid - 128;
+            const long long r = r0 + i;
+            const int l = (int)(r % p.Lp);
+            s_in2[i] = (i < TS && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
+        }
+    } else {
+        for (int i = tid; i < rowsM; i += NT) {
+            const long long r = m0 + i;
+            const int l = (int)(((r % p.Lp) + p.Lp) % p.Lp);
+            s_in1[i] = (r >= 0 && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
+        }
+        for (int i = tid; i < MROWS; i += NT) {
+            const long long r = r0 + i;
+            const int l = (int)(r % p.Lp);
+            s_in2[i] = (i < TS && r < p.R && l >= p.HP && l < p.HP + p.L) ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int u = 0; u < NAU; ++u) {
@@ -151,12 +167,12 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
     };
     // one conv over the tile in `src` (row i of the output <-> row i + hh + tap offset of src); the ring holds units u .. u + RU - 1
     auto run_conv = [&](const bf16_t *src, int hh, int off0, int dstep, __amdgpu_buffer_rsrc_t rW) __attribute__((always_inline)) {
-        const bf16_t *ab[3];                                            // A fragment of (tap, k-step 0) for this lane's first row block
+        const bf16_t *ab[KT];                                           // A fragment of (tap, k-step 0) for this lane's first row block
 #pragma unroll
-        for (int t = 0; t < 3; ++t) ab[t] = src + (rg * MB * 32 + li + hh + off0 + t * dstep) * RS + 8 * kg;
+        for (int t = 0; t < KT; ++t) ab[t] = src + (rg * MB * 32 + li + hh + off0 + t * dstep) * RS + 8 * kg;
         auto afrag = [&](auto uc, int it, bf16x8 (&x)[MB]) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value, tap = u % 3, ksl = u / 3;    // u may run past the turn: k-step 4 it + ksl all the same
-            const bf16_t *pa = ab[tap] + 16 * ((RU / 3) * it + ksl);
+            constexpr int u = decltype(uc)::value, tap = u % KT, ksl = u / KT;  // u may run past the turn: k-step (RU / KT) it + ksl all the same
+            const bf16_t *pa = ab[tap] + 16 * ((RU / KT) * it + ksl);
 #pragma unroll
             for (int m = 0; m < MB; ++m) x[m] = *reinterpret_cast<const bf16x8 *>(pa + m * 32 * RS);
         };
@@ -184,6 +200,15 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
                 __builtin_amdgcn_sched_group_barrier(0x020, NBW, 0);        // ... then the refill of this ring slot
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (RU % 3 != 0) {
+                // the A ring of three turns with the units: a turn of 14 (7 taps) or 11 units leaves the fragments of the next turn's
+                // units 0 / 1 in slots RU % 3 / (RU + 1) % 3 - moved to where that turn reads them (2 MB register quads per turn)
+                bf16x8 t0[MB], t1[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) t0[m] = xr[RU % 3][m], t1[m] = xr[(RU + 1) % 3][m];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) xr[0][m] = t0[m], xr[1][m] = t1[m];
+            }
         }
     };
 
@@ -311,14 +336,15 @@ __device__ __forceinline__ void conv_pair_body(const PairParams &p, const int ti
     PAIR_STAMP(5);
 }
 
-inline int reach3(int off0, int dstep) {
+inline int reachk(int off0, int dstep, int k) {
     int h = 0;
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < k; ++t) {
         const int o = off0 + t * dstep;
         h = (o < 0 ? -o : o) > h ? (o < 0 ? -o : o) : h;
     }
     return h;
 }
+inline int reach3(int off0, int dstep) { return reachk(off0, dstep, 3); }
 
 }  // namespace pairk
 

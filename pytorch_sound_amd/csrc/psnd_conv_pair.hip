@@ -1,4 +1,4 @@
-// psnd_conv_pair.hip - TWO chained 3-tap Conv1d of a residual pair in ONE launch, for gfx950:
+// psnd_conv_pair.hip - TWO chained Conv1d (3, 7 or 11 taps) of a residual pair in ONE launch, for gfx950:
 //      mid = leaky( mask1( conv(A; W1) + bias1 ) )            (kept in LDS, also written out: the backward needs it)
 //      out = mask2( conv(mid; W2) + bias2 ) + res              -> out_raw, out_act = leaky(out)
 // which is `leaky -> conv(d) -> leaky -> conv(1) -> + x` of hifi_gan.py:56-62 in the CL layout of psnd_conv.hip (forward: A = the
@@ -25,16 +25,26 @@ extern std::atomic<long long> g_conv_pair_stats[4];     // psnd_conv.hip (psnd_c
 
 namespace {
 using namespace pairk;
-template <int C, int MR, bool HASM1>
+template <int C, int MR, bool HASM1, int KT = 3>
 __global__ __launch_bounds__(512, 1) void conv_pair_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    conv_pair_body<C, MR, HASM1, 8, RU8>(p, blockIdx.x, smem);
+    // ring depth: 4 k-steps of 3 taps, 2 of 7, 1 of 11 - 11 ... 14 KB of weight fragments in flight per wave
+    constexpr int RU = KT == 3 ? RU8 : (KT == 7 ? 14 : 11);
+    conv_pair_body<C, MR, HASM1, 8, RU, KT, (KT == 3 ? HMAXP : HMAXW)>(p, blockIdx.x, smem);
 }
+// rows of `mid` per workgroup: 64, or 128 at 64 channels (the eight waves are 2 column groups x 4 row blocks there)
+inline int pair_rows(int C) { return C == 64 ? 128 : 64; }
 }  // namespace
 
+// Round 5: beside the 3-tap pairs (C = 128 / 256, both convs reach <= 8) the 7- and 11-tap pairs of a HiFi-GAN stage's other two resblocks
+// (hifi_gan.py:32-63: kernel sizes 3 / 7 / 11, dilations 1 / 3 / 5 then 1) at 64 / 128 / 256 channels and the 3-tap pair at 64, in the
+// FORWARD order: the first conv may reach 25 rows, the second (dilation 1) at most 8 - a second conv with a long reach would leave few rows
+// of a 64-row tile (the input-gradient order of those pairs stays on the per-conv kernels).
 extern "C" int psnd_conv1d_cl_pair_supported(int C, int k, int off1, int dstep1, int off2, int dstep2) {
-    if (k != 3 || (C != 128 && C != 256)) return 0;
-    return reach3(off1, dstep1) <= HMAXP && reach3(off2, dstep2) <= HMAXP ? 1 : 0;
+    if (k == 3 && (C == 128 || C == 256)) return reach3(off1, dstep1) <= HMAXP && reach3(off2, dstep2) <= HMAXP ? 1 : 0;
+    if ((k == 3 && C == 64) || ((k == 7 || k == 11) && (C == 64 || C == 128 || C == 256)))
+        return reachk(off1, dstep1, k) <= (k == 3 ? HMAXP : HMAXW) && reachk(off2, dstep2, k) <= HMAXP ? 1 : 0;
+    return 0;
 }
 
 extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const void *M1, float m1_slope, float act1_slope,
@@ -44,8 +54,10 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     if (!A || !W1 || !W2 || (!out_raw && !out_act)) PSND_FAIL(PSND_E_ARG, "conv1d_cl_pair: null pointer");
     if (N < 0 || Lp <= 0 || L <= 0 || HP < 0 || Lp < L + HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair: N=%lld Lp=%d L=%d HP=%d", (long long)N, Lp, L, HP);
     if (!psnd_conv1d_cl_pair_supported(C, k, off1, dstep1, off2, dstep2))
-        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d taps (%d,%d) (%d,%d): only k = 3, C = 128 / 256, reach <= %d", C, k, off1, dstep1,
-                  off2, dstep2, HMAXP);
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d taps (%d,%d) (%d,%d): k = 3 / 7 / 11 at C = 64 / 128 / 256, reach <= %d (first conv of a "
+                  "7- / 11-tap pair: %d)", C, k, off1, dstep1, off2, dstep2, HMAXP, HMAXW);
+    const bool wide = !(k == 3 && C != 64);            // the instances of round 5: no masked (input-gradient) form
+    if (wide && (M1 || M2)) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d: the masked (input-gradient) form exists for k = 3, C = 128 / 256 only", C, k);
     if (N == 0) return PSND_OK;
     if ((size_t)N * Lp * C * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair: operand larger than 2 GB");
     PairParams p;
@@ -54,7 +66,7 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     p.res = static_cast<const bf16_t *>(res), p.mid_out = static_cast<bf16_t *>(mid_out);
     p.out_raw = static_cast<bf16_t *>(out_raw), p.out_act = static_cast<bf16_t *>(out_act);
     p.R = N * (int64_t)Lp, p.Lp = Lp, p.L = L, p.HP = HP;
-    p.off1 = off1, p.dstep1 = dstep1, p.h1 = reach3(off1, dstep1), p.off2 = off2, p.dstep2 = dstep2, p.h2 = reach3(off2, dstep2);
+    p.off1 = off1, p.dstep1 = dstep1, p.h1 = reachk(off1, dstep1, k), p.off2 = off2, p.dstep2 = dstep2, p.h2 = reachk(off2, dstep2, k);
     p.m1_slope = m1_slope, p.m2_slope = m2_slope, p.act1_slope = act1_slope, p.act2_slope = act2_slope;
     p.trace = nullptr;
 #ifdef PSND_TRACE      // tools/trace_pair.py builds only
@@ -64,9 +76,11 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     }
 #endif
     // 64-row tiles when they fill the chip; at the config-2 size (95 of them) 32-row tiles: twice the CUs share the stores
-    int MR = 2;
-    if (C == 256 && (p.R + (64 - 2 * p.h2) - 1) / (64 - 2 * p.h2) < 256 && 32 - 2 * p.h2 >= 16) MR = 1;
-    if (const char *e = PSND_ENV("PSND_PAIR_MR")) MR = (atoi(e) == 1 && C == 256 && 32 - 2 * p.h2 >= 8) ? 1 : 2;
+    int MR = pair_rows(C) / 32;
+    if (!wide) {
+        if (C == 256 && (p.R + (64 - 2 * p.h2) - 1) / (64 - 2 * p.h2) < 256 && 32 - 2 * p.h2 >= 16) MR = 1;
+        if (const char *e = PSND_ENV("PSND_PAIR_MR")) MR = (atoi(e) == 1 && C == 256 && 32 - 2 * p.h2 >= 8) ? 1 : 2;
+    }
     const int MROWS = 32 * MR, TS = MROWS - 2 * p.h2;
     const int64_t tiles = (p.R + TS - 1) / TS;
     const int RS = C + 8;
@@ -75,10 +89,18 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     if (lds < lds_o) lds = lds_o;
     hipStream_t st = static_cast<hipStream_t>(stream);
     auto launch = [&](auto kern) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, p);
     };
-    if (C == 256 && MR == 1) {
+    if (wide) {
+        if (C == 256 && k == 7) launch(conv_pair_kernel<256, 2, false, 7>);
+        else if (C == 256) launch(conv_pair_kernel<256, 2, false, 11>);
+        else if (C == 128 && k == 7) launch(conv_pair_kernel<128, 2, false, 7>);
+        else if (C == 128) launch(conv_pair_kernel<128, 2, false, 11>);
+        else if (k == 3) launch(conv_pair_kernel<64, 4, false, 3>);
+        else if (k == 7) launch(conv_pair_kernel<64, 4, false, 7>);
+        else launch(conv_pair_kernel<64, 4, false, 11>);
+    } else if (C == 256 && MR == 1) {
         if (M1) launch(conv_pair_kernel<256, 1, true>);
         else launch(conv_pair_kernel<256, 1, false>);
     } else if (C == 256) {

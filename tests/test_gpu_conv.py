@@ -556,3 +556,61 @@ def test_prep_all_packs_bit_identical_to_single_prep():
             idx = ((((j * (Cb >> 5) + (co >> 5)) * (Ca >> 4) + (ci >> 4)) * 64 + (((ci & 15) >> 3) << 5) + (co & 31)) * 8 + (ci & 7))
             got = float(mf.flatten()[idx])
             assert abs(got - float(w[co, ci, j])) <= 2 ** -8 * abs(float(w[co, ci, j])) + 1e-30
+
+
+@pytest.mark.parametrize('channels,k,N,T', [(128, 7, 3, 300), (128, 11, 2, 257), (256, 7, 3, 90), (256, 11, 2, 131), (64, 3, 2, 500),
+                                             (64, 7, 3, 411), (64, 11, 2, 333), (128, 11, 1, 40)])
+def test_wide_tap_pair_launch_matches_two_launches(channels, k, N, T, monkeypatch):
+    """Round 5: the 7- / 11-tap residual pairs of a HiFi-GAN stage (hifi_gan.py:32-63, kernel sizes 7 / 11, dilations 1 / 3 / 5 then 1) and
+    the 3-tap pair at 64 channels as ONE psnd_conv1d_cl_pair launch per pair in the forward pass - against two psnd_conv1d_cl launches
+    per pair (PSND_CL_PAIR=0): same operands, same bf16 rounding points.
+      * ONE pair (dilation 1, 3, 5 each): output to 1e-3 relative Frobenius (accumulation order: a few bf16 flips), every gradient to 1e-3
+        (the backward is the same per-conv path in both runs, fed by the saved activations);
+      * the block of three pairs: output to 3e-3, gradients to 3e-2 - with rows of norm ~1 (every conv a gain of about one, so that the
+        branch is as large as the residual stream) a bf16 flip behind the first pair moves a few leaky_relu signs in the next ones, which
+        shows in sums over a few hundred rows (bias gradients) at the per-cent level between ANY two launch orders;
+      * against the fp32 torch formulation of the block; rows outside the clips stay zero; psnd_conv_pair_stats proves the launches."""
+    from pytorch_sound_amd import cl
+    from pytorch_sound_amd.models.vocoders.hifi_gan import ResBlock1
+    dev = torch.device('cuda:0')
+    x = torch.randn(N, channels, T, device=dev)
+    gy = torch.randn(N, channels, T, device=dev)
+    shape = cl.CLShape(N, T, 25)
+    for dils, tol_o, tol_g in (((1,), 1e-3, 1e-3), ((3,), 1e-3, 1e-3), ((5,), 1e-3, 1e-3), ((1, 3, 5), 3e-3, 3e-2)):
+        torch.manual_seed(channels + 3 * k + T + len(dils))
+        blk = ResBlock1(None, channels, k, dils).to(dev)
+        with torch.no_grad():
+            for c in list(blk.convs1) + list(blk.convs2):
+                c.weight_g.copy_(0.7 + 0.6 * torch.rand_like(c.weight_g))      # (init_std = 0.01 leaves the branch at 1 % of the residual stream)
+
+        def run(pair):
+            monkeypatch.setenv('PSND_CL_PAIR', '1' if pair else '0')
+            blk.zero_grad()
+            xc = x.clone().requires_grad_(True)
+            xr = cl.ToCL.apply(xc, shape, 0)
+            xa = cl.MeanActCL.apply(0.1, xr)
+            _pair_stats(reset=True)
+            y, _ = cl.resblock1_cl(blk, xr, xa, shape, want_raw=True)
+            st = _pair_stats()
+            out = cl.FromCL.apply(y, channels, T, shape)
+            (out * gy).sum().backward()
+            return out.detach().clone(), xc.grad.clone(), {n_: p.grad.clone() for n_, p in blk.named_parameters()}, st
+
+        o1, gx1, g1, st1 = run(True)
+        o0, gx0, g0, st0 = run(False)
+        assert st1[0] + st1[1] == len(dils) and st0[0] + st0[1] == 0, (st1, st0)      # one launch per pair
+        assert relf(o1, o0) < tol_o, (dils, relf(o1, o0))
+        assert relf(gx1, gx0) < tol_g, (dils, relf(gx1, gx0))
+        for n_ in g0:
+            # (weight_v of the block of three: the weight-norm backward keeps the part of the weight gradient orthogonal to v - a difference
+            #  of two nearly equal projections, which shows the moved signs about three times as much)
+            assert relf(g1[n_], g0[n_]) < tol_g * (3 if (len(dils) > 1 and n_.endswith('weight_v')) else 1), (dils, n_, relf(g1[n_], g0[n_]))
+        ref = blk(x)
+        assert rel(o1, ref) < 2e-2, (dils, rel(o1, ref))
+        # rows outside the clips stay exactly zero in the pair kernel's outputs
+        monkeypatch.setenv('PSND_CL_PAIR', '1')
+        xr = cl.ToCL.apply(x, shape, 0)
+        y, ya = cl.resblock1_cl(blk, xr, cl.MeanActCL.apply(0.1, xr), shape, want_raw=True)
+        for buf in (y, ya):
+            b_ = buf.detach().float()
+            assert float(b_[:, :shape.HP].abs().max()) == 0 and float(b_[:, shape.HP + T:].abs().max()) == 0
