@@ -77,6 +77,13 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
 #endif
     // 64-row tiles when they fill the chip; at the config-2 size (95 of them) 32-row tiles: twice the CUs share the stores
     int MR = pair_rows(C) / 32;
+    if (wide && C != 256) {
+        // twice the rows per workgroup (every weight fragment feeds two MFMAs of its wave) once that still leaves a workgroup for every CU
+        const int big = 2 * MR;
+        const char *e = PSND_ENV("PSND_PAIR_BIG");
+        const int64_t tiles_big = (p.R + (32 * big - 2 * p.h2) - 1) / (32 * big - 2 * p.h2);
+        if (e ? atoi(e) != 0 : tiles_big >= 256) MR = big;
+    }
     if (!wide) {
         if (C == 256 && (p.R + (64 - 2 * p.h2) - 1) / (64 - 2 * p.h2) < 256 && 32 - 2 * p.h2 >= 16) MR = 1;
         if (const char *e = PSND_ENV("PSND_PAIR_MR")) MR = (atoi(e) == 1 && C == 256 && 32 - 2 * p.h2 >= 8) ? 1 : 2;
@@ -95,8 +102,13 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     if (wide) {
         if (C == 256 && k == 7) launch(conv_pair_kernel<256, 2, false, 7>);
         else if (C == 256) launch(conv_pair_kernel<256, 2, false, 11>);
+        else if (C == 128 && k == 7 && MR == 4) launch(conv_pair_kernel<128, 4, false, 7>);
+        else if (C == 128 && MR == 4) launch(conv_pair_kernel<128, 4, false, 11>);
         else if (C == 128 && k == 7) launch(conv_pair_kernel<128, 2, false, 7>);
         else if (C == 128) launch(conv_pair_kernel<128, 2, false, 11>);
+        else if (k == 3 && MR == 8) launch(conv_pair_kernel<64, 8, false, 3>);
+        else if (k == 7 && MR == 8) launch(conv_pair_kernel<64, 8, false, 7>);
+        else if (MR == 8) launch(conv_pair_kernel<64, 8, false, 11>);
         else if (k == 3) launch(conv_pair_kernel<64, 4, false, 3>);
         else if (k == 7) launch(conv_pair_kernel<64, 4, false, 7>);
         else launch(conv_pair_kernel<64, 4, false, 11>);
