@@ -29,20 +29,20 @@ template <int C, int MR, bool HASM1, int KT = 3>
 __global__ __launch_bounds__(512, 1) void conv_pair_kernel(PairParams p) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     // ring depth: 4 k-steps of 3 taps, 2 of 7, 1 of 11 - 11 ... 14 KB of weight fragments in flight per wave
-    constexpr int RU = KT == 3 ? RU8 : (KT == 7 ? 14 : 11);
+    constexpr int RU = KT == 3 ? (C == 32 ? 6 : RU8) : (KT == 7 ? 14 : 11);      // (32 channels: two k-steps in all)
     conv_pair_body<C, MR, HASM1, 8, RU, KT, (KT == 3 ? HMAXP : HMAXW)>(p, blockIdx.x, smem);
 }
 // rows of `mid` per workgroup: 64, or 128 at 64 channels (the eight waves are 2 column groups x 4 row blocks there)
-inline int pair_rows(int C) { return C == 64 ? 128 : 64; }
+inline int pair_rows(int C) { return C == 32 ? 256 : (C == 64 ? 128 : 64); }
 }  // namespace
 
 // Round 5: beside the 3-tap pairs (C = 128 / 256, both convs reach <= 8) the 7- and 11-tap pairs of a HiFi-GAN stage's other two resblocks
-// (hifi_gan.py:32-63: kernel sizes 3 / 7 / 11, dilations 1 / 3 / 5 then 1) at 64 / 128 / 256 channels and the 3-tap pair at 64, in the
+// (hifi_gan.py:32-63: kernel sizes 3 / 7 / 11, dilations 1 / 3 / 5 then 1) at 32 / 64 / 128 / 256 channels and the 3-tap pair at 32 / 64, in the
 // FORWARD order: the first conv may reach 25 rows, the second (dilation 1) at most 8 - a second conv with a long reach would leave few rows
 // of a 64-row tile (the input-gradient order of those pairs stays on the per-conv kernels).
 extern "C" int psnd_conv1d_cl_pair_supported(int C, int k, int off1, int dstep1, int off2, int dstep2) {
     if (k == 3 && (C == 128 || C == 256)) return reach3(off1, dstep1) <= HMAXP && reach3(off2, dstep2) <= HMAXP ? 1 : 0;
-    if ((k == 3 && C == 64) || ((k == 7 || k == 11) && (C == 64 || C == 128 || C == 256)))
+    if ((k == 3 && (C == 64 || C == 32)) || ((k == 7 || k == 11) && (C == 32 || C == 64 || C == 128 || C == 256)))
         return reachk(off1, dstep1, k) <= (k == 3 ? HMAXP : HMAXW) && reachk(off2, dstep2, k) <= HMAXP ? 1 : 0;
     return 0;
 }
@@ -54,9 +54,9 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
     if (!A || !W1 || !W2 || (!out_raw && !out_act)) PSND_FAIL(PSND_E_ARG, "conv1d_cl_pair: null pointer");
     if (N < 0 || Lp <= 0 || L <= 0 || HP < 0 || Lp < L + HP) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair: N=%lld Lp=%d L=%d HP=%d", (long long)N, Lp, L, HP);
     if (!psnd_conv1d_cl_pair_supported(C, k, off1, dstep1, off2, dstep2))
-        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d taps (%d,%d) (%d,%d): k = 3 / 7 / 11 at C = 64 / 128 / 256, reach <= %d (first conv of a "
+        PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d taps (%d,%d) (%d,%d): k = 3 / 7 / 11 at C = 32 / 64 / 128 / 256, reach <= %d (first conv of a "
                   "7- / 11-tap pair: %d)", C, k, off1, dstep1, off2, dstep2, HMAXP, HMAXW);
-    const bool wide = !(k == 3 && C != 64);            // the instances of round 5: no masked (input-gradient) form
+    const bool wide = !(k == 3 && C >= 128);           // the instances of round 5: no masked (input-gradient) form
     if (wide && (M1 || M2)) PSND_FAIL(PSND_E_UNSUPPORTED, "conv1d_cl_pair: C=%d k=%d: the masked (input-gradient) form exists for k = 3, C = 128 / 256 only", C, k);
     if (N == 0) return PSND_OK;
     if ((size_t)N * Lp * C * 2 >= ((size_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "conv1d_cl_pair: operand larger than 2 GB");
@@ -77,7 +77,7 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
 #endif
     // 64-row tiles when they fill the chip; at the config-2 size (95 of them) 32-row tiles: twice the CUs share the stores
     int MR = pair_rows(C) / 32;
-    if (wide && C != 256) {
+    if (wide && (C == 64 || C == 128)) {
         // twice the rows per workgroup (every weight fragment feeds two MFMAs of its wave) once that still leaves a workgroup for every CU
         const int big = 2 * MR;
         const char *e = PSND_ENV("PSND_PAIR_BIG");
@@ -106,6 +106,9 @@ extern "C" int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *b
         else if (C == 128 && MR == 4) launch(conv_pair_kernel<128, 4, false, 11>);
         else if (C == 128 && k == 7) launch(conv_pair_kernel<128, 2, false, 7>);
         else if (C == 128) launch(conv_pair_kernel<128, 2, false, 11>);
+        else if (C == 32 && k == 3) launch(conv_pair_kernel<32, 8, false, 3>);
+        else if (C == 32 && k == 7) launch(conv_pair_kernel<32, 8, false, 7>);
+        else if (C == 32) launch(conv_pair_kernel<32, 8, false, 11>);
         else if (k == 3 && MR == 8) launch(conv_pair_kernel<64, 8, false, 3>);
         else if (k == 7 && MR == 8) launch(conv_pair_kernel<64, 8, false, 7>);
         else if (MR == 8) launch(conv_pair_kernel<64, 8, false, 11>);

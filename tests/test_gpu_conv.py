@@ -559,7 +559,7 @@ def test_prep_all_packs_bit_identical_to_single_prep():
 
 
 @pytest.mark.parametrize('channels,k,N,T', [(128, 7, 3, 300), (128, 11, 2, 257), (256, 7, 3, 90), (256, 11, 2, 131), (64, 3, 2, 500),
-                                             (64, 7, 3, 411), (64, 11, 2, 333), (128, 11, 1, 40)])
+                                             (64, 7, 3, 411), (64, 11, 2, 333), (128, 11, 1, 40), (32, 3, 2, 700), (32, 7, 2, 513), (32, 11, 1, 1000)])
 def test_wide_tap_pair_launch_matches_two_launches(channels, k, N, T, monkeypatch):
     """Round 5: the 7- / 11-tap residual pairs of a HiFi-GAN stage (hifi_gan.py:32-63, kernel sizes 7 / 11, dilations 1 / 3 / 5 then 1) and
     the 3-tap pair at 64 channels as ONE psnd_conv1d_cl_pair launch per pair in the forward pass - against two psnd_conv1d_cl launches
