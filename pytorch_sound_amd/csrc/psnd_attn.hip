@@ -845,7 +845,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) {
             const f32x4_t st = *reinterpret_cast<const f32x4_t *>(&tS[4 * rho(r, kk)]);
             const bool dead = kbad || st[3] > 0.f || 32 * it + rho(r, kk) >= p.T;
-            const float pr = dead ? 0.f : __expf(s[r] * p.scale - st[0]) * st[1];
+            // (selects, not `dead ? 0 : exp(..)`: that form compiles to an exec-mask branch around every one of the 16 exponentials of a tile -
+            //  432 -> 388 us per config-4 launch; exp(-inf) is exactly 0)
+            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - st[0]) * (dead ? 0.f : st[1]);
             s[r] = pr;
             dp[r] = p.scale * pr * (dp[r] - st[2]);
         }
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {     
         for (int r = 0; r < 16; ++r) {
             const int row = rho(r, kk);
             const bool dead = qdead || ((bad >> row) & 1u);
-            const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
+            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - mx) * (dead ? 0.f : inv);           // (selects, not a branch per element)
             float g = dp[r];
             if (GATT && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
             dp[r] = p.scale * pr * (g - dl);
@@ -1305,7 +1307,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         for (int r = 0; r < 16; ++r) {
             const f32x4_t st = *reinterpret_cast<const f32x4_t *>(&tS[4 * rho(r, kk)]);
             const bool dead = kbad || st[3] > 0.f || 32 * it + rho(r, kk) >= p.T;
-            const float pr = dead ? 0.f : __expf(s[r] * p.scale - st[0]) * st[1];
+            // (selects, not `dead ? 0 : exp(..)`: that form compiles to an exec-mask branch around every one of the 16 exponentials of a tile -
+            //  432 -> 388 us per config-4 launch; exp(-inf) is exactly 0)
+            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - st[0]) * (dead ? 0.f : st[1]);
             s[r] = pr;
             dp[r] = p.scale * pr * (dp[r] - st[2]);
         }
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
         for (int r = 0; r < 16; ++r) {
             const int row = rho(r, kk);
             const bool dead = qdead || ((bad >> row) & 1u);
-            const float pr = dead ? 0.f : __expf(s[r] * p.scale - mx) * inv;
+            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - mx) * (dead ? 0.f : inv);           // (selects, not a branch per element)
             float g = dp[r];
             if (GATT && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
             dp[r] = p.scale * pr * (g - dl);
