@@ -1260,16 +1260,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) dK[mt][i] = 0.f, dV[mt][i] = 0.f;
     const int ntile = (p.T + 31) / 32;
+    const float cexp = p.scale * 1.44269504088896341f;
     float pq[HDP / 32][4], pg[HDP / 32][4];
     auto stage = [&](int it, int buf) __attribute__((always_inline)) {
         if (tid < 32) {
             const int t = 32 * it + tid;
-            f32x4_t st = {0.f, 0.f, 0.f, 1.f};
+            // Round 5: per query row ONE exponent offset e0 = log2(e) max - log2(1 / sum), so that the probability is exp2(s c - e0) with
+            // c = scale log2(e) - an FMA and a v_exp_f32 per element instead of multiply, subtract, multiply, v_exp_f32, multiply and
+            // two selects; a dead row (padding, or past T) has e0 = +inf: exp2(-inf) = 0, no select.  (The loop is bound by this
+            // arithmetic: profiles/NOTEBOOK.md, ablation of round 5.)
+            f32x4_t st = {INFINITY, 0.f, 0.f, 0.f};
             if (t < p.T) {
-                st[0] = p.stats[((long long)b * T + t) * 2];
-                st[1] = p.stats[((long long)b * T + t) * 2 + 1];
-                st[2] = p.delta[(long long)b * T + t];
-                st[3] = (mrow && mrow[t]) ? 1.f : 0.f;
+                const float mxq = p.stats[((long long)b * T + t) * 2], invq = p.stats[((long long)b * T + t) * 2 + 1];
+                st[0] = (mrow && mrow[t]) ? INFINITY : mxq * 1.44269504088896341f - __builtin_log2f(invq);
+                st[1] = p.delta[(long long)b * T + t];
             }
             *reinterpret_cast<f32x4_t *>(&sSt[buf][4 * tid]) = st;
         }
@@ -1305,13 +1309,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const f32x4_t st = *reinterpret_cast<const f32x4_t *>(&tS[4 * rho(r, kk)]);
-            const bool dead = kbad || st[3] > 0.f || 32 * it + rho(r, kk) >= p.T;
-            // (selects, not `dead ? 0 : exp(..)`: that form compiles to an exec-mask branch around every one of the 16 exponentials of a tile -
-            //  432 -> 388 us per config-4 launch; exp(-inf) is exactly 0)
-            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - st[0]) * (dead ? 0.f : st[1]);
+            const f32x2_v st = *reinterpret_cast<const f32x2_v *>(&tS[4 * rho(r, kk)]);
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cexp, -st[0]));     // (a dead KEY - this lane's column - is cleared at the end)
             s[r] = pr;
-            dp[r] = p.scale * pr * (dp[r] - st[2]);
+            dp[r] = pr * (dp[r] - st[1]);                                                  // (the factor `scale` of the score gradient: on dK, at the end)
         }
         bf16x8_t pb[2], db[2];
         pack_acc_b(s, pb);
@@ -1321,13 +1322,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     }
     if (tk < p.T) {
         float *gk = p.gkvq + ((long long)n * 3 * p.C + h * p.d) * T + tk, *gv = gk + (long long)p.C * T;
+        const float ks = kbad ? 0.f : p.scale, vs = kbad ? 0.f : 1.f;          // a padded key receives no gradient
 #pragma unroll
         for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (mt * 32 + rho(r, kk) < p.d) {
-                    gk[(long long)(mt * 32 + rho(r, kk)) * T] = dK[mt][r];
-                    gv[(long long)(mt * 32 + rho(r, kk)) * T] = dV[mt][r];
+                    gk[(long long)(mt * 32 + rho(r, kk)) * T] = kbad ? 0.f : dK[mt][r] * ks;
+                    gv[(long long)(mt * 32 + rho(r, kk)) * T] = kbad ? 0.f : dV[mt][r] * vs;
                 }
     }
 }
@@ -1349,8 +1351,10 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     load_frag_b<HDP>(Gp, T, p.d, tq0, li, kk, gf);
     const bool qdead = tq >= p.T || (mrow && mrow[tq]);
-    const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 0.f;
+    const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 1.f;
     const float dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
+    // (as in attn_bwd_kv_bf16_kernel: probability = exp2(s c - e0); the factor `scale` and a dead query are applied to dQ at the end)
+    const float cexp = p.scale * 1.44269504088896341f, e0 = mx * 1.44269504088896341f - __builtin_log2f(inv);
     f32x16 dQ[HDP / 32];
 #pragma unroll
     for (int mt = 0; mt < HDP / 32; ++mt)
@@ -1375,14 +1379,15 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
             commit_tile_b<HDP, true, true>(sKt[(it + 1) & 1], sKd[(it + 1) & 1], tid, pk);
             commit_tile_b<HDP, true, false>(sVt[(it + 1) & 1], nullptr, tid, pv);
         }
+        const unsigned badl = bad >> (4 * kk);                       // bit rho(r, 0) <-> register r
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rho(r, kk);
-            const bool dead = qdead || ((bad >> row) & 1u);
-            const float pr = __expf(dead ? -INFINITY : s[r] * p.scale - mx) * (dead ? 0.f : inv);           // (selects, not a branch per element)
+            const bool kdead = (badl & (1u << rho(r, 0))) != 0;
+            const float pr = __builtin_amdgcn_exp2f(kdead ? -INFINITY : __builtin_fmaf(s[r], cexp, -e0));
             float g = dp[r];
-            if (GATT && !dead) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
-            dp[r] = p.scale * pr * (g - dl);
+            if (GATT && !(qdead || kdead)) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            dp[r] = pr * (g - dl);
         }
         bf16x8_t db[2];
         pack_acc_b(dp, db);
@@ -1394,7 +1399,7 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
         for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (mt * 32 + rho(r, kk) < p.d) gq[(long long)(mt * 32 + rho(r, kk)) * T] = dQ[mt][r];
+                if (mt * 32 + rho(r, kk) < p.d) gq[(long long)(mt * 32 + rho(r, kk)) * T] = qdead ? 0.f : dQ[mt][r] * p.scale;
     }
 }
 
