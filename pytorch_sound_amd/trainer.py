@@ -540,8 +540,14 @@ class Trainer:
         # buckets left before their last gradients - zeros next to branches, an all-reduce ahead of its data on several ranks).
         # PSND_DDP_BRANCHES=0: round 4's behaviour (no branches next to a reducer) for A/B runs.
         red_blocks = red is not None and red.active and os.environ.get('PSND_DDP_BRANCHES', '1') != '1'
-        cl.AUTO_SECTIONS = not (red_blocks or bool(self.prefetch_copy) or bool(self.prefetch_prepare)
-                                or getattr(self, '_pre_stream', None) is not None)
+        # Round 5: next to `prefetch_copy` (a COPY-only side stream, picked by _independent_stream so that it runs next to the compute
+        # stream) the branches stay on: config 3 with pinned host batches 2.86-2.93 ms with them, 3.55-3.65 without, 2.91 with the pool
+        # on the device - six fresh processes each for configs 3 and 4, no slow step among them (tools/r05/prefetch_branches.py;
+        # PSND_PREFETCH_BRANCHES=0 switches them off).  `prefetch_prepare` runs KERNELS on its side stream (prepare() of the next batch):
+        # that stream competes with the branches for the hardware queues, as measured in round 3 with batch sections - branches off.
+        pre_copy_only = (bool(self.prefetch_copy) or getattr(self, '_pre_stream', None) is not None) and not bool(self.prefetch_prepare)
+        pre_blocks = bool(self.prefetch_prepare) or (pre_copy_only and os.environ.get('PSND_PREFETCH_BRANCHES', '1') != '1')
+        cl.AUTO_SECTIONS = not (red_blocks or pre_blocks)
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
         if getattr(self, '_root_grad', None) is None or self._root_grad.device != st['inputs'][0].device:
             self._root_grad = torch.ones((), dtype=torch.float32, device=st['inputs'][0].device)   # not inside the capture

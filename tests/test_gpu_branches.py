@@ -228,3 +228,55 @@ def test_branches_next_to_a_gradient_reducer_are_bit_identical():
         assert all(a == n for (_, a), n in zip(e1, need)), (e1, need)   # ... every bucket left with exactly its parameters arrived, once each
         for k in w0:
             assert np.array_equal(w0[k], w1[k]), (nstep, k)
+
+
+def test_branches_next_to_a_prefetch_copy_stream_train_the_same(tmp_path):
+    """Round 5: graph branches stay on next to Trainer.prefetch_copy (the next batch's host -> device copy on a side stream).  A small
+    HiFi-GAN generator trained for 6 captured steps from batches in PINNED HOST memory (prefetch_copy, branches on: cl.AUTO_SECTIONS stays
+    True) ends at the same parameters, bit for bit, as the same steps from a device-resident pool - and as the prefetch run with the
+    branches switched off (PSND_PREFETCH_BRANCHES=0)."""
+    import os
+    from pytorch_sound_amd import cl, kernels as K, optim as poptim
+    from pytorch_sound_amd.trainer import Trainer, LogType
+    dev = torch.device('cuda:0')
+    g0 = torch.Generator().manual_seed(11)
+    host = [(torch.randn(2, 80, 16, generator=g0), torch.randn(2, 1, 16 * 8, generator=g0)) for _ in range(6)]
+
+    def run(where, env):
+        old = os.environ.get('PSND_PREFETCH_BRANCHES')
+        if env is None:
+            os.environ.pop('PSND_PREFETCH_BRANCHES', None)
+        else:
+            os.environ['PSND_PREFETCH_BRANCHES'] = env
+        try:
+            gen = _gen(9)
+
+            class T(Trainer):
+                def forward(self, m, w, is_logging=False):
+                    loss = K.l1_loss(self.model(m), w)
+                    return loss, {'loss': (loss, LogType.SCALAR)}
+
+            data = [tuple(t.pin_memory() for t in b) for b in host] if where == 'host' else [tuple(t.to(dev) for t in b) for b in host]
+            tr = T(gen, poptim.Adam(gen.parameters(), lr=1e-3), data, data, max_step=6, valid_max_step=1, save_interval=100,
+                   log_interval=100, save_dir=str(tmp_path / (where + str(env))), seed=3)
+            tr.graph_steps = True
+            tr.prefetch_copy = where == 'host'
+            gen.train()
+            for i in range(1, 7):
+                tr.step = i
+                tr.train(i)
+            torch.cuda.synchronize()
+            return {n: p.detach().clone() for n, p in gen.named_parameters()}, cl.AUTO_SECTIONS
+        finally:
+            if old is None:
+                os.environ.pop('PSND_PREFETCH_BRANCHES', None)
+            else:
+                os.environ['PSND_PREFETCH_BRANCHES'] = old
+
+    pd, sd = run('dev', None)
+    ph, sh = run('host', None)
+    p0, s0 = run('host', '0')
+    assert sd is True and sh is True and s0 is False, (sd, sh, s0)
+    for n in pd:
+        assert torch.equal(pd[n], ph[n]), n
+        assert torch.equal(pd[n], p0[n]), n
