@@ -157,3 +157,31 @@ def test_fanout_sums_stage_gradients_in_one_launch():
     outs = cl.FanOutCL.apply(xr, xa, 3)
     (outs[2].float() * gs[0].float()).sum().backward()
     assert torch.equal(xr.grad, gs[0]) and xa.grad is None
+
+
+@pytest.mark.parametrize('N,Lp,C,lo,hi', [(3, 40, 32, 5, 33), (16, 306, 256, 25, 281), (2, 8200, 64, 25, 8175), (5, 64, 128, 0, 64), (1, 24, 8, 3, 3)])
+def test_cl_colsum_window(N, Lp, C, lo, hi):
+    """psnd_cl_colsum (bias gradient of a transposed conv, hifi_gan.py:107-110): fp32 column sums of a channels-last bf16 matrix over the
+    rows [lo, hi) of every Lp-row clip buffer - rows outside the window are never read (NaN there must not show) - and over all rows with
+    Lp = 0; against a float64 sum, and repeatable bit for bit"""
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check
+    dev = torch.device('cuda:0')
+    torch.manual_seed(N + Lp + C)
+    g = torch.randn(N, Lp, C, device=dev).to(torch.bfloat16)
+    poisoned = g.clone()
+    poisoned[:, :lo] = float('nan')
+    poisoned[:, hi:] = float('nan')
+    rows = N * Lp
+    part = torch.empty(int(lib().psnd_cl_colsum_splits(rows, C)) * C, dtype=torch.float32, device=dev)
+    out = torch.empty(C, dtype=torch.float32, device=dev)
+    st = stream_ptr(dev)
+    check(lib().psnd_cl_colsum(ptr(poisoned), rows, C, Lp, lo, hi, ptr(part), ptr(out), st), 'colsum')
+    want = g[:, lo:hi].double().sum(dim=(0, 1))
+    assert bool(torch.isfinite(out).all())
+    assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())) + 1e-4
+    out2 = torch.empty_like(out)
+    check(lib().psnd_cl_colsum(ptr(poisoned), rows, C, Lp, lo, hi, ptr(part), ptr(out2), st), 'colsum')
+    assert torch.equal(out, out2)
+    check(lib().psnd_cl_colsum(ptr(g), rows, C, 0, 0, 0, ptr(part), ptr(out), st), 'colsum')
+    want_all = g.double().sum(dim=(0, 1))
+    assert float((out.double() - want_all).abs().max()) <= 1e-5 * max(1.0, float(want_all.abs().max())) + 1e-4

@@ -251,3 +251,27 @@ def test_trainer_folds_clip_grad_into_the_optimizer_step(tmp_path):
     for k, v in m.state_dict().items():
         assert (out['fused'][k] - v).abs().max() <= 2e-5 * max(1.0, float(v.abs().max())), k
         assert (out['override'][k] - v).abs().max() <= 2e-5 * max(1.0, float(v.abs().max())), k
+
+
+def test_grad_pack_unpack_bf16_round_to_nearest_even():
+    """psnd_grad_pack_bf16 / psnd_grad_unpack_bf16 (the bf16 wire of FlatGradReducer): pack = torch's fp32 -> bf16 conversion bit for bit
+    (round to nearest even, NaN / inf / denormals included), with a scale; unpack is exact; n must be a multiple of 8"""
+    from pytorch_sound_amd._lib import lib, ptr, stream_ptr, check, PsndError
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(8 * 1237, generator=g) * torch.logspace(-30, 30, 8 * 1237)).to(dev)
+    x[:8] = torch.tensor([0.0, -0.0, float('inf'), -float('inf'), float('nan'), 1.0039062, 1.0117188, 3.0e-41], device=dev)   # ties, a denormal
+    out = torch.empty(x.numel(), dtype=torch.bfloat16, device=dev)
+    back = torch.empty_like(x)
+    st = stream_ptr(dev)
+    for scale in (1.0, 0.125):
+        check(lib().psnd_grad_pack_bf16(ptr(x), ptr(out), x.numel(), scale, st), 'pack')
+        want = (x * scale).to(torch.bfloat16)
+        same = (out.view(torch.int16) == want.view(torch.int16)) | (torch.isnan(out.float()) & torch.isnan(want.float()))
+        assert bool(same.all()), int((~same).sum())
+        check(lib().psnd_grad_unpack_bf16(ptr(out), ptr(back), x.numel(), 4.0, st), 'unpack')
+        ref = want.float() * 4.0
+        ok = (back == ref) | (torch.isnan(back) & torch.isnan(ref))
+        assert bool(ok.all())
+    with pytest.raises(PsndError):
+        check(lib().psnd_grad_pack_bf16(ptr(x), ptr(out), 12, 1.0, st), 'pack')
