@@ -171,14 +171,16 @@ int psnd_conv1d_cl(const void *A, const void *A2, const void *AM, float a2_slope
                    int off0, int dstep, float act_slope, float mask_slope, void *out_raw, void *out_act,
                    void *a_eff_out, void *stream);
 int psnd_conv1d_cl_wgrad_splits(int64_t N, int Lp, int Ca, int Cb, int k);
-/* Two chained 3-tap convs of a residual pair in one launch (csrc/psnd_conv_pair.hip; hifi_gan.py:56-62 `leaky -> conv(d) -> leaky ->
+/* Two chained convs (3, 7 or 11 taps each) of a residual pair in one launch (csrc/psnd_conv_pair.hip; hifi_gan.py:56-62 `leaky -> conv(d) -> leaky ->
  * conv(1) -> + x` and the input-gradient chain of the same pair):
  *      mid = leaky( (conv(A; W1, taps off1 + t*dstep1) + bias1) * (M1 > 0 ? 1 : m1_slope), act1_slope )   -> mid_out (may be NULL)
  *      out = (conv(mid; W2, taps off2 + t*dstep2) + bias2) * (M2 > 0 ? 1 : m2_slope) + res               -> out_raw, out_act
- * A, M1, M2, res, mid_out, out_*: CL bf16 (N, Lp, C); W1, W2: the [3][C][C] packs of psnd_conv1d_prep (forward: the [j][co][ci] pack,
+ * A, M1, M2, res, mid_out, out_*: CL bf16 (N, Lp, C); W1, W2: the [k][C][C] packs of psnd_conv1d_prep (forward: the [j][co][ci] pack,
  * input gradient: the [j][ci][co] pack with mirrored taps); bias / masks / res may be NULL; rows outside the clip are written as zero.
- * Same values as two psnd_conv1d_cl launches (mid is rounded to bf16 in both).  k = 3, C = 128 or 256, tap reach <= 8 - ask
- * psnd_conv1d_cl_pair_supported (1 / 0) first; PSND_E_UNSUPPORTED otherwise. */
+ * Same values as two psnd_conv1d_cl launches (mid is rounded to bf16 in both).  Covered: k = 3, C = 128 or 256, both tap reaches <= 8,
+ * with or without masks (forward and input-gradient form); since round 5 also, WITHOUT masks (the forward order of a pair): k = 7 / 11 at
+ * C = 32 / 64 / 128 / 256 and k = 3 at C = 32 / 64, first conv reach <= 25, second <= 8 (hifi_gan.py:32-63: kernel sizes 3 / 7 / 11,
+ * dilations 1 / 3 / 5, then 1).  Ask psnd_conv1d_cl_pair_supported (1 / 0) first; PSND_E_UNSUPPORTED otherwise. */
 int psnd_conv1d_cl_pair_supported(int C, int k, int off1, int dstep1, int off2, int dstep2);
 int psnd_conv1d_cl_pair(const void *A, const void *W1, const float *bias1, const void *M1, float m1_slope, float act1_slope,
                         void *mid_out, const void *W2, const float *bias2, const void *M2, float m2_slope, const void *res,
