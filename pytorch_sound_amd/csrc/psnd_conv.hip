@@ -1988,7 +1988,10 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
     const int pair_mt = pe ? atoi(pe) : 0;
     // 128-row input-gradient tiles at every size: half as many workgroups of that role share the CUs with the weight-gradient role
     // (config-2 launch 17.4 -> 15.5 us with 192 weight-gradient workgroups; no change for the long HiFi-GAN stages, which took them anyway)
-    const int mt = (pair_mt == 1 || pair_mt == 2) ? pair_mt : 2;
+    // (round 5: 192-row input-gradient tiles - three MFMAs per weight fragment - where the forward takes them too (conv_row_tiles: stages
+    //  with enough rows), for the plain instances: config-3 step 2.988 -> 2.955 ms, six interleaved runs each)
+    const bool can3 = !G2 && hm <= 25 && Ca > 32;
+    const int mt = (pair_mt == 1 || pair_mt == 2 || (pair_mt == 3 && can3)) ? pair_mt : ((can3 && conv_row_tiles(pc.R, Ca, true) == 3) ? 3 : 2);
     // narrow input gradient over long clips (Ca <= 32): 256-row tiles, the four waves along the rows (conv_cl_body, WNC = 1)
     const bool narrow = Ca <= 32 && mt == 2 && hm <= 25 && !G2 && (pc.R + 63) / 64 >= 1024 && !PSND_ENV("PSND_CONV_NO_NARROW");
     const int bm = narrow ? 256 : 64 * mt, bn = narrow ? 32 : BN;
@@ -2013,6 +2016,9 @@ extern "C" int psnd_conv1d_cl_bwd(const void *G1, const void *G2, const void *GM
 #define PSND_PAIR_LAUNCH(KT_, D_, C_, H_)                                                                              \
     do {                                                                                                              \
         auto kern = mt == 2 ? conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_> : conv_bwd_pair_kernel<KT_, D_, 2, C_, 1, H_>;   \
+        if constexpr (H_ == 25 && !C_) {                                                                              \
+            if (mt == 3) kern = conv_bwd_pair_kernel<KT_, (D_ > 4 ? 4 : D_), 2, false, 3, H_>;                        \
+        }                                                                                                             \
         if constexpr (H_ == 25) {                                                                                     \
             if (wn && mt == 2) kern = conv_bwd_pair_kernel<KT_, (C_ ? 2 : (D_ > 4 ? 4 : D_)), 2, C_, 2, H_, 32, 2, true>;   \
         }                                                                                                             \
