@@ -1004,6 +1004,17 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ['PSND_BENCH_WATCHDOG']), exit=True)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the product path)')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL, rendezvous on 127.0.0.1) with the
+        # same arguments; rank 0 of the children prints the one JSON line, which passes through on our stdout
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.config != 2:
         out = config_bench(args)
         if out is not None:

@@ -13,6 +13,8 @@ gradient), split-K weight gradient with all taps / bias gradient fused, weight-n
 """
 import ctypes
 import os
+import weakref
+
 import torch
 
 from . import _lib
@@ -376,37 +378,86 @@ NODE_GRANULARITY = 'body'
 #   sink.deliver(params)    -> these parameters' gradients are in place (enqueued on the current stream)
 GRAD_SINK = None
 
-# ---- how many autograd nodes of the running forward pass will produce a gradient for a parameter --------------------------------------
+# ---- how many autograd nodes will produce a gradient for a parameter in the backward pass that is running ---------------------------------
 # A node may hand a parameter's gradient over early (GRAD_SINK.dest / deliver) or produce it on a side stream (BRANCH_PARAM_GRADS) only when
 # it is the parameter's ONLY producer in this backward: with a second node (a module applied twice, shared weights) autograd accumulates
 # the two contributions - into a slot whose bucket may already be on its way through the all-reduce, or on the main stream with no
-# dependency on the side stream.  Every node that uses one of these shortcuts notes its parameters in forward; the table
-# resets itself when the first note arrives after a backward pass has consulted it.
-_PARAM_USES = {}
-_PARAM_USES_PHASE = ['fwd']
+# dependency on the side stream.  The count is kept PER AUTOGRAD GRAPH, not per process: every node that uses one
+# of these shortcuts notes its parameters in forward; a note lives as long as its node does (weak reference: a graph that is dropped takes
+# its notes with it) and until the node's backward has run (`consume_param_use`).  Two forwards before one backward therefore count two
+# however many unrelated backward passes run in between; forward / backward / forward (a GAN step) counts one each time.
+#   * a parameter seen with more than one live note during a backward stays multi-use for the rest of THAT backward (graph-task id), so the
+#     last of its nodes - whose siblings have been consumed by then - does not see itself alone;
+#   * a note that arrives WHILE a backward is running (checkpoint recomputation: the same module may be recomputed once per checkpoint
+#     segment, one at a time) marks the parameter multi-use for good - those models keep autograd's own accumulation.
+_PARAM_NOTES = {}                # id(parameter) -> {id(node ctx), ...} of live, not yet consumed nodes
+_PARAM_MULTI_TASK = {}           # id(parameter) -> graph-task id of the backward that saw it with several producers
+_PARAM_FORCED_MULTI = set()      # id(parameter): noted from inside a backward pass
+
+
+def _graph_task_id():
+    return torch._C._current_graph_task_id()
+
+
+def _drop_notes(cid, pids):
+    for pid in pids:
+        live = _PARAM_NOTES.get(pid)
+        if live is not None:
+            live.discard(cid)
+            if not live:
+                del _PARAM_NOTES[pid]
 
 
 def note_param_use(ctx, *params):
     """called from an autograd.Function's forward (grad mode is off in there: ctx.needs_input_grad tells a recorded pass from inference)"""
     if not any(ctx.needs_input_grad):
         return
-    if _PARAM_USES_PHASE[0] != 'fwd':
-        _PARAM_USES.clear()
-        _PARAM_USES_PHASE[0] = 'fwd'
-    for p in params:
-        if p is not None:
-            _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+    pids = tuple(id(p) for p in params if p is not None)
+    if not pids:
+        return
+    cid = id(ctx)
+    in_backward = _graph_task_id() != -1
+    for pid in pids:
+        _PARAM_NOTES.setdefault(pid, set()).add(cid)
+        if in_backward:
+            _PARAM_FORCED_MULTI.add(pid)
+    ctx._psnd_noted = pids
+    weakref.finalize(ctx, _drop_notes, cid, pids)
 
 
 def single_use(p) -> bool:
-    """true iff exactly one node of the forward pass that this backward belongs to noted `p` (unknown parameters: false)"""
-    _PARAM_USES_PHASE[0] = 'bwd'
-    return p is None or _PARAM_USES.get(id(p), 0) == 1
+    """true iff the node whose backward is running is the only live producer of a gradient for `p` in this backward pass
+    (parameters nobody noted: false)"""
+    if p is None:
+        return True
+    pid = id(p)
+    if pid in _PARAM_FORCED_MULTI:
+        return False
+    task = _graph_task_id()
+    if task != -1 and _PARAM_MULTI_TASK.get(pid) == task:
+        return False
+    n = len(_PARAM_NOTES.get(pid, ()))
+    if n > 1 and task != -1:
+        _PARAM_MULTI_TASK[pid] = task
+    return n == 1
+
+
+def consume_param_use(ctx):
+    """end of a noting node's backward: its parameters' gradients have been produced (a second backward through a retained graph finds
+    no note: not single-use, autograd accumulates)"""
+    pids = getattr(ctx, '_psnd_noted', None)
+    if pids:
+        task = _graph_task_id()
+        for pid in pids:                                 # siblings of this backward must keep seeing several producers
+            if len(_PARAM_NOTES.get(pid, ())) > 1 and task != -1:
+                _PARAM_MULTI_TASK[pid] = task
+        _drop_notes(id(ctx), pids)
 
 
 def reset_param_uses():
-    _PARAM_USES.clear()
-    _PARAM_USES_PHASE[0] = 'fwd'
+    _PARAM_NOTES.clear()
+    _PARAM_MULTI_TASK.clear()
+    _PARAM_FORCED_MULTI.clear()
 
 
 # the hand-over points: the body's input-gradient launches (one per ResBlock1: 4 at config 2) are cut into this many chunks; every
@@ -758,6 +809,7 @@ class ConvTransposeCL(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)
                 _join_side_at_end_of_backward(dev, side)
+        consume_param_use(ctx)
         return gx, gv, gg, g_bias, None, None, None, None, None, None
 
 
@@ -1389,6 +1441,7 @@ class ResBlockCL(torch.autograd.Function):
                 #  node's backward, 0.655-0.660 -> 0.668-0.679 ms and one 3.3 ms block in 18 - tools/r04/ab_c2.sh)
                 wgrad_batch(wbatch)
                 finish([ci for ci in range(n) if descs[ci] is not None])
+        consume_param_use(ctx)
         return (g_raw, g_act, None, None, None, None, None, None) + tuple(grads)
 
 

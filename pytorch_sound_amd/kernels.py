@@ -563,6 +563,7 @@ class Linear1x1(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)
                 cl._join_side_at_end_of_backward(dev, side)
+        cl.consume_param_use(ctx)
         return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None
 
 

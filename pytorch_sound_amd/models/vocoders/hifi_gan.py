@@ -247,7 +247,15 @@ class Generator(nn.Module):
     def forward_cl(self, x):
         from pytorch_sound_amd import cl
         self._check_cl()
+        if self.cl_upsample not in ('polyphase', 'kernel'):
+            raise ValueError("hifi_gan Generator.cl_upsample must be 'polyphase' or 'kernel', got %r" % (self.cl_upsample,))
         if self.cl_upsample != 'polyphase' or not self._polyphase_ok():
+            if self.cl_upsample == 'polyphase' and not getattr(self, '_zero_spread_logged', False):
+                self._zero_spread_logged = True          # once per model: the form costs stride - 1 of every stride products on zeros
+                import logging
+                logging.getLogger('pytorch_sound_amd').info(
+                    'hifi_gan: upsamplers %s are outside the polyphase kernel (k = 2 * stride, even stride, padding = stride / 2): '
+                    'running them as zero-spread convolutions', [(u.weight_v.shape[2], u.stride, u.padding) for u in self.ups])
             return self._forward_cl_zero_spread(x)
         N, _, T = x.shape
         nst = len(self.ups)

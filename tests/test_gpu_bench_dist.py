@@ -42,3 +42,21 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert 'cpu_baseline' not in out
     assert out['roofline']['bound'] == 'hbm' and 0 < out['roofline']['frac'] < 1
     assert len(out['timing']['blocks_ms_per_step']) >= 5
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('extra', [[], ['--config', '3'], ['--config', '5']])
+def test_plain_command_starts_its_own_ranks(extra):
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run (the shape of the driver's one-GPU command): bench.py re-executes
+    itself under torch.distributed.run and rank 0's one JSON line comes through."""
+    env = dict(os.environ, PSND_DIST_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+    assert math.isfinite(out['value']) and out['value'] > 0

@@ -185,3 +185,11 @@ def test_cl_colsum_window(N, Lp, C, lo, hi):
     check(lib().psnd_cl_colsum(ptr(g), rows, C, 0, 0, 0, ptr(part), ptr(out), st), 'colsum')
     want_all = g.double().sum(dim=(0, 1))
     assert float((out.double() - want_all).abs().max()) <= 1e-5 * max(1.0, float(want_all.abs().max())) + 1e-4
+
+
+def test_unknown_upsample_mode_raises():
+    """'library' (removed in round 5) or a typo must not silently select the zero-spread form"""
+    g = _make('1', [4, 2], [8, 4], 64, [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]])
+    g.cl_upsample = 'library'
+    with pytest.raises(ValueError, match='cl_upsample'):
+        g(torch.randn(1, 80, 8, device='cuda'))
