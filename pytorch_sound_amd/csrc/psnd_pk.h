@@ -41,6 +41,26 @@ __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) {
 // twiddle-free butterfly of the next stage, which absorbs the rotation in its two v_pk_fma.
 // SIGN = +1 gives the inverse-sign transform (e^{+i..}).
 // ---------------------------------------------------------------------------------------
+// the twiddle of butterfly (H, J) on the difference t (1, or -i left pending: nothing)
+template <int R, int H, int BLK, int J, int SIGN>
+__device__ __forceinline__ void bfly_tail(v2f (&z)[R], v2f t) {
+    constexpr int i1 = BLK + J + H;
+    constexpr float sg = SIGN > 0 ? -1.f : 1.f;
+    if constexpr (J == 0 || 2 * J == H) {
+        z[i1] = t;   // 1, or -i left pending
+    } else if constexpr (4 * J == H) {           // forward (1 - i)/sqrt2: r * (tx + ty, ty - tx)
+        constexpr float r = (float)ct::cos2pi(1, 8);
+        z[i1] = fma(swp(t), v2f{sg, -sg}, t) * v2f{r, r};
+    } else if constexpr (4 * J == 3 * H) {       // forward (-1 - i)/sqrt2: -r * (tx - ty, ty + tx)
+        constexpr float r = (float)ct::cos2pi(1, 8);
+        z[i1] = fma(swp(t), v2f{-sg, sg}, t) * v2f{-r, -r};
+    } else {                                      // forward t * (c - i s) = (tx c + ty s, ty c - tx s)
+        constexpr float c = (float)ct::cos2pi(J, 2 * H);
+        constexpr float s = sg * (float)ct::sin2pi(J, 2 * H);
+        z[i1] = fma(swp(t), v2f{s, -s}, t * v2f{c, c});
+    }
+}
+
 template <int R, int H, int BLK, int J, int SIGN>
 __device__ __forceinline__ void bfly(v2f (&z)[R]) {
     constexpr int i0 = BLK + J, i1 = BLK + J + H;
@@ -57,19 +77,17 @@ __device__ __forceinline__ void bfly(v2f (&z)[R]) {
         z[i0] = a + b;
         t = a - b;
     }
-    if constexpr (J == 0 || 2 * J == H) {
-        z[i1] = t;   // 1, or -i left pending
-    } else if constexpr (4 * J == H) {           // forward (1 - i)/sqrt2: r * (tx + ty, ty - tx)
-        constexpr float r = (float)ct::cos2pi(1, 8);
-        z[i1] = fma(swp(t), v2f{sg, -sg}, t) * v2f{r, r};
-    } else if constexpr (4 * J == 3 * H) {       // forward (-1 - i)/sqrt2: -r * (tx - ty, ty + tx)
-        constexpr float r = (float)ct::cos2pi(1, 8);
-        z[i1] = fma(swp(t), v2f{-sg, sg}, t) * v2f{-r, -r};
-    } else {                                      // forward t * (c - i s) = (tx c + ty s, ty c - tx s)
-        constexpr float c = (float)ct::cos2pi(J, 2 * H);
-        constexpr float s = sg * (float)ct::sin2pi(J, 2 * H);
-        z[i1] = fma(swp(t), v2f{s, -s}, t * v2f{c, c});
-    }
+    bfly_tail<R, H, BLK, J, SIGN>(z, t);
+}
+
+// first stage (H = R/2) of fft<R> on WINDOWED data, the per-element real window (wa for z[J], wb for z[J + R/2]; one weight per
+// component) folded into the butterfly: a wa +- b wb as one multiply and two fused multiply-adds instead of two multiplies and two adds
+template <int R, int J, int SIGN = -1>
+__device__ __forceinline__ void bfly_windowed(v2f (&z)[R], v2f wa, v2f wb) {
+    constexpr int H = R / 2;
+    const v2f aw = z[J] * wa, b = z[J + H];
+    z[J] = fma(b, wb, aw);
+    bfly_tail<R, H, 0, J, SIGN>(z, fma(b, -wb, aw));
 }
 
 template <int R, int H, int SIGN>

@@ -70,32 +70,79 @@ template <int OFF>
 __device__ __forceinline__ void lds_rd64(v2f &dst, unsigned addr) {
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(f32x4 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// wait until at most N (<= 15: the counter's width) LDS operations of this wave are outstanding; `v` is what the wait makes available
+// (its uses are ordered behind the wait).  The "memory" clobber keeps hipcc's own LDS accesses on their side of it, so that the counts
+// written at the call sites - which include the stores hipcc emits - hold.
+template <int N, class V>
+__device__ __forceinline__ void lds_wait(V &v) {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+template <class V>
+__device__ __forceinline__ void lds_touch(V &v) {              // orders the uses of v behind the asm statements in front of it
+    asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)); }
 
-// magnitude writer for post_emit_pk: the wave-uniform descriptor covers the quad's frames, voff = frame * 4 K + bin * 4
-struct EmitNfk {
-    __amdgpu_buffer_rsrc_t r;
-    v2f eps2;
-    template <bool CONJ>
-    __device__ __forceinline__ OutVal make(v2f x) const {
-        OutVal o;
-        const v2f sq = pk::fma(x, x, eps2);
-        o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
-        return o;
+// the split twiddles of a lane in registers (post_emit_pk_vk with hooks): those of evaluation pairs 0 .. 3 and of the middle bin are
+// requested before the second pass's transforms (first()), those of pairs 4 .. 7 when the split begins - behind them come the eight
+// staging stores of pairs 0 .. 3 (at least four instructions: hipcc may fuse two into a ds_write2_b32), so one wait in front of pair 4
+// that leaves four operations outstanding has them all
+struct VkRegs {
+    static constexpr bool kHooks = true;
+    v2f a_[kL / 2], b_[kL / 2], mid_;
+    unsigned va, vb;
+    __device__ __forceinline__ void first(unsigned vk_lds) {
+        static_for<0, kL / 4>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            lds_rd64<8 * kR1 * pp>(a_[pp], va);
+            lds_rd64<8 * kR1 * pp>(b_[pp], vb);
+        });
+        lds_rd64<8 * kR1 * (kL / 2)>(mid_, vk_lds);
     }
-    __device__ __forceinline__ void store(int voff, int soff, const OutVal &o) const {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o.m), r, voff, soff, 0);
+    __device__ __forceinline__ void first_arrived() {           // (call behind a wait that covers first())
+        static_for<0, kL / 4>([&](auto pc) __attribute__((always_inline)) { lds_touch(a_[decltype(pc)::value]), lds_touch(b_[decltype(pc)::value]); });
+        lds_touch(mid_);
     }
+    __device__ __forceinline__ void begin() {
+        static_for<kL / 4, kL / 2>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int pp = decltype(pc)::value;
+            lds_rd64<8 * kR1 * pp>(a_[pp], va);
+            lds_rd64<8 * kR1 * pp>(b_[pp], vb);
+        });
+    }
+    template <class PC>
+    __device__ __forceinline__ void before(PC) {
+        if constexpr (PC::value == kL / 4) {
+            lds_wait<4>(a_[kL / 4]);
+            static_for<kL / 4, kL / 2>([&](auto pc) __attribute__((always_inline)) { lds_touch(a_[decltype(pc)::value]), lds_touch(b_[decltype(pc)::value]); });
+        }
+    }
+    template <class PC>
+    __device__ __forceinline__ v2f a(PC) const { return a_[PC::value]; }
+    template <class PC>
+    __device__ __forceinline__ v2f b(PC) const { return b_[PC::value]; }
+    __device__ __forceinline__ v2f mid() const { return mid_; }
 };
 
 // magnitude writer into the wave's LDS buffer: the quad's four spectra as they will lie in memory (frame * K + bin), post_emit_pk's
 // byte offsets are used as they are
 struct EmitStage {
+    static constexpr bool kPairMag = true;
     float *buf;
-    v2f eps2;
+    float eps;
+    __device__ __forceinline__ v2f pair_mag(v2f za, v2f zb, v2f v) const {
+        const v2f sq = rfft_pair_sq(za, zb, v, v2f{eps, eps});
+        return v2f{__builtin_amdgcn_sqrtf(sq.x), __builtin_amdgcn_sqrtf(sq.y)};
+    }
     template <bool CONJ>
     __device__ __forceinline__ OutVal make(v2f x) const {
         OutVal o;
-        const v2f sq = pk::fma(x, x, eps2);
+        const v2f sq = pk::fma(x, x, v2f{eps, 0.f});
         o.m = __builtin_amdgcn_sqrtf(sq.x + sq.y);
         return o;
     }
@@ -107,13 +154,22 @@ struct EmitStage {
 // HOP256: hop == 256 (settings.py:13, every BASELINE config at this size) - the span is stored with a skew of 32 floats per 256
 // samples, so that the two frames of a 32-lane group (256 samples apart = the same 32 of 64 banks) read disjoint banks; the tap
 // offsets stay compile-time immediates.  Other hops: plain span (partial two-way conflicts on the tap reads).
+//
+// LDS schedule of a quad (round 6).  A wave's time is a chain of LDS round trips - taps, window, inter-pass twiddles, rows, split
+// twiddles, staged magnitudes - with four waves per SIMD to cover them.  hipcc issues a table read next to its use and answers it with
+// lgkmcnt(0), which also waits for the LDS stores in front of it: ~40 exposed round trips per quad.  Here every table read is an explicit
+// instruction issued one phase AHEAD of its use, with counted waits (LDS operations of a wave complete in order):
+//   taps + window pieces of the first two butterfly groups (one wait) | window groups 2, 3 behind groups 0, 1 | twiddles of the first
+//   exchange half before the last three radix-32 stages | twiddles of the second half in the middle of the first half's stores | rows A |
+//   rows B and all 17 split twiddles before the rows' transforms | staged magnitudes out in one sweep.
+// 119-122 -> 112 us for 1024 clips x 2 s in interleaved runs on one box, bit-identical output.
 template <bool HOP256>
 __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_wt = smem, *s_tw = smem + kL * kRow, *s_vk = smem + 2 * kL * kRow;
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    float *xw = smem + kTab + w * kXW;             // this wave's buffer: span of samples, then the exchange halves
+    float *xw = smem + kTab + w * kXW;             // this wave's buffer: span of samples, then the exchange halves, then the magnitudes
     // lane = (frame of the quad fi = lane >> 4, l = lane & 15): pass 1 lane l of the frame, pass 2 row pair qq = l.
     // Per-lane addresses are NOT kept across the loop: every phase derives its own from a lane id laundered through an empty asm (hipcc
     // would hoist ~15 address registers out of the loop, past the 128 there are - and a scratch reload issued behind a global store
@@ -123,6 +179,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
         asm volatile("" : "+v"(ln));
         return ln;
     };
+    (void)lane;
     const int hop = p.hop;
     const TileWalk tw = tile_walk(p.total_groups);
 
@@ -145,14 +202,16 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
     // The quad's span of samples goes STRAIGHT into the wave's LDS buffer (buffer_load_dwordx4 ... lds: 1 KiB = 256 samples per
     // instruction, lane-linear - exactly the span's layout, the skew of HOP256 falls between two instructions): no staging registers,
     // no commit pass.  Range-checked by the descriptor (lanes past the span deliver zeros).  The instructions are written out: as a
-    // builtin hipcc answers the next LDS read with vmcnt(0), i.e. it waits for the 33 STORES issued behind the transfer as well (one
+    // builtin hipcc answers the next LDS read with vmcnt(0), i.e. it waits for the STORES issued behind the transfer as well (one
     // in-order counter for loads and stores); here the wait at the top of the next quad is counted - vmcnt(kStoresPerQuad).
-    // Clip edges (reflect indexing; the first and the last one or two quads of a clip): element by element in a rolled loop.
+    // Clip edges (reflect indexing; the first and the last two quads of a clip): one 4-byte load per sample, all in flight at once.
     auto request_span = [&](int clip, int f0, int nval) __attribute__((always_inline)) {
         const float *x_ = p.wav + (size_t)clip * p.T;
         const int span_len = (nval - 1) * hop + kNFFT;
         const long long g0 = (long long)f0 * hop - p.pad;
+#ifdef PSND_LAB
         if (p.ablate & 4) return;                                // A/B: no sample loads
+#endif
         if (g0 >= 0 && g0 + span_len <= p.T) {                   // wave-uniform
             const unsigned long long a = reinterpret_cast<unsigned long long>(x_ + g0);
             u32x4 rs;
@@ -169,9 +228,25 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                              :: "s"(dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
             }
         } else {
+            // every sample of the span as one 4-byte load per lane, ALL in flight before the first lands (round 6: a rolled loop waited
+            // for each of its 28 loads in turn - ~8 us of exposed latency in three of a clip's 44 quads, and most waves own one of them)
             const int Ti = (int)p.T, gb = (int)g0;
-#pragma unroll 1
-            for (int s = fresh_lane(); s < span_len; s += 64) xw[s + (HOP256 ? 32 * (s >> 8) : 0)] = x_[reflect_idx32(gb + s, Ti)];
+            constexpr int kNE = kSPV * 4;                        // loads per lane: 64 x kNE >= the longest span
+            const int ln = fresh_lane();
+            float ev[kNE];
+            static_for<0, kNE>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                const int sj = ln + 64 * j;
+                ev[j] = x_[reflect_idx32(gb + (sj < span_len ? sj : span_len - 1), Ti)];
+            });
+            // written unconditionally (a slot past the span holds a copy of its last sample: those frames are never stored; the highest
+            // index, 63 + 64 (kNE - 1) + skew, lies inside the wave's buffer) - a predicated write leaves its load pending on the path that
+            // skips it, and hipcc then answers the tap reads of the MAIN path with vmcnt(0), i.e. it waits for the ten stores
+            static_for<0, kNE>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;           // ((ln + 64 j) >> 8 == j / 4: the skew is a compile-time constant)
+                xw[ln + 64 * j + (HOP256 ? 32 * (j / 4) : 0)] = ev[j];
+            });
+            static_assert(63 + 64 * (kNE - 1) + (HOP256 ? 32 * ((kNE - 1) / 4) : 0) < kXW, "edge fill stays inside the wave's buffer");
         }
     };
 
@@ -188,85 +263,138 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
         if (group + tw.step < tw.end) quad_of(group + tw.step, nclip, nf0, nnval);
         if (nval > 0) {                                         // wave-uniform
             // the span transfer was issued in front of the previous quad's stores: wait for IT, not for them
+#ifdef PSND_LAB
             if (group != tw.first && !(p.ablate & 2)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStoresPerQuad) : "memory");
+#else
+            if (group != tw.first) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStoresPerQuad) : "memory");
+#endif
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- pass 1: taps, window, radix-32, inter-pass twiddle ---------------------------------------------------------------
             v2f z[kR1];
+            f32x4 wq[3][4];                                     // window pieces of three butterfly groups (a group = J = 4 g .. 4 g + 3)
+            const int ln = fresh_lane(), fi = ln >> 4, l = ln & 15;
+            const unsigned wa_lds = lds_addr(s_wt + l * kRow);
+            // piece (g, 0 | 1): w[J], w[J + 16] for J = 4 g, 4 g + 1; (g, 2 | 3): for J = 4 g + 2, 4 g + 3
+            auto window_group = [&](auto gc, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                lds_rd128<32 * g>(dst[0], wa_lds), lds_rd128<32 * g + 4 * kR1>(dst[1], wa_lds);
+                lds_rd128<32 * g + 16>(dst[2], wa_lds), lds_rd128<32 * g + 16 + 4 * kR1>(dst[3], wa_lds);
+            };
+            auto butterflies = [&](auto gc, f32x4 (&wv)[4]) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                // the window rides in the first butterfly stage: z[a] w[a] +- z[a + 16] w[a + 16] = one multiply + two fused multiply-adds
+                pk::bfly_windowed<kR1, 4 * g>(z, pk::lo(wv[0]), pk::lo(wv[1]));
+                pk::bfly_windowed<kR1, 4 * g + 1>(z, pk::hi(wv[0]), pk::hi(wv[1]));
+                pk::bfly_windowed<kR1, 4 * g + 2>(z, pk::lo(wv[2]), pk::lo(wv[3]));
+                pk::bfly_windowed<kR1, 4 * g + 3>(z, pk::hi(wv[2]), pk::hi(wv[3]));
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
             {
-                const int ln = fresh_lane(), fi = ln >> 4, l = ln & 15;
-                const int sb = fi * hop + 2 * l;
-                const float *tb = xw + sb + (HOP256 ? 32 * fi : 0);
+                const unsigned ta = lds_addr(xw + fi * hop + 2 * l + (HOP256 ? 32 * fi : 0));
                 // explicit ds_read_b64: hipcc pairs neighbouring taps into ds_read2_b64, which the LDS serves at half the rate of two
                 // ds_read_b64 (MI355X_MICROARCH.md, LDS table; round 5: psnd_stft_r.hip)
-                const unsigned ta = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tb));
                 static_for<0, kR1>([&](auto ac) __attribute__((always_inline)) {
                     constexpr int a = decltype(ac)::value;
                     // sample 2 (l + 16 a) of the frame; HOP256: 32 a + 2 l < 256 (a % 8 + 1), so the block of the skew is fi + a / 8
                     lds_rd64<4 * (32 * a + (HOP256 ? 32 * (a / 8) : 0))>(z[a], ta);
                 });
+                window_group(I0{}, wq[0]);
+                window_group(I1{}, wq[1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]),
-                             "+v"(z[8]), "+v"(z[9]), "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15]));
+                             "+v"(z[8]), "+v"(z[9]), "+v"(z[10]), "+v"(z[11]), "+v"(z[12]), "+v"(z[13]), "+v"(z[14]), "+v"(z[15]) :: "memory");
                 asm volatile("" : "+v"(z[16]), "+v"(z[17]), "+v"(z[18]), "+v"(z[19]), "+v"(z[20]), "+v"(z[21]), "+v"(z[22]), "+v"(z[23]),
                              "+v"(z[24]), "+v"(z[25]), "+v"(z[26]), "+v"(z[27]), "+v"(z[28]), "+v"(z[29]), "+v"(z[30]), "+v"(z[31]));
+                asm volatile("" : "+v"(wq[0][0]), "+v"(wq[0][1]), "+v"(wq[0][2]), "+v"(wq[0][3]), "+v"(wq[1][0]), "+v"(wq[1][1]), "+v"(wq[1][2]), "+v"(wq[1][3]));
             }
+            window_group(I2{}, wq[2]);
+            butterflies(I0{}, wq[0]);
             Q_SB();
-            {
-                const float *wrow = s_wt + (fresh_lane() & 15) * kRow;
-                static_for<0, kR1 / 2>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(wrow + 4 * i);
-                    z[2 * i] *= pk::lo(wv);
-                    z[2 * i + 1] *= pk::hi(wv);
-                    if constexpr (i % 4 == 3) Q_SB();
-                });
-            }
+            window_group(I3{}, wq[0]);
+            butterflies(I1{}, wq[1]);
             Q_SB();
-            pk::fft<kR1>(z);
+            lds_wait<4>(wq[2][0]);                              // (the four pieces of group 3 are behind it)
+            lds_touch(wq[2][1]), lds_touch(wq[2][2]), lds_touch(wq[2][3]);
+            butterflies(I2{}, wq[2]);
             Q_SB();
-
             // ---- exchange inside the wave, two half rounds (rows 0..15, then 16..31) ------------------------------------------------
-            const int ln2 = fresh_lane(), fi = ln2 >> 4, l = ln2 & 15;
-            const float *trow = s_tw + l * kRow;
+            const unsigned tw_lds = lds_addr(s_tw + l * kRow);
             float *oz = xw + fi * kXF + 2 * l;
-            const bool special2 = l == 0;
-            const int rowB = special2 ? 0 : 16 - l;             // row inside the second half (rows 16 .. 31)
-            auto write_half = [&](auto hc) __attribute__((always_inline)) {
+            const int rowB = l == 0 ? 0 : 16 - l;               // row inside the second half (rows 16 .. 31)
+            f32x4 twa[8], twb[8];                               // twiddle pieces (q0, q0 + 1) of the two halves
+            auto twiddles = [&](auto hc, f32x4 (&dst)[8]) __attribute__((always_inline)) {
                 constexpr int Q0 = decltype(hc)::value;
-                static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int q0 = Q0 + 2 * decltype(ic)::value, q1 = q0 + 1;
-                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(trow + 2 * q0);
-                    constexpr int s0_ = ct::bitrev(q0, 5), s1_ = ct::bitrev(q1, 5);
-                    if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[s0_];
-                    else *reinterpret_cast<v2f *>(oz + (q0 - Q0) * kRP) = pk::cmul(z[s0_], pk::lo(wv));
-                    *reinterpret_cast<v2f *>(oz + (q1 - Q0) * kRP) = pk::cmul(z[s1_], pk::hi(wv));
-                });
+                static_for<0, 8>([&](auto ic) __attribute__((always_inline)) { lds_rd128<8 * (Q0 + 2 * decltype(ic)::value)>(dst[decltype(ic)::value], tw_lds); });
+            };
+            auto write_pair = [&](auto hc, auto ic, const f32x4 &wv) __attribute__((always_inline)) {
+                constexpr int Q0 = decltype(hc)::value, q0 = Q0 + 2 * decltype(ic)::value, q1 = q0 + 1;
+                constexpr int s0_ = ct::bitrev(q0, 5), s1_ = ct::bitrev(q1, 5);
+                if constexpr (q0 == 0) *reinterpret_cast<v2f *>(oz) = z[s0_];
+                else *reinterpret_cast<v2f *>(oz + (q0 - Q0) * kRP) = pk::cmul(z[s0_], pk::lo(wv));
+                *reinterpret_cast<v2f *>(oz + (q1 - Q0) * kRP) = pk::cmul(z[s1_], pk::hi(wv));
             };
             auto read_row = [&](int row, v2f (&r)[kL]) __attribute__((always_inline)) {
-                const float *pr = xw + fi * kXF + row * kRP;
+                const unsigned ra = lds_addr(xw + fi * kXF + row * kRP);
                 static_for<0, kL / 2>([&](auto ic) __attribute__((always_inline)) {
                     constexpr int i = decltype(ic)::value;
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(pr + 4 * i);
-                    r[2 * i] = pk::lo(v);
-                    r[2 * i + 1] = pk::hi(v);
+                    lds_rd128<16 * i>(*reinterpret_cast<f32x4 *>(&r[2 * i]), ra);
                 });
             };
-            v2f za[kL], zb[kL];
+            using H0 = std::integral_constant<int, 0>;
+            using H1 = std::integral_constant<int, 16>;
+            lds_wait<0>(wq[0][0]);                              // window group 3
+            lds_touch(wq[0][1]), lds_touch(wq[0][2]), lds_touch(wq[0][3]);
+            butterflies(I3{}, wq[0]);
+            Q_SB();
+            twiddles(H0{}, twa);                                // in flight under the three radix-32 stages that follow
+            pk::stage<kR1, kR1 / 4, -1>(z);
+            Q_SB();
             // (the taps above were read out of the same buffer: one wave's LDS operations execute in order)
-            write_half(std::integral_constant<int, 0>{});
+            // first half: behind piece i stand pieces i + 1 .. 7 and the stores of the i pairs in front of it - AT LEAST i instructions
+            // (hipcc fuses the two stores of a pair into one ds_write2_b64 when it can): every count below is such a lower bound
+            static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                lds_wait<7>(twa[i]);
+                write_pair(H0{}, ic, twa[i]);
+            });
+            twiddles(H1{}, twb);                                // the registers of the four pairs written hold the second half's pieces
+            static_for<4, 8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                lds_wait<15>(twa[i]);                           // (behind it: 7 - i pieces, >= i stores, 8 pieces of the second half)
+                write_pair(H0{}, ic, twa[i]);
+            });
+            v2f za[kL], zb[kL];
             read_row(l, za);
-            write_half(std::integral_constant<int, 16>{});
+            // second half: behind piece i stand >= 4 stores of the first half, the 8 reads of rows A and 7 more: the widest wait serves
+            static_for<0, 8>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                lds_wait<15>(twb[i]);
+                write_pair(H1{}, ic, twb[i]);
+            });
             Q_SB();
-            pk::fft<kL>(za);
+            // rows B and the split twiddles v[qA + 32 pp], v[qB + 32 pp], v[256]: requested now, used behind the two radix-16 transforms
             read_row(rowB, zb);
+            VkRegs vk;
+            vk.va = lds_addr(s_vk + 2 * l), vk.vb = lds_addr(s_vk + 2 * (l == 0 ? kR1 / 2 : kR1 - l));
+            vk.first(lds_addr(s_vk));
+            lds_wait<15>(za[0]);                                // rows A: >= 8 stores + 8 + 9 reads behind them
+            static_for<1, kL>([&](auto ic) __attribute__((always_inline)) { lds_touch(za[decltype(ic)::value]); });
+            pk::fft<kL>(za);
             Q_SB();
-            pk::fft<kL>(zb);                                    // (waits for zb: the buffer has been read out)
+            lds_wait<9>(zb[0]);                                 // rows B: the 9 split twiddles behind them
+            static_for<1, kL>([&](auto ic) __attribute__((always_inline)) { lds_touch(zb[decltype(ic)::value]); });
+            pk::fft<kL>(zb);
             Q_SB();
+            lds_wait<0>(vk.mid_);                               // the buffer has been read out, the first split twiddles are here
+            vk.first_arrived();
             // ---- real-FFT split + magnitude into the wave's buffer: the quad's region of the output, byte for byte (4 x 2052 B) -----------
             {
                 const int ln3 = fresh_lane(), qq = ln3 & 15;
                 const bool special = qq == 0;
-                EmitStage emit{xw, v2f{p.mag_eps, 0.f}};
-                post_emit_pk<kR1, kL>(za, zb, special, qq, special ? kR1 / 2 : kR1 - qq, s_vk, emit, 1, (ln3 >> 4) * (kK * 4));
+                EmitStage emit{xw, p.mag_eps};
+                post_emit_pk_vk<kR1, kL>(za, zb, special, qq, special ? kR1 / 2 : kR1 - qq, vk, emit, 1, (ln3 >> 4) * (kK * 4));
             }
             Q_SB();
             // ---- out again as 16 bytes per lane: a store instruction writes 1 KiB of contiguous memory ---------------------------------
@@ -290,7 +418,10 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
             // the next quad's span: into the (free) buffer, AHEAD of this quad's stores in the in-order vector-memory queue
             if (nnval > 0) request_span(nclip, nf0, nnval);
             Q_SB();
-            if (!(p.ablate & 2)) {
+#ifdef PSND_LAB
+            if (!(p.ablate & 2))
+#endif
+            {
                 // every store is ISSUED whatever the quad (the wait above counts them): what lies past the quad's bytes is dropped by
                 // the descriptor's range check (frames past F of a clip's last quad)
                 const __amdgpu_buffer_rsrc_t ro = make_uniform_rsrc(p.mag + ((size_t)clip * (size_t)p.F + (size_t)f0) * kK, bytes);

@@ -159,3 +159,21 @@ def test_ring_kernel_repeats_exactly():
             o.fill_(float('nan'))
             K.stft_mag_nfk(x, 4096, 1024, plan, out=o)
             assert torch.equal(o, f), rep
+
+
+def test_q_kernel_full_chip_repeats_equal_nkf():
+    """round 6: the n = 1024 (N, F, K) kernel issues its LDS table reads a phase ahead of their use with COUNTED waits; a count that is
+    one too generous only shows when every CU is loaded (a first version passed every small shape and failed 1024 clips x 2 s).  The
+    full-chip launch, three inputs, poisoned output, against the (N, K, F) kernel (pinned to the oracle in test_gpu_features)."""
+    from pytorch_sound_amd import kernels as K
+    n_fft, hop, N, T = 1024, 256, 1024, 44100
+    plan = K.stft_plan(n_fft, ofe.analysis_window(n_fft)).to(DEV)
+    for rep in range(3):
+        g = torch.Generator(device='cpu').manual_seed(100 + rep)
+        a = (0.0708 * torch.randn(N, T, generator=g)).to(DEV)
+        nkf = K.stft_forward(a, n_fft, hop, plan)['mag']
+        out = torch.full((N, K.frame_count(T, n_fft, hop), n_fft // 2 + 1), float('nan'), device=DEV)
+        for _ in range(4):
+            K.stft_mag_nfk(a, n_fft, hop, plan, out=out)
+        assert not torch.isnan(out).any()
+        assert float((out.transpose(1, 2) - nkf).abs().max()) <= 8e-6 * float(nkf.max()), rep
