@@ -746,7 +746,7 @@ def _mel_roofline(device, clips=1024, Fr=173, Kb=513, M=80):
     m = _time_launches(lambda: K.mel_forward(mag, plan, M, K.LOG_E, 1e-6, None, -11.5, 6.9, out=out))
     t = m['t']
     b = 4 * clips * Kb * Fr + 4 * clips * M * Fr
-    return {'bound': 'hbm', 'kernel': 'mel_kernel<false> (band-sparse fp32 MFMA 16x16x4: magnitude (N,K,F) -> log-mel (N,M,F))', 'achieved': b / t / 1e9,
+    return {'bound': 'hbm', 'kernel': 'mel_fwd_once_kernel<5> (band-sparse fp32 MFMA 16x16x4, a wave owns all five mel tiles of its 64 frames: every magnitude read once; (N,K,F) -> log-mel (N,M,F))', 'achieved': b / t / 1e9,
             'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': b / t / HBM_PEAK, 'traffic': _pmc_traffic('mel'), 'traffic_source': _pmc_traffic('mel', 'source'),
             'bytes_per_launch': b, **_launch_fields(m), 'flops_per_launch': 2.0 * M * Kb * clips * Fr,
             'workload': '%d clips x 2 s: %d x %d x %d magnitudes -> %d mel bands (%.0f MB)' % (clips, clips, Kb, Fr, M, b / 1e6)}

@@ -52,6 +52,7 @@ struct MelParams {
     const float *l1_g;
     float l1_coef;
     int wn_off, CS16;   // NFK forward: float offset of the 16-bin-group weights, groups per row tile
+    int seg_off;        // forward, read-once kernel: int offset of the segment table (mel_layout)
 };
 
 // derivative of the forward epilogue wrt mel (0 where any clamp is active; matches autograd of
@@ -287,8 +288,126 @@ __global__ __launch_bounds__(256) void mel_kernel(MelParams p) {
     }
 }
 
+// ---- forward, every magnitude read ONCE (round 6) ---------------------------------------------------------------------------------------
+// mel_kernel<false> gives every 16-mel tile a wave of its own, which walks the tile's band of bins: neighbouring tiles overlap in bins
+// and a tile's 64-frame segments of a 692-byte row share their first and last lines with the neighbouring frame tiles of OTHER workgroups,
+// i.e. other XCDs' L2s - 438.8 MB fetched for the 363.5 MB of a 1024-clip batch (profiles/stft_pmc.json).  Here a wave owns ALL the mel
+// tiles of its (clip, 64-frame tile): it walks the union of the bands once, feeding every k-step to the one or two tiles whose triangles
+// cover it (the plan's range table: per tile the k-steps it takes alone and those it shares with the next tile), and the frame tiles of a clip sit in one
+// workgroup (shared lines meet in that CU's L1).  Bins above the last triangle (fmax < sr / 2) are never read.  The accumulators of MTMAX
+// tiles stay in registers (16 VGPRs per tile); the MFMA count is the band-sparse one of mel_kernel.  A filter matrix whose bands overlap in
+// more than two tiles (the dense DCT of MelToMFCC) has every tile walk its whole band alone, as in mel_kernel; more than kOnceTiles
+// tiles (M > 128) take mel_kernel.
+constexpr int kOnceTiles = 8;
+
+template <int MTMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MTMAX <= 5 ? 4 : 2))) void mel_fwd_once_kernel(MelParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)p.nft * p.N) return;
+    const int clip = (int)(wid / p.nft);
+    const int ft = (int)(wid - (long long)clip * p.nft);
+    const long long F = p.F;
+    const long long f = (long long)ft * 64 + 4 * (lane & 15);
+    const int kk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t r0 = make_uniform_rsrc(p.in0 + (size_t)clip * p.Cc * F, (int)((size_t)p.Cc * F * sizeof(float)));
+    const float *Wbase = reinterpret_cast<const float *>(p.plan) + p.w_off + lane;
+    const int *seg = p.plan + p.seg_off;
+
+    f32x4 acc[MTMAX][4];
+#pragma unroll
+    for (int t = 0; t < MTMAX; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[t][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int MU = 4;                      // k-steps per batch: all their loads in flight (4 KiB per wave, 16 waves per CU)
+    auto run = [&](auto tc, auto twoc, int sb, int se) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+        constexpr bool TWO = decltype(twoc)::value;
+        const float *W0 = Wbase + (size_t)T * p.CS * 64, *W1 = Wbase + (size_t)(T + 1) * p.CS * 64;
+        for (int s0 = sb; s0 < se; s0 += MU) {
+            float a0[MU], a1[MU];
+            f32x4 b[MU];
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const int sc = min(s0 + u, se - 1);
+                a0[u] = W0[(size_t)sc * 64];
+                if constexpr (TWO) a1[u] = W1[(size_t)sc * 64];
+                b[u] = load_b_raw(r0, s0 + u < se ? 4 * (s0 + u) + kk : p.Cc, p.Cc, f, F);       // past the segment: zeros
+            }
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[T][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b[u][g], acc[T][g], 0, 0, 0);
+                    if constexpr (TWO) acc[T + 1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u][g], acc[T + 1][g], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // tile T alone over [seg[4T], seg[4T+1]), then tiles T and T + 1 together over [seg[4T+2], seg[4T+3]): the k-steps of every tile in
+    // ascending order, as mel_kernel walks them (same MFMA sequence per accumulator: bit-identical results)
+    static_for<0, MTMAX>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+        if (T < p.RT) {                                                                            // wave-uniform (scalar loads)
+            run(tc, std::false_type{}, seg[4 * T], seg[4 * T + 1]);
+            if constexpr (T + 1 < MTMAX) run(tc, std::true_type{}, seg[4 * T + 2], seg[4 * T + 3]);
+        }
+    });
+    // D layout: col = lane&15 (-> frames f..f+3 across accumulators 0..3), row = 4*(lane>>4) + reg
+    const size_t obase = (size_t)clip * p.R * F;
+    static_for<0, MTMAX>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int T = decltype(tc)::value;
+        float l1acc = 0.f;
+        if (T < p.RT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * T + 4 * kk + r;
+                if (row >= p.R) continue;
+                const f32x4 v = {acc[T][0][r], acc[T][1][r], acc[T][2][r], acc[T][3][r]};
+                f32x4 y;
+                y.x = fminf(fmaxf(log_apply(v.x, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+                y.y = fminf(fmaxf(log_apply(v.y, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+                y.z = fminf(fmaxf(log_apply(v.z, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+                y.w = fminf(fmaxf(log_apply(v.w, p.log_kind, p.log_offset, p.pre_clamp_min), p.clamp_lo), p.clamp_hi);
+                const size_t o = obase + (size_t)row * F + f;
+                if (p.l1_ref) {                                            // fused L1 against ref: the log-mel itself is not written
+                    if (f + 3 < F) {
+                        const f32x4 rf = *reinterpret_cast<const f32x4_u *>(p.l1_ref + o);
+                        l1acc += fabsf(y.x - rf.x) + fabsf(y.y - rf.y) + fabsf(y.z - rf.z) + fabsf(y.w - rf.w);
+                        *reinterpret_cast<f32x4_u *>(p.lin + o) = v;
+                    } else {
+                        for (int j = 0; j < 4; ++j)
+                            if (f + j < F) {
+                                l1acc += fabsf(y[j] - p.l1_ref[o + j]);
+                                p.lin[o + j] = v[j];
+                            }
+                    }
+                    continue;
+                }
+                if (f + 3 < F) {
+                    *reinterpret_cast<f32x4_u *>(p.out + o) = y;
+                    if (p.lin) *reinterpret_cast<f32x4_u *>(p.lin + o) = v;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (f + j < F) {
+                            p.out[o + j] = y[j];
+                            if (p.lin) p.lin[o + j] = v[j];
+                        }
+                }
+            }
+            if (p.l1_part) {                  // the partial sums keep mel_kernel's order: one per (clip, frame tile, mel tile)
+                double d = (double)l1acc;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m, 64);
+                if (lane == 0) p.l1_part[wid * p.RT + T] = d;
+            }
+        }
+    });
+}
+
 struct MelHostPlan {
-    int M, K, MT, KS, KT, MS, hdr, fw_off, bw_off, wn_off, KS16;
+    int M, K, MT, KS, KT, MS, hdr, fw_off, bw_off, wn_off, KS16, seg_off;
     size_t total_bytes;
 };
 MelHostPlan mel_layout(int M, int K) {
@@ -302,7 +421,10 @@ MelHostPlan mel_layout(int M, int K) {
     // forward weights once more, in 16-bin groups for the bin-fastest operand: Wn[((t*KS16 + S)*64 + lane)*4 + j] = W[16 t + (lane&15)][16 S + 4 (lane>>4) + j]
     h.KS16 = (K + 15) / 16;
     h.wn_off = h.bw_off + h.KT * h.MS * 64;
-    h.total_bytes = sizeof(float) * ((size_t)h.wn_off + (size_t)h.MT * h.KS16 * 256);
+    // range table of the read-once forward (mel_fwd_once_kernel), four ints per mel tile t: [begin, end) of the k-steps tile t takes alone,
+    // [begin, end) of those it shares with tile t + 1
+    h.seg_off = h.wn_off + h.MT * h.KS16 * 256;
+    h.total_bytes = sizeof(float) * ((size_t)h.seg_off + 4 * h.MT + 4);
     return h;
 }
 
@@ -361,6 +483,25 @@ extern "C" int psnd_mel_plan_build(int M, int K, const float *W, void *plan_host
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 4; ++j)
                     fl[h.wn_off + (((size_t)t * h.KS16 + S) * 64 + lane) * 4 + j] = w(16 * t + (lane & 15), 16 * S + 4 * (lane >> 4) + j);
+    // ranges of the read-once forward: tile t alone, then tiles t and t + 1 together.  Banded = the bands start and end in tile order and no
+    // k-step lies in three of them; any other matrix (the dense DCT of MelToMFCC): every tile walks its whole band alone.
+    {
+        int *sg = hdr + h.seg_off;
+        auto lo = [&](int t) { return hdr[8 + 2 * t]; };
+        auto hi = [&](int t) { return hdr[8 + 2 * t + 1]; };
+        bool banded = true;
+        for (int t = 0; t + 1 < h.MT; ++t) banded &= lo(t) <= lo(t + 1) && hi(t) <= hi(t + 1) && hi(t) > lo(t) && hi(t + 1) > lo(t + 1);
+        for (int t = 0; t + 2 < h.MT; ++t) banded &= hi(t) <= lo(t + 2);
+        for (int t = 0; t < h.MT; ++t) {
+            int s1b = lo(t), s1e = hi(t), s2b = 0, s2e = 0;
+            if (banded) {
+                if (t > 0 && hi(t - 1) > s1b) s1b = hi(t - 1);                 // [lo(t), hi(t-1)) was walked with tile t - 1
+                if (t + 1 < h.MT && lo(t + 1) < s1e) s2b = lo(t + 1), s2e = s1e, s1e = s2b;
+                if (s1e < s1b) s1e = s1b;
+            }
+            sg[4 * t] = s1b, sg[4 * t + 1] = s1e, sg[4 * t + 2] = s2b, sg[4 * t + 3] = s2e;
+        }
+    }
     return PSND_OK;
 }
 
@@ -381,12 +522,13 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     p.log_kind = log_kind, p.log_offset = log_offset, p.pre_clamp_min = pre, p.clamp_lo = lo, p.clamp_hi = hi;
     p.nft = (int)((F + 63) / 64);
     p.l1_ref = l1_ref, p.l1_part = l1_part, p.l1_g = l1_g, p.l1_coef = l1_coef;
-    p.wn_off = h.wn_off, p.CS16 = h.KS16;
+    p.wn_off = h.wn_off, p.CS16 = h.KS16, p.seg_off = h.seg_off;
     if (!bwd) {
         p.R = M, p.Cc = K, p.RT = h.MT, p.CS = h.KS, p.band_off = 8, p.w_off = h.fw_off;
     } else {
         p.R = K, p.Cc = M, p.RT = h.KT, p.CS = h.MS, p.band_off = 8 + 2 * h.MT, p.w_off = h.bw_off;
     }
+    const bool once = !bwd && !nfk && h.MT <= kOnceTiles;          // forward on (N, K, F): every magnitude read once
     const long long waves = (long long)N * p.nft * p.RT;
     const long long blocks = (waves + 3) / 4;
     if (blocks >= (1ll << 31)) PSND_FAIL(PSND_E_SHAPE, "mel: grid too large");
@@ -394,6 +536,10 @@ static int mel_launch(bool bwd, const float *in0, const float *in1, int64_t N, i
     if (nfk) {
         if (!bwd) hipLaunchKernelGGL((mel_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((mel_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else if (!bwd && once) {
+        const long long ob = ((long long)N * p.nft + 3) / 4;
+        if (h.MT <= 5) hipLaunchKernelGGL(mel_fwd_once_kernel<5>, dim3((unsigned)ob), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(mel_fwd_once_kernel<8>, dim3((unsigned)ob), dim3(256), 0, s, p);
     } else if (!bwd) hipLaunchKernelGGL(mel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(mel_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     PSND_CHECK_LAUNCH(bwd ? "mel_bwd" : "mel_fwd");
