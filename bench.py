@@ -519,16 +519,17 @@ def _config4_build(device, T=1292):
     net.mha.return_att = False
 
     class Step(Trainer):
-        def forward(self, mel_, valid, is_logging=False):
+        def forward(self, mel_, valid, pad, is_logging=False):
             with torch.autocast('cuda', dtype=torch.bfloat16):
-                y = self.model(mel_, valid < 0.5)
+                y = self.model(mel_, pad)
             loss = K.masked_l1_loss(y.float(), mel_, valid)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
     g = torch.Generator().manual_seed(2 + int(os.environ.get('RANK', '0')))
     lens = torch.linspace(0.8 * T, T, N).long()
     valid = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
-    pool = [(torch.randn(N, 80, T, generator=g).to(device), valid) for _ in range(3)]
+    pad = valid < 0.5                                    # the padding mask comes with the batch (the collate function knows the lengths)
+    pool = [(torch.randn(N, 80, T, generator=g).to(device), valid, pad) for _ in range(3)]
     tr = Step(net, poptim.Adam(net.parameters(), lr=1e-4), pool, pool, max_step=10 ** 9, valid_max_step=1, save_interval=10 ** 9,
               log_interval=10 ** 9, save_dir=tempfile.mkdtemp(prefix='psnd_c4_'), seed=1)
     tr.graph_steps = True

@@ -408,6 +408,11 @@ int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_
 int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T);
 int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                        int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
+/* psnd_linear1x1_bwd with gx = w^T gy' + gx_addend (N, Cin, T; NULL: none): the gradient that reaches x along a residual connection
+ * (`x + self.drop_out(...)` before the GroupNorm, modules.py:56-58, 114-116) is added in the GEMM's epilogue - autograd's separate
+ * accumulation pass over both tensors disappears. */
+int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                           int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
                  int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,

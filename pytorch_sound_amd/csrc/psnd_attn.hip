@@ -44,6 +44,8 @@ struct GemmParams {
     // all the tiles of one batch chunk in weight-gradient mode - are numbered consecutively AND land on one XCD (workgroup L runs on XCD
     // L % 8): the first of them brings the bytes into that XCD's L2, the others hit.  tiles_x / tiles_y / tiles_z: the logical grid.
     int tiles_x, tiles_y, tiles_z;
+    const float *addend;         // null, or a tensor indexed like C: C = A B + addend (the residual branch's gradient folded into the
+                                 // input-gradient GEMM of the branch's first projection: no separate accumulation pass)
 };
 
 // logical tile (x, y, z) of workgroup L; false = padding workgroup (the numbering is padded to whole groups of 8 outer tiles)
@@ -152,7 +154,17 @@ __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&a
             coff = z * p.sCz + (n - z * p.flatT);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            float ad[16];
+            if (p.addend) {                      // all sixteen loads of the block in flight before its first store (C and addend may alias
+                                                 // as far as hipcc knows: next to the stores every load would be waited for in turn)
+                const float *ap = p.addend + (C - p.C) + coff;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + t * 32 + rho(r, half);
+                    ad[r] = ap[(long long)(m < p.M ? m : p.M - 1) * p.sCm];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + t * 32 + rho(r, half);
@@ -160,9 +172,11 @@ __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&a
                     float v = acc[t][u][r];
                     if (p.bias) v += p.bias[m];
                     if (p.relu) v = v > 0.f ? v : 0.f;
+                    if (p.addend) v += ad[r];
                     C[(long long)m * p.sCm + coff] = v;
                 }
             }
+        }
     }
 }
 
@@ -436,6 +450,45 @@ __global__ __launch_bounds__(1024) void rowsum_kernel(const float *g, const floa
     red[tid] = acc;
     __syncthreads();
     for (int s = 512; s >= 1; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[c] = (float)red[0];
+}
+
+// The same sum for rows of whole 16-byte pieces (T % 4 == 0; round 6): a workgroup per channel walks the (clip, 16-byte piece) items of its
+// Z rows flat - no partly filled pass over a row (T = 1292: the sixth 256-frame pass of the kernel above had 12 live lanes of 256) -
+// with four 16-byte loads per operand in flight per thread; fp32 partial sums of at most a few hundred terms per thread, the tree in
+// double.  338 MB (32 x 1024 x 1292, masked) in 228 -> ~90 us.
+template <bool MASK>
+__global__ __launch_bounds__(512) void rowsum4_kernel(const float *g, const float *mask, int Z, int C, int Q /* T / 4 */, float *out) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const long long items = (long long)Z * Q;
+    const long long rowq = (long long)C * Q;                   // 16-byte pieces between the same channel of two clips
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g) + (long long)c * Q;
+    const f32x4 *m4 = reinterpret_cast<const f32x4 *>(mask) + (long long)c * Q;
+    float acc = 0.f;
+    for (long long i0 = tid; i0 < items; i0 += 4 * 512) {
+        f32x4 v[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            long long i = i0 + 512 * u;
+            i = i < items ? i : items - 1;
+            const long long z = i / Q, o = z * rowq + (i - z * Q);
+            v[u] = g4[o];
+            if (MASK) m[u] = m4[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + 512 * u >= items) continue;
+            if (MASK) acc += (m[u].x > 0.f ? v[u].x : 0.f) + (m[u].y > 0.f ? v[u].y : 0.f) + (m[u].z > 0.f ? v[u].z : 0.f) + (m[u].w > 0.f ? v[u].w : 0.f);
+            else acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        }
+    }
+    __shared__ double red[512];
+    red[tid] = (double)acc;
+    __syncthreads();
+    for (int s = 256; s >= 1; s >>= 1) {
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
@@ -1485,8 +1538,16 @@ extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int6
 }
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
+extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                      int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                   int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
+    return psnd_linear1x1_bwd_acc(gy, ymask, x, w, N, Cin, Cout, T, bf16, nullptr, gx, gw, gw_part, gbias, stream);
+}
+// ... with gx = W^T gy' + gx_addend (N, Cin, T): the gradient that reaches x along another branch (a residual connection) rides in the
+// GEMM's epilogue instead of a separate accumulation pass over both tensors
+extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                      int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
     if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
     if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
@@ -1495,7 +1556,7 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
     int rc = PSND_OK;
     if (gx) {
         GemmParams p = {};
-        p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask;
+        p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask, p.addend = gx_addend;
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
         p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
@@ -1519,7 +1580,10 @@ extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const flo
         PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
     }
     if (gbias) {
-        if (ymask) hipLaunchKernelGGL(rowsum_kernel<true>, dim3(Cout), dim3(1024), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
+        const bool vec = T % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(ymask)) % 16 == 0;
+        if (vec && ymask) hipLaunchKernelGGL(rowsum4_kernel<true>, dim3(Cout), dim3(512), 0, st, gy, ymask, (int)N, Cout, (int)(T / 4), gbias);
+        else if (vec) hipLaunchKernelGGL(rowsum4_kernel<false>, dim3(Cout), dim3(512), 0, st, gy, gy, (int)N, Cout, (int)(T / 4), gbias);
+        else if (ymask) hipLaunchKernelGGL(rowsum_kernel<true>, dim3(Cout), dim3(1024), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
         else hipLaunchKernelGGL(rowsum_kernel<false>, dim3(Cout), dim3(1024), 0, st, gy, ymask, (int)N, Cout, (long long)T, gbias);
         PSND_CHECK_LAUNCH("linear1x1_bwd(bias)");
     }

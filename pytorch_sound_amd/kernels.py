@@ -425,14 +425,40 @@ def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9, window=None):
 # ---------------------------------------------------------------------------------------------
 # transformer blocks (models/modules.py): GroupNorm(1, C)(x + res) and the masked softmax over keys
 # ---------------------------------------------------------------------------------------------
+RESIDUAL_LINKS = os.environ.get('PSND_RESIDUAL_LINKS', '1') == '1'      # 0: autograd accumulates the two gradients of a block's input (A/B)
+
+
+class ResidualLink:
+    """One residual connection y = norm(f(x) + x) whose branch f starts with a Linear1x1 on the same x (MultiHeadAttention,
+    PointwiseFeedForward): autograd would add the two gradients of x in a pass of its own (three tensor sweeps); instead the norm's
+    backward hands its gradient for x to the link and returns none, and the Linear1x1's backward - which runs later in the same pass and
+    consumes it - writes W^T gy + that gradient (psnd_linear1x1_bwd_acc).  The projection registers itself when its forward was recorded
+    with x requiring a gradient; without a registered consumer the norm returns its gradient as usual."""
+
+    def __init__(self):
+        self.consumer = False      # a Linear1x1 node that will produce a gradient for x holds this link
+        self.g = None
+
+    def offer(self, g) -> bool:
+        if not self.consumer or not RESIDUAL_LINKS:
+            return False
+        self.g = g
+        return True
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
 class GroupNorm1(torch.autograd.Function):
     """y = GroupNorm(1, C)(x + res) [-> ReLU]: statistics over (C x T) per sample (modules.py:58, :114-116)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, relu):
+    def forward(ctx, x, res, gamma, beta, eps, relu, link=None):
         _need_cuda(x, 'x')
         x = x.contiguous()
         res = None if res is None else res.contiguous()
+        ctx.link = link if (link is not None and res is not None) else None
         N, C, T = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((N, 2), dtype=torch.float32, device=x.device)
@@ -457,7 +483,10 @@ class GroupNorm1(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(lib().psnd_groupnorm1_bwd(ptr(gy), ptr(x), ptr(res), ptr(g32), ptr(y), ptr(stats), N, C, T, int(ctx.relu),
                                             ptr(gx), ptr(gg), ptr(gb), ptr(ws), stream_ptr(x.device)), 'psnd_groupnorm1_bwd')
-        return gx, (gx if ctx.has_res else None), gg, gb, None, None
+        if ctx.link is not None and ctx.needs_input_grad[1] and ctx.link.offer(gx):
+            # the residual's gradient travels with the link: the first projection of the branch adds it in its input-gradient GEMM
+            return gx, None, gg, gb, None, None, None
+        return gx, (gx if ctx.has_res else None), gg, gb, None, None, None
 
 
 class SoftmaxKeys(torch.autograd.Function):
@@ -501,8 +530,11 @@ class Linear1x1(torch.autograd.Function):
     masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1); output and gradients fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu, bf16=False):
+    def forward(ctx, x, w, bias, relu, bf16=False, link=None):
         _need_cuda(x, 'input')
+        ctx.link = None
+        if link is not None and ctx.needs_input_grad[0]:
+            ctx.link, link.consumer = link, True
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
         N, Cin, T = x.shape
@@ -529,6 +561,9 @@ class Linear1x1(torch.autograd.Function):
         Cout = w2.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dev = x.device
+        addend = ctx.link.take() if ctx.link is not None else None      # the residual branch's gradient for x (ResidualLink)
+        if addend is not None and (addend.shape != x.shape or addend.dtype != torch.float32 or not addend.is_contiguous()):
+            raise PsndError('Linear1x1: residual gradient %s does not fit the input %s' % (tuple(addend.shape), tuple(x.shape)))
         gx = torch.empty_like(x) if need_x else None
         gw = torch.empty_like(w2) if need_w else None
         gb = torch.empty(Cout, dtype=torch.float32, device=dev) if need_b else None
@@ -549,13 +584,13 @@ class Linear1x1(torch.autograd.Function):
                 cl.GRAD_SINK.note_producer(ctx.params, side)
         with torch.cuda.device(dev):
             if side is None:
-                check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), ptr(gw), ptr(part), ptr(gb),
-                                               stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                check(lib().psnd_linear1x1_bwd_acc(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(gx), ptr(gw),
+                                                   ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
             else:
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)                          # gy is complete on the main stream
-                check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(gx), None, None, None,
-                                               stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                check(lib().psnd_linear1x1_bwd_acc(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(gx), None, None,
+                                                   None, stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 with torch.cuda.stream(side):
                     check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), None, ptr(gw), ptr(part),
                                                    ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
@@ -564,7 +599,7 @@ class Linear1x1(torch.autograd.Function):
                         t.record_stream(side)
                 cl._join_side_at_end_of_backward(dev, side)
         cl.consume_param_use(ctx)
-        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None
 
 
 class PosEnc(torch.autograd.Function):

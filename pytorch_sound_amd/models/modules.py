@@ -34,16 +34,19 @@ def _to_kernel_dtype(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu: bool = False) -> torch.Tensor:
-    """GroupNorm(1, C)(x + residual) [-> ReLU]"""
+def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu: bool = False, link=None) -> torch.Tensor:
+    """GroupNorm(1, C)(x + residual) [-> ReLU]; `link`: the kernels.ResidualLink the branch's first projection was given - the residual's
+    gradient then reaches the input through that projection's input-gradient GEMM instead of a separate accumulation pass"""
     if _hip_ok(x):
         from pytorch_sound_amd import kernels as K
-        return K.GroupNorm1.apply(x.float(), residual.float(), norm.weight.float(), norm.bias.float(), norm.eps, relu)
+        if link is not None and residual.dtype != torch.float32:
+            link = None                                      # (the gradient would be of the converted copy, not of `residual`)
+        return K.GroupNorm1.apply(x.float(), residual.float(), norm.weight.float(), norm.bias.float(), norm.eps, relu, link)
     y = norm(x + residual)
     return F.relu(y) if relu else y
 
 
-def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False, link=None) -> torch.Tensor:
     """the 1x1 Conv1d projections of modules.py:21-22, 93-95 as what they are - one GEMM over (C_in, N*T), on the exact-fp32
     matrix-core kernel (psnd_linear1x1_*, bias and the following ReLU fused).  CPU tensors (and the tests' fp32 yardstick) keep
     the torch formulation."""
@@ -54,7 +57,9 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False) -> torch.Tens
     # under torch.autocast(bfloat16) the products take bf16 operands (fp32 accumulation, fp32 activations in memory): 16x the
     # matrix rate; without autocast they are exact fp32
     bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-    return K.Linear1x1.apply(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16)
+    if link is not None and x.dtype != torch.float32:
+        link = None
+    return K.Linear1x1.apply(x.float(), conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16, link)
 
 
 class MultiHeadAttention(nn.Module):
@@ -85,7 +90,11 @@ class MultiHeadAttention(nn.Module):
     def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         in_dtype = input.dtype
         input = _to_kernel_dtype(input)
-        kvq = _conv1x1(self.linear_kvq, input)
+        link = None
+        if _hip_ok(input) and input.dtype == torch.float32 and input.requires_grad and torch.is_grad_enabled():
+            from pytorch_sound_amd import kernels as K
+            link = K.ResidualLink()                     # input feeds the projection AND the residual: one gradient pass for both
+        kvq = _conv1x1(self.linear_kvq, input, link=link)
         if _hip_ok(input):
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
             if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 128:
@@ -93,7 +102,8 @@ class MultiHeadAttention(nn.Module):
                 raise PsndError('MultiHeadAttention(hidden_dim=%d, heads=%d): psnd_mha_* covers head dimensions up to 128 that divide '
                                 'hidden_dim; there is no library path for a HIP tensor' % (self.hidden_dim, self.heads))
             from pytorch_sound_amd import kernels as K
-            mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
+            # (a bool mask already is one byte of 0 / 1 per frame: a view, no conversion launch)
+            mask_u8 = None if mask is None else (mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous())
             # under torch.autocast(bfloat16) the score / accumulate products take bf16 operands, as the projections do
             bf16 = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
             x, att = K.AttentionKVQ.apply(kvq, mask_u8, self.heads, self.return_att, bf16)
@@ -107,7 +117,7 @@ class MultiHeadAttention(nn.Module):
         x = _conv1x1(self.linear, x)
         if self.drop_out is not None:
             x = self.drop_out(x)
-        x = _add_norm(self.layernorm, x, input)
+        x = _add_norm(self.layernorm, x, input, link=link)
         if in_dtype != x.dtype:
             x, att = x.to(in_dtype), (None if att is None else att.to(in_dtype))
         return x, att
@@ -158,10 +168,14 @@ class PointwiseFeedForward(nn.Module):
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         in_dtype = input.dtype
         input = _to_kernel_dtype(input)
-        x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True))
+        link = None
+        if _hip_ok(input) and input.dtype == torch.float32 and input.requires_grad and torch.is_grad_enabled():
+            from pytorch_sound_amd import kernels as K
+            link = K.ResidualLink()
+        x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True, link=link))
         if self.drop_out is not None:
             x = self.drop_out(x)
-        x = _add_norm(self.layernorm, x, input, relu=True)
+        x = _add_norm(self.layernorm, x, input, relu=True, link=link)
         return x if x.dtype == in_dtype else x.to(in_dtype)
 
 
