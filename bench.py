@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement; `settle` = untim
   roofline_instep  the step's launch as it runs inside the timed steps (64 clips, 34 MB, cache resident): a latency figure
   roofline_config5 BASELINE config 5: n_fft 4096 / hop 1024, 32 clips x 30 s at 44.1 kHz (508 MB), (N, F, K) - stft_fwd_n4096r_kernel;
                    roofline_config5_nkf: the (N, K, F) kernel
+  roofline_copy    a plain copy of the same bytes as the judged launch under the same timing (what the box delivers to the simplest kernel)
   roofline_mel     the unfused mel stage; roofline_conv: the conv kernels that take most of the step, against the dense bf16 MFMA peak
   config3_step / config4_step   BASELINE configs[2] / configs[3] on one GPU: ms/step, p50 / p99 / max over 200 steps, fraction of the MFMA peak
   dropin_step      configs[1] written against the reference's API names only (Trainer.forward override, STFT.transform, F.l1_loss)
@@ -376,10 +377,13 @@ def gpu_bench(args):
         roofline['frac_config5'] = roofline_config5['frac']
         roofline['frac_nkf'] = roofline_nkf['frac']
         roofline['frac_config5_nkf'] = roofline_config5_nkf['frac']
+        roofline_copy = _copy_roofline(device, roofline['bytes_per_launch'])
+        roofline['frac_copy'] = roofline_copy['frac']
         roofline['note'] = ('frac: the step\'s STFT kernel (N, F, K) on 1024 clips x 2 s; frac_config5: configs[4] (4096/1024, 32 x 30 s) in the same '
                             'layout (full entry: roofline_config5); frac_nkf / frac_config5_nkf: the same transforms writing the reference\'s (N, K, F) '
-                            '(roofline_nkf, roofline_config5_nkf).  Every frac is the mean over 32 back-to-back launches behind 8 untimed ones (SUSTAINED; '
-                            'first_launch_us / burst8_launch_us / best_launch_us beside it).  `traffic` fields are RECORDED counter passes (profiles/stft_pmc.json, rocprofv3 '
+                            '(roofline_nkf, roofline_config5_nkf).  Every frac is the mean over 32 back-to-back launches behind >= 80 ms of untimed '
+                            'back-to-back launches (SUSTAINED at the running clock: an idle MI355X needs 30-40 ms of work to leave its ~100 MHz idle clock; '
+                            'first_launch_us / ramp8_launch_us = the first launches out of idle, best / worst of the 32 beside it; frac_copy = a plain copy of the same bytes under the same timing).  `traffic` fields are RECORDED counter passes (profiles/stft_pmc.json, rocprofv3 '
                             '--pmc in separate runs), not measured in this run')
         roofline_mel = _mel_roofline(device)
         roofline_conv = _conv_roofline(device, N, Fr)
@@ -401,7 +405,7 @@ def gpu_bench(args):
                        'model_params': sum(p.numel() for p in model.parameters())},
             'settle_note': '`settle` untimed set-up steps (clock ramp) run in front of the `warmup` steps; timing.blocks_ms_per_step shows what is left of the ramp',
             'roofline': roofline, 'roofline_instep': roofline_instep, 'roofline_nkf': roofline_nkf, 'roofline_config5': roofline_config5,
-            'roofline_config5_nkf': roofline_config5_nkf, 'roofline_conv': roofline_conv,
+            'roofline_config5_nkf': roofline_config5_nkf, 'roofline_copy': roofline_copy, 'roofline_conv': roofline_conv,
             'roofline_mel': roofline_mel, 'h2d_inclusive': h2d, 'timing': timing,
         }
         out.update(legs)
@@ -697,26 +701,61 @@ def config_bench(args):
 
 
 SUSTAINED_LAUNCHES = 32      # back-to-back launches behind every roofline figure (a burst of 8 flattered config 5 by 20 %)
+SUSTAINED_WARM_S = 0.08      # untimed back-to-back launches in front of them.  An idle MI355X sits at sclk ~100 MHz and takes ~30-40 ms of
+                             # continuous work to reach its running clock (tools/r06/series.py, profiles/r06_launch_series.txt: the n = 1024 kernel
+                             # reads 150-165 us for its first 48 launches out of idle, 111-113 us from launch ~250 on and stays there for 1024
+                             # launches; a plain copy of the same bytes 102-103 us throughout) - 8 untimed launches (round 5 / the first round-6
+                             # line) timed that RAMP, not the kernel
 
 
-def _time_launches(launch, n=SUSTAINED_LAUNCHES, warm=8):
-    """HIP events around each of `warm` + `n` back-to-back launches on the current stream: the SUSTAINED mean over the last n (what the
-    `frac` fields are computed from), plus the first launch (cold: clocks and caches) and the best one, in seconds"""
+def _time_launches(launch, n=SUSTAINED_LAUNCHES, warm_s=SUSTAINED_WARM_S):
+    """HIP events around each of `n` back-to-back launches on the current stream, behind >= `warm_s` seconds of untimed back-to-back launches (the
+    clock ramp out of idle): the SUSTAINED mean over the n (what the `frac` fields are computed from), the first launch of the whole run (cold:
+    clocks and caches), the best one, and the mean of the first 8 launches out of idle (`ramp8`: what a short burst reads), in seconds"""
+    torch.cuda.synchronize()
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    head = []
+    for _ in range(8):                                   # the first launches out of idle, timed for the record
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        head.append((e0, e1))
+    warm_launches, t0 = 8, time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(64):
+            launch()
+        warm_launches += 64
+        torch.cuda.synchronize()
     evs = []
-    for _ in range(warm + n):
+    for _ in range(64):                                  # (no gap between the last warm chunk and the timed launches)
+        launch()
+    for _ in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
+    hs = [a.elapsed_time(b) * 1e-3 for a, b in head]
     ts = [a.elapsed_time(b) * 1e-3 for a, b in evs]
-    return {'t': float(np.mean(ts[warm:])), 'first': ts[0], 'best': float(np.min(ts[warm:])), 'burst8': float(np.mean(ts[warm:warm + 8])), 'n': n}
+    return {'t': float(np.mean(ts)), 'first': hs[0], 'best': float(np.min(ts)), 'worst': float(np.max(ts)), 'ramp8': float(np.mean(hs)), 'n': n,
+            'warm_launches': warm_launches + 64}
 
 
 def _launch_fields(m):
-    return {'launch_us': m['t'] * 1e6, 'launches_timed': m['n'], 'first_launch_us': m['first'] * 1e6, 'best_launch_us': m['best'] * 1e6,
-            'burst8_launch_us': m['burst8'] * 1e6}
+    return {'launch_us': m['t'] * 1e6, 'launches_timed': m['n'], 'untimed_launches_before': m['warm_launches'], 'first_launch_us': m['first'] * 1e6,
+            'best_launch_us': m['best'] * 1e6, 'worst_launch_us': m['worst'] * 1e6, 'ramp8_launch_us': m['ramp8'] * 1e6}
+
+
+def _copy_roofline(device, nbytes):
+    """a plain device copy moving the same number of bytes as the judged STFT launch (nbytes / 2 read + nbytes / 2 written): what this box's HBM
+    delivers to the simplest kernel there is, under the same timing"""
+    a = torch.empty(nbytes // 8, device=device)
+    b = torch.empty_like(a)
+    m = _time_launches(lambda: b.copy_(a))
+    return {'bound': 'hbm', 'kernel': 'torch copy_ (fp32, %d MB read + %d MB written)' % (nbytes // 2e6, nbytes // 2e6), 'achieved': nbytes / m['t'] / 1e9,
+            'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': nbytes / m['t'] / HBM_PEAK, 'bytes_per_launch': nbytes, **_launch_fields(m)}
 
 
 def _nfk_roofline(device, n_fft, hop, clips, T, label):
