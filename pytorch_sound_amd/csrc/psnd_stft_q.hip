@@ -33,6 +33,9 @@
 #define PSND_Q_STORE_AUX 2    // cache-policy bits of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  nt: whole lines written once, never
                               // re-read by this kernel - measured 148 against 162 us (same box, 1024 clips x 2 s); 17 / 18 / 19: 166 / 159 / 161
 #endif
+#ifndef PSND_Q_LOAD_MOD
+#define PSND_Q_LOAD_MOD ""    // cache-policy modifiers of the span transfers (A/B builds: " nt", " sc1", " sc0 sc1")
+#endif
 #ifdef PSND_Q_NOSB            // A/B builds (tools/r04/variant_q.sh): no scheduling fences between the phases
 #define Q_SB()
 #else
@@ -224,29 +227,49 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
             for (int j = 0; j < kSPV; ++j) {
                 const unsigned dst = xw_lds + 4u * kPiece * j;
                 const int soff = 1024 * j;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" PSND_Q_LOAD_MOD " lds"
                              :: "s"(dst), "v"(voff), "s"(rs), "s"(soff) : "memory");
             }
         } else {
-            // every sample of the span as one 4-byte load per lane, ALL in flight before the first lands (round 6: a rolled loop waited
-            // for each of its 28 loads in turn - ~8 us of exposed latency in three of a clip's 44 quads, and most waves own one of them)
+            // A span that crosses a clip edge (the first and the last two quads of a clip), piece by piece (256 samples = one transfer instruction
+            // of the main path; every test below is wave-uniform): a piece inside the clip goes the way of the main path, a piece the reflection
+            // reaches is fetched as four 4-byte loads per lane with reflected indices (all in flight before the first lands) and written into its
+            // place, a piece past the span (quads of fewer than four frames) is left alone - its frames are never stored.  Round 6, first form:
+            // all 28 loads per lane reflected whatever the piece - ~600 VALU instructions of index arithmetic per edge quad, next to ~700 for the
+            // quad's transforms, in 3 of a clip's 44 quads.
             const int Ti = (int)p.T, gb = (int)g0;
-            constexpr int kNE = kSPV * 4;                        // loads per lane: 64 x kNE >= the longest span
             const int ln = fresh_lane();
-            float ev[kNE];
-            static_for<0, kNE>([&](auto jc) __attribute__((always_inline)) {
+            static_for<0, kSPV>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                const int sj = ln + 64 * j;
-                ev[j] = x_[reflect_idx32(gb + (sj < span_len ? sj : span_len - 1), Ti)];
+                const int a0 = gb + 256 * j;                     // first sample of the piece in the clip (wave-uniform)
+                if (256 * j < span_len) {
+                    if (a0 >= 0 && a0 + 256 <= Ti) {
+                        const unsigned long long a = reinterpret_cast<unsigned long long>(x_ + a0);
+                        u32x4 rs;
+                        rs.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+                        rs.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+                        rs.z = 1024u;
+                        rs.w = 0x00020000u;
+                        const unsigned dst = xw_lds + 4u * kPiece * j;
+                        const int voff = ln * 16;
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen" PSND_Q_LOAD_MOD " lds"
+                                     :: "s"(dst), "v"(voff), "s"(rs) : "memory");
+                    } else {
+                        float ev[4];
+                        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+                            constexpr int i = decltype(ic)::value;
+                            const int sj = 256 * j + ln + 64 * i;
+                            ev[i] = x_[reflect_idx32(gb + (sj < span_len ? sj : span_len - 1), Ti)];
+                        });
+                        // (written unconditionally: a slot past the span holds a copy of its last sample)
+                        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) {
+                            constexpr int i = decltype(ic)::value;
+                            xw[kPiece * j + ln + 64 * i] = ev[i];
+                        });
+                    }
+                }
             });
-            // written unconditionally (a slot past the span holds a copy of its last sample: those frames are never stored; the highest
-            // index, 63 + 64 (kNE - 1) + skew, lies inside the wave's buffer) - a predicated write leaves its load pending on the path that
-            // skips it, and hipcc then answers the tap reads of the MAIN path with vmcnt(0), i.e. it waits for the ten stores
-            static_for<0, kNE>([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;           // ((ln + 64 j) >> 8 == j / 4: the skew is a compile-time constant)
-                xw[ln + 64 * j + (HOP256 ? 32 * (j / 4) : 0)] = ev[j];
-            });
-            static_assert(63 + 64 * (kNE - 1) + (HOP256 ? 32 * ((kNE - 1) / 4) : 0) < kXW, "edge fill stays inside the wave's buffer");
+            static_assert(kPiece * (kSPV - 1) + 255 < kXW, "edge fill stays inside the wave's buffer");
         }
     };
 
