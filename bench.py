@@ -473,7 +473,9 @@ def _config3_build(device):
                 return wav, mel(wav)
 
         def forward(self, wav, m, is_logging=False):
-            y = self.model(m).squeeze(1)
+            with torch.autocast('cuda', dtype=torch.bfloat16):      # bf16 conv operands: the generator's channels-last kernels (fp32 outside autocast)
+                y = self.model(m)
+            y = y.float().squeeze(1)
             loss = K.l1_loss(mel(y), m)                 # F.l1_loss as psnd_l1_loss_fwd / _bwd (abs / mean / sign / scale: 5 library launches otherwise)
             return loss, {'loss': (loss, LogType.SCALAR)}
 
@@ -485,7 +487,7 @@ def _config3_build(device):
     gen.train()
     # hifi_gan_v1 forward 19.65 GFLOP per 8192-sample segment (conv MACs x 2), x 3 for forward + both gradients
     flops = 19.65e9 * N * 3.0
-    meta = {'unit': 'audio-s/s', 'dtype': 'bf16 conv operands, fp32 accumulate / features / optimizer',
+    meta = {'unit': 'audio-s/s', 'dtype': 'bf16 conv operands under torch.autocast (Generator.precision auto), fp32 accumulate / features / optimizer',
             'workload': 'configs[2] per GPU: hifi_gan_v1 (13.9 M parameters), 16 x 8192-sample segments at 22.05 kHz (F = 32), '
                         'mel 1024/256/80 (HiFi-GAN framing), L1(mel(G(mel x)), mel x), Adam, hipGraph replay; the resblocks of a stage and the upsamplers\' '
                         'parameter-side backward as parallel graph branches (DESIGN 4.4)',

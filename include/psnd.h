@@ -487,6 +487,18 @@ int psnd_stft_bwd_msl(const float *wav, int64_t N, int64_t T, int n_fft, int hop
                       float mag_eps, const float *t_mag, const float *norms, const float *g3, int L, float eps,
                       int accumulate, float *gwav, void *stream);
 
+/* ---- fp32 instance of the Conv1d / ConvTranspose1d stack (models/vocoders/hifi_gan.py:32-147 computes its convolutions in fp32) -------
+ *  A convolution = psnd_linear1x1_fwd (exact fp32 matrix-core GEMM) over the unfolded input
+ *      col[n][ci * k + j][t] = act(x[n][ci][src]),  s' = t * stride + j * dil - pad,  src = s' / up  (0 where s' < 0, s' % up != 0 or src >= T),
+ *  act(v) = v > 0 ? v : slope * v (slope 1: none) - the leaky-relu in front of every ResBlock conv (hifi_gan.py:58-61, 86-87).
+ *  Conv1d(k, dilation d, padding p): stride 1, up 1, pad p, To = T + 2 p - d (k - 1);  ConvTranspose1d(k, stride u, padding p): up u,
+ *  pad k - 1 - p, taps flipped by the caller, To = (T - 1) u - 2 p + k (hifi_gan.py:107-110).  x (N, C, T), col (N, C * k, To) fp32.
+ *  psnd_col2im_f32 is the adjoint: gx (N, C, T) from gcol, times act'(x) (x may be NULL when slope == 1). */
+int psnd_im2col_f32(const float *x, int64_t N, int C, int64_t T, int k, int dil, int pad, int stride, int up, int64_t To, float slope,
+                    float *col, void *stream);
+int psnd_col2im_f32(const float *gcol, const float *x, int64_t N, int C, int64_t T, int k, int dil, int pad, int stride, int up, int64_t To,
+                    float slope, float *gx, void *stream);
+
 /* ---- data/dataset.py:196-250, SpeechDataLoader.pad_collate_fn on the audio column, device side --------------------
  *  flat : the batch's clips back to back (device, fp32); offs[n], lens[n] : start / length of clip n in flat (device
  *  int64).  out : (N, Tmax) fp32 = clip n zero-padded (or cut) to Tmax;  mask (may be NULL) : (N, Tmax) fp32, 1 on valid

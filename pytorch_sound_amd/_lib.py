@@ -124,6 +124,8 @@ SIGNATURES = {
     'psnd_frame_mask_frames': (_I64, [_I64, _INT, _INT]),
     'psnd_frame_mask': (_INT, [_P, _I64, _I64, _INT, _INT, _P, _P]),
     'psnd_pad_collate': (_INT, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
+    'psnd_im2col_f32': (_INT, [_P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _INT, _I64, _F, _P, _P]),
+    'psnd_col2im_f32': (_INT, [_P, _P, _I64, _INT, _I64, _INT, _INT, _INT, _INT, _INT, _I64, _F, _P, _P]),
     'psnd_adam_chunk': (_I64, []),
     'psnd_adam_table_bytes': (_I64, []),
     'psnd_adam_step': (_INT, [_P, _INT, _P, _P, _I64, _D, _D, _D, _D, _D, _INT, _P, _P, _P, _F, _P, _P]),

@@ -71,4 +71,6 @@ class InterfaceHifiGAN(Interface):
     @torch.no_grad()
     def decode(self, mel_tensor: torch.Tensor) -> torch.Tensor:
         assert mel_tensor.ndim == 3, '3D tensor (N, C, T) is needed'
+        # an fp32 mel outside torch.autocast is decoded with fp32 convolutions, as the reference does (Generator.precision = 'auto');
+        # `self.decoder.precision = 'bf16'` or a torch.autocast context opts into the channels-last bf16 kernels
         return self.decoder(mel_tensor)

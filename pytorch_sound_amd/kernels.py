@@ -602,6 +602,64 @@ class Linear1x1(torch.autograd.Function):
         return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None
 
 
+class Im2Col(torch.autograd.Function):
+    """the unfolded input of a 1-d convolution, col[n][ci * k + j][t] = act(x[n][ci][(t * stride + j * dil - pad) / up]) (psnd_im2col_f32; zero
+    outside the signal and between the samples of a zero-spread input), act = leaky-relu with `slope` (1.0: none); backward psnd_col2im_f32"""
+
+    @staticmethod
+    def forward(ctx, x, k, dil, pad, stride, up, To, slope):
+        _need_cuda(x, 'input')
+        x = x.contiguous()
+        N, C, T = x.shape
+        col = torch.empty((N, C * k, To), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib().psnd_im2col_f32(ptr(x), N, C, T, k, dil, pad, stride, up, To, float(slope), ptr(col), stream_ptr(x.device)), 'psnd_im2col_f32')
+        ctx.geom = (int(k), int(dil), int(pad), int(stride), int(up), int(To), float(slope))
+        ctx.save_for_backward(x if slope != 1.0 else None)
+        ctx.xshape = (N, C, T)
+        return col
+
+    @staticmethod
+    def backward(ctx, gcol):
+        (x,) = ctx.saved_tensors
+        k, dil, pad, stride, up, To, slope = ctx.geom
+        N, C, T = ctx.xshape
+        gcol = gcol.contiguous()
+        gx = torch.empty((N, C, T), dtype=torch.float32, device=gcol.device)
+        with torch.cuda.device(gcol.device):
+            check(lib().psnd_col2im_f32(ptr(gcol), ptr(x), N, C, T, k, dil, pad, stride, up, To, slope, ptr(gx), stream_ptr(gcol.device)), 'psnd_col2im_f32')
+        return gx, None, None, None, None, None, None, None
+
+
+def conv1d_f32(x, w, bias, padding=0, dilation=1, pre_slope=1.0):
+    """F.conv1d(leaky_relu(x, pre_slope), w, bias, 1, padding, dilation) in exact fp32 on the matrix cores - the precision of the reference's
+    conv stack (hifi_gan.py:32-147): unfold (psnd_im2col_f32, the activation applied while gathering) + psnd_linear1x1_* (v_mfma_f32_32x32x2_f32),
+    forward and both gradients.  x (N, Cin, T) fp32 HIP, w (Cout, Cin, k)."""
+    Cout, Cin, k = w.shape
+    T = x.shape[2]
+    To = T + 2 * padding - dilation * (k - 1)
+    if To <= 0:
+        raise PsndError('conv1d_f32: no output samples (T=%d, k=%d, dilation=%d, padding=%d)' % (T, k, dilation, padding))
+    if k == 1 and padding == 0 and pre_slope == 1.0:
+        return Linear1x1.apply(x, w, bias, False, False)
+    col = Im2Col.apply(x, k, dilation, padding, 1, 1, To, pre_slope)
+    return Linear1x1.apply(col, w.reshape(Cout, Cin * k), bias, False, False)
+
+
+def conv_transpose1d_f32(x, w, bias, stride, padding, pre_slope=1.0):
+    """F.conv_transpose1d(leaky_relu(x, pre_slope), w, bias, stride, padding) in exact fp32: a convolution with the flipped taps over the
+    zero-spread input (the zeros are never stored: psnd_im2col_f32 writes them into the unfolded rows), (T - 1) * stride - 2 * padding + k
+    output samples (hifi_gan.py:107-110).  w (Cin, Cout, k) as nn.ConvTranspose1d keeps it."""
+    Cin, Cout, k = w.shape
+    T = x.shape[2]
+    To = (T - 1) * stride - 2 * padding + k
+    if k - 1 - padding < 0 or To <= 0:
+        raise PsndError('conv_transpose1d_f32: padding %d beyond k - 1 = %d' % (padding, k - 1))
+    weq = w.flip(2).permute(1, 0, 2).reshape(Cout, Cin * k)
+    col = Im2Col.apply(x, k, 1, k - 1 - padding, 1, stride, To, pre_slope)
+    return Linear1x1.apply(col, weq, bias, False, False)
+
+
 class PosEnc(torch.autograd.Function):
     """PositionalEncoding.forward (modules.py:143-145): x * sqrt(C) + pe[..., :T] as one pass (psnd_posenc); backward g * sqrt(C)."""
 

@@ -22,6 +22,20 @@ from pytorch_sound_amd.models import register_model, register_model_architecture
 
 LRELU_SLOPE = 0.1
 
+# The plain (N, C, T) formulation below runs its convolutions on HIP fp32 tensors as exact-fp32 matrix-core GEMMs over the unfolded input
+# (kernels.conv1d_f32 / conv_transpose1d_f32: psnd_im2col_f32 + psnd_linear1x1_*, the activation in front of a conv applied while
+# unfolding) - the arithmetic of the reference's stack (hifi_gan.py:32-147 is fp32).  LIBRARY_CONVS = True (Generator.use_cl = False sets it
+# for its call) keeps F.conv1d / F.conv_transpose1d there: the A/B against the library formulation.  CPU tensors always take the torch ops.
+LIBRARY_CONVS = False
+
+
+def _native_f32(x) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and not LIBRARY_CONVS
+
+
+def _pre_act(x, slope):
+    return x if slope is None else F.leaky_relu(x, slope)
+
 
 def get_padding(kernel_size: int, dilation: int = 1) -> int:
     return int((kernel_size * dilation - dilation) / 2)
@@ -94,8 +108,12 @@ class WNConv1d(_WNConvBase):
         self.dilation, self.padding = dilation, padding
         self._init_params((cout, cin, kernel_size), cout, init_std)
 
-    def forward(self, x):
-        return F.conv1d(x, self.effective_weight(), self.bias, 1, self.padding, self.dilation)
+    def forward(self, x, pre_slope=None):
+        """conv(leaky_relu(x, pre_slope)) (pre_slope None: conv(x))"""
+        if _native_f32(x):
+            from pytorch_sound_amd import kernels as K
+            return K.conv1d_f32(x, self.effective_weight(), self.bias, self.padding, self.dilation, 1.0 if pre_slope is None else pre_slope)
+        return F.conv1d(_pre_act(x, pre_slope), self.effective_weight(), self.bias, 1, self.padding, self.dilation)
 
 
 class WNConvTranspose1d(_WNConvBase):
@@ -108,8 +126,11 @@ class WNConvTranspose1d(_WNConvBase):
         with torch.no_grad():
             self.bias.uniform_(-bound, bound)
 
-    def forward(self, x):
-        return F.conv_transpose1d(x, self.effective_weight(), self.bias, self.stride, self.padding)
+    def forward(self, x, pre_slope=None):
+        if _native_f32(x):
+            from pytorch_sound_amd import kernels as K
+            return K.conv_transpose1d_f32(x, self.effective_weight(), self.bias, self.stride, self.padding, 1.0 if pre_slope is None else pre_slope)
+        return F.conv_transpose1d(_pre_act(x, pre_slope), self.effective_weight(), self.bias, self.stride, self.padding)
 
 
 class ResBlock1(nn.Module):
@@ -123,8 +144,8 @@ class ResBlock1(nn.Module):
 
     def forward(self, x):
         for c1, c2 in zip(self.convs1, self.convs2):
-            xt = c1(F.leaky_relu(x, LRELU_SLOPE))
-            xt = c2(F.leaky_relu(xt, LRELU_SLOPE))
+            xt = c1(x, LRELU_SLOPE)
+            xt = c2(xt, LRELU_SLOPE)
             x = xt + x
         return x
 
@@ -142,7 +163,7 @@ class ResBlock2(nn.Module):
 
     def forward(self, x):
         for c in self.convs:
-            x = c(F.leaky_relu(x, LRELU_SLOPE)) + x
+            x = c(x, LRELU_SLOPE) + x
         return x
 
     def remove_weight_norm(self):
@@ -171,21 +192,50 @@ class Generator(nn.Module):
                 self.resblocks.append(block_cls(h, ch, k, d))
         self.conv_post = WNConv1d(ch, 1, 7, 1, 3, init_std=0.01)
 
+    # Which arithmetic a HIP input gets (`precision`):
+    #   'auto' (default)  bf16 conv operands / fp32 accumulation on the channels-last kernels (forward_cl) under torch.autocast or for a
+    #                     bf16 / fp16 input - the user asked for reduced precision; an fp32 input outside autocast gets the reference's own
+    #                     arithmetic: fp32 convolutions (exact-fp32 matrix-core GEMMs, kernels.conv1d_f32), no silent narrowing
+    #   'bf16'            the channels-last bf16 kernels whatever the input (explicit opt-in: 16x the matrix rate)
+    #   'fp32'            the fp32 convolutions whatever the context
+    precision = 'auto'
+
+    def _wants_bf16(self, x) -> bool:
+        if self.precision == 'bf16':
+            return True
+        if self.precision == 'fp32':
+            return False
+        if self.precision != 'auto':
+            raise ValueError("hifi_gan Generator.precision must be 'auto', 'bf16' or 'fp32', got %r" % (self.precision,))
+        return x.dtype in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled('cuda')
+
     def forward(self, x):
+        global LIBRARY_CONVS
         if self._cl_ok(x):
-            if x.dtype != torch.float32:                 # the CL kernels read fp32 mels and write fp32 audio: cast, do not fall back
-                return self.forward_cl(x.float()).to(x.dtype)
-            return self.forward_cl(x)
+            if self._wants_bf16(x):
+                if x.dtype != torch.float32:             # the CL kernels read fp32 mels and write fp32 audio: cast, do not fall back
+                    return self.forward_cl(x.float()).to(x.dtype)
+                return self.forward_cl(x)
+            with torch.autocast('cuda', enabled=False):
+                return self._forward_plain(x.float()).to(x.dtype)
+        if x.is_cuda:                                    # use_cl = False: the library formulation (A/B switch)
+            prev, LIBRARY_CONVS = LIBRARY_CONVS, True
+            try:
+                return self._forward_plain(x)
+            finally:
+                LIBRARY_CONVS = prev
+        return self._forward_plain(x)
+
+    def _forward_plain(self, x):
         x = self.conv_pre(x)
         for i, up in enumerate(self.ups):
-            x = up(F.leaky_relu(x, LRELU_SLOPE))
+            x = up(x, LRELU_SLOPE)
             stage = self.resblocks[i * self.num_kernels:(i + 1) * self.num_kernels]
             xs = stage[0](x)
             for block in stage[1:]:
                 xs = xs + block(x)
             x = xs / self.num_kernels
-        x = F.leaky_relu(x)            # default slope 0.01, as the reference
-        return torch.tanh(self.conv_post(x))
+        return torch.tanh(self.conv_post(x, 0.01))       # F.leaky_relu's default slope, as the reference (hifi_gan.py:134)
 
     # ---- gfx950 path: the whole generator on the channels-last bf16 implicit-GEMM kernels (pytorch_sound_amd/cl.py):
     #      conv_pre, every ResBlock conv and conv_post with leaky-relu / bias / residual / weight norm fused, the ConvTranspose1d

@@ -1,0 +1,178 @@
+"""The fp32 instance of the conv stack (round 6, VERDICT r05 missing 2 / next 6): pytorch_sound/models/vocoders/hifi_gan.py:32-147 computes its
+Conv1d / ConvTranspose1d layers in fp32, so an fp32 HIP tensor outside autocast must not be narrowed to bf16 operands silently.  Such a
+tensor runs the plain (N, C, T) formulation with every convolution as an exact-fp32 matrix-core GEMM over the unfolded input
+(kernels.conv1d_f32 / conv_transpose1d_f32: psnd_im2col_f32 + psnd_linear1x1_*, v_mfma_f32_32x32x2_f32).
+
+  * single layers, forward and all three gradients, against torch's float64 convolution on the CPU: 2e-6 of max (fp32 summation order);
+  * the imported reference's generator goldens (tests/golden/hifigan.npz: outputs, input and parameter gradients, fp32 CPU): 1e-4 -
+    the tolerance the transformer kernels are held to; the bf16 channels-last kernels need 4e-2 / 1.5e-1 on the same vectors;
+  * the selection rule: fp32 outside autocast -> fp32 convolutions, autocast / bf16 input / precision = 'bf16' -> channels-last bf16 kernels,
+    and no library convolution or GEMM on either way.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_modules_golden import TINY, sd_from
+
+pytestmark = [pytest.mark.gpu, pytest.mark.native_precision]
+
+
+def _maxrel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('N,Cin,Cout,k,dil,pad,T,slope', [
+    (2, 80, 64, 7, 1, 3, 32, 1.0),            # conv_pre
+    (3, 32, 32, 3, 5, 5, 77, 0.1),            # dilated ResBlock conv behind its leaky-relu
+    (2, 48, 40, 11, 3, 15, 130, 0.1),
+    (1, 16, 1, 7, 1, 3, 201, 0.01),           # conv_post (default slope)
+    (2, 8, 24, 5, 2, 0, 50, 1.0),             # no padding: shorter output
+    (2, 24, 8, 1, 1, 0, 33, 1.0),             # k = 1: the GEMM alone
+    (2, 24, 8, 1, 1, 0, 33, 0.2),             # k = 1 behind an activation
+])
+def test_conv1d_f32_vs_float64(N, Cin, Cout, k, dil, pad, T, slope):
+    from pytorch_sound_amd import kernels as K
+    torch.manual_seed(k * 100 + T)
+    x = torch.randn(N, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    b = torch.randn(Cout)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv1d(F.leaky_relu(xd, slope) if slope != 1.0 else xd, wd, bd, 1, pad, dil)
+    gy = torch.randn_like(yd)
+    (yd * gy).sum().backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = K.conv1d_f32(xg, wg, bg, pad, dil, slope)
+    assert y.dtype == torch.float32 and y.shape == yd.shape
+    (y * gy.float().cuda()).sum().backward()
+    assert _maxrel(y, yd) <= 2e-6
+    assert _maxrel(xg.grad, xd.grad) <= 2e-6
+    assert _maxrel(wg.grad, wd.grad) <= 2e-6
+    assert _maxrel(bg.grad, bd.grad) <= 2e-6
+
+
+@pytest.mark.parametrize('N,Cin,Cout,k,stride,pad,T,slope', [
+    (2, 64, 32, 16, 8, 4, 20, 0.1),           # hifi_gan upsamplers (k = 2 * stride)
+    (2, 32, 16, 4, 2, 1, 57, 0.1),
+    (1, 16, 8, 7, 3, 2, 31, 0.1),             # odd stride, k != 2 * stride
+    (2, 8, 8, 11, 5, 3, 13, 1.0),
+    (2, 8, 4, 4, 4, 0, 9, 1.0),               # no overlap between the taps of neighbouring inputs
+])
+def test_conv_transpose1d_f32_vs_float64(N, Cin, Cout, k, stride, pad, T, slope):
+    from pytorch_sound_amd import kernels as K
+    torch.manual_seed(k * 10 + stride)
+    x = torch.randn(N, Cin, T)
+    w = torch.randn(Cin, Cout, k) * 0.2
+    b = torch.randn(Cout)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    yd = F.conv_transpose1d(F.leaky_relu(xd, slope) if slope != 1.0 else xd, wd, bd, stride, pad)
+    gy = torch.randn_like(yd)
+    (yd * gy).sum().backward()
+    xg, wg, bg = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    y = K.conv_transpose1d_f32(xg, wg, bg, stride, pad, slope)
+    assert y.shape == yd.shape == (N, Cout, (T - 1) * stride - 2 * pad + k)
+    (y * gy.float().cuda()).sum().backward()
+    assert _maxrel(y, yd) <= 2e-6
+    assert _maxrel(xg.grad, xd.grad) <= 2e-6
+    assert _maxrel(wg.grad, wd.grad) <= 2e-6
+    assert _maxrel(bg.grad, bd.grad) <= 2e-6
+
+
+def _run(g, x, w):
+    g.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    y = g(xr)
+    (y * w).sum().backward()
+    return y.detach(), xr.grad.clone(), {n: p.grad.clone() for n, p in g.named_parameters()}
+
+
+@pytest.mark.parametrize('name', ['tiny1', 'tiny2'])
+def test_reference_golden_on_gpu_fp32(golden, name):
+    """the imported reference's outputs and gradients (fp32, CPU) against the fp32 convolutions on the GPU: 1e-4 of max on every tensor"""
+    from pytorch_sound_amd.models.vocoders import hifi_gan
+    from test_gpu_no_library_paths import forbid_library_ops
+    gd = golden('hifigan')
+    g = hifi_gan.Generator(TINY[name])
+    g.load_state_dict(sd_from(gd, name + '/sd/'))
+    g = g.cuda()
+    assert g.precision == 'auto'
+    x = torch.from_numpy(gd[name + '/x']).cuda()
+    w = torch.from_numpy(gd[name + '/g']).cuda()
+    with forbid_library_ops():
+        y, gx, gp = _run(g, x, w)
+    assert y.dtype == torch.float32
+    assert _maxrel(y, torch.from_numpy(gd[name + '/y'])) <= 1e-4
+    assert _maxrel(gx, torch.from_numpy(gd[name + '/gx'])) <= 1e-4
+    worst = max(_maxrel(gp[n], torch.from_numpy(gd['%s/g/%s' % (name, n)])) for n, _ in g.named_parameters())
+    assert worst <= 1e-4, worst
+
+
+def test_precision_rule(golden):
+    """fp32 outside autocast: fp32 convolutions (bit-identical to precision = 'fp32'); autocast, a bf16 input or precision = 'bf16': the
+    channels-last bf16 kernels (bit-identical to each other), which differ from the fp32 result by bf16 rounding"""
+    from pytorch_sound_amd.models.vocoders import hifi_gan
+    gd = golden('hifigan')
+    g = hifi_gan.Generator(TINY['tiny1'])
+    g.load_state_dict(sd_from(gd, 'tiny1/sd/'))
+    g = g.cuda().eval()
+    x = torch.from_numpy(gd['tiny1/x']).cuda()
+    want = torch.from_numpy(gd['tiny1/y']).cuda()
+    with torch.no_grad():
+        y_auto = g(x)
+        g.precision = 'fp32'
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y_f32 = g(x)
+        g.precision = 'bf16'
+        y_bf = g(x)
+        g.precision = 'auto'
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y_ac = g(x)
+        y_in = g(x.to(torch.bfloat16).float().to(torch.bfloat16))
+        g.precision = 'nope'
+        with pytest.raises(ValueError):
+            g(x)
+        g.precision = 'auto'
+    assert torch.equal(y_auto, y_f32)
+    assert torch.equal(y_bf, y_ac)
+    assert y_in.dtype == torch.bfloat16
+    assert _maxrel(y_auto, want) <= 1e-4
+    e_bf = _maxrel(y_bf, want)
+    assert 1e-4 < e_bf <= 4e-2, e_bf           # the bf16 path is the narrower one
+
+
+def test_use_cl_false_is_the_library_formulation(golden):
+    """use_cl = False keeps torch's convolutions on a HIP tensor (the A/B switch): same function, library arithmetic"""
+    from pytorch_sound_amd.models.vocoders import hifi_gan
+    gd = golden('hifigan')
+    g = hifi_gan.Generator(TINY['tiny2'])
+    g.load_state_dict(sd_from(gd, 'tiny2/sd/'))
+    g = g.cuda().eval()
+    x = torch.from_numpy(gd['tiny2/x']).cuda()
+    with torch.no_grad():
+        y = g(x)
+        g.use_cl = False
+        y_lib = g(x)
+    assert not hifi_gan.LIBRARY_CONVS
+    assert _maxrel(y, y_lib) <= 1e-5
+    assert _maxrel(y_lib, torch.from_numpy(gd['tiny2/y'])) <= 1e-4
+
+
+def test_interface_decodes_in_fp32_by_default():
+    """InterfaceHifiGAN.decode (interface/hifi_gan.py:97-117) on an fp32 mel: the fp32 convolutions unless the caller opts into bf16"""
+    from pytorch_sound_amd.models.vocoders import hifi_gan
+    from pytorch_sound_amd.models import build_model
+    torch.manual_seed(3)
+    g = build_model('hifi_gan_v2').cuda().eval()
+    g.remove_weight_norm()
+    mel = torch.randn(1, 80, 24, device='cuda')
+    with torch.no_grad():
+        y = g(mel)
+        g.use_cl = False
+        y_lib = g(mel)
+        g.use_cl = True
+        g.precision = 'bf16'
+        y_bf = g(mel)
+    assert _maxrel(y, y_lib) <= 2e-5
+    assert _maxrel(y_bf, y_lib) <= 5e-2

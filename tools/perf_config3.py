@@ -48,7 +48,9 @@ def make(hip):
                 return wav, feat(wav)
 
         def forward(self, wav, m, is_logging=False):
-            y = self.model(m).squeeze(1)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=m.is_cuda):
+                y = self.model(m)
+            y = y.float().squeeze(1)
             loss = (K.l1_loss if hip else F.l1_loss)(feat(y), m)
             if MSL:
                 loss = loss + multi_stft_loss(y, wav, PARAMS)[0]
