@@ -44,9 +44,12 @@ extern "C" {
 
 int psnd_version(void);
 const char *psnd_last_error(void);
-/* the PSND_* A/B switches of the dispatchers are read from the environment once per call site; a process that changes its
- * environment afterwards (parity tests flipping kernel instances) calls this to have them looked up again */
+#ifdef PSND_LAB
+/* LAB builds only (libpsnd_hip_lab.so, `python -m pytorch_sound_amd._build --lab`): the dispatchers read PSND_* A/B switches (kernel-instance
+ * choices, ablations, trace pointers) from the environment once per call site; a process that changes its environment afterwards (parity
+ * tests flipping kernel instances) calls this to have them looked up again.  The product library has no environment switch. */
 void psnd_env_refresh(void);
+#endif
 
 /* ---- stream events: release points inside a captured step graph (data-parallel training) ------------------------
  * psnd_event_record_external on a CAPTURING stream adds an external event-record node (hipEventRecordExternal): after the

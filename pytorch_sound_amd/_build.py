@@ -2,6 +2,10 @@
 
 `python -m pytorch_sound_amd._build` or `__graft_entry__.build()`.  hipcc cross-compiles
 without a GPU.  Objects are cached under csrc/build/ by source mtime.
+
+`--lab` builds libpsnd_hip_lab.so from the same sources with -DPSND_LAB: the PSND_* environment switches of the dispatchers (kernel-instance
+choices, ablations), psnd_env_refresh() - what tools/ and the parity tests of kernel instances load (tests/conftest.py `lab_lib`).  The
+product library has no environment switch.
 """
 import os
 import shutil
@@ -34,11 +38,14 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, hipcc, hdr_mtime, verbose):
-    obj = os.path.join(BUILD, os.path.basename(src)[:-4] + '.o')
+LAB_LIB = os.path.join(HERE, 'libpsnd_hip_lab.so')
+
+
+def _compile(src, hipcc, hdr_mtime, verbose, lab=False):
+    obj = os.path.join(BUILD, os.path.basename(src)[:-4] + ('.lab.o' if lab else '.o'))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_mtime):
         return obj
-    cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+    cmd = [hipcc] + FLAGS + (['-DPSND_LAB'] if lab else []) + ['-c', src, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -47,16 +54,19 @@ def _compile(src, hipcc, hdr_mtime, verbose):
     return obj
 
 
-def build(verbose=True, force=False):
+def build(verbose=True, force=False, lab=False):
+    """lab: the -DPSND_LAB build (libpsnd_hip_lab.so) instead of the product library"""
+    LIB = LAB_LIB if lab else globals()['LIB']
     os.makedirs(BUILD, exist_ok=True)
     hipcc = _hipcc()
     hdr_mtime = _deps_mtime()
     if force:
         for f in os.listdir(BUILD):
-            os.remove(os.path.join(BUILD, f))
+            if f.endswith('.lab.o') == lab:
+                os.remove(os.path.join(BUILD, f))
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, hipcc, hdr_mtime, verbose), srcs))
+        objs = list(ex.map(lambda s: _compile(s, hipcc, hdr_mtime, verbose, lab), srcs))
     if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
@@ -68,4 +78,4 @@ def build(verbose=True, force=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, lab='--lab' in sys.argv))

@@ -24,7 +24,6 @@ _D = _c.c_double
 SIGNATURES = {
     'psnd_version': (_INT, []),
     'psnd_last_error': (_c.c_char_p, []),
-    'psnd_env_refresh': (None, []),
     'psnd_event_create': (_P, []),
     'psnd_event_destroy': (_INT, [_P]),
     'psnd_event_record_external': (_INT, [_P, _P]),
@@ -177,13 +176,58 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise PsndError('libpsnd_hip.so not found at %s - run `python -m pytorch_sound_amd._build` '
                             '(there is no CPU / eager fallback)' % LIB_PATH)
-        h = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(h, name)       # AttributeError if the .so does not export a declared symbol
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path):
+    h = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    for name, (res, args) in LAB_SIGNATURES.items():     # entry points of a -DPSND_LAB build only
+        fn = getattr(h, name, None)
+        if fn is not None:
             fn.restype = res
             fn.argtypes = args
-        _lib = h
-    return _lib
+    return h
+
+
+LAB_LIB_PATH = os.path.join(_HERE, 'libpsnd_hip_lab.so')     # `python -m pytorch_sound_amd._build --lab`
+LAB_SIGNATURES = {'psnd_env_refresh': (None, [])}
+
+
+def is_lab() -> bool:
+    """True when the loaded library is a lab build (reads PSND_* A/B switches from the environment)"""
+    return hasattr(lib(), 'psnd_env_refresh')
+
+
+def refresh_switches():
+    """lab build: have the PSND_* switches looked up again after the environment changed; product build: nothing to refresh"""
+    if _lib is not None and hasattr(_lib, 'psnd_env_refresh'):
+        _lib.psnd_env_refresh()
+
+
+class use_library:
+    """context manager: route every call of this process through another build of the same ABI (the lab library in parity tests of kernel
+    instances, tools/ A/B runs) and back.  Plans and tensors are plain memory: they carry over."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        lib()
+        if not os.path.exists(self.path):
+            raise PsndError('%s not found - run `python -m pytorch_sound_amd._build --lab`' % self.path)
+        self.prev, _lib = _lib, _load(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def check(rc, what):

@@ -25,12 +25,15 @@ void psnd_set_error(const char *fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------------------------------
-// A/B switches (host).  The PSND_* environment switches of the dispatchers (kernel-instance choices for parity tests and same-box
-// A/B timings) are looked up ONCE per call site and kept; a launch costs one atomic load per switch, not a getenv().  A process that
-// changes its environment afterwards calls psnd_env_refresh() (tests/conftest.py does, around monkeypatch.setenv).
+// A/B switches (host) - LAB builds only (-DPSND_LAB: `python -m pytorch_sound_amd._build --lab` -> libpsnd_hip_lab.so, what tools/ and the
+// parity tests of kernel instances load).  In the product build PSND_ENV(...) is a null constant: no getenv, no switch - every dispatcher
+// takes its measured default and the compiler drops the branches.  In a lab build the PSND_* environment switches of the dispatchers
+// (kernel-instance choices for parity tests and same-box A/B timings, ablations, trace pointers) are looked up ONCE per call site and kept; a
+// process that changes its environment afterwards calls psnd_env_refresh() (tests/conftest.py does, around monkeypatch.setenv).
 // ---------------------------------------------------------------------------------------
-#include <atomic>
 #include <stdlib.h>
+#ifdef PSND_LAB
+#include <atomic>
 extern std::atomic<int> g_psnd_env_gen;
 struct PsndEnvSlot {
     std::atomic<int> gen{-1};
@@ -45,6 +48,11 @@ inline const char *psnd_env_lookup(PsndEnvSlot &c, const char *name) {
     return c.val;
 }
 #define PSND_ENV(name_) ([]() -> const char * { static PsndEnvSlot slot_; return psnd_env_lookup(slot_, name_); }())
+#define PSND_ABL(p_, bits_) ((p_).ablate & (bits_))      // ablation bits of a kernel's parameter block (PSND_ABLATE)
+#else
+#define PSND_ENV(name_) (static_cast<const char *>(nullptr))
+#define PSND_ABL(p_, bits_) 0
+#endif
 // integer switch clamped to [lo, hi]; `dflt` when unset or unparsable
 inline int psnd_env_int(const char *v, int dflt, int lo, int hi) {
     if (!v || !*v) return dflt;

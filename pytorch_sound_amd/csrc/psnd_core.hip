@@ -14,8 +14,10 @@ extern "C" int psnd_version(void) { return 134; }  // 0.1.34: + psnd_im2col_f32 
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 
+#ifdef PSND_LAB
 std::atomic<int> g_psnd_env_gen{0};
 extern "C" void psnd_env_refresh(void) { g_psnd_env_gen.fetch_add(1, std::memory_order_acq_rel); }
+#endif
 
 static inline int64_t pad_of(int n_fft, int hop, int framing) {
     if (framing == PSND_FRAMING_NONE) return 0;

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
     // strided XCD-contiguous walk: neighbouring tiles run at the SAME time on neighbouring CUs of one XCD.
     // (a contiguous run per workgroup - neighbours written ~10 us apart by one CU - measured 45 % slower:
     // L2 keeps partially written lines only briefly; PSND_ABLATE=8 selects it for A/B runs)
-    const TileWalk tw = p.ablate & 8 ? tile_run(p.total_tiles) : tile_walk(p.total_tiles);
+    const TileWalk tw = PSND_ABL(p, 8) ? tile_run(p.total_tiles) : tile_walk(p.total_tiles);
     if (tw.first < tw.end) {
         // every global load of the prologue is in flight before the first wait: span first (HBM), then the
         // tables (L2); the first barrier of the tile loop publishes both
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
                 });
             });
         });
-        if (more && (p.ablate & 16)) request_span(tile + tw.step);   // A/B: prefetch a whole tile ahead
+        if (more && (PSND_ABL(p, 16))) request_span(tile + tw.step);   // A/B: prefetch a whole tile ahead
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, NR>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
         write_half(std::integral_constant<int, 0>{});
         __syncthreads();
         read_row(rowA, za);
-        if (more && !(p.ablate & 16)) request_span(tile + tw.step);
+        if (more && !(PSND_ABL(p, 16))) request_span(tile + tw.step);
         __syncthreads();                 // first-half rows consumed: the buffer may take rows 16..31
         PSND_STAMP(4);
         write_half(std::integral_constant<int, HR>{});
@@ -636,9 +636,9 @@ __global__ __launch_bounds__(256, L_ == 32 ? 2 : (PERSIST ? 3 : 4)) void stft_fw
         } else {
         const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
         const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
-        EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(p.ablate & 2));
-        emit.nostore = p.ablate & 4;
-        if (emit.valid && !((p.ablate & 32) && special)) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
+        EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f2) < F) && !(PSND_ABL(p, 2)));
+        emit.nostore = PSND_ABL(p, 4);
+        if (emit.valid && !((PSND_ABL(p, 32)) && special)) post_emit_pk<R1, L>(za, zb, special, qA, qB, s_vk, emit, (int)F, f2 * 4);
         }
 #ifdef PSND_TRACE
         __builtin_amdgcn_sched_barrier(0);
@@ -816,8 +816,8 @@ __global__ __launch_bounds__(512, 1) void stft_fwd_n4096_kernel(StftFwdParams p)
     const long long F = p.F;
     const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
     const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
-    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f) < F) && !(p.ablate & 2));
-    emit.nostore = p.ablate & 4;
+    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + f) < F) && !(PSND_ABL(p, 2)));
+    emit.nostore = PSND_ABL(p, 4);
     if (emit.valid) post_emit_pk<128, 16>(za, zb, special, rA, rB, s_vk, emit, (int)F, f * 4);
     }   // tile loop
 }
@@ -993,8 +993,8 @@ __global__ __launch_bounds__(512, 4) void stft_fwd_n4096b_kernel(StftFwdParams p
     const long long F = p.F;
     const size_t cbase = (size_t)clip * (size_t)(C + 1) * (size_t)F + (size_t)f0;
     const int cbytes = (int)(((long long)(C + 1) * F - f0) * 4);
-    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + fc) < F) && !(p.ablate & 2));
-    emit.nostore = p.ablate & 4;
+    EmitPk<MAG, PHASE, REIM> emit(p.mag, p.phase, p.re, p.im, cbase, cbytes, p.mag_eps, ((f0 + fc) < F) && !(PSND_ABL(p, 2)));
+    emit.nostore = PSND_ABL(p, 4);
     if (emit.valid) {
         const int iF = (int)F;
         const int off_lo = r * iF * 4 + fc * 4, off_hi = (128 - r) * iF * 4 + fc * 4;

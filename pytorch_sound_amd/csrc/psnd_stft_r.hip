@@ -240,7 +240,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096r_kernel(RParams p) {
         if (t == 0) *s_next = 0;
         __syncthreads();                                        // flags reset before anyone publishes
 
-        const bool nostore = p.ablate & 2;
+        const bool nostore = PSND_ABL(p, 2);
         if (w == kWaves - 1) {
             // ---- THE LOADER WAVE: chunks in order, kBatch at a time, two batches in flight; a slot is free once every reader of the chunk 16
             //      back is through.  vmcnt counts this wave's transfers in order (4 instructions per chunk): everything in front of the newest

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
             const float *nx = nullptr;
             const int nkind = tile + tw.step < tw.end ? frame_kind(tile + tw.step, ns0, nx) : 0;
             if (nkind == 1) request_interior(nx, ns0);            // ahead of this frame's stores in the in-order vector-memory queue
-            if (had && !(p.ablate & 2)) {
+            if (had && !(PSND_ABL(p, 2))) {
                 const int ln = fresh_lane();
                 const int lam_ = ln & 31, g_ = ln >> 5;
                 // frame f0 + w of the clip: K contiguous floats (wave-uniform base, range-checked by the descriptor)
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096w_kernel(WParams p) {
         const int nkind = tile + tw.step < tw.end ? frame_kind(tile + tw.step, ns0, nx) : 0;
 
         float *oclip = p.mag + (size_t)clip * kK * (size_t)F + f0;                   // this clip's spectrogram at the tile's first frame (uniform)
-        const bool nostore = p.ablate & 2;
+        const bool nostore = PSND_ABL(p, 2);
         const int iF = (int)F;
         auto flush = [&](int nrows, int row_base) __attribute__((always_inline)) {
             // staging rows [0, nrows) -> bins row_base + r: every store instruction writes 16 rows x 64 bytes.  r = r0 + 16 it + rr:

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from pytorch_sound_amd.models import register_model, register_model_architecture
-from pytorch_sound_amd.models.vocoders.hifi_gan import WNConv1d, ResBlock1, LRELU_SLOPE
+from pytorch_sound_amd.models.vocoders.hifi_gan import WNConv1d, ResBlock1, LRELU_SLOPE, wants_bf16
 
 
 @register_model('conv_separator')
@@ -24,13 +24,23 @@ class ConvSeparator(nn.Module):
         self.blocks = nn.ModuleList([ResBlock1(None, channels, kernel_size, tuple(dilation)) for _ in range(num_blocks)])
         self.conv_post = WNConv1d(channels, spec_size, 3, 1, 1, init_std=0.01)
 
+    # arithmetic of a HIP input, as for the HiFi-GAN generator (hifi_gan.wants_bf16): 'auto' = the channels-last bf16 kernels under
+    # torch.autocast / for a bf16 input, fp32 convolutions (exact-fp32 matrix-core GEMMs, kernels.conv1d_f32) for an fp32 input outside it
+    precision = 'auto'
+
     def forward(self, mag: torch.Tensor) -> torch.Tensor:
-        if mag.is_cuda:
+        if mag.is_cuda and wants_bf16(self.precision, mag):
             return self.forward_cl(mag)
+        if mag.is_cuda:
+            with torch.autocast('cuda', enabled=False):
+                return self._forward_plain(mag.float()).to(mag.dtype)
+        return self._forward_plain(mag)
+
+    def _forward_plain(self, mag):
         x = self.conv_pre(torch.log1p(mag))
         for block in self.blocks:
             x = block(x)
-        mask = torch.sigmoid(self.conv_post(F.leaky_relu(x, LRELU_SLOPE)))
+        mask = torch.sigmoid(self.conv_post(x, LRELU_SLOPE))
         return mask * mag
 
 

@@ -33,6 +33,18 @@ def _native_f32(x) -> bool:
     return x.is_cuda and x.dtype == torch.float32 and not LIBRARY_CONVS
 
 
+def wants_bf16(precision, x) -> bool:
+    """which arithmetic a HIP input of a conv stack gets: 'bf16' / 'fp32' as named; 'auto': bf16 conv operands (fp32 accumulation, the
+    channels-last kernels) under torch.autocast or for a bf16 / fp16 input, the reference's fp32 convolutions for an fp32 input outside it"""
+    if precision == 'bf16':
+        return True
+    if precision == 'fp32':
+        return False
+    if precision != 'auto':
+        raise ValueError("precision must be 'auto', 'bf16' or 'fp32', got %r" % (precision,))
+    return x.dtype in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled('cuda')
+
+
 def _pre_act(x, slope):
     return x if slope is None else F.leaky_relu(x, slope)
 
@@ -201,13 +213,7 @@ class Generator(nn.Module):
     precision = 'auto'
 
     def _wants_bf16(self, x) -> bool:
-        if self.precision == 'bf16':
-            return True
-        if self.precision == 'fp32':
-            return False
-        if self.precision != 'auto':
-            raise ValueError("hifi_gan Generator.precision must be 'auto', 'bf16' or 'fp32', got %r" % (self.precision,))
-        return x.dtype in (torch.bfloat16, torch.float16) or torch.is_autocast_enabled('cuda')
+        return wants_bf16(self.precision, x)
 
     def forward(self, x):
         global LIBRARY_CONVS

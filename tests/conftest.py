@@ -52,13 +52,25 @@ def seeded_wav(seed, N, T, sr=22050):
 
 
 def _refresh_switches():
-    """libpsnd_hip.so looks its PSND_* A/B switches up once per call site (psnd_env_refresh, include/psnd.h): tests that flip them inside one
-    process have them read again.  No-op when the library is not built / loadable."""
+    """A LAB build of the library (libpsnd_hip_lab.so, fixture `lab_lib`) looks its PSND_* A/B switches up once per call site: tests that flip
+    them inside one process have them read again.  The product library has no switches - nothing to refresh."""
     try:
-        from pytorch_sound_amd._lib import lib
-        lib().psnd_env_refresh()
+        from pytorch_sound_amd import _lib
+        _lib.refresh_switches()
     except Exception:      # noqa: BLE001 - CPU-only collection without the library
         pass
+
+
+@pytest.fixture
+def lab_lib():
+    """route the test's calls through the lab build of the library (-DPSND_LAB: the dispatchers' PSND_* switches select kernel instances that
+    the product library only takes at other sizes).  Built by __graft_entry__.build() / `python -m pytorch_sound_amd._build --lab`."""
+    from pytorch_sound_amd import _lib
+    with _lib.use_library(_lib.LAB_LIB_PATH) as h:
+        assert hasattr(h, 'psnd_env_refresh')
+        _lib.refresh_switches()
+        yield h
+        _lib.refresh_switches()
 
 
 @pytest.fixture(autouse=True)
@@ -95,7 +107,8 @@ def _generator_precision(request):
     except Exception:      # noqa: BLE001
         yield
         return
-    old = Generator.precision
-    Generator.precision = 'auto' if request.node.get_closest_marker('native_precision') else 'bf16'
+    from pytorch_sound_amd.models.separator import ConvSeparator
+    old = Generator.precision, ConvSeparator.precision
+    Generator.precision = ConvSeparator.precision = 'auto' if request.node.get_closest_marker('native_precision') else 'bf16'
     yield
-    Generator.precision = old
+    Generator.precision, ConvSeparator.precision = old

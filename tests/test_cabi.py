@@ -13,6 +13,7 @@ from oracle import features as ofe
 def _declared():
     txt = open(os.path.join(ROOT, 'include', 'psnd.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'#ifdef PSND_LAB.*?#endif', '', txt, flags=re.S)         # lab-only entry points (libpsnd_hip_lab.so)
     return sorted(set(re.findall(r'\b(psnd_[a-z0-9_]+)\s*\(', txt)))
 
 
@@ -31,6 +32,7 @@ def test_exports_every_declared_symbol(L):
     for n in names:
         assert hasattr(h, n), 'include/psnd.h declares %s but the library does not export it' % n
     assert sorted(L.SIGNATURES) == names, 'ctypes table and header disagree'
+    assert not hasattr(h, 'psnd_env_refresh'), 'the product library exports the lab build\'s switch refresh'
     assert L.lib().psnd_version() >= 100
 
 

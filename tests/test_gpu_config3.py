@@ -172,7 +172,7 @@ def test_single_output_conv_exact_on_rounded_operands(Cin, Cout, k, dil, L, N, o
 
 @pytest.mark.parametrize('mt', [1, 2])
 @pytest.mark.parametrize('Cin,Cout,k,dil,L,N', SHAPES)
-def test_fused_conv_exact_on_rounded_operands(Cin, Cout, k, dil, L, N, mt, monkeypatch):
+def test_fused_conv_exact_on_rounded_operands(Cin, Cout, k, dil, L, N, mt, monkeypatch, lab_lib):
     """one fused conv, forward + backward, against EXACT (float64) arithmetic on the bf16-rounded operands the kernels see:
     the bf16 outputs to one rounding (2^-8 relative per element; + 4e-4 of max absolute: the kernel's weight-norm scale
     g / ||v|| is summed in another order than torch's, so a handful of the 10^5 weights round to the neighbouring bf16), the

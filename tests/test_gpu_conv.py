@@ -137,7 +137,7 @@ def test_pair_launch_matches_two_launches(channels, N, T, monkeypatch):
 
 
 @pytest.mark.parametrize('N,T,blocks,chain', [(32, 173, 4, 3), (4, 173, 2, 3), (3, 50, 1, 2), (5, 97, 2, 4), (1, 20, 1, 3), (6, 120, 2, -2)])
-def test_chain_launch_is_bit_identical_to_pair_launches(N, T, blocks, chain, monkeypatch):
+def test_chain_launch_is_bit_identical_to_pair_launches(N, T, blocks, chain, monkeypatch, lab_lib):
     """psnd_conv1d_cl_chain (the pairs of a ResBlock1 in ONE launch, a workgroup carrying its 64-row tile through all of them on the chip
     and owning the rows that stay valid) against the same forward as one psnd_conv1d_cl_pair launch per pair: the arithmetic, its order
     and the rounding points are the same, so the output and EVERY tensor saved for the backward - hence every gradient - are bit-identical.

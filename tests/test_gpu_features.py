@@ -106,7 +106,7 @@ N4096W_CASES = [
 
 
 @pytest.mark.parametrize('n_fft,hop,win,framing,N,T', N4096W_CASES)
-def test_stft_4096_wave_kernel_vs_oracle(n_fft, hop, win, framing, N, T, monkeypatch):
+def test_stft_4096_wave_kernel_vs_oracle(n_fft, hop, win, framing, N, T, monkeypatch, lab_lib):
     monkeypatch.setenv('PSND_STFT4096_W', '1')
     wav = seeded_wav(n_fft + hop + T, N, T)
     got = _stft(wav, n_fft, hop, win, framing, want_mag=True)['mag']
@@ -122,7 +122,7 @@ def test_stft_4096_wave_kernel_vs_oracle(n_fft, hop, win, framing, N, T, monkeyp
     assert np.abs(got - old).max() <= 2 * FFT_RTOL * np.abs(ref).max()
 
 
-def test_stft_4096_wave_kernel_full_size(monkeypatch):
+def test_stft_4096_wave_kernel_full_size(monkeypatch, lab_lib):
     """config 5 at the size where the dispatcher picks the wave-per-frame kernel by itself (32 clips x 30 s: 2592 tiles): equal to the
     4-frame kernel on the same input, Parseval per frame, every element written (NaN-filled output)."""
     K = _k()
@@ -203,7 +203,7 @@ def test_frame_indexing_bit_exact():
 
 
 @pytest.mark.parametrize('variant', ['wave', 'tile4', 'reim'])
-def test_frame_indexing_bit_exact_n4096(variant, monkeypatch):
+def test_frame_indexing_bit_exact_n4096(variant, monkeypatch, lab_lib):
     """the same impulse contract at n_fft = 4096 on BOTH magnitude-only kernels of config 5 (`stft_fwd_n4096w_kernel` with its
     hand-resolved reflect loads, forced at this size, and `stft_fwd_n4096b_kernel`) and on the (re, im) instance: |DC| of frame f is
     the number of taps of frame f that read sample p - small integers, exact in fp32 (transforms.py:55-66)."""
@@ -231,7 +231,7 @@ def test_frame_indexing_bit_exact_n4096(variant, monkeypatch):
                 assert np.array_equal(got[i, 0, :], count), (variant, hop, T, framing, p)
 
 
-def test_config5_one_clip_vs_oracle(monkeypatch):
+def test_config5_one_clip_vs_oracle(monkeypatch, lab_lib):
     """one 30-s clip of config 5 (44.1 kHz, 4096 / 1024) against ofe.stft_mag_f64 on both 4096 magnitude kernels."""
     wav = seeded_wav(55, 1, 1323000, 44100)
     ref = ofe.stft_mag_f64(wav, 4096, 1024)

@@ -176,3 +176,32 @@ def test_interface_decodes_in_fp32_by_default():
         y_bf = g(mel)
     assert _maxrel(y, y_lib) <= 2e-5
     assert _maxrel(y_bf, y_lib) <= 5e-2
+
+
+def test_separator_fp32_outside_autocast():
+    """conv_separator (BASELINE configs[1] model) on an fp32 HIP tensor outside autocast: fp32 convolutions, equal to the float64 torch
+    formulation on the CPU to 1e-5 - output and every parameter gradient; under autocast the channels-last bf16 kernels"""
+    import copy
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models import separator  # noqa: F401
+    from test_gpu_no_library_paths import forbid_library_ops
+    torch.manual_seed(5)
+    m = build_model('conv_separator_voicebank', {'channels': 64, 'num_blocks': 2})
+    mag = torch.rand(2, 513, 40) * 3
+    md = copy.deepcopy(m).double()
+    yd = md(mag.double())
+    w = torch.randn_like(yd)
+    (yd * w).sum().backward()
+    mg = m.cuda()
+    with forbid_library_ops():
+        y = mg(mag.cuda())
+        (y * w.float().cuda()).sum().backward()
+    assert y.dtype == torch.float32
+    assert _maxrel(y, yd) <= 1e-5
+    gd = dict(md.named_parameters())
+    worst = max(_maxrel(p.grad, gd[n].grad) for n, p in mg.named_parameters())
+    assert worst <= 2e-5, worst
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        yb = mg(mag.cuda()).float()
+    e = _maxrel(yb, yd)
+    assert 1e-5 < e <= 5e-2, e

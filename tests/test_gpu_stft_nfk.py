@@ -128,7 +128,7 @@ RING_SHAPES = [
 
 
 @pytest.mark.parametrize('N,T,framing', RING_SHAPES)
-def test_ring_kernel_is_bit_identical_to_the_register_load_kernel(N, T, framing, monkeypatch):
+def test_ring_kernel_is_bit_identical_to_the_register_load_kernel(N, T, framing, monkeypatch, lab_lib):
     """stft_fwd_n4096r_kernel (samples through the workgroup's LDS ring) and stft_fwd_n4096w_kernel<NFK> (every wave loads its frame) run the
     same arithmetic on the same values: equal bit for bit - and the latter is pinned to the oracle / goldens / impulse contract above."""
     from pytorch_sound_amd import kernels as K

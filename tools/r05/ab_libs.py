@@ -36,7 +36,7 @@ for sp in specs:
     if path != 'default':
         h.psnd_stft_mag_nfk.restype = INT; h.psnd_stft_mag_nfk.argtypes = [P, I64, I64, INT, INT, INT, P, FL, P, P]
         h.psnd_stft_fwd.restype = INT; h.psnd_stft_fwd.argtypes = [P, I64, I64, INT, INT, INT, P, FL, P, P, P, P, P]
-        h.psnd_env_refresh.restype = None
+        if hasattr(h, 'psnd_env_refresh'): h.psnd_env_refresh.restype = None
     env = dict(e.split('=') for e in envs.split(',') if e)
     variants.append((name, h, env))
 st = _lib.stream_ptr(dev)
@@ -45,7 +45,7 @@ ALLENV = sorted({k for _, _, e in variants for k in e})
 def launch(h, env):
     for k in ALLENV: os.environ.pop(k, None)
     os.environ.update(env)
-    h.psnd_env_refresh()
+    getattr(h, 'psnd_env_refresh', lambda: None)()
     if nkf: rc = h.psnd_stft_fwd(_lib.ptr(x), N, T, n_fft, hop, 0, _lib.ptr(plan), 0.0, _lib.ptr(o), None, None, None, st)
     else: rc = h.psnd_stft_mag_nfk(_lib.ptr(x), N, T, n_fft, hop, 0, _lib.ptr(plan), 0.0, _lib.ptr(o), st)
     assert rc == 0, rc

@@ -14,13 +14,13 @@ plan = K.stft_plan(4096, w).to(dev)
 
 
 def both(x, framing=0):
-    os.environ.pop('PSND_STFT4096_NORING', None); _lib.lib().psnd_env_refresh()
+    os.environ.pop('PSND_STFT4096_NORING', None); _lib.refresh_switches()
     a = K.stft_mag_nfk(x, 4096, 1024, plan, framing)
     torch.cuda.synchronize()
-    os.environ['PSND_STFT4096_NORING'] = '1'; _lib.lib().psnd_env_refresh()
+    os.environ['PSND_STFT4096_NORING'] = '1'; _lib.refresh_switches()
     b = K.stft_mag_nfk(x, 4096, 1024, plan, framing)
     torch.cuda.synchronize()
-    os.environ.pop('PSND_STFT4096_NORING', None); _lib.lib().psnd_env_refresh()
+    os.environ.pop('PSND_STFT4096_NORING', None); _lib.refresh_switches()
     return a, b
 
 
@@ -51,7 +51,7 @@ for N in (32, 16, 64):
     for name, env in (('ring', None), ('regs', '1'), ('ring', None), ('regs', '1')):
         if env: os.environ['PSND_STFT4096_NORING'] = env
         else: os.environ.pop('PSND_STFT4096_NORING', None)
-        _lib.lib().psnd_env_refresh()
+        _lib.refresh_switches()
         ts = timeit(lambda: K.stft_mag_nfk(x, 4096, 1024, plan, out=o))
         print('N %d %s: mean %.1f us min %.1f us -> %.3f of 8 TB/s (mean)' % (N, name, ts.mean(), ts.min(), nbytes / ts.mean() / 1e-6 / 8e12), flush=True)
 os.environ.pop('PSND_STFT4096_NORING', None)

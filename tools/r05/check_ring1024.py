@@ -7,11 +7,11 @@ from pytorch_sound_amd.models.transforms import periodic_window
 dev = torch.device('cuda:0')
 plan = K.stft_plan(1024, periodic_window('hann', 1024).astype(np.float32)).to(dev)
 def both(x, framing=0):
-    os.environ.pop('PSND_STFT1024_NORING', None); _lib.lib().psnd_env_refresh()
+    os.environ.pop('PSND_STFT1024_NORING', None); _lib.refresh_switches()
     a = K.stft_mag_nfk(x, 1024, 256, plan, framing); torch.cuda.synchronize()
-    os.environ['PSND_STFT1024_NORING'] = '1'; _lib.lib().psnd_env_refresh()
+    os.environ['PSND_STFT1024_NORING'] = '1'; _lib.refresh_switches()
     b = K.stft_mag_nfk(x, 1024, 256, plan, framing); torch.cuda.synchronize()
-    os.environ.pop('PSND_STFT1024_NORING', None); _lib.lib().psnd_env_refresh()
+    os.environ.pop('PSND_STFT1024_NORING', None); _lib.refresh_switches()
     return a, b
 for (N, T, framing) in [(1, 1024, 0), (1, 2052, 0), (4, 44100, 0), (3, 8192, 1), (37, 10000, 0), (1, 516, 0), (64, 44100, 0), (300, 3000, 0), (1024, 44100, 0), (2, 1323000, 0)]:
     x = 0.07 * torch.randn(N, T, device=dev)
