@@ -13,6 +13,7 @@ gradient), split-K weight gradient with all taps / bias gradient fused, weight-n
 """
 import ctypes
 import os
+from pytorch_sound_amd import _switches as _sw
 import weakref
 
 import torch
@@ -471,7 +472,7 @@ def _sections(dev, N, rows):
     while the weight-gradient role was a 40 k-cycle chain per launch; with the transposing-read weight gradient (26 k cycles) one and
     two sections measure the same (1.014 / 1.017 ms), so the simpler graph is the default."""
     import os
-    e = os.environ.get('PSND_CL_SECTIONS', 'auto')
+    e = _sw.lab('PSND_CL_SECTIONS', 'auto')
     n = 1 if e == 'auto' else int(e)
     if n <= 1 or N % n != 0 or N // n < 1 or (e == 'auto' and not AUTO_SECTIONS):
         return 1, []
@@ -498,7 +499,7 @@ def _run_sections(dev, nsec, sides, fn):
 
 
 # the parameter-side launches of a transposed conv's backward on a side stream / graph branch (ConvTransposeCL.backward)
-BRANCH_PARAM_GRADS = os.environ.get('PSND_BRANCH_PARAM_GRADS', '1') == '1'
+BRANCH_PARAM_GRADS = _sw.lab('PSND_BRANCH_PARAM_GRADS', '1') == '1'
 _BRANCH_STREAMS = {}
 _PARAM_STREAM = {}
 
@@ -531,9 +532,9 @@ def _wgrad_streams(dev):
     on one stream - the branches overlap for only a fifth of their time (tools/overlap.py) and every kernel runs slower next to
     another one (wgrad 20 -> 26 us, the masked pair launch 22 us): kept as an A/B switch and for the parity tests."""
     import os
-    if os.environ.get('PSND_CL_BWD_SPLIT', '0') != '1' or not _pair_enabled() or not AUTO_SECTIONS:
+    if _sw.lab('PSND_CL_BWD_SPLIT', '0') != '1' or not _pair_enabled() or not AUTO_SECTIONS:
         return []
-    n = int(os.environ.get('PSND_CL_WGRAD_STREAMS', '3'))
+    n = int(_sw.lab('PSND_CL_WGRAD_STREAMS', '3'))
     pool = _WGRAD_STREAMS.setdefault(dev.index, [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
@@ -542,14 +543,14 @@ def _wgrad_streams(dev):
 
 def _pair_enabled():
     import os
-    return os.environ.get('PSND_CL_PAIR', '1') != '0'
+    return _sw.lab('PSND_CL_PAIR', '1') != '0'
 
 
 def _chain_pairs_bwd(plan, rows):
     """the same for the input-gradient launches ('pairb') of the batched backward: consecutive pairs, each reading the gradient the one
     before wrote, as one masked psnd_conv1d_cl_chain launch"""
     import os
-    mx = int(os.environ.get('PSND_CL_CHAIN_BWD', os.environ.get('PSND_CL_CHAIN', '3')))
+    mx = int(_sw.lab('PSND_CL_CHAIN_BWD', _sw.lab('PSND_CL_CHAIN', '3')))
     if mx < 2 or rows > 8192:
         return plan
     out = []
@@ -572,7 +573,7 @@ def _chain_pairs(plan, rows):
     to PSND_CL_CHAIN pairs - default 3, a ResBlock1 - on the chip; 0 switches it off).  Only where a launch is a latency chain of few
     workgroups (<= 8192 rows: the config-2 size); a pair joins the chain in front of it when it reads that chain's outputs."""
     import os
-    mx = int(os.environ.get('PSND_CL_CHAIN', '3'))
+    mx = int(_sw.lab('PSND_CL_CHAIN', '3'))
     if mx < 2 or rows > 8192:
         return plan
     out = []
@@ -944,7 +945,7 @@ def prep_all(owner, convs, defer_backward_packs=False):
     later (input-gradient chains 38 -> 47 us each) - the per-channel kernel's 2-byte stores did not show that, at 35 us per launch."""
     import struct
     import os
-    if os.environ.get('PSND_NO_PREP_ALL') == '1':      # A/B switch: one prep launch per conv
+    if _sw.lab('PSND_NO_PREP_ALL') == '1':      # A/B switch: one prep launch per conv
         return None
     # psnd_conv1d_prep_multi stages 8 rows of Cin * k bf16 values in LDS: wider rows (e.g. 1024 channels x 11 taps) take the per-conv prep
     # launch (fused_conv / ResBlockCL with prep = None) instead of failing with PSND_E_SHAPE (ADVICE r04)
@@ -975,7 +976,7 @@ def prep_all(owner, convs, defer_backward_packs=False):
     for c in convs:
         if not (c.weight_v.is_contiguous() and c.weight_g.is_contiguous() and c.weight_v.dtype == torch.float32):
             raise _lib.PsndError('prep_all: fp32 contiguous weight_v / weight_g expected')
-    defer = bool(defer_backward_packs) and torch.is_grad_enabled() and os.environ.get('PSND_PREP_NO_DEFER') != '1'
+    defer = bool(defer_backward_packs) and torch.is_grad_enabled() and _sw.lab('PSND_PREP_NO_DEFER') != '1'
     with torch.cuda.device(cache['dev']):
         check(lib().psnd_conv1d_prep_multi(ptr(cache['table']), cache['n'], cache['blocks'], cache['max_row'], 1 if defer else 3,
                                            stream_ptr(cache['dev'])), 'psnd_conv1d_prep_multi')
@@ -1132,12 +1133,12 @@ class ResBlockCL(torch.autograd.Function):
         skip = -1                              # conv already handled as the first conv of a fused input-gradient pair
         # batched backward (default; PSND_CL_BWD_BATCH=0: one psnd_conv1d_cl_pair_bwd launch per pair): the input-gradient chain runs alone (one psnd_conv1d_cl_pair launch per residual pair,
         # masks and mirrored taps), the weight gradients of all its convs follow in ONE launch (psnd_conv1d_cl_wgrad_multi)
-        batch = (nsec == 1 and not wstreams and _pair_enabled() and os.environ.get('PSND_CL_BWD_BATCH', '1') == '1'
+        batch = (nsec == 1 and not wstreams and _pair_enabled() and _sw.lab('PSND_CL_BWD_BATCH', '1') == '1'
                  and shape.N * shape.Lp <= 8192)
         wbatch = []
         own_launch = []                        # (plan entry, conv): convs whose weight-gradient slabs are written by that entry itself
         flush_after = {}                       # id(input-gradient tensor a pair launch writes) -> len(wbatch) once that launch has run
-        pair_bwd = (nsec == 1 and not wstreams and not batch and _pair_enabled() and os.environ.get('PSND_CL_PAIR_BWD', '1') != '0'
+        pair_bwd = (nsec == 1 and not wstreams and not batch and _pair_enabled() and _sw.lab('PSND_CL_PAIR_BWD', '1') != '0'
                     and shape.N * shape.Lp <= 8192)
         lag = None                             # weight gradient of a pair's first conv, carried to the next pair launch
         with torch.cuda.device(dev):
@@ -1233,7 +1234,7 @@ class ResBlockCL(torch.autograd.Function):
                 g_here = g_out if need_gout else G1          # this conv's combined gradient (= what its residual input receives)
                 # convs outside the residual pairs (a model's head / tail) keep their own launches: with them the one weight-gradient launch
                 # grows by as much as their launches took (PSND_CL_BWD_BATCH_ENDS=1: 81 -> 122 us against 23 + 7 us saved at config 2)
-                wb_ok = batch and G2 is None and not need_gout and os.environ.get('PSND_CL_BWD_BATCH_ENDS', '0') == '1'
+                wb_ok = batch and G2 is None and not need_gout and _sw.lab('PSND_CL_BWD_BATCH_ENDS', '0') == '1'
                 if i == 0 and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
                     # the chain's input needs no gradient (features): weight gradient only
                     gx = None
@@ -1462,7 +1463,7 @@ class _PackList(list):
 
 def _use_block_node(convs, x):
     import os
-    return (os.environ.get('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 64
+    return (_sw.lab('PSND_NO_BLOCK_NODE') != '1' and x is not None and len(convs) <= 64
             and all(c.weight_v.shape[0] == c.weight_v.shape[1] for c in convs))
 
 
@@ -1471,7 +1472,7 @@ def conv_body_cl(head, blocks, tail, x0, shape, prep=None):
     x0: activated CL input of the head conv.  Returns the tail conv's raw output."""
     import os
     stack = [c for b in blocks for pair in zip(b.convs1, b.convs2) for c in pair]
-    if (os.environ.get('PSND_NO_BODY_NODE') == '1' or os.environ.get('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled()
+    if (_sw.lab('PSND_NO_BODY_NODE') == '1' or _sw.lab('PSND_NO_BLOCK_NODE') == '1' or not _stack_enabled()
             or NODE_GRANULARITY == 'block'):
         if isinstance(prep, PrepPacks):
             prep.write_backward_packs()                    # per-conv nodes keep their backward pack from the forward
@@ -1511,7 +1512,7 @@ def resblock1_stack_cl(blocks, x, xa, shape, last_act_slope=0.1, want_raw=True, 
 
 def _stack_enabled():
     import os
-    return os.environ.get('PSND_NO_BLOCK_STACK') != '1' and NODE_GRANULARITY != 'block'       # one node per block instead
+    return _sw.lab('PSND_NO_BLOCK_STACK') != '1' and NODE_GRANULARITY != 'block'       # one node per block instead
 
 
 def resblock2_cl(block, x, xa, shape, last_act_slope=0.1, want_raw=True, prep=None):

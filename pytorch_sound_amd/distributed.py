@@ -18,6 +18,7 @@ so that all but the last sixth of the reduction can run under the backward.
 """
 import collections
 import os
+from pytorch_sound_amd import _switches as _sw
 from typing import List
 
 import torch
@@ -382,7 +383,7 @@ class FlatGradReducer:
         from ._lib import lib
         nccl = dist.get_backend() == 'nccl'
         default = 'capture' if nccl else 'deferred'
-        mode = os.environ.get('PSND_DDP_GRAPH', default)
+        mode = _sw.lab('PSND_DDP_GRAPH', default)
         if mode not in ('events', 'capture', 'deferred'):
             raise ValueError('PSND_DDP_GRAPH=%s (events | capture | deferred)' % mode)
         if mode == 'events' and not lib().psnd_event_external_supported():
@@ -425,7 +426,7 @@ class FlatGradReducer:
         if not b['flat'].is_cuda:
             import contextlib
             return contextlib.nullcontext()
-        if os.environ.get('PSND_DDP_RELEASE', 'stream') != 'stream':
+        if _sw.lab('PSND_DDP_RELEASE', 'stream') != 'stream':
             self._join_streams(b)
             return torch.cuda.current_stream(dev)
         if self._release is None:

@@ -6,6 +6,7 @@ or a missing library raises.
 """
 import math
 import os
+from pytorch_sound_amd import _switches as _sw
 import numpy as np
 import torch
 
@@ -425,7 +426,7 @@ def istft(magnitude, phase, n_fft, hop, plan, eps=1e-9, window=None):
 # ---------------------------------------------------------------------------------------------
 # transformer blocks (models/modules.py): GroupNorm(1, C)(x + res) and the masked softmax over keys
 # ---------------------------------------------------------------------------------------------
-RESIDUAL_LINKS = os.environ.get('PSND_RESIDUAL_LINKS', '1') == '1'      # 0: autograd accumulates the two gradients of a block's input (A/B)
+RESIDUAL_LINKS = _sw.lab('PSND_RESIDUAL_LINKS', '1') == '1'      # 0: autograd accumulates the two gradients of a block's input (A/B)
 
 
 class ResidualLink:
@@ -689,7 +690,7 @@ class PosEnc(torch.autograd.Function):
 
 # measured, off: the two attention gradient kernels on two streams - config-4 block 2.24 -> 2.36 ms (both kernels fill the chip at 2-3 waves
 # per SIMD: next to each other each runs slower than the overlap returns; tools/r04/ab_c4.sh)
-ATTN_BWD_TWO_STREAMS = os.environ.get('PSND_ATTN_BWD_TWO_STREAMS', '0') == '1'
+ATTN_BWD_TWO_STREAMS = _sw.lab('PSND_ATTN_BWD_TWO_STREAMS', '0') == '1'
 
 
 class AttentionKVQ(torch.autograd.Function):
@@ -783,7 +784,7 @@ class PreEmphasisFn(torch.autograd.Function):
 def _msl_fused(n_fft, hop):
     """psnd_stft_bwd_msl takes this resolution (PSND_MSL_FUSED=0: the two-launch path, for A/B runs and tests)."""
     import os
-    return os.environ.get('PSND_MSL_FUSED', '1') != '0' and bool(lib().psnd_stft_bwd_msl_supported(int(n_fft), int(hop)))
+    return _sw.lab('PSND_MSL_FUSED', '1') != '0' and bool(lib().psnd_stft_bwd_msl_supported(int(n_fft), int(hop)))
 
 
 class MultiStftLossFn(torch.autograd.Function):

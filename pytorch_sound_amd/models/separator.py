@@ -93,6 +93,11 @@ class ConvSeparator(nn.Module):
         x0 = cl.ToCL.apply(mag.float(), shape, 1)                                  # log1p(mag), CL bf16
         y = cl.conv_body_cl(self.conv_pre, list(self.blocks), self.conv_post, x0, shape, prep)     # 26 convs: one autograd node
         if mag.dtype == torch.float32 and not mag.requires_grad:
+            from pytorch_sound_amd import deferred
+            if deferred.ENABLED:
+                # the estimate as a deferred tensor: torch ops of the reference's loss recipe on it (matmul with a LogMelSpectrogram's
+                # mel_filter, log, clamp, F.l1_loss) are recorded and resolve to the fused loss node; any other use forms it first
+                return deferred.est(y, mag.contiguous(), shape)
             return cl.MaskHeadCL.apply(y, mag, shape)                               # sigmoid(from_cl(y)) * mag, one pass
         logits = cl.FromCL.apply(y, C, T, shape)
         return torch.sigmoid(logits) * mag

@@ -178,6 +178,8 @@ class LogMelSpectrogram(nn.Module):
         self.stft = STFT(filter_length=win_length, hop_length=hop_length)
         self.register_buffer('mel_filter', torch.from_numpy(
             mel_filterbank(sample_rate, n_fft, mel_size, fmin=mel_min, fmax=mel_max)))
+        from pytorch_sound_amd import deferred
+        deferred.MEL_MODULES.add(self)        # matmul(self.mel_filter, <deferred estimate>) is recognised (deferred.py)
         self.min_db = np.log(np.power(10, min_db / 10)) if min_db else None
         self.max_db = np.log(np.power(10, max_db / 10)) if max_db else None
         self._plans = _PlanCache()

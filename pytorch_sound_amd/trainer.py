@@ -16,6 +16,7 @@ import abc
 import enum
 import glob
 import os
+from pytorch_sound_amd import _switches as _sw
 from collections import defaultdict
 from typing import Any, Dict, Tuple
 
@@ -206,6 +207,20 @@ class Trainer:
     def forward(self, *inputs, is_logging: bool = False) -> Tuple[torch.Tensor, Dict]:
         """override: returns (loss tensor, {name: (value, LogType)})"""
         raise NotImplementedError
+
+    def _forward_resolved(self, *inputs, is_logging: bool = False):
+        """self.forward(...) with deferred tensors resolved (deferred.py: a loss written with torch ops on a model's deferred estimate becomes
+        the fused loss node here; anything else in `meta` the plain tensor it stands for)"""
+        from pytorch_sound_amd.deferred import Deferred, resolve
+        loss, meta = self.forward(*inputs, is_logging=is_logging)
+        if isinstance(loss, Deferred):
+            real = resolve(loss)
+            if meta:
+                meta = {k: ((real if v[0] is loss else resolve(v[0])), *v[1:]) if isinstance(v, tuple) and v else v for k, v in meta.items()}
+            loss = real
+        elif meta and any(isinstance(v, tuple) and v and isinstance(v[0], Deferred) for v in meta.values()):
+            meta = {k: (resolve(v[0]), *v[1:]) if isinstance(v, tuple) and v else v for k, v in meta.items()}
+        return loss, meta
 
     def prepare(self, *inputs):
         """Optional override (not in the reference): parameter-free preprocessing of a batch (feature extraction)
@@ -539,14 +554,14 @@ class Trainer:
         # (the engine calls the post-accumulate hooks of its AccumulateGrad node although the node returned None for it; counted twice,
         # buckets left before their last gradients - zeros next to branches, an all-reduce ahead of its data on several ranks).
         # PSND_DDP_BRANCHES=0: round 4's behaviour (no branches next to a reducer) for A/B runs.
-        red_blocks = red is not None and red.active and os.environ.get('PSND_DDP_BRANCHES', '1') != '1'
+        red_blocks = red is not None and red.active and _sw.lab('PSND_DDP_BRANCHES', '1') != '1'
         # Round 5: next to `prefetch_copy` (a COPY-only side stream, picked by _independent_stream so that it runs next to the compute
         # stream) the branches stay on: config 3 with pinned host batches 2.86-2.93 ms with them, 3.55-3.65 without, 2.91 with the pool
         # on the device - six fresh processes each for configs 3 and 4, no slow step among them (tools/r05/prefetch_branches.py;
         # PSND_PREFETCH_BRANCHES=0 switches them off).  `prefetch_prepare` runs KERNELS on its side stream (prepare() of the next batch):
         # that stream competes with the branches for the hardware queues, as measured in round 3 with batch sections - branches off.
         pre_copy_only = (bool(self.prefetch_copy) or getattr(self, '_pre_stream', None) is not None) and not bool(self.prefetch_prepare)
-        pre_blocks = bool(self.prefetch_prepare) or (pre_copy_only and os.environ.get('PSND_PREFETCH_BRANCHES', '1') != '1')
+        pre_blocks = bool(self.prefetch_prepare) or (pre_copy_only and _sw.lab('PSND_PREFETCH_BRANCHES', '1') != '1')
         cl.AUTO_SECTIONS = not (red_blocks or pre_blocks)
         params = [p for p in self._bare_model.parameters() if p.requires_grad]
         if getattr(self, '_root_grad', None) is None or self._root_grad.device != st['inputs'][0].device:
@@ -561,7 +576,7 @@ class Trainer:
                 # thread_local: the process group's watchdog thread keeps querying events of earlier collectives while this
                 # thread captures ("operation not permitted when stream is capturing" under the default global mode)
                 with torch.cuda.graph(graph, capture_error_mode='thread_local' if red is not None else 'global'):
-                    loss, _ = self.forward(*st['inputs'], is_logging=False)
+                    loss, _ = self._forward_resolved(*st['inputs'], is_logging=False)
                     st['flag'] = self._nan_flag(loss)
                     if mode in ('events', 'capture'):
                         red.capture_begin(st['flag'], mode)   # the captured backward fills and releases the buckets itself
@@ -668,7 +683,25 @@ class Trainer:
             self._nan_pending.append((step, host_flag, event))
         self._poll_nan_log()
 
+    # Python's cyclic collector walks every tracked object of the process in a full (generation-2) pass: with torch, numpy and a model
+    # imported that is ~10^6 objects and tens of milliseconds during which no kernel is launched - the 50-120 ms steps of an eager loop
+    # (tools/r06/stall.py: every slow step coincides with a gen-2 pass).  After the first steps - modules, plans, graph and autograd closures built -
+    # everything alive is moved to the permanent generation once (gc.freeze): later passes only look at what the loop itself allocates.
+    gc_freeze = True
+    _gc_frozen = False
+    _gc_freeze_after = 4
+
+    def _maybe_freeze_gc(self):
+        if self.gc_freeze and not Trainer._gc_frozen:
+            self._steps_seen = getattr(self, '_steps_seen', 0) + 1
+            if self._steps_seen > self._gc_freeze_after:
+                import gc
+                gc.collect()
+                gc.freeze()
+                Trainer._gc_frozen = True
+
     def train(self, step: int):
+        self._maybe_freeze_gc()
         log_flag = step % self.log_interval == 0
         batch = self._take_train_batch()
         if self.graph_steps and not log_flag and self._train_graph(step, batch):
@@ -677,7 +710,7 @@ class Trainer:
             self._reducer.zero_grad()
         else:
             self.optimizer.zero_grad()
-        loss, meta = self.forward(*batch, is_logging=log_flag)
+        loss, meta = self._forward_resolved(*batch, is_logging=log_flag)
 
         if self._can_skip_on_device(loss):
             self._train_device_skip(step, loss)
@@ -714,7 +747,7 @@ class Trainer:
         stat = defaultdict(float)
         for i in range(self.valid_max_step):
             with torch.no_grad():
-                batch_loss, meta = self.forward(*self.prepare(*self._next_batch(self.valid_dataset)), is_logging=True)
+                batch_loss, meta = self._forward_resolved(*self.prepare(*self._next_batch(self.valid_dataset)), is_logging=True)
                 loss += batch_loss
             for key, (value, log_type) in meta.items():
                 if log_type == LogType.SCALAR:

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# the host side reads its A/B switches (PSND_CL_*, PSND_NO_*, PSND_DDP_GRAPH ...: pytorch_sound_amd/_switches.py) only in a lab environment; the
+# tests flip them (monkeypatch.setenv / os.environ, child processes inherit) - unflipped, every switch has its product default
+os.environ.setdefault('PSND_LAB', '1')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -1,4 +1,5 @@
 #!/bin/sh
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 # build a variant of libpsnd_hip.so with extra compiler flags: tools/build_variant.sh <name> <flags...>
 # -> tools/mb/variants/libpsnd_<name>.so  (select it with PSND_LIB=...)
 set -e

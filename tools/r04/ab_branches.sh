@@ -1,4 +1,5 @@
 # A/B: hifi_gan_v1 config-3 step: a stage's resblocks on parallel streams (PSND_HIFIGAN_BRANCHES), the parameter-side backward launches on a side stream (PSND_BRANCH_PARAM_GRADS)
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 for v in "1 1" "1 0" "1 1" "1 0"; do
   set -- $v
   PSND_HIFIGAN_BRANCHES=$1 PSND_BRANCH_PARAM_GRADS=$2 python tools/r04/run_leg.py config3 2>&1 | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/config3 branches=$1 param_side=$2 /"

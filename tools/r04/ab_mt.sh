@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 R=$GRAFT_REPO_ROOT
 for v in base mt2; do
   if [ $v = mt2 ]; then export PSND_CONV_MT=2; fi

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 for v in 0 1; do
   rm -rf /tmp/prof
   export PSND_PREP_NO_DEFER=$v

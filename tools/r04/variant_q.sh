@@ -1,4 +1,5 @@
 #!/bin/sh
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 # A/B builds of ONE source file: tools/r04/variant_q.sh <name> <file.hip> <flags...> -> tools/mb/variants/libpsnd_<name>.so (PSND_LIB=...)
 # (the other objects are the ones of the regular build, pytorch_sound_amd/csrc/build)
 set -e

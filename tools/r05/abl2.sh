@@ -1,4 +1,5 @@
 V=tools/mb/variants
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 timeout 120 python tools/r05/check_ring.py 2>&1 | grep -v amdgpu.ids | head -8
 for i in 1 2; do
 python tools/r05/time_ring.py

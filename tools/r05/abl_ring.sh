@@ -1,4 +1,5 @@
 V=tools/mb/variants
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 python tools/r05/time_ring.py
 PSND_ABLATE=2 python tools/r05/time_ring.py
 PSND_STFT4096_NORING=1 python tools/r05/time_ring.py

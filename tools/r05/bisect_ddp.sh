@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r05
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 run() { env "$@" MASTER_PORT=$((29600 + RANDOM % 300)) python bench.py --config ${CFG:-3} --steps 40 --warmup 5 --settle 10 --force-ddp 2>/dev/null | grep "^{" | tail -1 | python -c "
 import json,sys
 t=sys.stdin.read()

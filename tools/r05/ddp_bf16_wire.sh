@@ -1,4 +1,5 @@
 # one-rank RCCL runs: fp32 buckets on the wire against their bf16 image (FlatGradReducer comm_dtype, PSND_DDP_COMM=bf16): what the two extra
+export PSND_LAB=1   # the host side reads its A/B switches only in a lab environment (pytorch_sound_amd/_switches.py)
 # launches per bucket (pack / unpack on the release stream) cost on one GPU - the bytes they save only show on >= 2 devices
 OUT=${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/r05; mkdir -p $OUT
 for rep in 1 2; do
