@@ -9,7 +9,8 @@ convolution / fft / bmm on a HIP tensor, and no silent fallback: without libpsnd
 
 The inverse (transforms.py:71-101) is the matching dense synthesis: frames = W_inv [mag cos(phase); mag sin(phase)] with the one-sided
 inverse-DFT matrix, windowed, overlap-added (F.fold) and divided by the squared-window envelope + eps (host.istft states the conventions).
-Even filter_length only (the reference's K = n / 2 + 1 bins)."""
+Any filter_length >= 2: K = int(n / 2 + 1) bins as transforms.py:34 cuts them (an odd size has no Nyquist bin).
+Long batches are unfolded and multiplied in chunks of clips (CHUNK_BYTES of frames at a time)."""
 import math
 
 import numpy as np
@@ -17,28 +18,30 @@ import torch
 import torch.nn.functional as F
 
 _CACHE = {}
+CHUNK_BYTES = 1 << 30        # unfolded frames materialised at a time (the unfold is n / hop x the input)
 
 
 def _bases(n, window_np, device):
     key = (n, window_np.tobytes(), str(device))
     got = _CACHE.get(key)
     if got is None:
-        if n % 2 != 0:
-            from ._lib import PsndError
-            raise PsndError('STFT on a HIP tensor: filter_length %d is odd (K = n / 2 + 1 bins need an even size)' % n)
         k = np.arange(n // 2 + 1)[:, None].astype(np.float64)
         m = np.arange(n)[None, :].astype(np.float64)
         ang = 2.0 * np.pi * k * m / n
         w = window_np.astype(np.float64)[None, :]
         fwd = np.vstack([np.cos(ang), -np.sin(ang)]) * w                                   # (2K, n): re = sum w x cos, im = -sum w x sin
         c = np.full((n // 2 + 1, 1), 2.0)
-        c[0, 0] = c[-1, 0] = 1.0
+        c[0, 0] = 1.0
+        if n % 2 == 0:
+            c[-1, 0] = 1.0                                                                  # the Nyquist bin (an odd size has none: K = (n + 1) / 2)
         inv = np.hstack([(c * np.cos(ang)).T, (-c * np.sin(ang)).T]) / n                   # (n, 2K): x[m] = sum_k c_k (Re cos - Im sin) / n
         got = (torch.from_numpy(fwd.astype(np.float32)).to(device), torch.from_numpy(inv.astype(np.float32)).to(device),
                torch.from_numpy(window_np.astype(np.float32)).to(device))
-        if len(_CACHE) > 8:
-            _CACHE.clear()
-        _CACHE[key] = got
+        while len(_CACHE) >= 8:                                                            # least recently used first (dict order: see below)
+            _CACHE.pop(next(iter(_CACHE)))
+    else:
+        _CACHE.pop(key)
+    _CACHE[key] = got                                                                       # most recently used last
     return got
 
 
@@ -51,7 +54,14 @@ def stft_mag_phase(wav, n, hop, window_np, pad, mag_eps=0.0, want_phase=True, de
     """(N, T) HIP tensor -> magnitude, phase (N, n / 2 + 1, F), F = (T + 2 pad - n) // hop + 1"""
     from . import kernels as K
     fwd, _, _ = _bases(n, window_np, wav.device)
-    y = K.Linear1x1.apply(_frames(wav.float(), n, hop, pad), fwd, None, False)             # exact-fp32 MFMA GEMM
+    wav = wav.float()
+    Fr = (wav.shape[1] + 2 * pad - n) // hop + 1
+    per_clip = 4 * n * max(Fr, 1)                                                          # bytes of unfolded frames per clip: n / hop x the clip
+    step = max(1, CHUNK_BYTES // per_clip)
+    if wav.shape[0] <= step:
+        y = K.Linear1x1.apply(_frames(wav, n, hop, pad), fwd, None, False)                 # exact-fp32 MFMA GEMM
+    else:                                                                                  # chunks of clips: the frames of one chunk at a time
+        y = torch.cat([K.Linear1x1.apply(_frames(wav[i:i + step], n, hop, pad), fwd, None, False) for i in range(0, wav.shape[0], step)])
     Kb = n // 2 + 1
     re, im = y[:, :Kb], y[:, Kb:]
     mag = torch.sqrt(re * re + im * im + mag_eps) if mag_eps else torch.sqrt(re * re + im * im)

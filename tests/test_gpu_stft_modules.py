@@ -164,8 +164,9 @@ def test_polar_bwd_kernel_matches_formula():
 
 
 # ---- round 5: filter_length that is not a power of two on HIP tensors (reference transforms.py:19-51 takes any) -------------------------------
-@pytest.mark.parametrize('n,hop,win', [(800, 200, None), (1200, 300, None), (2400, 600, 2000), (1000, 250, None), (48, 12, None)])
-def test_stft_any_even_filter_length_on_hip_tensors(n, hop, win):
+@pytest.mark.parametrize('n,hop,win', [(800, 200, None), (1200, 300, None), (2400, 600, 2000), (1000, 250, None), (48, 12, None),
+                                       (801, 200, None), (75, 25, None), (1025, 256, 1001)])     # round 6: odd sizes (K = int(n / 2 + 1), no Nyquist bin)
+def test_stft_any_filter_length_on_hip_tensors(n, hop, win):
     """STFT(filter_length = 800 / 1200 / 2400 ...) used to raise on a HIP tensor; it now runs the reference's dense-basis formulation on the
     exact-fp32 matrix-core GEMM (pytorch_sound_amd/dense.py, psnd_linear1x1_*): magnitude and phase against the float64 oracle, the
     magnitude's gradient against the oracle's adjoint, inverse(transform(x)) == x, no library convolution / fft / bmm on the way.
@@ -196,5 +197,6 @@ def test_stft_any_even_filter_length_on_hip_tensors(n, hop, win):
     gref = ofe.stft_mag_bwd_f64(g.cpu().numpy().astype(np.float64), wav_np, n, hop, win)
     assert np.abs(x.grad.cpu().numpy() - gref).max() <= 5e-5 * np.abs(gref).max()
     Fr = mag.shape[2]
-    assert rec.shape == (N, (Fr - 1) * hop)
-    assert float((rec - x.detach()[:, :(Fr - 1) * hop]).abs().max()) <= 2e-5 * float(x.detach().abs().max()) + 2e-5
+    L = (Fr - 1) * hop + n % 2                                            # n + hop (F - 1) - 2 int(n / 2) samples (transforms.py:96-99)
+    assert rec.shape == (N, L)
+    assert float((rec - x.detach()[:, :L]).abs().max()) <= 2e-5 * float(x.detach().abs().max()) + 2e-5
