@@ -16,7 +16,7 @@ WORK = {'n1024': ('stft_fwd_n1024_kernel<mag>', '1024 clips x 2 s, 1024/256', 4 
         'nfk4096': ('stft_fwd_n4096r_kernel', '32 clips x 30 s at 44.1 kHz, 4096/1024, output (N, F, K)', 4 * 32 * 1323000 + 4 * 32 * 2049 * 1292),
         # psnd_mel_fwd (tools/pmc_stft.sh ... RUNNER=tools/r05/run_mel_only.py; kernel name match 'mel_kernel')
         'mel': ('mel_kernel', '1024 clips x 2 s: (N, K, F) magnitudes -> 80 log-mel bands', 4 * 1024 * 513 * 173 + 4 * 1024 * 80 * 173)}
-MATCH = {'mel': 'mel_kernel'}
+MATCH = {'mel': 'mel_'}                 # mel_fwd_once_kernel (round 6: the read-once forward) or mel_kernel
 
 
 def summarise(d, match='stft_fwd'):
