@@ -615,7 +615,7 @@ def _dropin_leg(device, steps=60, warm=8):
                             'Trainer.forward override, STFT.transform (magnitude and phase) x 2 + LogMelSpectrogram inside forward, torch.matmul / '
                             'log / clamp on `mel_filter` for the mel of the estimate, F.l1_loss x 2 - what a user gets who switches the import and '
                             'changes nothing else (round 6: the model hands out its estimate as a deferred tensor, pytorch_sound_amd/deferred.py - those torch '
-                            'ops are recorded and resolve to the fused loss node; gc.freeze() after the first steps ends the 50-120 ms cyclic-GC steps of the '
+                            'ops are recorded and resolve to the fused loss node, and STFT.transform hands out its magnitude bin-fastest (N, F, K) as a deferred tensor standing for (N, K, F), the phase on first use; gc.freeze() after the first steps ends the 50-120 ms cyclic-GC steps of the '
                             'eager loop); the headline `value` is the same step on the library\'s prepare() / (N, F, K) / fused-loss API'})
     return res
 

@@ -160,9 +160,12 @@ def stft_reim_bwd_f64(gre, gim, T, n_fft, hop, win_length=None, framing=CENTER, 
     w = analysis_window(n_fft, win_length).astype(np.float64) if window is None else np.asarray(window, np.float64)
     # adjoint of the one-sided DFT: halve the interior bins and use the unnormalised c2r
     G = (gre + 1j * gim).transpose(0, 2, 1).copy()                            # N,F,K
-    G[..., 1:K - 1] *= 0.5
     G[..., 0] = G[..., 0].real
-    G[..., K - 1] = G[..., K - 1].real
+    if n_fft % 2 == 0:
+        G[..., 1:K - 1] *= 0.5
+        G[..., K - 1] = G[..., K - 1].real                                    # the Nyquist bin
+    else:
+        G[..., 1:K] *= 0.5                                                    # an odd size has no Nyquist bin (K = (n + 1) / 2: transforms.py:34)
     gfr = np.fft.irfft(G, n=n_fft, axis=-1) * n_fft * w[None, None, :]       # N,F,n
     idx = frame_sample_index(np.arange(F)[:, None], np.arange(n_fft)[None, :], T, n_fft, hop, framing)
     gw = np.zeros((N, T), np.float64)

@@ -21,6 +21,13 @@ and resolves them when a real tensor is needed: `resolve()` (Trainer calls it on
 to a Deferred - which first materialises its operands with the plain kernels (mask head, kernels.MelLog, kernels.l1_loss) and then runs as
 written.  A Sum of one magnitude term and one log-mel term of the SAME estimate resolves to the fused node; every other shape resolves term by
 term.  Nothing is approximated and nothing is skipped: an unrecognised use costs the unfused launches, never a different result.
+
+The same mechanism carries the LAYOUT (round 6): `STFT.transform` on a HIP waveform hands out its magnitude as a `MagNFK` - the bin-fastest
+(N, F, K) result of the kernel that runs at 0.62 of the HBM roofline (psnd_stft_mag_nfk; the reference's frame-fastest (N, K, F) is written at
+0.48) - reporting the reference's shape (N, K, F).  The consumers of this library take it as it is (the separator's way into the channels-last
+layout, the fused loss as target, the mel kernels); any other use transposes it once into a real (N, K, F) tensor.  The phase, which the
+reference computes with every transform and its own LogMelSpectrogram discards (transforms.py:232), is a `Phase` node: computed from the waveform
+on first use (an in-place write to the waveform in between is detected by its version counter and raises).
 """
 import weakref
 
@@ -44,16 +51,45 @@ class _Node:
         return self._real
 
 
-class Est(_Node):
-    """sigmoid(from_cl(y)) * mag of a masking model (ConvSeparator): y = logits, channels-last bf16; mag (N, K, F) fp32"""
+class MagNFK(_Node):
+    """an STFT magnitude held bin-fastest: `nfk` (N, F, K) fp32, no gradient; stands for the reference's (N, K, F) tensor"""
 
-    def __init__(self, y, mag, shape):
-        self.y, self.mag, self.cl_shape = y, mag, shape
-        self.shape, self.device, self.requires_grad = tuple(mag.shape), mag.device, y.requires_grad
+    def __init__(self, nfk):
+        self.nfk = nfk
+        N, Fr, K = nfk.shape
+        self.shape, self.device, self.requires_grad = (N, K, Fr), nfk.device, False
+
+    def _materialize(self):
+        return self.nfk.transpose(1, 2).contiguous()
+
+
+class Phase(_Node):
+    """atan2(im, re) of STFT.transform (detached in the reference, transforms.py:69), not yet computed"""
+
+    def __init__(self, wav, module, shape):
+        self.wav, self.version, self.module = wav, wav._version, module
+        self.shape, self.device, self.requires_grad = tuple(shape), wav.device, False
+
+    def _materialize(self):
+        if self.wav._version != self.version:
+            raise RuntimeError('the waveform handed to STFT.transform was modified in place before the first use of the phase it returned '
+                               '(the phase is computed on first use: pytorch_sound_amd/deferred.py; deferred.ENABLED = False computes it at once)')
+        return self.module._transform_now(self.wav)[1]
+
+
+class Est(_Node):
+    """sigmoid(from_cl(y)) * mag of a masking model (ConvSeparator): y = logits, channels-last bf16; mag (N, K, F) fp32 - or, `mag_node` given,
+    the bin-fastest magnitude of a MagNFK (then y was formed from it on the plain-stream way in, and the fused loss runs bin-fastest too)"""
+
+    def __init__(self, y, mag, shape, mag_node=None):
+        self.y, self.mag, self.cl_shape, self.mag_node = y, mag, shape, mag_node
+        self.shape = tuple(mag.shape) if mag_node is None else mag_node.shape
+        self.device, self.requires_grad = y.device, y.requires_grad
 
     def _materialize(self):
         from . import cl
-        return cl.MaskHeadCL.apply(self.y, self.mag, self.cl_shape)
+        mag = self.mag if self.mag_node is None else self.mag_node.real()
+        return cl.MaskHeadCL.apply(self.y, mag, self.cl_shape)
 
 
 class MelLin(_Node):
@@ -79,7 +115,11 @@ class LogMel(_Node):
         self.shape, self.device, self.requires_grad = lin.shape, lin.device, lin.requires_grad
 
     def _materialize(self):
-        m, x = self.module, self.est.real()
+        m = self.module
+        if isinstance(self.est, MagNFK):                                       # the log-mel of a bin-fastest magnitude: the (N, F, K) mel kernel
+            from . import kernels as K
+            return K.MelLogNfk.apply(self.est.nfk, m._mel_plan(), m.mel_filter.shape[0], K.LOG_E, float(self.eps), None, self.lo, self.hi)
+        x = self.est.real()
         if not x.is_cuda:                                                     # host tensors: the ops as written
             y = torch.log(torch.matmul(m.mel_filter, x) + self.eps)
             return y if self.lo is None and self.hi is None else y.clamp(self.lo, self.hi)
@@ -103,17 +143,27 @@ class Sum(_Node):
         if len(mag_t) != 1 or len(mel_t) != 1 or mel_t[0][1].est is not mag_t[0][1]:
             return None
         (w1, est, mag_ref), (w2, lm, mel_ref) = mag_t[0], mel_t[0]
-        ok = (est._real is None and lm._real is None and est.mag.dtype == torch.float32 and not est.mag.requires_grad
-              and all(t.dtype == torch.float32 and t.is_cuda and not t.requires_grad for t in (mag_ref, mel_ref))
-              and tuple(mag_ref.shape) == est.shape and tuple(mel_ref.shape) == lm.shape)
-        if not ok:
-            return None
         from . import cl, kernels as K
         m = lm.module
-        loss, est_real = cl.MaskHeadSpectralL1CL.apply(est.y, est.mag.contiguous(), mag_ref.contiguous(), mel_ref.contiguous(), m._mel_plan(), est.cl_shape,
-                                                       m.mel_filter.shape[0], K.LOG_E, float(lm.eps), None, lm.lo, lm.hi, float(w1), float(w2))
+        plain = lambda t: isinstance(t, torch.Tensor) and not isinstance(t, Deferred) and t.dtype == torch.float32 and t.is_cuda and not t.requires_grad  # noqa: E731
+        if est._real is not None or lm._real is not None or not plain(mel_ref) or tuple(mel_ref.shape) != lm.shape:
+            return None
+        ref_node = _node(mag_ref, MagNFK)
+        if est.mag_node is not None and ref_node is not None and ref_node.shape == est.shape and ref_node._real is None:
+            # bin-fastest end to end: mixture magnitude, target and estimate are (N, F, K)
+            loss, est_nfk = cl.MaskHeadSpectralL1NFK.apply(est.y, est.mag_node.nfk, ref_node.nfk, mel_ref.contiguous(), m._mel_plan(), est.cl_shape,
+                                                           m.mel_filter.shape[0], K.LOG_E, float(lm.eps), None, lm.lo, lm.hi, float(w1), float(w2))
+            est_real = est_nfk.detach().transpose(1, 2)    # the reference's (N, K, F) as a view
+        else:
+            mag = est.mag if est.mag_node is None else est.mag_node.real()
+            ref = resolve(mag_ref)
+            if not (plain(mag) and plain(ref) and tuple(ref.shape) == est.shape):
+                return None
+            loss, est_real = cl.MaskHeadSpectralL1CL.apply(est.y, mag.contiguous(), ref.contiguous(), mel_ref.contiguous(), m._mel_plan(), est.cl_shape,
+                                                           m.mel_filter.shape[0], K.LOG_E, float(lm.eps), None, lm.lo, lm.hi, float(w1), float(w2))
+            est_real = est_real.detach()
         loss.psnd_nan_flag = cl.LAST_LOSS_NAN_FLAG[0]      # isnan(loss), written by the launch that formed the loss (Trainer._nan_flag)
-        est._real = est_real.detach()                      # for logging / metrics: carries no gradient of its own (the loss node holds it)
+        est._real = est_real                               # for logging / metrics: carries no gradient of its own (the loss node holds it)
         return loss
 
     def _materialize(self):
@@ -123,7 +173,7 @@ class Sum(_Node):
         from . import kernels as K
         tot = None
         for w, node, target in self.terms:
-            x = node.real()
+            x, target = node.real(), resolve(target)
             t = K.l1_loss(x, target) if (x.is_cuda and x.dtype == torch.float32 and target.dtype == torch.float32 and x.shape == target.shape) \
                 else F.l1_loss(x, target)
             t = t if w == 1.0 else t * w
@@ -183,9 +233,20 @@ def resolve(x):
     return x._node.real() if isinstance(x, Deferred) else x
 
 
-def est(y, mag, shape):
+def est(y, mag, shape, mag_node=None):
     """what a masking model returns for est = sigmoid(from_cl(y)) * mag when ENABLED (models/separator.py)"""
-    return Deferred(Est(y, mag, shape))
+    return Deferred(Est(y, mag, shape, mag_node))
+
+
+def mag_nfk(nfk):
+    """STFT.transform's magnitude, held bin-fastest (N, F, K), standing for the reference's (N, K, F)"""
+    return Deferred(MagNFK(nfk))
+
+
+def nfk_of(x):
+    """the MagNFK node behind `x` if it is an un-transposed lazy magnitude, else None"""
+    n = _node(x, MagNFK)
+    return n if n is not None and n._real is None else None
 
 
 def _node(x, kinds):
@@ -203,7 +264,7 @@ def _h_to(x, *a, **k):
 
 
 def _h_matmul(a, b, *rest, **k):
-    e = _node(b, Est)
+    e = _node(b, (Est, MagNFK))
     if e is None or rest or k or isinstance(a, Deferred) or not isinstance(a, torch.Tensor) or a.dim() != 2:
         return NotImplemented
     for m in MEL_MODULES:
@@ -241,7 +302,7 @@ def _h_clamp(x, min=None, max=None, **k):
 
 def _h_l1(input, target, *a, **k):
     n = _node(input, (Est, LogMel))
-    if n is None or a or isinstance(target, Deferred) or not isinstance(target, torch.Tensor):
+    if n is None or a or not isinstance(target, torch.Tensor) or (isinstance(target, Deferred) and _node(target, MagNFK) is None):
         return NotImplemented
     if any(k.get(key) is not None for key in ('size_average', 'reduce')) or k.get('reduction', 'mean') != 'mean' or k.get('weight') is not None:
         return NotImplemented
@@ -277,3 +338,28 @@ _HANDLERS = {
     torch.mul: _h_mul, torch.Tensor.mul: _h_mul, torch.Tensor.__mul__: _h_mul, torch.Tensor.__rmul__: _h_mul,
     torch.div: _h_div, torch.Tensor.div: _h_div, torch.Tensor.__truediv__: _h_div, torch.true_divide: _h_div,
 }
+
+
+# ---- custom autograd Functions --------------------------------------------------------------------------------------------------------
+# torch.autograd.Function.apply does not consult __torch_function__: handed a Deferred it would run `forward` on the wrapper - the numbers
+# right (every op inside resolves it) but WITHOUT a gradient edge, the wrapper itself having no history.  Every apply therefore resolves
+# deferred operands first (also for Functions defined outside this package: a silent loss of gradients is not an acceptable way to fail).
+def _patch_function_apply():
+    base = torch.autograd.Function
+    if getattr(base.apply, '_psnd_resolves_deferred', False):
+        return
+    orig = base.apply.__func__
+
+    def apply(cls, *args, **kwargs):
+        if any(isinstance(a, Deferred) for a in args):
+            args = tuple(resolve(a) for a in args)
+        if kwargs and any(isinstance(a, Deferred) for a in kwargs.values()):
+            kwargs = {k: resolve(v) for k, v in kwargs.items()}
+        return orig(cls, *args, **kwargs)
+
+    apply._psnd_resolves_deferred = True
+    apply.__doc__ = orig.__doc__
+    base.apply = classmethod(apply)
+
+
+_patch_function_apply()

@@ -29,8 +29,16 @@ class ConvSeparator(nn.Module):
     precision = 'auto'
 
     def forward(self, mag: torch.Tensor) -> torch.Tensor:
+        from pytorch_sound_amd import deferred
         if mag.is_cuda and wants_bf16(self.precision, mag):
-            return self.forward_cl(mag)
+            node = deferred.nfk_of(mag) if deferred.ENABLED else None
+            if node is not None:
+                # STFT.transform's lazy bin-fastest magnitude: (N, F, K) is the channels-last order itself - the way in is a plain stream,
+                # and the estimate stays deferred on that layout (the fused loss then runs bin-fastest end to end)
+                y, shape = self.logits_cl(node.nfk, 'nfk')
+                return deferred.est(y, None, shape, node)
+            return self.forward_cl(deferred.resolve(mag))
+        mag = deferred.resolve(mag)
         if mag.is_cuda:
             with torch.autocast('cuda', enabled=False):
                 return self._forward_plain(mag.float()).to(mag.dtype)

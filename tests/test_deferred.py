@@ -100,3 +100,25 @@ def test_trainer_resolves_what_forward_returns():
     loss, meta = t._forward_resolved()
     assert not isinstance(loss, D.Deferred) and meta['loss'][0] is loss and meta['loss'][1] == LogType.SCALAR
     assert not isinstance(meta['mag'][0], D.Deferred) and meta['mag'][0].dim() == 0
+
+
+def test_custom_autograd_functions_get_the_real_tensor():
+    """torch.autograd.Function.apply does not go through __torch_function__: a Deferred operand is resolved first, so the gradient edge exists"""
+    fe, logits, mag, mag_ref, _ = _setup()
+
+    class Double(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            assert not isinstance(x, D.Deferred)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    e = D.Deferred(_HostEst(logits, mag))
+    y = Double.apply(e)
+    assert y.requires_grad and y.grad_fn is not None
+    y.sum().backward()
+    want = torch.autograd.grad((torch.sigmoid(logits) * mag * 2).sum(), logits)[0]
+    assert torch.allclose(logits.grad, want)
