@@ -36,6 +36,13 @@
 #ifndef PSND_Q_LOAD_MOD
 #define PSND_Q_LOAD_MOD ""    // cache-policy modifiers of the span transfers (A/B builds: " nt", " sc1", " sc0 sc1")
 #endif
+#ifndef PSND_Q_PRIO_MEM
+#define PSND_Q_PRIO_MEM 2     // wave priority of a quad's memory phase (read-out of the staged magnitudes, next span's transfer, stores) - round 6: every raised setting measures 1.5-2 % faster than none (0 / 0), same-box interleaved medians of 480 launches: 115.2 (0/0) 113.9 (0/2) 113.0 (0/1) 113.3 (3/1) 112.9 (3/2) 112.7 (2/1) us
+#endif
+#ifndef PSND_Q_PRIO_X
+#define PSND_Q_PRIO_X 1       // ... of the exchange between the passes (LDS round trips)
+#endif
+#define Q_PRIO(n_) do { if ((PSND_Q_PRIO_MEM) != 0 || (PSND_Q_PRIO_X) != 0) __builtin_amdgcn_s_setprio(n_); } while (0)
 #ifdef PSND_Q_NOSB            // A/B builds (tools/r04/variant_q.sh): no scheduling fences between the phases
 #define Q_SB()
 #else
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
             butterflies(I2{}, wq[2]);
             Q_SB();
             // ---- exchange inside the wave, two half rounds (rows 0..15, then 16..31) ------------------------------------------------
+            Q_PRIO(PSND_Q_PRIO_X);
             const unsigned tw_lds = lds_addr(s_tw + l * kRow);
             float *oz = xw + fi * kXF + 2 * l;
             const int rowB = l == 0 ? 0 : 16 - l;               // row inside the second half (rows 16 .. 31)
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 write_pair(H1{}, ic, twb[i]);
             });
             Q_SB();
+            Q_PRIO(0);
             // rows B and the split twiddles v[qA + 32 pp], v[qB + 32 pp], v[256]: requested now, used behind the two radix-16 transforms
             read_row(rowB, zb);
             VkRegs vk;
@@ -421,6 +430,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
             }
             Q_SB();
             // ---- out again as 16 bytes per lane: a store instruction writes 1 KiB of contiguous memory ---------------------------------
+            Q_PRIO(PSND_Q_PRIO_MEM);
             constexpr int kPieces = (4 * kK * 4 + 1023) / 1024;              // 9: 8 full instructions + the last 16 bytes
             f32x4 o[kPieces];
             const int lnf = fresh_lane();
@@ -457,6 +467,7 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), ro, toff < bytes ? toff : (1 << 30), 0, 0);
             }
         }
+        Q_PRIO(0);
         clip = nclip, f0 = nf0, nval = nnval;
     }
 }
