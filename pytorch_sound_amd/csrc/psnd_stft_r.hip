@@ -46,6 +46,9 @@
 #ifndef PSND_R_STORE_AUX
 #define PSND_R_STORE_AUX 2     // cache-policy bits of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
+#ifndef PSND_R_LOADER_PRIO
+#define PSND_R_LOADER_PRIO 3   // wave priority of the loader wave - the wave every frame wave waits for (round 6: 123.5 -> 122.0 us, same-box medians)
+#endif
 #ifndef PSND_R_BATCH
 #define PSND_R_BATCH 4         // ring chunks the loader wave requests per poll (4 LDS-DMA instructions each); two batches in flight
 #endif
@@ -242,6 +245,9 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096r_kernel(RParams p) {
 
         const bool nostore = PSND_ABL(p, 2);
         if (w == kWaves - 1) {
+#if PSND_R_LOADER_PRIO
+            __builtin_amdgcn_s_setprio(PSND_R_LOADER_PRIO);     // the wave every frame wave waits for
+#endif
             // ---- THE LOADER WAVE: chunks in order, kBatch at a time, two batches in flight; a slot is free once every reader of the chunk 16
             //      back is through.  vmcnt counts this wave's transfers in order (4 instructions per chunk): everything in front of the newest
             //      batch has landed when at most 4 kBatch instructions are outstanding.  Clip-edge chunks (gathered with ordinary loads) and the
@@ -281,6 +287,9 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n4096r_kernel(RParams p) {
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (head < nch) publish_chunks(head, nch);
+#if PSND_R_LOADER_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             continue;                                           // next segment (its first barrier waits for the frame waves)
         }
         int titer = -1;
