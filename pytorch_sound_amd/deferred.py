@@ -54,12 +54,16 @@ class _Node:
 class MagNFK(_Node):
     """an STFT magnitude held bin-fastest: `nfk` (N, F, K) fp32, no gradient; stands for the reference's (N, K, F) tensor"""
 
-    def __init__(self, nfk):
-        self.nfk = nfk
+    def __init__(self, nfk, owner=None):
+        self.nfk, self.owner = nfk, owner
         N, Fr, K = nfk.shape
         self.shape, self.device, self.requires_grad = (N, K, Fr), nfk.device, False
 
     def _materialize(self):
+        # a consumer outside the library: one transposing pass - and the module that produced it stops deferring (its next transforms write
+        # the reference's layout directly: a consumer that wants (N, K, F) should not pay for two passes every step)
+        if self.owner is not None:
+            self.owner._lazy_transform = False
         return self.nfk.transpose(1, 2).contiguous()
 
 
@@ -74,6 +78,7 @@ class Phase(_Node):
         if self.wav._version != self.version:
             raise RuntimeError('the waveform handed to STFT.transform was modified in place before the first use of the phase it returned '
                                '(the phase is computed on first use: pytorch_sound_amd/deferred.py; deferred.ENABLED = False computes it at once)')
+        self.module._lazy_transform = False                  # the phase IS used: this module's next transforms compute both at once
         return self.module._transform_now(self.wav)[1]
 
 
@@ -238,9 +243,9 @@ def est(y, mag, shape, mag_node=None):
     return Deferred(Est(y, mag, shape, mag_node))
 
 
-def mag_nfk(nfk):
+def mag_nfk(nfk, owner=None):
     """STFT.transform's magnitude, held bin-fastest (N, F, K), standing for the reference's (N, K, F)"""
-    return Deferred(MagNFK(nfk))
+    return Deferred(MagNFK(nfk, owner))
 
 
 def nfk_of(x):

@@ -100,14 +100,19 @@ class STFT(nn.Module):
         if not D.is_fast_size(self.filter_length):           # e.g. 800 / 1200 / 2400: the dense-basis GEMM on the matrix cores (dense.py)
             return D.stft_mag_phase(wav, self.filter_length, self.hop_length, self._window_np, self.pad_amount)
         from pytorch_sound_amd import deferred
-        if deferred.ENABLED and wav.dtype == torch.float32 and not (torch.is_grad_enabled() and wav.requires_grad):
+        if (deferred.ENABLED and self._lazy_transform and wav.dtype == torch.float32
+                and not (torch.is_grad_enabled() and wav.requires_grad)):
             # no gradient wanted: the magnitude from the bin-fastest kernel (psnd_stft_mag_nfk: 0.62 of the HBM roofline against 0.48 for
             # the frame-fastest store) as a deferred tensor that stands for the reference's (N, K, F) - consumers of this library take it as
-            # it is, any other use transposes it once; the phase is computed when something uses it (deferred.py)
+            # it is, any other use transposes it once; the phase is computed when something uses it (deferred.py).  Adaptive: the first
+            # time a magnitude of this module is transposed or a phase is used, `_lazy_transform` goes off and the module computes both
+            # at once in the reference's layout from then on (set it back to True to probe again).
             nfk = K.stft_mag_nfk(wav, self.filter_length, self.hop_length, self._plan(wav.device), K.FRAMING_CENTER, 0.0)
-            mag = deferred.mag_nfk(nfk)
+            mag = deferred.mag_nfk(nfk, self)
             return mag, deferred.Deferred(deferred.Phase(wav, self, mag.shape))
         return self._transform_now(wav)
+
+    _lazy_transform = True
 
     def _transform_now(self, wav):
         return K.StftMagPhase.apply(wav, self._plan(wav.device), self.filter_length, self.hop_length, K.FRAMING_CENTER, 0.0, True)

@@ -140,12 +140,15 @@ def test_transform_hands_out_a_lazy_bin_fastest_magnitude():
     assert mag.shape == mag0.shape and ph.shape == ph0.shape and mag._node._real is None and ph._node._real is None
     assert float((mag + 0 - mag0).abs().max()) <= 2e-6 * float(mag0.abs().max()) and mag._node._real is not None     # the bin-fastest kernel, transposed once
     assert torch.equal(D.resolve(ph), ph0)
+    assert not stft._lazy_transform                                                           # a magnitude was transposed, a phase used: this module
+    m_e, p_e = stft.transform(x)                                                              # computes both at once from now on
+    assert not isinstance(m_e, D.Deferred) and torch.equal(m_e, mag0) and torch.equal(p_e, ph0)
     rec = stft.inverse(mag, ph)                                                               # deferred operands into a kernel wrapper
     assert torch.allclose(rec, x[:, :rec.shape[1]], atol=2e-5)
     xg = x.clone().requires_grad_(True)                                                       # a gradient is wanted: the eager autograd path
     mg, _ = stft.transform(xg)
     assert not isinstance(mg, D.Deferred) and mg.grad_fn is not None
-    m2, p2 = stft.transform(x.clone())
+    stft._lazy_transform = True                                                               # probe again
     w = x.clone()
     m3, p3 = stft.transform(w)
     w.mul_(2.0)                                                                               # the waveform changes before the phase is used
