@@ -22,7 +22,7 @@
 //   * stores: 16 lanes x 4 bytes = 64 contiguous bytes per frame and instruction, 4 frames per instruction; a wave's 34 store
 //     instructions fill one contiguous 8.2 KB region that no other wave touches.
 //
-// Bound: HBM, 4 hop + 4 K = 3076 B per frame at hop 256 (DESIGN.md 4.1d for the measured fraction).
+// Bound: HBM, 4 hop + 4 K = 3076 B per frame at hop 256 (DESIGN.md 4.1 for the measured fraction).
 #include "psnd_pk.h"
 #include "psnd_stft_pass.h"
 #include "psnd_stft_emit.h"

@@ -37,7 +37,7 @@
 //
 // The transform itself (radix-2 in lane, v_permlane32_swap, radix-32, 32 x 32 transpose per half-wave, radix-32, real-FFT split through
 // ds_bpermute, magnitudes stored straight from registers) is the one of psnd_stft_w.hip; see there for the index algebra.
-// Bound: HBM (4 hop + 4 K = 12 292 B per frame); DESIGN.md 4.1e for the measured fraction.
+// Bound: HBM (4 hop + 4 K = 12 292 B per frame); DESIGN.md 4.1 for the measured fraction.
 #include "psnd_pk.h"
 #include "psnd_stft_pass.h"
 #include "psnd_stft_w.h"

@@ -32,7 +32,7 @@
 //                      (ds_bpermute); a lane then owns bins 64 j + c (j < 16: rows 0..1023) and their mirrors 2048 - 64 j - c
 //                      (rows 1025..2048); lane 0 pairs inside itself and owns bins 0 | 2048 and 1024
 //
-// Bound: HBM (4 hop + 4 K = 12 292 B per frame), see DESIGN.md 4.1c for the measured fraction.
+// Bound: HBM (4 hop + 4 K = 12 292 B per frame), see DESIGN.md 4.1 for the measured fraction.
 #include "psnd_pk.h"
 #include "psnd_stft_pass.h"
 #include "psnd_stft_w.h"
