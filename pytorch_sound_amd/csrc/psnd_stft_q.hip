@@ -15,12 +15,13 @@
 //     inter-pass twiddle), pass 2 lane (frame, qq) holds the rows qq and 32 - qq (two radix-16, real-FFT split: post_emit_pk of the
 //     span-staged kernel) - the exchange between the passes never leaves the wave: a 9.2 KB LDS buffer of its own, two half rounds,
 //     LDS operations of one wave execute in order => NO workgroup barrier anywhere in the tile loop;
-//   * the wave's span of samples (3 hop + 1024 = 7 KB) is fetched with 16-byte loads into registers one quad AHEAD (requested before
-//     the current quad's stores in the in-order vector-memory queue) and staged through the same LDS buffer;
+//   * the wave's span of samples (3 hop + 1024 = 7 KB) goes straight into the same LDS buffer by LDS-DMA one quad AHEAD (requested before
+//     the current quad's stores in the in-order vector-memory queue; round 6);
 //   * 16 waves = one persistent 1024-thread workgroup per CU share nothing but the tables (10.8 KB, loaded once per workgroup instead
 //     of once per tile); they drift apart, so loads, butterflies, LDS rounds and stores of different waves overlap freely;
-//   * stores: 16 lanes x 4 bytes = 64 contiguous bytes per frame and instruction, 4 frames per instruction; a wave's 34 store
-//     instructions fill one contiguous 8.2 KB region that no other wave touches.
+//   * stores: the quad's magnitudes are staged in the wave's buffer frame by frame (pitch 2112 B: the four lane groups of a staging write on
+//     disjoint banks) and leave as 16-byte pieces - a store instruction writes 1 KiB of one frame's spectrum, nine instructions per quad
+//     fill one contiguous 8.2 KB region that no other wave touches.
 //
 // Bound: HBM, 4 hop + 4 K = 3076 B per frame at hop 256 (DESIGN.md 4.1 for the measured fraction).
 #include "psnd_pk.h"
@@ -62,7 +63,11 @@ constexpr int kXF = 16 * kRP;                      // one frame's half exchange 
 constexpr int kXW = 4 * kXF;                       // a wave's buffer: 2304 floats = 9216 B (also its span of samples)
 constexpr int kLdsFloats = kTab + kWaves * kXW;
 static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
-constexpr int kStoresPerQuad = 10;                 // store instructions a wave issues per quad (behind the next span's transfer): 9 x 16 bytes per lane + 1 tail
+constexpr int kFPitch = 2112;                      // bytes between two frames' staged magnitudes (2052 used): 528 words = 16 (mod 64) banks - the four 16-lane
+                                                   // groups of a staging write hit disjoint banks (a pitch of 513 words put them one bank apart: 4-way conflicts) -
+                                                   // and a multiple of 16 bytes: the read-out stays on aligned ds_read_b128
+static_assert(4 * kFPitch <= kXW * 4, "padded staging fits the wave's buffer");
+constexpr int kStoresPerQuad = 9;                  // store instructions a wave issues per quad (behind the next span's transfer): 8 x 16 bytes per lane + the frames' last words
 constexpr int kSPVMax = 9;                         // 16-byte span pieces per lane: 64 x 9 x 4 = 2304 samples (hop 256: 7)
 
 struct QParams {
@@ -426,12 +431,14 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 const int ln3 = fresh_lane(), qq = ln3 & 15;
                 const bool special = qq == 0;
                 EmitStage emit{xw, p.mag_eps};
-                post_emit_pk_vk<kR1, kL>(za, zb, special, qq, special ? kR1 / 2 : kR1 - qq, vk, emit, 1, (ln3 >> 4) * (kK * 4));
+                post_emit_pk_vk<kR1, kL>(za, zb, special, qq, special ? kR1 / 2 : kR1 - qq, vk, emit, 1, (ln3 >> 4) * kFPitch);
             }
             Q_SB();
             // ---- out again as 16 bytes per lane: a store instruction writes 1 KiB of contiguous memory ---------------------------------
             Q_PRIO(PSND_Q_PRIO_MEM);
-            constexpr int kPieces = (4 * kK * 4 + 1023) / 1024;              // 9: 8 full instructions + the last 16 bytes
+            // Frame f's 2052 bytes lie at f * kFPitch in the buffer: 128 whole 16-byte pieces + one word.  Store instruction j takes the 64 pieces
+            // [64 (j % 2), 64 (j % 2) + 64) of frame j / 2 - 1 KiB of contiguous memory, LDS reads 16-byte aligned - and a ninth one the four last words.
+            constexpr int kPieces = 8;
             f32x4 o[kPieces];
             const int lnf = fresh_lane();
             const int bytes = nval * (kK * 4);
@@ -439,13 +446,10 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 const char *src = reinterpret_cast<const char *>(xw) + lnf * 16;
                 static_for<0, kPieces>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
-                    if constexpr (j < kPieces - 1) o[j] = *reinterpret_cast<const f32x4 *>(src + 1024 * j);
-                    else o[j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(xw) + 8192);     // (every lane: the last piece)
+                    o[j] = *reinterpret_cast<const f32x4 *>(src + (j / 2) * kFPitch + (j % 2) * 1024);
                 });
             }
-            const int full = bytes & ~15;                                    // bytes covered by whole 16-byte pieces
-            const int toff = full + 4 * lnf;                                 // the 1 - 3 dwords behind them (odd frame counts: 2052 = 16 * 128 + 4)
-            const float tv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xw) + (toff < bytes ? toff : 0));
+            const float tv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xw) + (lnf & 3) * kFPitch + 2048);   // lane f < 4: bin 512 of frame f
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the buffer has been read out
             Q_SB();
             // the next quad's span: into the (free) buffer, AHEAD of this quad's stores in the in-order vector-memory queue
@@ -460,11 +464,10 @@ __global__ __launch_bounds__(1024, 1) void stft_fwd_n1024q_kernel(QParams p) {
                 const __amdgpu_buffer_rsrc_t ro = make_uniform_rsrc(p.mag + ((size_t)clip * (size_t)p.F + (size_t)f0) * kK, bytes);
                 static_for<0, kPieces>([&](auto jc) __attribute__((always_inline)) {
                     constexpr int j = decltype(jc)::value;
-                    int off = j < kPieces - 1 ? lnf * 16 + 1024 * j : 8192 + (lnf == 0 ? 0 : (1 << 30));
-                    off = off + 16 <= full ? off : (1 << 30);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[j]), ro, off, 0, PSND_Q_STORE_AUX);
+                    // (frames past nval: offsets at or beyond `bytes`, dropped by the range check)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[j]), ro, (j / 2) * (kK * 4) + (j % 2) * 1024 + lnf * 16, 0, PSND_Q_STORE_AUX);
                 });
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), ro, toff < bytes ? toff : (1 << 30), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tv), ro, lnf < 4 ? lnf * (kK * 4) + 2048 : (1 << 30), 0, 0);
             }
         }
         Q_PRIO(0);
