@@ -17,6 +17,8 @@ def _gen(seed=5):
     h = Namespace(resblock='1', upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=64,
                   resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
     g = Generator(h).cuda()
+    g.precision = 'bf16'       # the channels-last kernels (with their graph branches) whatever the context: also inside spawned workers,
+    #                            which do not see conftest's fixture (an fp32 input outside autocast would take the fp32 convolutions)
     with torch.no_grad():
         for n, p in g.named_parameters():
             if n.endswith('weight_v'):
