@@ -32,6 +32,7 @@ def _maxrel(a, b):
     (2, 8, 24, 5, 2, 0, 50, 1.0),             # no padding: shorter output
     (2, 24, 8, 1, 1, 0, 33, 1.0),             # k = 1: the GEMM alone
     (2, 24, 8, 1, 1, 0, 33, 0.2),             # k = 1 behind an activation
+    (9, 1024, 16, 8, 1, 3, 24, 0.1),          # 73 728 unfolded rows: the launch's row index spans grid.y x grid.z
 ])
 def test_conv1d_f32_vs_float64(N, Cin, Cout, k, dil, pad, T, slope):
     from pytorch_sound_amd import kernels as K
@@ -47,7 +48,7 @@ def test_conv1d_f32_vs_float64(N, Cin, Cout, k, dil, pad, T, slope):
     y = K.conv1d_f32(xg, wg, bg, pad, dil, slope)
     assert y.dtype == torch.float32 and y.shape == yd.shape
     (y * gy.float().cuda()).sum().backward()
-    assert _maxrel(y, yd) <= 2e-6
+    assert _maxrel(y, yd) <= (4e-6 if Cin * k > 4096 else 2e-6)            # fp32 sums of Cin * k products (8192 at the widest case)
     assert _maxrel(xg.grad, xd.grad) <= 2e-6
     assert _maxrel(wg.grad, wd.grad) <= 2e-6
     assert _maxrel(bg.grad, bd.grad) <= 2e-6
@@ -205,3 +206,29 @@ def test_separator_fp32_outside_autocast():
         yb = mg(mag.cuda()).float()
     e = _maxrel(yb, yd)
     assert 1e-5 < e <= 5e-2, e
+
+
+def test_generator_v1_fp32_at_training_shape():
+    """registered hifi_gan_v1 on an fp32 batch outside autocast (4 x 32 frames -> 4 x 8192 samples): the fp32 convolutions against the library
+    formulation of the same module (use_cl = False; MIOpen's own fp32 algorithms differ from run to run at the 1e-5 level) - output 1e-4 of max,
+    gradients 1e-3 relative L2; the tight bounds are the goldens and the per-layer float64 tests above - and no library convolution"""
+    from pytorch_sound_amd.models import build_model
+    from pytorch_sound_amd.models.vocoders import hifi_gan  # noqa: F401
+    from test_gpu_no_library_paths import forbid_library_ops
+    torch.manual_seed(2)
+    g = build_model('hifi_gan_v1').cuda()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith('weight_v') and p.abs().max() < 0.1:
+                p.mul_(10.0)
+    x = torch.randn(4, 80, 32, device='cuda')
+    w = torch.randn(4, 1, 8192, device='cuda')
+    with forbid_library_ops():
+        y, gx, gp = _run(g, x, w)
+    g.use_cl = False
+    yl, gxl, gpl = _run(g, x, w)
+    assert y.shape == (4, 1, 8192)
+    assert _maxrel(y, yl) <= 1e-4
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))     # noqa: E731
+    assert rel(gx, gxl) <= 1e-3
+    assert max(rel(gp[n], gpl[n]) for n in gp) <= 1e-3
