@@ -620,6 +620,29 @@ def _dropin_leg(device, steps=60, warm=8):
     return res
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio, which is block-buffered when stdout is a pipe: left alone it comes out when the process
+    exits - BEHIND the JSON line, on every rank.  Flushed here (right behind the communicator's first collective, and again in front of the
+    line) so that the JSON line is the last thing rank 0 writes."""
+    import ctypes
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001
+        pass
+
+
+def _emit_line(out):
+    """barrier, tear the process group down, flush what C code buffered, then the one JSON line (rank 0) as the last write"""
+    _flush_c_stdio()                                 # every rank: its buffered banner out BEFORE the barrier below ...
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()                  # ... so that nothing of another rank can land behind rank 0's line
+        torch.distributed.destroy_process_group()
+    _flush_c_stdio()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
 def _dist_setup(args):
     from pytorch_sound_amd import distributed as pdist
     if args.force_ddp and int(os.environ.get('WORLD_SIZE', '1')) <= 1:
@@ -634,6 +657,9 @@ def _dist_setup(args):
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
     local = 0 if os.environ.get('PSND_DIST_SHARE_GPU') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
+    if distributed or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        torch.distributed.barrier()              # the communicator exists (and has printed its banner) on every rank
+        _flush_c_stdio()
     return distributed, rank, world, torch.device('cuda', local)
 
 
@@ -1035,6 +1061,9 @@ def main():
                     help='which BASELINE configuration the contract line runs (1-based as in BASELINE.json configs: 2 = the headline, 3 = conv vocoder DDP, '
                          '4 = transformer block DDP, 5 = 4096-point STFT of 30-s clips); 3 / 4 / 5 take --gpus N under torch.distributed.run like the headline')
     args = ap.parse_args()
+    # RCCL (this torch build's) writes a five-line version banner to STDOUT when the process exits - behind the JSON line - unless its log level is
+    # set: rank 0's line must be the last thing on stdout (a caller that wants RCCL's messages sets NCCL_DEBUG itself)
+    os.environ.setdefault('NCCL_DEBUG', 'NONE')
     if args.leg:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: no GPU visible')
@@ -1058,22 +1087,14 @@ def main():
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
     if args.config != 2:
-        out = config_bench(args)
-        if out is not None:
-            print(json.dumps(out), flush=True)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.barrier()
-            torch.distributed.destroy_process_group()
+        _emit_line(config_bench(args))
         return
     out, device = gpu_bench(args)
     if out is not None:
         if args.gpus == 1 and args.cpu_seconds > 0:
             out['cpu_baseline'] = cpu_baseline(args.cpu_seconds * 0.6, 'port')
             out['cpu_baseline_torch_stft'] = cpu_baseline(args.cpu_seconds * 0.4, 'torch_stft')
-        print(json.dumps(out), flush=True)
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    _emit_line(out)
 
 
 if __name__ == '__main__':
