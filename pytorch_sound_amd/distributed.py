@@ -13,7 +13,7 @@ FlatGradReducer
     and scales by 1/world.
 Bucket size: gradients here are small (hifi_gan_v1 55.7 MB fp32, the config-2 separator 22 MB, v2 3.7 MB):
 xGMI rings are per-link bound (~153 GB/s/link), so latency, not bandwidth, dominates -> few large
-buckets, but more than one: by default about six per model (`auto_bucket_bytes`: whole MiB, 1..32 MiB),
+buckets, but more than one: by default about six per model (`auto_bucket_bytes`: whole MiB, 4..32 MiB),
 so that all but the last sixth of the reduction can run under the backward.
 """
 import collections
@@ -155,7 +155,8 @@ class FlatGradReducer:
         self._handles = []
         order = list(reversed(self.params))
         if bucket_bytes is None:
-            bucket_bytes = self.auto_bucket_bytes(sum(p.numel() * 4 for p in order))
+            lab_mib = _sw.lab('PSND_DDP_BUCKET_MIB')       # A/B: bucket size in MiB
+            bucket_bytes = (int(float(lab_mib) * (1 << 20)) if lab_mib else self.auto_bucket_bytes(sum(p.numel() * 4 for p in order)))
         self.bucket_bytes = bucket_bytes
         # the parameters of one leaf module (a conv's weight_v / weight_g / bias) stay in ONE bucket: their gradients appear together, and
         # a bucket that holds the bias of the NEXT conv as well would wait for that conv's block (measured at config 2: bucket 3 of 6
@@ -237,13 +238,16 @@ class FlatGradReducer:
 
     @staticmethod
     def auto_bucket_bytes(total_bytes: int, target_buckets: int = 6) -> int:
-        """bucket size when none is given: about `target_buckets` buckets per model, whole MiB, between 1 and 32 MiB.  One 32 MiB bucket
+        """bucket size when none is given: about `target_buckets` buckets per model, whole MiB, between 4 and 32 MiB.  One 32 MiB bucket
         holds ALL 22 MB of the config-2 separator's gradients - its all-reduce could not start before the last gradient of the
-        backward exists, i.e. no overlap at all; six buckets leave one sixth of the reduction exposed.  Below 1 MiB the per-collective
-        latency of RCCL (~20-30 us over xGMI) outweighs what the overlap returns."""
+        backward exists, i.e. no overlap at all; six buckets leave one sixth of the reduction exposed.  Below 4 MiB a bucket costs more
+        than its overlap returns: besides RCCL's ~20-30 us per collective over xGMI, every bucket is a release point of the step graph
+        (copy into the flat buffer, fork to the release stream, captured collective, join) - measured with a one-rank RCCL group on the
+        config-4 block (4.2 MB of gradients, round 6): 5 buckets of 1 MiB 2.35 ms, 3 of 2 MiB 2.39, ONE bucket 2.18 (2.15 without a
+        reducer); the 22 MB separator: 0.717 ms at 1 MiB, 0.705 at 4 MiB."""
         mib = 1 << 20
         per = -(-total_bytes // target_buckets)
-        return int(min(32 * mib, max(mib, -(-per // mib) * mib)))
+        return int(min(32 * mib, max(4 * mib, -(-per // mib) * mib)))
 
     # ---- cl.GRAD_SINK protocol: gradients produced INSIDE a node's backward ------------------------------------------------------
     def sink_active(self) -> bool:

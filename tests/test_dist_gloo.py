@@ -174,7 +174,8 @@ def test_auto_bucket_size_gives_the_backward_something_to_overlap():
     mib = 1 << 20
     assert FlatGradReducer.auto_bucket_bytes(22 * mib) == 4 * mib
     assert FlatGradReducer.auto_bucket_bytes(56 * mib) == 10 * mib
-    assert FlatGradReducer.auto_bucket_bytes(100) == mib and FlatGradReducer.auto_bucket_bytes(1 << 40) == 32 * mib
+    assert FlatGradReducer.auto_bucket_bytes(100) == 4 * mib and FlatGradReducer.auto_bucket_bytes(1 << 40) == 32 * mib     # floor 4 MiB (round 6: a bucket is a release point of the step graph)
+    assert FlatGradReducer.auto_bucket_bytes(int(4.2 * mib)) == 4 * mib                                                      # the config-4 block: one or two buckets, not five
     sep = build_model('conv_separator_voicebank')
     red = FlatGradReducer(sep)
     total = sum(p.numel() * 4 for p in sep.parameters())
