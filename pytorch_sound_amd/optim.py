@@ -108,7 +108,26 @@ class Adam(torch.optim.Optimizer):
                     grads.append(g if g.is_contiguous() and g.dtype == torch.float32 else g.contiguous().float())
                 raw = b''.join(struct.pack('<5Qq', s[0], g.data_ptr(), s[1], s[2], s[3], s[4]) for s, g in zip(plan['static'], grads))
                 assert len(raw) == len(params) * int(lib().psnd_adam_table_bytes())
-                plan['table'] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+                # stream-ordered upload from page-locked memory: a plain .to(device) of a pageable tensor is a SYNCHRONOUS copy - the host waits
+                # for everything enqueued so far (the whole backward), the GPU then idles while the host catches up: every eager step whose
+                # gradients came back at new addresses took ~4 ms instead of ~1.7 (round 6, tools/r06/stall.py)
+                stage = plan.get('stage')
+                if stage is None or stage[0][0].numel() != len(raw):
+                    stage = plan['stage'] = [[torch.empty(len(raw), dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
+                    plan['stage_i'] = 0
+                    plan['uploads'] = 0
+                slot = stage[plan['stage_i']]
+                plan['stage_i'] ^= 1
+                plan['uploads'] += 1
+                if slot[1] is not None:
+                    slot[1].synchronize()                   # the copy that last read this staging buffer (two uploads ago) has run
+                slot[0].numpy()[:] = np.frombuffer(raw, dtype=np.uint8)
+                if plan['table'] is not None and plan['table'].numel() == len(raw) and not torch.cuda.is_current_stream_capturing():
+                    plan['table'].copy_(slot[0], non_blocking=True)
+                else:
+                    plan['table'] = slot[0].to(device, non_blocking=True)
+                slot[1] = torch.cuda.Event()
+                slot[1].record()
                 # converted copies (non-contiguous / non-fp32 gradients) are not stable addresses: look again next step
                 stable = all(g is p.grad for g, p in zip(grads, params))
                 plan['gptrs'] = gptrs if stable else None
