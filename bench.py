@@ -597,24 +597,28 @@ def _dropin_leg(device, steps=60, warm=8):
             return loss, {'loss': (loss, LogType.SCALAR)}
 
     res = {}
-    for mode in ('eager', 'graph_steps'):
+    for mode in ('default', 'eager', 'graph_steps'):
         torch.manual_seed(1234)
         model = build_model('conv_separator_voicebank').to(device)
         pool = [synth_batch(1234 + 1000 * i, N, T, device) for i in range(4)]
-        tr = Step(model, poptim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99)), pool, pool, max_step=10 ** 9, valid_max_step=1,
+        # the optimizer as the reference's recipes build it: a stock torch.optim.Adam (Trainer adopts it: pytorch_sound_amd.optim.Adam's launch)
+        tr = Step(model, torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.8, 0.99)), pool, pool, max_step=10 ** 9, valid_max_step=1,
                   save_interval=10 ** 9, log_interval=10 ** 9, save_dir=tempfile.mkdtemp(prefix='psnd_dropin_'), seed=1234)
-        tr.graph_steps = mode == 'graph_steps'
+        if mode != 'default':                              # 'default': Trainer.graph_steps = 'auto' - nothing set by the caller
+            tr.graph_steps = mode == 'graph_steps'
         model.train()
         try:
-            ms, dist = _time_steps(tr, steps, warm + (tr.graph_warmup + 1 if tr.graph_steps else 0))
-            res[mode] = {'ms_per_step': ms, 'value': N * CLIP_SECONDS / (ms * 1e-3), 'step_ms': dist}
+            ms, dist = _time_steps(tr, steps, warm + tr.graph_warmup + 1)
+            res[mode] = {'ms_per_step': ms, 'value': N * CLIP_SECONDS / (ms * 1e-3), 'step_ms': dist,
+                         'captured': bool(any('graph' in v for v in getattr(tr, '_graphs', {}).values())),
+                         'optimizer': type(tr.optimizer).__module__ + '.' + type(tr.optimizer).__name__}
         except Exception as e:                                  # noqa: BLE001 - a mode that cannot run is reported, not fatal
             res[mode] = {'error': repr(e)[:300]}
     res.update({'unit': 'audio-s/s', 'n_gpus': 1, 'steps': steps, 'dtype': 'bf16 autocast around the model, fp32 features / loss',
                 'workload': 'configs[1] (32 x 2 s, conv_separator_voicebank, Adam) with the step written against the reference\'s API only: '
                             'Trainer.forward override, STFT.transform (magnitude and phase) x 2 + LogMelSpectrogram inside forward, torch.matmul / '
                             'log / clamp on `mel_filter` for the mel of the estimate, F.l1_loss x 2 - what a user gets who switches the import and '
-                            'changes nothing else (round 6: the model hands out its estimate as a deferred tensor, pytorch_sound_amd/deferred.py - those torch '
+                            'changes nothing else = the `default` entry (Trainer.graph_steps = \'auto\' captures a step whose forward() is free of host-side randomness / step-count reads, a stock torch.optim.Adam is adopted; `eager` / `graph_steps`: the switch set by hand) (round 6: the model hands out its estimate as a deferred tensor, pytorch_sound_amd/deferred.py - those torch '
                             'ops are recorded and resolve to the fused loss node, and STFT.transform hands out its magnitude bin-fastest (N, F, K) as a deferred tensor standing for (N, K, F), the phase on first use; gc.freeze() after the first steps ends the 50-120 ms cyclic-GC steps of the '
                             'eager loop); the headline `value` is the same step on the library\'s prepare() / (N, F, K) / fused-loss API'})
     return res

@@ -192,6 +192,35 @@ class Trainer:
                 from pytorch_sound_amd import cl
                 cl.NODE_GRANULARITY = 'block'
 
+    # `step` is a plain attribute in the reference; here reads are noticed while forward() runs under graph_steps = 'auto'
+    @property
+    def step(self):
+        if self.__dict__.get('_watch_forward'):
+            self.__dict__['_step_read_in_forward'] = True
+        return self.__dict__.get('_step', 0)
+
+    @step.setter
+    def step(self, v):
+        self.__dict__['_step'] = v
+
+    def _maybe_adopt_optimizer(self):
+        if self._opt_adopted is not None:
+            return
+        self._opt_adopted = False
+        opt = self.optimizer
+        if not self.adopt_optimizer or type(opt) not in (torch.optim.Adam, torch.optim.AdamW) or 'step' in opt.__dict__:
+            return                                    # (an LR scheduler patched the instance's step(): leave it alone)
+        from pytorch_sound_amd import optim as poptim
+        for g in opt.param_groups:
+            if (g.get('amsgrad') or g.get('maximize') or g.get('differentiable') or g.get('capturable')
+                    or any(isinstance(g[k], torch.Tensor) for k in ('lr', 'eps', 'weight_decay')) or any(isinstance(b, torch.Tensor) for b in g['betas'])
+                    or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in g['params'])):
+                return
+        opt.__class__ = poptim.AdamW if type(opt) is torch.optim.AdamW else poptim.Adam
+        opt._plans = {}
+        self._opt_adopted = True
+        self._log('optimizer %s adopted: its steps run as one HIP launch (pytorch_sound_amd.optim)' % type(opt).__name__)
+
     # ------------------------------------------------------------------------------------------
     @property
     def _bare_model(self) -> nn.Module:
@@ -212,7 +241,24 @@ class Trainer:
         """self.forward(...) with deferred tensors resolved (deferred.py: a loss written with torch ops on a model's deferred estimate becomes
         the fused loss node here; anything else in `meta` the plain tensor it stands for)"""
         from pytorch_sound_amd.deferred import Deferred, resolve
-        loss, meta = self.forward(*inputs, is_logging=is_logging)
+        watch = (self.graph_steps == 'auto' and self._graph_auto_ok is None and torch.cuda.is_available()
+                 and not torch.cuda.is_current_stream_capturing())
+        if watch:
+            import random
+            before = (hash(random.getstate()), hash(np.random.get_state()[1].tobytes()), hash(torch.get_rng_state().numpy().tobytes()))
+            self.__dict__['_watch_forward'], self.__dict__['_step_read_in_forward'] = True, False
+        try:
+            loss, meta = self.forward(*inputs, is_logging=is_logging)
+        finally:
+            if watch:
+                self.__dict__['_watch_forward'] = False
+        if watch:
+            after = (hash(random.getstate()), hash(np.random.get_state()[1].tobytes()), hash(torch.get_rng_state().numpy().tobytes()))
+            why = ('forward() reads self.step' if self.__dict__.get('_step_read_in_forward') else
+                   'forward() draws host-side random numbers' if after != before else None)
+            if why is not None:
+                self._graph_auto_ok = False
+                self._log("graph_steps = 'auto': %s - the steps stay eager (set graph_steps = True to capture anyway)" % why)
         if isinstance(loss, Deferred):
             real = resolve(loss)
             if meta:
@@ -486,8 +532,22 @@ class Trainer:
     # copy, the per-bucket backward hooks are deferred to one all-reduce after the replay).  Requirements:
     # CUDA inputs, no scheduler, an optimizer with the found_inf protocol (fused Adam/AdamW/SGD), a forward()
     # free of host synchronisation.  Logging steps and the first `graph_warmup` steps of a signature run eagerly.
-    graph_steps = False
+    #
+    # graph_steps = 'auto' (default, round 6): capture when it is SAFE to - no gradient reducer (a data-parallel run opts in with True, all
+    # ranks alike), and during the eager warm-up steps forward() neither consumed host-side randomness (python `random`, numpy, torch's
+    # CPU generator) nor read `self.step`: a replayed step repeats the HOST-side decisions of the captured call, so a forward that draws
+    # a crop on the host or anneals a weight by the step count must keep running.  A capture that fails (a host synchronisation inside
+    # forward: `.item()`, a pageable copy) is logged once and the Trainer stays eager.  What cannot be detected: side effects of forward()
+    # on Python state (appending to a list every step) - such a Trainer sets graph_steps = False.  True: always capture (errors raise);
+    # False: never.
+    graph_steps = 'auto'
     graph_warmup = 3
+    _graph_auto_ok = None          # 'auto': None undecided / True / False (stay eager)
+    # Trainer adopts a stock `torch.optim.Adam` / `AdamW` handed to it (exact types, amsgrad / maximize / capturable off, fp32 HIP
+    # parameters): the instance keeps its identity, param_groups and state, its class becomes pytorch_sound_amd.optim.Adam / AdamW - one
+    # launch per step, on-device NaN skip, capturable steps (trainer.py:215-216 calls whatever optimizer the recipe built).
+    adopt_optimizer = True
+    _opt_adopted = None
     # (not in the reference) a prepare() that writes its outputs into persistent buffers of its own and returns those same
     # tensors every step may say so: the captured graph then reads them where they are (no copy into graph-owned inputs per step)
     static_prepare = False
@@ -507,7 +567,23 @@ class Trainer:
                 st['seen'] += 1
                 self._trim_graph_cache()
                 return False
-            self._capture(st, batch)
+            if self.graph_steps == 'auto':
+                try:
+                    self._capture(st, batch)
+                    self._graph_auto_ok = True
+                except Exception as e:                 # noqa: BLE001 - a forward() that cannot be captured: stay eager, say why once
+                    self._graph_auto_ok = False
+                    self._graphs.pop(sig, None)
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:                  # noqa: BLE001
+                        pass
+                    for p in self._bare_model.parameters():
+                        p.grad = None
+                    self._log("graph_steps = 'auto': the step could not be captured (%s) - the steps stay eager" % repr(e)[:200])
+                    return False
+            else:
+                self._capture(st, batch)
             self._trim_graph_cache()
         for dst, src in zip(st['inputs'], batch):
             if src.data_ptr() != dst.data_ptr():           # static_prepare: already there
@@ -692,19 +768,21 @@ class Trainer:
     _gc_freeze_after = 4
 
     def _maybe_freeze_gc(self):
-        if self.gc_freeze and not Trainer._gc_frozen:
+        if self.gc_freeze and not self._gc_frozen:             # (per Trainer: what a later Trainer of the process builds is frozen after ITS first steps)
             self._steps_seen = getattr(self, '_steps_seen', 0) + 1
             if self._steps_seen > self._gc_freeze_after:
                 import gc
                 gc.collect()
                 gc.freeze()
-                Trainer._gc_frozen = True
+                self._gc_frozen = True
 
     def train(self, step: int):
         self._maybe_freeze_gc()
         log_flag = step % self.log_interval == 0
         batch = self._take_train_batch()
-        if self.graph_steps and not log_flag and self._train_graph(step, batch):
+        self._maybe_adopt_optimizer()
+        use_graph = self.graph_steps is True or (self.graph_steps == 'auto' and self._graph_auto_ok is not False and self._reducer is None)
+        if use_graph and not log_flag and self._train_graph(step, batch):
             return
         if self._reducer is not None:
             self._reducer.zero_grad()
