@@ -381,7 +381,7 @@ def gpu_bench(args):
         roofline['frac_copy'] = roofline_copy['frac']
         roofline['note'] = ('frac: the step\'s STFT kernel (N, F, K) on 1024 clips x 2 s; frac_config5: configs[4] (4096/1024, 32 x 30 s) in the same '
                             'layout (full entry: roofline_config5); frac_nkf / frac_config5_nkf: the same transforms writing the reference\'s (N, K, F) '
-                            '(roofline_nkf, roofline_config5_nkf).  Every frac is the mean over 32 back-to-back launches behind >= 80 ms of untimed '
+                            '(roofline_nkf, roofline_config5_nkf).  Every frac is the mean over 64 back-to-back launches behind >= 150 ms of untimed '
                             'back-to-back launches (SUSTAINED at the running clock: an idle MI355X needs 30-40 ms of work to leave its ~100 MHz idle clock; '
                             'first_launch_us / ramp8_launch_us = the first launches out of idle, best / worst of the 32 beside it; frac_copy = a plain copy of the same bytes under the same timing).  `traffic` fields are RECORDED counter passes (profiles/stft_pmc.json, rocprofv3 '
                             '--pmc in separate runs), not measured in this run')
@@ -734,8 +734,8 @@ def config_bench(args):
     return out
 
 
-SUSTAINED_LAUNCHES = 32      # back-to-back launches behind every roofline figure (a burst of 8 flattered config 5 by 20 %)
-SUSTAINED_WARM_S = 0.08      # untimed back-to-back launches in front of them.  An idle MI355X sits at sclk ~100 MHz and takes ~30-40 ms of
+SUSTAINED_LAUNCHES = 64      # back-to-back launches behind every roofline figure (a burst of 8 flattered config 5 by 20 %)
+SUSTAINED_WARM_S = 0.15      # untimed back-to-back launches in front of them.  An idle MI355X sits at sclk ~100 MHz and takes ~30-40 ms of
                              # continuous work to reach its running clock (tools/r06/series.py, profiles/r06_launch_series.txt: the n = 1024 kernel
                              # reads 150-165 us for its first 48 launches out of idle, 111-113 us from launch ~250 on and stays there for 1024
                              # launches; a plain copy of the same bytes 102-103 us throughout) - 8 untimed launches (round 5 / the first round-6
