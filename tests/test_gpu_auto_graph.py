@@ -106,3 +106,47 @@ def test_explicit_switch_and_non_adoptable_optimizers():
     assert type(tr.optimizer) is torch.optim.Adam and not tr._opt_adopted                   # amsgrad: left alone
     tr, _ = _trainer(plain, opt_cls=lambda p, lr: torch.optim.SGD(p, lr=lr))
     assert type(tr.optimizer) is torch.optim.SGD
+
+
+def test_resume_with_an_adopted_optimizer(tmp_path):
+    """save() / load() round trip of a Trainer whose stock torch.optim.Adam was adopted: the resumed run continues the moments and step counts
+    (a fresh stock optimizer loads the checkpoint, is adopted again) and ends where the uninterrupted run ends"""
+    from pytorch_sound_amd.trainer import Trainer, LogType
+
+    class T(Trainer):
+        def forward(self, x, y, is_logging=False):
+            loss = F.mse_loss(self.model(x), y)
+            return loss, {'loss': (loss, LogType.SCALAR)}
+
+    data = _data(10)
+
+    def make(save_dir):
+        net = _net()
+        tr = T(net, torch.optim.Adam(net.parameters(), lr=1e-2), data, data[:1], max_step=10, valid_max_step=1, save_interval=10 ** 6,
+               log_interval=10 ** 6, save_dir=str(save_dir), save_prefix='r', seed=1)
+        tr.graph_steps = False                       # (eager: the resumed Trainer sees the batches in the same order)
+        net.train()
+        return tr, net
+
+    def steps(tr, a, b):
+        for i in range(a, b + 1):
+            tr.step = i
+            x, y = data[i - 1]
+            tr.optimizer.zero_grad()
+            loss, _ = tr._forward_resolved(x, y)
+            loss.backward()
+            tr._maybe_adopt_optimizer()
+            tr.optimizer.step()
+
+    tr, net = make(tmp_path / 'a')
+    steps(tr, 1, 10)
+    want = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    tr, net = make(tmp_path / 'b')
+    steps(tr, 1, 5)
+    tr.save(5)
+    tr2, net2 = make(tmp_path / 'b')                 # loads the step-5 checkpoint in its constructor
+    assert tr2.step == 5
+    steps(tr2, 6, 10)
+    assert tr2._opt_adopted
+    for k, v in net2.state_dict().items():
+        assert float((v.cpu() - want[k]).abs().max()) <= 1e-6 * max(1.0, float(want[k].abs().max())), k
