@@ -568,9 +568,16 @@ class Trainer:
                 self._trim_graph_cache()
                 return False
             if self.graph_steps == 'auto':
+                # variable-length batches (a bucketed loader) bring a new input signature every few steps: a capture costs ~0.1 s and pays only
+                # when its signature comes back - once 8 signatures are captured and each was replayed fewer than 8 times on average, new
+                # signatures run eagerly (the captured ones keep replaying)
+                caps, reps = getattr(self, '_auto_caps', 0), getattr(self, '_auto_replays', 0)
+                if caps >= 8 and reps < 8 * caps:
+                    return False
                 try:
                     self._capture(st, batch)
                     self._graph_auto_ok = True
+                    self._auto_caps = caps + 1
                 except Exception as e:                 # noqa: BLE001 - a forward() that cannot be captured: stay eager, say why once
                     self._graph_auto_ok = False
                     self._graphs.pop(sig, None)
@@ -589,6 +596,7 @@ class Trainer:
             if src.data_ptr() != dst.data_ptr():           # static_prepare: already there
                 dst.copy_(src, non_blocking=True)
         st['graph'].replay()
+        self._auto_replays = getattr(self, '_auto_replays', 0) + 1
         self._stage_overlapped()                       # the next batch's prepare(): side stream, next to this step's optimizer launch
         if self._reducer is not None and st.get('ddp') in ('events', 'capture'):
             # the captured backward filled the flat buckets itself and marked where each is complete: bucket i is all-reduced
