@@ -416,6 +416,11 @@ int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, cons
  * accumulation pass over both tensors disappears. */
 int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                            int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
+/* ... or with gx = (gx_mask > 0) ? w^T gy' : 0, gx_mask (N, Cin, T; NULL: none; not together with gx_addend): x is the output of a ReLU
+ * (Conv1d -> ReLU -> Conv1d, modules.py:93-95; gx_mask = x) and gx is wanted for the ReLU's input.  The layer before the ReLU then calls
+ * with ymask = NULL: its two GEMMs and its bias sum read the gradient alone instead of gradient + mask. */
+int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T, int bf16,
+                          const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
                  int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,

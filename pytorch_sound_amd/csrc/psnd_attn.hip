@@ -46,6 +46,9 @@ struct GemmParams {
     int tiles_x, tiles_y, tiles_z;
     const float *addend;         // null, or a tensor indexed like C: C = A B + addend (the residual branch's gradient folded into the
                                  // input-gradient GEMM of the branch's first projection: no separate accumulation pass)
+    const float *omask;          // null, or a tensor indexed like C: C = omask > 0 ? A B : 0 - the input of this projection is the output of a
+                                 // ReLU (the feed-forward pair, modules.py:93-95): the ReLU's backward rides in the epilogue of the GEMM that
+                                 // PRODUCES its gradient, and the two GEMMs behind the ReLU read that gradient without a mask (round 6)
 };
 
 // logical tile (x, y, z) of workgroup L; false = padding workgroup (the numbering is padded to whole groups of 8 outer tiles)
@@ -156,9 +159,10 @@ __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&a
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float ad[16];
-            if (p.addend) {                      // all sixteen loads of the block in flight before its first store (C and addend may alias
+            const float *side = p.addend ? p.addend : p.omask;      // never both (psnd_linear1x1_bwd_ex refuses)
+            if (side) {                          // all sixteen loads of the block in flight before its first store (C and addend may alias
                                                  // as far as hipcc knows: next to the stores every load would be waited for in turn)
-                const float *ap = p.addend + (C - p.C) + coff;
+                const float *ap = side + (C - p.C) + coff;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 64 + t * 32 + rho(r, half);
@@ -173,6 +177,7 @@ __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&a
                     if (p.bias) v += p.bias[m];
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     if (p.addend) v += ad[r];
+                    else if (p.omask) v = ad[r] > 0.f ? v : 0.f;
                     C[(long long)m * p.sCm + coff] = v;
                 }
             }
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(512) void rowsum4_kernel(const float *g, const floa
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i0 + 512 * u >= items) continue;
-            if (MASK) acc += (m[u].x > 0.f ? v[u].x : 0.f) + (m[u].y > 0.f ? v[u].y : 0.f) + (m[u].z > 0.f ? v[u].z : 0.f) + (m[u].w > 0.f ? v[u].w : 0.f);
+            if (MASK) acc += ((m[u].x > 0.f ? v[u].x : 0.f) + (m[u].y > 0.f ? v[u].y : 0.f)) + ((m[u].z > 0.f ? v[u].z : 0.f) + (m[u].w > 0.f ? v[u].w : 0.f));   // same grouping as below
             else acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
         }
     }
@@ -1538,16 +1543,26 @@ extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int6
 }
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
-extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                      int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
+extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                     int bf16, const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias,
+                                     void *stream);
 extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                   int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
-    return psnd_linear1x1_bwd_acc(gy, ymask, x, w, N, Cin, Cout, T, bf16, nullptr, gx, gw, gw_part, gbias, stream);
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, nullptr, nullptr, gx, gw, gw_part, gbias, stream);
 }
 // ... with gx = W^T gy' + gx_addend (N, Cin, T): the gradient that reaches x along another branch (a residual connection) rides in the
 // GEMM's epilogue instead of a separate accumulation pass over both tensors
 extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                       int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, gx_addend, nullptr, gx, gw, gw_part, gbias, stream);
+}
+// ... or with gx = (gx_mask > 0) ? W^T gy' : 0, gx_mask (N, Cin, T): x is the output of a ReLU (gx_mask = x itself, or the ReLU's output
+// wherever it is kept) and gx is wanted for the ReLU's INPUT - the layer before the ReLU then takes gx as it is (ymask = null there: its two
+// GEMMs and its bias sum read one tensor instead of two).  Not together with gx_addend.
+extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                     int bf16, const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias,
+                                     void *stream) {
+    if (gx_addend && gx_mask) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gx_addend and gx_mask exclude each other");
     if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
     if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
@@ -1556,7 +1571,7 @@ extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const
     int rc = PSND_OK;
     if (gx) {
         GemmParams p = {};
-        p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask, p.addend = gx_addend;
+        p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask, p.addend = gx_addend, p.omask = gx_mask;
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
         p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;

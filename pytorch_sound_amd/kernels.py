@@ -451,6 +451,27 @@ class ResidualLink:
         return g
 
 
+RELU_LINKS = _sw.lab('PSND_RELU_LINKS', '1') == '1'              # 0: each GEMM behind the ReLU masks its operand itself (A/B)
+
+
+class ReluLink:
+    """Conv1d -> ReLU -> Conv1d (PointwiseFeedForward, modules.py:93-95) as two Linear1x1 nodes: the first one's backward would read
+    its incoming gradient together with the ReLU's output as a mask in both of its GEMMs and its bias sum (two 169 MB tensors each at 32
+    clips x 1292 frames x 1024 channels).  With a link the SECOND node, which produces that gradient and holds the ReLU's output as its
+    input, zeroes it where the ReLU was off in its GEMM's epilogue (psnd_linear1x1_bwd_ex, gx_mask), says so here, and the first node
+    reads the gradient alone.  The values are the same either way (a masked element is an exact zero in both)."""
+
+    def __init__(self):
+        self.consumer = False      # the second node was recorded on the first one's output and will produce a gradient for it
+        self.y = None              # (address, shape) of the ReLU's output as the first node returned it: the second node checks that ITS
+                                   # input is that tensor (no reference: the output's grad_fn holds the link)
+        self.masked = False        # set by the second node's backward: the gradient arrives masked
+
+    def take(self) -> bool:
+        m, self.masked = self.masked, False
+        return m
+
+
 class GroupNorm1(torch.autograd.Function):
     """y = GroupNorm(1, C)(x + res) [-> ReLU]: statistics over (C x T) per sample (modules.py:58, :114-116)."""
 
@@ -531,11 +552,19 @@ class Linear1x1(torch.autograd.Function):
     masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1); output and gradients fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu, bf16=False, link=None):
+    def forward(ctx, x, w, bias, relu, bf16=False, link=None, relu_link=None):
         _need_cuda(x, 'input')
         ctx.link = None
         if link is not None and ctx.needs_input_grad[0]:
             ctx.link, link.consumer = link, True
+        # relu_link: this node is the one BEFORE the ReLU (relu=True: it publishes its output) or the one AFTER it (its input is that
+        # output, and a gradient for it is wanted)
+        ctx.relu_out = ctx.relu_in = None
+        if relu_link is not None and RELU_LINKS:
+            if relu:
+                ctx.relu_out = relu_link
+            elif relu_link.y == (x.data_ptr(), tuple(x.shape)) and x.is_contiguous() and x.dtype == torch.float32 and ctx.needs_input_grad[0]:
+                ctx.relu_in, relu_link.consumer = relu_link, True
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
         N, Cin, T = x.shape
@@ -552,12 +581,17 @@ class Linear1x1(torch.autograd.Function):
         from . import cl
         cl.note_param_use(ctx, w, bias)
         ctx.save_for_backward(x, w2, y if relu else None)
+        if ctx.relu_out is not None:
+            ctx.relu_out.y = (y.data_ptr(), tuple(y.shape))
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w2, y = ctx.saved_tensors
         gy = gy.contiguous()
+        if ctx.relu_out is not None and ctx.relu_out.take():
+            y = None                                                    # the gradient arrives masked (ReluLink)
+        xmask = x if ctx.relu_in is not None else None
         N, Cin, T = x.shape
         Cout = w2.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
@@ -585,13 +619,13 @@ class Linear1x1(torch.autograd.Function):
                 cl.GRAD_SINK.note_producer(ctx.params, side)
         with torch.cuda.device(dev):
             if side is None:
-                check(lib().psnd_linear1x1_bwd_acc(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(gx), ptr(gw),
-                                                   ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(xmask), ptr(gx),
+                                                  ptr(gw), ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
             else:
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)                          # gy is complete on the main stream
-                check(lib().psnd_linear1x1_bwd_acc(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(gx), None, None,
-                                                   None, stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(xmask), ptr(gx),
+                                                  None, None, None, stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 with torch.cuda.stream(side):
                     check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), None, ptr(gw), ptr(part),
                                                    ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
@@ -599,8 +633,10 @@ class Linear1x1(torch.autograd.Function):
                     if t is not None:
                         t.record_stream(side)
                 cl._join_side_at_end_of_backward(dev, side)
+        if xmask is not None and need_x:
+            ctx.relu_in.masked = True
         cl.consume_param_use(ctx)
-        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None, None
 
 
 class Im2Col(torch.autograd.Function):

@@ -364,3 +364,75 @@ def test_residual_link_gradient_equals_autograd_accumulation():
     a, b = run(True), run(False)
     for u, v in zip(a, b):
         assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+@pytest.mark.parametrize('shape', [(3, 64, 120), (2, 96, 173), (1, 32, 7)])
+def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
+    """Conv1d -> ReLU -> Conv1d of PointwiseFeedForward (modules.py:93-95): the ReLU's backward in the epilogue of the second projection's
+    input-gradient GEMM (psnd_linear1x1_bwd_ex, gx_mask) against each GEMM of the first projection masking its operand itself.  On the
+    pair of projections alone the numbers are THE SAME (a masked element is an exact zero either way), with and without a gradient wanted
+    for the input; the whole block (its GroupNorm sums with atomics) agrees to rounding, and with the torch formulation in fp32 at the
+    GEMM's tolerance."""
+    from pytorch_sound_amd.models import modules as M
+    from pytorch_sound_amd import kernels as K
+    import torch.nn.functional as F
+    dev = _dev()
+    torch.manual_seed(2)
+    n, c, t = shape
+    ffn = M.PointwiseFeedForward(c, 0.0).to(dev)
+    x0, w = torch.randn(n, c, t, device=dev), torch.randn(n, c, t, device=dev)
+    seen = []
+    orig = K.ReluLink.take
+
+    def take(self):
+        seen.append(self.masked)
+        return orig(self)
+    monkeypatch.setattr(K.ReluLink, 'take', take)
+    params = list(ffn.ff.parameters())
+
+    def pair(on, need_x):
+        monkeypatch.setattr(K, 'RELU_LINKS', on)
+        x = x0.clone().requires_grad_(need_x)
+        link = K.ReluLink()
+        h = K.Linear1x1.apply(x, ffn.ff[0].weight, ffn.ff[0].bias, True, bf16, None, link)
+        y = K.Linear1x1.apply(h, ffn.ff[2].weight, ffn.ff[2].bias, False, bf16, None, link)
+        (y * w).sum().backward()
+        g = ([x.grad.clone()] if need_x else []) + [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        return g
+
+    for need_x in (True, False):
+        del seen[:]
+        a = pair(True, need_x)
+        assert seen == [True], 'the second projection did not mask the gradient it produced'
+        b = pair(False, need_x)
+        assert len(a) == len(b) == 4 + int(need_x)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+
+    def block(on):
+        monkeypatch.setattr(K, 'RELU_LINKS', on)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16):
+            z = ffn(x)
+        (z.float() * w).sum().backward()
+        g = [x.grad.clone()] + [p.grad.clone() for p in ffn.parameters()]
+        for p in ffn.parameters():
+            p.grad = None
+        return g
+
+    del seen[:]
+    a, b = block(True), block(False)
+    assert seen == [True]
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-7
+    if not bf16:
+        x = x0.clone().requires_grad_(True)
+        h = ffn.ff[2](F.relu(ffn.ff[0](x)))
+        z = F.relu(F.group_norm(h + x, 1, ffn.layernorm.weight, ffn.layernorm.bias, ffn.layernorm.eps))
+        (z * w).sum().backward()
+        ref = [x.grad] + [p.grad for p in ffn.parameters()]
+        for u, v in zip(a, ref):
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-6
