@@ -1009,42 +1009,56 @@ struct BTile {
     static constexpr int DP = HDP + 8;           // tT row pitch (bf16): 144 B at HDP = 64 - 16-byte aligned rows, conflict-free b128 reads
     static constexpr int TPB = 36;               // tD row pitch (bf16): 72 B - 8-byte aligned, the 32 rows of a read on 64 distinct banks
     static constexpr int TT = 32 * DP, TD = HDP * TPB;
+    static constexpr int NP = HDP > 64 ? HDP / 64 : 1;      // passes of the 256 threads over a tile: 64 rows x 32 columns a pass
 };
-// the thread's 2 x 2 blocks of a (HDP x 32) tile: v[u] = { X[dd][t], X[dd][t+1], X[dd+1][t], X[dd+1][t+1] }, t = t0 + 2 (tid & 15),
-// dd = 2 (tid >> 4) + 32 u; out-of-range elements read as zero (buffer loads, no branch)
+// the thread's 2 x 4 blocks of a (HDP x 32) tile: v[u] = { X[dd][t .. t + 3], X[dd + 1][t .. t + 3] }, t = t0 + 4 (tid & 7),
+// dd = 2 (tid >> 3) + 64 u.  A tile INSIDE the matrix (d == HDP, t0 + 32 <= T: all but the last one at the model's sizes) takes two
+// 16-byte loads per block whose per-thread offset never changes - the tile's position rides in the instruction's scalar offset, no
+// address arithmetic or range selects in the loop (round 6: the loops are bound by their vector ALU work; rows are 4-byte aligned only,
+// T = 1292 - gfx9 memory takes that); any other tile element loads that read zeros outside the matrix.
 template <int HDP>
-__device__ __forceinline__ void fetch_tile_b(rsrc_t src, long long T, int d, int t0, int tid, float (&v)[HDP / 32][4]) {
-    const int t = t0 + 2 * (tid & 15);
+__device__ __forceinline__ void fetch_tile_b(rsrc_t src, long long T, int d, int t0, int tid, float (&v)[BTile<HDP>::NP][8]) {
+    const int tl = 4 * (tid & 7);
+    const bool inside = d == HDP && t0 + 32 <= (int)T;
 #pragma unroll
-    for (int u = 0; u < HDP / 32; ++u) {
-        const int dd = 2 * (tid >> 4) + 32 * u;
+    for (int u = 0; u < BTile<HDP>::NP; ++u) {
+        const int dd = 2 * (tid >> 3) + 64 * u;
+        if (inside) {
+            const unsigned voff = dd < HDP ? (unsigned)(dd * (int)T + tl) * 4u : kOOB;
+            const f32x4_t a = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(src, (int)voff, t0 * 4, 0));
+            const f32x4_t c = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(src, (int)(voff + (unsigned)T * 4u), t0 * 4, 0));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int te = t + (e & 1), de = dd + (e >> 1);
-            v[u][e] = buf_f32(src, (te < T && de < d) ? (unsigned)(de * (int)T + te) * 4u : kOOB);
+            for (int e = 0; e < 4; ++e) v[u][e] = a[e], v[u][4 + e] = c[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int te = t0 + tl + (e & 3), de = dd + (e >> 2);
+                v[u][e] = buf_f32(src, (te < T && de < d) ? (unsigned)(de * (int)T + te) * 4u : kOOB);
+            }
         }
     }
 }
 template <int HDP, bool WT, bool WD>
-__device__ __forceinline__ void commit_tile_b(unsigned short *tT, unsigned short *tD, int tid, const float (&v)[HDP / 32][4]) {
+__device__ __forceinline__ void commit_tile_b(unsigned short *tT, unsigned short *tD, int tid, const float (&v)[BTile<HDP>::NP][8]) {
     using B = BTile<HDP>;
-    const int tl = 2 * (tid & 15);
+    const int tl = 4 * (tid & 7);
+    if (HDP < 64 && tid >= 4 * HDP) return;      // (HDP = 32: the tile has 32 rows, the upper 128 threads hold zeros)
 #pragma unroll
-    for (int u = 0; u < HDP / 32; ++u) {
-        const int dd = 2 * (tid >> 4) + 32 * u;
+    for (int u = 0; u < B::NP; ++u) {
+        const int dd = 2 * (tid >> 3) + 64 * u;
         if constexpr (WT) {
-            *reinterpret_cast<unsigned *>(tT + tl * B::DP + dd) = pack2_bf16(v[u][0], v[u][2]);
-            *reinterpret_cast<unsigned *>(tT + (tl + 1) * B::DP + dd) = pack2_bf16(v[u][1], v[u][3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned *>(tT + (tl + e) * B::DP + dd) = pack2_bf16(v[u][e], v[u][4 + e]);
         }
         if constexpr (WD) {
-            *reinterpret_cast<unsigned *>(tD + dd * B::TPB + tl) = pack2_bf16(v[u][0], v[u][1]);
-            *reinterpret_cast<unsigned *>(tD + (dd + 1) * B::TPB + tl) = pack2_bf16(v[u][2], v[u][3]);
+            *reinterpret_cast<uint2 *>(tD + dd * B::TPB + tl) = make_uint2(pack2_bf16(v[u][0], v[u][1]), pack2_bf16(v[u][2], v[u][3]));
+            *reinterpret_cast<uint2 *>(tD + (dd + 1) * B::TPB + tl) = make_uint2(pack2_bf16(v[u][4], v[u][5]), pack2_bf16(v[u][6], v[u][7]));
         }
     }
 }
 template <int HDP, bool WT, bool WD>
 __device__ __forceinline__ void load_tile_b(rsrc_t src, long long T, int d, int t0, unsigned short *tT, unsigned short *tD, int tid) {
-    float v[HDP / 32][4];
+    float v[BTile<HDP>::NP][8];
     fetch_tile_b<HDP>(src, T, d, t0, tid, v);
     commit_tile_b<HDP, WT, WD>(tT, tD, tid, v);
 }
@@ -1115,13 +1129,17 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
     bf16x8_t qf[HDP / 16];
     load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     const int ntile = (p.T + 31) / 32;
-    float pk[HDP / 32][4], pv[HDP / 32][4];
+    float pk[B::NP][8], pv[B::NP][8];
     if constexpr (!ATT) {
         // ---- ONE pass when the probabilities themselves are not returned (round 4): running column maximum and sum, the accumulator
         // rescaled when the maximum moves (O *= exp(m_old - m_new): 32 multiplies per 32 x 32 tile) - the second K^T Q product of the
         // two-pass form, its exponentials and its K tile loads are gone.  The statistics written for the backward are the same
         // (global maximum, 1 / sum).
-        float mx = -INFINITY, sum = 0.f;
+        // Round 6: the loop is bound by its vector ALU work (248 instructions next to 8 matrix ones), so: the maximum runs over the RAW
+        // scores and `scale` rides in the exponential's FMA (exp2(s c - m c), c = scale log2(e): the form the backward kernels recompute
+        // the probabilities in); a tile without a masked key (the key bits are wave-uniform) skips the sixteen bit tests and selects.
+        float mx = -INFINITY, sum = 0.f;                          // mx: running maximum of the raw scores
+        const float cexp = p.scale * 1.44269504088896341f;
         f32x16 O[HDP / 32];
 #pragma unroll
         for (int mt = 0; mt < HDP / 32; ++mt)
@@ -1138,28 +1156,30 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
             __syncthreads();
             fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
             fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
-            const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+            const unsigned bad = __builtin_amdgcn_readfirstlane(it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane));
             f32x16 sn;
             mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
-            float tm = -INFINITY;
+            if (bad != 0) {
+                const unsigned badl = bad >> (4 * kk);               // bit rho(r, 0) <-> register r
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = (bad >> rho(r, kk)) & 1u ? -INFINITY : s[r] * p.scale;
-                s[r] = v;
-                tm = fmaxf(tm, v);
+                for (int r = 0; r < 16; ++r) s[r] = (badl & (1u << rho(r, 0))) ? -INFINITY : s[r];
             }
+            float tm = fmaxf(s[0], s[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) tm = fmaxf(tm, fmaxf(s[r], s[r + 1]));
             tm = fmaxf(tm, __shfl_xor(tm, 32, 64));            // the column's 32 keys sit in the two half-waves
             const float m2 = fmaxf(mx, tm);
             const float m2s = m2 > -INFINITY ? m2 : 0.f;
-            const float alpha = __expf(mx - m2s);             // (mx = -inf: 0, and O is still 0)
-            float asum = 0.f;
+            const float alpha = __builtin_amdgcn_exp2f((mx - m2s) * cexp);      // (mx = -inf: 0, and O is still 0)
+            const float mc = m2s * cexp;
+            f32x2_v as2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(s[r] - m2s);
-                s[r] = e;
-                asum += e;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_v e = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cexp, -mc)), __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], cexp, -mc))};
+                s[r] = e[0], s[r + 1] = e[1];
+                as2 += e;
             }
-            sum = sum * alpha + asum;
+            sum = sum * alpha + (as2[0] + as2[1]);
             mx = m2;
 #pragma unroll
             for (int mt = 0; mt < HDP / 32; ++mt)
@@ -1172,6 +1192,7 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
             commit_tile_b<HDP, false, true>(nullptr, sV[(it + 1) & 1], tid, pv);
             s = sn;
         }
+        mx *= p.scale;                                             // the statistics keep the maximum of the SCALED scores
         sum += __shfl_xor(sum, 32, 64);
         const bool qpad = tq < p.T && mrow && mrow[tq];
         const float inv = 1.f / sum;
@@ -1319,40 +1340,59 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         for (int i = 0; i < 16; ++i) dK[mt][i] = 0.f, dV[mt][i] = 0.f;
     const int ntile = (p.T + 31) / 32;
     const float cexp = p.scale * 1.44269504088896341f;
-    float pq[HDP / 32][4], pg[HDP / 32][4];
-    auto stage = [&](int it, int buf) __attribute__((always_inline)) {
+    float pq[B::NP][8], pg[B::NP][8];
+    // Per query row ONE exponent offset e0 = log2(e) max - log2(1 / sum), so that the probability is exp2(s c - e0) with c = scale log2(e)
+    // - an FMA and a v_exp_f32 per element (round 5); a dead row (padding, or past T) has e0 = +inf: exp2(-inf) = 0, no select.
+    // Round 6: the statistics of a query tile and the tile's Q / dOut elements are REQUESTED a whole iteration before they are written
+    // to LDS (registers in between): requested at the top of the iteration that writes them they were waited for on the spot - a memory
+    // latency per iteration in front of the barrier every wave of the workgroup stands at.
+    float sr[3] = {0.f, 0.f, 0.f};
+    int sflag = 0;                                               // 0: past T, 1: live row, 2: padded row
+    auto stage_fetch = [&](int it) __attribute__((always_inline)) {
+        sflag = 0;
         if (tid < 32) {
             const int t = 32 * it + tid;
-            // Round 5: per query row ONE exponent offset e0 = log2(e) max - log2(1 / sum), so that the probability is exp2(s c - e0) with
-            // c = scale log2(e) - an FMA and a v_exp_f32 per element instead of multiply, subtract, multiply, v_exp_f32, multiply and
-            // two selects; a dead row (padding, or past T) has e0 = +inf: exp2(-inf) = 0, no select.  (The loop is bound by this
-            // arithmetic: profiles/NOTEBOOK.md, ablation of round 5.)
-            f32x4_t st = {INFINITY, 0.f, 0.f, 0.f};
             if (t < p.T) {
-                const float mxq = p.stats[((long long)b * T + t) * 2], invq = p.stats[((long long)b * T + t) * 2 + 1];
-                st[0] = (mrow && mrow[t]) ? INFINITY : mxq * 1.44269504088896341f - __builtin_log2f(invq);
-                st[1] = p.delta[(long long)b * T + t];
+                sr[0] = p.stats[((long long)b * T + t) * 2], sr[1] = p.stats[((long long)b * T + t) * 2 + 1];
+                sr[2] = p.delta[(long long)b * T + t];
+                sflag = (mrow && mrow[t]) ? 2 : 1;
+            }
+        }
+    };
+    auto stage_commit = [&](int buf) __attribute__((always_inline)) {
+        if (tid < 32) {
+            f32x4_t st = {INFINITY, 0.f, 0.f, 0.f};
+            if (sflag) {
+                st[0] = sflag == 2 ? INFINITY : sr[0] * 1.44269504088896341f - __builtin_log2f(sr[1]);
+                st[1] = sr[2];
             }
             *reinterpret_cast<f32x4_t *>(&sSt[buf][4 * tid]) = st;
         }
     };
-    stage(0, 0);
+    stage_fetch(0);
+    stage_commit(0);
     load_tile_b<HDP, true, true>(Qp, T, p.d, 0, sQt[0], sQd[0], tid);
     load_tile_b<HDP, true, true>(Gp, T, p.d, 0, sGt[0], sGd[0], tid);
+    if (ntile > 1) {
+        stage_fetch(1);
+        fetch_tile_b<HDP>(Qp, T, p.d, 32, tid, pq);
+        fetch_tile_b<HDP>(Gp, T, p.d, 32, tid, pg);
+    }
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        if (it + 1 < ntile) {
-            stage(it + 1, (it + 1) & 1);
-            fetch_tile_b<HDP>(Qp, T, p.d, 32 * (it + 1), tid, pq);
-            fetch_tile_b<HDP>(Gp, T, p.d, 32 * (it + 1), tid, pg);
-        }
         const float *tS = sSt[it & 1];
         f32x16 s, dp;
         mma_tile_frag_b<HDP>(sQt[it & 1], kf, li, kk, s);        // rows: queries of the tile, column: this lane's key
         mma_tile_frag_b<HDP>(sGt[it & 1], vf, li, kk, dp);
-        if (it + 1 < ntile) {
+        if (it + 1 < ntile) {                                    // tile it + 1 (requested an iteration ago) -> LDS, tile it + 2 requested
+            stage_commit((it + 1) & 1);
             commit_tile_b<HDP, true, true>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
             commit_tile_b<HDP, true, true>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
+            if (it + 2 < ntile) {
+                stage_fetch(it + 2);
+                fetch_tile_b<HDP>(Qp, T, p.d, 32 * (it + 2), tid, pq);
+                fetch_tile_b<HDP>(Gp, T, p.d, 32 * (it + 2), tid, pg);
+            }
         }
         if constexpr (GATT) {
             float *tt = sT[wave];
@@ -1422,29 +1462,38 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     load_tile_b<HDP, true, true>(Kp, T, p.d, 0, sKt[0], sKd[0], tid);
     load_tile_b<HDP, true, false>(Vp, T, p.d, 0, sVt[0], nullptr, tid);
     fill_key_bits(s_kb, mrow, p.T, ntile, tid);
+    float pk[B::NP][8], pv[B::NP][8];                           // tile it + 1, requested a whole iteration before it is written to LDS (round 6)
+    if (ntile > 1) {
+        fetch_tile_b<HDP>(Kp, T, p.d, 32, tid, pk);
+        fetch_tile_b<HDP>(Vp, T, p.d, 32, tid, pv);
+    }
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        float pk[HDP / 32][4], pv[HDP / 32][4];
-        if (it + 1 < ntile) {
-            fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 1), tid, pk);
-            fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
-        }
-        const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
+        const unsigned bad = __builtin_amdgcn_readfirstlane(it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane));
         f32x16 s, dp;
         mma_tile_frag_b<HDP>(sKt[it & 1], qf, li, kk, s);
         mma_tile_frag_b<HDP>(sVt[it & 1], gf, li, kk, dp);
         if (it + 1 < ntile) {
             commit_tile_b<HDP, true, true>(sKt[(it + 1) & 1], sKd[(it + 1) & 1], tid, pk);
             commit_tile_b<HDP, true, false>(sVt[(it + 1) & 1], nullptr, tid, pv);
+            if (it + 2 < ntile) {
+                fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+                fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 2), tid, pv);
+            }
         }
-        const unsigned badl = bad >> (4 * kk);                       // bit rho(r, 0) <-> register r
+        if (bad != 0) {                                              // (wave-uniform: a tile without a masked key skips the bit tests and selects)
+            const unsigned badl = bad >> (4 * kk);                   // bit rho(r, 0) <-> register r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (badl & (1u << rho(r, 0))) ? -INFINITY : s[r];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = rho(r, kk);
-            const bool kdead = (badl & (1u << rho(r, 0))) != 0;
-            const float pr = __builtin_amdgcn_exp2f(kdead ? -INFINITY : __builtin_fmaf(s[r], cexp, -e0));
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cexp, -e0));     // (a masked key: exp2(-inf) = 0)
             float g = dp[r];
-            if (GATT && !(qdead || kdead)) g += p.gatt[((long long)b * T + 32 * it + row) * T + tq];
+            if constexpr (GATT) {
+                const bool kdead = (bad >> rho(r, kk)) & 1u;
+                if (!(qdead || kdead)) g += p.gatt[((long long)b * T + 32 * it + rho(r, kk)) * T + tq];
+            }
             dp[r] = pr * (g - dl);
         }
         bf16x8_t db[2];
