@@ -518,7 +518,19 @@ struct AttnParams {
     float *gkvq;                // bwd: (N, 3C, T)
     int N, H, C, T, d;          // d = C / H, the head dimension (<= HDP)
     float scale;
+    int tiles;                  // 128-column tiles per (head, clip)
 };
+
+// Workgroup -> (128-column tile, head x clip).  The tiles of one (head, clip) read the same rows in their loops - K / V (forward, query
+// gradient) or Q / dOut (key / value gradient) - so they are numbered consecutively on ONE XCD (workgroup L runs on XCD L % 8, each XCD
+// has its own L2): numbered tile-fastest across the grid they sat on all eight, and every L2 fetched every (head, clip)'s rows (round 6).
+// The launch is one-dimensional, (head x clip) padded to a multiple of 8; false = padding workgroup.
+__device__ __forceinline__ bool attn_tile(const AttnParams &p, int &tx, int &b) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    b = (j / p.tiles) * 8 + xcd;
+    tx = j - (j / p.tiles) * p.tiles;
+    return b < p.H * p.N;
+}
 
 // cooperative load of a (64 x 32) tile X[dd][t0 + c] of a (d x T) matrix into LDS [dd][TP]; elements outside the matrix read as zero
 // in two halves - fetch (global -> registers, issued BEFORE the tile in flight is multiplied) and commit (registers -> LDS, after) -
@@ -625,12 +637,14 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_kernel(AttnParams p
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     float qf[HDP / 2];
     load_frag<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     const int ntile = (p.T + 31) / 32;
@@ -840,13 +854,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];           // per query of the tile: max, 1 / sum, delta, query padded
     __shared__ float sT[4][32 * TP];                                     // per wave: a gatt tile, transposed through LDS
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tk0 = blockIdx.x * 128 + wave * 32, tk = tk0 + li;
+    const int tk0 = tx * 128 + wave * 32, tk = tk0 + li;
     const bool kbad = tk >= p.T || (mrow && mrow[tk]);
     float kf[HDP / 2], vf[HDP / 2];
     load_frag<HDP>(Kp, T, p.d, tk0, li, kk, kf);
@@ -932,13 +948,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(AttnParams p) {     
     __shared__ float sK[2][HDP * TP], sV[2][HDP * TP];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     float qf[HDP / 2], gf[HDP / 2];
     load_frag<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     load_frag<HDP>(Gp, T, p.d, tq0, li, kk, gf);
@@ -1120,12 +1138,14 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][B::TT], sV[2][B::TD];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     bf16x8_t qf[HDP / 16];
     load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     const int ntile = (p.T + 31) / 32;
@@ -1322,13 +1342,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     __shared__ __attribute__((aligned(16))) float sSt[2][32 * 4];
     __shared__ float sT[4][32 * TP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tk0 = blockIdx.x * 128 + wave * 32, tk = tk0 + li;
+    const int tk0 = tx * 128 + wave * 32, tk = tk0 + li;
     const bool kbad = tk >= p.T || (mrow && mrow[tk]);
     bf16x8_t kf[HDP / 16], vf[HDP / 16];
     load_frag_b<HDP>(Kp, T, p.d, tk0, li, kk, kf);
@@ -1438,13 +1460,15 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     __shared__ __attribute__((aligned(16))) unsigned short sKt[2][B::TT], sKd[2][B::TD], sVt[2][B::TT];
     __shared__ unsigned s_kb[KBITS_MAX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y, h = b / p.N, n = b - h * p.N;
+    int tx, b;
+    if (!attn_tile(p, tx, b)) return;
+    const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
     const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
-    const int tq0 = blockIdx.x * 128 + wave * 32, tq = tq0 + li;
+    const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     bf16x8_t qf[HDP / 16], gf[HDP / 16];
     load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
     load_frag_b<HDP>(Gp, T, p.d, tq0, li, kk, gf);
@@ -1665,6 +1689,7 @@ extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const 
 static int mha_check(const char *what, int64_t N, int H, int C, int64_t T) {
     if (N <= 0 || H <= 0 || C % H != 0 || C / H > 128) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: hidden_dim %d / heads %d: head dimensions up to 128 only", what, C, H);
     if (T <= 0 || T >= ((int64_t)1 << 24) || (int64_t)H * N > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: T=%lld, H*N=%lld", what, (long long)T, (long long)(H * N));
+    if (((int64_t)H * N + 7) / 8 * 8 * ((T + 127) / 128) > 0x7fffffff) PSND_FAIL(PSND_E_SHAPE, "%s: T=%lld, H*N=%lld: grid too large", what, (long long)T, (long long)(H * N));
     return PSND_OK;
 }
 
@@ -1676,7 +1701,8 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     AttnParams p = {};
     p.kvq = kvq, p.mask = mask, p.out = out, p.att = att, p.stats = stats;
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
-    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
+    p.tiles = (int)((T + 127) / 128);
+    const dim3 grid((unsigned)((H * N + 7) / 8 * 8 * p.tiles));
     if (bf16) {
         if (att) {
             PSND_ATTN_LAUNCH(attn_fwd_bf16_kernel, true, static_cast<hipStream_t>(stream));
@@ -1707,7 +1733,8 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     AttnParams p = {};
     p.kvq = kvq, p.mask = mask, p.stats = const_cast<float *>(stats), p.gout = gout, p.gatt = gatt, p.delta = delta, p.gkvq = gkvq;
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
-    const dim3 grid((unsigned)((T + 127) / 128), (unsigned)(H * N));
+    p.tiles = (int)((T + 127) / 128);
+    const dim3 grid((unsigned)((H * N + 7) / 8 * 8 * p.tiles));
     if (!(parts & 2)) {
     } else if (bf16) {
         if (p.gatt) {
