@@ -418,9 +418,16 @@ int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, 
                            int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
 /* ... or with gx = (gx_mask > 0) ? w^T gy' : 0, gx_mask (N, Cin, T; NULL: none; not together with gx_addend): x is the output of a ReLU
  * (Conv1d -> ReLU -> Conv1d, modules.py:93-95; gx_mask = x) and gx is wanted for the ReLU's input.  The layer before the ReLU then calls
- * with ymask = NULL: its two GEMMs and its bias sum read the gradient alone instead of gradient + mask. */
-int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T, int bf16,
-                          const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias, void *stream);
+ * with ymask = NULL: its two GEMMs and its bias sum read the gradient alone instead of gradient + mask.
+ * io_h (with bf16 != 0; 0: every tensor is fp32): 1 = gy is STORED as bf16 (2-byte elements, same shape; ymask NULL), 2 = x, gx_mask and gx
+ * are (gx_addend NULL) - the hidden tensor of that pair under torch.autocast(bfloat16): the products round their operands to bf16 when
+ * they load them, so the values multiplied are the same and the tensor and its gradient move at half the bytes.  The weight, bias and
+ * parameter gradients are always fp32. */
+int psnd_linear1x1_bwd_ex(const void *gy, const float *ymask, const void *x, const float *w, int64_t N, int Cin, int Cout, int64_t T, int bf16,
+                          int io_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part, float *gbias, void *stream);
+/* psnd_linear1x1_fwd with io_h (bf16 != 0): 1 = x is stored as bf16, 2 = y is (see psnd_linear1x1_bwd_ex); 0 = psnd_linear1x1_fwd */
+int psnd_linear1x1_fwd_ex(const void *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16, int io_h,
+                          void *y, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
                  int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,

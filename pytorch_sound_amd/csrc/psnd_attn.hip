@@ -46,6 +46,10 @@ struct GemmParams {
     int tiles_x, tiles_y, tiles_z;
     const float *addend;         // null, or a tensor indexed like C: C = A B + addend (the residual branch's gradient folded into the
                                  // input-gradient GEMM of the branch's first projection: no separate accumulation pass)
+    int a_h, b_h, c_h;           // (bf16 kernel only) the operand / the output is STORED as bf16 (2-byte elements, same indexing): the hidden
+                                 // tensor of the feed-forward pair and its gradient under autocast - the GEMMs round their operands to bf16 when
+                                 // they load them, so the stored values are the ones multiplied either way, at half the bytes (round 6).
+                                 // c_h: C and omask are bf16 (bias / addend stay fp32)
     const float *omask;          // null, or a tensor indexed like C: C = omask > 0 ? A B : 0 - the input of this projection is the output of a
                                  // ReLU (the feed-forward pair, modules.py:93-95): the ReLU's backward rides in the epilogue of the GEMM that
                                  // PRODUCES its gradient, and the two GEMMs behind the ReLU read that gradient without a mask (round 6)
@@ -143,8 +147,54 @@ __device__ __forceinline__ void gemm_commit(float *tile, int tid, const f32x4_t 
     }
 }
 
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    const f32x2_v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2_t));
+}
 // epilogue shared by both GEMM kernels: bias, relu, store (flat mode: column -> (batch, t))
+template <bool C_H = false>
 __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0, int bz) {
+    if constexpr (C_H) {             // bf16 output (and mask): no slabs, no addend
+        unsigned short *C = reinterpret_cast<unsigned short *>(p.C) + (p.flatT > 0 ? 0 : z0 * p.sCz);
+        const unsigned short *M = p.omask ? reinterpret_cast<const unsigned short *>(p.omask) + (p.flatT > 0 ? 0 : z0 * p.sCz) : nullptr;
+        const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = n0 + wn * 64 + u * 32 + li;
+            if (n >= ncols) continue;
+            long long coff = n;
+            if (p.flatT > 0) {
+                const int z = n / p.flatT;
+                coff = z * p.sCz + (n - z * p.flatT);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unsigned short mk[16];
+                if (M) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + t * 32 + rho(r, half);
+                        mk[r] = M[(long long)(m < p.M ? m : p.M - 1) * p.sCm + coff];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + t * 32 + rho(r, half);
+                    if (m < p.M) {
+                        float v = acc[t][u][r];
+                        if (p.bias) v += p.bias[m];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        if (M) v = __builtin_bit_cast(float, (unsigned)mk[r] << 16) > 0.f ? v : 0.f;
+                        C[(long long)m * p.sCm + coff] = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu);
+                    }
+                }
+            }
+        }
+        return;
+    }
     float *C = p.C + (p.zchunk > 0 ? bz * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
     const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
 #pragma unroll
@@ -272,13 +322,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 //                          ds_write_b128 - no transposing scatter into LDS
 // With 8 MFMAs of 32 cycles per 32-deep k-tile the kernel is bound by the 32 KB of fp32 operands it stages per tile, not by MFMA time.
 // ---------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
-typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
-    const f32x2_v v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2_t));
-}
 constexpr int HBK = 32, HP = 40;      // k-tile depth, LDS row pitch (bf16)
 
 // the thread's share of a (128 rows x 32 k) tile: two runs of 8 consecutive k of one row, raw fp32.  ROW_CONTIG: the 128-direction is
@@ -329,11 +372,81 @@ __device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, cons
     }
 }
 
+// ---- an operand STORED as bf16 (GemmParams a_h / b_h): half the bytes, no conversion.  The thread's share of the (128 rows x 32 k) tile is
+// eight dwords:
+//   k-contiguous source  : 8 consecutive k of rows tid / 4 and tid / 4 + 64 - one 16-byte load each, written to LDS as they are
+//   row-contiguous source: rows 2 (tid % 64) and + 1 at the 8 k of group tid / 64 - one dword load per k (the two rows are neighbours in
+//                          memory; a pair that straddles two batches of a flat column axis, or ends the matrix, takes two 2-byte loads),
+//                          the halves sorted into the two rows' 16-byte LDS writes by v_perm_b32
+// `rowoff` (row-contiguous): element offsets of the thread's two rows, < 0 = no such row.
+__device__ __forceinline__ unsigned ldg_u16(const unsigned short *p) { return *p; }
+template <bool ROW_CONTIG>
+__device__ __forceinline__ void hgemm_fetch_h(const unsigned short *base, long long s_row, long long s_k, int limrow, int limk, int orow, int ok, int tid,
+                                              const long long (&rowoff)[2], unsigned (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0u;
+    if constexpr (!ROW_CONTIG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = orow + (tid >> 2) + 64 * u, k = ok + 8 * (tid & 3);
+            if (row < limrow) {
+                const unsigned short *p = base + (long long)row * s_row + k;
+                if (k + 7 < limk) {
+                    typedef unsigned u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+                    const u32x4_u a = *reinterpret_cast<const u32x4_u *>(p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[4 * u + e] = a[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (k + e < limk) f[4 * u + (e >> 1)] |= ldg_u16(p + e) << (16 * (e & 1));
+                }
+            }
+        }
+    } else {
+        const int k = ok + 8 * (tid >> 6);
+        const bool pair = rowoff[0] >= 0 && rowoff[1] == rowoff[0] + 1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (k + e >= limk) continue;
+            const unsigned short *p = base + (long long)(k + e) * s_k;
+            if (pair) {
+                typedef unsigned u32_u __attribute__((aligned(2)));
+                f[e] = *reinterpret_cast<const u32_u *>(p + rowoff[0]);
+            } else {
+                if (rowoff[0] >= 0) f[e] = ldg_u16(p + rowoff[0]);
+                if (rowoff[1] >= 0) f[e] |= ldg_u16(p + rowoff[1]) << 16;
+            }
+        }
+    }
+}
+template <bool ROW_CONTIG>
+__device__ __forceinline__ void hgemm_commit_h(unsigned short *tile, int tid, const unsigned (&f)[8]) {
+    if constexpr (!ROW_CONTIG) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            *reinterpret_cast<uint4 *>(tile + ((tid >> 2) + 64 * u) * HP + 8 * (tid & 3)) = make_uint4(f[4 * u], f[4 * u + 1], f[4 * u + 2], f[4 * u + 3]);
+    } else {
+        const int row = 2 * (tid & 63), k = 8 * (tid >> 6);
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = __builtin_amdgcn_perm(f[2 * j + 1], f[2 * j], 0x05040100u);      // the low halves of dwords 2 j, 2 j + 1: row `row`
+            hi[j] = __builtin_amdgcn_perm(f[2 * j + 1], f[2 * j], 0x07060302u);      // the high halves: row + 1
+        }
+        *reinterpret_cast<uint4 *>(tile + row * HP + k) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4 *>(tile + (row + 1) * HP + k) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    }
+}
+
 // MASKED: a relu mask travels with an operand (input / weight gradient behind a ReLU).  Without one the two mask stages (64 registers) do not
 // exist: 3 workgroups per CU instead of 2 - the kernel is a latency chain per workgroup (8 k-steps behind barriers, operands two steps
 // ahead), so residency is what hides it, and 646 workgroups (256 -> 256 at 32 x 1292) fit the chip in ONE round instead of 1.26.
-template <bool A_MCONTIG, bool B_NCONTIG, bool MASKED>
+// DT: 1 = A is stored as bf16, 2 = B is, 4 = C (and omask) are (never together with MASKED).
+template <bool A_MCONTIG, bool B_NCONTIG, bool MASKED, int DT = 0>
 __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmParams p) {
+    static_assert(!(MASKED && DT != 0), "operand masks come with fp32 storage only");
+    constexpr bool A_H = (DT & 1) != 0, B_H = (DT & 2) != 0, C_H = (DT & 4) != 0;
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM * HP], sB[2][GBN * HP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
@@ -366,14 +479,37 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
             rowB = rb;
         }
     }
+    long long rowAh[2] = {-1, -1}, rowBh[2] = {-1, -1};        // bf16-stored, row-contiguous operands: the thread's two neighbouring rows
+    if constexpr (A_H && A_MCONTIG) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (m0 + 2 * (tid & 63) + q < p.M) rowAh[q] = m0 + 2 * (tid & 63) + q;
+    }
+    if constexpr (B_H && B_NCONTIG) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int rb = n0 + 2 * (tid & 63) + q;
+            if (p.flatT > 0) {
+                if (rb < p.Z * p.flatT) {
+                    const int z = rb / p.flatT;
+                    rowBh[q] = z * p.sBz + (rb - z * p.flatT);
+                }
+            } else if (rb < p.N) {
+                rowBh[q] = rb;
+            }
+        }
+    }
     const bool ma = MASKED && p.amask != nullptr, mb = MASKED && p.bmask != nullptr;
-    float fa[2][2][8], fb[2][2][8], fam[MASKED ? 2 : 1][2][8], fbm[MASKED ? 2 : 1][2][8];
+    float fa[A_H ? 1 : 2][2][8], fb[B_H ? 1 : 2][2][8], fam[MASKED ? 2 : 1][2][8], fbm[MASKED ? 2 : 1][2][8];
+    unsigned ha[A_H ? 2 : 1][8], hb[B_H ? 2 : 1][8];
     auto fetch = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         const int zi = it / nk, k0 = kbeg + (it - zi * nk) * HBK;
         const long long za = (long long)(z0 + zi) * p.sAz, zb = p.flatT > 0 ? 0 : (long long)(z0 + zi) * p.sBz;
-        hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowA, fa[S]);
-        hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowB, fb[S]);
+        if constexpr (A_H) hgemm_fetch_h<A_MCONTIG>(reinterpret_cast<const unsigned short *>(p.A) + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowAh, ha[S]);
+        else hgemm_fetch<A_MCONTIG>(p.A + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowA, fa[S]);
+        if constexpr (B_H) hgemm_fetch_h<B_NCONTIG>(reinterpret_cast<const unsigned short *>(p.B) + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowBh, hb[S]);
+        else hgemm_fetch<B_NCONTIG>(p.B + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowB, fb[S]);
         if constexpr (MASKED) {
             if (ma) hgemm_fetch<A_MCONTIG>(p.amask + za, p.sAm, p.sAk, p.M, kend, m0, k0, tid, rowA, fam[S]);
             if (mb) hgemm_fetch<B_NCONTIG>(p.bmask + zb, p.sBn, p.sBk, p.N, kend, n0, k0, tid, rowB, fbm[S]);
@@ -382,8 +518,10 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
     auto body = [&](int it, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
         unsigned short *tA = sA[S], *tB = sB[S];
-        hgemm_commit<A_MCONTIG>(tA, tid, fa[S], fam[MASKED ? S : 0], ma);
-        hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[MASKED ? S : 0], mb);
+        if constexpr (A_H) hgemm_commit_h<A_MCONTIG>(tA, tid, ha[S]);
+        else hgemm_commit<A_MCONTIG>(tA, tid, fa[S], fam[MASKED ? S : 0], ma);
+        if constexpr (B_H) hgemm_commit_h<B_NCONTIG>(tB, tid, hb[S]);
+        else hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[MASKED ? S : 0], mb);
         __syncthreads();
         if (it + 2 < steps) fetch(it + 2, sc);
 #pragma unroll
@@ -406,7 +544,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
+    gemm_store<C_H>(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
 }
 
 // out[i] = sum over slabs of part[s][i].  64 elements x 4 slab groups per workgroup, four loads in flight per thread: one thread walking
@@ -489,6 +627,44 @@ __global__ __launch_bounds__(512) void rowsum4_kernel(const float *g, const floa
             if (MASK) acc += ((m[u].x > 0.f ? v[u].x : 0.f) + (m[u].y > 0.f ? v[u].y : 0.f)) + ((m[u].z > 0.f ? v[u].z : 0.f) + (m[u].w > 0.f ? v[u].w : 0.f));   // same grouping as below
             else acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
         }
+    }
+    __shared__ double red[512];
+    red[tid] = (double)acc;
+    __syncthreads();
+    for (int s = 256; s >= 1; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[c] = (float)red[0];
+}
+
+// ... over a tensor STORED as bf16 (the gradient of the feed-forward pair's hidden tensor): four elements per 8-byte load when T % 4 == 0,
+// fp32 partial sums per thread, the tree in double (as rowsum4_kernel)
+__global__ __launch_bounds__(512) void rowsum_h_kernel(const unsigned short *g, int Z, int C, long long T, float *out) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0) {
+        const long long Q = T / 4, items = (long long)Z * Q, rowq = (long long)C * Q;
+        const uint2 *g4 = reinterpret_cast<const uint2 *>(g) + (long long)c * Q;
+        for (long long i0 = tid; i0 < items; i0 += 4 * 512) {
+            uint2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                long long i = i0 + 512 * u;
+                i = i < items ? i : items - 1;
+                const long long z = i / Q;
+                v[u] = g4[z * rowq + (i - z * Q)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + 512 * u >= items) continue;
+                acc += (__builtin_bit_cast(float, v[u].x << 16) + __builtin_bit_cast(float, v[u].x & 0xffff0000u)) +
+                       (__builtin_bit_cast(float, v[u].y << 16) + __builtin_bit_cast(float, v[u].y & 0xffff0000u));
+            }
+        }
+    } else {
+        for (int z = 0; z < Z; ++z)
+            for (long long t = tid; t < T; t += 512) acc += __builtin_bit_cast(float, (unsigned)g[((long long)z * C + c) * T + t] << 16);
     }
     __shared__ double red[512];
     red[tid] = (double)acc;
@@ -1552,7 +1728,17 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
     const dim3 grid((unsigned)total);
     if (bf16) {
         const bool masked = p.amask || p.bmask;
-        if (masked) {
+        const int dt = (p.a_h ? 1 : 0) | (p.b_h ? 2 : 0) | (p.c_h ? 4 : 0);
+        if (dt) {                                // bf16-stored hidden tensor of the feed-forward pair: the six instances that pair launches
+            if (masked || (p.c_h && (p.addend || p.zchunk > 0))) PSND_FAIL(PSND_E_ARG, "%s: bf16 storage with an operand mask, or a bf16 output with an addend / slabs", what);
+            if (!a_mcontig && b_ncontig && dt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, false, 4>), grid, dim3(256), 0, st, p);
+            else if (!a_mcontig && b_ncontig && dt == 2) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, false, 2>), grid, dim3(256), 0, st, p);
+            else if (a_mcontig && b_ncontig && dt == 4) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, 4>), grid, dim3(256), 0, st, p);
+            else if (a_mcontig && b_ncontig && dt == 2) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, 2>), grid, dim3(256), 0, st, p);
+            else if (!a_mcontig && !b_ncontig && dt == 2) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, 2>), grid, dim3(256), 0, st, p);
+            else if (!a_mcontig && !b_ncontig && dt == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, false, 1>), grid, dim3(256), 0, st, p);
+            else PSND_FAIL(PSND_E_UNSUPPORTED, "%s: no instance for bf16 storage %d with this operand layout", what, dt);
+        } else if (masked) {
             if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, true>), grid, dim3(256), 0, st, p);
             else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, true>), grid, dim3(256), 0, st, p);
             else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, true>), grid, dim3(256), 0, st, p);
@@ -1565,6 +1751,7 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
         if (e2 != hipSuccess) PSND_FAIL(PSND_E_HIP, "%s: %s", what, hipGetErrorString(e2));
         return PSND_OK;
     }
+    if (p.a_h || p.b_h || p.c_h) PSND_FAIL(PSND_E_ARG, "%s: bf16 storage comes with bf16 operands only", what);
     if (a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
     else if (!a_mcontig && b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
     else if (!a_mcontig && !b_ncontig) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
@@ -1574,9 +1761,21 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
     return PSND_OK;
 }
 
+extern "C" int psnd_linear1x1_fwd_ex(const void *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
+                                     int io_h, void *y, void *stream);
 extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
                                   float *y, void *stream) {
+    return psnd_linear1x1_fwd_ex(x, w, bias, N, Cin, Cout, T, relu, bf16, 0, y, stream);
+}
+// io_h (bf16 != 0 only): 1 = x is STORED as bf16, 2 = y is - the hidden tensor of Conv1d -> ReLU -> Conv1d under autocast: the products take
+// bf16 operands either way, so the values multiplied are the same and the tensor moves at half the bytes (as torch.autocast's own conv
+// output would be).  One of the two per call.
+extern "C" int psnd_linear1x1_fwd_ex(const void *xv, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
+                                     int io_h, void *yv, void *stream) {
+    const float *x = static_cast<const float *>(xv);
+    float *y = static_cast<float *>(yv);
     if (!x || !w || !y) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: null pointer");
+    if (io_h && (!bf16 || (io_h != 1 && io_h != 2))) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: io_h=%d (1 or 2, with bf16 operands)", io_h);
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_fwd: N=%lld Cin=%d Cout=%d T=%lld", (long long)N, Cin, Cout, (long long)T);
     GemmParams p = {};
     p.A = w, p.B = x, p.C = y, p.bias = bias, p.amask = nullptr, p.bmask = nullptr;
@@ -1584,6 +1783,7 @@ extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *b
     p.sAm = Cin, p.sAk = 1, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cin * T, p.sCm = T, p.sCz = (long long)Cout * T;
     p.relu = relu, p.zchunk = 0, p.sCslab = 0;
     p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
+    p.b_h = io_h & 1, p.c_h = (io_h & 2) != 0;
     return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
@@ -1616,26 +1816,31 @@ extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int6
 }
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
-extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                     int bf16, const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias,
-                                     void *stream);
+extern "C" int psnd_linear1x1_bwd_ex(const void *gy, const float *ymask, const void *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                     int bf16, int io_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part,
+                                     float *gbias, void *stream);
 extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                   int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
-    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, nullptr, nullptr, gx, gw, gw_part, gbias, stream);
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, nullptr, nullptr, gx, gw, gw_part, gbias, stream);
 }
 // ... with gx = W^T gy' + gx_addend (N, Cin, T): the gradient that reaches x along another branch (a residual connection) rides in the
 // GEMM's epilogue instead of a separate accumulation pass over both tensors
 extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                       int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
-    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, gx_addend, nullptr, gx, gw, gw_part, gbias, stream);
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, gx_addend, nullptr, gx, gw, gw_part, gbias, stream);
 }
 // ... or with gx = (gx_mask > 0) ? W^T gy' : 0, gx_mask (N, Cin, T): x is the output of a ReLU (gx_mask = x itself, or the ReLU's output
 // wherever it is kept) and gx is wanted for the ReLU's INPUT - the layer before the ReLU then takes gx as it is (ymask = null there: its two
 // GEMMs and its bias sum read one tensor instead of two).  Not together with gx_addend.
-extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                     int bf16, const float *gx_addend, const float *gx_mask, float *gx, float *gw, float *gw_part, float *gbias,
-                                     void *stream) {
+// io_h (bf16 != 0 only; see psnd_linear1x1_fwd_ex): 1 = gy is STORED as bf16 (no ymask then), 2 = x, gx_mask and gx are (no gx_addend then).
+extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const void *xv, const float *w, int64_t N, int Cin, int Cout, int64_t T,
+                                     int bf16, int io_h, const float *gx_addend, const void *gx_maskv, void *gxv, float *gw, float *gw_part,
+                                     float *gbias, void *stream) {
+    const float *gy = static_cast<const float *>(gyv), *x = static_cast<const float *>(xv), *gx_mask = static_cast<const float *>(gx_maskv);
+    float *gx = static_cast<float *>(gxv);
     if (gx_addend && gx_mask) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gx_addend and gx_mask exclude each other");
+    if (io_h && (!bf16 || (io_h != 1 && io_h != 2))) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: io_h=%d (1 or 2, with bf16 operands)", io_h);
+    if ((io_h == 1 && ymask) || (io_h == 2 && gx_addend)) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: bf16 storage with an operand mask / addend");
     if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
     if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
@@ -1645,6 +1850,7 @@ extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const 
     if (gx) {
         GemmParams p = {};
         p.A = w, p.B = gy, p.C = gx, p.bias = nullptr, p.amask = nullptr, p.bmask = ymask, p.addend = gx_addend, p.omask = gx_mask;
+        p.b_h = io_h & 1, p.c_h = (io_h & 2) != 0;
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
         p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
@@ -1658,6 +1864,7 @@ extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const 
         const int64_t slabs = zslabs * ks;
         GemmParams p = {};
         p.A = gy, p.B = x, p.C = gw_part, p.bias = nullptr, p.amask = ymask, p.bmask = nullptr;
+        p.a_h = io_h & 1, p.b_h = (io_h & 2) != 0;
         p.M = Cout, p.N = Cin, p.K = (int)T, p.Z = (int)N;
         p.sAm = T, p.sAk = 1, p.sAz = (long long)Cout * T, p.sBk = 1, p.sBn = T, p.sBz = (long long)Cin * T, p.sCm = Cin, p.sCz = 0;
         p.zchunk = (int)((N + zslabs - 1) / zslabs), p.sCslab = (long long)Cout * Cin, p.ksplit = ks, p.kpart = kp;
@@ -1667,7 +1874,10 @@ extern "C" int psnd_linear1x1_bwd_ex(const float *gy, const float *ymask, const 
         hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, gw_part, (int)slabs, n, gw);
         PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
     }
-    if (gbias) {
+    if (gbias && (io_h & 1)) {
+        hipLaunchKernelGGL(rowsum_h_kernel, dim3(Cout), dim3(512), 0, st, reinterpret_cast<const unsigned short *>(gy), (int)N, Cout, (long long)T, gbias);
+        PSND_CHECK_LAUNCH("linear1x1_bwd(bias)");
+    } else if (gbias) {
         const bool vec = T % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(ymask)) % 16 == 0;
         if (vec && ymask) hipLaunchKernelGGL(rowsum4_kernel<true>, dim3(Cout), dim3(512), 0, st, gy, ymask, (int)N, Cout, (int)(T / 4), gbias);
         else if (vec) hipLaunchKernelGGL(rowsum4_kernel<false>, dim3(Cout), dim3(512), 0, st, gy, gy, (int)N, Cout, (int)(T / 4), gbias);

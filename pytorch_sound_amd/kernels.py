@@ -454,6 +454,9 @@ class ResidualLink:
 RELU_LINKS = _sw.lab('PSND_RELU_LINKS', '1') == '1'              # 0: each GEMM behind the ReLU masks its operand itself (A/B)
 
 
+HIDDEN_BF16 = _sw.lab('PSND_FFN_HIDDEN_BF16', '1') == '1'      # 0: the feed-forward pair's hidden tensor stays fp32 under autocast (A/B)
+
+
 class ReluLink:
     """Conv1d -> ReLU -> Conv1d (PointwiseFeedForward, modules.py:93-95) as two Linear1x1 nodes: the first one's backward would read
     its incoming gradient together with the ReLU's output as a mask in both of its GEMMs and its bias sum (two 169 MB tensors each at 32
@@ -552,8 +555,18 @@ class Linear1x1(torch.autograd.Function):
     masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1); output and gradients fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu, bf16=False, link=None, relu_link=None):
-        _need_cuda(x, 'input')
+    def forward(ctx, x, w, bias, relu, bf16=False, link=None, relu_link=None, out_h=False):
+        # out_h (with bf16 operands): the output is STORED as bf16 - the hidden tensor of Conv1d -> ReLU -> Conv1d under autocast; the node
+        # behind it takes it as it is (x.dtype == bfloat16).  The products round their operands to bf16 anyway: same values, half the bytes.
+        x_h = x.dtype == torch.bfloat16
+        if not (x_h and isinstance(x, torch.Tensor) and x.is_cuda):
+            _need_cuda(x, 'input')
+        if (x_h or out_h) and not bf16:
+            raise PsndError('Linear1x1: bf16 storage comes with bf16 operands (torch.autocast) only')
+        if x_h and out_h:
+            raise PsndError('Linear1x1: bf16 storage on one side of a projection only')
+        if x_h:
+            link = None
         ctx.link = None
         if link is not None and ctx.needs_input_grad[0]:
             ctx.link, link.consumer = link, True
@@ -563,7 +576,7 @@ class Linear1x1(torch.autograd.Function):
         if relu_link is not None and RELU_LINKS:
             if relu:
                 ctx.relu_out = relu_link
-            elif relu_link.y == (x.data_ptr(), tuple(x.shape)) and x.is_contiguous() and x.dtype == torch.float32 and ctx.needs_input_grad[0]:
+            elif relu_link.y == (x.data_ptr(), tuple(x.shape)) and x.is_contiguous() and ctx.needs_input_grad[0]:
                 ctx.relu_in, relu_link.consumer = relu_link, True
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
@@ -572,11 +585,12 @@ class Linear1x1(torch.autograd.Function):
         if w2.shape[1] != Cin:
             raise PsndError('Linear1x1: weight %s does not fit %d input channels' % (tuple(w.shape), Cin))
         b = None if bias is None else bias.contiguous()
-        y = torch.empty((N, Cout, T), dtype=torch.float32, device=x.device)
+        y = torch.empty((N, Cout, T), dtype=torch.bfloat16 if out_h else torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            check(lib().psnd_linear1x1_fwd(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), int(bool(bf16)), ptr(y), stream_ptr(x.device)),
-                  'psnd_linear1x1_fwd')
+            check(lib().psnd_linear1x1_fwd_ex(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), int(bool(bf16)), 1 if x_h else (2 if out_h else 0),
+                                              ptr(y), stream_ptr(x.device)), 'psnd_linear1x1_fwd')
         ctx.relu, ctx.has_bias, ctx.wshape, ctx.bf16 = bool(relu), bias is not None, tuple(w.shape), bool(bf16)
+        ctx.x_h, ctx.out_h = x_h, bool(out_h)
         ctx.params = (w, bias)
         from . import cl
         cl.note_param_use(ctx, w, bias)
@@ -591,6 +605,12 @@ class Linear1x1(torch.autograd.Function):
         gy = gy.contiguous()
         if ctx.relu_out is not None and ctx.relu_out.take():
             y = None                                                    # the gradient arrives masked (ReluLink)
+        if gy.dtype != torch.float32 and (y is not None or ctx.x_h or not ctx.bf16):
+            # a bf16 gradient that still needs this node's mask, or bf16 on both sides: outside the feed-forward pair's plan - in fp32
+            gy = gy.float()
+            if y is not None:
+                gy, y = gy * (y > 0), None
+        io_h = 1 if gy.dtype == torch.bfloat16 else (2 if ctx.x_h else 0)
         xmask = x if ctx.relu_in is not None else None
         N, Cin, T = x.shape
         Cout = w2.shape[0]
@@ -619,16 +639,16 @@ class Linear1x1(torch.autograd.Function):
                 cl.GRAD_SINK.note_producer(ctx.params, side)
         with torch.cuda.device(dev):
             if side is None:
-                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(xmask), ptr(gx),
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ptr(addend), ptr(xmask), ptr(gx),
                                                   ptr(gw), ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
             else:
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)                          # gy is complete on the main stream
-                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), ptr(addend), ptr(xmask), ptr(gx),
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ptr(addend), ptr(xmask), ptr(gx),
                                                   None, None, None, stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 with torch.cuda.stream(side):
-                    check(lib().psnd_linear1x1_bwd(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), None, ptr(gw), ptr(part),
-                                                   ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
+                    check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, None, None, None, ptr(gw),
+                                                      ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 for t in (gy, y, x, w2, gw, part, gb):          # main-stream blocks the side stream reads / writes
                     if t is not None:
                         t.record_stream(side)
@@ -636,7 +656,7 @@ class Linear1x1(torch.autograd.Function):
         if xmask is not None and need_x:
             ctx.relu_in.masked = True
         cl.consume_param_use(ctx)
-        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None, None
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None, None, None
 
 
 class Im2Col(torch.autograd.Function):

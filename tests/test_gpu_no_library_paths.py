@@ -412,6 +412,8 @@ def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
 
+    monkeypatch.setattr(K, 'HIDDEN_BF16', False)          # (the bf16 hidden tensor has its own test below)
+
     def block(on):
         monkeypatch.setattr(K, 'RELU_LINKS', on)
         x = x0.clone().requires_grad_(True)
@@ -436,3 +438,51 @@ def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
         ref = [x.grad] + [p.grad for p in ffn.parameters()]
         for u, v in zip(a, ref):
             assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 120), (2, 96, 173), (1, 32, 7), (2, 256, 431)])
+def test_ffn_hidden_tensor_stored_as_bf16(shape, monkeypatch):
+    """PointwiseFeedForward under torch.autocast(bfloat16): the tensor between the two projections (and its gradient) STORED as bf16
+    (psnd_linear1x1_fwd_ex / _bwd_ex, io_h) against the same block with that tensor in fp32.  The products round their operands to bf16 when
+    they load them, so the block's output, the input gradient and the weight gradients are THE SAME numbers up to the GroupNorm's atomics;
+    only the first projection's bias gradient sums rounded values (bf16 rounding of each term).  Odd T (173: 2-byte aligned rows), a
+    single short clip and channel counts off the tile size included; eval mode (no autograd) takes the bf16 tensor too."""
+    from pytorch_sound_amd.models import modules as M
+    from pytorch_sound_amd import kernels as K
+    dev = _dev()
+    torch.manual_seed(3)
+    n, c, t = shape
+    ffn = M.PointwiseFeedForward(c, 0.0).to(dev)
+    x0, w = torch.randn(n, c, t, device=dev), torch.randn(n, c, t, device=dev)
+    seen = []
+    orig = K.Linear1x1.forward
+
+    def fwd(ctx, x, *a):
+        seen.append(x.dtype)
+        return orig(ctx, x, *a)
+    monkeypatch.setattr(K.Linear1x1, 'forward', staticmethod(fwd))
+
+    def block(hidden_h):
+        monkeypatch.setattr(K, 'HIDDEN_BF16', hidden_h)
+        del seen[:]
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            z = ffn(x)
+        assert seen == [torch.float32, torch.bfloat16 if hidden_h else torch.float32]
+        (z.float() * w).sum().backward()
+        g = [z.detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in ffn.parameters()]
+        for p in ffn.parameters():
+            p.grad = None
+        return g
+
+    a, b = block(True), block(False)
+    names = ['out', 'gx'] + [k for k, _ in ffn.named_parameters()]
+    for k, u, v in zip(names, a, b):
+        tol = 4e-3 if k == 'ff.0.bias' else 2e-6
+        assert float((u - v).abs().max()) <= tol * float(v.abs().max()) + 1e-7, k
+    monkeypatch.setattr(K, 'HIDDEN_BF16', True)
+    del seen[:]
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        z = ffn(x0)
+    assert seen == [torch.float32, torch.bfloat16]
+    assert float((z.float() - a[0]).abs().max()) <= 2e-6 * float(a[0].abs().max())
