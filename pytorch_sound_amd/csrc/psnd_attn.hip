@@ -155,46 +155,7 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2_t));
 }
 // epilogue shared by both GEMM kernels: bias, relu, store (flat mode: column -> (batch, t))
-template <bool C_H = false>
 __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0, int bz) {
-    if constexpr (C_H) {             // bf16 output (and mask): no slabs, no addend
-        unsigned short *C = reinterpret_cast<unsigned short *>(p.C) + (p.flatT > 0 ? 0 : z0 * p.sCz);
-        const unsigned short *M = p.omask ? reinterpret_cast<const unsigned short *>(p.omask) + (p.flatT > 0 ? 0 : z0 * p.sCz) : nullptr;
-        const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int n = n0 + wn * 64 + u * 32 + li;
-            if (n >= ncols) continue;
-            long long coff = n;
-            if (p.flatT > 0) {
-                const int z = n / p.flatT;
-                coff = z * p.sCz + (n - z * p.flatT);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                unsigned short mk[16];
-                if (M) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + wm * 64 + t * 32 + rho(r, half);
-                        mk[r] = M[(long long)(m < p.M ? m : p.M - 1) * p.sCm + coff];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + t * 32 + rho(r, half);
-                    if (m < p.M) {
-                        float v = acc[t][u][r];
-                        if (p.bias) v += p.bias[m];
-                        if (p.relu) v = v > 0.f ? v : 0.f;
-                        if (M) v = __builtin_bit_cast(float, (unsigned)mk[r] << 16) > 0.f ? v : 0.f;
-                        C[(long long)m * p.sCm + coff] = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu);
-                    }
-                }
-            }
-        }
-        return;
-    }
     float *C = p.C + (p.zchunk > 0 ? bz * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
     const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
 #pragma unroll
@@ -372,6 +333,78 @@ __device__ __forceinline__ void hgemm_commit(unsigned short *tile, int tid, cons
     }
 }
 
+// Epilogue for a bf16 OUTPUT (GemmParams c_h; no slabs, no addend): the workgroup's (128 x 128) tile goes through LDS - the accumulator
+// layout has a lane's neighbours along n in OTHER lanes, so direct stores are 2-byte scatters (64-byte runs) - and leaves as 16-byte
+// stores, 256 bytes of one output row per 16 lanes; the ReLU mask of psnd_linear1x1_bwd_ex (bf16, indexed like C) is read the same way.
+// `sT`: the kernel's operand tiles (free behind a barrier), 128 rows of CPH bf16.
+constexpr int CPH = 136;             // 272-byte rows: 16-byte aligned, the rows of one store on different banks
+__device__ __forceinline__ void gemm_store_h(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0,
+                                             int tid, unsigned short *sT) {
+    __syncthreads();                 // every wave is done with the operand tiles
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = wm * 64 + t * 32 + rho(r, half), m = m0 + ml;
+            const float bv = (p.bias && m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v = acc[t][u][r] + bv;
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                sT[ml * CPH + wn * 64 + u * 32 + li] = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu);
+            }
+        }
+    __syncthreads();
+    unsigned short *C = reinterpret_cast<unsigned short *>(p.C) + (p.flatT > 0 ? 0 : z0 * p.sCz);
+    const unsigned short *M = p.omask ? reinterpret_cast<const unsigned short *>(p.omask) + (p.flatT > 0 ? 0 : z0 * p.sCz) : nullptr;
+    const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
+    typedef unsigned u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i, row = c >> 4, col = (c & 15) * 8;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= p.M || n >= ncols) continue;
+        const uint4 q = *reinterpret_cast<const uint4 *>(sT + row * CPH + col);
+        unsigned w[4] = {q.x, q.y, q.z, q.w};
+        long long coff = n;
+        bool whole = n + 7 < ncols;
+        if (p.flatT > 0) {
+            const int z = n / p.flatT, tt = n - z * p.flatT;
+            coff = z * p.sCz + tt;
+            whole = whole && tt + 7 < p.flatT;
+        }
+        const long long off = (long long)m * p.sCm + coff;
+        if (whole) {
+            if (M) {
+                const u32x4_a2 mk = *reinterpret_cast<const u32x4_a2 *>(M + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {         // a bf16 is > 0 when its sign bit is clear and it is not zero (the mask is a ReLU's output)
+                    const unsigned lo = mk[j] & 0xffffu, hi = mk[j] >> 16;
+                    const unsigned keep = ((lo - 1u) < 0x7fffu ? 0xffffu : 0u) | ((hi - 1u) < 0x7fffu ? 0xffff0000u : 0u);
+                    w[j] &= keep;
+                }
+            }
+            u32x4_a2 o = {w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<u32x4_a2 *>(C + off) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ne = n + e;
+                if (ne >= ncols) break;
+                long long ce = ne;
+                if (p.flatT > 0) {
+                    const int z = ne / p.flatT;
+                    ce = z * p.sCz + (ne - z * p.flatT);
+                }
+                const long long oe = (long long)m * p.sCm + ce;
+                unsigned short v = (unsigned short)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                if (M && !((unsigned)(M[oe] - 1u) < 0x7fffu)) v = 0;
+                C[oe] = v;
+            }
+        }
+    }
+}
+
 // ---- an operand STORED as bf16 (GemmParams a_h / b_h): half the bytes, no conversion.  The thread's share of the (128 rows x 32 k) tile is
 // eight dwords:
 //   k-contiguous source  : 8 consecutive k of rows tid / 4 and tid / 4 + 64 - one 16-byte load each, written to LDS as they are
@@ -406,6 +439,13 @@ __device__ __forceinline__ void hgemm_fetch_h(const unsigned short *base, long l
     } else {
         const int k = ok + 8 * (tid >> 6);
         const bool pair = rowoff[0] >= 0 && rowoff[1] == rowoff[0] + 1;
+        typedef unsigned u32_u2 __attribute__((aligned(2)));
+        if (k + 7 < limk && __builtin_amdgcn_ballot_w64(!pair) == 0) {        // (wave-uniform) the whole wave on whole pairs: eight plain loads
+            const unsigned short *p = base + (long long)k * s_k + rowoff[0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const u32_u2 *>(p + (long long)e * s_k);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (k + e >= limk) continue;
@@ -447,7 +487,10 @@ template <bool A_MCONTIG, bool B_NCONTIG, bool MASKED, int DT = 0>
 __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmParams p) {
     static_assert(!(MASKED && DT != 0), "operand masks come with fp32 storage only");
     constexpr bool A_H = (DT & 1) != 0, B_H = (DT & 2) != 0, C_H = (DT & 4) != 0;
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][GBM * HP], sB[2][GBN * HP];
+    __shared__ __attribute__((aligned(16))) unsigned short sAB[2 * GBM * HP + 2 * GBN * HP];      // the operand tiles; a bf16 output tile afterwards
+    static_assert(128 * CPH <= 2 * GBM * HP + 2 * GBN * HP, "the bf16 output tile fits the operand tiles");
+    unsigned short(*sA)[GBM * HP] = reinterpret_cast<unsigned short(*)[GBM * HP]>(sAB);
+    unsigned short(*sB)[GBN * HP] = reinterpret_cast<unsigned short(*)[GBN * HP]>(sAB + 2 * GBM * HP);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kg = lane >> 5;
     int tbx, tby, tbz;
@@ -544,7 +587,8 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
-    gemm_store<C_H>(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
+    if constexpr (C_H) gemm_store_h(p, acc, m0, n0, wm, wn, li, kg, z0, tid, sAB);
+    else gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
 }
 
 // out[i] = sum over slabs of part[s][i].  64 elements x 4 slab groups per workgroup, four loads in flight per thread: one thread walking
