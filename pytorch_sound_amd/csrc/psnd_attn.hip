@@ -46,6 +46,7 @@ struct GemmParams {
     int tiles_x, tiles_y, tiles_z;
     const float *addend;         // null, or a tensor indexed like C: C = A B + addend (the residual branch's gradient folded into the
                                  // input-gradient GEMM of the branch's first projection: no separate accumulation pass)
+    int ablate;                  // lab builds only (PSND_GEMM_ABLATE): 1 = no operand fetches behind the first two k-tiles, 2 = no MFMAs, 4 = no epilogue
     int a_h, b_h, c_h;           // (bf16 kernel only) the operand / the output is STORED as bf16 (2-byte elements, same indexing): the hidden
                                  // tensor of the feed-forward pair and its gradient under autocast - the GEMMs round their operands to bf16 when
                                  // they load them, so the stored values are the ones multiplied either way, at half the bytes (round 6).
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
         if constexpr (B_H) hgemm_commit_h<B_NCONTIG>(tB, tid, hb[S]);
         else hgemm_commit<B_NCONTIG>(tB, tid, fb[S], fbm[MASKED ? S : 0], mb);
         __syncthreads();
-        if (it + 2 < steps) fetch(it + 2, sc);
+        if (it + 2 < steps && !PSND_ABL(p, 1)) fetch(it + 2, sc);
+        if (PSND_ABL(p, 2)) return;
 #pragma unroll
         for (int s = 0; s < HBK / 16; ++s) {
             bf16x8_t a[2], b[2];
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(256, MASKED ? 2 : 3) void gemm_bf16_kernel(GemmPara
         body(it, std::integral_constant<int, 0>{});
         if (it + 1 < steps) body(it + 1, std::integral_constant<int, 1>{});
     }
+    if (PSND_ABL(p, 4)) return;
     if constexpr (C_H) gemm_store_h(p, acc, m0, n0, wm, wn, li, kg, z0, tid, sAB);
     else gemm_store(p, acc, m0, n0, wm, wn, li, kg, z0, tbz);
 }
@@ -1771,6 +1774,8 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
     p.tiles_x = (int)tx, p.tiles_y = (int)ty, p.tiles_z = (int)tz;
     const dim3 grid((unsigned)total);
     if (bf16) {
+        const char *abl = PSND_ENV("PSND_GEMM_ABLATE");
+        p.ablate = abl ? atoi(abl) : 0;
         const bool masked = p.amask || p.bmask;
         const int dt = (p.a_h ? 1 : 0) | (p.b_h ? 2 : 0) | (p.c_h ? 4 : 0);
         if (dt) {                                // bf16-stored hidden tensor of the feed-forward pair: the six instances that pair launches
