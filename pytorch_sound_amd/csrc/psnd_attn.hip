@@ -159,6 +159,17 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int li, int half, int z0, int bz) {
     float *C = p.C + (p.zchunk > 0 ? bz * p.sCslab : (p.flatT > 0 ? 0 : z0 * p.sCz));
     const int ncols = p.flatT > 0 ? p.Z * p.flatT : p.N;
+    // the thread's 32 bias values BEFORE its first store (round 6): loaded next to the stores each one was waited for behind the stores in
+    // front of it - C and bias may alias as far as hipcc knows, and gfx9 counts loads and stores in one in-order counter - a store latency
+    // per block of sixteen (the wide-output projections were bound by this epilogue, not by their k-loop: PSND_GEMM_ABLATE, notebook)
+    float bv[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + t * 32 + rho(r, half);
+            bv[t][r] = p.bias ? p.bias[m < p.M ? m : p.M - 1] : 0.f;
+        }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int n = n0 + wn * 64 + u * 32 + li;
@@ -185,8 +196,7 @@ __device__ __forceinline__ void gemm_store(const GemmParams &p, const f32x16 (&a
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + t * 32 + rho(r, half);
                 if (m < p.M) {
-                    float v = acc[t][u][r];
-                    if (p.bias) v += p.bias[m];
+                    float v = acc[t][u][r] + bv[t][r];
                     if (p.relu) v = v > 0.f ? v : 0.f;
                     if (p.addend) v += ad[r];
                     else if (p.omask) v = ad[r] > 0.f ? v : 0.f;

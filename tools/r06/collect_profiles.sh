@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- python $ROO
 python $ROOT/tools/kstats.py /tmp/p_c3 70 $OUT/r06_config3_kernel_stats.txt > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- python $ROOT/bench.py --leg config4 > $OUT/c4.log 2>&1
 python $ROOT/tools/kstats.py /tmp/p_c4 40 $OUT/r06_config4_block_bf16_kernel_stats.txt > /dev/null
+python $ROOT/tools/step_timeline.py /tmp/p_c4 30 $OUT/r06_config4_timeline.txt > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -- python $ROOT/bench.py --config 5 --steps 20 --warmup 5 --settle 5 > $OUT/c5.log 2>&1
 python $ROOT/tools/kstats.py /tmp/p_c5 10 $OUT/r06_config5_kernel_stats.txt > /dev/null
 grep -h -o '"ms_per_step": [0-9.]*' $OUT/c3.log $OUT/c4.log $OUT/c5.log
