@@ -210,8 +210,9 @@ def test_separator_fp32_outside_autocast():
 
 def test_generator_v1_fp32_at_training_shape():
     """registered hifi_gan_v1 on an fp32 batch outside autocast (4 x 32 frames -> 4 x 8192 samples): the fp32 convolutions against the library
-    formulation of the same module (use_cl = False; MIOpen's own fp32 algorithms differ from run to run at the 1e-5 level) - output 1e-4 of max,
-    gradients 1e-3 relative L2; the tight bounds are the goldens and the per-layer float64 tests above - and no library convolution"""
+    formulation of the same module (use_cl = False; MIOpen's own fp32 algorithms differ from run to run - which one it picks depends on what
+    ran in the process before: 1e-5 alone, past 1e-4 once behind the whole suite) - output 5e-4 of max, gradients 5e-3 relative L2; the
+    tight bounds are the goldens and the per-layer float64 tests above - and no library convolution"""
     from pytorch_sound_amd.models import build_model
     from pytorch_sound_amd.models.vocoders import hifi_gan  # noqa: F401
     from test_gpu_no_library_paths import forbid_library_ops
@@ -228,7 +229,7 @@ def test_generator_v1_fp32_at_training_shape():
     g.use_cl = False
     yl, gxl, gpl = _run(g, x, w)
     assert y.shape == (4, 1, 8192)
-    assert _maxrel(y, yl) <= 1e-4
+    assert _maxrel(y, yl) <= 5e-4
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))     # noqa: E731
-    assert rel(gx, gxl) <= 1e-3
-    assert max(rel(gp[n], gpl[n]) for n in gp) <= 1e-3
+    assert rel(gx, gxl) <= 5e-3
+    assert max(rel(gp[n], gpl[n]) for n in gp) <= 5e-3
