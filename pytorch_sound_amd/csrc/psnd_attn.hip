@@ -1846,10 +1846,12 @@ extern "C" int psnd_linear1x1_fwd_ex(const void *xv, const float *w, const float
     return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
-// weight-gradient launch of psnd_linear1x1_bwd: batch chunks x K parts (frames of a clip) so that there are ~3 workgroups per CU
+// weight-gradient launch of psnd_linear1x1_bwd: batch chunks x K parts (frames of a clip) so that there are ~2 workgroups per CU
 static void wgrad_split(int64_t N, int Cin, int Cout, int64_t T, int64_t *zslabs, int *ksplit, int *kpart) {
     const int64_t tiles = (int64_t)((Cout + GBM - 1) / GBM) * ((Cin + GBN - 1) / GBN);
-    int64_t want = 768 / (tiles > 0 ? tiles : 1);
+    int64_t target = 512;                        // (round 6: 768 -> 512 workgroups - half the slabs to write and add up: config-4 step 1.776 -> 1.764 ms; 256 the same, 1536 1.836)
+    if (const char *e = PSND_ENV("PSND_WGRAD_WGS")) target = atoi(e) > 0 ? atoi(e) : target;      // lab A/B: workgroups the launch aims at
+    int64_t want = target / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
     int64_t zs = want > N ? N : want;
     const int64_t chunk = (N + zs - 1) / zs;
