@@ -1267,14 +1267,33 @@ struct BTile {
 // 16-byte loads per block whose per-thread offset never changes - the tile's position rides in the instruction's scalar offset, no
 // address arithmetic or range selects in the loop (round 6: the loops are bound by their vector ALU work; rows are 4-byte aligned only,
 // T = 1292 - gfx9 memory takes that); any other tile element loads that read zeros outside the matrix.
-template <int HDP>
+// H: the matrix is STORED as bf16 (kvq written by the projection's epilogue under autocast, round 6): the same 2 x 4 block is two 8-byte loads,
+// v[u][0..3] then hold the packed words {row dd: t, t+1 | t+2, t+3}, {row dd + 1: ...} - nothing to convert on the way to LDS.
+template <int HDP, bool H = false>
 __device__ __forceinline__ void fetch_tile_b(rsrc_t src, long long T, int d, int t0, int tid, float (&v)[BTile<HDP>::NP][8]) {
     const int tl = 4 * (tid & 7);
     const bool inside = d == HDP && t0 + 32 <= (int)T;
 #pragma unroll
     for (int u = 0; u < BTile<HDP>::NP; ++u) {
         const int dd = 2 * (tid >> 3) + 64 * u;
-        if (inside) {
+        if constexpr (H) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
+            if (inside) {
+                const unsigned voff = dd < HDP ? (unsigned)(dd * (int)T + tl) * 2u : kOOB;
+                const uint2 a = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(src, (int)voff, t0 * 2, 0));
+                const uint2 c = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(src, (int)(voff + (unsigned)T * 2u), t0 * 2, 0));
+                w[0] = a.x, w[1] = a.y, w[2] = c.x, w[3] = c.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int te = t0 + tl + (e & 3), de = dd + (e >> 2);
+                    const unsigned x = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(src, (te < T && de < d) ? (unsigned)(de * (int)T + te) * 2u : kOOB, 0, 0);
+                    w[e >> 1] |= x << (16 * (e & 1));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][e] = __builtin_bit_cast(float, w[e]);
+        } else if (inside) {
             const unsigned voff = dd < HDP ? (unsigned)(dd * (int)T + tl) * 4u : kOOB;
             const f32x4_t a = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(src, (int)voff, t0 * 4, 0));
             const f32x4_t c = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(src, (int)(voff + (unsigned)T * 4u), t0 * 4, 0));
@@ -1289,7 +1308,7 @@ __device__ __forceinline__ void fetch_tile_b(rsrc_t src, long long T, int d, int
         }
     }
 }
-template <int HDP, bool WT, bool WD>
+template <int HDP, bool WT, bool WD, bool H = false>
 __device__ __forceinline__ void commit_tile_b(unsigned short *tT, unsigned short *tD, int tid, const float (&v)[BTile<HDP>::NP][8]) {
     using B = BTile<HDP>;
     const int tl = 4 * (tid & 7);
@@ -1297,36 +1316,68 @@ __device__ __forceinline__ void commit_tile_b(unsigned short *tT, unsigned short
 #pragma unroll
     for (int u = 0; u < B::NP; ++u) {
         const int dd = 2 * (tid >> 3) + 64 * u;
-        if constexpr (WT) {
+        if constexpr (H) {
+            const unsigned w0 = __builtin_bit_cast(unsigned, v[u][0]), w1 = __builtin_bit_cast(unsigned, v[u][1]);
+            const unsigned w2 = __builtin_bit_cast(unsigned, v[u][2]), w3 = __builtin_bit_cast(unsigned, v[u][3]);
+            if constexpr (WT) {                  // (row dd, row dd + 1) at one frame: the low / high halves of the two rows' words
+                *reinterpret_cast<unsigned *>(tT + (tl + 0) * B::DP + dd) = __builtin_amdgcn_perm(w2, w0, 0x05040100u);
+                *reinterpret_cast<unsigned *>(tT + (tl + 1) * B::DP + dd) = __builtin_amdgcn_perm(w2, w0, 0x07060302u);
+                *reinterpret_cast<unsigned *>(tT + (tl + 2) * B::DP + dd) = __builtin_amdgcn_perm(w3, w1, 0x05040100u);
+                *reinterpret_cast<unsigned *>(tT + (tl + 3) * B::DP + dd) = __builtin_amdgcn_perm(w3, w1, 0x07060302u);
+            }
+            if constexpr (WD) {
+                *reinterpret_cast<uint2 *>(tD + dd * B::TPB + tl) = make_uint2(w0, w1);
+                *reinterpret_cast<uint2 *>(tD + (dd + 1) * B::TPB + tl) = make_uint2(w2, w3);
+            }
+        } else {
+            if constexpr (WT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned *>(tT + (tl + e) * B::DP + dd) = pack2_bf16(v[u][e], v[u][4 + e]);
-        }
-        if constexpr (WD) {
-            *reinterpret_cast<uint2 *>(tD + dd * B::TPB + tl) = make_uint2(pack2_bf16(v[u][0], v[u][1]), pack2_bf16(v[u][2], v[u][3]));
-            *reinterpret_cast<uint2 *>(tD + (dd + 1) * B::TPB + tl) = make_uint2(pack2_bf16(v[u][4], v[u][5]), pack2_bf16(v[u][6], v[u][7]));
+                for (int e = 0; e < 4; ++e) *reinterpret_cast<unsigned *>(tT + (tl + e) * B::DP + dd) = pack2_bf16(v[u][e], v[u][4 + e]);
+            }
+            if constexpr (WD) {
+                *reinterpret_cast<uint2 *>(tD + dd * B::TPB + tl) = make_uint2(pack2_bf16(v[u][0], v[u][1]), pack2_bf16(v[u][2], v[u][3]));
+                *reinterpret_cast<uint2 *>(tD + (dd + 1) * B::TPB + tl) = make_uint2(pack2_bf16(v[u][4], v[u][5]), pack2_bf16(v[u][6], v[u][7]));
+            }
         }
     }
 }
-template <int HDP, bool WT, bool WD>
+template <int HDP, bool WT, bool WD, bool H = false>
 __device__ __forceinline__ void load_tile_b(rsrc_t src, long long T, int d, int t0, unsigned short *tT, unsigned short *tD, int tid) {
     float v[BTile<HDP>::NP][8];
-    fetch_tile_b<HDP>(src, T, d, t0, tid, v);
-    commit_tile_b<HDP, WT, WD>(tT, tD, tid, v);
+    fetch_tile_b<HDP, H>(src, T, d, t0, tid, v);
+    commit_tile_b<HDP, WT, WD, H>(tT, tD, tid, v);
+}
+// the descriptor of one head's (d x T) rows of a matrix stored as fp32 or (H) bf16, `off` elements into `base`
+template <bool H>
+__device__ __forceinline__ rsrc_t head_rsrc_e(const void *base, long long off, int d, long long T) {
+    if constexpr (H) return make_uniform_rsrc(static_cast<const unsigned short *>(base) + off, (int)(d * T * 2));
+    else return make_uniform_rsrc(static_cast<const float *>(base) + off, (int)(d * T * 4));
 }
 // B-operand fragments of a (d x T) matrix for the wave's 32 columns: f[s] slot e = X[16 s + 8 kk + e][t0 + li]
-template <int HDP>
+template <int HDP, bool H = false>
 __device__ __forceinline__ void load_frag_b(rsrc_t src, long long T, int d, int t0, int li, int kk, bf16x8_t (&f)[HDP / 16]) {
     const int t = t0 + li;
 #pragma unroll
     for (int s = 0; s < HDP / 16; ++s) {
-        float x[8];
+        if constexpr (H) {
+            unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int dd = 16 * s + 8 * kk + e;
-            x[e] = buf_f32(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 4u : kOOB);
+            for (int e = 0; e < 8; ++e) {
+                const int dd = 16 * s + 8 * kk + e;
+                const unsigned x = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 2u : kOOB, 0, 0);
+                w[e >> 1] |= x << (16 * (e & 1));
+            }
+            f[s] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+        } else {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int dd = 16 * s + 8 * kk + e;
+                x[e] = buf_f32(src, (t < T && dd < d) ? (unsigned)(dd * (int)T + t) * 4u : kOOB);
+            }
+            const uint4 pk = make_uint4(pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3]), pack2_bf16(x[4], x[5]), pack2_bf16(x[6], x[7]));
+            f[s] = __builtin_bit_cast(bf16x8_t, pk);
         }
-        const uint4 pk = make_uint4(pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3]), pack2_bf16(x[4], x[5]), pack2_bf16(x[6], x[7]));
-        f[s] = __builtin_bit_cast(bf16x8_t, pk);
     }
 }
 // S tile: acc[i = rows t of the tile][j] = sum_dd X[dd][i] frag[dd][j]
@@ -1365,7 +1416,8 @@ __device__ __forceinline__ void mma_tile_acc_b(const unsigned short *tD, const b
         }
 }
 
-template <int HDP, bool ATT>
+// KH: kvq (and, backward, gkvq) STORED as bf16 (psnd_mha_fwd / _bwd with bf16 = 2)
+template <int HDP, bool ATT, bool KH = false>
 __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sK[2][B::TT], sV[2][B::TD];
@@ -1375,12 +1427,13 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
     if (!attn_tile(p, tx, b)) return;
     const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
-    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const long long Ko = ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc_e<KH>(p.kvq, Ko, p.d, T), Vp = head_rsrc_e<KH>(p.kvq, Ko + (long long)p.C * T, p.d, T),
+                 Qp = head_rsrc_e<KH>(p.kvq, Ko + 2 * (long long)p.C * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     bf16x8_t qf[HDP / 16];
-    load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    load_frag_b<HDP, KH>(Qp, T, p.d, tq0, li, kk, qf);
     const int ntile = (p.T + 31) / 32;
     float pk[B::NP][8], pv[B::NP][8];
     if constexpr (!ATT) {
@@ -1398,17 +1451,17 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
         for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) O[mt][i] = 0.f;
-        load_tile_b<HDP, true, false>(Kp, T, p.d, 0, sK[0], nullptr, tid);
-        load_tile_b<HDP, true, false>(Kp, T, p.d, 32, sK[1], nullptr, tid);
-        load_tile_b<HDP, false, true>(Vp, T, p.d, 0, nullptr, sV[0], tid);
+        load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 0, sK[0], nullptr, tid);
+        load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 32, sK[1], nullptr, tid);
+        load_tile_b<HDP, false, true, KH>(Vp, T, p.d, 0, nullptr, sV[0], tid);
         fill_key_bits(s_kb, mrow, p.T, ntile, tid);
         __syncthreads();
         f32x16 s;
         mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
         for (int it = 0; it < ntile; ++it) {
             __syncthreads();
-            fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
-            fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
+            fetch_tile_b<HDP, KH>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+            fetch_tile_b<HDP, KH>(Vp, T, p.d, 32 * (it + 1), tid, pv);
             const unsigned bad = __builtin_amdgcn_readfirstlane(it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane));
             f32x16 sn;
             mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
@@ -1441,8 +1494,8 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
             bf16x8_t pb[2];
             pack_acc_b(s, pb);
             mma_tile_acc_b<HDP>(sV[it & 1], pb, li, kk, O);
-            commit_tile_b<HDP, true, false>(sK[it & 1], nullptr, tid, pk);
-            commit_tile_b<HDP, false, true>(nullptr, sV[(it + 1) & 1], tid, pv);
+            commit_tile_b<HDP, true, false, KH>(sK[it & 1], nullptr, tid, pk);
+            commit_tile_b<HDP, false, true, KH>(nullptr, sV[(it + 1) & 1], tid, pv);
             s = sn;
         }
         mx *= p.scale;                                             // the statistics keep the maximum of the SCALED scores
@@ -1466,15 +1519,15 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
     }
     // ---- pass 1: column statistics
     float mx = -INFINITY, sum = 0.f;
-    load_tile_b<HDP, true, false>(Kp, T, p.d, 0, sK[0], nullptr, tid);
-    load_tile_b<HDP, true, false>(Kp, T, p.d, 32, sK[1], nullptr, tid);
+    load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 0, sK[0], nullptr, tid);
+    load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 32, sK[1], nullptr, tid);
     fill_key_bits(s_kb, mrow, p.T, ntile, tid);
     __syncthreads();
     f32x16 s;
     mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+        fetch_tile_b<HDP, KH>(Kp, T, p.d, 32 * (it + 2), tid, pk);
         const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 sn;
         mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
@@ -1492,7 +1545,7 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
         for (int r = 0; r < 16; ++r) a += __expf(s[r] - m2s);
         sum = sum * __expf(mx - m2s) + a;
         mx = m2;
-        commit_tile_b<HDP, true, false>(sK[it & 1], nullptr, tid, pk);
+        commit_tile_b<HDP, true, false, KH>(sK[it & 1], nullptr, tid, pk);
         s = sn;
     }
     {
@@ -1516,16 +1569,16 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
     const bool nancol = !(sum > 0.f);
     const float mxs = nancol ? 0.f : mx;
     __syncthreads();
-    load_tile_b<HDP, true, false>(Kp, T, p.d, 0, sK[0], nullptr, tid);
-    load_tile_b<HDP, true, false>(Kp, T, p.d, 32, sK[1], nullptr, tid);
-    load_tile_b<HDP, false, true>(Vp, T, p.d, 0, nullptr, sV[0], tid);
+    load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 0, sK[0], nullptr, tid);
+    load_tile_b<HDP, true, false, KH>(Kp, T, p.d, 32, sK[1], nullptr, tid);
+    load_tile_b<HDP, false, true, KH>(Vp, T, p.d, 0, nullptr, sV[0], tid);
     __syncthreads();
     mma_tile_frag_b<HDP>(sK[0], qf, li, kk, s);
     float *attp = ATT ? p.att + (long long)b * T * T + tq : nullptr;      // ATT: the (H N, T, T) tensor is written (its own instances)
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
-        fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
-        fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 1), tid, pv);
+        fetch_tile_b<HDP, KH>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+        fetch_tile_b<HDP, KH>(Vp, T, p.d, 32 * (it + 1), tid, pv);
         const unsigned bad = it < KBITS_MAX ? s_kb[it] : key_bits(mrow, p.T, 32 * it, lane);
         f32x16 sn;
         mma_tile_frag_b<HDP>(sK[(it + 1) & 1], qf, li, kk, sn);
@@ -1552,8 +1605,8 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
         bf16x8_t pb[2];
         pack_acc_b(s, pb);
         mma_tile_acc_b<HDP>(sV[it & 1], pb, li, kk, O);
-        commit_tile_b<HDP, true, false>(sK[it & 1], nullptr, tid, pk);
-        commit_tile_b<HDP, false, true>(nullptr, sV[(it + 1) & 1], tid, pv);
+        commit_tile_b<HDP, true, false, KH>(sK[it & 1], nullptr, tid, pk);
+        commit_tile_b<HDP, false, true, KH>(nullptr, sV[(it + 1) & 1], tid, pv);
         s = sn;
     }
     if (tq < p.T) {
@@ -1568,7 +1621,7 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
 
 // GATT: a gradient arrives for the returned attention tensor too (modules.py:60 returns `att`; training recipes rarely differentiate it).
 // The plain instances do not carry that path: 232 / 158 instead of 256 (13 spilled) / 190 registers - the query kernel runs three waves per SIMD.
-template <int HDP, bool GATT>
+template <int HDP, bool GATT, bool KH = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sQt[2][B::TT], sQd[2][B::TD], sGt[2][B::TT], sGd[2][B::TD];
@@ -1579,15 +1632,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     if (!attn_tile(p, tx, b)) return;
     const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
-    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const long long Ko = ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc_e<KH>(p.kvq, Ko, p.d, T), Vp = head_rsrc_e<KH>(p.kvq, Ko + (long long)p.C * T, p.d, T),
+                 Qp = head_rsrc_e<KH>(p.kvq, Ko + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tk0 = tx * 128 + wave * 32, tk = tk0 + li;
     const bool kbad = tk >= p.T || (mrow && mrow[tk]);
     bf16x8_t kf[HDP / 16], vf[HDP / 16];
-    load_frag_b<HDP>(Kp, T, p.d, tk0, li, kk, kf);
-    load_frag_b<HDP>(Vp, T, p.d, tk0, li, kk, vf);
+    load_frag_b<HDP, KH>(Kp, T, p.d, tk0, li, kk, kf);
+    load_frag_b<HDP, KH>(Vp, T, p.d, tk0, li, kk, vf);
     f32x16 dK[HDP / 32], dV[HDP / 32];
 #pragma unroll
     for (int mt = 0; mt < HDP / 32; ++mt)
@@ -1626,11 +1680,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     };
     stage_fetch(0);
     stage_commit(0);
-    load_tile_b<HDP, true, true>(Qp, T, p.d, 0, sQt[0], sQd[0], tid);
+    load_tile_b<HDP, true, true, KH>(Qp, T, p.d, 0, sQt[0], sQd[0], tid);
     load_tile_b<HDP, true, true>(Gp, T, p.d, 0, sGt[0], sGd[0], tid);
     if (ntile > 1) {
         stage_fetch(1);
-        fetch_tile_b<HDP>(Qp, T, p.d, 32, tid, pq);
+        fetch_tile_b<HDP, KH>(Qp, T, p.d, 32, tid, pq);
         fetch_tile_b<HDP>(Gp, T, p.d, 32, tid, pg);
     }
     for (int it = 0; it < ntile; ++it) {
@@ -1641,11 +1695,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         mma_tile_frag_b<HDP>(sGt[it & 1], vf, li, kk, dp);
         if (it + 1 < ntile) {                                    // tile it + 1 (requested an iteration ago) -> LDS, tile it + 2 requested
             stage_commit((it + 1) & 1);
-            commit_tile_b<HDP, true, true>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
+            commit_tile_b<HDP, true, true, KH>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
             commit_tile_b<HDP, true, true>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
             if (it + 2 < ntile) {
                 stage_fetch(it + 2);
-                fetch_tile_b<HDP>(Qp, T, p.d, 32 * (it + 2), tid, pq);
+                fetch_tile_b<HDP, KH>(Qp, T, p.d, 32 * (it + 2), tid, pq);
                 fetch_tile_b<HDP>(Gp, T, p.d, 32 * (it + 2), tid, pg);
             }
         }
@@ -1674,20 +1728,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         mma_tile_acc_b<HDP>(sQd[it & 1], db, li, kk, dK);
     }
     if (tk < p.T) {
-        float *gk = p.gkvq + ((long long)n * 3 * p.C + h * p.d) * T + tk, *gv = gk + (long long)p.C * T;
+        const long long go = ((long long)n * 3 * p.C + h * p.d) * T + tk;
+        float *gk = p.gkvq + go, *gv = gk + (long long)p.C * T;
+        unsigned short *gkh = reinterpret_cast<unsigned short *>(p.gkvq) + go, *gvh = gkh + (long long)p.C * T;
         const float ks = kbad ? 0.f : p.scale, vs = kbad ? 0.f : 1.f;          // a padded key receives no gradient
 #pragma unroll
         for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (mt * 32 + rho(r, kk) < p.d) {
-                    gk[(long long)(mt * 32 + rho(r, kk)) * T] = kbad ? 0.f : dK[mt][r] * ks;
-                    gv[(long long)(mt * 32 + rho(r, kk)) * T] = kbad ? 0.f : dV[mt][r] * vs;
+                    const float a = kbad ? 0.f : dK[mt][r] * ks, c = kbad ? 0.f : dV[mt][r] * vs;
+                    if constexpr (KH) {
+                        gkh[(long long)(mt * 32 + rho(r, kk)) * T] = (unsigned short)(pack2_bf16(a, 0.f) & 0xffffu);
+                        gvh[(long long)(mt * 32 + rho(r, kk)) * T] = (unsigned short)(pack2_bf16(c, 0.f) & 0xffffu);
+                    } else {
+                        gk[(long long)(mt * 32 + rho(r, kk)) * T] = a;
+                        gv[(long long)(mt * 32 + rho(r, kk)) * T] = c;
+                    }
                 }
     }
 }
 
-template <int HDP, bool GATT>
+template <int HDP, bool GATT, bool KH = false>
 __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(AttnParams p) {
     using B = BTile<HDP>;
     __shared__ __attribute__((aligned(16))) unsigned short sKt[2][B::TT], sKd[2][B::TD], sVt[2][B::TT];
@@ -1697,13 +1759,14 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     if (!attn_tile(p, tx, b)) return;
     const int h = b / p.N, n = b - h * p.N;
     const long long T = p.T;
-    const float *Kg = p.kvq + ((long long)n * 3 * p.C + h * p.d) * T;
-    const rsrc_t Kp = head_rsrc(Kg, p.d, T), Vp = head_rsrc(Kg + (long long)p.C * T, p.d, T), Qp = head_rsrc(Kg + 2 * (long long)p.C * T, p.d, T);
+    const long long Ko = ((long long)n * 3 * p.C + h * p.d) * T;
+    const rsrc_t Kp = head_rsrc_e<KH>(p.kvq, Ko, p.d, T), Vp = head_rsrc_e<KH>(p.kvq, Ko + (long long)p.C * T, p.d, T),
+                 Qp = head_rsrc_e<KH>(p.kvq, Ko + 2 * (long long)p.C * T, p.d, T);
     const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     bf16x8_t qf[HDP / 16], gf[HDP / 16];
-    load_frag_b<HDP>(Qp, T, p.d, tq0, li, kk, qf);
+    load_frag_b<HDP, KH>(Qp, T, p.d, tq0, li, kk, qf);
     load_frag_b<HDP>(Gp, T, p.d, tq0, li, kk, gf);
     const bool qdead = tq >= p.T || (mrow && mrow[tq]);
     const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 1.f;
@@ -1716,13 +1779,13 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
 #pragma unroll
         for (int i = 0; i < 16; ++i) dQ[mt][i] = 0.f;
     const int ntile = (p.T + 31) / 32;
-    load_tile_b<HDP, true, true>(Kp, T, p.d, 0, sKt[0], sKd[0], tid);
-    load_tile_b<HDP, true, false>(Vp, T, p.d, 0, sVt[0], nullptr, tid);
+    load_tile_b<HDP, true, true, KH>(Kp, T, p.d, 0, sKt[0], sKd[0], tid);
+    load_tile_b<HDP, true, false, KH>(Vp, T, p.d, 0, sVt[0], nullptr, tid);
     fill_key_bits(s_kb, mrow, p.T, ntile, tid);
     float pk[B::NP][8], pv[B::NP][8];                           // tile it + 1, requested a whole iteration before it is written to LDS (round 6)
     if (ntile > 1) {
-        fetch_tile_b<HDP>(Kp, T, p.d, 32, tid, pk);
-        fetch_tile_b<HDP>(Vp, T, p.d, 32, tid, pv);
+        fetch_tile_b<HDP, KH>(Kp, T, p.d, 32, tid, pk);
+        fetch_tile_b<HDP, KH>(Vp, T, p.d, 32, tid, pv);
     }
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
@@ -1731,11 +1794,11 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
         mma_tile_frag_b<HDP>(sKt[it & 1], qf, li, kk, s);
         mma_tile_frag_b<HDP>(sVt[it & 1], gf, li, kk, dp);
         if (it + 1 < ntile) {
-            commit_tile_b<HDP, true, true>(sKt[(it + 1) & 1], sKd[(it + 1) & 1], tid, pk);
-            commit_tile_b<HDP, true, false>(sVt[(it + 1) & 1], nullptr, tid, pv);
+            commit_tile_b<HDP, true, true, KH>(sKt[(it + 1) & 1], sKd[(it + 1) & 1], tid, pk);
+            commit_tile_b<HDP, true, false, KH>(sVt[(it + 1) & 1], nullptr, tid, pv);
             if (it + 2 < ntile) {
-                fetch_tile_b<HDP>(Kp, T, p.d, 32 * (it + 2), tid, pk);
-                fetch_tile_b<HDP>(Vp, T, p.d, 32 * (it + 2), tid, pv);
+                fetch_tile_b<HDP, KH>(Kp, T, p.d, 32 * (it + 2), tid, pk);
+                fetch_tile_b<HDP, KH>(Vp, T, p.d, 32 * (it + 2), tid, pv);
             }
         }
         if (bad != 0) {                                              // (wave-uniform: a tile without a masked key skips the bit tests and selects)
@@ -1758,12 +1821,18 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
         mma_tile_acc_b<HDP>(sKd[it & 1], db, li, kk, dQ);
     }
     if (tq < p.T) {
-        float *gq = p.gkvq + ((long long)n * 3 * p.C + 2 * p.C + h * p.d) * T + tq;
+        const long long go = ((long long)n * 3 * p.C + 2 * p.C + h * p.d) * T + tq;
+        float *gq = p.gkvq + go;
+        unsigned short *gqh = reinterpret_cast<unsigned short *>(p.gkvq) + go;
 #pragma unroll
         for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (mt * 32 + rho(r, kk) < p.d) gq[(long long)(mt * 32 + rho(r, kk)) * T] = qdead ? 0.f : dQ[mt][r] * p.scale;
+                if (mt * 32 + rho(r, kk) < p.d) {
+                    const float a = qdead ? 0.f : dQ[mt][r] * p.scale;
+                    if constexpr (KH) gqh[(long long)(mt * 32 + rho(r, kk)) * T] = (unsigned short)(pack2_bf16(a, 0.f) & 0xffffu);
+                    else gq[(long long)(mt * 32 + rho(r, kk)) * T] = a;
+                }
     }
 }
 
@@ -1957,6 +2026,14 @@ extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const 
         else hipLaunchKernelGGL((kern_<128, flag_>), grid, dim3(256), 0, st_, p);                                   \
     } while (0)
 
+// ... the instances that take kvq (and write gkvq) STORED as bf16 (bf16 = 2): without the attention tensor / its gradient only
+#define PSND_ATTN_LAUNCH_KH(kern_, st_)                                                                              \
+    do {                                                                                                            \
+        if (p.d <= 32) hipLaunchKernelGGL((kern_<32, false, true>), grid, dim3(256), 0, st_, p);                    \
+        else if (p.d <= 64) hipLaunchKernelGGL((kern_<64, false, true>), grid, dim3(256), 0, st_, p);               \
+        else hipLaunchKernelGGL((kern_<128, false, true>), grid, dim3(256), 0, st_, p);                             \
+    } while (0)
+
 static int mha_check(const char *what, int64_t N, int H, int C, int64_t T) {
     if (N <= 0 || H <= 0 || C % H != 0 || C / H > 128) PSND_FAIL(PSND_E_UNSUPPORTED, "%s: hidden_dim %d / heads %d: head dimensions up to 128 only", what, C, H);
     if (T <= 0 || T >= ((int64_t)1 << 24) || (int64_t)H * N > 65535) PSND_FAIL(PSND_E_SHAPE, "%s: T=%lld, H*N=%lld", what, (long long)T, (long long)(H * N));
@@ -1974,7 +2051,10 @@ extern "C" int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     p.tiles = (int)((T + 127) / 128);
     const dim3 grid((unsigned)((H * N + 7) / 8 * 8 * p.tiles));
-    if (bf16) {
+    if (bf16 == 2) {
+        if (att) PSND_FAIL(PSND_E_UNSUPPORTED, "mha_fwd: kvq stored as bf16 (bf16 = 2) comes without the attention tensor");
+        PSND_ATTN_LAUNCH_KH(attn_fwd_bf16_kernel, static_cast<hipStream_t>(stream));
+    } else if (bf16) {
         if (att) {
             PSND_ATTN_LAUNCH(attn_fwd_bf16_kernel, true, static_cast<hipStream_t>(stream));
         } else PSND_ATTN_LAUNCH(attn_fwd_bf16_kernel, false, static_cast<hipStream_t>(stream));
@@ -2006,7 +2086,10 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     p.tiles = (int)((T + 127) / 128);
     const dim3 grid((unsigned)((H * N + 7) / 8 * 8 * p.tiles));
+    if (bf16 == 2 && (att || gatt)) PSND_FAIL(PSND_E_UNSUPPORTED, "mha_bwd: kvq stored as bf16 (bf16 = 2) comes without the attention tensor and its gradient");
     if (!(parts & 2)) {
+    } else if (bf16 == 2) {
+        PSND_ATTN_LAUNCH_KH(attn_bwd_kv_bf16_kernel, st);
     } else if (bf16) {
         if (p.gatt) {
             PSND_ATTN_LAUNCH(attn_bwd_kv_bf16_kernel, true, st);
@@ -2016,6 +2099,8 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     } else PSND_ATTN_LAUNCH(attn_bwd_kv_kernel, false, st);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
     if (!(parts & 4)) {
+    } else if (bf16 == 2) {
+        PSND_ATTN_LAUNCH_KH(attn_bwd_q_bf16_kernel, st);
     } else if (bf16) {
         if (p.gatt) {
             PSND_ATTN_LAUNCH(attn_bwd_q_bf16_kernel, true, st);

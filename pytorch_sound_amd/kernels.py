@@ -758,7 +758,13 @@ class AttentionKVQ(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kvq, mask_u8, heads, want_att, bf16=False):
-        _need_cuda(kvq, 'kvq')
+        # kvq.dtype == bfloat16 (with bf16 operands, without the attention tensor): the projection stored it that way (Linear1x1 out_h, round 6)
+        # - the kernels round the operands to bf16 when they load them anyway - and the gradient goes back the same way
+        kvq_h = kvq.dtype == torch.bfloat16
+        if kvq_h and (not bf16 or want_att):
+            raise PsndError('AttentionKVQ: a bf16-stored kvq comes with bf16 operands (torch.autocast) and without the attention tensor')
+        if not (kvq_h and isinstance(kvq, torch.Tensor) and kvq.is_cuda):
+            _need_cuda(kvq, 'kvq')
         kvq = kvq.contiguous()
         N, C3, T = kvq.shape
         C = C3 // 3
@@ -768,9 +774,9 @@ class AttentionKVQ(torch.autograd.Function):
         stats = torch.empty((heads * N, T, 2), dtype=torch.float32, device=dev)
         m = None if mask_u8 is None else mask_u8.contiguous()
         with torch.cuda.device(dev):
-            check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), int(bool(bf16)),
+            check(lib().psnd_mha_fwd(ptr(kvq), ptr(m), N, heads, C, T, ptr(out), ptr(att), ptr(stats), 2 if kvq_h else int(bool(bf16)),
                                      stream_ptr(dev)), 'psnd_mha_fwd')
-        ctx.heads, ctx.bf16 = heads, int(bool(bf16))
+        ctx.heads, ctx.bf16 = heads, (2 if kvq_h else int(bool(bf16)))
         ctx.set_materialize_grads(False)             # an unused `att` must not turn into an (H*N, T, T) tensor of zeros in backward
         ctx.save_for_backward(kvq, m, out, att, stats)
         if att is None:
@@ -791,6 +797,8 @@ class AttentionKVQ(torch.autograd.Function):
             gatt = None
         if gatt is not None:
             gatt = gatt.contiguous()
+        if gout.dtype != torch.float32:
+            gout = gout.float()
         delta = torch.empty((H * N, T), dtype=torch.float32, device=dev)
         gkvq = torch.empty_like(kvq)
         from . import cl

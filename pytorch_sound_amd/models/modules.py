@@ -13,6 +13,7 @@ import math
 from typing import Optional, Tuple
 
 import torch
+from pytorch_sound_amd import _switches as _sw
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -61,7 +62,7 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False, link=None, re
         link = None
     # hidden_out (the first projection of Conv1d -> ReLU -> Conv1d, modules.py:93-95) under autocast: the tensor between the two is STORED as
     # bf16 - what torch.autocast's own conv output is; the second projection takes it as it comes
-    out_h = bool(hidden_out and bf16 and K.HIDDEN_BF16 and ((relu_link is not None and K.RELU_LINKS) or not torch.is_grad_enabled()))
+    out_h = bool(hidden_out and bf16 and K.HIDDEN_BF16 and (not relu or (relu_link is not None and K.RELU_LINKS) or not torch.is_grad_enabled()))
     xin = x if (bf16 and x.dtype == torch.bfloat16) else x.float()
     return K.Linear1x1.apply(xin, conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16, link, relu_link, out_h)
 
@@ -90,6 +91,9 @@ class MultiHeadAttention(nn.Module):
     # (not in the reference) False: forward returns (x, None) and the (H*N, T, T) attention tensor is never written to memory -
     # 855 MB per layer at 32 clips x 1292 frames; the reference always materialises and returns it
     return_att = True
+    # (not in the reference) under torch.autocast(bfloat16) with return_att = False: kvq and its gradient as bf16 tensors between the
+    # projection and the attention kernels; False keeps them fp32
+    kvq_bf16 = _sw.lab('PSND_MHA_KVQ_BF16', '1') == '1'
 
     def forward(self, input: torch.Tensor, mask: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         in_dtype = input.dtype
@@ -98,7 +102,9 @@ class MultiHeadAttention(nn.Module):
         if _hip_ok(input) and input.dtype == torch.float32 and input.requires_grad and torch.is_grad_enabled():
             from pytorch_sound_amd import kernels as K
             link = K.ResidualLink()                     # input feeds the projection AND the residual: one gradient pass for both
-        kvq = _conv1x1(self.linear_kvq, input, link=link)
+        # under autocast, and when the attention tensor is not returned, the projection STORES kvq as bf16 (the attention kernels round their
+        # operands to bf16 when they load them: same products, half the bytes, no conversion in their loops); its gradient comes back as bf16
+        kvq = _conv1x1(self.linear_kvq, input, link=link, hidden_out=_hip_ok(input) and not self.return_att and self.kvq_bf16)
         if _hip_ok(input):
             # gfx950: projection -> attention over all heads in one kernel pair (psnd_mha_*), scores stay on the chip
             if self.hidden_dim % self.heads != 0 or self.hidden_dim // self.heads > 128:

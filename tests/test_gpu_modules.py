@@ -425,3 +425,74 @@ def test_attention_fp32_single_pass_forward(N, H, C, T, masked):
     assert float((out - out2).abs().max()) <= 1e-5 * float(o_x.abs().max())
     if masked and int(lens[-1]) < T:
         assert float(out[-1, :, int(lens[-1]):].abs().max()) == 0
+
+
+@pytest.mark.parametrize('N,H,C,T,masked', [(2, 4, 256, 173, True), (3, 4, 64, 50, True), (2, 4, 256, 1292, True), (2, 2, 96, 77, False),
+                                             (1, 2, 256, 300, True), (1, 4, 128, 31, False)])
+def test_attention_kvq_stored_as_bf16(N, H, C, T, masked):
+    """psnd_mha_fwd / _bwd with bf16 = 2 (kvq read, gkvq written as bf16 tensors - what the projection's epilogue stores under autocast)
+    against bf16 = 1 on the SAME values held in fp32: the kernels round their operands to bf16 when they load them, so out and the
+    statistics are bit-equal and gkvq is the fp32 result rounded to bf16 (one bf16 rounding: 2^-8 relative).  Head dimensions 16-128,
+    odd T (2-byte aligned rows), a short single tile."""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda')
+    torch.manual_seed(5)
+    kvq_h = torch.randn(N, 3 * C, T, device=dev).to(torch.bfloat16)
+    kvq_f = kvq_h.float()
+    mask = None
+    if masked:
+        mask = torch.zeros(N, T, dtype=torch.uint8, device=dev)
+        for n in range(N):
+            mask[n, T - 1 - 3 * n - (T // 5):] = 1
+    w = torch.randn(N, C, T, device=dev)
+
+    def run(kvq):
+        kvq = kvq.clone().requires_grad_(True)
+        out, _ = K.AttentionKVQ.apply(kvq, mask, H, False, True)
+        (out * w).sum().backward()
+        return out.detach(), kvq.grad
+
+    oh, gh = run(kvq_h)
+    of, gf = run(kvq_f)
+    assert oh.dtype == torch.float32 and gh.dtype == torch.bfloat16 and gf.dtype == torch.float32
+    assert torch.equal(oh, of)
+    assert torch.equal(gh, gf.to(torch.bfloat16))
+
+
+def test_mha_module_kvq_bf16_under_autocast(monkeypatch):
+    """MultiHeadAttention under autocast with return_att = False: the projection hands kvq over as a bf16 tensor (kvq_bf16) - output and
+    every gradient against the module with kvq kept in fp32: the weight gradients of the projection see the bf16-rounded gkvq (4e-3)"""
+    from pytorch_sound_amd.models import modules as M
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda')
+    torch.manual_seed(6)
+    mha = M.MultiHeadAttention(128, 4, 0.0).to(dev)
+    mha.return_att = False
+    x0, w = torch.randn(3, 128, 211, device=dev), torch.randn(3, 128, 211, device=dev)
+    pad = torch.zeros(3, 211, dtype=torch.bool, device=dev)
+    pad[1, 180:] = True
+    seen = []
+    orig = K.AttentionKVQ.forward
+
+    def fwd(ctx, kvq, *a):
+        seen.append(kvq.dtype)
+        return orig(ctx, kvq, *a)
+    monkeypatch.setattr(K.AttentionKVQ, 'forward', staticmethod(fwd))
+
+    def run(h):
+        mha.kvq_bf16 = h
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y, att = mha(x, pad)
+        assert att is None
+        (y.float() * w).sum().backward()
+        g = [y.detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in mha.parameters()]
+        for p in mha.parameters():
+            p.grad = None
+        return g
+
+    a, b = run(True), run(False)
+    assert seen == [torch.bfloat16, torch.float32]
+    assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(b[0].abs().max())
+    for u, v in zip(a[1:], b[1:]):
+        assert float((u - v).norm()) <= 4e-3 * float(v.norm())
