@@ -404,11 +404,12 @@ int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64
  *   leave the chip otherwise; stats (H*N, T, 2): per query column (max, 1/sum), kept for the backward.
  *   bf16 != 0: the operands of the four score / accumulate products (K, Q, V and the probabilities) are rounded to bf16 on their
  *   way to the matrix cores; scores, softmax statistics and accumulation stay fp32 (selected under torch.autocast(bfloat16)).
- *   bf16 == 2 (round 6; att == NULL only): as 1, and kvq is STORED as bf16 (2-byte elements, same shape - what psnd_linear1x1_fwd_ex
- *   writes with io_h = 2): the values multiplied are the same, the kernels convert nothing in their loops.
+ *   bf16 == 2 (round 6; att == NULL only): as 1, and kvq is read and out WRITTEN as bf16 tensors (2-byte elements, same shapes - what
+ *   psnd_linear1x1_fwd_ex writes with io_h = 2 and takes with io_h = 1): the values multiplied are the same, the kernels convert
+ *   nothing in their loops.
  * psnd_mha_bwd: gkvq (N, 3C, T) from gout (N, C, T) and, optionally, gatt (needs att).  delta (H*N, T) scratch.  bf16 as above (the
- *   probabilities are recomputed from the saved statistics: pass the forward's choice); bf16 == 2 (att, gatt NULL): kvq is read and gkvq
- *   WRITTEN as bf16 (psnd_linear1x1_bwd_ex takes it with io_h = 1); out, gout, stats, delta stay fp32. */
+ *   probabilities are recomputed from the saved statistics: pass the forward's choice); bf16 == 2 (att, gatt NULL): kvq, out and gout
+ *   are read and gkvq WRITTEN as bf16 (psnd_linear1x1_bwd_ex writes gout with io_h = 2 and takes gkvq with io_h = 1); stats, delta fp32. */
 int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
                        float *y, void *stream);
 int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T);

@@ -1057,20 +1057,26 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_kernel(AttnParams p
 }
 
 // delta[b][tq] = sum_dd gout[dd][tq] * out[dd][tq]  (+ sum_tk att[tk][tq] * gatt[tk][tq]): the softmax-backward column term
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float *out, const float *gout, const float *att, const float *gatt, int N, int H,
+// (ET = unsigned short: out and gout are STORED as bf16 - psnd_mha_bwd with bf16 = 2)
+template <typename ET>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const ET *out, const ET *gout, const float *att, const float *gatt, int N, int H,
                                                          int C, int d, long long T, float *delta) {
     const int b = blockIdx.y, h = b / N, n = b - h * N;
     const long long tq = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tq >= T) return;
-    const float *o = out + ((long long)n * C + h * d) * T + tq, *g = gout + ((long long)n * C + h * d) * T + tq;
+    const ET *o = out + ((long long)n * C + h * d) * T + tq, *g = gout + ((long long)n * C + h * d) * T + tq;
+    auto val = [](ET x) __attribute__((always_inline)) -> float {
+        if constexpr (sizeof(ET) == 2) return __builtin_bit_cast(float, (unsigned)x << 16);
+        else return x;
+    };
     float a = 0.f;
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int dd = 0; dd + 3 < d; dd += 4) {          // 8 independent loads in flight
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a4[e] = __builtin_fmaf(o[(dd + e) * T], g[(dd + e) * T], a4[e]);
+        for (int e = 0; e < 4; ++e) a4[e] = __builtin_fmaf(val(o[(dd + e) * T]), val(g[(dd + e) * T]), a4[e]);
     }
-    for (int dd = d & ~3; dd < d; ++dd) a = __builtin_fmaf(o[dd * T], g[dd * T], a);
+    for (int dd = d & ~3; dd < d; ++dd) a = __builtin_fmaf(val(o[dd * T]), val(g[dd * T]), a);
     a += (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (gatt) {
         const float *pa = att + (long long)b * T * T + tq, *pg = gatt + (long long)b * T * T + tq;
@@ -1508,12 +1514,18 @@ __global__ __launch_bounds__(256, ATT ? 2 : 3) void attn_fwd_bf16_kernel(AttnPar
             p.stats[((long long)b * T + tq) * 2 + 1] = inv;
         }
         if (tq < p.T) {
-            float *op = p.out + ((long long)n * p.C + h * p.d) * T + tq;
+            const long long oo = ((long long)n * p.C + h * p.d) * T + tq;
+            float *op = p.out + oo;
+            unsigned short *oph = reinterpret_cast<unsigned short *>(p.out) + oo;
 #pragma unroll
             for (int mt = 0; mt < HDP / 32; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (mt * 32 + rho(r, kk) < p.d) op[(long long)(mt * 32 + rho(r, kk)) * T] = qpad ? 0.f : (nancol ? NAN : O[mt][r] * inv);
+                    if (mt * 32 + rho(r, kk) < p.d) {
+                        const float ov = qpad ? 0.f : (nancol ? NAN : O[mt][r] * inv);
+                        if constexpr (KH) oph[(long long)(mt * 32 + rho(r, kk)) * T] = (unsigned short)(pack2_bf16(ov, 0.f) & 0xffffu);
+                        else op[(long long)(mt * 32 + rho(r, kk)) * T] = ov;
+                    }
         }
         return;
     }
@@ -1635,7 +1647,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     const long long Ko = ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc_e<KH>(p.kvq, Ko, p.d, T), Vp = head_rsrc_e<KH>(p.kvq, Ko + (long long)p.C * T, p.d, T),
                  Qp = head_rsrc_e<KH>(p.kvq, Ko + 2 * (long long)p.C * T, p.d, T);
-    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
+    const rsrc_t Gp = head_rsrc_e<KH>(p.gout, ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tk0 = tx * 128 + wave * 32, tk = tk0 + li;
     const bool kbad = tk >= p.T || (mrow && mrow[tk]);
@@ -1681,11 +1693,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
     stage_fetch(0);
     stage_commit(0);
     load_tile_b<HDP, true, true, KH>(Qp, T, p.d, 0, sQt[0], sQd[0], tid);
-    load_tile_b<HDP, true, true>(Gp, T, p.d, 0, sGt[0], sGd[0], tid);
+    load_tile_b<HDP, true, true, KH>(Gp, T, p.d, 0, sGt[0], sGd[0], tid);
     if (ntile > 1) {
         stage_fetch(1);
         fetch_tile_b<HDP, KH>(Qp, T, p.d, 32, tid, pq);
-        fetch_tile_b<HDP>(Gp, T, p.d, 32, tid, pg);
+        fetch_tile_b<HDP, KH>(Gp, T, p.d, 32, tid, pg);
     }
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
@@ -1696,11 +1708,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_bf16_kernel(AttnParams p) 
         if (it + 1 < ntile) {                                    // tile it + 1 (requested an iteration ago) -> LDS, tile it + 2 requested
             stage_commit((it + 1) & 1);
             commit_tile_b<HDP, true, true, KH>(sQt[(it + 1) & 1], sQd[(it + 1) & 1], tid, pq);
-            commit_tile_b<HDP, true, true>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
+            commit_tile_b<HDP, true, true, KH>(sGt[(it + 1) & 1], sGd[(it + 1) & 1], tid, pg);
             if (it + 2 < ntile) {
                 stage_fetch(it + 2);
                 fetch_tile_b<HDP, KH>(Qp, T, p.d, 32 * (it + 2), tid, pq);
-                fetch_tile_b<HDP>(Gp, T, p.d, 32 * (it + 2), tid, pg);
+                fetch_tile_b<HDP, KH>(Gp, T, p.d, 32 * (it + 2), tid, pg);
             }
         }
         if constexpr (GATT) {
@@ -1762,12 +1774,12 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     const long long Ko = ((long long)n * 3 * p.C + h * p.d) * T;
     const rsrc_t Kp = head_rsrc_e<KH>(p.kvq, Ko, p.d, T), Vp = head_rsrc_e<KH>(p.kvq, Ko + (long long)p.C * T, p.d, T),
                  Qp = head_rsrc_e<KH>(p.kvq, Ko + 2 * (long long)p.C * T, p.d, T);
-    const rsrc_t Gp = head_rsrc(p.gout + ((long long)n * p.C + h * p.d) * T, p.d, T);
+    const rsrc_t Gp = head_rsrc_e<KH>(p.gout, ((long long)n * p.C + h * p.d) * T, p.d, T);
     const unsigned char *mrow = p.mask ? p.mask + (long long)n * T : nullptr;
     const int tq0 = tx * 128 + wave * 32, tq = tq0 + li;
     bf16x8_t qf[HDP / 16], gf[HDP / 16];
     load_frag_b<HDP, KH>(Qp, T, p.d, tq0, li, kk, qf);
-    load_frag_b<HDP>(Gp, T, p.d, tq0, li, kk, gf);
+    load_frag_b<HDP, KH>(Gp, T, p.d, tq0, li, kk, gf);
     const bool qdead = tq >= p.T || (mrow && mrow[tq]);
     const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 1.f;
     const float dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
@@ -2077,8 +2089,13 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     if (rc != PSND_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (parts & 1) {
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st, out, gout, att, gatt, (int)N, H, C,
-                           C / H, (long long)T, delta);
+        if (bf16 == 2)
+            hipLaunchKernelGGL(attn_delta_kernel<unsigned short>, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st,
+                               reinterpret_cast<const unsigned short *>(out), reinterpret_cast<const unsigned short *>(gout), att, gatt, (int)N, H, C, C / H,
+                               (long long)T, delta);
+        else
+            hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st, out, gout, att, gatt, (int)N, H, C,
+                               C / H, (long long)T, delta);
         PSND_CHECK_LAUNCH("mha_bwd(delta)");
     }
     AttnParams p = {};

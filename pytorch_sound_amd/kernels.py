@@ -769,7 +769,7 @@ class AttentionKVQ(torch.autograd.Function):
         N, C3, T = kvq.shape
         C = C3 // 3
         dev = kvq.device
-        out = torch.empty((N, C, T), dtype=torch.float32, device=dev)
+        out = torch.empty((N, C, T), dtype=torch.bfloat16 if kvq_h else torch.float32, device=dev)      # (its consumer, the output projection, rounds it to bf16 anyway)
         att = torch.empty((heads * N, T, T), dtype=torch.float32, device=dev) if want_att else None
         stats = torch.empty((heads * N, T, 2), dtype=torch.float32, device=dev)
         m = None if mask_u8 is None else mask_u8.contiguous()
@@ -797,8 +797,8 @@ class AttentionKVQ(torch.autograd.Function):
             gatt = None
         if gatt is not None:
             gatt = gatt.contiguous()
-        if gout.dtype != torch.float32:
-            gout = gout.float()
+        if gout.dtype != out.dtype:
+            gout = gout.to(out.dtype)
         delta = torch.empty((H * N, T), dtype=torch.float32, device=dev)
         gkvq = torch.empty_like(kvq)
         from . import cl
