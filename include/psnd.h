@@ -428,10 +428,14 @@ int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, 
  * they load them, so the values multiplied are the same and the tensor and its gradient move at half the bytes.  The weight, bias and
  * parameter gradients are always fp32. */
 int psnd_linear1x1_bwd_ex(const void *gy, const float *ymask, const void *x, const float *w, int64_t N, int Cin, int Cout, int64_t T, int bf16,
-                          int io_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part, float *gbias, void *stream);
-/* psnd_linear1x1_fwd with io_h (bf16 != 0): 1 = x is stored as bf16, 2 = y is (see psnd_linear1x1_bwd_ex); 0 = psnd_linear1x1_fwd */
+                          int io_h, int64_t ld_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part, float *gbias,
+                          void *stream);
+/* psnd_linear1x1_fwd with io_h (bf16 != 0): 1 = x is stored as bf16, 2 = y is (see psnd_linear1x1_bwd_ex); 0 = psnd_linear1x1_fwd.
+ * ld_h (both entry points): row pitch in elements of the bf16-stored tensors - (N, C, ld_h) in memory, the first T frames of a row used;
+ * 0 = T.  They are the caller's own tensors between two calls: rows that start on 128-byte lines (ld_h a multiple of 64) spare the
+ * GEMMs the straddling loads and stores of odd row lengths. */
 int psnd_linear1x1_fwd_ex(const void *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16, int io_h,
-                          void *y, void *stream);
+                          int64_t ld_h, void *y, void *stream);
 int psnd_mha_fwd(const float *kvq, const unsigned char *mask, int64_t N, int H, int C, int64_t T, float *out, float *att, float *stats,
                  int bf16, void *stream);
 int psnd_mha_bwd(const float *kvq, const unsigned char *mask, const float *out, const float *att, const float *stats, const float *gout,

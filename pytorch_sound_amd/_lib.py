@@ -103,8 +103,8 @@ SIGNATURES = {
     'psnd_linear1x1_wgrad_slabs': (_I64, [_I64, _INT, _INT, _I64]),
     'psnd_linear1x1_bwd': (_INT, [_P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _P, _P, _P, _P, _P]),
     'psnd_linear1x1_bwd_acc': (_INT, [_P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _P, _P, _P, _P, _P, _P]),
-    'psnd_linear1x1_bwd_ex': (_INT, [_P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _INT, _P, _P, _P, _P, _P, _P, _P]),
-    'psnd_linear1x1_fwd_ex': (_INT, [_P, _P, _P, _I64, _INT, _INT, _I64, _INT, _INT, _INT, _P, _P]),
+    'psnd_linear1x1_bwd_ex': (_INT, [_P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _INT, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    'psnd_linear1x1_fwd_ex': (_INT, [_P, _P, _P, _I64, _INT, _INT, _I64, _INT, _INT, _INT, _I64, _P, _P]),
     'psnd_mha_fwd': (_INT, [_P, _P, _I64, _INT, _INT, _I64, _P, _P, _P, _INT, _P]),
     'psnd_mha_bwd': (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _P, _P, _INT, _P]),
     'psnd_mha_bwd_parts': (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _P, _P, _INT, _INT, _P]),

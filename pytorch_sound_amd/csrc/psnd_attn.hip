@@ -697,12 +697,12 @@ __global__ __launch_bounds__(512) void rowsum4_kernel(const float *g, const floa
 
 // ... over a tensor STORED as bf16 (the gradient of the feed-forward pair's hidden tensor): four elements per 8-byte load when T % 4 == 0,
 // fp32 partial sums per thread, the tree in double (as rowsum4_kernel)
-__global__ __launch_bounds__(512) void rowsum_h_kernel(const unsigned short *g, int Z, int C, long long T, float *out) {
+__global__ __launch_bounds__(512) void rowsum_h_kernel(const unsigned short *g, int Z, int C, long long T, long long LD, float *out) {
     const int c = blockIdx.x, tid = threadIdx.x;
     float acc = 0.f;
-    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0) {
-        const long long Q = T / 4, items = (long long)Z * Q, rowq = (long long)C * Q;
-        const uint2 *g4 = reinterpret_cast<const uint2 *>(g) + (long long)c * Q;
+    if ((T & 3) == 0 && (LD & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0) {
+        const long long Q = T / 4, items = (long long)Z * Q, rowq = (long long)C * (LD / 4);
+        const uint2 *g4 = reinterpret_cast<const uint2 *>(g) + (long long)c * (LD / 4);
         for (long long i0 = tid; i0 < items; i0 += 4 * 512) {
             uint2 v[4];
 #pragma unroll
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512) void rowsum_h_kernel(const unsigned short *g, 
         }
     } else {
         for (int z = 0; z < Z; ++z)
-            for (long long t = tid; t < T; t += 512) acc += __builtin_bit_cast(float, (unsigned)g[((long long)z * C + c) * T + t] << 16);
+            for (long long t = tid; t < T; t += 512) acc += __builtin_bit_cast(float, (unsigned)g[((long long)z * C + c) * LD + t] << 16);
     }
     __shared__ double red[512];
     red[tid] = (double)acc;
@@ -1902,16 +1902,18 @@ static int gemm_launch(GemmParams &p, bool a_mcontig, bool b_ncontig, int gz, hi
 }
 
 extern "C" int psnd_linear1x1_fwd_ex(const void *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
-                                     int io_h, void *y, void *stream);
+                                     int io_h, int64_t ld_h, void *y, void *stream);
 extern "C" int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
                                   float *y, void *stream) {
-    return psnd_linear1x1_fwd_ex(x, w, bias, N, Cin, Cout, T, relu, bf16, 0, y, stream);
+    return psnd_linear1x1_fwd_ex(x, w, bias, N, Cin, Cout, T, relu, bf16, 0, 0, y, stream);
 }
 // io_h (bf16 != 0 only): 1 = x is STORED as bf16, 2 = y is - the hidden tensor of Conv1d -> ReLU -> Conv1d under autocast: the products take
 // bf16 operands either way, so the values multiplied are the same and the tensor moves at half the bytes (as torch.autocast's own conv
-// output would be).  One of the two per call.
+// output would be).  One of the two per call.  ld_h: the row pitch (elements) of that bf16 tensor, (N, C, ld_h) in memory with T <= ld_h
+// frames used (0: T) - it is the caller's own tensor, and rows that start on 128-byte lines (ld_h a multiple of 64) spare the GEMMs the
+// straddling loads and stores of 1292-frame rows (-13..20 % at 32 x 1292: tools/r06/time_gemm_h.py).
 extern "C" int psnd_linear1x1_fwd_ex(const void *xv, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
-                                     int io_h, void *yv, void *stream) {
+                                     int io_h, int64_t ld_h, void *yv, void *stream) {
     const float *x = static_cast<const float *>(xv);
     float *y = static_cast<float *>(yv);
     if (!x || !w || !y) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: null pointer");
@@ -1924,6 +1926,9 @@ extern "C" int psnd_linear1x1_fwd_ex(const void *xv, const float *w, const float
     p.relu = relu, p.zchunk = 0, p.sCslab = 0;
     p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
     p.b_h = io_h & 1, p.c_h = (io_h & 2) != 0;
+    if (ld_h && (!io_h || ld_h < T)) PSND_FAIL(PSND_E_ARG, "linear1x1_fwd: ld_h=%lld (a bf16 tensor's row pitch, >= T)", (long long)ld_h);
+    if (ld_h && io_h == 1) p.sBk = ld_h, p.sBz = (long long)Cin * ld_h;
+    if (ld_h && io_h == 2) p.sCm = ld_h, p.sCz = (long long)Cout * ld_h;
     return gemm_launch(p, false, true, (int)N, static_cast<hipStream_t>(stream), "linear1x1_fwd", bf16 != 0);
 }
 
@@ -1959,30 +1964,33 @@ extern "C" int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int6
 
 // gx = W^T gy' (gy' = gy where ymask > 0 when ymask is given), gw = sum gy' x^T (slabs in `gw_part`, summed into gw), gbias = sum gy'
 extern "C" int psnd_linear1x1_bwd_ex(const void *gy, const float *ymask, const void *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                     int bf16, int io_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part,
+                                     int bf16, int io_h, int64_t ld_h, const float *gx_addend, const void *gx_mask, void *gx, float *gw, float *gw_part,
                                      float *gbias, void *stream);
 extern "C" int psnd_linear1x1_bwd(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                   int bf16, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
-    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, nullptr, nullptr, gx, gw, gw_part, gbias, stream);
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, 0, nullptr, nullptr, gx, gw, gw_part, gbias, stream);
 }
 // ... with gx = W^T gy' + gx_addend (N, Cin, T): the gradient that reaches x along another branch (a residual connection) rides in the
 // GEMM's epilogue instead of a separate accumulation pass over both tensors
 extern "C" int psnd_linear1x1_bwd_acc(const float *gy, const float *ymask, const float *x, const float *w, int64_t N, int Cin, int Cout, int64_t T,
                                       int bf16, const float *gx_addend, float *gx, float *gw, float *gw_part, float *gbias, void *stream) {
-    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, gx_addend, nullptr, gx, gw, gw_part, gbias, stream);
+    return psnd_linear1x1_bwd_ex(gy, ymask, x, w, N, Cin, Cout, T, bf16, 0, 0, gx_addend, nullptr, gx, gw, gw_part, gbias, stream);
 }
 // ... or with gx = (gx_mask > 0) ? W^T gy' : 0, gx_mask (N, Cin, T): x is the output of a ReLU (gx_mask = x itself, or the ReLU's output
 // wherever it is kept) and gx is wanted for the ReLU's INPUT - the layer before the ReLU then takes gx as it is (ymask = null there: its two
 // GEMMs and its bias sum read one tensor instead of two).  Not together with gx_addend.
 // io_h (bf16 != 0 only; see psnd_linear1x1_fwd_ex): 1 = gy is STORED as bf16 (no ymask then), 2 = x, gx_mask and gx are (no gx_addend then).
+// ld_h: the row pitch of the bf16-stored tensors (psnd_linear1x1_fwd_ex), 0 = T.
 extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const void *xv, const float *w, int64_t N, int Cin, int Cout, int64_t T,
-                                     int bf16, int io_h, const float *gx_addend, const void *gx_maskv, void *gxv, float *gw, float *gw_part,
+                                     int bf16, int io_h, int64_t ld_h, const float *gx_addend, const void *gx_maskv, void *gxv, float *gw, float *gw_part,
                                      float *gbias, void *stream) {
     const float *gy = static_cast<const float *>(gyv), *x = static_cast<const float *>(xv), *gx_mask = static_cast<const float *>(gx_maskv);
     float *gx = static_cast<float *>(gxv);
     if (gx_addend && gx_mask) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gx_addend and gx_mask exclude each other");
     if (io_h && (!bf16 || (io_h != 1 && io_h != 2))) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: io_h=%d (1 or 2, with bf16 operands)", io_h);
     if ((io_h == 1 && ymask) || (io_h == 2 && gx_addend)) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: bf16 storage with an operand mask / addend");
+    if (ld_h && (!io_h || ld_h < T)) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: ld_h=%lld (a bf16 tensor's row pitch, >= T)", (long long)ld_h);
+    const int64_t ld = ld_h ? ld_h : T;
     if (!gy || !x || !w) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: null pointer");
     if (N < 0 || Cin <= 0 || Cout <= 0 || T <= 0 || T >= ((int64_t)1 << 31)) PSND_FAIL(PSND_E_SHAPE, "linear1x1_bwd: bad shape");
     if (gw && !gw_part) PSND_FAIL(PSND_E_ARG, "linear1x1_bwd: gw needs the slab buffer gw_part (psnd_linear1x1_wgrad_slabs x Cout x Cin floats)");
@@ -1996,6 +2004,8 @@ extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const 
         p.M = Cin, p.N = (int)T, p.K = Cout, p.Z = (int)N;
         p.sAm = 1, p.sAk = Cin, p.sAz = 0, p.sBk = T, p.sBn = 1, p.sBz = (long long)Cout * T, p.sCm = T, p.sCz = (long long)Cin * T;
         p.flatT = (T >= 4 && N * T < ((int64_t)1 << 31)) ? (int)T : 0;
+        if (io_h == 1) p.sBk = ld, p.sBz = (long long)Cout * ld;
+        if (io_h == 2) p.sCm = ld, p.sCz = (long long)Cin * ld;
         rc = gemm_launch(p, true, true, (int)N, st, "linear1x1_bwd(data)", bf16 != 0);
         if (rc != PSND_OK) return rc;
     }
@@ -2010,6 +2020,8 @@ extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const 
         p.M = Cout, p.N = Cin, p.K = (int)T, p.Z = (int)N;
         p.sAm = T, p.sAk = 1, p.sAz = (long long)Cout * T, p.sBk = 1, p.sBn = T, p.sBz = (long long)Cin * T, p.sCm = Cin, p.sCz = 0;
         p.zchunk = (int)((N + zslabs - 1) / zslabs), p.sCslab = (long long)Cout * Cin, p.ksplit = ks, p.kpart = kp;
+        if (io_h == 1) p.sAm = ld, p.sAz = (long long)Cout * ld;
+        if (io_h == 2) p.sBn = ld, p.sBz = (long long)Cin * ld;
         rc = gemm_launch(p, false, false, (int)slabs, st, "linear1x1_bwd(weight)", bf16 != 0);
         if (rc != PSND_OK) return rc;
         const long long n = (long long)Cout * Cin;
@@ -2017,7 +2029,8 @@ extern "C" int psnd_linear1x1_bwd_ex(const void *gyv, const float *ymask, const 
         PSND_CHECK_LAUNCH("linear1x1_bwd(slab sum)");
     }
     if (gbias && (io_h & 1)) {
-        hipLaunchKernelGGL(rowsum_h_kernel, dim3(Cout), dim3(512), 0, st, reinterpret_cast<const unsigned short *>(gy), (int)N, Cout, (long long)T, gbias);
+        hipLaunchKernelGGL(rowsum_h_kernel, dim3(Cout), dim3(512), 0, st, reinterpret_cast<const unsigned short *>(gy), (int)N, Cout, (long long)T, (long long)ld,
+                           gbias);
         PSND_CHECK_LAUNCH("linear1x1_bwd(bias)");
     } else if (gbias) {
         const bool vec = T % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(ymask)) % 16 == 0;

@@ -454,6 +454,7 @@ class ResidualLink:
 RELU_LINKS = _sw.lab('PSND_RELU_LINKS', '1') == '1'              # 0: each GEMM behind the ReLU masks its operand itself (A/B)
 
 
+PAD_HIDDEN_ROWS = _sw.lab('PSND_FFN_PAD_ROWS', '1') == '1'       # 0: the bf16 hidden tensor's rows are T frames long (A/B)
 HIDDEN_BF16 = _sw.lab('PSND_FFN_HIDDEN_BF16', '1') == '1'      # 0: the feed-forward pair's hidden tensor stays fp32 under autocast (A/B)
 
 
@@ -555,7 +556,9 @@ class Linear1x1(torch.autograd.Function):
     masks by y > 0).  x: (N, Cin, T), w: (Cout, Cin) or (Cout, Cin, 1); output and gradients fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu, bf16=False, link=None, relu_link=None, out_h=False):
+    def forward(ctx, x, w, bias, relu, bf16=False, link=None, relu_link=None, out_h=False, t_len=None, pad_h=False):
+        # t_len: the frames of a row in use when x is a bf16 tensor with padded rows (N, Cin, ld_h >= t_len); pad_h: the bf16 output gets such
+        # rows (ld_h = the next multiple of 64 frames: every row starts on a 128-byte line) - a tensor between two nodes of this class only
         # out_h (with bf16 operands): the output is STORED as bf16 - the hidden tensor of Conv1d -> ReLU -> Conv1d under autocast; the node
         # behind it takes it as it is (x.dtype == bfloat16).  The products round their operands to bf16 anyway: same values, half the bytes.
         x_h = x.dtype == torch.bfloat16
@@ -581,16 +584,23 @@ class Linear1x1(torch.autograd.Function):
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], w.shape[1]).contiguous()
         N, Cin, T = x.shape
+        ld = 0
+        if t_len is not None and int(t_len) != T:
+            if not x_h or int(t_len) > T or int(t_len) <= 0:
+                raise PsndError('Linear1x1: t_len=%s with an input %s (padded rows are a bf16 tensor\'s)' % (t_len, tuple(x.shape)))
+            ld, T = T, int(t_len)
         Cout = w2.shape[0]
         if w2.shape[1] != Cin:
             raise PsndError('Linear1x1: weight %s does not fit %d input channels' % (tuple(w.shape), Cin))
         b = None if bias is None else bias.contiguous()
-        y = torch.empty((N, Cout, T), dtype=torch.bfloat16 if out_h else torch.float32, device=x.device)
+        if out_h and pad_h and T % 64:
+            ld = (T + 63) // 64 * 64
+        y = torch.empty((N, Cout, ld if (out_h and ld) else T), dtype=torch.bfloat16 if out_h else torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             check(lib().psnd_linear1x1_fwd_ex(ptr(x), ptr(w2), ptr(b), N, Cin, Cout, T, int(bool(relu)), int(bool(bf16)), 1 if x_h else (2 if out_h else 0),
-                                              ptr(y), stream_ptr(x.device)), 'psnd_linear1x1_fwd')
+                                              ld, ptr(y), stream_ptr(x.device)), 'psnd_linear1x1_fwd')
         ctx.relu, ctx.has_bias, ctx.wshape, ctx.bf16 = bool(relu), bias is not None, tuple(w.shape), bool(bf16)
-        ctx.x_h, ctx.out_h = x_h, bool(out_h)
+        ctx.x_h, ctx.out_h, ctx.t_len = x_h, bool(out_h), T
         ctx.params = (w, bias)
         from . import cl
         cl.note_param_use(ctx, w, bias)
@@ -605,14 +615,19 @@ class Linear1x1(torch.autograd.Function):
         gy = gy.contiguous()
         if ctx.relu_out is not None and ctx.relu_out.take():
             y = None                                                    # the gradient arrives masked (ReluLink)
+        T = ctx.t_len
         if gy.dtype != torch.float32 and (y is not None or ctx.x_h or not ctx.bf16):
             # a bf16 gradient that still needs this node's mask, or bf16 on both sides: outside the feed-forward pair's plan - in fp32
-            gy = gy.float()
+            gy = gy[..., :T].float()
             if y is not None:
-                gy, y = gy * (y > 0), None
+                gy, y = gy * (y[..., :T] > 0), None
+            gy = gy.contiguous()
         io_h = 1 if gy.dtype == torch.bfloat16 else (2 if ctx.x_h else 0)
+        ld = (gy.shape[-1] if io_h == 1 else x.shape[-1]) if io_h else 0
+        if ld == T:
+            ld = 0
         xmask = x if ctx.relu_in is not None else None
-        N, Cin, T = x.shape
+        N, Cin = x.shape[0], x.shape[1]
         Cout = w2.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dev = x.device
@@ -639,15 +654,15 @@ class Linear1x1(torch.autograd.Function):
                 cl.GRAD_SINK.note_producer(ctx.params, side)
         with torch.cuda.device(dev):
             if side is None:
-                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ptr(addend), ptr(xmask), ptr(gx),
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ld, ptr(addend), ptr(xmask), ptr(gx),
                                                   ptr(gw), ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
             else:
                 main = torch.cuda.current_stream(dev)
                 side.wait_stream(main)                          # gy is complete on the main stream
-                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ptr(addend), ptr(xmask), ptr(gx),
+                check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ld, ptr(addend), ptr(xmask), ptr(gx),
                                                   None, None, None, stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 with torch.cuda.stream(side):
-                    check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, None, None, None, ptr(gw),
+                    check(lib().psnd_linear1x1_bwd_ex(ptr(gy), ptr(y), ptr(x), ptr(w2), N, Cin, Cout, T, int(ctx.bf16), io_h, ld, None, None, None, ptr(gw),
                                                       ptr(part), ptr(gb), stream_ptr(dev)), 'psnd_linear1x1_bwd')
                 for t in (gy, y, x, w2, gw, part, gb):          # main-stream blocks the side stream reads / writes
                     if t is not None:
@@ -656,7 +671,7 @@ class Linear1x1(torch.autograd.Function):
         if xmask is not None and need_x:
             ctx.relu_in.masked = True
         cl.consume_param_use(ctx)
-        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None, None, None
+        return gx, (None if gw is None else gw.view(ctx.wshape)), gb, None, None, None, None, None, None, None
 
 
 class Im2Col(torch.autograd.Function):

@@ -47,7 +47,8 @@ def _add_norm(norm: nn.GroupNorm, x: torch.Tensor, residual: torch.Tensor, relu:
     return F.relu(y) if relu else y
 
 
-def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False, link=None, relu_link=None, hidden_out: bool = False) -> torch.Tensor:
+def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False, link=None, relu_link=None, hidden_out: bool = False, t_len=None,
+             pad_rows: bool = False) -> torch.Tensor:
     """the 1x1 Conv1d projections of modules.py:21-22, 93-95 as what they are - one GEMM over (C_in, N*T), on the exact-fp32
     matrix-core kernel (psnd_linear1x1_*, bias and the following ReLU fused).  CPU tensors (and the tests' fp32 yardstick) keep
     the torch formulation."""
@@ -64,7 +65,10 @@ def _conv1x1(conv: nn.Conv1d, x: torch.Tensor, relu: bool = False, link=None, re
     # bf16 - what torch.autocast's own conv output is; the second projection takes it as it comes
     out_h = bool(hidden_out and bf16 and K.HIDDEN_BF16 and (not relu or (relu_link is not None and K.RELU_LINKS) or not torch.is_grad_enabled()))
     xin = x if (bf16 and x.dtype == torch.bfloat16) else x.float()
-    return K.Linear1x1.apply(xin, conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16, link, relu_link, out_h)
+    # pad_rows: that bf16 tensor with rows of the next multiple of 64 frames (each starts on a 128-byte line); the call that takes it names the
+    # frames in use (t_len)
+    return K.Linear1x1.apply(xin, conv.weight.float(), None if conv.bias is None else conv.bias.float(), relu, bf16, link, relu_link, out_h, t_len,
+                             bool(pad_rows and K.PAD_HIDDEN_ROWS))
 
 
 class MultiHeadAttention(nn.Module):
@@ -184,7 +188,8 @@ class PointwiseFeedForward(nn.Module):
             relu_link = K.ReluLink()          # the ReLU's backward in the epilogue of the GEMM that produces its gradient
             if input.requires_grad:
                 link = K.ResidualLink()
-        x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True, link=link, relu_link=relu_link, hidden_out=True), relu_link=relu_link)
+        x = _conv1x1(self.ff[2], _conv1x1(self.ff[0], input, relu=True, link=link, relu_link=relu_link, hidden_out=True, pad_rows=True),
+                     relu_link=relu_link, t_len=input.size(-1))
         if self.drop_out is not None:
             x = self.drop_out(x)
         x = _add_norm(self.layernorm, x, input, relu=True, link=link)

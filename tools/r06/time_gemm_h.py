@@ -21,17 +21,18 @@ def timeit(fn, n=30):
 
 x = torch.randn(N, C, T, device=dev); w1 = torch.randn(Hd, C, device=dev) * 0.05; b1 = torch.zeros(Hd, device=dev)
 w2 = torch.randn(C, Hd, device=dev) * 0.05; b2 = torch.zeros(C, device=dev)
-h = torch.empty(N, Hd, T, device=dev, dtype=torch.bfloat16); y = torch.empty(N, C, T, device=dev)
+LD = int(os.environ.get('LD', '0'))      # row pitch of the bf16 tensors (0: T)
+h = torch.empty(N, Hd, LD or T, device=dev, dtype=torch.bfloat16); y = torch.empty(N, C, T, device=dev)
 gy = torch.randn(N, C, T, device=dev); gh = torch.empty_like(h); gx = torch.empty_like(x)
 L = lib()
 S1 = int(L.psnd_linear1x1_wgrad_slabs(N, C, Hd, T)); S2 = int(L.psnd_linear1x1_wgrad_slabs(N, Hd, C, T))
 p1 = torch.empty(S1, Hd, C, device=dev); p2 = torch.empty(S2, C, Hd, device=dev); gw1 = torch.empty_like(w1); gw2 = torch.empty_like(w2)
 gb1 = torch.empty_like(b1); gb2 = torch.empty_like(b2)
 t = {}
-t['ffn1 fwd (out bf16)'] = timeit(lambda: check(L.psnd_linear1x1_fwd_ex(ptr(x), ptr(w1), ptr(b1), N, C, Hd, T, 1, 1, 2, ptr(h), st), 'f1'))
-t['ffn2 fwd (in bf16)'] = timeit(lambda: check(L.psnd_linear1x1_fwd_ex(ptr(h), ptr(w2), ptr(b2), N, Hd, C, T, 0, 1, 1, ptr(y), st), 'f2'))
-t['ffn2 gx (mask, out bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gy), None, ptr(h), ptr(w2), N, Hd, C, T, 1, 2, None, ptr(h), ptr(gh), None, None, None, st), 'g2'))
-t['ffn2 gw (x bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gy), None, ptr(h), ptr(w2), N, Hd, C, T, 1, 2, None, None, None, ptr(gw2), ptr(p2), ptr(gb2), st), 'w2'))
-t['ffn1 gx (gy bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gh), None, ptr(x), ptr(w1), N, C, Hd, T, 1, 1, None, None, ptr(gx), None, None, None, st), 'g1'))
-t['ffn1 gw (gy bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gh), None, ptr(x), ptr(w1), N, C, Hd, T, 1, 1, None, None, None, ptr(gw1), ptr(p1), ptr(gb1), st), 'w1'))
+t['ffn1 fwd (out bf16)'] = timeit(lambda: check(L.psnd_linear1x1_fwd_ex(ptr(x), ptr(w1), ptr(b1), N, C, Hd, T, 1, 1, 2, LD, ptr(h), st), 'f1'))
+t['ffn2 fwd (in bf16)'] = timeit(lambda: check(L.psnd_linear1x1_fwd_ex(ptr(h), ptr(w2), ptr(b2), N, Hd, C, T, 0, 1, 1, LD, ptr(y), st), 'f2'))
+t['ffn2 gx (mask, out bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gy), None, ptr(h), ptr(w2), N, Hd, C, T, 1, 2, LD, None, ptr(h), ptr(gh), None, None, None, st), 'g2'))
+t['ffn2 gw (x bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gy), None, ptr(h), ptr(w2), N, Hd, C, T, 1, 2, LD, None, None, None, ptr(gw2), ptr(p2), ptr(gb2), st), 'w2'))
+t['ffn1 gx (gy bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gh), None, ptr(x), ptr(w1), N, C, Hd, T, 1, 1, LD, None, None, ptr(gx), None, None, None, st), 'g1'))
+t['ffn1 gw (gy bf16)'] = timeit(lambda: check(L.psnd_linear1x1_bwd_ex(ptr(gh), None, ptr(x), ptr(w1), N, C, Hd, T, 1, 1, LD, None, None, None, ptr(gw1), ptr(p1), ptr(gb1), st), 'w1'))
 print('  '.join('%s %.1f' % kv for kv in t.items()), flush=True)
