@@ -354,8 +354,9 @@ def test_positional_encoding_kernel_matches_the_torch_formulation():
     from pytorch_sound_amd.models import modules as M
     dev = torch.device('cuda:0')
     torch.manual_seed(2)
-    for N, C, T in ((3, 16, 10), (2, 256, 173), (1, 30, 1000)):
-        pe = M.PositionalEncoding(C, 1200).to(dev)
+    # (1000, 1292 frames: the four-frames-per-thread kernel; 66 x 512 x 1028: more 16-byte pieces than its capped grid covers in one trip)
+    for N, C, T in ((3, 16, 10), (2, 256, 173), (1, 30, 1000), (32, 256, 1292), (66, 512, 1028)):
+        pe = M.PositionalEncoding(C, 1200 if T <= 1200 else 2048).to(dev)
         x = torch.randn(N, C, T, device=dev, requires_grad=True)
         y = pe(x)
         ref = x.detach() * (C ** 0.5) + pe.pe[..., :T]
