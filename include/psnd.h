@@ -409,7 +409,9 @@ int psnd_mask_head_bwd(const float *gest, const float *mag, const void *y, int64
  *   nothing in their loops.
  * psnd_mha_bwd: gkvq (N, 3C, T) from gout (N, C, T) and, optionally, gatt (needs att).  delta (H*N, T) scratch.  bf16 as above (the
  *   probabilities are recomputed from the saved statistics: pass the forward's choice); bf16 == 2 (att, gatt NULL): kvq, out and gout
- *   are read and gkvq WRITTEN as bf16 (psnd_linear1x1_bwd_ex writes gout with io_h = 2 and takes gkvq with io_h = 1); stats, delta fp32. */
+ *   are read and gkvq WRITTEN as bf16 (psnd_linear1x1_bwd_ex writes gout with io_h = 2 and takes gkvq with io_h = 1); stats, delta fp32
+ *   (delta is then formed by the query-gradient kernel from the fragments it holds - no separate pass over out and gout; psnd_mha_bwd_parts
+ *   takes bf16 = 2 with parts = 7 only). */
 int psnd_linear1x1_fwd(const float *x, const float *w, const float *bias, int64_t N, int Cin, int Cout, int64_t T, int relu, int bf16,
                        float *y, void *stream);
 int64_t psnd_linear1x1_wgrad_slabs(int64_t N, int Cin, int Cout, int64_t T);

@@ -1782,7 +1782,29 @@ __global__ __launch_bounds__(256, GATT ? 2 : 3) void attn_bwd_q_bf16_kernel(Attn
     load_frag_b<HDP, KH>(Gp, T, p.d, tq0, li, kk, gf);
     const bool qdead = tq >= p.T || (mrow && mrow[tq]);
     const float mx = tq < p.T ? p.stats[((long long)b * T + tq) * 2] : 0.f, inv = tq < p.T ? p.stats[((long long)b * T + tq) * 2 + 1] : 1.f;
-    const float dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
+    // delta[tq] = sum_dd out[dd][tq] gout[dd][tq], the softmax-backward column term.  With the operands stored as bf16 (KH) this kernel forms it
+    // itself from the fragments it holds anyway - the same bf16 values attn_delta_kernel would read -, writes it for the key / value kernel
+    // (launched BEHIND this one then) and the separate pass over out and gout (23 us in front of both kernels at 32 x 1292) is gone (round 6).
+    float dl;
+    if constexpr (KH && !GATT) {
+        bf16x8_t of[HDP / 16];
+        load_frag_b<HDP, KH>(head_rsrc_e<KH>(p.out, ((long long)n * p.C + h * p.d) * T, p.d, T), T, p.d, tq0, li, kk, of);
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < HDP / 16; ++s) {
+            const uint4 ow = __builtin_bit_cast(uint4, of[s]), gw = __builtin_bit_cast(uint4, gf[s]);
+            const unsigned o4[4] = {ow.x, ow.y, ow.z, ow.w}, g4[4] = {gw.x, gw.y, gw.z, gw.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                part = __builtin_fmaf(__builtin_bit_cast(float, o4[e] << 16), __builtin_bit_cast(float, g4[e] << 16), part);
+                part = __builtin_fmaf(__builtin_bit_cast(float, o4[e] & 0xffff0000u), __builtin_bit_cast(float, g4[e] & 0xffff0000u), part);
+            }
+        }
+        dl = part + __shfl_xor(part, 32, 64);                  // the head's channels sit in the two half-waves
+        if (tq < p.T && kk == 0) const_cast<float *>(p.delta)[(long long)b * T + tq] = dl;
+    } else {
+        dl = tq < p.T ? p.delta[(long long)b * T + tq] : 0.f;
+    }
     // (as in attn_bwd_kv_bf16_kernel: probability = exp2(s c - e0); the factor `scale` and a dead query are applied to dQ at the end)
     const float cexp = p.scale * 1.44269504088896341f, e0 = mx * 1.44269504088896341f - __builtin_log2f(inv);
     f32x16 dQ[HDP / 32];
@@ -2101,7 +2123,9 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     int rc = mha_check("mha_bwd", N, H, C, T);
     if (rc != PSND_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (parts & 1) {
+    const bool fold_delta = bf16 == 2 && parts == 7 && !gatt;      // the query kernel forms and writes delta itself, and runs first
+    if (bf16 == 2 && parts != 7) PSND_FAIL(PSND_E_UNSUPPORTED, "mha_bwd: bf16 = 2 runs as a whole (parts = 7)");
+    if ((parts & 1) && !fold_delta) {
         if (bf16 == 2)
             hipLaunchKernelGGL(attn_delta_kernel<unsigned short>, dim3((unsigned)((T + 255) / 256), (unsigned)(H * N)), dim3(256), 0, st,
                                reinterpret_cast<const unsigned short *>(out), reinterpret_cast<const unsigned short *>(gout), att, gatt, (int)N, H, C, C / H,
@@ -2113,10 +2137,15 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
     }
     AttnParams p = {};
     p.kvq = kvq, p.mask = mask, p.stats = const_cast<float *>(stats), p.gout = gout, p.gatt = gatt, p.delta = delta, p.gkvq = gkvq;
+    p.out = const_cast<float *>(out);
     p.N = (int)N, p.H = H, p.C = C, p.T = (int)T, p.d = C / H, p.scale = 1.f / __builtin_sqrtf((float)(C / H));
     p.tiles = (int)((T + 127) / 128);
     const dim3 grid((unsigned)((H * N + 7) / 8 * 8 * p.tiles));
     if (bf16 == 2 && (att || gatt)) PSND_FAIL(PSND_E_UNSUPPORTED, "mha_bwd: kvq stored as bf16 (bf16 = 2) comes without the attention tensor and its gradient");
+    if (fold_delta) {
+        PSND_ATTN_LAUNCH_KH(attn_bwd_q_bf16_kernel, st);
+        PSND_CHECK_LAUNCH("mha_bwd(q)");
+    }
     if (!(parts & 2)) {
     } else if (bf16 == 2) {
         PSND_ATTN_LAUNCH_KH(attn_bwd_kv_bf16_kernel, st);
@@ -2128,7 +2157,7 @@ extern "C" int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, c
         PSND_ATTN_LAUNCH(attn_bwd_kv_kernel, true, st);
     } else PSND_ATTN_LAUNCH(attn_bwd_kv_kernel, false, st);
     PSND_CHECK_LAUNCH("mha_bwd(kv)");
-    if (!(parts & 4)) {
+    if (!(parts & 4) || fold_delta) {
     } else if (bf16 == 2) {
         PSND_ATTN_LAUNCH_KH(attn_bwd_q_bf16_kernel, st);
     } else if (bf16) {

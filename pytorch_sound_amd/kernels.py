@@ -819,7 +819,7 @@ class AttentionKVQ(torch.autograd.Function):
         from . import cl
         args = (ptr(kvq), ptr(m), ptr(out), ptr(att), ptr(stats), ptr(gout), ptr(gatt), N, H, C, T, ptr(delta), ptr(gkvq), ctx.bf16)
         with torch.cuda.device(dev):
-            if ATTN_BWD_TWO_STREAMS and cl.AUTO_SECTIONS:
+            if ATTN_BWD_TWO_STREAMS and cl.AUTO_SECTIONS and ctx.bf16 != 2:      # (bf16 = 2 runs as a whole: its query kernel forms delta)
                 # the key / value and the query gradient kernels need `delta` only and write disjoint rows of gkvq: two streams (inside
                 # the step graph: two branches) behind the delta launch, joined before the projection's backward reads gkvq
                 main, side = torch.cuda.current_stream(dev), cl.branch_streams(dev, 1)[0]
