@@ -158,7 +158,7 @@ def _reducer_worker(port, q):
     import os
     import sys
     import tempfile
-    faulthandler.dump_traceback_later(150, exit=True)        # a hang in here must not outlive the test's timeout
+    faulthandler.dump_traceback_later(350, exit=True)        # a hang in here must not outlive the test's timeout
     try:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), LOCAL_RANK='0', PSND_DDP_FORCE='1')
@@ -205,7 +205,7 @@ def _reducer_worker(port, q):
         raise
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(700)
 def test_branches_next_to_a_gradient_reducer_are_bit_identical():
     import socket
     import numpy as np
@@ -218,7 +218,7 @@ def test_branches_next_to_a_gradient_reducer_are_bit_identical():
     q = ctx.Queue()
     p = ctx.Process(target=_reducer_worker, args=(port, q))
     p.start()
-    got = q.get(timeout=200)
+    got = q.get(timeout=400)
     p.join(timeout=60)
     assert p.exitcode == 0 and got[0] == 'ok', got
     for nstep in (2, 4):

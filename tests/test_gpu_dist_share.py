@@ -96,7 +96,7 @@ def _two_ranks(tmp_path, graph, hip_adam, ddp_mode, share, clip, expect_backend,
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, graph, hip_adam, ddp_mode, share, clip)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=150) for _ in procs)
+    res = dict(q.get(timeout=400) for _ in procs)
     assert all(isinstance(v, dict) for v in res.values()), res
     for p in procs:
         p.join(timeout=120)
@@ -126,7 +126,7 @@ def _two_ranks(tmp_path, graph, hip_adam, ddp_mode, share, clip, expect_backend,
         assert np.abs(v.numpy() - res[0][k]).max() <= 2e-5 * max(1.0, np.abs(v.numpy()).max()), k
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize('graph,hip_adam,ddp_mode,clip', [(True, True, None, False), (False, True, None, False), (True, False, None, False),
                                                           (True, True, 'events', False), (True, True, None, True),
                                                           (False, False, None, True)])
@@ -138,7 +138,7 @@ def test_two_ranks_on_one_gpu(tmp_path, graph, hip_adam, ddp_mode, clip):
     _two_ranks(tmp_path, graph, hip_adam, ddp_mode, True, clip, 'gloo', ['deferred'] if graph else [])
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(900)
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank: this box has one GPU (the captured-RCCL '
                     'path is covered there by the one-rank group of test_rccl_all_reduce_captured_in_the_step_graph)')
 @pytest.mark.parametrize('graph', [True, False])
@@ -210,7 +210,7 @@ def _capture_worker(port, tmp, q, use_ddp):
         raise
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(900)
 def test_rccl_all_reduce_captured_in_the_step_graph(tmp_path):
     ctx = mp.get_context('spawn')
     res = {}
@@ -218,7 +218,7 @@ def test_rccl_all_reduce_captured_in_the_step_graph(tmp_path):
         q = ctx.Queue()
         p = ctx.Process(target=_capture_worker, args=(_port(), str(tmp_path), q, use_ddp))
         p.start()
-        got = q.get(timeout=200)
+        got = q.get(timeout=400)
         p.join(timeout=120)
         assert p.exitcode == 0 and len(got) == 3, got
         res[use_ddp] = got
@@ -298,7 +298,7 @@ def _gan_train(rank, world, tmp, graph, steps=4):
     return out
 
 
-@pytest.mark.timeout(400)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize('graph', [False, True])
 def test_two_ranks_hifigan_with_branches(tmp_path, graph):
     ctx = mp.get_context('spawn')
@@ -307,7 +307,7 @@ def test_two_ranks_hifigan_with_branches(tmp_path, graph):
     procs = [ctx.Process(target=_gan_worker, args=(r, 2, port, str(tmp_path), q, graph)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=200) for _ in procs)
+    res = dict(q.get(timeout=400) for _ in procs)
     assert all(isinstance(v, dict) for v in res.values()), res
     for p in procs:
         p.join(timeout=120)
@@ -315,7 +315,7 @@ def test_two_ranks_hifigan_with_branches(tmp_path, graph):
     q1 = ctx.Queue()
     one = ctx.Process(target=_gan_worker, args=(0, 1, _port(), str(tmp_path), q1, graph))
     one.start()
-    ref = q1.get(timeout=200)[1]
+    ref = q1.get(timeout=400)[1]
     one.join(timeout=120)
     assert isinstance(ref, dict), ref
     modes = [[str(m) for m in res[r].pop('__modes__')] for r in (0, 1)]
