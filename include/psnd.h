@@ -450,13 +450,14 @@ int psnd_mha_bwd_parts(const float *kvq, const unsigned char *mask, const float 
 /* ---- transformer blocks of models/modules.py: the parts that are not plain GEMMs --------------------------
  *  psnd_groupnorm1_fwd: y = GroupNorm(1, C)(x + res) [relu]  (modules.py:30,58 / :98,114-116): mean / variance over
  *      (C x T) per sample (accumulated in double), per-channel affine.  x, res (may be NULL), y : (N,C,T) fp32;
- *      stats : (N,2) {mean, rstd} saved for backward; ws : (N,16,2) double scratch (caller owned, overwritten;
- *      PSND_GN_WS_DOUBLES doubles per sample).
- *  psnd_groupnorm1_bwd: gx (gradient wrt x and wrt res), ggamma, gbeta (C) - all fully overwritten.
+ *      stats : (N,2) {mean, rstd} saved for backward; ws : (N,C,2) double scratch (caller owned, overwritten;
+ *      PSND_GN_WS_DOUBLES(C) doubles per sample): one pair of sums per row, written and then added up in a fixed order - no
+ *      atomics, the statistics are the same bits from run to run (round 6; rounds 3-5 took 32 doubles per sample).
+ *  psnd_groupnorm1_bwd: gx (gradient wrt x and wrt res), ggamma, gbeta (C) - all fully overwritten; ws as above.
  *  psnd_softmax_keys_fwd: in place on scores (B,Tk,Tq): a = softmax over Tk of scale*s with key-padded rows at -inf,
  *      query-padded columns set to 0 (modules.py:66-76); mask (B,T) uint8, 1 = padded, or NULL.
  *  psnd_softmax_keys_bwd: gscores = scale * a * (gatt - sum_tk gatt*a). */
-#define PSND_GN_WS_DOUBLES 32
+#define PSND_GN_WS_DOUBLES(C) (2 * (size_t)(C))
 /* PositionalEncoding.forward (modules.py:119-145): y = x * scale + pe[:, :T] in one pass; x, y (N,C,T) fp32, pe (C, pe_len) rows (the module's
  * buffer (1, C, max_len)), pe_len >= T.  pe == NULL: y = x * scale (the backward: gx = g * scale). */
 int psnd_posenc(const float *x, const float *pe, float scale, int64_t N, int C, int64_t T, int64_t pe_len, float *y, void *stream);

@@ -10,7 +10,7 @@ void psnd_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int psnd_version(void) { return 136; }  // 0.1.36: + psnd_linear1x1_fwd_ex, psnd_linear1x1_bwd_ex takes io_h (round 6: the hidden tensor of Conv1d -> ReLU -> Conv1d stored as bf16 under autocast); 0.1.35: + psnd_linear1x1_bwd_ex (round 6: the ReLU between two projections masks in the producing GEMM); 0.1.34: + psnd_im2col_f32 / psnd_col2im_f32 (round 6: the fp32 instance of the conv stack); 0.1.33: + psnd_cl_colsum, psnd_grad_pack_bf16 / _unpack_bf16 (round 5); 0.1.32: + psnd_mha_bwd_parts, psnd_convtr1d_cl_bwd takes either role alone (round 4); 0.1.31: psnd_mha_fwd / _bwd take `bf16` (round 3); 0.1.30: + psnd_polar_bwd, psnd_grad_sumsq
+extern "C" int psnd_version(void) { return 137; }  // 0.1.37: psnd_groupnorm1_* take 2 C doubles of scratch per sample (one pair of sums per row: no atomics; round 6); 0.1.36: + psnd_linear1x1_fwd_ex, psnd_linear1x1_bwd_ex takes io_h (round 6: the hidden tensor of Conv1d -> ReLU -> Conv1d stored as bf16 under autocast); 0.1.35: + psnd_linear1x1_bwd_ex (round 6: the ReLU between two projections masks in the producing GEMM); 0.1.34: + psnd_im2col_f32 / psnd_col2im_f32 (round 6: the fp32 instance of the conv stack); 0.1.33: + psnd_cl_colsum, psnd_grad_pack_bf16 / _unpack_bf16 (round 5); 0.1.32: + psnd_mha_bwd_parts, psnd_convtr1d_cl_bwd takes either role alone (round 4); 0.1.31: psnd_mha_fwd / _bwd take `bf16` (round 3); 0.1.30: + psnd_polar_bwd, psnd_grad_sumsq
 
 extern "C" const char *psnd_last_error(void) { return g_err; }
 

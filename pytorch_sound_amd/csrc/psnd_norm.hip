@@ -29,16 +29,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ------------------------------------------------------------------------------------------------------------
 // GroupNorm(1, C): one workgroup per (channel row chunk, sample); rows are contiguous T floats.
-// pass A: ws[n][c % 16] += {sum, sum of squares} of s = x + res (double atomics: E[s^2] - mean^2 is formed in double).  SIXTEEN slots
-// per sample: with one, the C workgroups of a sample queued on the same two addresses and the L2 retired their double atomics one
-// after the other - 88 us per launch at 32 x 256 x 1292 for 42 MB (0.5 TB/s); the readers add the slots up.
+// pass A: ws[n][c] = {sum, sum of squares} of s = x + res over the row (double: E[s^2] - mean^2 is formed in double).  One pair PER ROW,
+// written, not accumulated (round 6): no atomics, no memset launch in front, and every reader adds the C pairs of a sample up in the same
+// order - the statistics are the same bits from run to run.  (Rounds 3-5 accumulated into 16 slots per sample with double atomics.)
 // pass B: y = (s - mean) * rstd * gamma[c] + beta[c] (ReLU optional); stats[n] = {mean, rstd}
 // ------------------------------------------------------------------------------------------------------------
-constexpr int GN_SLOTS = 16;
-__device__ __forceinline__ void gn_ws_sum(const double *ws, int n, double &a, double &b) {
-    a = 0.0, b = 0.0;
-#pragma unroll
-    for (int s = 0; s < GN_SLOTS; ++s) a += ws[2 * (n * GN_SLOTS + s)], b += ws[2 * (n * GN_SLOTS + s) + 1];
+// the C pairs of sample n, optionally weighted by w[c], added up by the whole workgroup in a fixed order (the same in every workgroup)
+__device__ __forceinline__ void gn_ws_sum(const double *ws, const float *w, int n, int C, double &a, double &b) {
+    double pa = 0.0, pb = 0.0;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        const double wi = w ? (double)w[i] : 1.0;
+        pa += wi * ws[2 * ((size_t)n * C + i)], pb += wi * ws[2 * ((size_t)n * C + i) + 1];
+    }
+    pa = wave_sum(pa), pb = wave_sum(pb);
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pa, red[4 + (threadIdx.x >> 6)] = pb;
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]), b = (red[4] + red[5]) + (red[6] + red[7]);
 }
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float *x, const float *res, int C, long long T, double *ws) {
     const int c = blockIdx.x, n = blockIdx.y;
@@ -65,8 +72,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *x, const flo
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d1, red[4 + (threadIdx.x >> 6)] = d2;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(ws + 2 * (n * GN_SLOTS + (c & (GN_SLOTS - 1))), red[0] + red[1] + red[2] + red[3]);
-        unsafeAtomicAdd(ws + 2 * (n * GN_SLOTS + (c & (GN_SLOTS - 1))) + 1, red[4] + red[5] + red[6] + red[7]);
+        ws[2 * ((size_t)n * C + c)] = red[0] + red[1] + red[2] + red[3];
+        ws[2 * ((size_t)n * C + c) + 1] = red[4] + red[5] + red[6] + red[7];
     }
 }
 
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, const flo
     const int c = blockIdx.x, n = blockIdx.y;
     const double M = (double)C * (double)T;
     double w1, w2;
-    gn_ws_sum(ws, n, w1, w2);
+    gn_ws_sum(ws, nullptr, n, C, w1, w2);
     const double mean = w1 / M;
     double var = w2 / M - mean * mean;
     if (var < 0) var = 0;
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, const flo
 }
 
 // backward pass A: per row (n, c):  a = sum_t gy',  b = sum_t gy' * xhat   (gy' = gy * [y > 0] under ReLU)
-//   ggamma[c] += b ; gbeta[c] += a ; ws[n] += {gamma[c] * a, gamma[c] * b}
+//   ws[n][c] = {a, b}  (written per row; pass B adds gamma[c] * {a, b} up per sample, and its workgroups of sample 0 add the rows of all
+//   samples up into gbeta[c] / ggamma[c] - no atomics, no zeroing launch: round 6)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *gy, const float *x, const float *res, const float *gamma,
                                                             const float *y, const float *stats, int C, long long T, int relu,
                                                             double *ws, float *ggamma, float *gbeta) {
@@ -148,22 +156,29 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float *gy, con
     __syncthreads();
     if (threadIdx.x == 0) {
         const float ta = red[0] + red[1] + red[2] + red[3], tb = red[4] + red[5] + red[6] + red[7];
-        unsafeAtomicAdd(gbeta + c, ta);
-        unsafeAtomicAdd(ggamma + c, tb);
-        unsafeAtomicAdd(ws + 2 * (n * GN_SLOTS + (c & (GN_SLOTS - 1))), (double)gamma[c] * (double)ta);
-        unsafeAtomicAdd(ws + 2 * (n * GN_SLOTS + (c & (GN_SLOTS - 1))) + 1, (double)gamma[c] * (double)tb);
+        ws[2 * ((size_t)n * C + c)] = (double)ta;
+        ws[2 * ((size_t)n * C + c) + 1] = (double)tb;
     }
 }
 
 // backward pass B: gx = rstd * (gamma gy' - S1/M - xhat * S2/M)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *gy, const float *x, const float *res, const float *gamma,
                                                            const float *y, const float *stats, int C, long long T, int relu,
-                                                           const double *ws, float *gx) {
+                                                           const double *ws, float *gx, int N, float *ggamma, float *gbeta) {
     const int c = blockIdx.x, n = blockIdx.y;
     const double M = (double)C * (double)T;
     const float mu = stats[2 * n], rstd = stats[2 * n + 1];
+    if (n == 0) {                                // the parameter gradients of channel c: its rows of all samples, in sample order
+        double ga = 0.0, gb = 0.0;
+        for (int i = threadIdx.x; i < N; i += 256) ga += ws[2 * ((size_t)i * C + c)], gb += ws[2 * ((size_t)i * C + c) + 1];
+        ga = wave_sum(ga), gb = wave_sum(gb);
+        __shared__ double pred[8];
+        if ((threadIdx.x & 63) == 0) pred[threadIdx.x >> 6] = ga, pred[4 + (threadIdx.x >> 6)] = gb;
+        __syncthreads();
+        if (threadIdx.x == 0) gbeta[c] = (float)((pred[0] + pred[1]) + (pred[2] + pred[3])), ggamma[c] = (float)((pred[4] + pred[5]) + (pred[6] + pred[7]));
+    }
     double w1, w2;
-    gn_ws_sum(ws, n, w1, w2);
+    gn_ws_sum(ws, gamma, n, C, w1, w2);
     const float m1 = (float)(w1 / M), m2 = (float)(w2 / M);
     const float gc = gamma[c];
     const size_t base = ((size_t)n * C + c) * T;
@@ -392,14 +407,6 @@ __global__ __launch_bounds__(256) void softmax_keys_bwd4_kernel(const float *a, 
     }
 }
 
-// zero the statistics slots and the two parameter-gradient rows of one backward in ONE launch (three memset launches otherwise: ~5 us each
-// on the step's critical path)
-__global__ __launch_bounds__(256) void gn_zero_kernel(double *ws, long long nws, float *a, float *b, int C) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < nws) ws[i] = 0.0;
-    if (i < C) a[i] = 0.f, b[i] = 0.f;
-}
-
 }  // namespace
 
 extern "C" int psnd_groupnorm1_fwd(const float *x, const float *res, const float *gamma, const float *beta, int64_t N, int C,
@@ -408,8 +415,6 @@ extern "C" int psnd_groupnorm1_fwd(const float *x, const float *res, const float
     if (N < 0 || C <= 0 || T <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "groupnorm1_fwd: N=%lld C=%d T=%lld", (long long)N, C, (long long)T);
     if (N == 0) return PSND_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * GN_SLOTS * (size_t)N, s);
-    if (e != hipSuccess) PSND_FAIL(PSND_E_HIP, "groupnorm1_fwd: memset: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(gn_stats_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, x, res, C, (long long)T, ws);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, x, res, gamma, beta, C, (long long)T, eps, relu, ws, y, stats);
     PSND_CHECK_LAUNCH("groupnorm1_fwd");
@@ -423,11 +428,10 @@ extern "C" int psnd_groupnorm1_bwd(const float *gy, const float *x, const float 
     if (N < 0 || C <= 0 || T <= 0 || N > 65535) PSND_FAIL(PSND_E_SHAPE, "groupnorm1_bwd: bad shape");
     if (N == 0) return PSND_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const long long nws = 2ll * GN_SLOTS * (long long)N, nz = nws > C ? nws : C;
-    hipLaunchKernelGGL(gn_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, ws, nws, ggamma, gbeta, C);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws,
                        ggamma, gbeta);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws, gx);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(C, (unsigned)N), dim3(256), 0, s, gy, x, res, gamma, y, stats, C, (long long)T, relu, ws, gx, (int)N,
+                       ggamma, gbeta);
     PSND_CHECK_LAUNCH("groupnorm1_bwd");
     return PSND_OK;
 }

@@ -488,7 +488,7 @@ class GroupNorm1(torch.autograd.Function):
         N, C, T = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((N, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((N, 32), dtype=torch.float64, device=x.device)            # PSND_GN_WS_DOUBLES per sample
+        ws = torch.empty((N, 2 * C), dtype=torch.float64, device=x.device)         # PSND_GN_WS_DOUBLES(C) per sample: a pair of sums per row
         g32, b32 = gamma.detach().contiguous(), beta.detach().contiguous()
         with torch.cuda.device(x.device):
             check(lib().psnd_groupnorm1_fwd(ptr(x), ptr(res), ptr(g32), ptr(b32), N, C, T, float(eps), int(relu), ptr(y),
@@ -505,7 +505,7 @@ class GroupNorm1(torch.autograd.Function):
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=x.device)
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws = torch.empty((N, 32), dtype=torch.float64, device=x.device)            # PSND_GN_WS_DOUBLES per sample
+        ws = torch.empty((N, 2 * C), dtype=torch.float64, device=x.device)         # PSND_GN_WS_DOUBLES(C) per sample: a pair of sums per row
         with torch.cuda.device(x.device):
             check(lib().psnd_groupnorm1_bwd(ptr(gy), ptr(x), ptr(res), ptr(g32), ptr(y), ptr(stats), N, C, T, int(ctx.relu),
                                             ptr(gx), ptr(gg), ptr(gb), ptr(ws), stream_ptr(x.device)), 'psnd_groupnorm1_bwd')

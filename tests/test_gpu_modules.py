@@ -500,3 +500,24 @@ def test_mha_module_kvq_bf16_under_autocast(monkeypatch):
     assert float((a[0] - b[0]).abs().max()) <= 2e-6 * float(b[0].abs().max())
     for u, v in zip(a[1:], b[1:]):
         assert float((u - v).norm()) <= 4e-3 * float(v.norm())
+
+
+def test_groupnorm1_is_reproducible_bit_for_bit():
+    """psnd_groupnorm1_fwd / _bwd keep one pair of sums per row and add them up in a fixed order (no atomics since round 6): two runs on the
+    same data give the same bits - output, statistics, input gradient and the parameter gradients (which add the rows of all samples up)"""
+    from pytorch_sound_amd import kernels as K
+    dev = torch.device('cuda:0')
+    torch.manual_seed(7)
+    for N, C, T, relu in ((32, 256, 1292, True), (3, 48, 173, False), (5, 300, 64, True)):
+        x, res, w = (torch.randn(N, C, T, device=dev) for _ in range(3))
+        gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev)
+        runs = []
+        for _ in range(3):
+            xx, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+            g, b = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            y = K.GroupNorm1.apply(xx, rr, g, b, 1e-5, relu)
+            (y * w).sum().backward()
+            runs.append([y.detach().clone(), xx.grad.clone(), rr.grad.clone(), g.grad.clone(), b.grad.clone()])
+        for other in runs[1:]:
+            for u, v in zip(runs[0], other):
+                assert torch.equal(u, v)
