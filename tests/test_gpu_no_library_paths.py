@@ -372,8 +372,7 @@ def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
     """Conv1d -> ReLU -> Conv1d of PointwiseFeedForward (modules.py:93-95): the ReLU's backward in the epilogue of the second projection's
     input-gradient GEMM (psnd_linear1x1_bwd_ex, gx_mask) against each GEMM of the first projection masking its operand itself.  On the
     pair of projections alone the numbers are THE SAME (a masked element is an exact zero either way), with and without a gradient wanted
-    for the input; the whole block (its GroupNorm sums with atomics) agrees to rounding, and with the torch formulation in fp32 at the
-    GEMM's tolerance."""
+    for the input, and so is the whole block; with the torch formulation in fp32 it agrees at the GEMM's tolerance."""
     from pytorch_sound_amd.models import modules as M
     from pytorch_sound_amd import kernels as K
     import torch.nn.functional as F
@@ -429,7 +428,7 @@ def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
     a, b = block(True), block(False)
     assert seen == [True]
     for u, v in zip(a, b):
-        assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) + 1e-7
+        assert torch.equal(u, v)                 # (the GroupNorm behind the pair adds its sums up in a fixed order since round 6: the whole block is the same bits)
     if not bf16:
         x = x0.clone().requires_grad_(True)
         h = ffn.ff[2](F.relu(ffn.ff[0](x)))
@@ -444,7 +443,7 @@ def test_relu_link_gradients_are_the_unlinked_ones(shape, bf16, monkeypatch):
 def test_ffn_hidden_tensor_stored_as_bf16(shape, monkeypatch):
     """PointwiseFeedForward under torch.autocast(bfloat16): the tensor between the two projections (and its gradient) STORED as bf16
     (psnd_linear1x1_fwd_ex / _bwd_ex, io_h) against the same block with that tensor in fp32.  The products round their operands to bf16 when
-    they load them, so the block's output, the input gradient and the weight gradients are THE SAME numbers up to the GroupNorm's atomics;
+    they load them, so the block's output, the input gradient and the weight gradients are THE SAME bits;
     only the first projection's bias gradient sums rounded values (bf16 rounding of each term).  Odd T (173: 2-byte aligned rows), a
     single short clip and channel counts off the tile size included; eval mode (no autograd) takes the bf16 tensor too."""
     from pytorch_sound_amd.models import modules as M
@@ -478,8 +477,10 @@ def test_ffn_hidden_tensor_stored_as_bf16(shape, monkeypatch):
     a, b = block(True), block(False)
     names = ['out', 'gx'] + [k for k, _ in ffn.named_parameters()]
     for k, u, v in zip(names, a, b):
-        tol = 4e-3 if k == 'ff.0.bias' else 2e-6
-        assert float((u - v).abs().max()) <= tol * float(v.abs().max()) + 1e-7, k
+        if k == 'ff.0.bias':
+            assert float((u - v).abs().max()) <= 4e-3 * float(v.abs().max()) + 1e-7, k
+        else:
+            assert torch.equal(u, v), k          # the same products, a reproducible GroupNorm: the same bits
     monkeypatch.setattr(K, 'HIDDEN_BF16', True)
     del seen[:]
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
