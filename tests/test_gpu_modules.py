@@ -521,3 +521,43 @@ def test_groupnorm1_is_reproducible_bit_for_bit():
         for other in runs[1:]:
             for u, v in zip(runs[0], other):
                 assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_transformer_block_gradients_are_reproducible(autocast):
+    """1x1 projection -> PositionalEncoding -> MultiHeadAttention -> PointwiseFeedForward -> 1x1 projection (the config-4 block), forward and
+    backward twice on the same data: every kernel of it adds up in a fixed order (slab sums, row sums, the GroupNorm's row pairs since round
+    6, no atomics) - loss and all gradients are the same bits, with the parameter side on its own stream or not"""
+    from pytorch_sound_amd.models import modules as M
+    dev = torch.device('cuda:0')
+    torch.manual_seed(11)
+    C, H, T, N = 128, 4, 333, 5
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inp, self.pe = torch.nn.Conv1d(80, C, 1), M.PositionalEncoding(C, 512)
+            self.mha, self.ffn, self.out = M.MultiHeadAttention(C, H, 0.0), M.PointwiseFeedForward(C, 0.0), torch.nn.Conv1d(C, 80, 1)
+            self.mha.return_att = False
+
+        def forward(self, x, pad):
+            y, _ = self.mha(self.pe(M._conv1x1(self.inp, x)), pad)
+            return M._conv1x1(self.out, self.ffn(y))
+
+    net = Net().to(dev)
+    x, w = torch.randn(N, 80, T, device=dev), torch.randn(N, 80, T, device=dev)
+    pad = torch.zeros(N, T, dtype=torch.bool, device=dev)
+    pad[2, 300:] = True
+    runs = []
+    for _ in range(3):
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            y = net(x, pad)
+        loss = (y.float() * w).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append([loss.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+        for p in net.parameters():
+            p.grad = None
+    for other in runs[1:]:
+        for u, v in zip(runs[0], other):
+            assert torch.equal(u, v)
